@@ -1,0 +1,213 @@
+"""Generate tests/golden/*.pt from the REAL reference (run in the build container only).
+
+    python -m oracle.make_golden
+
+TEST INFRASTRUCTURE.  Every fixture stores the seeded inputs AND the outputs the reference's own
+code (executed on CPU from /root/reference, via oracle/reference_loader.py) produced for them, so the
+oracle restatement and the HIP path can both be checked on machines without the reference tree.
+Fixtures are deliberately small (a few hundred KB in total).
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+
+from oracle import reference_loader
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def rollout(seed, T, B, C, p_done):
+    g = torch.Generator().manual_seed(seed)
+    rewards = torch.rand(T, B, C, generator=g)
+    values = torch.randn(T + 1, B, C, generator=g)
+    dones = torch.rand(T + 1, B, C, generator=g) < p_done
+    dones[0] = False
+    return rewards, values, dones
+
+
+def make_advantages(ref):
+    cases = []
+    grid = [  # (seed, T, B, C, p_done, gamma, lam, masked, normalize, adv_type, group, reward_type)
+        (1234, 16, 64, 1, 0.02, 0.8, 0.9, False, True, "gae", 1, "action_level"),
+        (1234, 16, 64, 1, 0.02, 0.99, 0.95, False, False, "gae", 1, "action_level"),
+        (7, 50, 32, 1, 0.05, 0.8, 0.9, True, True, "gae", 1, "action_level"),
+        (8, 12, 16, 4, 0.05, 0.99, 0.95, True, True, "gae", 1, "action_level"),
+        (9, 12, 16, 4, 0.05, 0.99, 0.95, False, True, "gae", 1, "chunk_level"),
+        (10, 33, 128, 1, 0.0, 0.99, 0.95, False, True, "gae", 1, "action_level"),
+        (11, 20, 64, 1, 0.08, 1.0, 1.0, True, True, "grpo", 8, "action_level"),
+        (12, 10, 24, 2, 0.10, 1.0, 1.0, True, True, "grpo", 4, "action_level"),
+        (13, 128, 8, 1, 0.02, 0.8, 0.9, False, True, "gae", 1, "action_level"),  # configs[0]: 8 envs
+    ]
+    for seed, T, B, C, p, gamma, lam, masked, norm, adv_type, G, rtype in grid:
+        rewards, values, dones = rollout(seed, T, B, C, p)
+        lm = lms = None
+        if masked:
+            lm, lms = ref.metric_utils.compute_loss_mask(dones)
+            if rtype == "chunk_level":
+                lm, lms = lm.any(dim=-1, keepdim=True), lms[..., -1:]
+        vals = values[..., :1] if rtype == "chunk_level" else values
+        kw = dict(task_type="embodied", adv_type=adv_type, rewards=rewards, dones=dones,
+                  values=vals if adv_type == "gae" else None, gamma=gamma, gae_lambda=lam, group_size=G,
+                  reward_type=rtype, loss_mask=lm, loss_mask_sum=lms)
+        if adv_type == "gae":
+            kw["normalize_advantages"] = norm
+        out = ref.registry.calculate_adv_and_returns(**kw)
+        cases.append(dict(
+            params=dict(seed=seed, T=T, B=B, C=C, p_done=p, gamma=gamma, gae_lambda=lam, masked=masked,
+                        normalize_advantages=norm, adv_type=adv_type, group_size=G, reward_type=rtype),
+            rewards=rewards, values=vals, dones=dones,
+            loss_mask=None if lm is None else lm.contiguous(),
+            loss_mask_sum=None if lms is None else lms[:1].contiguous(),
+            advantages=out["advantages"].contiguous(),
+            returns=out["returns"].contiguous() if "returns" in out else None))
+    torch.save(cases, os.path.join(OUT, "advantages.pt"))
+
+
+def make_loss_mask(ref):
+    cases = []
+    for seed, T, B, C, p in [(1, 12, 16, 1, 0.05), (2, 12, 16, 4, 0.05), (3, 8, 8, 1, 0.0), (4, 8, 8, 2, 0.6),
+                             (5, 128, 64, 1, 0.02)]:
+        _, _, dones = rollout(seed, T, B, C, p)
+        m, s = ref.metric_utils.compute_loss_mask(dones)
+        cases.append(dict(dones=dones, loss_mask=m.contiguous(), loss_mask_sum_row=s[0].contiguous()))
+    torch.save(cases, os.path.join(OUT, "loss_mask.pt"))
+
+
+def make_losses(ref):
+    cases = []
+    idx = 0
+    for logprob_type in ("action_level", "token_level", "chunk_level"):
+        for masked in (False, True):
+            for variant in ("plain", "dual", "logclip", "warmup", "ratio_agg"):
+                if variant == "ratio_agg" and not masked:
+                    continue
+                idx += 1
+                g = torch.Generator().manual_seed(100 + idx)
+                mb, C, A = 48, 2, 8
+                lp = (torch.randn(mb, C * A, generator=g) * 0.3 - 1.0).requires_grad_(True)
+                old = lp.detach() + torch.randn(mb, C * A, generator=g) * 0.1
+                adv = torch.randn(mb, C, generator=g)
+                v = torch.randn(mb, C, generator=g).requires_grad_(True)
+                pv = v.detach() + torch.randn(mb, C, generator=g) * 0.7
+                ret = torch.randn(mb, C, generator=g) * 3
+                ret[0, 0] = 40.0  # force the linear branch of the Huber loss
+                lm = (torch.rand(mb, C, generator=g) < 0.7) if masked else None
+                lms = torch.randint(1, 50, (mb, 1), generator=g).expand(mb, C).contiguous() if masked else None
+                if logprob_type == "chunk_level":
+                    adv, pv, ret = adv[:, 0].contiguous(), pv[:, 0].contiguous(), ret[:, 0].contiguous()
+                    v = v.detach()[:, 0].contiguous().requires_grad_(True)
+                    lm = None if lm is None else lm[:, 0].contiguous()
+                    lms = None if lms is None else lms[:, 0].contiguous()
+                extra = {}
+                if variant == "dual":
+                    extra["clip_ratio_c"] = 3.0
+                if variant == "logclip":
+                    extra.update(clip_log_ratio_min=-0.05, clip_log_ratio_max=0.05)
+                if variant == "warmup":
+                    extra["critic_warmup"] = True
+                mes = 50 if variant == "ratio_agg" else None
+                loss, metrics = ref.registry.policy_loss(
+                    loss_type="actor_critic", task_type="embodied", logprob_type=logprob_type,
+                    reward_type="action_level", single_action_dim=A, logprobs=lp, values=v,
+                    old_logprobs=old, advantages=adv, returns=ret, prev_values=pv, clip_ratio_high=0.2,
+                    clip_ratio_low=0.2, value_clip=1.0, huber_delta=10.0, loss_mask=lm, loss_mask_sum=lms,
+                    max_episode_steps=mes, **extra)
+                g_lp, g_v = torch.autograd.grad(loss, [lp, v], allow_unused=True)
+                cases.append(dict(
+                    params=dict(logprob_type=logprob_type, masked=masked, variant=variant, action_dim=A,
+                                clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0,
+                                max_episode_steps=mes, **extra),
+                    logprobs=lp.detach(), old_logprobs=old, advantages=adv, values=v.detach(),
+                    prev_values=pv, returns=ret, loss_mask=lm, loss_mask_sum=lms,
+                    loss=loss.detach(), grad_logprobs=g_lp, grad_values=g_v,
+                    metrics={k: float(val) for k, val in metrics.items()}))
+    torch.save(cases, os.path.join(OUT, "losses.pt"))
+
+
+PERTURB_SEED = 99
+
+
+def perturbation(shape):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(PERTURB_SEED + len(shape) * 1000 + shape[-1])) * 0.01
+
+
+def make_policy(ref):
+    torch.manual_seed(4321)
+    pol = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+    sd = {k: v.clone() for k, v in pol.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    states = torch.randn(96, 42, generator=g)
+    torch.manual_seed(777)
+    acts, res = pol.predict_action_batch({"states": states}, mode="train")
+    torch.manual_seed(777)
+    eps = torch.randn(96, 8)
+    acts_eval, res_eval = pol.predict_action_batch({"states": states}, mode="eval")
+    stored_action = res["forward_inputs"]["action"].clone()
+    # perturb the policy a little so the training forward sees a non-unit ratio; the perturbation is
+    # regenerated by the tests from PERTURB_SEED (keeps the fixture small)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(perturbation(p.shape))
+    out = pol.default_forward({"states": states, "action": stored_action})
+    adv = torch.randn(96, 1, generator=g)
+    ret = torch.randn(96, 1, generator=g)
+    loss, metrics = ref.registry.policy_loss(
+        loss_type="actor_critic", task_type="embodied", logprob_type="action_level",
+        reward_type="action_level", single_action_dim=8, logprobs=out["logprobs"], values=out["values"],
+        old_logprobs=res["prev_logprobs"], advantages=adv, returns=ret, prev_values=res["prev_values"],
+        clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0, huber_delta=10.0, loss_mask=None,
+        loss_mask_sum=None, max_episode_steps=50)
+    names = [n for n, _ in pol.named_parameters()]
+    opt = torch.optim.AdamW(
+        [{"params": [p for n, p in pol.named_parameters() if "value_head" not in n], "lr": 3e-4,
+          "betas": (0.9, 0.999)},
+         {"params": [p for n, p in pol.named_parameters() if "value_head" in n], "lr": 3e-4,
+          "betas": (0.9, 0.999)}], eps=1e-8, weight_decay=0.01)
+    opt.zero_grad()
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in pol.named_parameters()}
+    gnorm = torch.nn.utils.clip_grad_norm_(pol.parameters(), 0.5)
+    opt.step()
+    # after-step parameters: every 16th element of each tensor (the AdamW update is elementwise)
+    sd_after = {k: v.reshape(-1)[::16].clone() for k, v in pol.state_dict().items()}
+    torch.save(dict(
+        param_names=names, state_dict=sd, states=states, eps=eps,
+        action=acts.reshape(96, 8), prev_logprobs=res["prev_logprobs"], prev_values=res["prev_values"],
+        eval_action=acts_eval.reshape(96, 8), eval_logprobs=res_eval["prev_logprobs"],
+        perturb_seed=PERTURB_SEED, train_logprobs=out["logprobs"].detach(),
+        train_entropy=out["entropy"].detach(), train_values=out["values"].detach(),
+        advantages=adv, returns=ret, loss=loss.detach(), metrics={k: float(v) for k, v in metrics.items()},
+        grads=grads, grad_norm=gnorm.detach(), params_after_step_stride16=sd_after,
+    ), os.path.join(OUT, "policy.pt"))
+
+
+def make_shuffle(ref):
+    g = torch.Generator().manual_seed(2)
+    T, B = 6, 20
+    batch = dict(rewards=torch.rand(T, B, 1, generator=g), dones=torch.rand(T + 1, B, 1, generator=g) < 0.1,
+                 prev_values=torch.randn(T + 1, B, 1, generator=g),
+                 prev_logprobs=torch.randn(T, B, 8, generator=g),
+                 forward_inputs=dict(states=torch.randn(T, B, 42, generator=g),
+                                     action=torch.randn(T, B, 8, generator=g)))
+    perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(1234))
+    out = ref.nested.process_nested_dict_for_train(batch, perm)
+    torch.save(dict(batch=batch, perm=perm, out=out), os.path.join(OUT, "shuffle.pt"))
+
+
+def main():
+    ref = reference_loader.load()
+    os.makedirs(OUT, exist_ok=True)
+    make_advantages(ref)
+    make_loss_mask(ref)
+    make_losses(ref)
+    make_policy(ref)
+    make_shuffle(ref)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,255 @@
+"""Pin the CPU oracle (oracle/ppo_oracle.py) against the REAL reference executed on CPU.
+
+Runs only where /root/reference exists (the build container).  Everything here must be bit-exact:
+the restatement uses the same torch ops in the same order as the reference.
+"""
+
+import copy
+
+import pytest
+import torch
+
+from conftest import synth_rollout
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.reference
+
+
+def _eq(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert a.dtype == b.dtype, (a.dtype, b.dtype)
+    assert torch.equal(a, b), (a - b).abs().max() if a.is_floating_point() else "mismatch"
+
+
+@pytest.mark.parametrize("C", [1, 4])
+@pytest.mark.parametrize("p_done", [0.0, 0.05, 0.5])
+def test_loss_mask(ref, C, p_done):
+    d = synth_rollout(T=12, B=16, C=C, p_done=p_done)["dones"]
+    m0, s0 = ref.metric_utils.compute_loss_mask(d)
+    m1, s1 = O.loss_mask_from_dones(d)
+    _eq(m0, m1)
+    _eq(s0, s1)
+
+
+@pytest.mark.parametrize("C", [1, 2])
+@pytest.mark.parametrize("norm", [True, False])
+@pytest.mark.parametrize("gl", [(0.8, 0.9), (0.99, 0.95)])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_gae_embodied(ref, C, norm, gl, use_mask):
+    r = synth_rollout(T=16, B=32, C=C, p_done=0.05)
+    lm, lms = (ref.metric_utils.compute_loss_mask(r["dones"]) if use_mask else (None, None))
+    kw = dict(task_type="embodied", adv_type="gae", rewards=r["rewards"], dones=r["dones"],
+              values=r["values"], gamma=gl[0], gae_lambda=gl[1], group_size=8,
+              reward_type="action_level", loss_mask=lm, loss_mask_sum=lms,
+              normalize_advantages=norm)
+    want = ref.registry.calculate_adv_and_returns(**kw)
+    got = O.embodied_adv_and_returns(adv_type="gae", rewards=r["rewards"], dones=r["dones"],
+                                     values=r["values"], gamma=gl[0], gae_lambda=gl[1], loss_mask=lm,
+                                     loss_mask_sum=lms, normalize_advantages=norm)
+    _eq(want["advantages"], got["advantages"])
+    _eq(want["returns"], got["returns"])
+
+
+def test_gae_critic_free_and_chunk_level(ref):
+    r = synth_rollout(T=10, B=8, C=4, p_done=0.1)
+    want = ref.advantages.compute_gae_advantages_and_returns(
+        rewards=r["rewards"][..., 0], values=None, dones=r["dones"][..., 0], gamma=0.9, gae_lambda=0.8)
+    got = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], None, 0.9, 0.8)
+    _eq(want[0], got[0])
+    _eq(want[1], got[1])
+    kw = dict(task_type="embodied", adv_type="gae", rewards=r["rewards"], dones=r["dones"],
+              values=r["values"][..., :1], gamma=0.99, gae_lambda=0.95, reward_type="chunk_level",
+              loss_mask=None, loss_mask_sum=None)
+    want = ref.registry.calculate_adv_and_returns(**kw)
+    got = O.embodied_adv_and_returns(adv_type="gae", rewards=r["rewards"], dones=r["dones"],
+                                     values=r["values"][..., :1], gamma=0.99, gae_lambda=0.95,
+                                     reward_type="chunk_level")
+    _eq(want["advantages"], got["advantages"])
+    _eq(want["returns"], got["returns"])
+
+
+@pytest.mark.parametrize("C", [1, 2])
+@pytest.mark.parametrize("G", [2, 8])
+def test_grpo_embodied(ref, C, G):
+    r = synth_rollout(T=12, B=32, C=C, p_done=0.08)
+    lm, lms = ref.metric_utils.compute_loss_mask(r["dones"])
+    kw = dict(task_type="embodied", adv_type="grpo", rewards=r["rewards"], dones=r["dones"],
+              values=None, gamma=1.0, gae_lambda=1.0, group_size=G, reward_type="action_level",
+              loss_mask=lm, loss_mask_sum=lms)
+    want = ref.registry.calculate_adv_and_returns(**kw)
+    got = O.embodied_adv_and_returns(adv_type="grpo", rewards=r["rewards"], dones=r["dones"],
+                                     loss_mask=lm, loss_mask_sum=lms, group_size=G)
+    _eq(want["advantages"], got["advantages"])
+    assert "returns" not in want and "returns" not in got
+
+
+def _loss_inputs(seed, mb=64, C=1, A=8, masked=False):
+    g = torch.Generator().manual_seed(seed)
+    lp = (torch.randn(mb, C * A, generator=g) * 0.3 - 1.0).requires_grad_(True)
+    old = lp.detach() + torch.randn(mb, C * A, generator=g) * 0.1
+    adv = torch.randn(mb, C, generator=g)
+    v = torch.randn(mb, C, generator=g).requires_grad_(True)
+    pv = v.detach() + torch.randn(mb, C, generator=g) * 0.7
+    ret = torch.randn(mb, C, generator=g) * 3
+    lm = (torch.rand(mb, C, generator=g) < 0.7) if masked else None
+    lms = (torch.randint(1, 50, (mb, 1), generator=g).expand(mb, C)) if masked else None
+    return lp, old, adv, v, pv, ret, lm, lms
+
+
+@pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("variant", ["plain", "dual", "logclip", "warmup", "ratio_agg"])
+def test_actor_critic_loss(ref, logprob_type, masked, variant):
+    C = 2
+    lp, old, adv, v, pv, ret, lm, lms = _loss_inputs(7, C=C, masked=masked)
+    if logprob_type == "chunk_level":
+        adv, v, pv, ret = adv[:, 0], v[:, :1].detach().squeeze(-1).requires_grad_(True), pv[:, 0], ret[:, 0]
+        lm = None if lm is None else lm[:, 0]
+        lms = None if lms is None else lms[:, 0]
+    extra = {}
+    if variant == "dual":
+        extra["clip_ratio_c"] = 3.0
+    if variant == "logclip":
+        extra.update(clip_log_ratio_min=-0.05, clip_log_ratio_max=0.05)
+    if variant == "warmup":
+        extra["critic_warmup"] = True
+    mes = 50 if variant == "ratio_agg" else None
+    if variant == "ratio_agg" and not masked:
+        pytest.skip("ratio aggregation needs a loss mask")
+    kw = dict(loss_type="actor_critic", task_type="embodied", logprob_type=logprob_type,
+              reward_type="action_level", single_action_dim=8, logprobs=lp, values=v, old_logprobs=old,
+              advantages=adv, returns=ret, prev_values=pv, clip_ratio_high=0.2, clip_ratio_low=0.2,
+              value_clip=1.0, huber_delta=10.0, loss_mask=lm, loss_mask_sum=lms,
+              max_episode_steps=mes, **extra)
+    loss0, m0 = ref.registry.policy_loss(**kw)
+    g0 = torch.autograd.grad(loss0, [lp, v], allow_unused=True)
+
+    shaped = O.shape_loss_inputs(lp, old, adv, logprob_type, 8, loss_mask=lm, loss_mask_sum=lms,
+                                 values=v, prev_values=pv, returns=ret)
+    loss1, m1 = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0,
+                                        huber_delta=10.0, max_episode_steps=mes, **extra, **shaped)
+    g1 = torch.autograd.grad(loss1, [lp, v], allow_unused=True)
+    assert torch.equal(loss0.detach(), loss1.detach())
+    for a, b in zip(g0, g1):
+        if a is None:
+            assert b is None
+        else:
+            _eq(a, b)
+    for k in ("actor/policy_loss", "actor/policy_loss_abs", "actor/ratio", "actor/ratio_abs",
+              "actor/clipped_ratio", "actor/dual_cliped_ratio", "actor/approx_kl", "actor/clip_fraction",
+              "critic/value_loss", "critic/value_clip_ratio"):
+        assert m0[k] == pytest.approx(float(m1[k]), rel=0, abs=0), k
+    ev_ref = {k.split("/")[-1]: val for k, val in m0.items() if "explained_variance" in k}
+    for k in O.EV_KEYS:
+        assert ev_ref[k] == float(m1[f"ev/{k}"]), k
+
+
+def test_grpo_actor_loss_name(ref):
+    lp, old, adv, *_ = _loss_inputs(3)
+    kw = dict(loss_type="actor", task_type="embodied", logprob_type="action_level",
+              reward_type="action_level", single_action_dim=8, logprobs=lp, old_logprobs=old,
+              advantages=adv, clip_ratio_high=0.28, clip_ratio_low=0.2, loss_mask=None,
+              loss_mask_sum=None, max_episode_steps=None)
+    loss0, m0 = ref.registry.policy_loss(**kw)
+    shaped = O.shape_loss_inputs(lp, old, adv, "action_level", 8)
+    loss1, m1 = O.ppo_actor_loss(shaped["logprobs"], shaped["old_logprobs"], shaped["advantages"], 0.2, 0.28)
+    assert torch.equal(loss0.detach(), loss1.detach())
+
+
+def _paired_policies(ref, seed=0):
+    torch.manual_seed(seed)
+    theirs = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+    ours = O.OracleMLPPolicy(42, 8, 1)
+    missing = ours.load_state_dict(copy.deepcopy(theirs.state_dict()), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return theirs, ours
+
+
+def test_policy_param_names_and_init_distribution(ref):
+    theirs, ours = _paired_policies(ref)
+    assert [n for n, _ in theirs.named_parameters()] == [n for n, _ in ours.named_parameters()]
+    assert sum(p.numel() for p in ours.parameters()) == 287504
+    torch.manual_seed(5)
+    a = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+    torch.manual_seed(5)
+    b = O.OracleMLPPolicy(42, 8, 1)
+    # same construction order + same seed -> identical initial weights
+    for (n, p), (m, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert n == m
+        _eq(p.detach(), q.detach())
+
+
+def test_policy_rollout_with_injected_noise(ref):
+    theirs, ours = _paired_policies(ref)
+    g = torch.Generator().manual_seed(11)
+    states = torch.randn(64, 42, generator=g)
+    torch.manual_seed(99)
+    acts0, res0 = theirs.predict_action_batch({"states": states}, mode="train")
+    torch.manual_seed(99)
+    eps = torch.randn(64, 8)  # same generator state -> the draw torch.normal(mean, std) consumed
+    a1, lp1, v1 = ours.act(states, eps=eps, mode="train")
+    _eq(acts0.reshape(64, 8), a1)
+    _eq(res0["prev_logprobs"], lp1)
+    _eq(res0["prev_values"], v1)
+    _eq(res0["forward_inputs"]["action"], a1)
+    acts0, res0 = theirs.predict_action_batch({"states": states}, mode="eval")
+    a1, lp1, v1 = ours.act(states, mode="eval")
+    _eq(acts0.reshape(64, 8), a1)
+    _eq(res0["prev_logprobs"], lp1)
+
+
+def test_policy_training_forward_and_optimizer_step(ref):
+    theirs, ours = _paired_policies(ref)
+    g = torch.Generator().manual_seed(21)
+    mb = 128
+    states = torch.randn(mb, 42, generator=g)
+    action = torch.randn(mb, 8, generator=g) * 0.5
+    o0 = theirs.default_forward({"states": states, "action": action})
+    o1 = ours.evaluate(states, action)
+    for k in ("logprobs", "entropy", "values"):
+        _eq(o0[k].detach(), o1[k].detach())
+    # one full optimizer step, reference-style, against the oracle's
+    batch = dict(states=states, action=action, prev_logprobs=o0["logprobs"].detach() + 0.05,
+                 advantages=torch.randn(mb, 1, generator=g), prev_values=torch.randn(mb, 1, generator=g),
+                 returns=torch.randn(mb, 1, generator=g))
+    opt0 = torch.optim.AdamW(
+        [{"params": [p for n, p in theirs.named_parameters() if "value_head" not in n], "lr": 3e-4,
+          "betas": (0.9, 0.999)},
+         {"params": [p for n, p in theirs.named_parameters() if "value_head" in n], "lr": 3e-4,
+          "betas": (0.9, 0.999)}], eps=1e-8, weight_decay=0.01)
+    opt0.zero_grad()
+    out = theirs.default_forward({"states": states, "action": action})
+    loss, _ = ref.registry.policy_loss(
+        loss_type="actor_critic", task_type="embodied", logprob_type="action_level",
+        reward_type="action_level", single_action_dim=8, logprobs=out["logprobs"], values=out["values"],
+        old_logprobs=batch["prev_logprobs"], advantages=batch["advantages"], returns=batch["returns"],
+        prev_values=batch["prev_values"], clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
+        huber_delta=10.0, loss_mask=None, loss_mask_sum=None, max_episode_steps=50)
+    loss.backward()
+    gn0 = torch.nn.utils.clip_grad_norm_(theirs.parameters(), 0.5)
+    opt0.step()
+    opt1 = O.build_adamw(ours)
+    m = O.ppo_minibatch_step(ours, opt1, batch)
+    assert float(gn0) == float(m["actor/grad_norm"])
+    for (n, p), (_, q) in zip(theirs.named_parameters(), ours.named_parameters()):
+        _eq(p.detach(), q.detach())
+
+
+def test_flatten_and_shuffle(ref):
+    g = torch.Generator().manual_seed(2)
+    T, B = 6, 10
+    batch = dict(rewards=torch.rand(T, B, 1, generator=g), dones=torch.rand(T + 1, B, 1, generator=g) < 0.1,
+                 prev_values=torch.randn(T + 1, B, 1, generator=g),
+                 forward_inputs=dict(states=torch.randn(T, B, 42, generator=g)))
+    perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(1234))
+    want = ref.nested.process_nested_dict_for_train(batch, perm)
+    got = O.flatten_and_shuffle(batch, perm)
+    _eq(want["rewards"], got["rewards"])
+    _eq(want["dones"], got["dones"])
+    _eq(want["prev_values"], got["prev_values"])
+    _eq(want["forward_inputs"]["states"], got["forward_inputs"]["states"])
+    w = ref.nested.split_dict_to_chunk(want, 4)
+    o = O.chunk_batch(got, 4)
+    for i in range(4):
+        _eq(w[i]["forward_inputs"]["states"], o[i]["forward_inputs"]["states"])
+        _eq(w[i]["rewards"], o[i]["rewards"])
