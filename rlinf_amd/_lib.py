@@ -1,0 +1,80 @@
+"""ctypes binding of librlx_hip.so (the C ABI declared in include/rlx.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises, and
+every op that needs the GPU raises when no HIP device is visible.  Build with
+``python -m rlinf_amd.csrc.build`` (or ``__graft_entry__.build()``).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librlx_hip.so")
+
+
+class RlxError(RuntimeError):
+    pass
+
+
+class GaeParams(Structure):
+    _fields_ = [
+        ("gamma", c_float),
+        ("gamma_lambda", c_float),
+        ("normalize_advantages", c_int32),
+        ("normalize_returns", c_int32),
+        ("norm_eps", c_float),
+        ("variant", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/rlx.h
+PROTOTYPES = {
+    "rlx_version": (c_int, []),
+    "rlx_last_error": (c_char_p, []),
+    "rlx_device_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "rlx_done_prefix_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rlx_gae_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rlx_gae_scan": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                             c_int, c_int, c_int, POINTER(GaeParams), c_void_p]),
+    "rlx_standardize_workspace_bytes": (c_size_t, [c_size_t]),
+    "rlx_masked_standardize": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_size_t, c_void_p]),
+    "rlx_grpo_group_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load librlx_hip.so and bind every prototype.  Raises RlxError loudly when it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RlxError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m rlinf_amd.csrc.build` "
+            "(needs hipcc); rlinf_amd has no CPU fallback by design.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise RlxError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RlxError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.rlx_version() < 100:
+        raise RlxError("librlx_hip.so is older than this Python package; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().rlx_last_error()
+        raise RlxError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,476 @@
+// gae_scan.hip -- GAE advantages/returns over the (env x step) trajectory buffer, gfx950.
+//
+// Replaces rlinf/algorithms/advantages.py:24-86 (compute_gae_advantages_and_returns), its
+// [n,B,C]<->[T,B] pre/post-processing (rlinf/algorithms/utils.py:67-131,155-174) and
+// safe_normalize (rlinf/algorithms/utils.py:397-404).
+//
+// Data is time-major ([T(+1), B] for C == 1): the recurrence runs along T, coalescing wants lanes
+// along B.  One lane owns VEC consecutive envs (VEC*4-byte vector loads, 64*VEC envs per wave); the
+// T axis of one env group is cut into NSEG segments, one wave each:
+//
+//   pass 1  every wave streams its segment backwards (coalesced rows of r, V, done), forms
+//           delta_t and the segment's affine map  g_start = A * g_in + G  (A = prod c_t), and
+//           parks delta_t / V_t in an LDS slab [t][lane] (lane-private columns: conflict-free);
+//   carry   the NSEG maps are exchanged through LDS and composed from the tail -> g_in per wave;
+//   pass 2  every wave replays its segment from LDS with the true g_in using the SAME sequential
+//           recurrence, writes adv/ret rows (coalesced) and accumulates the masked moments.
+//
+// NSEG == 1 degenerates to a single streaming pass (no LDS): each byte is read once and written
+// once, and the arithmetic is the reference's op-for-op (explicitly rounded mul/add, no FMA
+// contraction), so un-normalised outputs are bit-identical to the CPU loop.
+//
+// Roofline: HBM-bound, 17 B per env-step (r 4 + V 4 + done 1 read, adv 4 + ret 4 write); the
+// normalisation pass re-reads/re-writes adv (+8 B), +1 B with a loss mask.
+
+#include <algorithm>
+#include <type_traits>
+
+#include "rlx_common.h"
+
+namespace rlx {
+namespace {
+
+struct GaeArgs {
+    const float* r;
+    const float* v;      // nullptr => critic-free
+    const uint8_t* d;
+    const uint8_t* m;    // nullptr => all elements
+    float* adv;
+    float* ret;
+    double* partials;    // [gridDim.x][5] = {count, sum_adv, sumsq_adv, sum_ret, sumsq_ret}
+    int T, B, C;
+    float gamma, gl;
+};
+
+template <int VEC> struct Vf;
+template <> struct Vf<1> { typedef float type; typedef uint8_t btype; };
+template <> struct Vf<2> { typedef float type __attribute__((ext_vector_type(2))); typedef uint16_t btype; };
+template <> struct Vf<4> { typedef float type __attribute__((ext_vector_type(4))); typedef uint32_t btype; };
+
+template <int VEC>
+__device__ __forceinline__ void ld(const float* p, float (&out)[VEC]) {
+    typename Vf<VEC>::type x = *reinterpret_cast<const typename Vf<VEC>::type*>(p);
+    if constexpr (VEC == 1) out[0] = x;
+    else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[k] = x[k];
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void st(float* p, const float (&in)[VEC]) {
+    typename Vf<VEC>::type x;
+    if constexpr (VEC == 1) x = in[0];
+    else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) x[k] = in[k];
+    }
+    *reinterpret_cast<typename Vf<VEC>::type*>(p) = x;
+}
+template <int VEC>
+__device__ __forceinline__ uint32_t ldb(const uint8_t* p) {  // VEC bools packed little-endian
+    return (uint32_t)*reinterpret_cast<const typename Vf<VEC>::btype*>(p);
+}
+
+struct Moments {
+    double n = 0.0, sa = 0.0, qa = 0.0, sr = 0.0, qr = 0.0;
+    __device__ __forceinline__ void add(float adv, float ret, bool on) {
+        if (on) {
+            n += 1.0;
+            sa += (double)adv;
+            qa += (double)adv * (double)adv;
+            sr += (double)ret;
+            qr += (double)ret * (double)ret;
+        }
+    }
+};
+
+__device__ __forceinline__ void flush_moments(const Moments& mo, double* partials, double* scratch) {
+    double v[5] = {mo.n, mo.sa, mo.qa, mo.sr, mo.qr};
+    block_sum<5>(v, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) partials[(size_t)blockIdx.x * 5 + k] = v[k];
+    }
+}
+
+// One backward step of the reference loop (advantages.py:66-77), op for op.
+__device__ __forceinline__ void gae_step(float r, float v, float v_next, float alive, bool critic,
+                                         float gamma, float gl, float& g, float& adv, float& ret) {
+    if (critic) {
+        const float delta = fsub(fadd(r, fmul(fmul(gamma, v_next), alive)), v);
+        g = fadd(delta, fmul(fmul(gl, alive), g));
+        ret = fadd(g, v);
+        adv = fsub(ret, v);
+    } else {
+        g = fadd(r, fmul(alive, g));  // gamma = lambda = 1, delta = r
+        ret = g;
+        adv = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C == 1 fast path.  grid = ceil(B / (64*VEC)), block = 64*NSEG threads.
+// dynamic LDS (NSEG > 1): delta[T][64*VEC] f32, v[T][64*VEC] f32, carryA/carryG[NSEG][64*VEC] f32,
+//                         + 5*NSEG doubles of reduction scratch.
+// ------------------------------------------------------------------------------------------
+template <int VEC, int NSEG, int U>
+__global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int W = 64 * VEC;  // envs per block
+    const int lane = threadIdx.x & 63;
+    const int seg = NSEG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long e0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    const bool active = e0 < a.B;
+    const bool critic = a.v != nullptr;
+    const int T = a.T;
+    const size_t B = (size_t)a.B;
+    const int seg_len = (T + NSEG - 1) / NSEG;
+    const int t_lo = seg * seg_len;
+    const int t_hi = min(T, t_lo + seg_len);
+
+    float* s_delta = reinterpret_cast<float*>(smem);
+    float* s_v = s_delta + (NSEG > 1 ? (size_t)T * W : 0);
+    float* s_ca = s_v + (NSEG > 1 ? (size_t)T * W : 0);
+    float* s_cg = s_ca + (NSEG > 1 ? NSEG * W : 0);
+    double* s_red = reinterpret_cast<double*>(s_cg + (NSEG > 1 ? NSEG * W : 0));
+
+    Moments mo;
+    float g[VEC], A[VEC], vnext[VEC];
+    unsigned long long alive_bits[VEC], mask_bits[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { g[k] = 0.f; A[k] = 1.f; vnext[k] = 0.f; alive_bits[k] = 0; mask_bits[k] = ~0ull; }
+
+    if (active && t_hi > t_lo) {
+        if (critic) ld<VEC>(a.v + (size_t)t_hi * B + e0, vnext);
+
+        // ---- pass 1 (the only pass when NSEG == 1) -------------------------------------------
+        auto batch = [&](auto uu_tag, int t_top) {  // handles steps t_top-1 ... t_top-UU
+            constexpr int UU = decltype(uu_tag)::value;
+            float r[UU][VEC], v[UU][VEC];
+            uint32_t dn[UU], mk[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                const size_t t = (size_t)(t_top - 1 - u);
+                ld<VEC>(a.r + t * B + e0, r[u]);
+                if (critic) ld<VEC>(a.v + t * B + e0, v[u]);
+                dn[u] = ldb<VEC>(a.d + (t + 1) * B + e0);
+                mk[u] = a.m ? ldb<VEC>(a.m + t * B + e0) : 0x01010101u;
+            }
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                const int t = t_top - 1 - u;
+                float adv[VEC], ret[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const bool done = (dn[u] >> (8 * k)) & 0xffu;
+                    const bool on = (mk[u] >> (8 * k)) & 0xffu;
+                    const float alive = done ? 0.f : 1.f;
+                    const float vk = critic ? v[u][k] : 0.f;
+                    if constexpr (NSEG == 1) {
+                        gae_step(r[u][k], vk, vnext[k], alive, critic, a.gamma, a.gl, g[k], adv[k], ret[k]);
+                        mo.add(adv[k], ret[k], on);
+                    } else {
+                        // local scan with g_in = 0; remember delta, V and the alive/mask bits
+                        const float delta = critic ? fsub(fadd(r[u][k], fmul(fmul(a.gamma, vnext[k]), alive)), vk)
+                                                   : r[u][k];
+                        const float c = critic ? fmul(a.gl, alive) : alive;
+                        g[k] = fadd(delta, fmul(c, g[k]));
+                        A[k] = A[k] * c;
+                        adv[k] = delta;  // staged below
+                        const unsigned long long bit = 1ull << (t - t_lo);
+                        if (!done) alive_bits[k] |= bit;
+                        if (!on) mask_bits[k] &= ~bit;
+                    }
+                    vnext[k] = vk;
+                }
+                if constexpr (NSEG == 1) {
+                    st<VEC>(a.adv + (size_t)t * B + e0, adv);
+                    st<VEC>(a.ret + (size_t)t * B + e0, ret);
+                } else {
+                    st<VEC>(s_delta + ((size_t)t * 64 + lane) * VEC, adv);
+                    if (critic) st<VEC>(s_v + ((size_t)t * 64 + lane) * VEC, v[u]);
+                }
+            }
+        };
+        int t = t_hi;
+        for (; t - U >= t_lo; t -= U) batch(std::integral_constant<int, U>{}, t);
+        for (; t > t_lo; --t) batch(std::integral_constant<int, 1>{}, t);
+    }
+
+    if constexpr (NSEG > 1) {
+        // ---- carry exchange: compose the later segments' maps, tail first -----------------------
+        if (active) {
+            st<VEC>(s_ca + ((size_t)seg * 64 + lane) * VEC, A);
+            st<VEC>(s_cg + ((size_t)seg * 64 + lane) * VEC, g);
+        }
+        __syncthreads();
+        float gin[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) gin[k] = 0.f;
+        if (active) {
+            for (int s = NSEG - 1; s > seg; --s) {
+                float As[VEC], Gs[VEC];
+                ld<VEC>(s_ca + ((size_t)s * 64 + lane) * VEC, As);
+                ld<VEC>(s_cg + ((size_t)s * 64 + lane) * VEC, Gs);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) gin[k] = fadd(Gs[k], fmul(As[k], gin[k]));
+            }
+            // ---- pass 2: replay the segment from LDS with the true incoming accumulator --------
+            for (int t = t_hi - 1; t >= t_lo; --t) {
+                float dl[VEC], vv[VEC], adv[VEC], ret[VEC];
+                ld<VEC>(s_delta + ((size_t)t * 64 + lane) * VEC, dl);
+                if (critic) ld<VEC>(s_v + ((size_t)t * 64 + lane) * VEC, vv);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const float alive = ((alive_bits[k] >> (t - t_lo)) & 1ull) ? 1.f : 0.f;
+                    const bool on = (mask_bits[k] >> (t - t_lo)) & 1ull;
+                    if (critic) {
+                        gin[k] = fadd(dl[k], fmul(fmul(a.gl, alive), gin[k]));
+                        ret[k] = fadd(gin[k], vv[k]);
+                        adv[k] = fsub(ret[k], vv[k]);
+                    } else {
+                        gin[k] = fadd(dl[k], fmul(alive, gin[k]));
+                        ret[k] = gin[k];
+                        adv[k] = gin[k];
+                    }
+                    mo.add(adv[k], ret[k], on);
+                }
+                st<VEC>(a.adv + (size_t)t * B + e0, adv);
+                st<VEC>(a.ret + (size_t)t * B + e0, ret);
+            }
+        }
+    }
+    flush_moments(mo, a.partials, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic time-chunk layout (C > 1): one lane per env, sequential, strided addressing.
+//   time step t = k*C + c  ->  element ((k*B + b)*C + c); dones use flat rows shifted by C-1
+//   (the reference keeps the LAST T+1 rows of the (n+1)*C flattened done rows, utils.py:111-114),
+//   values the FIRST T+1 rows (utils.py:116-120).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t tc_index(int f, size_t b, size_t B, int C) {
+    return ((size_t)(f / C) * B + b) * C + (f % C);
+}
+
+__global__ __launch_bounds__(64) void gae_scan_chunked(GaeArgs a) {
+    __shared__ double s_red[5];
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const bool critic = a.v != nullptr;
+    Moments mo;
+    if (b < (size_t)a.B) {
+        float g = 0.f;
+        float vnext = critic ? a.v[tc_index(a.T, b, a.B, a.C)] : 0.f;
+        for (int t = a.T - 1; t >= 0; --t) {
+            const size_t i = tc_index(t, b, a.B, a.C);
+            const float r = a.r[i];
+            const float v = critic ? a.v[i] : 0.f;
+            const bool done = a.d[tc_index(t + 1 + (a.C - 1), b, a.B, a.C)] != 0;
+            const bool on = a.m ? a.m[i] != 0 : true;
+            float adv, ret;
+            gae_step(r, v, vnext, done ? 0.f : 1.f, critic, a.gamma, a.gl, g, adv, ret);
+            vnext = v;
+            a.adv[i] = adv;
+            a.ret[i] = ret;
+            mo.add(adv, ret, on);
+        }
+    }
+    flush_moments(mo, a.partials, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
+// Moments of an arbitrary masked array (stand-alone safe_normalize) and the normalising pass.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moments_kernel(const float* x, const uint8_t* m, size_t n, double* partials) {
+    __shared__ double s_red[5 * 4];
+    Moments mo;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float xv = x[i];
+        mo.add(xv, xv, m ? m[i] != 0 : true);
+    }
+    flush_moments(mo, partials, s_red);
+}
+
+// which = 0: use {sum_adv, sumsq_adv}; which = 1: {sum_ret, sumsq_ret}.
+__global__ __launch_bounds__(256) void standardize_kernel(float* x, size_t n, const double* partials, int nparts,
+                                                          int which, float eps) {
+    __shared__ double s_red[3 * 4];
+    __shared__ float s_mean, s_den;
+    __shared__ int s_skip;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int p = threadIdx.x; p < nparts; p += blockDim.x) {
+        acc[0] += partials[(size_t)p * 5 + 0];
+        acc[1] += partials[(size_t)p * 5 + 1 + 2 * which];
+        acc[2] += partials[(size_t)p * 5 + 2 + 2 * which];
+    }
+    block_sum<3>(acc, s_red);
+    if (threadIdx.x == 0) {
+        const double cnt = acc[0];
+        s_skip = cnt <= 0.0;  // "if len(valid_array) > 0" (utils.py:399)
+        const double mean = acc[1] / cnt;
+        const double var = (acc[2] - acc[1] * acc[1] / cnt) / (cnt - 1.0);  // unbiased; NaN for cnt == 1, as torch
+        s_mean = (float)mean;
+        s_den = fadd((float)sqrt(var > 0.0 || var != var ? var : 0.0), eps);
+    }
+    __syncthreads();
+    if (s_skip) return;
+    const float mean = s_mean, den = s_den;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = (reinterpret_cast<uintptr_t>(x) % 16 == 0) ? n / 4 : 0;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 q = x4[i];
+        q.x = fsub(q.x, mean) / den;
+        q.y = fsub(q.y, mean) / den;
+        q.z = fsub(q.z, mean) / den;
+        q.w = fsub(q.w, mean) / den;
+        x4[i] = q;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        x[i] = fsub(x[i], mean) / den;
+}
+
+constexpr int kMaxParts = 4096;
+
+inline size_t lds_bytes(int vec, int nseg, int T) {
+    if (nseg == 1) return 0;
+    const size_t W = 64 * (size_t)vec;
+    return (size_t)T * W * 4 * 2 + (size_t)nseg * W * 4 * 2 + 5 * nseg * sizeof(double);
+}
+
+template <int VEC, int NSEG>
+int launch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
+    constexpr int U = VEC == 4 ? 4 : 8;
+    const size_t lds = lds_bytes(VEC, NSEG, a.T);
+    auto kern = gae_scan_c1<VEC, NSEG, U>;
+    if (lds > 48 * 1024) {
+        RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NSEG), lds, s, a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int standardize_grid(size_t n) {
+    const long long want = (long long)((n / 4 + 255) / 256);
+    const long long cap = (long long)num_cu() * 8;
+    return (int)std::max<long long>(1, std::min(want, cap));
+}
+
+}  // namespace
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" size_t rlx_gae_workspace_bytes(int n_chunk, int batch, int chunk) {
+    (void)n_chunk;
+    (void)chunk;
+    if (batch <= 0) return 0;
+    return (size_t)(ceil_div(batch, 64)) * 5 * sizeof(double);
+}
+
+extern "C" size_t rlx_standardize_workspace_bytes(size_t n) {
+    (void)n;
+    return (size_t)kMaxParts * 5 * sizeof(double);
+}
+
+extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
+                            const uint8_t* loss_mask, float* advantages, float* returns, void* workspace,
+                            size_t workspace_bytes, int n_chunk, int batch, int chunk,
+                            const rlx_gae_params* p, rlx_stream_t stream) {
+    RLX_REQUIRE(rewards && dones && advantages && returns && p, "rlx_gae_scan: NULL argument");
+    RLX_REQUIRE(n_chunk >= 0 && batch >= 0 && chunk >= 1, "rlx_gae_scan: bad sizes n_chunk=%d batch=%d chunk=%d",
+                n_chunk, batch, chunk);
+    if (n_chunk == 0 || batch == 0) return RLX_OK;  // empty buffer: nothing to do
+    RLX_REQUIRE(workspace != nullptr, "rlx_gae_scan: NULL workspace");
+    if (workspace_bytes < rlx_gae_workspace_bytes(n_chunk, batch, chunk)) {
+        set_error("rlx_gae_scan: workspace %zu < %zu bytes", workspace_bytes,
+                  rlx_gae_workspace_bytes(n_chunk, batch, chunk));
+        return RLX_ENOSPC;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GaeArgs a;
+    a.r = rewards; a.v = values; a.d = dones; a.m = loss_mask; a.adv = advantages; a.ret = returns;
+    a.partials = static_cast<double*>(workspace);
+    a.T = n_chunk * chunk; a.B = batch; a.C = chunk;
+    a.gamma = p->gamma; a.gl = p->gamma_lambda;
+    const size_t n = (size_t)a.T * batch;
+
+    int nblk;
+    if (chunk != 1) {
+        nblk = ceil_div(batch, 64);
+        hipLaunchKernelGGL(gae_scan_chunked, dim3(nblk), dim3(64), 0, s, a);
+        RLX_LAUNCH_CHECK();
+    } else {
+        int vec = p->variant & 0xff, nseg = (p->variant >> 8) & 0xff;
+        const bool aligned16 = ((reinterpret_cast<uintptr_t>(rewards) | reinterpret_cast<uintptr_t>(values) |
+                                 reinterpret_cast<uintptr_t>(advantages) | reinterpret_cast<uintptr_t>(returns)) % 16 == 0) &&
+                               ((reinterpret_cast<uintptr_t>(dones) | reinterpret_cast<uintptr_t>(loss_mask)) % 4 == 0);
+        if (p->variant == 0) {
+            // auto: widest vector that still gives >= 2 waves per CU worth of env groups, then as
+            // many time segments as needed to reach ~8 waves per CU (segments of <= 64 steps, LDS-bounded)
+            const int cus = num_cu();
+            vec = 1;
+            for (int cand : {4, 2}) {
+                if (aligned16 && batch % cand == 0 && batch / (64 * cand) >= 2 * cus) { vec = cand; break; }
+            }
+            nseg = 1;
+            const int groups = ceil_div(batch, 64 * vec);
+            while (nseg < 8 && groups * nseg < 8 * cus && a.T / (nseg * 2) >= 8 &&
+                   lds_bytes(vec, nseg * 2, a.T) <= 64 * 1024)
+                nseg *= 2;
+            while (nseg > 1 && ceil_div(a.T, nseg) > 64) nseg = 1;
+            if (nseg == 1 && ceil_div(a.T, 2) <= 64 && groups < 4 * cus && lds_bytes(vec, 2, a.T) <= 64 * 1024 &&
+                a.T >= 16)
+                nseg = 2;
+        }
+        RLX_REQUIRE(vec == 1 || vec == 2 || vec == 4, "rlx_gae_scan: variant vec=%d", vec);
+        RLX_REQUIRE(nseg == 1 || nseg == 2 || nseg == 4 || nseg == 8, "rlx_gae_scan: variant nseg=%d", nseg);
+        RLX_REQUIRE(vec == 1 || (aligned16 && batch % vec == 0),
+                    "rlx_gae_scan: vec=%d needs 16-byte aligned buffers and batch %% vec == 0", vec);
+        RLX_REQUIRE(nseg == 1 || ceil_div(a.T, nseg) <= 64, "rlx_gae_scan: nseg=%d leaves segments > 64 steps (T=%d)",
+                    nseg, a.T);
+        RLX_REQUIRE(lds_bytes(vec, nseg, a.T) <= 160 * 1024, "rlx_gae_scan: vec=%d nseg=%d T=%d exceeds LDS", vec, nseg,
+                    a.T);
+        nblk = ceil_div(batch, 64 * vec);
+        int rc = RLX_ENOSYS;
+#define RLX_CASE(V, S) if (vec == V && nseg == S) rc = launch_c1<V, S>(a, s, nblk);
+        RLX_CASE(1, 1) RLX_CASE(1, 2) RLX_CASE(1, 4) RLX_CASE(1, 8)
+        RLX_CASE(2, 1) RLX_CASE(2, 2) RLX_CASE(2, 4) RLX_CASE(2, 8)
+        RLX_CASE(4, 1) RLX_CASE(4, 2) RLX_CASE(4, 4) RLX_CASE(4, 8)
+#undef RLX_CASE
+        if (rc != RLX_OK) return rc;
+    }
+    if (p->normalize_advantages) {
+        hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, advantages, n,
+                           a.partials, nblk, 0, p->norm_eps);
+        RLX_LAUNCH_CHECK();
+    }
+    if (p->normalize_returns) {
+        hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, returns, n, a.partials,
+                           nblk, 1, p->norm_eps);
+        RLX_LAUNCH_CHECK();
+    }
+    return RLX_OK;
+}
+
+extern "C" int rlx_masked_standardize(float* x, const uint8_t* mask, size_t n, float eps, void* workspace,
+                                      size_t workspace_bytes, rlx_stream_t stream) {
+    RLX_REQUIRE(x != nullptr || n == 0, "rlx_masked_standardize: NULL x");
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(workspace != nullptr, "rlx_masked_standardize: NULL workspace");
+    if (workspace_bytes < rlx_standardize_workspace_bytes(n)) {
+        set_error("rlx_masked_standardize: workspace too small");
+        return RLX_ENOSPC;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = (int)std::max<long long>(1, std::min<long long>((long long)((n + 255) / 256), std::min(kMaxParts, num_cu() * 8)));
+    double* partials = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(moments_kernel, dim3(nblk), dim3(256), 0, s, x, mask, n, partials);
+    RLX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, x, n, partials, nblk, 0, eps);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}

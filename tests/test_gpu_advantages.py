@@ -1,0 +1,207 @@
+"""Parity of the HIP advantage/return/mask kernels (through the C ABI) with the CPU oracle and with the
+committed reference outputs.  Needs a real MI355X: run with `pytest -m gpu`.
+
+Bars: bool/int outputs bit-exact; the streaming scan (nseg == 1) un-normalised adv/ret bit-exact;
+segmented scans and everything that passes through a mean/std reduction within rtol 1e-5 / atol 1e-6
+of the fp32 CPU result (different summation order only).
+"""
+
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR, synth_rollout
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+VARIANTS = [(v | (s << 8)) for v in (1, 2, 4) for s in (1, 2, 4, 8)]
+
+
+def _ops():
+    from rlinf_amd import ops
+    return ops
+
+
+def _golden(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name), weights_only=False)
+
+
+def _cuda(t):
+    return None if t is None else t.cuda()
+
+
+def test_loss_mask_golden_bit_exact():
+    ops = _ops()
+    for case in _golden("loss_mask.pt"):
+        mask, cnt = ops.done_prefix_mask(case["dones"].cuda())
+        assert torch.equal(mask.cpu(), case["loss_mask"])
+        assert torch.equal(cnt.cpu(), case["loss_mask_sum_row"][:, 0])
+
+
+@pytest.mark.parametrize("T,B,C,p", [(128, 1024, 1, 0.02), (50, 1000, 1, 0.05), (7, 3, 1, 0.3), (16, 100, 4, 0.05),
+                                     (1, 64, 1, 0.5), (128, 8, 1, 0.02), (128, 65536, 1, 0.02)])
+def test_loss_mask_vs_oracle(T, B, C, p):
+    ops = _ops()
+    d = synth_rollout(seed=T * 7 + B, T=T, B=B, C=C, p_done=p)["dones"]
+    mask, cnt = ops.done_prefix_mask(d.cuda())
+    m0, s0 = O.loss_mask_from_dones(d)
+    assert torch.equal(mask.cpu(), m0)
+    assert torch.equal(cnt.cpu(), s0[0, :, 0])
+    # properties: monotone non-increasing along time, sum == first done index
+    mm = mask.cpu().transpose(1, 2).reshape(-1, B)
+    assert bool((mm[1:] <= mm[:-1]).all())
+
+
+def test_advantages_golden():
+    ops = _ops()
+    for case in _golden("advantages.pt"):
+        p = case["params"]
+        rewards, values, dones, lm = case["rewards"], case["values"], case["dones"], case["loss_mask"]
+        if p["reward_type"] == "chunk_level":  # reductions over the chunk dim (utils.py:80-89) are host-side views
+            rewards = rewards.sum(dim=-1, keepdim=True)
+            dones = dones.max(dim=-1, keepdim=True)[0]
+        if p["adv_type"] == "gae":
+            for variant in (0, 1):
+                adv, ret = ops.gae_scan(_cuda(rewards), _cuda(values), _cuda(dones), _cuda(lm), p["gamma"],
+                                        p["gae_lambda"], normalize_advantages=p["normalize_advantages"],
+                                        variant=variant if rewards.shape[-1] == 1 else 0)
+                if variant == 1 or rewards.shape[-1] != 1:
+                    assert torch.equal(ret.cpu(), case["returns"]), p  # streaming scan: bit-exact
+                    if not p["normalize_advantages"]:
+                        assert torch.equal(adv.cpu(), case["advantages"]), p
+                torch.testing.assert_close(ret.cpu(), case["returns"], rtol=RTOL, atol=ATOL)
+                torch.testing.assert_close(adv.cpu(), case["advantages"], rtol=RTOL, atol=ATOL)
+        else:
+            adv, scores = ops.grpo_group_adv(_cuda(rewards), _cuda(dones), _cuda(lm), p["group_size"])
+            torch.testing.assert_close(adv.cpu(), case["advantages"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("T,B", [(128, 1024), (50, 256), (17, 68), (128, 8)])
+def test_gae_variants_vs_oracle(variant, T, B):
+    ops = _ops()
+    vec, nseg = variant & 0xff, variant >> 8
+    if B % vec:
+        pytest.skip("batch not divisible by vec")
+    r = synth_rollout(seed=3 + T + B, T=T, B=B, p_done=0.03)
+    if nseg > 1 and (T * 64 * vec * 8 + nseg * 64 * vec * 8 + 40 * nseg > 160 * 1024 or -(-T // nseg) > 64):
+        from rlinf_amd._lib import RlxError
+        with pytest.raises(RlxError):  # the slab does not fit in the CU's 160 KB of LDS: rejected, not wrong
+            ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), None, 0.99, 0.95, variant=variant)
+        return
+    want_adv, want_ret = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], r["values"][..., 0], 0.99, 0.95,
+                                  normalize_advantages=False)
+    adv, ret = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), None, 0.99, 0.95,
+                            normalize_advantages=False, variant=variant)
+    adv, ret = adv.cpu()[..., 0], ret.cpu()[..., 0]
+    if nseg == 1:
+        assert torch.equal(adv, want_adv) and torch.equal(ret, want_ret)
+    torch.testing.assert_close(adv, want_adv, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(ret, want_ret, rtol=RTOL, atol=ATOL)
+    # the reference's own identity adv = ret - V[:-1], computed in f32 (advantages.py:79)
+    assert torch.equal(adv, ret - r["values"][:-1, :, 0])
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("gl", [(0.8, 0.9), (0.99, 0.95)])
+def test_gae_normalised_north_star_shape(masked, gl):
+    """1024 envs x 128 steps (BASELINE.json configs[1]) against the oracle, auto variant."""
+    ops = _ops()
+    r = synth_rollout(seed=1234, T=128, B=1024, p_done=0.02)
+    lm = O.loss_mask_from_dones(r["dones"])[0] if masked else None
+    want = O.embodied_adv_and_returns(adv_type="gae", rewards=r["rewards"], dones=r["dones"], values=r["values"],
+                                      gamma=gl[0], gae_lambda=gl[1], loss_mask=lm)
+    adv, ret = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), _cuda(lm), gl[0], gl[1])
+    torch.testing.assert_close(adv.cpu(), want["advantages"], rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(ret.cpu(), want["returns"], rtol=RTOL, atol=ATOL)
+    adv_r, ret_r = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), _cuda(lm), gl[0], gl[1],
+                                normalize_returns=True)
+    sel = ret_r if lm is None else ret_r[lm.cuda()]
+    assert abs(float(sel.mean())) < 1e-4 and abs(float(sel.std()) - 1.0) < 1e-3
+
+
+def test_gae_edge_cases():
+    ops = _ops()
+    # critic-free (values=None): gamma/lambda forced to 1 (advantages.py:61-64)
+    r = synth_rollout(seed=5, T=20, B=64, p_done=0.1)
+    want = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], None, 0.9, 0.8, normalize_advantages=False)
+    for variant in (1, 4 | (4 << 8)):
+        adv, ret = ops.gae_scan(r["rewards"].cuda(), None, r["dones"].cuda(), None, 0.9, 0.8,
+                                normalize_advantages=False, variant=variant)
+        torch.testing.assert_close(adv.cpu()[..., 0], want[0], rtol=RTOL, atol=ATOL)
+        torch.testing.assert_close(ret.cpu()[..., 0], want[1], rtol=RTOL, atol=ATOL)
+    # done at the very last row, all-done, no-done
+    for p in (0.0, 1.0):
+        r = synth_rollout(seed=6, T=9, B=70, p_done=p)
+        r["dones"][-1] = True
+        want = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], r["values"][..., 0], 0.99, 0.95)
+        adv, ret = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), None, 0.99, 0.95)
+        torch.testing.assert_close(adv.cpu()[..., 0], want[0], rtol=RTOL, atol=ATOL)
+    # all-False loss mask: safe_normalize leaves the array untouched (utils.py:399)
+    r = synth_rollout(seed=7, T=8, B=64, p_done=0.0)
+    lm = torch.zeros(8, 64, 1, dtype=torch.bool)
+    adv, _ = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), lm.cuda(), 0.99, 0.95, variant=1)
+    raw, _ = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), None, 0.99, 0.95,
+                          normalize_advantages=False, variant=1)
+    assert torch.equal(adv, raw)
+    # empty buffers
+    e_adv, e_ret = ops.gae_scan(torch.zeros(0, 64, 1).cuda(), torch.zeros(1, 64, 1).cuda(),
+                                torch.zeros(1, 64, 1, dtype=torch.bool).cuda())
+    assert e_adv.numel() == 0 and e_ret.numel() == 0
+    # chunked layout (C = 4), masked
+    r = synth_rollout(seed=8, T=12, B=40, C=4, p_done=0.05)
+    lm, lms = O.loss_mask_from_dones(r["dones"])
+    want = O.embodied_adv_and_returns(adv_type="gae", rewards=r["rewards"], dones=r["dones"], values=r["values"],
+                                      gamma=0.99, gae_lambda=0.95, loss_mask=lm, loss_mask_sum=lms)
+    adv, ret = ops.gae_scan(r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), lm.cuda(), 0.99, 0.95)
+    torch.testing.assert_close(adv.cpu(), want["advantages"].contiguous(), rtol=RTOL, atol=ATOL)
+    assert torch.equal(ret.cpu(), want["returns"].contiguous())
+
+
+def test_masked_standardize_standalone():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1000, 37, generator=g) * 3 + 5
+    m = torch.rand(1000, 37, generator=g) < 0.4
+    for mask in (None, m):
+        want = O.masked_standardize(x, mask)
+        got = ops.masked_standardize_(x.clone().cuda(), None if mask is None else mask.cuda())
+        torch.testing.assert_close(got.cpu(), want, rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("T,B,C,G", [(128, 1024, 1, 8), (80, 256, 1, 8), (12, 24, 2, 4), (20, 64, 1, 2), (5, 6, 1, 3)])
+def test_grpo_vs_oracle(T, B, C, G):
+    ops = _ops()
+    r = synth_rollout(seed=11 + T, T=T, B=B, C=C, p_done=0.05)
+    lm, lms = O.loss_mask_from_dones(r["dones"])
+    want = O.embodied_adv_and_returns(adv_type="grpo", rewards=r["rewards"], dones=r["dones"], loss_mask=lm,
+                                      loss_mask_sum=lms, group_size=G)
+    adv, scores = ops.grpo_group_adv(r["rewards"].cuda(), r["dones"].cuda(), lm.cuda(), G)
+    f = O.flatten_embodied_inputs(r["rewards"], r["dones"], None, lm, lms, want_values=False)
+    want_scores = O.first_episode_scores(f["rewards"], f["dones"])
+    torch.testing.assert_close(scores.cpu(), want_scores, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(adv.cpu(), want["advantages"].contiguous(), rtol=2e-5, atol=2e-5)
+    # property: group members sum to ~0 wherever the whole group is unmasked at t = 0
+    a0 = adv[0, :, 0].reshape(-1, G)
+    full = lm[0, :, 0].reshape(-1, G).all(dim=1).cuda()
+    if bool(full.any()):
+        assert float(a0[full].sum(dim=1).abs().max()) < 1e-3
+
+
+def test_scaled_buffer_streaming_vs_segmented_agree():
+    """65536 x 128 (the shape the HBM roofline is judged on): every variant must agree with the
+    bit-exact streaming scan, and the streaming scan with the oracle."""
+    ops = _ops()
+    r = synth_rollout(seed=99, T=128, B=65536, p_done=0.02)
+    want_adv, want_ret = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], r["values"][..., 0], 0.99, 0.95,
+                                  normalize_advantages=False)
+    rc, vc, dc = r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda()
+    base_adv, base_ret = ops.gae_scan(rc, vc, dc, None, 0.99, 0.95, normalize_advantages=False, variant=1)
+    assert torch.equal(base_adv.cpu()[..., 0], want_adv) and torch.equal(base_ret.cpu()[..., 0], want_ret)
+    for variant in (4, 2 | (4 << 8), 1 | (8 << 8), 0):
+        adv, ret = ops.gae_scan(rc, vc, dc, None, 0.99, 0.95, normalize_advantages=False, variant=variant)
+        torch.testing.assert_close(adv, base_adv, rtol=RTOL, atol=ATOL)
+        torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
