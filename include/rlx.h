@@ -73,10 +73,10 @@ int rlx_done_prefix_mask(const uint8_t* dones, uint8_t* loss_mask, int64_t* mask
  *   returns     [n_chunk,   B, C] f32 out
  * gamma_lambda is passed separately because the reference forms gamma*gae_lambda in double before
  * rounding it to f32 (advantages.py:76).
- * variant: 0 = auto; otherwise (vec | nseg << 8): vec in {1,2,4} envs per lane, nseg in {1,2,4,8}
- * time segments per env group.  nseg == 1 is a pure streaming scan whose un-normalised outputs are
- * bit-identical to the reference's CPU loop; nseg > 1 is the segmented scan (per-wave affine maps
- * combined through LDS), equal to it within f32 rounding.
+ * variant: 0 = auto; otherwise (1 | nseg << 8) with nseg in {1,2,4,8,16} time segments per 64-env
+ * group.  nseg == 1 is a pure streaming scan whose un-normalised outputs are bit-identical to the
+ * reference's CPU loop; nseg > 1 is the segmented scan (per-wave affine maps combined through LDS),
+ * equal to it within f32 rounding.  (Wider per-lane vectors were measured and compiled out.)
  * ------------------------------------------------------------------------------------------ */
 typedef struct rlx_gae_params {
     float gamma;

