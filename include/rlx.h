@@ -110,6 +110,121 @@ int rlx_grpo_group_adv(const float* rewards, const uint8_t* dones, const uint8_t
                        float* scores, float* advantages, int n_chunk, int batch, int chunk,
                        int group_size, float eps, rlx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a18-a21  ppo_loss  <- preprocess_loss_inputs (rlinf/algorithms/utils.py:280-376),
+ *                       compute_ppo_actor_loss (rlinf/algorithms/losses.py:170-312),
+ *                       compute_ppo_critic_loss (losses.py:315-380), huber_loss (utils.py:20-23),
+ *                       masked_mean / masked_mean_ratio (rlinf/utils/utils.py:323-356),
+ *                       compute_critic_explained_variance_stats (rlinf/utils/metric_utils.py:232-258)
+ * One thread owns one ADVANTAGE element e (n_adv of them = numel of advantages / loss_mask /
+ * values / prev_values / returns) and the `raw_per_adv` consecutive per-dimension log-probs under
+ * it, which form `sub_per_adv` loss elements of raw_per_adv/sub_per_adv summed log-probs each:
+ *     logprob_type  action_level: raw = A, sub = 1      (sum over action_dim, one ratio per chunk)
+ *                   token_level : raw = A, sub = A      (one ratio per dim, advantage broadcast)
+ *                   chunk_level : raw = C*A, sub = 1    (one ratio per env-step)
+ *   logprobs, old_logprobs  [n_adv * raw_per_adv] f32
+ *   advantages              [n_adv] f32
+ *   values, prev_values, returns [n_adv] f32, all NULL when has_critic == 0 (registry name "actor")
+ *   loss_mask               [n_adv] u8 or NULL;  loss_mask_sum [n_adv] i64 or NULL
+ * Forward writes
+ *   g_logp  [n_adv * sub_per_adv] f32   d(loss)/d(summed log-prob) up to the global scale out[16]
+ *   g_value [n_adv] f32                 d(loss)/d(value)           up to the global scale out[17]
+ *   out     [RLX_PPO_OUT_FLOATS] f32    see enum rlx_ppo_out; everything stays on the device
+ * Backward expands them: d_logprobs[e*raw + j] = grad_out * out[16] * g_logp[...],
+ *                        d_values[e] = grad_out * out[17] * g_value[e]   (grad_out: device scalar).
+ * ------------------------------------------------------------------------------------------ */
+enum rlx_ppo_out {
+    RLX_PPO_LOSS = 0,            /* actor (0 under critic_warmup) + critic */
+    RLX_PPO_POLICY_LOSS = 1,     /* actor/policy_loss        */
+    RLX_PPO_POLICY_LOSS_ABS = 2, /* actor/policy_loss_abs    */
+    RLX_PPO_RATIO = 3,           /* actor/ratio              */
+    RLX_PPO_RATIO_ABS = 4,       /* actor/ratio_abs          */
+    RLX_PPO_CLIPPED_RATIO = 5,   /* actor/clipped_ratio      */
+    RLX_PPO_DUAL_CLIPPED_RATIO = 6, /* actor/dual_cliped_ratio */
+    RLX_PPO_APPROX_KL = 7,       /* actor/approx_kl          */
+    RLX_PPO_CLIP_FRACTION = 8,   /* actor/clip_fraction      */
+    RLX_PPO_VALUE_LOSS = 9,      /* critic/value_loss        */
+    RLX_PPO_VALUE_CLIP_RATIO = 10, /* critic/value_clip_ratio */
+    RLX_PPO_EV_COUNT = 11,       /* explained-variance sufficient statistics (metric_utils.py:252-258) */
+    RLX_PPO_EV_RETURNS_SUM = 12,
+    RLX_PPO_EV_RETURNS_SQ_SUM = 13,
+    RLX_PPO_EV_ERRORS_SUM = 14,
+    RLX_PPO_EV_ERRORS_SQ_SUM = 15,
+    RLX_PPO_ACTOR_GRAD_SCALE = 16,
+    RLX_PPO_CRITIC_GRAD_SCALE = 17,
+    RLX_PPO_OUT_FLOATS = 20
+};
+
+typedef struct rlx_ppo_loss_params {
+    float ratio_lo, ratio_hi;      /* (float)(1.0 - clip_ratio_low), (float)(1.0 + clip_ratio_high): formed in
+                                      double on the host exactly like the reference's python scalars */
+    float clip_ratio_c;            /* used when use_dual_clip */
+    float clip_log_ratio_min, clip_log_ratio_max;
+    float value_clip, huber_delta;
+    int32_t use_dual_clip, use_clip_log_ratio_min, use_clip_log_ratio_max;
+    int32_t has_critic, critic_warmup;
+    int32_t max_episode_steps;     /* > 0 together with loss_mask and loss_mask_sum selects the
+                                      masked_mean_ratio aggregation (losses.py:219-227) */
+    int32_t raw_per_adv, sub_per_adv;
+} rlx_ppo_loss_params;
+
+size_t rlx_ppo_loss_workspace_bytes(int64_t n_adv);
+int rlx_ppo_loss_fwd(const float* logprobs, const float* old_logprobs, const float* advantages,
+                     const float* values, const float* prev_values, const float* returns,
+                     const uint8_t* loss_mask, const int64_t* loss_mask_sum, int64_t n_adv,
+                     const rlx_ppo_loss_params* params, float* g_logp, float* g_value, float* out,
+                     void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+int rlx_ppo_loss_bwd(const float* g_logp, const float* g_value, const float* out, const float* grad_out,
+                     float* d_logprobs, float* d_values, int64_t n_adv, int raw_per_adv, int sub_per_adv,
+                     rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a16  shuffle_gather  <- process_nested_dict_for_train, rlinf/utils/nested_dict_process.py:272-285
+ *   for every field f:  dst_f[i, :] = src_f[index[i], :]   (rows of row_bytes_f bytes; the caller has
+ *   already dropped the last time row of dones/terminations/truncations/prev_values by passing a
+ *   shorter view).  Up to RLX_GATHER_MAX_FIELDS fields per launch.  Bit-exact by construction.
+ * ------------------------------------------------------------------------------------------ */
+#define RLX_GATHER_MAX_FIELDS 16
+typedef struct rlx_gather_field {
+    const void* src;
+    void* dst;
+    int64_t row_bytes;
+} rlx_gather_field;
+int rlx_gather_rows(const rlx_gather_field* fields, int n_fields, const int64_t* index, int64_t n_rows,
+                    rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a23  clip_adamw_step  <- FSDPModelManager.optimizer_step, rlinf/hybrid_engines/fsdp/fsdp_model_manager.py:429-463
+ *        = torch.nn.utils.clip_grad_norm_ (strategy/fsdp.py:363-369) + torch.optim.AdamW.step
+ *          with the two parameter groups of build_optimizer (fsdp_model_manager.py:501-590)
+ * Flat f32 buffers of n elements: params, grads, exp_avg, exp_avg_sq.  `groups` partitions [0, n)
+ * into ranges with their own learning rate (names containing "value_head" use value_lr).
+ *   total_norm = ||grads||_2;  grads *= min(1, max_norm / (total_norm + 1e-6))  (always applied)
+ *   if total_norm is non-finite the AdamW update is skipped (step count is the caller's to keep)
+ *   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g;
+ *   p -= (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)
+ * stats[0] = total_norm (pre-clip), stats[1] = 1 if the step was applied else 0.  Device-side.
+ * grad_partials > 1: grads holds that many stacked partial buffers [grad_partials][n] which are summed
+ * first (split-K weight-gradient slabs); the sum is what gets clipped and applied.
+ * ------------------------------------------------------------------------------------------ */
+#define RLX_ADAMW_MAX_GROUPS 8
+typedef struct rlx_adamw_group {
+    int64_t begin, end; /* element range */
+    float lr;
+} rlx_adamw_group;
+typedef struct rlx_adamw_params {
+    float beta1, beta2, eps, weight_decay, max_grad_norm; /* max_grad_norm <= 0: no clipping */
+    int32_t step;            /* 1-based step count of THIS update */
+    int32_t n_groups;
+    int32_t grad_partials;   /* >= 1 */
+    float grad_scale;        /* applied to the summed gradient before the norm (e.g. 1/world_size) */
+    rlx_adamw_group groups[RLX_ADAMW_MAX_GROUPS];
+} rlx_adamw_params;
+size_t rlx_adamw_workspace_bytes(int64_t n);
+int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const rlx_adamw_params* p, float* stats, void* workspace, size_t workspace_bytes,
+                        rlx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

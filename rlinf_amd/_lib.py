@@ -30,6 +30,45 @@ class GaeParams(Structure):
     ]
 
 
+class PpoLossParams(Structure):
+    _fields_ = [
+        ("ratio_lo", c_float), ("ratio_hi", c_float), ("clip_ratio_c", c_float),
+        ("clip_log_ratio_min", c_float), ("clip_log_ratio_max", c_float),
+        ("value_clip", c_float), ("huber_delta", c_float),
+        ("use_dual_clip", c_int32), ("use_clip_log_ratio_min", c_int32), ("use_clip_log_ratio_max", c_int32),
+        ("has_critic", c_int32), ("critic_warmup", c_int32), ("max_episode_steps", c_int32),
+        ("raw_per_adv", c_int32), ("sub_per_adv", c_int32),
+    ]
+
+
+class GatherField(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("row_bytes", c_int64)]
+
+
+GATHER_MAX_FIELDS = 16
+ADAMW_MAX_GROUPS = 8
+
+
+class AdamwGroup(Structure):
+    _fields_ = [("begin", c_int64), ("end", c_int64), ("lr", c_float)]
+
+
+class AdamwParams(Structure):
+    _fields_ = [
+        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+        ("max_grad_norm", c_float), ("step", c_int32), ("n_groups", c_int32), ("grad_partials", c_int32),
+        ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
+    ]
+
+
+PPO_OUT_FLOATS = 20
+PPO_OUT_NAMES = {
+    "loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, "actor/ratio": 3, "actor/ratio_abs": 4,
+    "actor/clipped_ratio": 5, "actor/dual_cliped_ratio": 6, "actor/approx_kl": 7, "actor/clip_fraction": 8,
+    "critic/value_loss": 9, "critic/value_clip_ratio": 10, "ev/count": 11, "ev/returns_sum": 12,
+    "ev/returns_sq_sum": 13, "ev/errors_sum": 14, "ev/errors_sq_sum": 15,
+}
+
 # name -> (restype, argtypes); kept in one table so tests can check it against include/rlx.h
 PROTOTYPES = {
     "rlx_version": (c_int, []),
@@ -43,6 +82,15 @@ PROTOTYPES = {
     "rlx_masked_standardize": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_size_t, c_void_p]),
     "rlx_grpo_group_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_void_p]),
+    "rlx_ppo_loss_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_ppo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 POINTER(PpoLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rlx_ppo_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                 c_void_p]),
+    "rlx_gather_rows": (c_int, [POINTER(GatherField), c_int, c_void_p, c_int64, c_void_p]),
+    "rlx_adamw_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamwParams), c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,292 @@
+// ppo_loss.hip -- fused PPO clipped-surrogate + clipped-Huber value loss, forward and backward, gfx950.
+//
+// Replaces (after rlinf/algorithms/utils.py:280-376 preprocess_loss_inputs):
+//   compute_ppo_actor_loss   rlinf/algorithms/losses.py:170-312
+//   compute_ppo_critic_loss  rlinf/algorithms/losses.py:315-380  (+ huber_loss utils.py:20-23,
+//   masked_mean / masked_mean_ratio rlinf/utils/utils.py:323-356, explained-variance stats
+//   rlinf/utils/metric_utils.py:232-258)
+// i.e. ~40 elementwise torch kernels + ~15 reductions per micro-batch become ONE streaming pass
+// (80 B read per sample at A = 8) + a 1-block finalize; backward is one expand pass (36 B written).
+// All scalars (loss, 15 metrics, gradient scales) stay on the device: no .item() syncs.
+//
+// The per-element derivative is computed in the forward pass, exactly as autograd would for the
+// reference graph, including its tie rules: torch.max / torch.min send half the gradient to each
+// argument on ties, clamp passes gradient on its closed interval, where() routes to the taken branch.
+
+#include <algorithm>
+
+#include "rlx_common.h"
+
+namespace rlx {
+namespace {
+
+constexpr int NS = 16;  // reduction slots
+enum { S_NM = 0, S_LOSS, S_ABS, S_RATIO, S_RABS, S_CLIPPED, S_DUAL, S_KL, S_CLIPFRAC, S_VLOSS, S_VIND,
+       S_EVN, S_EVR, S_EVRR, S_EVE, S_EVEE };
+
+struct LossArgs {
+    const float* lp;
+    const float* old;
+    const float* adv;
+    const float* v;
+    const float* pv;
+    const float* ret;
+    const uint8_t* m;
+    const int64_t* msum;
+    float* g_lp;
+    float* g_v;
+    double* partials;
+    long long n;
+    rlx_ppo_loss_params p;
+};
+
+__device__ __forceinline__ float huber(float e, float delta, float half_delta) {
+    const float ae = fabsf(e);
+    return ae < delta ? fmul(0.5f, fmul(e, e)) : fmul(delta, fsub(ae, half_delta));
+}
+__device__ __forceinline__ float huber_grad(float e, float delta) {
+    const float ae = fabsf(e);
+    return ae < delta ? e : (e > 0.f ? delta : (e < 0.f ? -delta : 0.f));
+}
+__device__ __forceinline__ float tie_weight_gt(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+__device__ __forceinline__ float tie_weight_lt(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ppo_loss_fwd_kernel(LossArgs a) {
+    __shared__ double s_red[NS * 4];
+    const rlx_ppo_loss_params& p = a.p;
+    const int K = p.raw_per_adv, S = p.sub_per_adv, R = K / S;
+    const bool ratio_mode = p.max_episode_steps > 0 && a.m != nullptr && a.msum != nullptr;
+    const float half_delta = (float)(0.5 * (double)p.huber_delta);
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < a.n; e += stride) {
+        const bool on = a.m ? a.m[e] != 0 : true;
+        const float mf = on ? 1.f : 0.f;
+        float w = 1.f;
+        if (ratio_mode) w = ((float)a.msum[e] * 1.0f) / (float)p.max_episode_steps;
+        const float adv = a.adv[e];
+        const float nadv = -adv;
+        acc[S_NM] += on ? 1.0 : 0.0;
+        const float* lpp = a.lp + e * K;
+        const float* olp = a.old + e * K;
+        for (int s = 0; s < S; ++s) {
+            float lp = 0.f, old = 0.f;
+            if constexpr (VEC4) {
+                for (int j = 0; j < R; j += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(lpp + s * R + j);
+                    const float4 y = *reinterpret_cast<const float4*>(olp + s * R + j);
+                    lp = fadd(fadd(fadd(fadd(lp, x.x), x.y), x.z), x.w);
+                    old = fadd(fadd(fadd(fadd(old, y.x), y.y), y.z), y.w);
+                }
+            } else {
+                for (int j = 0; j < R; ++j) {
+                    lp = fadd(lp, lpp[s * R + j]);
+                    old = fadd(old, olp[s * R + j]);
+                }
+            }
+            float lr = fsub(lp, old);
+            float cg = 1.f;  // gradient of the two log-ratio clamps
+            if (p.use_clip_log_ratio_min) {
+                if (!(lr >= p.clip_log_ratio_min)) cg = 0.f;
+                lr = fmaxf(lr, p.clip_log_ratio_min);
+            }
+            if (p.use_clip_log_ratio_max) {
+                if (!(lr <= p.clip_log_ratio_max)) cg = 0.f;
+                lr = fminf(lr, p.clip_log_ratio_max);
+            }
+            const float ratio = on ? expf(lr) : 0.f;
+            const float clipped = fminf(fmaxf(ratio, p.ratio_lo), p.ratio_hi);
+            const float pl1 = fmul(nadv, ratio), pl2 = fmul(nadv, clipped);
+            float pl = fmaxf(pl1, pl2);
+            const float w1 = tie_weight_gt(pl1, pl2);
+            const float in_rng = (ratio >= p.ratio_lo && ratio <= p.ratio_hi) ? 1.f : 0.f;
+            float dpl = nadv * (w1 + (1.f - w1) * in_rng);
+            bool dual = false;
+            if (p.use_dual_clip) {
+                const float sgn = adv > 0.f ? 1.f : (adv < 0.f ? -1.f : 0.f);
+                const float pl3 = fmul(fmul(sgn, p.clip_ratio_c), adv);
+                dual = pl3 < pl;
+                dpl *= tie_weight_lt(pl, pl3);
+                pl = fminf(pl, pl3);
+            }
+            const float contrib = ratio_mode ? fmul(pl / w, mf) : fmul(pl, mf);
+            const float contrib_abs = ratio_mode ? fmul(fabsf(pl) / w, mf) : fmul(fabsf(pl), mf);
+            acc[S_LOSS] += (double)contrib;
+            acc[S_ABS] += (double)contrib_abs;
+            acc[S_RATIO] += (double)fmul(ratio, mf);
+            acc[S_RABS] += (double)fmul(fabsf(fsub(ratio, 1.f)), mf);
+            acc[S_CLIPPED] += (double)fmul(clipped, mf);
+            acc[S_DUAL] += (dual && on) ? (double)ratio : 0.0;
+            acc[S_KL] += on ? (double)lr : 0.0;
+            acc[S_CLIPFRAC] += (pl1 < pl2 && on) ? 1.0 : 0.0;
+            float g = p.critic_warmup ? 0.f : dpl * ratio * cg * mf;  // ratio == d exp(lr)/d lr, 0 when masked
+            if (ratio_mode) g = g / w;
+            a.g_lp[e * S + s] = g;
+        }
+        if (p.has_critic) {
+            const float v = a.v[e], pv = a.pv[e], ret = a.ret[e];
+            const float diff = fsub(v, pv);
+            const float cl = fminf(fmaxf(diff, -p.value_clip), p.value_clip);
+            const float vclip = fadd(pv, cl);
+            const float e1 = fsub(ret, v), e2 = fsub(ret, vclip);
+            const float h1 = huber(e1, p.huber_delta, half_delta), h2 = huber(e2, p.huber_delta, half_delta);
+            const float h = fmaxf(h1, h2);
+            acc[S_VLOSS] += (double)(ratio_mode ? fmul(h / w, mf) : fmul(h, mf));
+            acc[S_VIND] += fabsf(fsub(vclip, pv)) > p.value_clip ? 1.0 : 0.0;
+            if (on) {
+                acc[S_EVN] += 1.0;
+                acc[S_EVR] += (double)ret;
+                acc[S_EVRR] += (double)fmul(ret, ret);
+                acc[S_EVE] += (double)e1;
+                acc[S_EVEE] += (double)fmul(e1, e1);
+            }
+            const float wh1 = tie_weight_gt(h1, h2);
+            const float pass = (diff >= -p.value_clip && diff <= p.value_clip) ? 1.f : 0.f;
+            float gv = -(wh1 * huber_grad(e1, p.huber_delta) + (1.f - wh1) * huber_grad(e2, p.huber_delta) * pass) * mf;
+            if (ratio_mode) gv = gv / w;
+            a.g_v[e] = gv;
+        }
+    }
+    block_sum<NS>(acc, s_red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) a.partials[(size_t)blockIdx.x * NS + k] = acc[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void ppo_loss_finalize(const double* partials, int nparts, long long n_adv,
+                                                         rlx_ppo_loss_params p, int has_mask, int has_msum,
+                                                         float* out) {
+    __shared__ double s_red[NS * 4];
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += partials[(size_t)i * NS + k];
+    }
+    block_sum<NS>(acc, s_red);
+    if (threadIdx.x != 0) return;
+    const double L = (double)n_adv * p.sub_per_adv;  // loss elements
+    const double Lc = (double)n_adv;
+    const double nm = acc[S_NM];
+    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
+    // masked_mean: sum/sum(mask); all-False mask -> plain sum (which is 0); no mask -> mean
+    const double den_actor = ratio_mode ? L : (has_mask ? (nm > 0 ? nm : 1.0) : L);
+    const double den_critic = ratio_mode ? Lc : (has_mask ? (nm > 0 ? nm : 1.0) : Lc);
+    const double den_metric = has_mask ? (nm > 0 ? nm * p.sub_per_adv : 1.0) : L;
+    const double count = has_mask ? (nm > 0 ? nm : 1.0) : L;  // loss_mask.count_nonzero() or 1
+    const float policy_loss = p.critic_warmup ? 0.f : (float)(acc[S_LOSS] / den_actor);
+    const float value_loss = p.has_critic ? (float)(acc[S_VLOSS] / den_critic) : 0.f;
+    out[RLX_PPO_LOSS] = policy_loss + value_loss;
+    out[RLX_PPO_POLICY_LOSS] = policy_loss;
+    out[RLX_PPO_POLICY_LOSS_ABS] = (float)(acc[S_ABS] / den_actor);
+    out[RLX_PPO_RATIO] = (float)(acc[S_RATIO] / den_metric);
+    out[RLX_PPO_RATIO_ABS] = (float)(acc[S_RABS] / den_metric);
+    out[RLX_PPO_CLIPPED_RATIO] = (float)(acc[S_CLIPPED] / den_metric);
+    out[RLX_PPO_DUAL_CLIPPED_RATIO] = (float)(acc[S_DUAL] / den_metric);
+    out[RLX_PPO_APPROX_KL] = (float)(-acc[S_KL] / count);
+    out[RLX_PPO_CLIP_FRACTION] = (float)(acc[S_CLIPFRAC] / count);
+    out[RLX_PPO_VALUE_LOSS] = value_loss;
+    out[RLX_PPO_VALUE_CLIP_RATIO] = p.has_critic ? (float)(acc[S_VIND] / Lc) : 0.f;
+    out[RLX_PPO_EV_COUNT] = (float)acc[S_EVN];
+    out[RLX_PPO_EV_RETURNS_SUM] = (float)acc[S_EVR];
+    out[RLX_PPO_EV_RETURNS_SQ_SUM] = (float)acc[S_EVRR];
+    out[RLX_PPO_EV_ERRORS_SUM] = (float)acc[S_EVE];
+    out[RLX_PPO_EV_ERRORS_SQ_SUM] = (float)acc[S_EVEE];
+    out[RLX_PPO_ACTOR_GRAD_SCALE] = (float)(1.0 / den_actor);
+    out[RLX_PPO_CRITIC_GRAD_SCALE] = (float)(1.0 / den_critic);
+    out[18] = (float)nm;
+    out[19] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void ppo_loss_bwd_kernel(const float* g_lp, const float* g_v, const float* out,
+                                                           const float* grad_out, float* d_lp, float* d_v,
+                                                           long long n_adv, int K, int S) {
+    const float go = grad_out ? grad_out[0] : 1.f;
+    const float sa = go * out[RLX_PPO_ACTOR_GRAD_SCALE], sc = go * out[RLX_PPO_CRITIC_GRAD_SCALE];
+    const int R = K / S;
+    const long long total = n_adv * K;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long e = i / K;
+        const int s = (int)(i - e * K) / R;
+        d_lp[i] = sa * g_lp[e * S + s];
+    }
+    if (d_v) {
+        for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_adv; e += stride) d_v[e] = sc * g_v[e];
+    }
+}
+
+constexpr int kMaxLossBlocks = 1024;
+
+int loss_grid(long long n) {
+    const long long want = (n + 255) / 256;
+    return (int)std::max<long long>(1, std::min<long long>(want, std::min<long long>(kMaxLossBlocks, (long long)num_cu() * 4)));
+}
+
+}  // namespace
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" size_t rlx_ppo_loss_workspace_bytes(int64_t n_adv) {
+    (void)n_adv;
+    return (size_t)kMaxLossBlocks * NS * sizeof(double);
+}
+
+extern "C" int rlx_ppo_loss_fwd(const float* logprobs, const float* old_logprobs, const float* advantages,
+                                const float* values, const float* prev_values, const float* returns,
+                                const uint8_t* loss_mask, const int64_t* loss_mask_sum, int64_t n_adv,
+                                const rlx_ppo_loss_params* p, float* g_logp, float* g_value, float* out, void* workspace,
+                                size_t workspace_bytes, rlx_stream_t stream) {
+    RLX_REQUIRE(p != nullptr && out != nullptr, "rlx_ppo_loss_fwd: NULL params/out");
+    RLX_REQUIRE(n_adv >= 0, "rlx_ppo_loss_fwd: negative size");
+    RLX_REQUIRE(p->raw_per_adv >= 1 && p->sub_per_adv >= 1 && p->raw_per_adv % p->sub_per_adv == 0,
+                "rlx_ppo_loss_fwd: raw_per_adv=%d must be a positive multiple of sub_per_adv=%d", p->raw_per_adv,
+                p->sub_per_adv);
+    RLX_REQUIRE(n_adv == 0 || (logprobs && old_logprobs && advantages && g_logp), "rlx_ppo_loss_fwd: NULL actor argument");
+    RLX_REQUIRE(!p->has_critic || n_adv == 0 || (values && prev_values && returns && g_value),
+                "rlx_ppo_loss_fwd: has_critic set but a critic tensor is NULL");
+    RLX_REQUIRE(!p->use_dual_clip || p->clip_ratio_c > 1.0f, "clip_ratio_c must be greater than 1.0");  // losses.py:262
+    RLX_REQUIRE(workspace != nullptr, "rlx_ppo_loss_fwd: NULL workspace");
+    if (workspace_bytes < rlx_ppo_loss_workspace_bytes(n_adv)) {
+        set_error("rlx_ppo_loss_fwd: workspace too small");
+        return RLX_ENOSPC;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossArgs a;
+    a.lp = logprobs; a.old = old_logprobs; a.adv = advantages; a.v = values; a.pv = prev_values; a.ret = returns;
+    a.m = loss_mask; a.msum = loss_mask_sum; a.g_lp = g_logp; a.g_v = g_value;
+    a.partials = static_cast<double*>(workspace);
+    a.n = n_adv; a.p = *p;
+    const int nblk = loss_grid(n_adv);
+    const int R = p->raw_per_adv / p->sub_per_adv;
+    const bool vec4 = R % 4 == 0 && (reinterpret_cast<uintptr_t>(logprobs) | reinterpret_cast<uintptr_t>(old_logprobs)) % 16 == 0;
+    if (vec4) hipLaunchKernelGGL(ppo_loss_fwd_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ppo_loss_fwd_kernel<false>, dim3(nblk), dim3(256), 0, s, a);
+    RLX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ppo_loss_finalize, dim3(1), dim3(256), 0, s, a.partials, nblk, (long long)n_adv, *p,
+                       loss_mask != nullptr ? 1 : 0, loss_mask_sum != nullptr ? 1 : 0, out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_ppo_loss_bwd(const float* g_logp, const float* g_value, const float* out, const float* grad_out,
+                                float* d_logprobs, float* d_values, int64_t n_adv, int raw_per_adv, int sub_per_adv,
+                                rlx_stream_t stream) {
+    RLX_REQUIRE(n_adv >= 0 && raw_per_adv >= 1 && sub_per_adv >= 1 && raw_per_adv % sub_per_adv == 0,
+                "rlx_ppo_loss_bwd: bad sizes");
+    if (n_adv == 0) return RLX_OK;
+    RLX_REQUIRE(g_logp && out && d_logprobs, "rlx_ppo_loss_bwd: NULL argument");
+    RLX_REQUIRE(d_values == nullptr || g_value != nullptr, "rlx_ppo_loss_bwd: d_values requested without g_value");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ppo_loss_bwd_kernel, dim3(loss_grid(n_adv * raw_per_adv)), dim3(256), 0, s, g_logp, g_value, out,
+                       grad_out, d_logprobs, d_values, (long long)n_adv, raw_per_adv, sub_per_adv);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import GaeParams, RlxError
+from ._lib import AdamwGroup, AdamwParams, GaeParams, GatherField, PpoLossParams, RlxError
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -146,3 +146,199 @@ def grpo_group_adv(rewards: torch.Tensor, dones: torch.Tensor, loss_mask: torch.
         _lib.check(lib.rlx_grpo_group_adv(r.data_ptr(), d8.data_ptr(), m8.data_ptr(), scores.data_ptr(), adv.data_ptr(),
                                           n, B, C, int(group_size), float(eps), _stream_ptr(dev)), "rlx_grpo_group_adv")
     return adv, scores
+
+
+# --------------------------------------------------------------------------------------------
+# a18-a21  fused PPO loss (forward + backward) as an autograd node
+# --------------------------------------------------------------------------------------------
+_LEVELS = ("action_level", "token_level", "chunk_level")
+
+
+def _loss_geometry(logprobs: torch.Tensor, logprob_type: str, action_dim: int):
+    """(n_adv, raw_per_adv, sub_per_adv) for a [bsz, C*A] log-prob tensor (algorithms/utils.py:325-356)."""
+    bsz = logprobs.shape[0]
+    per_row = logprobs.numel() // max(bsz, 1)
+    if logprob_type not in _LEVELS:
+        raise RlxError(f"logprob_type must be one of {_LEVELS}, got {logprob_type!r}")
+    if per_row % action_dim != 0:
+        raise RlxError(f"logprobs row of {per_row} elements is not a multiple of action_dim={action_dim}")
+    chunks = per_row // action_dim
+    if logprob_type == "action_level":
+        return bsz * chunks, action_dim, 1
+    if logprob_type == "token_level":
+        return bsz * chunks, action_dim, action_dim
+    return bsz, per_row, 1
+
+
+class _PpoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logprobs, values, old_logprobs, advantages, prev_values, returns, loss_mask, loss_mask_sum,
+                params: PpoLossParams, n_adv: int):
+        lib = _lib.load()
+        dev = logprobs.device
+        lp = logprobs.contiguous()
+        g_lp = torch.empty((n_adv * params.sub_per_adv,), dtype=torch.float32, device=dev)
+        g_v = torch.empty((n_adv,), dtype=torch.float32, device=dev) if params.has_critic else None
+        out = torch.empty((_lib.PPO_OUT_FLOATS,), dtype=torch.float32, device=dev)
+        ws_bytes = lib.rlx_ppo_loss_workspace_bytes(n_adv)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rlx_ppo_loss_fwd(lp.data_ptr(), old_logprobs.data_ptr(), advantages.data_ptr(), _ptr(values),
+                                            _ptr(prev_values), _ptr(returns), _ptr(loss_mask), _ptr(loss_mask_sum), n_adv,
+                                            byref(params), g_lp.data_ptr(), _ptr(g_v), out.data_ptr(), ws.data_ptr(),
+                                            ws_bytes, _stream_ptr(dev)), "rlx_ppo_loss_fwd")
+        ctx.save_for_backward(g_lp, g_v if g_v is not None else out, out)
+        ctx.has_critic = bool(params.has_critic)
+        ctx.geom = (n_adv, params.raw_per_adv, params.sub_per_adv)
+        ctx.lp_shape = logprobs.shape
+        ctx.v_shape = None if values is None else values.shape
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_out):
+        lib = _lib.load()
+        g_lp, g_v, out = ctx.saved_tensors
+        n_adv, raw, sub = ctx.geom
+        dev = g_lp.device
+        go = grad_loss.to(dtype=torch.float32).contiguous()
+        d_lp = torch.empty((n_adv * raw,), dtype=torch.float32, device=dev)
+        d_v = torch.empty((n_adv,), dtype=torch.float32, device=dev) if ctx.has_critic else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.rlx_ppo_loss_bwd(g_lp.data_ptr(), g_v.data_ptr() if ctx.has_critic else None, out.data_ptr(),
+                                            go.data_ptr(), d_lp.data_ptr(), _ptr(d_v), n_adv, raw, sub,
+                                            _stream_ptr(dev)), "rlx_ppo_loss_bwd")
+        return (d_lp.view(ctx.lp_shape), None if d_v is None else d_v.view(ctx.v_shape), None, None, None, None, None,
+                None, None, None)
+
+
+def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: torch.Tensor, *,
+             logprob_type: str = "action_level", action_dim: int = 8, clip_ratio_low: float, clip_ratio_high: float,
+             values: Optional[torch.Tensor] = None, prev_values: Optional[torch.Tensor] = None,
+             returns: Optional[torch.Tensor] = None, value_clip: Optional[float] = None,
+             huber_delta: Optional[float] = None, loss_mask: Optional[torch.Tensor] = None,
+             loss_mask_sum: Optional[torch.Tensor] = None, max_episode_steps: Optional[int] = None,
+             clip_ratio_c: Optional[float] = None, clip_log_ratio_min: Optional[float] = None,
+             clip_log_ratio_max: Optional[float] = None, critic_warmup: bool = False, has_critic: bool = True):
+    """Fused actor(+critic) PPO loss.  Inputs are the RAW per-dimension tensors the reference hands to
+    policy_loss (before preprocess_loss_inputs); returns (loss 0-dim tensor with grad, out f32[20] on device,
+    see _lib.PPO_OUT_NAMES).  losses.py asserts float32 inputs (:232-240); so do we."""
+    dev = _dev(logprobs, old_logprobs, advantages, values, prev_values, returns, loss_mask, loss_mask_sum)
+    for name, t in (("logprobs", logprobs), ("old_logprobs", old_logprobs), ("advantages", advantages)):
+        if t.dtype != torch.float32:
+            raise RlxError(f"{name} must be float32 to keep numerical stability")
+    n_adv, raw, sub = _loss_geometry(logprobs, logprob_type, action_dim)
+    if old_logprobs.numel() != logprobs.numel():
+        raise RlxError("old_logprobs must have the shape of logprobs")
+    if advantages.numel() != n_adv:
+        raise RlxError(f"advantages has {advantages.numel()} elements, expected {n_adv} for {logprob_type}")
+    if has_critic:
+        if values is None or prev_values is None or returns is None or value_clip is None or huber_delta is None:
+            raise RlxError("actor_critic loss needs values, prev_values, returns, value_clip and huber_delta")
+        for name, t in (("values", values), ("prev_values", prev_values), ("returns", returns)):
+            if t.numel() != n_adv:
+                raise RlxError(f"{name} has {t.numel()} elements, expected {n_adv}")
+            if t.dtype != torch.float32:
+                raise RlxError(f"{name} must be float32")
+    m8 = _as_u8(loss_mask)
+    if m8 is not None and m8.numel() != n_adv:
+        raise RlxError(f"loss_mask has {m8.numel()} elements, expected {n_adv}")
+    msum = None
+    if loss_mask_sum is not None:
+        if loss_mask_sum.numel() != n_adv:
+            msum = loss_mask_sum.expand(advantages.shape if loss_mask_sum.dim() == advantages.dim() else loss_mask_sum.shape)
+        else:
+            msum = loss_mask_sum
+        msum = msum.to(torch.int64).contiguous()
+        if msum.numel() != n_adv:
+            raise RlxError(f"loss_mask_sum has {msum.numel()} elements, expected {n_adv}")
+    if clip_ratio_c is not None and not clip_ratio_c > 1.0:
+        raise AssertionError("clip_ratio_c must be greater than 1.0")
+    p = PpoLossParams()
+    p.ratio_lo, p.ratio_hi = float(1.0 - clip_ratio_low), float(1.0 + clip_ratio_high)
+    p.clip_ratio_c = float(clip_ratio_c) if clip_ratio_c is not None else 0.0
+    p.use_dual_clip = int(clip_ratio_c is not None)
+    p.clip_log_ratio_min = float(clip_log_ratio_min) if clip_log_ratio_min is not None else 0.0
+    p.clip_log_ratio_max = float(clip_log_ratio_max) if clip_log_ratio_max is not None else 0.0
+    p.use_clip_log_ratio_min = int(clip_log_ratio_min is not None)
+    p.use_clip_log_ratio_max = int(clip_log_ratio_max is not None)
+    p.value_clip = float(value_clip) if has_critic else 0.0
+    p.huber_delta = float(huber_delta) if has_critic else 0.0
+    p.has_critic = int(has_critic)
+    p.critic_warmup = int(bool(critic_warmup))
+    p.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
+    p.raw_per_adv, p.sub_per_adv = raw, sub
+    v = values.contiguous() if has_critic else None
+    return _PpoLossFn.apply(logprobs, v, old_logprobs.contiguous(), advantages.contiguous(),
+                            prev_values.contiguous() if has_critic else None,
+                            returns.contiguous() if has_critic else None, m8, msum, p, n_adv)
+
+
+# --------------------------------------------------------------------------------------------
+# a16  shuffle gather
+# --------------------------------------------------------------------------------------------
+def gather_rows(fields: list, index: torch.Tensor) -> list:
+    """fields: list of [N, ...] contiguous HIP tensors; returns [t[index] for t in fields] (one launch per 16)."""
+    lib = _lib.load()
+    if not fields:
+        return []
+    dev = _dev(index, *fields)
+    if index.dtype != torch.int64:
+        raise RlxError("index must be int64")
+    idx = index.contiguous()
+    n = idx.numel()
+    outs = []
+    for t in fields:
+        if not t.is_contiguous():
+            raise RlxError("gather_rows needs contiguous fields")
+        outs.append(torch.empty((n, *t.shape[1:]), dtype=t.dtype, device=dev))
+    with torch.cuda.device(dev):
+        for lo in range(0, len(fields), _lib.GATHER_MAX_FIELDS):
+            chunk = list(zip(fields, outs))[lo:lo + _lib.GATHER_MAX_FIELDS]
+            arr = (GatherField * len(chunk))()
+            k = 0
+            for src, dst in chunk:
+                row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
+                if row_bytes == 0:
+                    continue
+                arr[k].src, arr[k].dst, arr[k].row_bytes = src.data_ptr(), dst.data_ptr(), row_bytes
+                k += 1
+            if k and n:
+                _lib.check(lib.rlx_gather_rows(arr, k, idx.data_ptr(), n, _stream_ptr(dev)), "rlx_gather_rows")
+    return outs
+
+
+# --------------------------------------------------------------------------------------------
+# a23  clip + AdamW on flat buffers
+# --------------------------------------------------------------------------------------------
+def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+                     groups: list, step: int, *, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                     max_grad_norm: float = 0.5, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None):
+    """In-place clip_grad_norm_ + AdamW over flat f32 buffers.  groups = [(begin, end, lr), ...].
+    grads may be [n] or [slabs, n] (split-K slabs, summed first).  Returns stats f32[2] = (norm, applied)."""
+    lib = _lib.load()
+    dev = _dev(params, grads, exp_avg, exp_avg_sq)
+    n = params.numel()
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RlxError("clip_adamw_step_ needs contiguous float32 buffers")
+    if grads.numel() % max(n, 1) != 0 or exp_avg.numel() != n or exp_avg_sq.numel() != n:
+        raise RlxError("buffer sizes do not match")
+    slabs = grads.numel() // max(n, 1)
+    if len(groups) > _lib.ADAMW_MAX_GROUPS:
+        raise RlxError("too many parameter groups")
+    p = AdamwParams()
+    p.beta1, p.beta2, p.eps, p.weight_decay = float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+    p.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
+    p.step, p.n_groups, p.grad_partials, p.grad_scale = int(step), len(groups), int(slabs), float(grad_scale)
+    for k, (b, e, lr) in enumerate(groups):
+        p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
+    if stats is None:
+        stats = torch.empty((2,), dtype=torch.float32, device=dev)
+    ws_bytes = lib.rlx_adamw_workspace_bytes(n)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_clip_adamw_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                           byref(p), stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(dev)),
+                   "rlx_clip_adamw_step")
+    return stats

@@ -1,0 +1,202 @@
+"""Parity of the fused PPO loss (fwd+bwd), the shuffle-gather and the clip+AdamW kernels with the CPU
+oracle / committed reference outputs.  `pytest -m gpu`.
+
+Bars: gather is bit-exact; loss, metrics and gradients within rtol 1e-5 / atol 1e-6 of the fp32 CPU result
+(device expf and a different summation order are the only differences); AdamW state within rtol 1e-5 /
+atol 1e-7 after several steps.
+"""
+
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _golden(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name), weights_only=False)
+
+
+def _c(t):
+    return None if t is None else t.cuda()
+
+
+_METRICS = ("actor/policy_loss", "actor/policy_loss_abs", "actor/ratio", "actor/ratio_abs", "actor/clipped_ratio",
+            "actor/dual_cliped_ratio", "actor/approx_kl", "actor/clip_fraction", "critic/value_loss",
+            "critic/value_clip_ratio")
+
+
+def test_ppo_loss_golden_all_variants():
+    from rlinf_amd import _lib, ops
+    cases = _golden("losses.pt")
+    assert len(cases) == 27
+    for case in cases:
+        p = case["params"]
+        lp = case["logprobs"].cuda().requires_grad_(True)
+        v = case["values"].cuda().requires_grad_(True)
+        loss, out = ops.ppo_loss(
+            lp, _c(case["old_logprobs"]), _c(case["advantages"]), logprob_type=p["logprob_type"],
+            action_dim=p["action_dim"], clip_ratio_low=p["clip_ratio_low"], clip_ratio_high=p["clip_ratio_high"],
+            values=v, prev_values=_c(case["prev_values"]), returns=_c(case["returns"]), value_clip=p["value_clip"],
+            huber_delta=p["huber_delta"], loss_mask=_c(case["loss_mask"]), loss_mask_sum=_c(case["loss_mask_sum"]),
+            max_episode_steps=p["max_episode_steps"], clip_ratio_c=p.get("clip_ratio_c"),
+            clip_log_ratio_min=p.get("clip_log_ratio_min"), clip_log_ratio_max=p.get("clip_log_ratio_max"),
+            critic_warmup=p.get("critic_warmup", False))
+        (loss * 0.5).backward()  # non-unit upstream gradient, like loss /= grad_accum
+        tag = (p["logprob_type"], p["masked"], p["variant"])
+        torch.testing.assert_close(loss.detach().cpu(), case["loss"], rtol=RTOL, atol=ATOL, msg=lambda m: f"{tag}: {m}")
+        want_glp = case["grad_logprobs"]
+        if want_glp is None:  # critic warm-up: the actor term is a constant
+            assert float(lp.grad.abs().max()) == 0.0
+        else:
+            torch.testing.assert_close(lp.grad.cpu(), 0.5 * want_glp, rtol=RTOL, atol=1e-7, msg=lambda m: f"{tag}: {m}")
+        torch.testing.assert_close(v.grad.cpu(), 0.5 * case["grad_values"], rtol=RTOL, atol=1e-7,
+                                   msg=lambda m: f"{tag}: {m}")
+        o = out.cpu()
+        for k in _METRICS:
+            got, want = float(o[_lib.PPO_OUT_NAMES[k]]), case["metrics"][k]
+            assert got == pytest.approx(want, rel=2e-5, abs=2e-6), (tag, k, got, want)
+        ev = {k.split("/")[-1]: val for k, val in case["metrics"].items() if "explained_variance" in k}
+        for k in O.EV_KEYS:
+            got = float(o[_lib.PPO_OUT_NAMES[f"ev/{k}"]])
+            assert got == pytest.approx(ev[k], rel=2e-5, abs=1e-4), (tag, k)
+
+
+@pytest.mark.parametrize("mb", [8192, 1000, 1])
+def test_ppo_loss_vs_oracle_minibatch_shapes(mb):
+    """The shipped shape: action_level, A = 8, C = 1, no mask (auto_reset) -- against the oracle."""
+    from rlinf_amd import _lib, ops
+    g = torch.Generator().manual_seed(mb)
+    lp = (torch.randn(mb, 8, generator=g) * 0.3 - 1.0)
+    old = lp + torch.randn(mb, 8, generator=g) * 0.05
+    adv = torch.randn(mb, 1, generator=g)
+    v = torch.randn(mb, 1, generator=g)
+    pv = v + torch.randn(mb, 1, generator=g) * 0.7
+    ret = torch.randn(mb, 1, generator=g) * 3
+    lp0, v0 = lp.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    shaped = O.shape_loss_inputs(lp0, old, adv, "action_level", 8, values=v0, prev_values=pv, returns=ret)
+    want, wm = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0,
+                                       max_episode_steps=50, **shaped)
+    want.backward()
+    lp1, v1 = lp.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    loss, out = ops.ppo_loss(lp1, old.cuda(), adv.cuda(), logprob_type="action_level", action_dim=8, clip_ratio_low=0.2,
+                             clip_ratio_high=0.2, values=v1, prev_values=pv.cuda(), returns=ret.cuda(), value_clip=1.0,
+                             huber_delta=10.0, max_episode_steps=50)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), want.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(lp1.grad.cpu(), lp0.grad, rtol=RTOL, atol=1e-8)
+    torch.testing.assert_close(v1.grad.cpu(), v0.grad, rtol=RTOL, atol=1e-8)
+    assert float(out[_lib.PPO_OUT_NAMES["actor/clip_fraction"]]) == pytest.approx(float(wm["actor/clip_fraction"]), abs=1e-6)
+
+
+def test_actor_only_loss_and_all_false_mask():
+    from rlinf_amd import ops
+    g = torch.Generator().manual_seed(4)
+    lp = torch.randn(64, 8, generator=g) * 0.2
+    old = lp + torch.randn(64, 8, generator=g) * 0.05
+    adv = torch.randn(64, 1, generator=g)
+    shaped = O.shape_loss_inputs(lp, old, adv, "action_level", 8)
+    want, _ = O.ppo_actor_loss(shaped["logprobs"], shaped["old_logprobs"], shaped["advantages"], 0.2, 0.28)
+    loss, _ = ops.ppo_loss(lp.cuda(), old.cuda(), adv.cuda(), clip_ratio_low=0.2, clip_ratio_high=0.28, has_critic=False)
+    torch.testing.assert_close(loss.cpu(), want, rtol=RTOL, atol=ATOL)
+    mask = torch.zeros(64, 1, dtype=torch.bool)
+    shaped = O.shape_loss_inputs(lp, old, adv, "action_level", 8, loss_mask=mask)
+    want, wm = O.ppo_actor_loss(shaped["logprobs"], shaped["old_logprobs"], shaped["advantages"], 0.2, 0.2, loss_mask=mask)
+    loss, out = ops.ppo_loss(lp.cuda(), old.cuda(), adv.cuda(), clip_ratio_low=0.2, clip_ratio_high=0.2, has_critic=False,
+                             loss_mask=mask.cuda())
+    assert float(loss) == float(want) == 0.0
+    assert float(out[3]) == float(wm["actor/ratio"]) == 0.0
+    with pytest.raises(AssertionError):
+        ops.ppo_loss(lp.cuda(), old.cuda(), adv.cuda(), clip_ratio_low=0.2, clip_ratio_high=0.2, has_critic=False,
+                     clip_ratio_c=0.9)
+
+
+def test_gather_rows_golden_and_large():
+    from rlinf_amd import ops
+    G = _golden("shuffle.pt")
+    b = G["batch"]
+    fields = [b["rewards"], b["dones"][:-1], b["prev_values"][:-1], b["prev_logprobs"], b["forward_inputs"]["states"],
+              b["forward_inputs"]["action"]]
+    flat = [f.reshape(-1, *f.shape[2:]).contiguous().cuda() for f in fields]
+    outs = ops.gather_rows(flat, G["perm"].cuda())
+    want = [G["out"]["rewards"], G["out"]["dones"], G["out"]["prev_values"], G["out"]["prev_logprobs"],
+            G["out"]["forward_inputs"]["states"], G["out"]["forward_inputs"]["action"]]
+    for o, w in zip(outs, want):
+        assert o.dtype == w.dtype and torch.equal(o.cpu(), w)
+    # the north-star buffer: 131 072 samples, every field of the rollout batch
+    N = 128 * 1024
+    g = torch.Generator().manual_seed(1)
+    big = [torch.randn(N, 42, generator=g), torch.randn(N, 8, generator=g), torch.randn(N, 8, generator=g),
+           torch.randn(N, 1, generator=g), torch.rand(N, 1, generator=g) < 0.5, torch.randn(N, 3, generator=g).to(torch.float16),
+           torch.randint(0, 255, (N, 5), generator=g).to(torch.uint8)]
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1234))
+    outs = ops.gather_rows([t.cuda() for t in big], perm.cuda())
+    for o, t in zip(outs, big):
+        assert torch.equal(o.cpu(), t[perm])
+    # a permutation is invertible: gathering with the inverse restores the buffer
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(N)
+    back = ops.gather_rows(outs, inv.cuda())
+    for o, t in zip(back, big):
+        assert torch.equal(o.cpu(), t)
+    assert ops.gather_rows([torch.zeros(0, 4).cuda()], torch.zeros(0, dtype=torch.int64).cuda())[0].shape == (0, 4)
+
+
+def _flat_from(pol):
+    names, sizes = [], []
+    for n, p in pol.named_parameters():
+        names.append(n)
+        sizes.append(p.numel())
+    return names, sizes
+
+
+@pytest.mark.parametrize("slabs", [1, 3])
+def test_clip_adamw_matches_torch(slabs):
+    from rlinf_amd import ops
+    torch.manual_seed(0)
+    pol = O.OracleMLPPolicy(42, 8, 1)
+    opt = O.build_adamw(pol, lr=3e-4, value_lr=1e-3)
+    names, sizes = _flat_from(pol)
+    n = sum(sizes)
+    assert n == 287504
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cuda()
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    # parameter order: actor_logstd, value_head.*, backbone.*, actor_mean.* -> critic group is one range
+    off, groups, lo = 0, [], None
+    crit = [i for i, nm in enumerate(names) if "value_head" in nm]
+    starts = [sum(sizes[:i]) for i in range(len(sizes))]
+    c0, c1 = starts[crit[0]], starts[crit[-1]] + sizes[crit[-1]]
+    groups = [(0, c0, 3e-4), (c0, c1, 1e-3), (c1, n, 3e-4)]
+    g = torch.Generator().manual_seed(1)
+    for step in range(1, 5):
+        grads = [torch.randn(p.shape, generator=g) * (0.05 if step % 2 else 0.0005) for p in pol.parameters()]
+        for p, gr in zip(pol.parameters(), grads):
+            p.grad = gr.clone()
+        gn = torch.nn.utils.clip_grad_norm_(pol.parameters(), 0.5)
+        opt.step()
+        gflat = torch.cat([gr.reshape(-1) for gr in grads])
+        if slabs > 1:  # split-K slabs that sum to the gradient, plus a 1/world scale
+            parts = torch.randn(slabs - 1, n, generator=g) * 0.01
+            gdev = torch.cat([parts, (gflat * 2.0 - parts.sum(0))[None]], 0).cuda().contiguous()
+            scale = 0.5
+        else:
+            gdev, scale = gflat.cuda().clone(), 1.0
+        stats = ops.clip_adamw_step_(flat, gdev, m, v, groups, step, max_grad_norm=0.5, grad_scale=scale)
+        assert float(stats[0]) == pytest.approx(float(gn), rel=1e-5)
+        assert float(stats[1]) == 1.0
+        want = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+        torch.testing.assert_close(flat.cpu(), want, rtol=1e-5, atol=2e-7)
+    st = opt.state[next(iter(pol.value_head.parameters()))]
+    torch.testing.assert_close(m[c0:c0 + 42 * 256].cpu(), st["exp_avg"].reshape(-1), rtol=1e-5, atol=1e-9)
+    # non-finite gradient norm: the update is skipped (fsdp_model_manager.py:444-449)
+    before = flat.clone()
+    bad = torch.zeros(n, device="cuda")
+    bad[5] = float("inf")
+    stats = ops.clip_adamw_step_(flat, bad, m, v, groups, 5, max_grad_norm=0.5)
+    assert float(stats[1]) == 0.0 and torch.equal(flat, before)
