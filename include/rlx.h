@@ -109,6 +109,12 @@ int rlx_masked_standardize(float* x, const uint8_t* mask, size_t n, float eps,
 int rlx_grpo_group_adv(const float* rewards, const uint8_t* dones, const uint8_t* loss_mask,
                        float* scores, float* advantages, int n_chunk, int batch, int chunk,
                        int group_size, float eps, rlx_stream_t stream);
+/* the group normalisation + broadcast alone (compute_grpo_advantages, advantages.py:107-121) from given scores */
+int rlx_grpo_from_scores(const float* scores, const uint8_t* loss_mask, float* advantages, int n_chunk,
+                         int batch, int chunk, int group_size, float eps, rlx_stream_t stream);
+/* the score scan alone (calculate_scores, rlinf/algorithms/utils.py:134-152): scores [B] f32 out */
+int rlx_episode_scores(const float* rewards, const uint8_t* dones, float* scores, int n_chunk, int batch,
+                       int chunk, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a18-a21  ppo_loss  <- preprocess_loss_inputs (rlinf/algorithms/utils.py:280-376),

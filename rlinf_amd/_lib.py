@@ -82,6 +82,8 @@ PROTOTYPES = {
     "rlx_masked_standardize": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_size_t, c_void_p]),
     "rlx_grpo_group_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_void_p]),
+    "rlx_grpo_from_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rlx_episode_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rlx_ppo_loss_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_ppo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                  POINTER(PpoLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1,0 +1,86 @@
+"""Built-in advantage estimators behind the registry names "gae" and "grpo"
+(mirror of rlinf/algorithms/advantages.py:24-121), served by gae_scan.hip / grpo_adv.hip.
+
+Two entry shapes exist for each name:
+  * the reference's callee contract -- flattened ``[T, B]`` tensors, ``fn(**kwargs) -> (advantages,
+    returns_or_None)`` -- so that a maintainer can re-register these functions inside the real RLinf
+    (rlinf_amd/ext.py) and everything upstream keeps working;
+  * a native ``[n_chunk, B, C]`` path used by ``calculate_adv_and_returns`` here, which skips the
+    transpose/reshape copies entirely.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+from . import utils as _u
+from .registry import _mark_native_adv, register_advantage
+
+
+def _tb(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    return None if t is None else _u.stage(t, dev).contiguous().unsqueeze(-1)
+
+
+@register_advantage("gae")
+def compute_gae_advantages_and_returns(rewards: torch.Tensor, gamma: float = 1.0, gae_lambda: float = 1.0,
+                                       values: Optional[torch.Tensor] = None, normalize_advantages: bool = True,
+                                       normalize_returns: bool = False, loss_mask: Optional[torch.Tensor] = None,
+                                       dones: Optional[torch.Tensor] = None, **kwargs):
+    """rewards [T,B], values [T+1,B] (None = critic-free), dones [T+1,B] bool -> (advantages, returns) [T,B]."""
+    dev = _u.compute_device(rewards, values, dones, loss_mask)
+    adv, ret = ops.gae_scan(_tb(rewards.float(), dev), _tb(values, dev), _tb(dones, dev), _tb(loss_mask, dev),
+                            gamma, gae_lambda, normalize_advantages, normalize_returns,
+                            variant=int(kwargs.get("rlx_variant", 0)))
+    return _u.unstage(adv[..., 0], rewards), _u.unstage(ret[..., 0], rewards)
+
+
+@register_advantage("grpo")
+def compute_grpo_advantages(rewards: torch.Tensor, loss_mask: torch.Tensor, group_size: int, **kwargs):
+    """rewards = per-env scores (any shape with B elements, the reference passes [num_groups, group_size]);
+    loss_mask [T,B] -> (advantages [T,B], None).  advantages.py:89-121."""
+    dev = _u.compute_device(rewards, loss_mask)
+    scores = _u.stage(rewards, dev).float().reshape(-1)
+    mask = _u.stage(loss_mask, dev).contiguous().unsqueeze(-1)
+    adv = ops.grpo_from_scores(scores, mask, int(group_size))
+    return _u.unstage(adv[..., 0], loss_mask), None
+
+
+# ---- native [n_chunk, B, C] paths -------------------------------------------------------------------------
+def _chunk_level(rewards, dones, loss_mask, loss_mask_sum):
+    rewards = rewards.sum(dim=-1, keepdim=True)
+    dones = dones.max(dim=-1, keepdim=True)[0]
+    if loss_mask is not None:
+        loss_mask = loss_mask.max(dim=-1, keepdim=True)[0]
+    if loss_mask_sum is not None:
+        loss_mask_sum = loss_mask_sum.max(dim=-1, keepdim=True)[0]
+    return rewards, dones, loss_mask, loss_mask_sum
+
+
+def _native_gae(*, rewards, dones, values=None, loss_mask=None, loss_mask_sum=None, gamma=1.0, gae_lambda=1.0,
+                reward_type="action_level", normalize_advantages=True, normalize_returns=False, **kwargs):
+    dev = _u.compute_device(rewards, dones, values, loss_mask)
+    r, d, m = _u.stage(rewards, dev), _u.stage(dones, dev), _u.stage(loss_mask, dev)
+    if reward_type == "chunk_level":  # reductions over the chunk dim happen on device views (utils.py:80-89)
+        r, d, m, _ = _chunk_level(r, d, m, None)
+    v = _u.stage(values, dev)
+    adv, ret = ops.gae_scan(r.float(), v, d, m, gamma, gae_lambda, normalize_advantages, normalize_returns,
+                            variant=int(kwargs.get("rlx_variant", 0)))
+    return {"advantages": _u.unstage(adv, rewards), "returns": _u.unstage(ret, rewards)}
+
+
+def _native_grpo(*, rewards, dones, loss_mask=None, group_size=8, reward_type="action_level", **kwargs):
+    if loss_mask is None:
+        raise TypeError("compute_grpo_advantages() missing required argument: 'loss_mask'")
+    dev = _u.compute_device(rewards, dones, loss_mask)
+    r, d, m = _u.stage(rewards, dev), _u.stage(dones, dev), _u.stage(loss_mask, dev)
+    if reward_type == "chunk_level":
+        r, d, m, _ = _chunk_level(r, d, m, None)
+    adv, _ = ops.grpo_group_adv(r.float(), d, m, int(group_size))
+    return {"advantages": _u.unstage(adv, rewards)}
+
+
+_mark_native_adv("gae", _native_gae)
+_mark_native_adv("grpo", _native_grpo)

@@ -1,0 +1,128 @@
+"""Built-in policy losses behind the registry names "actor_critic" and "actor"
+(mirror of rlinf/algorithms/losses.py:170-380,397-425,513-535), served by ppo_loss.hip.
+
+``policy_loss(**kwargs)`` in the reference runs preprocess_loss_inputs, the loss, and then ``.item()``
+on every metric (15 device syncs per micro-batch).  Here the embodied entry takes the RAW kwargs the
+learner builds (rlinf/workers/actor/embodied_fsdp_actor_worker.py:640-662), the kernel fuses the
+shaping, and metrics come back as ONE lazily-read device vector: ``LossMetrics`` behaves like the
+reference's dict (same keys, float values) but performs a single D2H copy, on first read.
+"""
+
+from __future__ import annotations
+
+from collections.abc import Mapping
+from typing import Optional
+
+import torch
+
+from .. import ops
+from .._lib import PPO_OUT_NAMES
+from . import utils as _u
+from .registry import _mark_native_loss, register_policy_loss
+
+# hidden explained-variance keys, named as in rlinf/utils/metric_utils.py (popped by the learner)
+EV_PREFIX = "__sum__/_critic_explained_variance/"
+_EV_MAP = {"ev/count": EV_PREFIX + "count", "ev/returns_sum": EV_PREFIX + "returns_sum",
+           "ev/returns_sq_sum": EV_PREFIX + "returns_sq_sum", "ev/errors_sum": EV_PREFIX + "errors_sum",
+           "ev/errors_sq_sum": EV_PREFIX + "errors_sq_sum"}
+_ACTOR_KEYS = ("actor/policy_loss", "actor/policy_loss_abs", "actor/ratio", "actor/ratio_abs", "actor/clipped_ratio",
+               "actor/dual_cliped_ratio", "actor/approx_kl", "actor/clip_fraction")
+_CRITIC_KEYS = ("critic/value_loss", "critic/value_clip_ratio")
+
+
+class LossMetrics(Mapping):
+    """Read-only metrics dict over the kernel's f32[20] output; one D2H copy on first access."""
+
+    def __init__(self, out: torch.Tensor, has_critic: bool):
+        self.device_vector = out
+        self._keys = list(_ACTOR_KEYS) + (list(_CRITIC_KEYS) + list(_EV_MAP.values()) if has_critic else [])
+        self._host = None
+        self._extra = {}
+
+    def _load(self):
+        if self._host is None:
+            self._host = self.device_vector.tolist()
+        return self._host
+
+    def __getitem__(self, key):
+        if key in self._extra:
+            return self._extra[key]
+        if key not in self._keys:
+            raise KeyError(key)
+        host = self._load()
+        inv = {v: k for k, v in _EV_MAP.items()}
+        return host[PPO_OUT_NAMES[inv.get(key, key)]]
+
+    def __setitem__(self, key, value):  # the learner adds actor/entropy_loss, actor/total_loss
+        self._extra[key] = value
+
+    def pop(self, key, default=None):
+        if key in self._extra:
+            return self._extra.pop(key)
+        if key in self._keys:
+            val = self[key]
+            self._keys.remove(key)
+            return val
+        return default
+
+    def __iter__(self):
+        yield from self._keys
+        yield from self._extra
+
+    def __len__(self):
+        return len(self._keys) + len(self._extra)
+
+
+def _fused(kw: dict, has_critic: bool):
+    logprobs = kw["logprobs"]
+    dev = _u.compute_device(logprobs)
+    st = lambda name: _u.stage(kw.get(name), dev)  # noqa: E731
+    logprob_type = kw.get("logprob_type") or "action_level"
+    action_dim = kw.get("single_action_dim")
+    if action_dim is None:
+        raise TypeError("policy_loss(task_type='embodied') needs single_action_dim")
+    if kw.get("reward_type") == "chunk_level" and logprob_type != "chunk_level":
+        raise NotImplementedError("reward_type='chunk_level' is only fused together with logprob_type='chunk_level'")
+    loss, out = ops.ppo_loss(
+        _u.stage(logprobs, dev), st("old_logprobs"), st("advantages"), logprob_type=logprob_type,
+        action_dim=int(action_dim), clip_ratio_low=kw["clip_ratio_low"], clip_ratio_high=kw["clip_ratio_high"],
+        values=st("values") if has_critic else None, prev_values=st("prev_values") if has_critic else None,
+        returns=st("returns") if has_critic else None, value_clip=kw.get("value_clip"),
+        huber_delta=kw.get("huber_delta"), loss_mask=st("loss_mask"), loss_mask_sum=st("loss_mask_sum"),
+        max_episode_steps=kw.get("max_episode_steps"), clip_ratio_c=kw.get("clip_ratio_c"),
+        clip_log_ratio_min=kw.get("clip_log_ratio_min"), clip_log_ratio_max=kw.get("clip_log_ratio_max"),
+        critic_warmup=bool(kw.get("critic_warmup", False)), has_critic=has_critic)
+    return loss, LossMetrics(out, has_critic)
+
+
+@register_policy_loss("actor_critic")
+def compute_ppo_actor_critic_loss(**kwargs) -> tuple[torch.Tensor, Mapping]:
+    """PPO clipped surrogate + clipped-Huber value loss (losses.py:397-425) on RAW per-dimension inputs."""
+    return _fused(kwargs, has_critic=True)
+
+
+@register_policy_loss("actor")
+def compute_grpo_actor_loss_fn(**kwargs) -> tuple[torch.Tensor, Mapping]:
+    """Actor-only clipped surrogate used by GRPO (losses.py:513-535)."""
+    return _fused(kwargs, has_critic=False)
+
+
+_mark_native_loss("actor_critic", compute_ppo_actor_critic_loss)
+_mark_native_loss("actor", compute_grpo_actor_loss_fn)
+
+
+def explained_variance_from_stats(stats: Mapping) -> float:
+    """metric_utils.py:261-290 on summed sufficient statistics (host scalars)."""
+    n = float(stats[EV_PREFIX + "count"])
+    if n < 2:
+        return float("nan")
+    f32 = lambda x: torch.tensor(float(x), dtype=torch.float32)  # noqa: E731
+    rs, rss = f32(stats[EV_PREFIX + "returns_sum"]), f32(stats[EV_PREFIX + "returns_sq_sum"])
+    es, ess = f32(stats[EV_PREFIX + "errors_sum"]), f32(stats[EV_PREFIX + "errors_sq_sum"])
+    rc = rss - rs * rs / n
+    if torch.isnan(rc) or rc == 0:
+        return float("nan")
+    ec = ess - es * es / n
+    if torch.isnan(ec):
+        return float("nan")
+    return float(1 - ec / rc)

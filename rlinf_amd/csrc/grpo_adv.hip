@@ -94,6 +94,50 @@ __global__ __launch_bounds__(256) void grpo_broadcast(const float* __restrict__ 
 
 using namespace rlx;
 
+static int launch_scores(const float* rewards, const uint8_t* dones, float* scores, int n_chunk, int batch, int chunk,
+                         hipStream_t s) {
+    const int T = n_chunk * chunk;
+    const int groups = ceil_div(batch, 64);
+    int nseg = 1;
+    while (nseg < 8 && groups * nseg < 4 * num_cu() && T / (nseg * 2) >= 8) nseg *= 2;
+    hipLaunchKernelGGL(grpo_scores, dim3(groups), dim3(64 * nseg), nseg > 1 ? (size_t)2 * nseg * 64 * sizeof(float) : 0, s,
+                       rewards, dones, scores, T, batch, chunk);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+static int launch_broadcast(const float* scores, const uint8_t* loss_mask, float* advantages, int n_chunk, int batch,
+                            int chunk, int group_size, float eps, hipStream_t s) {
+    const size_t ncol = (size_t)batch * chunk;
+    const int gx = ceil_div((long long)ncol, 256);
+    int gy = 1;
+    while (gx * gy < 4 * num_cu() && n_chunk / (gy * 2) >= 4) gy *= 2;
+    const int rows = ceil_div(n_chunk, gy);
+    hipLaunchKernelGGL(grpo_broadcast, dim3(gx, ceil_div(n_chunk, rows)), dim3(256), 0, s, scores, loss_mask,
+                       advantages, n_chunk, batch, chunk, group_size, eps, rows);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_grpo_from_scores(const float* scores, const uint8_t* loss_mask, float* advantages, int n_chunk,
+                                    int batch, int chunk, int group_size, float eps, rlx_stream_t stream) {
+    RLX_REQUIRE(n_chunk >= 0 && batch >= 0 && chunk >= 1, "rlx_grpo_from_scores: bad sizes");
+    RLX_REQUIRE(group_size >= 1 && batch % group_size == 0, "rlx_grpo_from_scores: batch %d %% group_size %d != 0", batch,
+                group_size);
+    if (batch == 0 || n_chunk == 0) return RLX_OK;
+    RLX_REQUIRE(scores && loss_mask && advantages, "rlx_grpo_from_scores: NULL argument");
+    return launch_broadcast(scores, loss_mask, advantages, n_chunk, batch, chunk, group_size, eps,
+                            static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rlx_episode_scores(const float* rewards, const uint8_t* dones, float* scores, int n_chunk, int batch,
+                                  int chunk, rlx_stream_t stream) {
+    RLX_REQUIRE(n_chunk >= 0 && batch >= 0 && chunk >= 1, "rlx_episode_scores: bad sizes");
+    if (batch == 0) return RLX_OK;
+    RLX_REQUIRE(scores && (n_chunk == 0 || (rewards && dones)), "rlx_episode_scores: NULL argument");
+    return launch_scores(rewards, dones, scores, n_chunk, batch, chunk, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int rlx_grpo_group_adv(const float* rewards, const uint8_t* dones, const uint8_t* loss_mask, float* scores,
                                   float* advantages, int n_chunk, int batch, int chunk, int group_size, float eps,
                                   rlx_stream_t stream) {
@@ -104,21 +148,7 @@ extern "C" int rlx_grpo_group_adv(const float* rewards, const uint8_t* dones, co
     RLX_REQUIRE(rewards && dones && scores && (n_chunk == 0 || (loss_mask && advantages)),
                 "rlx_grpo_group_adv: NULL argument (a loss mask is required, advantages.py:118)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int T = n_chunk * chunk;
-    const int groups = ceil_div(batch, 64);
-    int nseg = 1;
-    while (nseg < 8 && groups * nseg < 4 * num_cu() && T / (nseg * 2) >= 8) nseg *= 2;
-    hipLaunchKernelGGL(grpo_scores, dim3(groups), dim3(64 * nseg), nseg > 1 ? (size_t)2 * nseg * 64 * sizeof(float) : 0, s,
-                       rewards, dones, scores, T, batch, chunk);
-    RLX_LAUNCH_CHECK();
-    if (n_chunk == 0) return RLX_OK;
-    const size_t ncol = (size_t)batch * chunk;
-    const int gx = ceil_div((long long)ncol, 256);
-    int gy = 1;
-    while (gx * gy < 4 * num_cu() && n_chunk / (gy * 2) >= 4) gy *= 2;
-    const int rows = ceil_div(n_chunk, gy);
-    hipLaunchKernelGGL(grpo_broadcast, dim3(gx, ceil_div(n_chunk, rows)), dim3(256), 0, s, scores, loss_mask,
-                       advantages, n_chunk, batch, chunk, group_size, eps, rows);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
+    const int rc = launch_scores(rewards, dones, scores, n_chunk, batch, chunk, s);
+    if (rc != RLX_OK || n_chunk == 0) return rc;
+    return launch_broadcast(scores, loss_mask, advantages, n_chunk, batch, chunk, group_size, eps, s);
 }

@@ -1,0 +1,58 @@
+"""Process hook for a real RLinf install: ``RLINF_EXT_MODULE=rlinf_amd.ext``.
+
+RLinf imports the module named by that environment variable in every worker process and calls its
+``register()`` once (rlinf/scheduler/cluster/utils.py:81-110, invoked from Worker._env_setup_before_init,
+rlinf/scheduler/worker/worker.py:348-394).  ``register()`` re-registers the hot-path names in RLinf's own
+registries -- the last registration wins (rlinf/algorithms/registry.py:33-53) -- so the unmodified
+learner (rlinf/workers/actor/embodied_fsdp_actor_worker.py:286-321,591-700) calls the HIP kernels.
+
+Because RLinf's ``policy_loss`` runs preprocess_loss_inputs BEFORE the registered callee and ``.item()``s
+every metric after it, the callees registered here take the already-shaped tensors (sub_per_adv == raw
+== 1 per element) and return plain tensors, exactly what that caller expects.
+"""
+
+from __future__ import annotations
+
+
+def register() -> None:
+    import torch
+    from rlinf.algorithms import registry as ref_registry  # the REAL package; ImportError is logged by RLinf
+
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_NAMES
+    from rlinf_amd.algorithms import advantages as adv
+    from rlinf_amd.algorithms import utils as u
+    from rlinf_amd.algorithms.losses import _ACTOR_KEYS, _CRITIC_KEYS, _EV_MAP
+
+    ref_registry.register_advantage("gae")(adv.compute_gae_advantages_and_returns)
+    ref_registry.register_advantage("grpo")(adv.compute_grpo_advantages)
+
+    def _shaped_loss(has_critic):
+        def fn(logprobs, old_logprobs, advantages, clip_ratio_low, clip_ratio_high, **kw):
+            dev = u.compute_device(logprobs)
+            per_adv = logprobs.numel() // max(advantages.numel(), 1)  # token_level keeps the action dim
+            st = lambda t: None if t is None else u.stage(t, dev).contiguous()  # noqa: E731
+            loss, out = ops.ppo_loss(
+                st(logprobs).reshape(advantages.numel(), per_adv), st(old_logprobs).reshape(advantages.numel(), per_adv),
+                st(advantages), logprob_type="token_level" if per_adv > 1 else "action_level", action_dim=per_adv,
+                clip_ratio_low=clip_ratio_low, clip_ratio_high=clip_ratio_high,
+                values=st(kw.get("values")) if has_critic else None,
+                prev_values=st(kw.get("prev_values")) if has_critic else None,
+                returns=st(kw.get("returns")) if has_critic else None, value_clip=kw.get("value_clip"),
+                huber_delta=kw.get("huber_delta"), loss_mask=st(kw.get("loss_mask")),
+                loss_mask_sum=st(kw.get("loss_mask_sum")), max_episode_steps=kw.get("max_episode_steps"),
+                clip_ratio_c=kw.get("clip_ratio_c"), clip_log_ratio_min=kw.get("clip_log_ratio_min"),
+                clip_log_ratio_max=kw.get("clip_log_ratio_max"), critic_warmup=bool(kw.get("critic_warmup", False)),
+                has_critic=has_critic)
+            keys = list(_ACTOR_KEYS) + (list(_CRITIC_KEYS) if has_critic else [])
+            metrics = {k: out[PPO_OUT_NAMES[k]] for k in keys}
+            if has_critic:
+                metrics.update({v: out[PPO_OUT_NAMES[k]] for k, v in _EV_MAP.items()})
+            return loss, metrics
+
+        return fn
+
+    ref_registry.register_policy_loss("actor_critic")(_shaped_loss(True))
+    ref_registry.register_policy_loss("actor")(_shaped_loss(False))
+    if not torch.cuda.is_available():
+        raise RuntimeError("rlinf_amd.ext registered HIP kernels but no HIP device is visible")

@@ -148,6 +148,38 @@ def grpo_group_adv(rewards: torch.Tensor, dones: torch.Tensor, loss_mask: torch.
     return adv, scores
 
 
+def grpo_from_scores(scores: torch.Tensor, loss_mask: torch.Tensor, group_size: int, eps: float = 1e-6) -> torch.Tensor:
+    """scores [B] f32, loss_mask [n,B,C] -> advantages [n,B,C] (advantages.py:107-121)."""
+    lib = _lib.load()
+    dev = _dev(scores, loss_mask)
+    n, B, C = _nbc(loss_mask, "loss_mask")
+    sc = _as_f32(scores.reshape(-1), "scores")
+    if sc.numel() != B or group_size < 1 or B % group_size != 0:
+        raise RlxError(f"scores must have {B} elements and batch must divide by group_size={group_size}")
+    m8 = _as_u8(loss_mask)
+    adv = torch.empty((n, B, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_grpo_from_scores(sc.data_ptr(), m8.data_ptr(), adv.data_ptr(), n, B, C, int(group_size),
+                                            float(eps), _stream_ptr(dev)), "rlx_grpo_from_scores")
+    return adv
+
+
+def episode_scores(rewards: torch.Tensor, dones: torch.Tensor) -> torch.Tensor:
+    """rewards [n,B,C], dones [n+1,B,C] -> per-env first-episode return [B] (utils.py:134-152)."""
+    lib = _lib.load()
+    dev = _dev(rewards, dones)
+    n, B, C = _nbc(rewards, "rewards")
+    r = _as_f32(rewards, "rewards")
+    d8 = _as_u8(dones)
+    if tuple(d8.shape) != (n + 1, B, C):
+        raise RlxError("dones must be [n+1,B,C]")
+    scores = torch.empty((B,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_episode_scores(r.data_ptr(), d8.data_ptr(), scores.data_ptr(), n, B, C, _stream_ptr(dev)),
+                   "rlx_episode_scores")
+    return scores
+
+
 # --------------------------------------------------------------------------------------------
 # a18-a21  fused PPO loss (forward + backward) as an autograd node
 # --------------------------------------------------------------------------------------------
