@@ -231,6 +231,55 @@ int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_
                         const rlx_adamw_params* p, float* stats, void* workspace, size_t workspace_bytes,
                         rlx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a1-a5, a17  MLP policy  <- MLPPolicy, rlinf/models/embodiment/mlp_policy/mlp_policy.py:91-107 (modules),
+ *     :238-293 (_sample_actions/_generate_actions), :295-320 (predict_action_batch), :202-236 (default_forward),
+ *     ValueHead rlinf/models/embodiment/modules/value_head.py:17-66, Normal.log_prob/entropy (torch).
+ * PPO configuration only: tanh MLPs obs->256->256->256, state-independent log-std, no tanh squashing.
+ * All parameters live in ONE flat f32 buffer in the reference's named_parameters() order; `rlx_mlp_layout`
+ * holds the element offsets.  Dense layers run on the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact f32
+ * products, f32 accumulate); heads, sampling, log-prob and entropy are fused epilogues.
+ *   net 0 = value head (value_head.mlp.{0,2,4,6}), net 1 = actor (backbone.{0,2,4} + actor_mean)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rlx_mlp_layout {
+    int32_t obs_dim;      /* D (42) */
+    int32_t act_dim;      /* num_action_chunks * action_dim (8) */
+    int32_t val_dim;      /* value head outputs (num_action_chunks, 1) */
+    int32_t hidden;       /* must be 256 */
+    int64_t n_params;     /* total elements of the flat buffer */
+    int64_t off_logstd;   /* actor_logstd [1, act_dim] */
+    int64_t off_w[2][4];  /* [net][layer] weight, row-major [out, in] */
+    int64_t off_b[2][4];  /* [net][layer] bias, or -1 (value head's last layer has none) */
+} rlx_mlp_layout;
+
+/* Derived weight images (zero-padded first layers, transposed hidden layers) the kernels consume;
+ * rebuild after every optimizer step.  packed: rlx_mlp_packed_bytes() bytes. */
+size_t rlx_mlp_packed_bytes(const rlx_mlp_layout* layout);
+int rlx_mlp_pack(const float* params, const rlx_mlp_layout* layout, float* packed, rlx_stream_t stream);
+
+/* Rollout: obs-preprocess is the identity on `states` (mlp_policy.py:122-124); one fused launch computes
+ *   mean, value, action = eps * exp(logstd) + mean (eps == NULL: eval mode, action = mean),
+ *   logprob = Normal(mean, std).log_prob(action) per dimension.
+ *   states [M, D], eps [M, act_dim] -> action [M, act_dim], logprob [M, act_dim], value [M, val_dim] */
+int rlx_mlp_rollout(const float* params, const float* packed, const rlx_mlp_layout* layout, const float* states,
+                    const float* eps, int64_t m, float* action, float* logprob, float* value, rlx_stream_t stream);
+
+/* Training forward on stored (states, action): logprob, entropy [M, act_dim], value [M, val_dim]; keeps what
+ * backward needs: mean [M, act_dim] and the six hidden activations acts [2][3][M][256]. */
+int rlx_mlp_train_fwd(const float* params, const float* packed, const rlx_mlp_layout* layout, const float* states,
+                      const float* action, int64_t m, float* logprob, float* entropy, float* value, float* mean,
+                      float* acts, rlx_stream_t stream);
+
+/* Training backward: from d_logprob, d_value (and optionally d_entropy) to parameter gradients.
+ *   grads: [slabs][n_params] f32 split-K slabs, every element written (summed by rlx_clip_adamw_step).
+ *   workspace: rlx_mlp_bwd_workspace_bytes(layout, m) bytes. */
+int rlx_mlp_bwd_slabs(int64_t m);
+size_t rlx_mlp_bwd_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);
+int rlx_mlp_train_bwd(const float* params, const float* packed, const rlx_mlp_layout* layout, const float* states,
+                      const float* action, const float* mean, const float* acts, const float* d_logprob,
+                      const float* d_entropy, const float* d_value, int64_t m, float* grads, int slabs,
+                      void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

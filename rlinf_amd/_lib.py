@@ -61,6 +61,14 @@ class AdamwParams(Structure):
     ]
 
 
+class MlpLayout(Structure):
+    _fields_ = [
+        ("obs_dim", c_int32), ("act_dim", c_int32), ("val_dim", c_int32), ("hidden", c_int32),
+        ("n_params", c_int64), ("off_logstd", c_int64),
+        ("off_w", (c_int64 * 4) * 2), ("off_b", (c_int64 * 4) * 2),
+    ]
+
+
 PPO_OUT_FLOATS = 20
 PPO_OUT_NAMES = {
     "loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, "actor/ratio": 3, "actor/ratio_abs": 4,
@@ -89,6 +97,16 @@ PROTOTYPES = {
                                  POINTER(PpoLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rlx_ppo_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                  c_void_p]),
+    "rlx_mlp_packed_bytes": (c_size_t, [POINTER(MlpLayout)]),
+    "rlx_mlp_pack": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
+    "rlx_mlp_rollout": (c_int, [c_void_p, c_void_p, POINTER(MlpLayout), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "rlx_mlp_train_fwd": (c_int, [c_void_p, c_void_p, POINTER(MlpLayout), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rlx_mlp_bwd_slabs": (c_int, [c_int64]),
+    "rlx_mlp_bwd_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),
+    "rlx_mlp_train_bwd": (c_int, [c_void_p, c_void_p, POINTER(MlpLayout), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "rlx_gather_rows": (c_int, [POINTER(GatherField), c_int, c_void_p, c_int64, c_void_p]),
     "rlx_adamw_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamwParams), c_void_p,

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AdamwGroup, AdamwParams, GaeParams, GatherField, PpoLossParams, RlxError
+from ._lib import AdamwGroup, AdamwParams, GaeParams, GatherField, MlpLayout, PpoLossParams, RlxError
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -374,3 +374,86 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
                                            byref(p), stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(dev)),
                    "rlx_clip_adamw_step")
     return stats
+
+
+# --------------------------------------------------------------------------------------------
+# a1-a5, a17  MLP policy kernels (flat parameter buffer + layout descriptor)
+# --------------------------------------------------------------------------------------------
+def mlp_pack(params: torch.Tensor, layout: MlpLayout, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    dev = _dev(params)
+    nbytes = lib.rlx_mlp_packed_bytes(byref(layout))
+    if packed is None:
+        packed = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_pack(params.data_ptr(), byref(layout), packed.data_ptr(), _stream_ptr(dev)), "rlx_mlp_pack")
+    return packed
+
+
+def mlp_rollout(params: torch.Tensor, packed: torch.Tensor, layout: MlpLayout, states: torch.Tensor,
+                eps: Optional[torch.Tensor]):
+    """states [M,D], eps [M,act]|None -> (action [M,act], logprob [M,act], value [M,val])."""
+    lib = _lib.load()
+    dev = _dev(params, packed, states, eps)
+    st = _as_f32(states, "states")
+    M = st.shape[0]
+    if st.dim() != 2 or st.shape[1] != layout.obs_dim:
+        raise RlxError(f"states must be [M, {layout.obs_dim}], got {tuple(st.shape)}")
+    e = _as_f32(eps, "eps")
+    if e is not None and tuple(e.shape) != (M, layout.act_dim):
+        raise RlxError(f"eps must be [{M}, {layout.act_dim}]")
+    action = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
+    logprob = torch.empty_like(action)
+    value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_rollout(params.data_ptr(), packed.data_ptr(), byref(layout), st.data_ptr(), _ptr(e), M,
+                                       action.data_ptr(), logprob.data_ptr(), value.data_ptr(), _stream_ptr(dev)),
+                   "rlx_mlp_rollout")
+    return action, logprob, value
+
+
+def mlp_train_fwd(params, packed, layout: MlpLayout, states, action, acts: Optional[torch.Tensor] = None):
+    """-> (logprob, entropy [M,act], value [M,val], mean [M,act], acts [2,3,M,256])."""
+    lib = _lib.load()
+    dev = _dev(params, packed, states, action)
+    st, ac = _as_f32(states, "states"), _as_f32(action, "action")
+    M = st.shape[0]
+    if tuple(ac.shape) != (M, layout.act_dim):
+        raise RlxError(f"action must be [{M}, {layout.act_dim}], got {tuple(ac.shape)}")
+    logprob = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
+    entropy = torch.empty_like(logprob)
+    mean = torch.empty_like(logprob)
+    value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
+    if acts is None or acts.numel() != 6 * M * 256:
+        acts = torch.empty((2, 3, M, 256), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_train_fwd(params.data_ptr(), packed.data_ptr(), byref(layout), st.data_ptr(), ac.data_ptr(), M,
+                                         logprob.data_ptr(), entropy.data_ptr(), value.data_ptr(), mean.data_ptr(),
+                                         acts.data_ptr(), _stream_ptr(dev)), "rlx_mlp_train_fwd")
+    return logprob, entropy, value, mean, acts
+
+
+def mlp_bwd_slabs(m: int) -> int:
+    return _lib.load().rlx_mlp_bwd_slabs(int(m))
+
+
+def mlp_train_bwd(params, packed, layout: MlpLayout, states, action, mean, acts, d_logprob, d_entropy, d_value,
+                  grads: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
+    """-> grads [slabs, n_params] (split-K slabs; every element written)."""
+    lib = _lib.load()
+    dev = _dev(params, packed, states, action, mean, acts, d_logprob, d_entropy, d_value)
+    M = states.shape[0]
+    slabs = lib.rlx_mlp_bwd_slabs(M) if grads is None else grads.shape[0]
+    if grads is None:
+        grads = torch.empty((slabs, layout.n_params), dtype=torch.float32, device=dev)
+    ws_bytes = lib.rlx_mlp_bwd_workspace_bytes(byref(layout), M)
+    if workspace is None or workspace.numel() < ws_bytes:
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    dl, dv = _as_f32(d_logprob, "d_logprob"), _as_f32(d_value, "d_value")
+    de = _as_f32(d_entropy, "d_entropy")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_train_bwd(params.data_ptr(), packed.data_ptr(), byref(layout), states.data_ptr(),
+                                         action.data_ptr(), mean.data_ptr(), acts.data_ptr(), dl.data_ptr(), _ptr(de),
+                                         dv.data_ptr(), M, grads.data_ptr(), slabs, workspace.data_ptr(),
+                                         workspace.numel(), _stream_ptr(dev)), "rlx_mlp_train_bwd")
+    return grads
