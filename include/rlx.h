@@ -227,9 +227,23 @@ typedef struct rlx_adamw_params {
     rlx_adamw_group groups[RLX_ADAMW_MAX_GROUPS];
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);
+/* out[i] = sum_k grads[k][i] (k < slabs): collapse the split-K slabs before a data-parallel all-reduce. */
+int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* out, rlx_stream_t stream);
+
+/* step_state: NULL (use p->step) or device int32[2] = {steps applied, pending flag}; the kernels then keep the
+ * step count on the device (t = state[0] + 1, advanced only when the update was applied), which makes a
+ * captured hipGraph of the update loop replayable.  Initialise it to {0, 0}. */
 int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                        const rlx_adamw_params* p, float* stats, void* workspace, size_t workspace_bytes,
-                        rlx_stream_t stream);
+                        const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace,
+                        size_t workspace_bytes, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a6  bootstrap_rewards  <- EnvWorker.compute_bootstrap_rewards, rlinf/workers/env/env_worker.py:718-758
+ *   rewards [B, C] f32 (in place): rewards[b, C-1] += gamma * bootstrap_values[b, 0] where flags[b, C-1]
+ *   (flags = dones for bootstrap_type "always", truncations for "standard").
+ * ------------------------------------------------------------------------------------------ */
+int rlx_bootstrap_rewards(float* rewards, const uint8_t* flags, const float* bootstrap_values, int batch, int chunk,
+                          int value_stride, float gamma, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a1-a5, a17  MLP policy  <- MLPPolicy, rlinf/models/embodiment/mlp_policy/mlp_policy.py:91-107 (modules),
@@ -263,6 +277,10 @@ int rlx_mlp_pack(const float* params, const rlx_mlp_layout* layout, float* packe
  *   states [M, D], eps [M, act_dim] -> action [M, act_dim], logprob [M, act_dim], value [M, val_dim] */
 int rlx_mlp_rollout(const float* params, const float* packed, const rlx_mlp_layout* layout, const float* states,
                     const float* eps, int64_t m, float* action, float* logprob, float* value, rlx_stream_t stream);
+
+/* Value head only (get_bootstrap_values, rlinf/workers/rollout/hf/huggingface_worker.py:612-627): value [M, val_dim]. */
+int rlx_mlp_value(const float* params, const float* packed, const rlx_mlp_layout* layout, const float* states, int64_t m,
+                  float* value, rlx_stream_t stream);
 
 /* Training forward on stored (states, action): logprob, entropy [M, act_dim], value [M, val_dim]; keeps what
  * backward needs: mean [M, act_dim] and the six hidden activations acts [2][3][M][256]. */

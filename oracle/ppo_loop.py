@@ -1,0 +1,116 @@
+"""CPU oracle of ONE embodied PPO iteration (rollout -> advantages -> update), sync mode.  TEST INFRASTRUCTURE.
+
+Restates the control flow of the reference's hot loops with the oracle arithmetic of ppo_oracle.py:
+  rollout        EnvWorker._run_interact_once, rlinf/workers/env/env_worker.py:1058-1306 (row alignment A.1),
+                 MultiStepRolloutWorker.generate_one_epoch, rlinf/workers/rollout/hf/huggingface_worker.py:677-800,
+                 bootstrap on auto-reset (env_worker.py:718-758, huggingface_worker.py:612-627)
+  advantages     EmbodiedFSDPActor.compute_advantages_and_returns, workers/actor/embodied_fsdp_actor_worker.py:286-321
+  update         EmbodiedFSDPActor.run_training, :483-589 (one randperm per call, re-chunked every epoch)
+The simulator is replaced by the same pre-generated tensors the product's synthetic env uses.
+Used by tests/ (end-to-end parity at small sizes) and by bench.py's cpu_baseline leg; never by rlinf_amd/.
+"""
+
+from __future__ import annotations
+
+import time
+
+import torch
+
+from . import ppo_oracle as O
+
+
+def synthetic_env_tensors(seed: int, T: int, B: int, obs_dim: int = 42, max_episode_steps: int = 50,
+                          mode: str = "periodic", p_done: float = 0.02):
+    """obs [T+1,B,D] ~ N(0,1), final_obs [T,B,D] ~ N(0,1), rewards [T,B] ~ U(0,1),
+    dones [T+1,B] (row 0 False): 'periodic' = truncation every max_episode_steps (auto-reset), or Bernoulli(p)."""
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(T + 1, B, obs_dim, generator=g)
+    final_obs = torch.randn(T, B, obs_dim, generator=g)
+    rewards = torch.rand(T, B, generator=g)
+    if mode == "periodic":
+        dones = torch.zeros(T + 1, B, dtype=torch.bool)
+        for t in range(1, T + 1):
+            if t % max_episode_steps == 0:
+                dones[t] = True
+    else:
+        dones = torch.rand(T + 1, B, generator=g) < p_done
+        dones[0] = False
+    return dict(obs=obs, final_obs=final_obs, rewards=rewards, dones=dones)
+
+
+def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: float, auto_reset: bool = True):
+    """-> batch dict in the reference's buffer shapes ([T,...] / [T+1,...] with C = 1)."""
+    T, B = env["rewards"].shape
+    A = policy.action_dim * policy.num_action_chunks
+    states = torch.empty(T, B, policy.obs_dim)
+    action = torch.empty(T, B, A)
+    logp = torch.empty(T, B, A)
+    values = torch.empty(T + 1, B, 1)
+    rewards = torch.empty(T, B, 1)
+    dones = torch.zeros(T + 1, B, 1, dtype=torch.bool)
+    obs = env["obs"][0]
+    for t in range(T):
+        a, lp, v = policy.act(obs, eps=eps[t], mode="train")
+        states[t], action[t], logp[t], values[t] = obs, a, lp, v
+        r = env["rewards"][t].clone().unsqueeze(-1)
+        d = env["dones"][t + 1].unsqueeze(-1)
+        if auto_reset and bool(d.any()):
+            vf = policy.value_head.mlp(env["final_obs"][t]).detach()[:, :1]
+            r = O.bootstrap_rewards(r, d, vf, gamma)
+        rewards[t], dones[t + 1] = r, d
+        obs = env["obs"][t + 1]
+    values[T] = policy.value_head.mlp(obs).detach()
+    return dict(rewards=rewards, dones=dones, prev_values=values, prev_logprobs=logp,
+                forward_inputs=dict(states=states, action=action))
+
+
+def advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = True):
+    lm = lms = None
+    if not auto_reset:  # embodied_fsdp_actor_worker.py:219-233
+        lm, lms = O.loss_mask_from_dones(batch["dones"])
+    out = O.embodied_adv_and_returns(adv_type="gae", rewards=batch["rewards"], dones=batch["dones"],
+                                     values=batch["prev_values"], gamma=gamma, gae_lambda=gae_lambda, loss_mask=lm,
+                                     loss_mask_sum=lms)
+    batch = dict(batch)
+    batch.update(advantages=out["advantages"].contiguous(), returns=out["returns"].contiguous())
+    if lm is not None:
+        batch.update(loss_mask=lm.contiguous(), loss_mask_sum=lms.contiguous())
+    return batch
+
+
+def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
+           value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None):
+    T, B = batch["prev_logprobs"].shape[:2]
+    perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
+    flat = O.flatten_and_shuffle(batch, perm)
+    n_mb = (T * B) // global_batch
+    assert (T * B) % global_batch == 0
+    metrics, steps = [], 0
+    for _ in range(update_epoch):
+        for mb in O.chunk_batch(flat, n_mb):
+            m = O.ppo_minibatch_step(
+                policy, opt, dict(states=mb["forward_inputs"]["states"], action=mb["forward_inputs"]["action"],
+                                  prev_logprobs=mb["prev_logprobs"], advantages=mb["advantages"],
+                                  prev_values=mb["prev_values"], returns=mb["returns"], loss_mask=mb.get("loss_mask")),
+                clip_low=clip_low, clip_high=clip_high, value_clip=value_clip, huber_delta=huber_delta,
+                clip_grad=clip_grad, action_dim=policy.action_dim)
+            metrics.append(m)
+            steps += 1
+            if max_steps is not None and steps >= max_steps:
+                return metrics
+    return metrics
+
+
+def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
+              max_update_steps=None, timings=None):
+    t0 = time.perf_counter()
+    batch = rollout(policy, env, eps, gamma, auto_reset)
+    t1 = time.perf_counter()
+    batch = advantages(batch, gamma, gae_lambda, auto_reset)
+    t2 = time.perf_counter()
+    metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
+                     max_steps=max_update_steps)
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))
+    return batch, metrics

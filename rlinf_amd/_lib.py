@@ -101,6 +101,7 @@ PROTOTYPES = {
     "rlx_mlp_pack": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
     "rlx_mlp_rollout": (c_int, [c_void_p, c_void_p, POINTER(MlpLayout), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    "rlx_mlp_value": (c_int, [c_void_p, c_void_p, POINTER(MlpLayout), c_void_p, c_int64, c_void_p, c_void_p]),
     "rlx_mlp_train_fwd": (c_int, [c_void_p, c_void_p, POINTER(MlpLayout), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_mlp_bwd_slabs": (c_int, [c_int64]),
@@ -109,8 +110,10 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "rlx_gather_rows": (c_int, [POINTER(GatherField), c_int, c_void_p, c_int64, c_void_p]),
     "rlx_adamw_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_sum_slabs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rlx_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamwParams), c_void_p,
-                                    c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rlx_bootstrap_rewards": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
 }
 
 _lib = None

@@ -18,9 +18,16 @@ namespace {
 
 constexpr int kMaxParts = 1024;
 
+// state (device, int32[2]): [0] = optimizer steps applied so far, [1] = "the previous call applied a step"
+// (folded into [0] here, i.e. strictly after that call's update kernel and before this call's), so that a
+// captured hipGraph can be replayed without host-side step bookkeeping.
 __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ grads, long long n, int nslab, float scale,
-                                                          double* __restrict__ partials) {
+                                                          double* __restrict__ partials, int* __restrict__ state) {
     __shared__ double s_red[4];
+    if (state != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && state[1] != 0) {
+        state[0] += 1;
+        state[1] = 0;
+    }
     double acc[1] = {0.0};
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ gr
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, rlx_adamw_params a,
                                                          const double* __restrict__ partials, int nparts,
-                                                         float* __restrict__ stats) {
+                                                         float* __restrict__ stats, int* __restrict__ state) {
     __shared__ double s_red[4];
     __shared__ float s_coef;
     __shared__ int s_skip;
@@ -53,14 +60,16 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         if (blockIdx.x == 0) {
             stats[0] = total_norm;
             stats[1] = s_skip ? 0.f : 1.f;
+            if (state != nullptr) state[1] = s_skip ? 0 : 1;
         }
     }
     __syncthreads();
     const float coef = s_coef;
     const bool skip = s_skip != 0;
     // bias corrections in double, like torch's python scalars
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)a.step);
-    const double bc2 = 1.0 - pow((double)a.beta2, (double)a.step);
+    const int step = state != nullptr ? state[0] + 1 : a.step;  // state[0] is stable for the whole launch
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)a.beta2, (double)step);
     const float bc2_sqrt = (float)sqrt(bc2);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -88,6 +97,15 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
     }
 }
 
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ g, long long n, int nslab, float* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float s = g[i];
+        for (int k = 1; k < nslab; ++k) s += g[(long long)k * n + i];
+        out[i] = s;
+    }
+}
+
 int grid_for(long long n) {
     return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, std::min<long long>(kMaxParts, (long long)num_cu() * 4)));
 }
@@ -102,11 +120,21 @@ extern "C" size_t rlx_adamw_workspace_bytes(int64_t n) {
     return (size_t)kMaxParts * sizeof(double);
 }
 
+extern "C" int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* out, rlx_stream_t stream) {
+    RLX_REQUIRE(n >= 0 && slabs >= 1, "rlx_sum_slabs: bad sizes");
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(grads && out, "rlx_sum_slabs: NULL argument");
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), grads, (long long)n,
+                       slabs, out);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
 extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                   const rlx_adamw_params* p, float* stats, void* workspace, size_t workspace_bytes,
-                                   rlx_stream_t stream) {
+                                   const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace,
+                                   size_t workspace_bytes, rlx_stream_t stream) {
     RLX_REQUIRE(p != nullptr, "rlx_clip_adamw_step: NULL params struct");
-    RLX_REQUIRE(n >= 0 && p->step >= 1 && p->n_groups >= 0 && p->n_groups <= RLX_ADAMW_MAX_GROUPS && p->grad_partials >= 1,
+    RLX_REQUIRE(n >= 0 && (p->step >= 1 || step_state != nullptr) && p->n_groups >= 0 && p->n_groups <= RLX_ADAMW_MAX_GROUPS && p->grad_partials >= 1,
                 "rlx_clip_adamw_step: bad sizes (n=%lld step=%d groups=%d slabs=%d)", (long long)n, p->step, p->n_groups,
                 p->grad_partials);
     if (n == 0) return RLX_OK;
@@ -122,10 +150,10 @@ extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, 
     double* partials = static_cast<double*>(workspace);
     const int nblk = grid_for(n);
     hipLaunchKernelGGL(grad_reduce_sqnorm, dim3(nblk), dim3(256), 0, s, grads, (long long)n, p->grad_partials, p->grad_scale,
-                       partials);
+                       partials, step_state);
     RLX_LAUNCH_CHECK();
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblk), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long long)n, *p,
-                       partials, nblk, stats);
+                       partials, nblk, stats, step_state);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -42,10 +42,30 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
     else gather_field<uint8_t>(fd, a.index, a.n_rows);
 }
 
+// a6: r[b, C-1] += gamma * V(final_obs)[b] where the env finished (env_worker.py:744-758)
+__global__ __launch_bounds__(256) void bootstrap_rewards_kernel(float* __restrict__ r, const uint8_t* __restrict__ flags,
+                                                                const float* __restrict__ v, int B, int C, int vs, float gamma) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t i = (size_t)b * C + (C - 1);
+    if (flags[i]) r[i] = fadd(r[i], fmul(gamma, v[(size_t)b * vs]));
+}
+
 }  // namespace
 }  // namespace rlx
 
 using namespace rlx;
+
+extern "C" int rlx_bootstrap_rewards(float* rewards, const uint8_t* flags, const float* bootstrap_values, int batch, int chunk,
+                                     int value_stride, float gamma, rlx_stream_t stream) {
+    RLX_REQUIRE(batch >= 0 && chunk >= 1 && value_stride >= 1, "rlx_bootstrap_rewards: bad sizes");
+    if (batch == 0) return RLX_OK;
+    RLX_REQUIRE(rewards && flags && bootstrap_values, "rlx_bootstrap_rewards: NULL argument");
+    hipLaunchKernelGGL(bootstrap_rewards_kernel, dim3(ceil_div(batch, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       rewards, flags, bootstrap_values, batch, chunk, value_stride, gamma);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
 
 extern "C" int rlx_gather_rows(const rlx_gather_field* fields, int n_fields, const int64_t* index, int64_t n_rows,
                                rlx_stream_t stream) {

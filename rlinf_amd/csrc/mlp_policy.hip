@@ -510,9 +510,16 @@ int check_layout(const rlx_mlp_layout* lay, const char* who) {
     return RLX_OK;
 }
 
+// once per kernel and process (not a stream operation: keep it out of hipGraph capture regions)
 template <typename K>
 int set_lds(K kern, size_t bytes) {
-    RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static thread_local const void* done[8] = {};
+    const void* key = reinterpret_cast<const void*>(kern);
+    for (const void* d : done)
+        if (d == key) return RLX_OK;
+    RLX_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    for (auto& d : done)
+        if (d == nullptr) { d = key; break; }
     return RLX_OK;
 }
 
@@ -547,6 +554,21 @@ extern "C" int rlx_mlp_rollout(const float* params, const float* packed, const r
     a.params = params; a.packed = packed; a.lay = *lay; a.states = states; a.eps = eps; a.M = m;
     a.out_action = action; a.out_logprob = logprob; a.out_value = value;
     hipLaunchKernelGGL(mlp_fwd_kernel<0>, dim3(ceil_div(m, BM), 2), dim3(256), FWD_LDS, static_cast<hipStream_t>(stream), a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_mlp_value(const float* params, const float* packed, const rlx_mlp_layout* lay, const float* states, int64_t m,
+                             float* value, rlx_stream_t stream) {
+    if (int rc = check_layout(lay, "rlx_mlp_value")) return rc;
+    RLX_REQUIRE(m >= 0, "rlx_mlp_value: negative batch");
+    if (m == 0) return RLX_OK;
+    RLX_REQUIRE(params && packed && states && value, "rlx_mlp_value: NULL argument");
+    if (int rc = set_lds(mlp_fwd_kernel<0>, FWD_LDS)) return rc;
+    FwdArgs a{};
+    a.params = params; a.packed = packed; a.lay = *lay; a.states = states; a.M = m; a.out_value = value;
+    // gridDim.y == 1: only net 0 (the value head) runs
+    hipLaunchKernelGGL(mlp_fwd_kernel<0>, dim3(ceil_div(m, BM), 1), dim3(256), FWD_LDS, static_cast<hipStream_t>(stream), a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

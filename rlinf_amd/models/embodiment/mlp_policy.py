@@ -57,7 +57,7 @@ class _MlpTrainFn(torch.autograd.Function):
                                   zl(d_logprob, (M, pol.layout.act_dim)).contiguous(),
                                   None if d_entropy is None else d_entropy.contiguous(),
                                   zl(d_value, (M, pol.layout.val_dim)).contiguous())
-        return grads.sum(dim=0), None, None, None
+        return ops.sum_slabs(grads), None, None, None
 
 
 class MLPPolicy(nn.Module):

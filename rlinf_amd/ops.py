@@ -81,7 +81,7 @@ def done_prefix_mask(dones: torch.Tensor):
 def gae_scan(rewards: torch.Tensor, values: Optional[torch.Tensor], dones: torch.Tensor,
              loss_mask: Optional[torch.Tensor] = None, gamma: float = 1.0, gae_lambda: float = 1.0,
              normalize_advantages: bool = True, normalize_returns: bool = False, norm_eps: float = 1e-5,
-             variant: int = 0):
+             variant: int = 0, out: Optional[tuple] = None):
     """rewards [n,B,C] f32, values [n+1,B,C] f32|None, dones [n+1,B,C] bool -> (adv, ret) [n,B,C].  a10-a12."""
     lib = _lib.load()
     dev = _dev(rewards, values, dones, loss_mask)
@@ -98,8 +98,13 @@ def gae_scan(rewards: torch.Tensor, values: Optional[torch.Tensor], dones: torch
         raise RlxError(f"loss_mask must be {(n, B, C)}, got {tuple(m8.shape)}")
     if v is None:  # critic-free: the reference forces gamma = lambda = 1 (advantages.py:61-64)
         gamma, gae_lambda = 1.0, 1.0
-    adv = torch.empty_like(r)
-    ret = torch.empty_like(r)
+    if out is not None:
+        adv, ret = out
+        if adv.shape != r.shape or ret.shape != r.shape or not (adv.is_contiguous() and ret.is_contiguous()):
+            raise RlxError("gae_scan: out tensors must be contiguous and shaped like rewards")
+    else:
+        adv = torch.empty_like(r)
+        ret = torch.empty_like(r)
     ws_bytes = max(8, lib.rlx_gae_workspace_bytes(n, B, C))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     p = GaeParams(float(gamma), float(float(gamma) * float(gae_lambda)), int(bool(normalize_advantages)),
@@ -306,10 +311,56 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
                             returns.contiguous() if has_critic else None, m8, msum, p, n_adv)
 
 
+def make_ppo_params(*, logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low, clip_ratio_high,
+                    value_clip=None, huber_delta=None, max_episode_steps=None, clip_ratio_c=None,
+                    clip_log_ratio_min=None, clip_log_ratio_max=None, critic_warmup=False, has_critic=True) -> PpoLossParams:
+    p = PpoLossParams()
+    p.ratio_lo, p.ratio_hi = float(1.0 - clip_ratio_low), float(1.0 + clip_ratio_high)
+    p.clip_ratio_c = float(clip_ratio_c) if clip_ratio_c is not None else 0.0
+    p.use_dual_clip = int(clip_ratio_c is not None)
+    p.clip_log_ratio_min = float(clip_log_ratio_min) if clip_log_ratio_min is not None else 0.0
+    p.clip_log_ratio_max = float(clip_log_ratio_max) if clip_log_ratio_max is not None else 0.0
+    p.use_clip_log_ratio_min, p.use_clip_log_ratio_max = int(clip_log_ratio_min is not None), int(clip_log_ratio_max is not None)
+    p.value_clip = float(value_clip) if has_critic else 0.0
+    p.huber_delta = float(huber_delta) if has_critic else 0.0
+    p.has_critic, p.critic_warmup = int(has_critic), int(bool(critic_warmup))
+    p.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
+    if logprob_type == "action_level":
+        p.raw_per_adv, p.sub_per_adv = action_dim, 1
+    elif logprob_type == "token_level":
+        p.raw_per_adv, p.sub_per_adv = action_dim, action_dim
+    elif logprob_type == "chunk_level":
+        p.raw_per_adv, p.sub_per_adv = action_dim * chunks, 1
+    else:
+        raise RlxError(f"logprob_type must be one of {_LEVELS}")
+    return p
+
+
+def ppo_loss_fwd_raw(params: PpoLossParams, n_adv: int, logprobs, old_logprobs, advantages, values, prev_values, returns,
+                     loss_mask, loss_mask_sum, g_logp, g_value, out, workspace):
+    """Allocation-free launcher (all tensors caller-owned) used by the learner's fused/graph-captured step."""
+    lib = _lib.load()
+    dev = logprobs.device
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_ppo_loss_fwd(logprobs.data_ptr(), old_logprobs.data_ptr(), advantages.data_ptr(), _ptr(values),
+                                        _ptr(prev_values), _ptr(returns), _ptr(loss_mask), _ptr(loss_mask_sum), n_adv,
+                                        byref(params), g_logp.data_ptr(), _ptr(g_value), out.data_ptr(),
+                                        workspace.data_ptr(), workspace.numel(), _stream_ptr(dev)), "rlx_ppo_loss_fwd")
+
+
+def ppo_loss_bwd_raw(params: PpoLossParams, n_adv: int, g_logp, g_value, out, grad_out, d_logprobs, d_values):
+    lib = _lib.load()
+    dev = g_logp.device
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_ppo_loss_bwd(g_logp.data_ptr(), _ptr(g_value), out.data_ptr(), _ptr(grad_out),
+                                        d_logprobs.data_ptr(), _ptr(d_values), n_adv, params.raw_per_adv, params.sub_per_adv,
+                                        _stream_ptr(dev)), "rlx_ppo_loss_bwd")
+
+
 # --------------------------------------------------------------------------------------------
 # a16  shuffle gather
 # --------------------------------------------------------------------------------------------
-def gather_rows(fields: list, index: torch.Tensor) -> list:
+def gather_rows(fields: list, index: torch.Tensor, outs: Optional[list] = None) -> list:
     """fields: list of [N, ...] contiguous HIP tensors; returns [t[index] for t in fields] (one launch per 16)."""
     lib = _lib.load()
     if not fields:
@@ -319,11 +370,11 @@ def gather_rows(fields: list, index: torch.Tensor) -> list:
         raise RlxError("index must be int64")
     idx = index.contiguous()
     n = idx.numel()
-    outs = []
     for t in fields:
         if not t.is_contiguous():
             raise RlxError("gather_rows needs contiguous fields")
-        outs.append(torch.empty((n, *t.shape[1:]), dtype=t.dtype, device=dev))
+    if outs is None:
+        outs = [torch.empty((n, *t.shape[1:]), dtype=t.dtype, device=dev) for t in fields]
     with torch.cuda.device(dev):
         for lo in range(0, len(fields), _lib.GATHER_MAX_FIELDS):
             chunk = list(zip(fields, outs))[lo:lo + _lib.GATHER_MAX_FIELDS]
@@ -345,9 +396,11 @@ def gather_rows(fields: list, index: torch.Tensor) -> list:
 # --------------------------------------------------------------------------------------------
 def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                      groups: list, step: int, *, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
-                     max_grad_norm: float = 0.5, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None):
+                     max_grad_norm: float = 0.5, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None,
+                     step_state: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
     """In-place clip_grad_norm_ + AdamW over flat f32 buffers.  groups = [(begin, end, lr), ...].
-    grads may be [n] or [slabs, n] (split-K slabs, summed first).  Returns stats f32[2] = (norm, applied)."""
+    grads may be [n] or [slabs, n] (split-K slabs, summed first).  Returns stats f32[2] = (norm, applied).
+    step_state: device int32[2] keeping the step count on the device (then ``step`` is ignored)."""
     lib = _lib.load()
     dev = _dev(params, grads, exp_avg, exp_avg_sq)
     n = params.numel()
@@ -368,12 +421,31 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
     if stats is None:
         stats = torch.empty((2,), dtype=torch.float32, device=dev)
     ws_bytes = lib.rlx_adamw_workspace_bytes(n)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    ws = workspace if workspace is not None and workspace.numel() >= ws_bytes else torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    if step_state is not None and (step_state.dtype != torch.int32 or step_state.numel() < 2):
+        raise RlxError("step_state must be int32[2]")
     with torch.cuda.device(dev):
         _lib.check(lib.rlx_clip_adamw_step(params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
-                                           byref(p), stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(dev)),
-                   "rlx_clip_adamw_step")
+                                           byref(p), stats.data_ptr(), _ptr(step_state), ws.data_ptr(), ws.numel(),
+                                           _stream_ptr(dev)), "rlx_clip_adamw_step")
     return stats
+
+
+def bootstrap_rewards_(rewards: torch.Tensor, flags: torch.Tensor, bootstrap_values: torch.Tensor, gamma: float):
+    """rewards [B,C] f32 in place: r[:, -1] += gamma * V[:, 0] where flags[:, -1]  (env_worker.py:744-758)."""
+    lib = _lib.load()
+    dev = _dev(rewards, flags, bootstrap_values)
+    if rewards.dim() != 2 or not rewards.is_contiguous() or rewards.dtype != torch.float32:
+        raise RlxError("rewards must be a contiguous float32 [B, C] tensor")
+    f8 = _as_u8(flags)
+    v = _as_f32(bootstrap_values, "bootstrap_values")
+    B, C = rewards.shape
+    if tuple(f8.shape) != (B, C) or v.shape[0] != B:
+        raise RlxError("flags must be [B,C] and bootstrap_values [B, >=1]")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_bootstrap_rewards(rewards.data_ptr(), f8.data_ptr(), v.data_ptr(), B, C,
+                                             v.numel() // max(B, 1), float(gamma), _stream_ptr(dev)), "rlx_bootstrap_rewards")
+    return rewards
 
 
 # --------------------------------------------------------------------------------------------
@@ -391,7 +463,7 @@ def mlp_pack(params: torch.Tensor, layout: MlpLayout, packed: Optional[torch.Ten
 
 
 def mlp_rollout(params: torch.Tensor, packed: torch.Tensor, layout: MlpLayout, states: torch.Tensor,
-                eps: Optional[torch.Tensor]):
+                eps: Optional[torch.Tensor], out: Optional[tuple] = None):
     """states [M,D], eps [M,act]|None -> (action [M,act], logprob [M,act], value [M,val])."""
     lib = _lib.load()
     dev = _dev(params, packed, states, eps)
@@ -402,9 +474,15 @@ def mlp_rollout(params: torch.Tensor, packed: torch.Tensor, layout: MlpLayout, s
     e = _as_f32(eps, "eps")
     if e is not None and tuple(e.shape) != (M, layout.act_dim):
         raise RlxError(f"eps must be [{M}, {layout.act_dim}]")
-    action = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
-    logprob = torch.empty_like(action)
-    value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
+    if out is not None:  # write straight into caller-owned rows (e.g. the trajectory buffer)
+        action, logprob, value = out
+        for t, w in ((action, layout.act_dim), (logprob, layout.act_dim), (value, layout.val_dim)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != M * w:
+                raise RlxError("mlp_rollout: out tensors must be contiguous float32 of the right size")
+    else:
+        action = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
+        logprob = torch.empty_like(action)
+        value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.rlx_mlp_rollout(params.data_ptr(), packed.data_ptr(), byref(layout), st.data_ptr(), _ptr(e), M,
                                        action.data_ptr(), logprob.data_ptr(), value.data_ptr(), _stream_ptr(dev)),
@@ -412,7 +490,33 @@ def mlp_rollout(params: torch.Tensor, packed: torch.Tensor, layout: MlpLayout, s
     return action, logprob, value
 
 
-def mlp_train_fwd(params, packed, layout: MlpLayout, states, action, acts: Optional[torch.Tensor] = None):
+def mlp_value(params, packed, layout: MlpLayout, states, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Value head only: states [M,D] -> value [M,val]."""
+    lib = _lib.load()
+    dev = _dev(params, packed, states)
+    st = _as_f32(states, "states")
+    M = st.shape[0]
+    value = out if out is not None else torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_value(params.data_ptr(), packed.data_ptr(), byref(layout), st.data_ptr(), M, value.data_ptr(),
+                                     _stream_ptr(dev)), "rlx_mlp_value")
+    return value
+
+
+def sum_slabs(grads: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[slabs, n] -> [n]."""
+    lib = _lib.load()
+    dev = _dev(grads)
+    slabs, n = grads.shape
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_sum_slabs(grads.data_ptr(), n, slabs, out.data_ptr(), _stream_ptr(dev)), "rlx_sum_slabs")
+    return out
+
+
+def mlp_train_fwd(params, packed, layout: MlpLayout, states, action, acts: Optional[torch.Tensor] = None,
+                  out: Optional[tuple] = None):
     """-> (logprob, entropy [M,act], value [M,val], mean [M,act], acts [2,3,M,256])."""
     lib = _lib.load()
     dev = _dev(params, packed, states, action)
@@ -420,10 +524,13 @@ def mlp_train_fwd(params, packed, layout: MlpLayout, states, action, acts: Optio
     M = st.shape[0]
     if tuple(ac.shape) != (M, layout.act_dim):
         raise RlxError(f"action must be [{M}, {layout.act_dim}], got {tuple(ac.shape)}")
-    logprob = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
-    entropy = torch.empty_like(logprob)
-    mean = torch.empty_like(logprob)
-    value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
+    if out is not None:
+        logprob, entropy, value, mean = out
+    else:
+        logprob = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
+        entropy = torch.empty_like(logprob)
+        mean = torch.empty_like(logprob)
+        value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
     if acts is None or acts.numel() != 6 * M * 256:
         acts = torch.empty((2, 3, M, 256), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

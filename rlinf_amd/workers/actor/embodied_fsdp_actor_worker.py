@@ -1,0 +1,304 @@
+"""EmbodiedFSDPActor: the PPO/GRPO learner (mirror of rlinf/workers/actor/embodied_fsdp_actor_worker.py:
+recv_rollout_trajectories :186-207, _process_received_rollout_batch :209-284, compute_advantages_and_returns
+:286-321, run_training :483-589, train_micro_batch :591-700) in its NO_SHARD data-parallel form
+(rlinf/hybrid_engines/fsdp: optimizer_step fsdp_model_manager.py:429-463, two-group AdamW :501-590).
+
+One optimizer step is a fixed chain of HIP launches on preallocated buffers -- no autograd graph, no
+``.item()``: training forward -> fused loss (+metrics) -> loss backward -> backward-data chain -> split-K weight
+gradients -> [RCCL all-reduce of one flat buffer] -> clip + AdamW -> weight re-pack.  Metrics of every step land
+in one device matrix read back once per ``run_training``.  Because the chain is static it can be captured in a
+hipGraph (``actor.enable_hip_graph``) and replayed: the step counter lives on the device for that reason.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
+from ...algorithms import calculate_adv_and_returns
+from ...algorithms.losses import EV_PREFIX, _ACTOR_KEYS, _CRITIC_KEYS, _EV_MAP, explained_variance_from_stats
+from ...data import convert_trajectories_to_batch
+from ...models import get_model
+from ...scheduler.dist import all_reduce_flat_, all_reduce_scalars
+from ...scheduler.placement import compute_split_num, minibatch_plan
+from ..common import Worker
+
+CRITIC_EXPLAINED_VARIANCE_KEY = "critic/explained_variance"
+
+
+class EmbodiedFSDPActor(Worker):
+    def __init__(self, cfg, ctx=None):
+        super().__init__(cfg, ctx)
+        self.model = None
+        self.rollout_batch: dict = {}
+        self.version = 0
+        self.optimizer_steps = 0
+        a = cfg.actor
+        self.gradient_accumulation = a.global_batch_size // a.micro_batch_size // self._world_size  # :91-95
+        self.critic_warmup_steps = int(a.optim.get("critic_warmup_steps", 0))
+        self.enable_hip_graph = bool(a.get("enable_hip_graph", False))
+        self._graph = None
+        self._graph_key = None
+
+    # ---- set-up ---------------------------------------------------------------------------------------------
+    def init_worker(self):
+        a = self.cfg.actor
+        seed = int(a.get("seed", 1234))
+        torch.manual_seed(seed)  # every rank builds identical initial weights
+        self.model = get_model(a.model).to(self.device)
+        n = self.model.n_params
+        dev = self.device
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.opt_stats = torch.zeros(2, device=dev)
+        self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        self.grad_flat = torch.zeros(n, device=dev)
+        self.groups = self.model.group_ranges(a.optim.lr, a.optim.value_lr)
+        self._ws = {}
+
+    def set_global_step(self, global_step: int):
+        self.version = global_step
+
+    def sync_model_to_rollout(self):
+        """Weights for the rollout worker (embodied_fsdp_actor_worker.py:142-154): the flat buffer itself."""
+        return self.model.flat.data
+
+    def state_dict(self):
+        return self.model.reference_state_dict()
+
+    # ---- trajectories -----------------------------------------------------------------------------------------
+    def recv_rollout_trajectories(self, trajectories: list):
+        send_num = self._world_size * self.cfg.rollout.get("pipeline_stage_num", 1)
+        split_num = compute_split_num(send_num, self._world_size)
+        assert len(trajectories) == split_num, f"expected {split_num} trajectories, got {len(trajectories)}"
+        self.rollout_batch = self._process_received_rollout_batch(convert_trajectories_to_batch(trajectories))
+
+    def _process_received_rollout_batch(self, batch: dict) -> dict:
+        tr = self.cfg.env.train
+        assert tr.get("rollout_epoch", 1) == 1, "rollout_epoch > 1: next tier"
+        if not tr.get("auto_reset", False) and not tr.get("ignore_terminations", False):  # :219-233
+            dones = batch["dones"].contiguous()
+            loss_mask, mask_sum = ops.done_prefix_mask(dones)
+            loss_mask_sum = mask_sum.view(1, -1, 1).expand_as(loss_mask)
+            if self.cfg.algorithm.reward_type == "chunk_level":
+                loss_mask = loss_mask.any(dim=-1, keepdim=True)
+                loss_mask_sum = loss_mask_sum[..., -1:]
+            batch["loss_mask"], batch["loss_mask_sum"] = loss_mask, loss_mask_sum
+        return batch
+
+    def compute_advantages_and_returns(self) -> dict:
+        alg, b = self.cfg.algorithm, self.rollout_batch
+        with self.timer("actor/compute_adv"):
+            out = calculate_adv_and_returns(
+                task_type=self.cfg.runner.task_type, adv_type=alg.adv_type, rewards=b["rewards"], dones=b["dones"],
+                values=b.get("prev_values"), gamma=alg.get("gamma", 1), gae_lambda=alg.get("gae_lambda", 1),
+                group_size=alg.get("group_size", 8), reward_type=alg.reward_type, loss_mask=b.get("loss_mask"),
+                loss_mask_sum=b.get("loss_mask_sum"))
+            b.update(out)
+            return self._rollout_metrics(b)
+
+    def _rollout_metrics(self, b: dict) -> dict:
+        """compute_rollout_metrics (rlinf/utils/metric_utils.py:422-506): masked mean / min / max of rewards,
+        advantages, returns; reduced over ranks in ONE sum call + ONE max call, read back in one copy."""
+        mask = b.get("loss_mask")
+        names, sums, maxs = [], [], []
+        for key in ("rewards", "advantages", "returns"):
+            v = b.get(key)
+            if v is None:
+                continue
+            sel = v.reshape(-1) if mask is None else v[torch.broadcast_to(mask, v.shape)]
+            n = sel.numel()
+            names.append(key)
+            sums += [sel.sum() if n else v.new_zeros(()), v.new_tensor(float(n))]
+            maxs += [-sel.min() if n else v.new_tensor(float("-inf")), sel.max() if n else v.new_tensor(float("-inf"))]
+        s, m = all_reduce_scalars(torch.stack(sums), torch.stack(maxs), self.ctx)
+        s, m = s.tolist(), m.tolist()
+        out = {}
+        for i, key in enumerate(names):
+            cnt = s[2 * i + 1]
+            mean = s[2 * i] / cnt if cnt > 0 else float("nan")
+            if key == "rewards":
+                out["rewards"] = mean
+            else:
+                out[f"{key}_mean"], out[f"{key}_max"], out[f"{key}_min"] = mean, m[2 * i + 1], -m[2 * i]
+        return out
+
+    # ---- update -------------------------------------------------------------------------------------------------
+    def _flatten_and_shuffle(self):
+        """process_nested_dict_for_train (rlinf/utils/nested_dict_process.py:272-285): one randperm per
+        run_training with Generator(seed = actor.seed + rank) (:511-513); one gather launch for every field."""
+        b = self.rollout_batch
+        T, B = b["prev_logprobs"].shape[:2]
+        N = T * B
+        g = torch.Generator()
+        g.manual_seed(int(self.cfg.actor.seed) + self._rank)
+        perm = torch.randperm(N, generator=g).to(self.device, non_blocking=True)
+        names = ["states", "action", "prev_logprobs", "advantages", "prev_values"]
+        src = [b["forward_inputs"]["states"], b["forward_inputs"]["action"], b["prev_logprobs"], b["advantages"],
+               b["prev_values"][:-1]]
+        if b.get("returns") is not None:
+            names.append("returns")
+            src.append(b["returns"])
+        if b.get("loss_mask") is not None:
+            names += ["loss_mask", "loss_mask_sum"]
+            src += [b["loss_mask"], b["loss_mask_sum"].contiguous()]
+        flat = [t.reshape(N, *t.shape[2:]).contiguous() for t in src]
+        key = ("shuf", N)
+        if key not in self._ws:
+            self._ws[key] = [torch.empty_like(t) for t in flat]
+        outs = ops.gather_rows(flat, perm, self._ws[key])
+        return dict(zip(names, outs)), N
+
+    def _minibatch_workspace(self, mb: int):
+        key = ("mb", mb)
+        if key not in self._ws:
+            lay, dev = self.model.layout, self.device
+            f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+            slabs = ops.mlp_bwd_slabs(mb)
+            lib = ops._lib.load()
+            self._ws[key] = dict(
+                logprob=f(mb, lay.act_dim), entropy=f(mb, lay.act_dim), value=f(mb, lay.val_dim), mean=f(mb, lay.act_dim),
+                acts=f(2, 3, mb, 256), g_lp=f(mb * lay.act_dim), g_v=f(mb * lay.val_dim), d_lp=f(mb, lay.act_dim),
+                d_v=f(mb, lay.val_dim), slabs=slabs,
+                loss_ws=torch.empty(lib.rlx_ppo_loss_workspace_bytes(mb), dtype=torch.uint8, device=dev),
+                bwd_ws=torch.empty(lib.rlx_mlp_bwd_workspace_bytes(ops.byref(lay), mb), dtype=torch.uint8, device=dev))
+        return self._ws[key]
+
+    def _loss_params(self, critic_warmup: bool):
+        alg, m = self.cfg.algorithm, self.cfg.actor.model
+        has_critic = alg.loss_type == "actor_critic"
+        return ops.make_ppo_params(
+            logprob_type=alg.logprob_type, action_dim=m.action_dim, chunks=m.num_action_chunks,
+            clip_ratio_low=alg.clip_ratio_low, clip_ratio_high=alg.clip_ratio_high, value_clip=alg.get("value_clip"),
+            huber_delta=alg.get("huber_delta"), max_episode_steps=self.cfg.env.train.get("max_episode_steps"),
+            critic_warmup=critic_warmup, has_critic=has_critic)
+
+    def train_micro_batch(self, mbatch: dict, ws: dict, grads: torch.Tensor, out_row: torch.Tensor, grad_out: torch.Tensor,
+                          lp: "ops.PpoLossParams"):
+        """forward -> loss -> backward for one micro-batch; parameter gradients land in ``grads`` [slabs, n]."""
+        m = self.model
+        lay = m.layout
+        mb = mbatch["states"].shape[0]
+        ops.mlp_train_fwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], acts=ws["acts"],
+                          out=(ws["logprob"], ws["entropy"], ws["value"], ws["mean"]))
+        n_adv = mb * lay.act_dim // lp.raw_per_adv  # advantage elements: [mb, C] (action/token level) or [mb] (chunk level)
+        has_critic = bool(lp.has_critic)
+        ops.ppo_loss_fwd_raw(lp, n_adv, ws["logprob"], mbatch["prev_logprobs"], mbatch["advantages"],
+                             ws["value"] if has_critic else None, mbatch["prev_values"] if has_critic else None,
+                             mbatch.get("returns") if has_critic else None,
+                             None if mbatch.get("loss_mask") is None else mbatch["loss_mask"].view(torch.uint8),
+                             mbatch.get("loss_mask_sum"), ws["g_lp"], ws["g_v"] if has_critic else None, out_row,
+                             ws["loss_ws"])
+        ops.ppo_loss_bwd_raw(lp, n_adv, ws["g_lp"], ws["g_v"] if has_critic else None, out_row, grad_out, ws["d_lp"],
+                             ws["d_v"] if has_critic else None)
+        if not has_critic:
+            ws["d_v"].zero_()
+        ops.mlp_train_bwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], ws["mean"], ws["acts"],
+                          ws["d_lp"], None, ws["d_v"], grads=grads, workspace=ws["bwd_ws"])
+
+    def optimizer_step(self, grads: torch.Tensor):
+        """clip_grad_norm_ + AdamW (+ data-parallel mean of the gradient) -> stats (norm, applied) on device."""
+        o = self.cfg.actor.optim
+        if self._world_size > 1:
+            ops.sum_slabs(grads, out=self.grad_flat)
+            all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1)
+            g, scale = self.grad_flat, 1.0 / self._world_size
+        else:
+            g, scale = grads, 1.0
+        ops.clip_adamw_step_(self.model.flat.data, g, self.exp_avg, self.exp_avg_sq, self.groups, 0,
+                             betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
+                             max_grad_norm=o.clip_grad, grad_scale=scale, stats=self.opt_stats,
+                             step_state=self.step_state, workspace=self.adamw_ws)
+        self.model.flat._version  # noqa: B018  (flat.data was updated in place by the kernel)
+        self.model.mark_updated()
+        self.optimizer_steps += 1
+
+    def _run_update(self, flat: dict, N: int, metrics_dev: torch.Tensor, norms_dev: torch.Tensor):
+        a, alg = self.cfg.actor, self.cfg.algorithm
+        n_mb, per_rank, accum = minibatch_plan(N, a.global_batch_size, a.micro_batch_size, self._world_size)
+        assert accum == self.gradient_accumulation
+        micro = a.micro_batch_size
+        ws = self._minibatch_workspace(micro)
+        key = ("grads", micro, accum)
+        if key not in self._ws:
+            self._ws[key] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
+            self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
+        grads, grad_out = self._ws[key], self._ws["grad_out"]
+        step = 0
+        for _ in range(alg.get("update_epoch", 1)):
+            for i in range(n_mb):
+                lp = self._loss_params(self.optimizer_steps < self.critic_warmup_steps)
+                for j in range(accum):
+                    lo = i * per_rank + j * micro
+                    mbatch = {k: v[lo:lo + micro] for k, v in flat.items()}
+                    self.train_micro_batch(mbatch, ws, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
+                                           metrics_dev[step * accum + j], grad_out, lp)
+                self.optimizer_step(grads)
+                norms_dev[step].copy_(self.opt_stats)
+                step += 1
+        return step
+
+    def run_training(self) -> dict:
+        a, alg = self.cfg.actor, self.cfg.algorithm
+        with self.timer("run_training"):
+            flat, N = self._flatten_and_shuffle()
+            n_mb, _, accum = minibatch_plan(N, a.global_batch_size, a.micro_batch_size, self._world_size)
+            n_steps = n_mb * alg.get("update_epoch", 1)
+            key = ("metrics", n_steps, accum)
+            if key not in self._ws:
+                self._ws[key] = (torch.zeros(n_steps * accum, PPO_OUT_FLOATS, device=self.device),
+                                 torch.zeros(n_steps, 2, device=self.device))
+            metrics_dev, norms_dev = self._ws[key]
+            if self.enable_hip_graph and self._world_size == 1:
+                self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
+            else:
+                self._run_update(flat, N, metrics_dev, norms_dev)
+            return self._collect_metrics(metrics_dev, norms_dev, accum)
+
+    def _replay_or_capture(self, flat, N, metrics_dev, norms_dev, n_steps):
+        """hipGraph of the whole update phase: buffers are persistent, so the captured launches can be replayed."""
+        gkey = (N, n_steps, tuple(sorted(flat)))
+        if self._graph is None or self._graph_key != gkey:
+            self._run_update(flat, N, metrics_dev, norms_dev)  # eager first call warms every workspace
+            torch.cuda.synchronize(self.device)
+            self._graph_pending = gkey
+            self._graph_key, self._graph = gkey, "warm"
+            return
+        if self._graph == "warm":
+            g = torch.cuda.CUDAGraph()
+            steps_before = self.optimizer_steps
+            with torch.cuda.graph(g):
+                self._run_update(flat, N, metrics_dev, norms_dev)
+            self.optimizer_steps = steps_before  # capture does not execute
+            self._graph = g
+        self._graph.replay()
+        self.optimizer_steps += n_steps
+
+    def _collect_metrics(self, metrics_dev, norms_dev, accum) -> dict:
+        """Mean over micro-batches, then AVG over ranks (embodied_fsdp_actor_worker.py:576-587); EV statistics are
+        summed (metric_utils.py:293-319).  One D2H copy for everything."""
+        has_critic = self.cfg.algorithm.loss_type == "actor_critic"
+        m = metrics_dev.mean(dim=0)
+        ev = metrics_dev[:, PPO_OUT_NAMES["ev/count"]:PPO_OUT_NAMES["ev/errors_sq_sum"] + 1].sum(dim=0)
+        gn = norms_dev[:, 0].mean()
+        vec = torch.cat([m, ev, gn.view(1)])
+        if self._world_size > 1:
+            avg = torch.cat([m, gn.view(1)])
+            all_reduce_flat_(avg, self.ctx, average=True)
+            all_reduce_flat_(ev, self.ctx)
+            vec = torch.cat([avg[:-1], ev, avg[-1:]])
+        host = vec.tolist()
+        out = {k: host[PPO_OUT_NAMES[k]] for k in _ACTOR_KEYS}
+        if has_critic:
+            out.update({k: host[PPO_OUT_NAMES[k]] for k in _CRITIC_KEYS})
+            stats = {name: host[PPO_OUT_FLOATS + i] for i, name in enumerate(_EV_MAP.values())}
+            out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(stats)
+        out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
+        out["actor/entropy_loss"] = 0.0
+        out["actor/grad_norm"] = host[-1]
+        out["actor/lr"] = float(self.cfg.actor.optim.lr)
+        out["critic/lr"] = float(self.cfg.actor.optim.value_lr)
+        return out

@@ -1,0 +1,85 @@
+"""In-process worker plumbing that stands in for RLinf's Ray worker groups on this path.
+
+The reference launches every worker class as a Ray actor group and drives it through RPC handles
+(``Worker.create_group(cfg).launch(...)``, ``group.method(...).wait()``,
+rlinf/scheduler/worker/worker_group.py:144-197,406-557).  Here there is one process per GPU (torchrun-style
+ranks) and the three workers of a rank live in that process, so a "group" is the local instance and a handle
+resolves immediately; the method names, call order and return conventions are kept so the runner reads like
+the reference's.
+"""
+
+from __future__ import annotations
+
+import time
+from contextlib import contextmanager
+from typing import Any
+
+
+class Handle:
+    """Result of a (synchronous) worker call; mirrors WorkerGroupFuncResult.wait()/consume_durations()."""
+
+    def __init__(self, value: Any, duration: float = 0.0):
+        self._value, self._duration = value, duration
+
+    def wait(self):
+        return [self._value]  # one entry per rank in the group: this rank's
+
+    def consume_durations(self):
+        return {"": self._duration}
+
+
+class Worker:
+    """Base class: rank bookkeeping + the ``timer`` metrics of rlinf/scheduler/worker/worker.py:1322-1376."""
+
+    def __init__(self, cfg, ctx=None):
+        from ..scheduler import DistContext
+
+        self.cfg = cfg
+        self.ctx = ctx or DistContext()
+        self._rank, self._world_size = self.ctx.rank, self.ctx.world_size
+        self.device = self.ctx.device
+        self._timer_metrics: dict = {}
+
+    @classmethod
+    def create_group(cls, cfg, ctx=None):
+        return _Group(cls, cfg, ctx)
+
+    @contextmanager
+    def timer(self, tag: str):
+        t0 = time.perf_counter()
+        yield
+        self._timer_metrics[tag] = self._timer_metrics.get(tag, 0.0) + time.perf_counter() - t0
+
+    def pop_execution_times(self) -> dict:
+        out, self._timer_metrics = self._timer_metrics, {}
+        return out
+
+
+class _Group:
+    """``Worker.create_group(cfg).launch(cluster, name=..., placement_strategy=...)`` -> the local worker, whose
+    methods return Handles."""
+
+    def __init__(self, cls, cfg, ctx):
+        self._cls, self._cfg, self._ctx = cls, cfg, ctx
+
+    def launch(self, cluster=None, name: str = "", placement_strategy=None):
+        return _HandleProxy(self._cls(self._cfg, self._ctx))
+
+
+class _HandleProxy:
+    def __init__(self, worker):
+        object.__setattr__(self, "worker", worker)
+
+    def __getattr__(self, item):
+        attr = getattr(self.worker, item)
+        if not callable(attr):
+            return attr
+
+        def call(*a, **kw):
+            t0 = time.perf_counter()
+            a = tuple(x.worker if isinstance(x, _HandleProxy) else x for x in a)
+            kw = {k: (v.worker if isinstance(v, _HandleProxy) else v) for k, v in kw.items()}
+            out = attr(*a, **kw)
+            return Handle(out, time.perf_counter() - t0)
+
+        return call

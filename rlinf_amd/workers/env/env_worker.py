@@ -1,0 +1,87 @@
+"""EnvWorker: steps the (synthetic) simulator, adds bootstrap rewards and fills the trajectory buffer
+(mirror of rlinf/workers/env/env_worker.py: shard arithmetic :137-140, compute_bootstrap_rewards :718-758,
+_run_interact_once :1058-1306, send_rollout_trajectories :1026).
+
+Row alignment: row t of the buffer holds the policy outputs for observation t and the env
+outputs (reward, dones) of the env step taken WITH action t, i.e. rewards[t] pairs with values[t], values[t+1]
+and dones[t+1]; row 0 of dones is the all-False bootstrap row; one extra value row closes the buffer.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from ...data import TrajectoryBuffer
+from ...envs.synthetic_env import SyntheticManiSkillEnv, generate_tensors
+from ...scheduler.placement import compute_split_num, env_shard
+from ..common import Worker
+
+
+class EnvWorker(Worker):
+    def __init__(self, cfg, ctx=None):
+        super().__init__(cfg, ctx)
+        self.train_cfg = cfg.env.train
+        self.stage_num = cfg.rollout.get("pipeline_stage_num", 1)
+        assert self.stage_num == 1, "pipeline stages are the next tier (SURVEY.md 8f item 2)"
+        self.num_envs = self.train_cfg.total_num_envs // self._world_size // self.stage_num  # env_worker.py:137-140
+        self.n_train_chunk_steps = (self.train_cfg.max_steps_per_rollout_epoch // cfg.actor.model.num_action_chunks)
+        self.rollout_epoch = self.train_cfg.get("rollout_epoch", 1)
+        assert self.rollout_epoch == 1, "rollout_epoch > 1 is folded by the learner; the env worker runs one epoch"
+        self.gamma = float(cfg.algorithm.get("gamma", 1))
+        self.bootstrap_type = cfg.algorithm.get("bootstrap_type", "standard")
+        self.auto_reset = bool(self.train_cfg.get("auto_reset", False))
+        self.env = None
+        self.buffer = None
+        self.rollout = None
+
+    def init_worker(self, env_tensors: dict | None = None):
+        m = self.cfg.actor.model
+        begin, end = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank)
+        if env_tensors is None:
+            env_tensors = generate_tensors(int(self.train_cfg.get("seed", 0)), self.n_train_chunk_steps,
+                                           self.train_cfg.total_num_envs, m.obs_dim,
+                                           int(self.train_cfg.get("max_episode_steps", 50)),
+                                           mode=self.train_cfg.get("synthetic_done_mode", "periodic"))
+        self.env = SyntheticManiSkillEnv(env_tensors, self.device, m.num_action_chunks, self.auto_reset, slice(begin, end))
+        self.buffer = TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs, m.obs_dim, m.action_dim,
+                                       m.num_action_chunks, device=self.device,
+                                       max_episode_length=int(self.train_cfg.get("max_episode_steps", 0)))
+        self._bootstrap_v = torch.zeros(self.num_envs, self.buffer.V, device=self.device)
+
+    def connect(self, rollout):
+        """In-process stand-in for the env<->rollout channels (env_worker.py:964-984,1120-1129)."""
+        self.rollout = rollout
+
+    def compute_bootstrap_rewards(self, rewards, dones, truncations, bootstrap_values):
+        """r[:, -1] += gamma * V(final_obs) where the env finished (env_worker.py:718-758); in place on the buffer row."""
+        if rewards is None or not self.auto_reset:
+            return rewards
+        flags = dones if self.bootstrap_type == "always" else truncations
+        return ops.bootstrap_rewards_(rewards, flags, bootstrap_values, self.gamma)
+
+    def interact(self, eps: torch.Tensor | None = None, mode: str = "train"):
+        """One rollout epoch: T chunk steps + the closing value row.  ``eps`` [T, B, A] injects the N(0,1) draws."""
+        buf, env, ro = self.buffer, self.env, self.rollout
+        buf.reset()
+        with self.timer("env/interact"):
+            obs, _ = env.reset()
+            for t in range(self.n_train_chunk_steps):
+                buf.states[t].copy_(obs["states"])  # forward_inputs.states of step t (return_obs=True)
+                chunk_actions = ro.predict(obs, out=buf.policy_rows(t), eps=None if eps is None else eps[t], mode=mode)
+                obs, rewards, term, trunc, infos = env.chunk_step(chunk_actions)
+                r_row, d_row, te_row, tr_row = buf.env_rows(t)
+                r_row.copy_(rewards)
+                te_row.copy_(term)
+                tr_row.copy_(trunc)
+                torch.logical_or(term, trunc, out=d_row)
+                if self.auto_reset:  # value of the true terminal observation enters through the reward (A.2)
+                    ro.get_bootstrap_values(infos["final_obs"], out=self._bootstrap_v)
+                    self.compute_bootstrap_rewards(r_row, d_row, tr_row, self._bootstrap_v)
+            ro.get_bootstrap_values(obs, out=buf.prev_values[self.n_train_chunk_steps])  # last row: values only
+        return None
+
+    def send_rollout_trajectories(self, actor_world_size: int | None = None) -> list:
+        """to_splited_trajectories(actor_split_num) (env_worker.py:1026,1463-1467): views, no copies."""
+        split = compute_split_num(actor_world_size or self._world_size, self._world_size * self.stage_num)
+        return self.buffer.to_splited_trajectories(split)
