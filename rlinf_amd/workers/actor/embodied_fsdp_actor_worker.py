@@ -252,28 +252,26 @@ class EmbodiedFSDPActor(Worker):
                 self._ws[key] = (torch.zeros(n_steps * accum, PPO_OUT_FLOATS, device=self.device),
                                  torch.zeros(n_steps, 2, device=self.device))
             metrics_dev, norms_dev = self._ws[key]
-            if self.enable_hip_graph and self._world_size == 1:
+            if self.enable_hip_graph and self._world_size == 1 and self.critic_warmup_steps == 0:
                 self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
             else:
                 self._run_update(flat, N, metrics_dev, norms_dev)
             return self._collect_metrics(metrics_dev, norms_dev, accum)
 
     def _replay_or_capture(self, flat, N, metrics_dev, norms_dev, n_steps):
-        """hipGraph of the whole update phase: buffers are persistent, so the captured launches can be replayed."""
-        gkey = (N, n_steps, tuple(sorted(flat)))
+        """hipGraph of the whole update phase (all epochs x minibatches): every buffer is persistent and the step
+        counter lives on the device, so the captured launch chain can be replayed as is."""
+        gkey = (N, n_steps, tuple(sorted(flat)), tuple(t.data_ptr() for t in flat.values()))
         if self._graph is None or self._graph_key != gkey:
-            self._run_update(flat, N, metrics_dev, norms_dev)  # eager first call warms every workspace
+            self._run_update(flat, N, metrics_dev, norms_dev)  # real run; also warms every workspace
             torch.cuda.synchronize(self.device)
-            self._graph_pending = gkey
-            self._graph_key, self._graph = gkey, "warm"
-            return
-        if self._graph == "warm":
-            g = torch.cuda.CUDAGraph()
             steps_before = self.optimizer_steps
+            g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._run_update(flat, N, metrics_dev, norms_dev)
-            self.optimizer_steps = steps_before  # capture does not execute
-            self._graph = g
+            self.optimizer_steps = steps_before  # capture records, it does not execute
+            self._graph, self._graph_key = g, gkey
+            return
         self._graph.replay()
         self.optimizer_steps += n_steps
 

@@ -31,9 +31,14 @@ class EnvWorker(Worker):
         self.gamma = float(cfg.algorithm.get("gamma", 1))
         self.bootstrap_type = cfg.algorithm.get("bootstrap_type", "standard")
         self.auto_reset = bool(self.train_cfg.get("auto_reset", False))
+        # rollout.enable_cuda_graph is the reference's switch (huggingface_worker.py / mlp_policy.py:344-440 capture
+        # _generate_actions); here the WHOLE T-step loop is one hipGraph, because every launch works on fixed rows.
+        self.use_graph = bool(cfg.rollout.get("enable_cuda_graph", False))
         self.env = None
         self.buffer = None
         self.rollout = None
+        self._graph = None
+        self._eps = None
 
     def init_worker(self, env_tensors: dict | None = None):
         m = self.cfg.actor.model
@@ -61,7 +66,28 @@ class EnvWorker(Worker):
         return ops.bootstrap_rewards_(rewards, flags, bootstrap_values, self.gamma)
 
     def interact(self, eps: torch.Tensor | None = None, mode: str = "train"):
-        """One rollout epoch: T chunk steps + the closing value row.  ``eps`` [T, B, A] injects the N(0,1) draws."""
+        """One rollout epoch: T chunk steps + the closing value row.  ``eps`` [T, B, A] injects the N(0,1) draws
+        (drawn on the device otherwise)."""
+        if self._eps is None:
+            self._eps = torch.empty(self.n_train_chunk_steps, self.num_envs, self.buffer.A, device=self.device)
+        if eps is None:
+            self._eps.normal_()
+        else:
+            self._eps.copy_(eps)
+        if not (self.use_graph and mode == "train" and self.device.type == "cuda"):
+            return self._interact_eager(self._eps, mode)
+        if self._graph is None:
+            self._interact_eager(self._eps, mode)  # real run; also warms every allocation
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._interact_eager(self._eps, mode)
+            self._graph = g
+            return None
+        self._graph.replay()
+        return None
+
+    def _interact_eager(self, eps: torch.Tensor, mode: str = "train"):
         buf, env, ro = self.buffer, self.env, self.rollout
         buf.reset()
         with self.timer("env/interact"):
