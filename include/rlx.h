@@ -245,6 +245,12 @@ int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_
 int rlx_bootstrap_rewards(float* rewards, const uint8_t* flags, const float* bootstrap_values, int batch, int chunk,
                           int value_stride, float gamma, rlx_stream_t stream);
 
+/* a7  store_env_rows  <- EmbodiedTrajectoryBuilder.append_step_result (env fields),
+ *     rlinf/data/schema/embodied_trajectory_builder.py:72-93: one env step's [B, C] outputs into the buffer rows
+ *     rewards[t], terminations / truncations / dones[t+1], with dones = terminations | truncations.  n = B * C. */
+int rlx_store_env_rows(const float* rewards, const uint8_t* terminations, const uint8_t* truncations, float* reward_row,
+                       uint8_t* done_row, uint8_t* termination_row, uint8_t* truncation_row, int64_t n, rlx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * a1-a5, a17  MLP policy  <- MLPPolicy, rlinf/models/embodiment/mlp_policy/mlp_policy.py:91-107 (modules),
  *     :238-293 (_sample_actions/_generate_actions), :295-320 (predict_action_batch), :202-236 (default_forward),
@@ -297,6 +303,80 @@ int rlx_mlp_train_bwd(const float* params, const float* packed, const rlx_mlp_la
                       const float* action, const float* mean, const float* acts, const float* d_logprob,
                       const float* d_entropy, const float* d_value, int64_t m, float* grads, int slabs,
                       void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * Fused hot launches (what the workers of rlinf_amd/ call every step; the entry points above stay for
+ * integrations that need the stages separately).
+ *
+ * rlx_mlp_rollout_step: ONE launch per rollout step.
+ *   policy job   <- MLPPolicy.predict_action_batch, mlp_policy.py:295-320 (obs-preprocess :122-124, forward
+ *                   :238-254, sample / log-prob / value :256-293): states [m, D], eps [m, act_dim] (NULL = eval)
+ *                   -> action, logprob [m, act_dim], value [m, val_dim], written in place (trajectory-buffer rows);
+ *                   states_copy (optional) receives the rows too (forward_inputs.states).
+ *   value jobs   <- MultiStepRolloutWorker.get_bootstrap_values, huggingface_worker.py:612-627, optionally fused
+ *                   with EnvWorker.compute_bootstrap_rewards, env_worker.py:718-758:
+ *                   values [m, val_dim] (optional) = V(states); rewards [m, chunk] (optional, in place):
+ *                   rewards[b, chunk-1] += gamma * V(states)[b, 0] where flags[b, chunk-1].
+ *   Needs act_dim, val_dim <= 16.  No packed weight image: weights are read from the flat parameter buffer.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rlx_value_job {
+    const float* states;
+    int64_t m;
+    float* values;
+    float* rewards;
+    const uint8_t* flags;
+    int32_t chunk;
+    float gamma;
+} rlx_value_job;
+typedef struct rlx_rollout_step {
+    const float* params;
+    const rlx_mlp_layout* layout;
+    const float* states;
+    const float* eps;
+    int64_t m;
+    float* action;
+    float* logprob;
+    float* value;
+    float* states_copy;
+    int32_t n_value_jobs; /* 0..2 */
+    rlx_value_job value_jobs[2];
+} rlx_rollout_step;
+int rlx_mlp_rollout_step(const rlx_rollout_step* step, rlx_stream_t stream);
+
+/* rlx_ppo_step: forward + loss + backward of one micro-batch in two launches
+ *   <- EmbodiedFSDPActor.train_micro_batch, rlinf/workers/actor/embodied_fsdp_actor_worker.py:591-700
+ *      = MLPPolicy.default_forward (mlp_policy.py:202-236) + policy_loss "actor_critic" | "actor"
+ *        (algorithms/registry.py:77-92, utils.py:280-376, losses.py:170-380) + loss.backward().
+ *   states [m, D], action / old_logprobs [m, act_dim], advantages / prev_values / returns / loss_mask /
+ *   loss_mask_sum: [m * act_dim / raw_per_adv] elements (the RAW minibatch views; preprocess_loss_inputs is fused).
+ *   grad_out = d(total loss)/d(this micro-batch's loss) = 1 / gradient_accumulation.
+ *   grads [slabs][n_params]: split-K gradient slabs, every element written (rlx_clip_adamw_step sums them);
+ *   slabs must equal rlx_ppo_step_slabs(layout, m).  out: the rlx_ppo_out metric row (device).
+ *   Needs act_dim, val_dim <= 16 and (has_critic) act_dim / raw_per_adv == val_dim. */
+typedef struct rlx_ppo_step_args {
+    const float* params;
+    const rlx_mlp_layout* layout;
+    const rlx_ppo_loss_params* loss;
+    const float* states;
+    const float* action;
+    const float* old_logprobs;
+    const float* advantages;
+    const float* prev_values;
+    const float* returns;
+    const uint8_t* loss_mask;
+    const int64_t* loss_mask_sum;
+    int64_t m;
+    float grad_out;
+    float* grads;
+    int32_t slabs;
+    float* out;
+    void* workspace;
+    size_t workspace_bytes;
+} rlx_ppo_step_args;
+int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);
+size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);
+int rlx_ppo_step(const rlx_ppo_step_args* args, rlx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,25 @@ class MlpLayout(Structure):
     ]
 
 
+class ValueJob(Structure):
+    _fields_ = [("states", c_void_p), ("m", c_int64), ("values", c_void_p), ("rewards", c_void_p), ("flags", c_void_p),
+                ("chunk", c_int32), ("gamma", c_float)]
+
+
+class RolloutStep(Structure):
+    _fields_ = [("params", c_void_p), ("layout", POINTER(MlpLayout)), ("states", c_void_p), ("eps", c_void_p),
+                ("m", c_int64), ("action", c_void_p), ("logprob", c_void_p), ("value", c_void_p),
+                ("states_copy", c_void_p), ("n_value_jobs", c_int32), ("value_jobs", ValueJob * 2)]
+
+
+class PpoStepArgs(Structure):
+    _fields_ = [("params", c_void_p), ("layout", POINTER(MlpLayout)), ("loss", POINTER(PpoLossParams)),
+                ("states", c_void_p), ("action", c_void_p), ("old_logprobs", c_void_p), ("advantages", c_void_p),
+                ("prev_values", c_void_p), ("returns", c_void_p), ("loss_mask", c_void_p), ("loss_mask_sum", c_void_p),
+                ("m", c_int64), ("grad_out", c_float), ("grads", c_void_p), ("slabs", c_int32), ("out", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
 PPO_OUT_FLOATS = 20
 PPO_OUT_NAMES = {
     "loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, "actor/ratio": 3, "actor/ratio_abs": 4,
@@ -114,6 +133,11 @@ PROTOTYPES = {
     "rlx_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamwParams), c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "rlx_bootstrap_rewards": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "rlx_store_env_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rlx_mlp_rollout_step": (c_int, [POINTER(RolloutStep), c_void_p]),
+    "rlx_ppo_step_slabs": (c_int, [POINTER(MlpLayout), c_int64]),
+    "rlx_ppo_step_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),
+    "rlx_ppo_step": (c_int, [POINTER(PpoStepArgs), c_void_p]),
 }
 
 _lib = None

@@ -134,7 +134,9 @@ template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK>
 __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
     // CRITIC / MASK are compile-time: a runtime "load or constant" select makes hipcc branch around
     // every load and drain vmcnt(0) per element (measured 27 us -> see DESIGN.md).
-    constexpr bool PF = NSEG == 1;  // streaming scan: always keep one batch in flight
+    // streaming scan: always keep one batch in flight (U >= 128: the whole trajectory is one register batch --
+    // every load of the wave is issued before the first dependent op, 384 VGPRs at one wave per SIMD)
+    constexpr bool PF = NSEG == 1 && U < 128;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int W = 64 * VEC;  // envs per block
     const int lane = threadIdx.x & 63;
@@ -294,6 +296,132 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Register-resident segmented scan (C == 1).  grid = ceil(B / (64*VEC)), block = 64*NSEG threads.
+//   Wave s of a block owns time segment [s*SEG, (s+1)*SEG) of 64*VEC envs and issues EVERY load of that segment
+//   up front (SEG rows x (r, V, done[, mask]) = 9 B per element live in VGPRs: SEG = 32, VEC = 4 -> 288 registers at
+//   one wave per SIMD, ~72 KB in flight per wave, 1 KiB per load instruction).  The recurrence then runs as a
+//   serial chain over the waves, latest segment first: wave s waits at a workgroup barrier for the accumulator
+//   g and hands it on through LDS (64*VEC floats -- the only LDS traffic), so every wave executes the reference's
+//   sequential recurrence with the true incoming g: results are bit-identical to the CPU loop, every byte is
+//   read once and written once, and while one wave computes and stores, the later waves' loads are still landing.
+// ------------------------------------------------------------------------------------------
+// Buffer (SRSRC) addressing: descriptor built from kernargs only (provably wave-uniform: no waterfall loops), the
+// per-lane part is one 32-bit voffset shared by every access, the row is a scalar soffset -- no per-lane 64-bit
+// address exists anywhere, which is what lets SEG x VEC x 9 bytes of segment data own the register file.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int VEC, bool NT>
+__device__ __forceinline__ void bld(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float (&out)[VEC]) {
+    constexpr int aux = NT ? 2 : 0;
+    if constexpr (VEC == 1) {
+        out[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux));
+    } else if constexpr (VEC == 2) {
+        const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux);
+        out[0] = __uint_as_float(x[0]); out[1] = __uint_as_float(x[1]);
+    } else {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = __uint_as_float(x[k]);
+    }
+}
+template <int VEC, bool NT>
+__device__ __forceinline__ void bst(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const float (&in)[VEC]) {
+    constexpr int aux = NT ? 2 : 0;
+    if constexpr (VEC == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(in[0]), rs, voff, soff, aux);
+    } else if constexpr (VEC == 2) {
+        u32x2 x; x[0] = __float_as_uint(in[0]); x[1] = __float_as_uint(in[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(x, rs, voff, soff, aux);
+    } else {
+        u32x4 x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = __float_as_uint(in[k]);
+        __builtin_amdgcn_raw_buffer_store_b128(x, rs, voff, soff, aux);
+    }
+}
+template <int VEC, bool NT>
+__device__ __forceinline__ uint32_t bldb(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    constexpr int aux = NT ? 2 : 0;
+    if constexpr (VEC == 1) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, aux);
+    else if constexpr (VEC == 2) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, aux);
+    else return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux);
+}
+
+template <int VEC, int NSEG, int SEG, bool NT, bool CRITIC, bool MASK>
+__global__ __launch_bounds__(64 * NSEG) void gae_scan_regseg(GaeArgs a) {
+    __shared__ float s_g[64 * VEC];
+    __shared__ double s_red[5 * NSEG];
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned e0 = ((unsigned)blockIdx.x * 64u + (unsigned)lane) * VEC;
+    const bool active = e0 < (unsigned)a.B;  // B % VEC == 0 (host-checked): a lane is all in or all out
+    const int T = a.T;
+    const unsigned B = (unsigned)a.B;
+    const int t_lo = seg * SEG;
+    const int t_hi = min(T, t_lo + SEG);
+    const unsigned nf = (unsigned)T * B * 4u, nf1 = (unsigned)(T + 1) * B * 4u;  // < 2^31 (host-checked)
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.r), 0, (int)nf, 0x00020000);
+    const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, CRITIC ? (int)nf1 : 0, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.d), 0, (int)(nf1 / 4), 0x00020000);
+    const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.m), 0, MASK ? (int)(nf / 4) : 0, 0x00020000);
+    const auto rs_adv = __builtin_amdgcn_make_buffer_rsrc(a.adv, 0, (int)nf, 0x00020000);
+    const auto rs_ret = __builtin_amdgcn_make_buffer_rsrc(a.ret, 0, (int)nf, 0x00020000);
+    // inactive lanes (e0 >= B) park their offset past every buffer: hardware bounds-checking returns 0 / drops stores
+    const unsigned vo4 = active ? e0 * 4u : 0x7fffffffu, vo1 = active ? e0 : 0x7fffffffu;
+
+    float r[SEG][VEC], v[SEG][VEC], vtop[VEC];
+    uint32_t dn[SEG], mk[SEG];
+    // rows past the end of a ragged last segment re-load row T-1 (valid memory, value unused): a clamped
+    // address keeps the loads branch-free, a per-row predicate would make hipcc drain vmcnt(0) per row
+#pragma unroll
+    for (int u = SEG - 1; u >= 0; --u) {  // latest row first: that is the order the recurrence consumes them
+        const unsigned t = (unsigned)min(t_lo + u, T - 1);
+        bld<VEC, NT>(rs_r, vo4, t * B * 4u, r[u]);
+        if constexpr (CRITIC) bld<VEC, NT>(rs_v, vo4, t * B * 4u, v[u]);
+        dn[u] = bldb<VEC, NT>(rs_d, vo1, (t + 1) * B);
+        if constexpr (MASK) mk[u] = bldb<VEC, NT>(rs_m, vo1, t * B);
+        else mk[u] = 0x01010101u;
+    }
+    if constexpr (CRITIC) bld<VEC, false>(rs_v, vo4, (unsigned)min(t_hi, T) * B * 4u, vtop);
+
+    Moments mo;
+    for (int s = NSEG - 1; s >= 0; --s) {
+        if (s == seg && active && t_hi > t_lo) {
+            float g[VEC], vnext[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                g[k] = (t_hi == T) ? 0.f : s_g[lane * VEC + k];
+                vnext[k] = CRITIC ? vtop[k] : 0.f;
+            }
+#pragma unroll
+            for (int u = SEG - 1; u >= 0; --u) {
+                if (t_lo + u < t_hi) {  // wave-uniform
+                    float adv[VEC], ret[VEC];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const bool done = (dn[u] >> (8 * k)) & 0xffu;
+                        const bool on = (mk[u] >> (8 * k)) & 0xffu;
+                        const float vk = CRITIC ? v[u][k] : 0.f;
+                        gae_step(r[u][k], vk, vnext[k], done ? 0.f : 1.f, CRITIC, a.gamma, a.gl, g[k], adv[k], ret[k]);
+                        mo.add(adv[k], ret[k], on);
+                        vnext[k] = vk;
+                    }
+                    const unsigned row = (unsigned)(t_lo + u) * B * 4u;
+                    bst<VEC, NT>(rs_adv, vo4, row, adv);
+                    bst<VEC, NT>(rs_ret, vo4, row, ret);
+                }
+            }
+            if (s > 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) s_g[lane * VEC + k] = g[k];
+            }
+        }
+        if (NSEG > 1 && s > 0) __syncthreads();
+    }
+    flush_moments(mo, a.partials, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic time-chunk layout (C > 1): one lane per env, sequential, strided addressing.
 //   time step t = k*C + c  ->  element ((k*B + b)*C + c); dones use flat rows shifted by C-1
 //   (the reference keeps the LAST T+1 rows of the (n+1)*C flattened done rows, utils.py:111-114),
@@ -406,12 +534,47 @@ int launch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
 // (profiles/r01_gae_variant_sweep.txt) showed wider vectors, deeper batches and nt accesses never win
 // (fewer waves in flight outweighs the wider loads), so they are compiled out rather than shipped.
 template <int NSEG>
-int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
+int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk, int rows = 8, bool nt = false) {
     const bool critic = a.v != nullptr, mask = a.m != nullptr;
+    if constexpr (NSEG == 1) {  // streaming-scan tuning variants (critic, no mask: the bench / sweep configuration)
+        if (critic && !mask) {
+            if (rows == 16) return nt ? launch_c1<1, 1, 16, true, true, false>(a, s, nblk) : launch_c1<1, 1, 16, false, true, false>(a, s, nblk);
+            if (rows == 32) return nt ? launch_c1<1, 1, 32, true, true, false>(a, s, nblk) : launch_c1<1, 1, 32, false, true, false>(a, s, nblk);
+            if (rows == 64) return nt ? launch_c1<1, 1, 64, true, true, false>(a, s, nblk) : launch_c1<1, 1, 64, false, true, false>(a, s, nblk);
+            if (rows == 128) return nt ? launch_c1<1, 1, 128, true, true, false>(a, s, nblk) : launch_c1<1, 1, 128, false, true, false>(a, s, nblk);
+            if (nt) return launch_c1<1, 1, 8, true, true, false>(a, s, nblk);
+        }
+    }
     if (critic && !mask) return launch_c1<1, NSEG, 8, false, true, false>(a, s, nblk);
     if (critic && mask) return launch_c1<1, NSEG, 8, false, true, true>(a, s, nblk);
     if (!critic && mask) return launch_c1<1, NSEG, 8, false, false, true>(a, s, nblk);
     return launch_c1<1, NSEG, 8, false, false, false>(a, s, nblk);
+}
+
+template <int VEC, int NSEG, int SEG, bool NT>
+int launch_regseg(const GaeArgs& a, hipStream_t s) {
+    const int nblk = ceil_div(a.B, 64 * VEC);
+    const bool critic = a.v != nullptr, mask = a.m != nullptr;
+    const dim3 g(nblk), b(64 * NSEG);
+    if (critic && !mask) hipLaunchKernelGGL((gae_scan_regseg<VEC, NSEG, SEG, NT, true, false>), g, b, 0, s, a);
+    else if (critic && mask) hipLaunchKernelGGL((gae_scan_regseg<VEC, NSEG, SEG, NT, true, true>), g, b, 0, s, a);
+    else if (!critic && mask) hipLaunchKernelGGL((gae_scan_regseg<VEC, NSEG, SEG, NT, false, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((gae_scan_regseg<VEC, NSEG, SEG, NT, false, false>), g, b, 0, s, a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+// register-resident segments of SEG steps: NSEG = ceil(T / SEG) waves per block (at most 16 waves)
+template <int VEC, int SEG, bool NT>
+int dispatch_regseg(const GaeArgs& a, hipStream_t s) {
+    const int nseg = ceil_div(a.T, SEG);
+    if (nseg <= 1) return launch_regseg<VEC, 1, SEG, NT>(a, s);
+    if (nseg <= 2) return launch_regseg<VEC, 2, SEG, NT>(a, s);
+    if (nseg <= 4) return launch_regseg<VEC, 4, SEG, NT>(a, s);
+    if (nseg <= 8) return launch_regseg<VEC, 8, SEG, NT>(a, s);
+    if (nseg <= 16) return launch_regseg<VEC, 16, SEG, NT>(a, s);
+    set_error("rlx_gae_scan: the register-resident variant needs T <= %d (T=%d)", 16 * SEG, a.T);
+    return RLX_EINVAL;
 }
 
 int standardize_grid(size_t n) {
@@ -468,6 +631,8 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
     } else {
         // variant word: bits 0-7 envs per lane (only 1 is compiled in), bits 8-15 time segments
         int vec = p->variant & 0xff, nseg = (p->variant >> 8) & 0xff;
+        const int rows = (p->variant >> 16) & 0xff;   // rows per register batch (0 = 8)
+        const bool nt = (p->variant >> 25) & 1;        // nontemporal loads/stores
         if (p->variant == 0) {
             // auto, from the MI355X sweep: with >= 4 env groups per CU the pure streaming scan is the
             // fastest (and bit-exact); below that, split time over just enough waves to reach that
@@ -483,6 +648,25 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         }
         if (vec == 0) vec = 1;
         if (nseg == 0) nseg = 1;
+        const bool regseg = (p->variant >> 26) & 1;  // register-resident 32-step segments, serial carry chain
+        if (regseg) {
+            RLX_REQUIRE(vec == 1 || vec == 2 || vec == 4, "rlx_gae_scan: regseg vec=%d", vec);
+            RLX_REQUIRE(batch % vec == 0, "rlx_gae_scan: regseg vec=%d needs batch %% vec == 0 (batch=%d)", vec, batch);
+            RLX_REQUIRE((unsigned long long)(a.T + 1) * (unsigned long long)batch * 4ull < (1ull << 31),
+                        "rlx_gae_scan: regseg addresses rows through 32-bit buffer offsets: (T+1)*B*4 must stay below 2 GiB");
+            const uintptr_t al = (uintptr_t)rewards | (uintptr_t)values | (uintptr_t)advantages | (uintptr_t)returns;
+            RLX_REQUIRE(vec == 1 || al % (4 * vec) == 0, "rlx_gae_scan: regseg vec=%d needs %d-byte aligned buffers", vec, 4 * vec);
+            nblk = ceil_div(batch, 64 * vec);
+            const bool seg16 = (p->variant >> 27) & 1;  // 16-step segments (twice the waves, half the registers)
+            int rc;
+            // VEC = 4 keeps 16-step segments only: 32 x 4 x 9 B = 288 data registers makes hipcc spill
+            if (vec == 4) rc = nt ? dispatch_regseg<4, 16, true>(a, s) : dispatch_regseg<4, 16, false>(a, s);
+            else if (vec == 2 && seg16) rc = nt ? dispatch_regseg<2, 16, true>(a, s) : dispatch_regseg<2, 16, false>(a, s);
+            else if (vec == 2) rc = nt ? dispatch_regseg<2, 32, true>(a, s) : dispatch_regseg<2, 32, false>(a, s);
+            else if (seg16) rc = nt ? dispatch_regseg<1, 16, true>(a, s) : dispatch_regseg<1, 16, false>(a, s);
+            else rc = nt ? dispatch_regseg<1, 32, true>(a, s) : dispatch_regseg<1, 32, false>(a, s);
+            if (rc != RLX_OK) return rc;
+        } else {
         if (vec != 1) {
             set_error("rlx_gae_scan: vec=%d is compiled out (no gain on MI355X, see profiles/r01_gae_variant_sweep.txt)", vec);
             return RLX_ENOSYS;
@@ -494,13 +678,14 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         nblk = ceil_div(batch, 64);
         int rc = RLX_ENOSYS;
         switch (nseg) {
-            case 1: rc = dispatch_c1<1>(a, s, nblk); break;
+            case 1: rc = dispatch_c1<1>(a, s, nblk, rows ? rows : 8, nt); break;
             case 2: rc = dispatch_c1<2>(a, s, nblk); break;
             case 4: rc = dispatch_c1<4>(a, s, nblk); break;
             case 8: rc = dispatch_c1<8>(a, s, nblk); break;
             case 16: rc = dispatch_c1<16>(a, s, nblk); break;
         }
         if (rc != RLX_OK) return rc;
+        }
     }
     if (p->normalize_advantages) {
         hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, advantages, n,

@@ -51,10 +51,37 @@ __global__ __launch_bounds__(256) void bootstrap_rewards_kernel(float* __restric
     if (flags[i]) r[i] = fadd(r[i], fmul(gamma, v[(size_t)b * vs]));
 }
 
+// a7: one env step's outputs -> trajectory-buffer rows (rewards[t], terminations / truncations / dones[t+1])
+__global__ __launch_bounds__(256) void store_env_rows_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ term,
+                                                             const uint8_t* __restrict__ trunc, float* __restrict__ r_row,
+                                                             uint8_t* __restrict__ d_row, uint8_t* __restrict__ te_row,
+                                                             uint8_t* __restrict__ tr_row, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t te = term[i] != 0, tr = trunc[i] != 0;
+    r_row[i] = rewards[i];
+    te_row[i] = te;
+    tr_row[i] = tr;
+    d_row[i] = te | tr;  // dones = terminations | truncations (maniskill_env.py:343-350)
+}
+
 }  // namespace
 }  // namespace rlx
 
 using namespace rlx;
+
+extern "C" int rlx_store_env_rows(const float* rewards, const uint8_t* terminations, const uint8_t* truncations,
+                                  float* reward_row, uint8_t* done_row, uint8_t* termination_row, uint8_t* truncation_row,
+                                  int64_t n, rlx_stream_t stream) {
+    RLX_REQUIRE(n >= 0, "rlx_store_env_rows: negative size");
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(rewards && terminations && truncations && reward_row && done_row && termination_row && truncation_row,
+                "rlx_store_env_rows: NULL argument");
+    hipLaunchKernelGGL(store_env_rows_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rewards,
+                       terminations, truncations, reward_row, done_row, termination_row, truncation_row, (int)n);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
 
 extern "C" int rlx_bootstrap_rewards(float* rewards, const uint8_t* flags, const float* bootstrap_values, int batch, int chunk,
                                      int value_stride, float gamma, rlx_stream_t stream) {

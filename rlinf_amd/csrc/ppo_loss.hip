@@ -15,14 +15,13 @@
 
 #include <algorithm>
 
+#include "ppo_loss_math.h"
 #include "rlx_common.h"
 
 namespace rlx {
 namespace {
 
-constexpr int NS = 16;  // reduction slots
-enum { S_NM = 0, S_LOSS, S_ABS, S_RATIO, S_RABS, S_CLIPPED, S_DUAL, S_KL, S_CLIPFRAC, S_VLOSS, S_VIND,
-       S_EVN, S_EVR, S_EVRR, S_EVE, S_EVEE };
+using namespace loss;
 
 struct LossArgs {
     const float* lp;
@@ -40,17 +39,6 @@ struct LossArgs {
     rlx_ppo_loss_params p;
 };
 
-__device__ __forceinline__ float huber(float e, float delta, float half_delta) {
-    const float ae = fabsf(e);
-    return ae < delta ? fmul(0.5f, fmul(e, e)) : fmul(delta, fsub(ae, half_delta));
-}
-__device__ __forceinline__ float huber_grad(float e, float delta) {
-    const float ae = fabsf(e);
-    return ae < delta ? e : (e > 0.f ? delta : (e < 0.f ? -delta : 0.f));
-}
-__device__ __forceinline__ float tie_weight_gt(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
-__device__ __forceinline__ float tie_weight_lt(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
-
 template <bool VEC4>
 __global__ __launch_bounds__(256) void ppo_loss_fwd_kernel(LossArgs a) {
     __shared__ double s_red[NS * 4];
@@ -65,11 +53,9 @@ __global__ __launch_bounds__(256) void ppo_loss_fwd_kernel(LossArgs a) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < a.n; e += stride) {
         const bool on = a.m ? a.m[e] != 0 : true;
-        const float mf = on ? 1.f : 0.f;
         float w = 1.f;
         if (ratio_mode) w = ((float)a.msum[e] * 1.0f) / (float)p.max_episode_steps;
         const float adv = a.adv[e];
-        const float nadv = -adv;
         acc[S_NM] += on ? 1.0 : 0.0;
         const float* lpp = a.lp + e * K;
         const float* olp = a.old + e * K;
@@ -88,66 +74,11 @@ __global__ __launch_bounds__(256) void ppo_loss_fwd_kernel(LossArgs a) {
                     old = fadd(old, olp[s * R + j]);
                 }
             }
-            float lr = fsub(lp, old);
-            float cg = 1.f;  // gradient of the two log-ratio clamps
-            if (p.use_clip_log_ratio_min) {
-                if (!(lr >= p.clip_log_ratio_min)) cg = 0.f;
-                lr = fmaxf(lr, p.clip_log_ratio_min);
-            }
-            if (p.use_clip_log_ratio_max) {
-                if (!(lr <= p.clip_log_ratio_max)) cg = 0.f;
-                lr = fminf(lr, p.clip_log_ratio_max);
-            }
-            const float ratio = on ? expf(lr) : 0.f;
-            const float clipped = fminf(fmaxf(ratio, p.ratio_lo), p.ratio_hi);
-            const float pl1 = fmul(nadv, ratio), pl2 = fmul(nadv, clipped);
-            float pl = fmaxf(pl1, pl2);
-            const float w1 = tie_weight_gt(pl1, pl2);
-            const float in_rng = (ratio >= p.ratio_lo && ratio <= p.ratio_hi) ? 1.f : 0.f;
-            float dpl = nadv * (w1 + (1.f - w1) * in_rng);
-            bool dual = false;
-            if (p.use_dual_clip) {
-                const float sgn = adv > 0.f ? 1.f : (adv < 0.f ? -1.f : 0.f);
-                const float pl3 = fmul(fmul(sgn, p.clip_ratio_c), adv);
-                dual = pl3 < pl;
-                dpl *= tie_weight_lt(pl, pl3);
-                pl = fminf(pl, pl3);
-            }
-            const float contrib = ratio_mode ? fmul(pl / w, mf) : fmul(pl, mf);
-            const float contrib_abs = ratio_mode ? fmul(fabsf(pl) / w, mf) : fmul(fabsf(pl), mf);
-            acc[S_LOSS] += (double)contrib;
-            acc[S_ABS] += (double)contrib_abs;
-            acc[S_RATIO] += (double)fmul(ratio, mf);
-            acc[S_RABS] += (double)fmul(fabsf(fsub(ratio, 1.f)), mf);
-            acc[S_CLIPPED] += (double)fmul(clipped, mf);
-            acc[S_DUAL] += (dual && on) ? (double)ratio : 0.0;
-            acc[S_KL] += on ? (double)lr : 0.0;
-            acc[S_CLIPFRAC] += (pl1 < pl2 && on) ? 1.0 : 0.0;
-            float g = p.critic_warmup ? 0.f : dpl * ratio * cg * mf;  // ratio == d exp(lr)/d lr, 0 when masked
-            if (ratio_mode) g = g / w;
+            const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, acc);
             a.g_lp[e * S + s] = g;
         }
         if (p.has_critic) {
-            const float v = a.v[e], pv = a.pv[e], ret = a.ret[e];
-            const float diff = fsub(v, pv);
-            const float cl = fminf(fmaxf(diff, -p.value_clip), p.value_clip);
-            const float vclip = fadd(pv, cl);
-            const float e1 = fsub(ret, v), e2 = fsub(ret, vclip);
-            const float h1 = huber(e1, p.huber_delta, half_delta), h2 = huber(e2, p.huber_delta, half_delta);
-            const float h = fmaxf(h1, h2);
-            acc[S_VLOSS] += (double)(ratio_mode ? fmul(h / w, mf) : fmul(h, mf));
-            acc[S_VIND] += fabsf(fsub(vclip, pv)) > p.value_clip ? 1.0 : 0.0;
-            if (on) {
-                acc[S_EVN] += 1.0;
-                acc[S_EVR] += (double)ret;
-                acc[S_EVRR] += (double)fmul(ret, ret);
-                acc[S_EVE] += (double)e1;
-                acc[S_EVEE] += (double)fmul(e1, e1);
-            }
-            const float wh1 = tie_weight_gt(h1, h2);
-            const float pass = (diff >= -p.value_clip && diff <= p.value_clip) ? 1.f : 0.f;
-            float gv = -(wh1 * huber_grad(e1, p.huber_delta) + (1.f - wh1) * huber_grad(e2, p.huber_delta) * pass) * mf;
-            if (ratio_mode) gv = gv / w;
+            const float gv = critic_elem(p, a.v[e], a.pv[e], a.ret[e], on, w, ratio_mode, half_delta, acc);
             a.g_v[e] = gv;
         }
     }
@@ -171,37 +102,7 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize(const double* partials,
     }
     block_sum<NS>(acc, s_red);
     if (threadIdx.x != 0) return;
-    const double L = (double)n_adv * p.sub_per_adv;  // loss elements
-    const double Lc = (double)n_adv;
-    const double nm = acc[S_NM];
-    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
-    // masked_mean: sum/sum(mask); all-False mask -> plain sum (which is 0); no mask -> mean
-    const double den_actor = ratio_mode ? L : (has_mask ? (nm > 0 ? nm : 1.0) : L);
-    const double den_critic = ratio_mode ? Lc : (has_mask ? (nm > 0 ? nm : 1.0) : Lc);
-    const double den_metric = has_mask ? (nm > 0 ? nm * p.sub_per_adv : 1.0) : L;
-    const double count = has_mask ? (nm > 0 ? nm : 1.0) : L;  // loss_mask.count_nonzero() or 1
-    const float policy_loss = p.critic_warmup ? 0.f : (float)(acc[S_LOSS] / den_actor);
-    const float value_loss = p.has_critic ? (float)(acc[S_VLOSS] / den_critic) : 0.f;
-    out[RLX_PPO_LOSS] = policy_loss + value_loss;
-    out[RLX_PPO_POLICY_LOSS] = policy_loss;
-    out[RLX_PPO_POLICY_LOSS_ABS] = (float)(acc[S_ABS] / den_actor);
-    out[RLX_PPO_RATIO] = (float)(acc[S_RATIO] / den_metric);
-    out[RLX_PPO_RATIO_ABS] = (float)(acc[S_RABS] / den_metric);
-    out[RLX_PPO_CLIPPED_RATIO] = (float)(acc[S_CLIPPED] / den_metric);
-    out[RLX_PPO_DUAL_CLIPPED_RATIO] = (float)(acc[S_DUAL] / den_metric);
-    out[RLX_PPO_APPROX_KL] = (float)(-acc[S_KL] / count);
-    out[RLX_PPO_CLIP_FRACTION] = (float)(acc[S_CLIPFRAC] / count);
-    out[RLX_PPO_VALUE_LOSS] = value_loss;
-    out[RLX_PPO_VALUE_CLIP_RATIO] = p.has_critic ? (float)(acc[S_VIND] / Lc) : 0.f;
-    out[RLX_PPO_EV_COUNT] = (float)acc[S_EVN];
-    out[RLX_PPO_EV_RETURNS_SUM] = (float)acc[S_EVR];
-    out[RLX_PPO_EV_RETURNS_SQ_SUM] = (float)acc[S_EVRR];
-    out[RLX_PPO_EV_ERRORS_SUM] = (float)acc[S_EVE];
-    out[RLX_PPO_EV_ERRORS_SQ_SUM] = (float)acc[S_EVEE];
-    out[RLX_PPO_ACTOR_GRAD_SCALE] = (float)(1.0 / den_actor);
-    out[RLX_PPO_CRITIC_GRAD_SCALE] = (float)(1.0 / den_critic);
-    out[18] = (float)nm;
-    out[19] = 0.f;
+    finalize_row(p, n_adv, has_mask != 0, has_msum != 0, acc, out);
 }
 
 __global__ __launch_bounds__(256) void ppo_loss_bwd_kernel(const float* g_lp, const float* g_v, const float* out,

@@ -1,0 +1,907 @@
+// ppo_step.hip -- the two hot launches of the actor-learner loop, gfx950:
+//
+//   rlx_mlp_rollout_step   ONE launch per rollout step: obs-preprocess -> actor + value MLPs -> Gaussian sample,
+//                          log-prob, value, written straight into the trajectory-buffer rows; value-only jobs
+//                          (bootstrap value of the previous step's terminal observations folded into that step's
+//                          reward row; the closing value row) ride in the same grid.
+//                          replaces MLPPolicy.predict_action_batch (mlp_policy.py:295-320),
+//                          MultiStepRolloutWorker.get_bootstrap_values (huggingface_worker.py:612-627) and
+//                          EnvWorker.compute_bootstrap_rewards (env_worker.py:718-758).
+//   rlx_ppo_step           one optimizer step's forward + loss + backward in TWO launches:
+//     (1) ppo_step_fused   per 32-row tile and network: training forward (mlp_policy.py:202-236), PPO actor / critic
+//                          loss element math + metric sums (losses.py:170-380), loss backward, backward-data chain.
+//                          Everything a row needs is row-local once the mean's denominator is known (the kernel
+//                          counts the loss mask itself), so activations never leave the CU between layers: the tile
+//                          lives in one LDS slab that is overwritten in place, the tanh derivative factors stay in
+//                          registers (96 VGPRs) from the forward sweep to the backward sweep.
+//     (2) ppo_step_dw      weight gradients dW_l = dZ_l^T H_{l-1} as split-K (over batch rows) 128x128 MFMA tiles into
+//                          per-slab gradient buffers, bias gradients as column sums, head gradients folded in from
+//                          the per-tile partials of (1), and the metric row finalised by the last block.
+//
+// Dense layers run on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate = an fmaf chain; 32-cycle issue):
+// a wave owns RT x CT tiles of 16x16 and feeds 4 MFMAs per operand from ONE ds_read_b128 (lane l holds k-block
+// l>>4; the k permutation is the same for A and B).  Weights stream L2 -> registers -> LDS in double-buffered
+// 16-k chunks, one barrier per chunk; two workgroups per CU keep each SIMD's matrix pipe busy while its other wave
+// sits in an epilogue or a barrier.
+
+#include <algorithm>
+
+#include "ppo_loss_math.h"
+#include "rlx_common.h"
+
+namespace rlx {
+namespace {
+
+using namespace loss;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HID = 256;   // hidden width (fixed by the reference: hidden_sizes=(256,256,256))
+constexpr int XS = 264;    // activation slab row stride (floats); stride % 16 == 8 -> conflict-free b128 fragment reads
+constexpr int KC = 16;     // k per weight chunk
+constexpr int WSF = 20;    // forward chunk image  [256 n][KC + 4]
+constexpr int WSB = 260;   // backward chunk image [KC k][256 + 4]
+constexpr int WC_FLOATS = 2 * HID * WSF;  // chunk double buffer (the backward image 2*16*260 is smaller)
+constexpr int W4S = 260;   // head weight image row stride
+constexpr int MAX_OUT = 16;  // head outputs supported by the fused kernels (act_dim, val_dim)
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+template <int RT, int NW>
+struct Geo {
+    static constexpr int BM = 16 * RT;          // rows per workgroup tile
+    static constexpr int NT = 64 * NW;          // threads
+    static constexpr int CT = HID / (16 * NW);  // 16-column tiles per wave
+    static constexpr int NLD = 1024 / NT;       // float4 staging loads per thread per weight chunk
+    static constexpr size_t LDS_BYTES = (size_t)(BM * XS + WC_FLOATS) * sizeof(float) + 4096;
+};
+
+template <int RT, int CT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][CT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int RT, int CT>
+__device__ __forceinline__ void mfma_step(const f32x4 (&a)[RT], const f32x4 (&b)[CT], f32x4 (&acc)[RT][CT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], b[ct][q], acc[rt][ct], 0, 0, 0);
+}
+
+// acc = X[0:BM, 0:K] . Wg[0:256, 0:K]^T      Wg row-major [256][ldw]  (a Linear's weight: out x in)
+// VEC: rows are 16-byte aligned and K % 4 == 0 (the hidden layers); otherwise scalar loads with a k < K guard (the
+// first layer: obs_dim = 42 gives 168-byte rows).  All threads must call; ends with a workgroup barrier.
+template <int RT, int NW, bool VEC>
+__device__ __forceinline__ void gemm_fwd(const float* __restrict__ Wg, int ldw, int K, const float* X, float* Wc,
+                                         f32x4 (&acc)[RT][Geo<RT, NW>::CT]) {
+    typedef Geo<RT, NW> G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    zero_acc(acc);
+    f32x4 stage[G::NLD];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) {
+            const int f = tid + G::NT * i, n = f >> 2, k = c * KC + (f & 3) * 4;
+            if constexpr (VEC) {
+                stage[i] = k < K ? *reinterpret_cast<const f32x4*>(Wg + (size_t)n * ldw + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const float* p = Wg + (size_t)n * ldw + k;
+                f32x4 v;
+                v[0] = k + 0 < K ? p[0] : 0.f;
+                v[1] = k + 1 < K ? p[1] : 0.f;
+                v[2] = k + 2 < K ? p[2] : 0.f;
+                v[3] = k + 3 < K ? p[3] : 0.f;
+                stage[i] = v;
+            }
+        }
+    };
+    auto swrite = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) {
+            const int f = tid + G::NT * i;
+            *reinterpret_cast<f32x4*>(buf + (f >> 2) * WSF + (f & 3) * 4) = stage[i];
+        }
+    };
+    const int nchunks = (K + KC - 1) / KC;
+    gload(0);
+    swrite(Wc);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* cur = Wc + (c & 1) * HID * WSF;
+        if (c + 1 < nchunks) gload(c + 1);
+        f32x4 a[RT], b[G::CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(X + (rt * 16 + r16) * XS + c * KC + 4 * kq);
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+            b[ct] = *reinterpret_cast<const f32x4*>(cur + (wave * 16 * G::CT + ct * 16 + r16) * WSF + 4 * kq);
+        mfma_step(a, b, acc);
+        if (c + 1 < nchunks) swrite(Wc + ((c + 1) & 1) * HID * WSF);
+        __syncthreads();
+    }
+}
+
+// acc = X[0:BM, 0:256] . Wg[0:256, 0:256]      (backward-data: dH = dZ . W, W row-major [out = k][in = j])
+template <int RT, int NW>
+__device__ __forceinline__ void gemm_bwd(const float* __restrict__ Wg, const float* X, float* Wc,
+                                         f32x4 (&acc)[RT][Geo<RT, NW>::CT]) {
+    typedef Geo<RT, NW> G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    zero_acc(acc);
+    f32x4 stage[G::NLD];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) {
+            const int f = tid + G::NT * i;
+            stage[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(c * KC + (f >> 6)) * HID + (f & 63) * 4);
+        }
+    };
+    auto swrite = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < G::NLD; ++i) {
+            const int f = tid + G::NT * i;
+            *reinterpret_cast<f32x4*>(buf + (f >> 6) * WSB + (f & 63) * 4) = stage[i];
+        }
+    };
+    constexpr int nchunks = HID / KC;
+    gload(0);
+    swrite(Wc);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* cur = Wc + (c & 1) * KC * WSB;
+        if (c + 1 < nchunks) gload(c + 1);
+        f32x4 a[RT], b[G::CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(X + (rt * 16 + r16) * XS + c * KC + 4 * kq);
+#pragma unroll
+        for (int ct = 0; ct < G::CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[ct][q] = cur[(4 * kq + q) * WSB + wave * 16 * G::CT + ct * 16 + r16];
+        mfma_step(a, b, acc);
+        if (c + 1 < nchunks) swrite(Wc + ((c + 1) & 1) * KC * WSB);
+        __syncthreads();
+    }
+}
+
+// coalesced copy of the slab's first 256 columns to a row-major [M][256] global array (1 KiB per row)
+template <int RT, int NW>
+__device__ __forceinline__ void flush_rows(const float* X, float* __restrict__ dst, long long m0, long long M) {
+    typedef Geo<RT, NW> G;
+    for (int f = threadIdx.x; f < G::BM * 64; f += G::NT) {
+        const int row = f >> 6, c4 = (f & 63) * 4;
+        if (m0 + row < M) *reinterpret_cast<f32x4*>(dst + (size_t)(m0 + row) * HID + c4) = *reinterpret_cast<const f32x4*>(X + row * XS + c4);
+    }
+}
+
+// obs-preprocess: the state rows themselves (mlp_policy.py:122-124); zero-pad the k tail and the rows past M.
+// states_copy: optional second destination (forward_inputs.states row of the trajectory buffer).
+template <int RT, int NW>
+__device__ __forceinline__ void load_states(const float* __restrict__ states, float* __restrict__ states_copy, int D,
+                                            long long m0, long long M, float* X) {
+    typedef Geo<RT, NW> G;
+    const int kp = round_up(D, KC);
+    for (int i = threadIdx.x; i < G::BM * kp; i += G::NT) {
+        const int r = i / kp, c = i % kp;
+        float v = 0.f;
+        if (c < D && m0 + r < M) {
+            v = states[(size_t)(m0 + r) * D + c];
+            if (states_copy) states_copy[(size_t)(m0 + r) * D + c] = v;
+        }
+        X[r * XS + c] = v;
+    }
+}
+
+// forward hidden-layer epilogue: h = tanh(acc + bias) -> slab (in place); KEEP: remember 1 - h^2 per element
+template <int RT, int NW, bool KEEP>
+__device__ __forceinline__ void epilogue_tanh(const f32x4 (&acc)[RT][Geo<RT, NW>::CT], const float* __restrict__ bias, float* X,
+                                              f32x4 (*kept)[Geo<RT, NW>::CT]) {
+    typedef Geo<RT, NW> G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) {
+        const int col = wave * 16 * G::CT + ct * 16 + r16;
+        const float b = bias[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = tanhf(acc[rt][ct][r] + b);
+                X[(rt * 16 + 4 * kq + r) * XS + col] = h;
+                if constexpr (KEEP) kept[rt][ct][r] = 1.f - h * h;
+            }
+    }
+    __syncthreads();
+}
+
+// stage the head weight [n_out][256] (+ bias) into LDS with a padded row stride
+__device__ __forceinline__ void stage_head(const float* __restrict__ W4, const float* __restrict__ b4, int n_out, float* W4s,
+                                           float* b4s, int nthreads) {
+    for (int f = threadIdx.x; f < n_out * 64; f += nthreads) {
+        const int o = f >> 6, c4 = (f & 63) * 4;
+        *reinterpret_cast<f32x4*>(W4s + o * W4S + c4) = *reinterpret_cast<const f32x4*>(W4 + (size_t)o * HID + c4);
+    }
+    if ((int)threadIdx.x < n_out) b4s[threadIdx.x] = b4 ? b4[threadIdx.x] : 0.f;
+}
+
+// head output (row, o): fmaf chain over the 256 hidden units in k order, then the bias
+__device__ __forceinline__ float head_dot(const float* xr, const float* wr, float bias, bool has_bias) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < HID; j += 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xr + j);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wr + j);
+        s = fmaf(x[0], w[0], s);
+        s = fmaf(x[1], w[1], s);
+        s = fmaf(x[2], w[2], s);
+        s = fmaf(x[3], w[3], s);
+    }
+    if (has_bias) s += bias;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rollout step: RT = 1 (16-row tiles), NW = 8 (512 threads): latency matters, B is ~1024 rows per step
+// ---------------------------------------------------------------------------------------------------------------
+struct ValueJob {
+    const float* states;
+    long long m;
+    float* values;         // [m, val_dim] or nullptr
+    float* rewards;        // [m, chunk] in place, or nullptr
+    const uint8_t* flags;  // [m, chunk]
+    int chunk;
+    float gamma;
+};
+struct RolloutArgs {
+    const float* params;
+    rlx_mlp_layout lay;
+    const float* states;   // policy job (may be nullptr with M == 0)
+    const float* eps;
+    long long M;
+    float* action;
+    float* logprob;
+    float* value;
+    float* states_copy;
+    ValueJob vj[2];
+    int tiles_policy, tiles_vj0, tiles_vj1;
+};
+
+__global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
+    constexpr int RT = 1, NW = 8;
+    typedef Geo<RT, NW> G;
+    extern __shared__ __align__(16) float smem[];
+    float* X = smem;
+    float* Wc = smem + G::BM * XS;
+    float* W4s = Wc;                      // the chunk buffer is free once the last GEMM has passed its barrier
+    float* b4s = W4s + MAX_OUT * W4S;
+    const rlx_mlp_layout& lay = a.lay;
+    const int D = lay.obs_dim, tid = threadIdx.x;
+
+    int b = blockIdx.x, y, job;  // job 0 = policy (y = net), 1 / 2 = value-only jobs
+    long long m0, M;
+    const float* states;
+    float* states_copy = nullptr;
+    if (b < 2 * a.tiles_policy) {
+        job = 0; y = b & 1; m0 = (long long)(b >> 1) * G::BM; M = a.M; states = a.states;
+        if (y == 1) states_copy = a.states_copy;
+    } else {
+        b -= 2 * a.tiles_policy;
+        job = b < a.tiles_vj0 ? 1 : 2;
+        if (job == 2) b -= a.tiles_vj0;
+        y = 0; m0 = (long long)b * G::BM; M = a.vj[job - 1].m; states = a.vj[job - 1].states;
+    }
+    load_states<RT, NW>(states, states_copy, D, m0, M, X);
+    f32x4 acc[RT][G::CT];
+    gemm_fwd<RT, NW, false>(a.params + lay.off_w[y][0], D, D, X, Wc, acc);
+    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][0], X, nullptr);
+    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][1], HID, HID, X, Wc, acc);
+    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][1], X, nullptr);
+    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][2], HID, HID, X, Wc, acc);
+    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][2], X, nullptr);
+
+    const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    __syncthreads();
+    for (int idx = tid; idx < G::BM * n_out; idx += G::NT) {
+        const int row = idx / n_out, o = idx % n_out;
+        const float s = head_dot(X + row * XS, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
+        if (m0 + row >= M) continue;
+        const size_t g = (size_t)(m0 + row) * n_out + o;
+        if (job == 0 && y == 0) {
+            a.value[g] = s;
+        } else if (job == 0) {
+            const float mean = s;
+            const float logstd = a.params[lay.off_logstd + o];
+            const float stdv = expf(logstd);
+            const float act = a.eps ? fadd(fmul(a.eps[g], stdv), mean) : mean;  // torch.normal: eps*std + mean; eval: mean
+            const float d = fsub(act, mean);
+            const float var = fmul(stdv, stdv);
+            const float log_scale = logf(stdv);
+            // Normal.log_prob: -((x - loc)**2) / (2*var) - log(scale) - log(sqrt(2*pi))
+            a.logprob[g] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            a.action[g] = act;
+        } else {
+            const ValueJob& v = a.vj[job - 1];
+            if (v.values) v.values[g] = s;
+            if (v.rewards && o == 0) {  // r[:, -1] += gamma * V(final_obs)[:, 0] where flags[:, -1] (env_worker.py:744-758)
+                const size_t i = (size_t)(m0 + row) * v.chunk + (v.chunk - 1);
+                if (v.flags[i]) v.rewards[i] = fadd(v.rewards[i], fmul(v.gamma, s));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused optimizer-step kernel (1): forward + loss + backward-data for one tile of one network
+// ---------------------------------------------------------------------------------------------------------------
+struct StepArgs {
+    const float* params;
+    rlx_mlp_layout lay;
+    const float* states;        // [M, D]
+    const float* action;        // [M, act_dim]
+    const float* old_logprobs;  // [M, act_dim]
+    const float* advantages;    // [M * adv_per_row]
+    const float* prev_values;   // [M * adv_per_row] (has_critic)
+    const float* returns;
+    const uint8_t* loss_mask;   // [M * adv_per_row] or nullptr
+    const int64_t* loss_mask_sum;
+    long long M;
+    rlx_ppo_loss_params p;
+    float grad_out;             // d(total)/d(loss) of this micro-batch (1 / gradient_accumulation)
+    float* h;                   // [2 nets][2][M][256]  hidden activations 1, 2   (B operands of the weight gradients)
+    float* dz;                  // [2 nets][3][M][256]  pre-activation gradients  (A operands)
+    float* head_part;           // [tiles][2][head_stride]  per-tile head gradients: dW4 [n_out][256], db4 [n_out], dlogstd [n_out]
+    double* loss_part;          // [tiles][2][NS]
+    int head_stride;
+};
+
+template <int RT, int NW>
+__global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_step_fused_kernel(StepArgs a) {
+    typedef Geo<RT, NW> G;
+    constexpr int BM = G::BM, CT = G::CT;
+    extern __shared__ __align__(16) float smem[];
+    float* X = smem;
+    float* Wc = smem + BM * XS;
+    float* W4s = Wc;                                  // [MAX_OUT][W4S]   (chunk buffer reused between the GEMM sweeps)
+    float* b4s = W4s + MAX_OUT * W4S;                 // [MAX_OUT]
+    float* sHead = b4s + MAX_OUT;                     // [BM][MAX_OUT] head outputs, then d(loss)/d(head output)
+    float* sLp = sHead + BM * MAX_OUT;                // [BM][MAX_OUT] per-dimension log-probs, then per-dim d/d logstd
+    float* sG = sLp + BM * MAX_OUT;                   // [BM][MAX_OUT] d(loss)/d(summed log-prob)
+    float* sD = sG + BM * MAX_OUT;                    // [BM][MAX_OUT] action - mean
+    double* sRed = reinterpret_cast<double*>(Wc + WC_FLOATS);  // NS * NW doubles of reduction scratch ...
+    double* sNm = sRed + 256;                         // ... and the mask count (no static __shared__: it would shift the
+                                                      // dynamic region off its 16-byte alignment)
+
+    const rlx_mlp_layout& lay = a.lay;
+    const rlx_ppo_loss_params& p = a.p;
+    const int y = blockIdx.y, tile = blockIdx.x, D = lay.obs_dim, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    const long long m0 = (long long)tile * BM, M = a.M;
+    const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    const int K = p.raw_per_adv, S = p.sub_per_adv, R = K / S;
+    const int npr = lay.act_dim / K;                  // advantage elements per row
+    const long long n_adv = M * npr;
+    const bool has_mask = a.loss_mask != nullptr, has_msum = a.loss_mask_sum != nullptr;
+    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
+
+    // ---- mask count of the whole micro-batch (the mean's denominator): 1 byte per element, L2-resident ------------
+    if (has_mask) {
+        double cnt[1] = {0.0};
+        for (long long e = tid; e < n_adv; e += G::NT) cnt[0] += a.loss_mask[e] != 0 ? 1.0 : 0.0;
+        block_sum<1>(cnt, sRed);
+        if (tid == 0) sNm[0] = cnt[0];
+    }
+
+    // ---- forward -----------------------------------------------------------------------------------------------------
+    load_states<RT, NW>(a.states, nullptr, D, m0, M, X);
+    f32x4 acc[RT][CT];
+    f32x4 kept[3][RT][CT];  // 1 - h_l^2 in the accumulator layout: the backward epilogues need exactly these lanes
+    float* hy = a.h + (size_t)(y * 2) * M * HID;
+    float* dzy = a.dz + (size_t)(y * 3) * M * HID;
+    gemm_fwd<RT, NW, false>(a.params + lay.off_w[y][0], D, D, X, Wc, acc);
+    epilogue_tanh<RT, NW, true>(acc, a.params + lay.off_b[y][0], X, kept[0]);
+    flush_rows<RT, NW>(X, hy, m0, M);
+    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][1], HID, HID, X, Wc, acc);
+    epilogue_tanh<RT, NW, true>(acc, a.params + lay.off_b[y][1], X, kept[1]);
+    flush_rows<RT, NW>(X, hy + (size_t)M * HID, m0, M);
+    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][2], HID, HID, X, Wc, acc);
+    epilogue_tanh<RT, NW, true>(acc, a.params + lay.off_b[y][2], X, kept[2]);
+
+    // ---- head + loss element math ---------------------------------------------------------------------------------------
+    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    __syncthreads();
+    const double nm = has_mask ? sNm[0] : 0.0;
+    const Denoms den = denominators(p, n_adv, nm, has_mask, has_msum);
+    const float half_delta = (float)(0.5 * (double)p.huber_delta);
+    double lacc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
+
+    for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+        const int row = idx / n_out, o = idx % n_out;
+        const float s = head_dot(X + row * XS, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
+        sHead[row * MAX_OUT + o] = s;
+        if (y == 1) {
+            const bool valid = m0 + row < M;
+            const size_t g = (size_t)(m0 + row) * n_out + o;
+            const float stdv = expf(a.params[lay.off_logstd + o]);
+            const float act = valid ? a.action[g] : s;
+            const float d = fsub(act, s);
+            const float var = fmul(stdv, stdv);
+            const float log_scale = logf(stdv);
+            sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            sD[row * MAX_OUT + o] = d;
+        }
+    }
+    __syncthreads();
+    if (y == 1) {
+        // one thread per advantage element of the tile: summed log-probs -> ratio / clip / dual clip -> gradient
+        for (int idx = tid; idx < BM * npr; idx += G::NT) {
+            const int row = idx / npr, c = idx % npr;
+            if (m0 + row >= M) continue;
+            const long long e = (m0 + row) * npr + c;
+            const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+            float w = 1.f;
+            if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+            const float adv = a.advantages[e];
+            lacc[S_NM] += on ? 1.0 : 0.0;
+            const float* olp = a.old_logprobs + (size_t)(m0 + row) * lay.act_dim + c * K;
+            for (int s = 0; s < S; ++s) {
+                float lp = 0.f, old = 0.f;
+                for (int j = 0; j < R; ++j) {
+                    lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
+                    old = fadd(old, olp[s * R + j]);
+                }
+                const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
+                sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+            const int row = idx / n_out, o = idx % n_out;
+            float dmu = 0.f, dls = 0.f;
+            if (m0 + row < M) {
+                const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
+                const float stdv = expf(a.params[lay.off_logstd + o]);
+                const float var = stdv * stdv, d = sD[row * MAX_OUT + o];
+                dmu = dlp * d / var;                     // d logprob / d mean
+                dls = dlp * (d * d / var - 1.f);         // d logprob / d logstd
+            }
+            sHead[row * MAX_OUT + o] = dmu;
+            sLp[row * MAX_OUT + o] = dls;
+        }
+    } else {
+        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+            const int row = idx / n_out, o = idx % n_out;
+            float gv = 0.f;
+            if (m0 + row < M && p.has_critic) {
+                const long long e = (m0 + row) * n_out + o;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                gv = (a.grad_out * (float)(1.0 / den.critic)) *
+                     critic_elem(p, sHead[row * MAX_OUT + o], a.prev_values[e], a.returns[e], on, w, ratio_mode, half_delta, lacc);
+            }
+            sHead[row * MAX_OUT + o] = gv;  // overwritten by the thread that read it
+        }
+    }
+    __syncthreads();
+
+    // ---- head parameter gradients of this tile (h3 is still in the slab) -----------------------------------------------
+    {
+        float* part = a.head_part + ((size_t)tile * 2 + y) * a.head_stride;
+        for (int j = tid; j < HID; j += G::NT) {
+            float s[MAX_OUT];
+#pragma unroll
+            for (int o = 0; o < MAX_OUT; ++o) s[o] = 0.f;
+            for (int row = 0; row < BM; ++row) {
+                const float hv = X[row * XS + j];
+#pragma unroll
+                for (int o = 0; o < MAX_OUT; ++o)
+                    if (o < n_out) s[o] = fmaf(sHead[row * MAX_OUT + o], hv, s[o]);
+            }
+#pragma unroll
+            for (int o = 0; o < MAX_OUT; ++o)
+                if (o < n_out) part[o * HID + j] = s[o];
+        }
+        if (tid < n_out) {
+            float sb = 0.f, sl = 0.f;
+            for (int row = 0; row < BM; ++row) {
+                sb += sHead[row * MAX_OUT + tid];
+                sl += sLp[row * MAX_OUT + tid];
+            }
+            part[n_out * HID + tid] = sb;
+            part[n_out * HID + n_out + tid] = y == 1 ? sl : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- dZ3 = (dOut . W4) * (1 - h3^2), in the accumulator layout, into the slab ---------------------------------------
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * 16 * CT + ct * 16 + r16;
+        float w4[MAX_OUT];
+#pragma unroll
+        for (int o = 0; o < MAX_OUT; ++o) w4[o] = o < n_out ? W4s[o * W4S + col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + 4 * kq + r;
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < MAX_OUT; ++o)
+                    if (o < n_out) s = fmaf(sHead[row * MAX_OUT + o], w4[o], s);
+                acc[rt][ct][r] = s * kept[2][rt][ct][r];
+            }
+    }
+    __syncthreads();  // every read of h3 / W4s / sHead is done: the slab and the chunk buffer may be overwritten
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[(rt * 16 + 4 * kq + r) * XS + wave * 16 * CT + ct * 16 + r16] = acc[rt][ct][r];
+    __syncthreads();
+    flush_rows<RT, NW>(X, dzy + 2 * (size_t)M * HID, m0, M);
+
+    // ---- backward-data chain -------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {
+        gemm_bwd<RT, NW>(a.params + lay.off_w[y][l], X, Wc, acc);  // dH_l = dZ_{l+1} . W_{l+1}
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    X[(rt * 16 + 4 * kq + r) * XS + wave * 16 * CT + ct * 16 + r16] = acc[rt][ct][r] * kept[l - 1][rt][ct][r];
+        __syncthreads();
+        flush_rows<RT, NW>(X, dzy + (size_t)(l - 1) * M * HID, m0, M);
+    }
+
+    // ---- metric sums of this tile ----------------------------------------------------------------------------------------------
+    block_sum<NS>(lacc, sRed);
+    if (tid == 0) {
+        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) lp[k] = lacc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused optimizer-step kernel (2): weight gradients (split-K slabs), head-gradient fold, metric finalisation
+//   1-D grid: [GEMM items (padded to a multiple of 8, XCD-grouped)] [slabs x 2 head-fold blocks] [1 finalise block]
+//   GEMM item = (slab, matrix, 128x128 output tile); 4 waves as 2x2, each 2x2 tiles of v_mfma_f32_32x32x2_f32.
+// ---------------------------------------------------------------------------------------------------------------
+struct DwArgs {
+    rlx_mlp_layout lay;
+    const float* states;
+    const float* h;          // [2][2][M][256]
+    const float* dz;         // [2][3][M][256]
+    const float* head_part;  // [tiles][2][head_stride]
+    const double* loss_part; // [tiles][2][NS]
+    long long M;
+    int rows_per_slab;       // multiple of 32
+    int slabs;
+    int tiles;               // row tiles of the fused kernel
+    int head_stride;
+    int gemm_items;          // slabs * 20, the grid holds round_up(gemm_items, 8) GEMM blocks
+    float* grads;            // [slabs][n_params]
+    rlx_ppo_loss_params p;
+    int has_mask, has_msum;
+    float* out;              // metric row (RLX_PPO_OUT_FLOATS)
+};
+
+__device__ __forceinline__ int frag_row32(int r, int khalf) { return (r & 3) + 8 * (r >> 2) + 4 * khalf; }
+
+__global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
+    __shared__ __align__(16) float As[2][32][128];
+    __shared__ __align__(16) float Bs[2][32][128];
+    const rlx_mlp_layout& lay = a.lay;
+    const long long M = a.M;
+    const int tid = threadIdx.x;
+    const int gemm_blocks = round_up(a.gemm_items, 8);
+    int b = blockIdx.x;
+
+    if (b >= gemm_blocks) {
+        b -= gemm_blocks;
+        if (b < a.slabs * 2) {
+            // ---- head gradients: slab s takes the tiles t == s (mod slabs); thread = hidden column j -------------
+            const int s = b >> 1, y = b & 1, j = tid;
+            const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+            float* slab = a.grads + (size_t)s * lay.n_params;
+            float acc[MAX_OUT];
+#pragma unroll
+            for (int o = 0; o < MAX_OUT; ++o) acc[o] = 0.f;
+            float sb = 0.f, sl = 0.f;
+            for (int t = s; t < a.tiles; t += a.slabs) {
+                const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
+#pragma unroll
+                for (int o = 0; o < MAX_OUT; ++o)
+                    if (o < n_out) acc[o] += part[o * HID + j];
+                if (j < n_out) {
+                    sb += part[n_out * HID + j];
+                    sl += part[n_out * HID + n_out + j];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < MAX_OUT; ++o)
+                if (o < n_out) slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc[o];
+            if (j < n_out) {
+                if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
+                if (y == 1) slab[lay.off_logstd + j] = sl;
+            }
+        } else {
+            // ---- metric row: sum the per-tile partials of both networks ---------------------------------------
+            double* s_red = reinterpret_cast<double*>(&As[0][0][0]);
+            double acc[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+            for (int i = tid; i < a.tiles * 2; i += 256) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
+            }
+            block_sum<NS>(acc, s_red);
+            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+        }
+        return;
+    }
+    // XCD grouping: block b runs on XCD b % 8; give each XCD a contiguous run of items, so the tiles that share A / B
+    // operand rows (same slab, same matrix) hit the same L2
+    const int item = (b & 7) * (gemm_blocks >> 3) + (b >> 3);
+    if (item >= a.gemm_items) return;
+    const int s = item / 20, w = item % 20;  // w: 0-15 hidden matrices (4 tiles each), 16-19 first layers (2 tiles each)
+    int y, l, i0, j0;
+    if (w < 16) {
+        const int mat = w >> 2, tile = w & 3;
+        y = mat >> 1; l = 1 + (mat & 1); i0 = (tile >> 1) * 128; j0 = (tile & 1) * 128;
+    } else {
+        y = (w - 16) >> 1; l = 0; i0 = ((w - 16) & 1) * 128; j0 = 0;
+    }
+    const int Kin = l == 0 ? lay.obs_dim : HID;
+    const float* A = a.dz + (size_t)(y * 3 + l) * M * HID;                          // [M][256]
+    const float* Bm = l == 0 ? a.states : a.h + (size_t)(y * 2 + l - 1) * M * HID;  // [M][Kin]
+    const bool vecB = (Kin % 4) == 0;
+    const int lane = tid & 63, wave = tid >> 6, lrow = lane & 31, khalf = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const long long r_begin = (long long)s * a.rows_per_slab;
+    const long long r_end = min(M, r_begin + a.rows_per_slab);
+    const int nchunks = r_end > r_begin ? (int)((r_end - r_begin + 31) / 32) : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+
+    const int ldr = tid >> 5, ldc4 = (tid & 31) * 4;  // loader: row ldr + 8*i, 4 columns at ldc4
+    float4 sa[4], sb[4];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long row = r_begin + (long long)c * 32 + ldr + 8 * i;
+            const bool ok = row < r_end;
+            sa[i] = ok ? *reinterpret_cast<const float4*>(A + (size_t)row * HID + i0 + ldc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const int col = j0 + ldc4;
+                if (vecB) {
+                    if (col < Kin) v = *reinterpret_cast<const float4*>(Bm + (size_t)row * Kin + col);
+                } else {
+                    const float* q = Bm + (size_t)row * Kin + col;
+                    if (col + 0 < Kin) v.x = q[0];
+                    if (col + 1 < Kin) v.y = q[1];
+                    if (col + 2 < Kin) v.z = q[2];
+                    if (col + 3 < Kin) v.w = q[3];
+                }
+            }
+            sb[i] = v;
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[buf][ldr + 8 * i][ldc4]) = sa[i];
+            *reinterpret_cast<float4*>(&Bs[buf][ldr + 8 * i][ldc4]) = sb[i];
+        }
+    };
+    if (nchunks > 0) {
+        gload(0);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) gload(c + 1);
+#pragma unroll 4
+        for (int kp = 0; kp < 16; ++kp) {
+            const int k = 2 * kp + khalf;
+            const float a0 = As[cur][k][wi * 64 + lrow], a1 = As[cur][k][wi * 64 + 32 + lrow];
+            const float b0 = Bs[cur][k][wj * 64 + lrow], b1 = Bs[cur][k][wj * 64 + 32 + lrow];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            bsum[0] += a0;
+            bsum[1] += a1;
+        }
+        if (c + 1 < nchunks) swrite(cur ^ 1);
+        __syncthreads();
+    }
+    float* slab = a.grads + (size_t)s * lay.n_params;
+    float* dW = slab + lay.off_w[y][l];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = j0 + wj * 64 + u * 32 + lrow;
+            if (col < Kin) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + wi * 64 + t * 32 + frag_row32(r, khalf);
+                    dW[(size_t)row * Kin + col] = acc[t][u][r];
+                }
+            }
+        }
+    if (j0 == 0 && wj == 0) {  // bias gradient = column sums of dZ, folded in as the A fragments go by
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float tot = bsum[t] + __shfl_xor(bsum[t], 32, 64);
+            if (khalf == 0) slab[lay.off_b[y][l] + i0 + wi * 64 + t * 32 + lrow] = tot;
+        }
+    }
+}
+
+int check_layout(const rlx_mlp_layout* lay, const char* who) {
+    RLX_REQUIRE(lay != nullptr, "%s: NULL layout", who);
+    RLX_REQUIRE(lay->hidden == HID, "%s: hidden=%d is not supported (the reference's MLP policy is 256 wide)", who, lay->hidden);
+    RLX_REQUIRE(lay->obs_dim >= 1 && lay->obs_dim <= 256, "%s: obs_dim=%d out of range [1,256]", who, lay->obs_dim);
+    RLX_REQUIRE(lay->act_dim >= 1 && lay->act_dim <= MAX_OUT && lay->val_dim >= 1 && lay->val_dim <= MAX_OUT,
+                "%s: act_dim=%d / val_dim=%d out of range [1,%d]", who, lay->act_dim, lay->val_dim, MAX_OUT);
+    for (int y = 0; y < 2; ++y)
+        for (int l = 0; l < 4; ++l) {
+            RLX_REQUIRE(lay->off_w[y][l] >= 0 && lay->off_w[y][l] < lay->n_params, "%s: weight offset out of range", who);
+            RLX_REQUIRE(lay->off_w[y][l] % 4 == 0 || l == 0, "%s: weight offsets of layers 2-4 must be 16-byte aligned", who);
+            RLX_REQUIRE(l == 3 || lay->off_b[y][l] >= 0, "%s: hidden layers need a bias", who);
+        }
+    return RLX_OK;
+}
+
+// once per kernel and process (not a stream operation: keep it out of hipGraph capture regions)
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    static thread_local const void* done[8] = {};
+    const void* key = reinterpret_cast<const void*>(kern);
+    for (const void* d : done)
+        if (d == key) return RLX_OK;
+    RLX_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    for (auto& d : done)
+        if (d == nullptr) { d = key; break; }
+    return RLX_OK;
+}
+
+int head_stride_of(const rlx_mlp_layout* lay) {
+    const int n = std::max(lay->act_dim, lay->val_dim);
+    return round_up(n * HID + 2 * n, 4);
+}
+
+struct StepPlan {
+    int tiles, slabs, rows_per_slab, head_stride;
+    size_t off_h, off_dz, off_head, off_loss, bytes;
+};
+StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m) {
+    StepPlan pl{};
+    pl.tiles = ceil_div(m, 32);
+    // 20 GEMM items per slab; fill 2 workgroups per CU once (no second, half-empty round)
+    int slabs = std::max(1, std::min(2 * num_cu() / 20, pl.tiles));
+    pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
+    pl.slabs = ceil_div(m, pl.rows_per_slab);
+    pl.head_stride = head_stride_of(lay);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    pl.off_h = take((size_t)4 * m * HID * sizeof(float));
+    pl.off_dz = take((size_t)6 * m * HID * sizeof(float));
+    pl.off_head = take((size_t)pl.tiles * 2 * pl.head_stride * sizeof(float));
+    pl.off_loss = take((size_t)pl.tiles * 2 * NS * sizeof(double));
+    pl.bytes = off;
+    return pl;
+}
+
+}  // namespace
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stream) {
+    RLX_REQUIRE(r != nullptr, "rlx_mlp_rollout_step: NULL argument struct");
+    if (int rc = check_layout(r->layout, "rlx_mlp_rollout_step")) return rc;
+    RLX_REQUIRE(r->params != nullptr, "rlx_mlp_rollout_step: NULL params");
+    RLX_REQUIRE(r->m >= 0 && r->n_value_jobs >= 0 && r->n_value_jobs <= 2, "rlx_mlp_rollout_step: bad sizes");
+    RLX_REQUIRE(r->m == 0 || (r->states && r->action && r->logprob && r->value), "rlx_mlp_rollout_step: NULL policy tensor");
+    RolloutArgs a{};
+    a.params = r->params; a.lay = *r->layout; a.states = r->states; a.eps = r->eps; a.M = r->m;
+    a.action = r->action; a.logprob = r->logprob; a.value = r->value; a.states_copy = r->states_copy;
+    a.tiles_policy = ceil_div(r->m, 16);
+    int tv[2] = {0, 0};
+    for (int k = 0; k < r->n_value_jobs; ++k) {
+        const rlx_value_job& j = r->value_jobs[k];
+        RLX_REQUIRE(j.m >= 0 && (j.m == 0 || j.states != nullptr), "rlx_mlp_rollout_step: value job %d has no states", k);
+        RLX_REQUIRE(j.rewards == nullptr || (j.flags != nullptr && j.chunk >= 1), "rlx_mlp_rollout_step: value job %d folds rewards without flags", k);
+        a.vj[k] = ValueJob{j.states, j.m, j.values, j.rewards, j.flags, j.chunk, j.gamma};
+        tv[k] = ceil_div(j.m, 16);
+    }
+    a.tiles_vj0 = tv[0]; a.tiles_vj1 = tv[1];
+    const int blocks = 2 * a.tiles_policy + tv[0] + tv[1];
+    if (blocks == 0) return RLX_OK;
+    const size_t lds = Geo<1, 8>::LDS_BYTES;
+    if (int rc = set_lds(rollout_step_kernel, lds)) return rc;
+    hipLaunchKernelGGL(rollout_step_kernel, dim3(blocks), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_ppo_step_slabs(const rlx_mlp_layout* lay, int64_t m) {
+    if (!lay || m <= 0) return 1;
+    return plan_step(lay, m).slabs;
+}
+
+extern "C" size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* lay, int64_t m) {
+    if (!lay || m <= 0) return 256;
+    return plan_step(lay, m).bytes;
+}
+
+extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
+    RLX_REQUIRE(s != nullptr && s->loss != nullptr, "rlx_ppo_step: NULL argument struct");
+    if (int rc = check_layout(s->layout, "rlx_ppo_step")) return rc;
+    const rlx_mlp_layout& lay = *s->layout;
+    const rlx_ppo_loss_params& p = *s->loss;
+    RLX_REQUIRE(s->m >= 1, "rlx_ppo_step: empty micro-batch");
+    RLX_REQUIRE(p.raw_per_adv >= 1 && p.sub_per_adv >= 1 && p.raw_per_adv % p.sub_per_adv == 0 && lay.act_dim % p.raw_per_adv == 0,
+                "rlx_ppo_step: raw_per_adv=%d / sub_per_adv=%d do not tile act_dim=%d", p.raw_per_adv, p.sub_per_adv, lay.act_dim);
+    RLX_REQUIRE(!p.has_critic || lay.act_dim / p.raw_per_adv == lay.val_dim,
+                "rlx_ppo_step: %d advantage elements per row but %d value outputs", lay.act_dim / p.raw_per_adv, lay.val_dim);
+    RLX_REQUIRE(!p.use_dual_clip || p.clip_ratio_c > 1.0f, "clip_ratio_c must be greater than 1.0");  // losses.py:262
+    RLX_REQUIRE(s->params && s->states && s->action && s->old_logprobs && s->advantages && s->grads && s->out && s->workspace,
+                "rlx_ppo_step: NULL argument");
+    RLX_REQUIRE(!p.has_critic || (s->prev_values && s->returns), "rlx_ppo_step: has_critic set but a critic tensor is NULL");
+    const StepPlan pl = plan_step(&lay, s->m);
+    RLX_REQUIRE(s->slabs == pl.slabs, "rlx_ppo_step: grads holds %d slabs, rlx_ppo_step_slabs() says %d", s->slabs, pl.slabs);
+    if (s->workspace_bytes < pl.bytes) {
+        set_error("rlx_ppo_step: workspace %zu < %zu bytes", s->workspace_bytes, pl.bytes);
+        return RLX_ENOSPC;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(s->workspace);
+    StepArgs a{};
+    a.params = s->params; a.lay = lay; a.states = s->states; a.action = s->action; a.old_logprobs = s->old_logprobs;
+    a.advantages = s->advantages; a.prev_values = s->prev_values; a.returns = s->returns; a.loss_mask = s->loss_mask;
+    a.loss_mask_sum = s->loss_mask_sum; a.M = s->m; a.p = p; a.grad_out = s->grad_out;
+    a.h = reinterpret_cast<float*>(ws + pl.off_h); a.dz = reinterpret_cast<float*>(ws + pl.off_dz);
+    a.head_part = reinterpret_cast<float*>(ws + pl.off_head); a.loss_part = reinterpret_cast<double*>(ws + pl.off_loss);
+    a.head_stride = pl.head_stride;
+    const size_t lds = Geo<2, 4>::LDS_BYTES;
+    if (int rc = set_lds(ppo_step_fused_kernel<2, 4>, lds)) return rc;
+    hipLaunchKernelGGL((ppo_step_fused_kernel<2, 4>), dim3(pl.tiles, 2), dim3(256), lds, st, a);
+    RLX_LAUNCH_CHECK();
+    DwArgs d{};
+    d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
+    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_stride = pl.head_stride;
+    d.gemm_items = pl.slabs * 20; d.grads = s->grads; d.p = p; d.has_mask = s->loss_mask != nullptr;
+    d.has_msum = s->loss_mask_sum != nullptr; d.out = s->out;
+    const int blocks = round_up(d.gemm_items, 8) + pl.slabs * 2 + 1;
+    hipLaunchKernelGGL(ppo_step_dw_kernel, dim3(blocks), dim3(256), 0, st, d);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}

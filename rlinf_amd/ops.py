@@ -11,7 +11,8 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AdamwGroup, AdamwParams, GaeParams, GatherField, MlpLayout, PpoLossParams, RlxError
+from ._lib import (AdamwGroup, AdamwParams, GaeParams, GatherField, MlpLayout, PpoLossParams, PpoStepArgs, RlxError,
+                   RolloutStep)
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -448,6 +449,22 @@ def bootstrap_rewards_(rewards: torch.Tensor, flags: torch.Tensor, bootstrap_val
     return rewards
 
 
+def store_env_rows_(rewards, terminations, truncations, reward_row, done_row, termination_row, truncation_row):
+    """One env step's [B, C] outputs -> buffer rows; dones = terminations | truncations.  One launch."""
+    lib = _lib.load()
+    dev = _dev(rewards, terminations, truncations, reward_row, done_row, termination_row, truncation_row)
+    r = _as_f32(rewards, "rewards")
+    te, tr = _as_u8(terminations), _as_u8(truncations)
+    n = r.numel()
+    for t in (te, tr, reward_row, done_row, termination_row, truncation_row):
+        if t.numel() != n or not t.is_contiguous():
+            raise RlxError("store_env_rows_: all tensors must be contiguous with rewards' number of elements")
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_store_env_rows(r.data_ptr(), te.data_ptr(), tr.data_ptr(), reward_row.data_ptr(),
+                                          done_row.data_ptr(), termination_row.data_ptr(), truncation_row.data_ptr(), n,
+                                          _stream_ptr(dev)), "rlx_store_env_rows")
+
+
 # --------------------------------------------------------------------------------------------
 # a1-a5, a17  MLP policy kernels (flat parameter buffer + layout descriptor)
 # --------------------------------------------------------------------------------------------
@@ -564,3 +581,102 @@ def mlp_train_bwd(params, packed, layout: MlpLayout, states, action, mean, acts,
                                          dv.data_ptr(), M, grads.data_ptr(), slabs, workspace.data_ptr(),
                                          workspace.numel(), _stream_ptr(dev)), "rlx_mlp_train_bwd")
     return grads
+
+
+# --------------------------------------------------------------------------------------------
+# fused hot launches (ppo_step.hip)
+# --------------------------------------------------------------------------------------------
+def mlp_rollout_step(params: torch.Tensor, layout: MlpLayout, states: Optional[torch.Tensor], eps: Optional[torch.Tensor],
+                     out: Optional[tuple] = None, states_copy: Optional[torch.Tensor] = None, value_jobs: tuple = ()):
+    """ONE launch: policy job on ``states`` (-> action, logprob, value rows in ``out``) plus up to two value-only jobs
+    ``dict(states=[m,D], values=[m,val]|None, rewards=[m,C]|None, flags=[m,C] bool, gamma=float)``: values <- V(states),
+    rewards[:, -1] += gamma * V(states)[:, 0] where flags[:, -1]."""
+    lib = _lib.load()
+    dev = _dev(params, states, eps, *[j["states"] for j in value_jobs])
+    st = RolloutStep()
+    st.params, st.layout = params.data_ptr(), ctypes_pointer(layout)
+    action = logprob = value = None
+    if states is not None:
+        s_ = _as_f32(states, "states")
+        M = s_.shape[0]
+        if s_.dim() != 2 or s_.shape[1] != layout.obs_dim:
+            raise RlxError(f"states must be [M, {layout.obs_dim}], got {tuple(s_.shape)}")
+        e = _as_f32(eps, "eps")
+        if e is not None and tuple(e.shape) != (M, layout.act_dim):
+            raise RlxError(f"eps must be [{M}, {layout.act_dim}]")
+        if out is not None:
+            action, logprob, value = out
+            for t, w in ((action, layout.act_dim), (logprob, layout.act_dim), (value, layout.val_dim)):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != M * w:
+                    raise RlxError("mlp_rollout_step: out tensors must be contiguous float32 of the right size")
+        else:
+            action = torch.empty((M, layout.act_dim), dtype=torch.float32, device=dev)
+            logprob = torch.empty_like(action)
+            value = torch.empty((M, layout.val_dim), dtype=torch.float32, device=dev)
+        if states_copy is not None and (states_copy.dtype != torch.float32 or not states_copy.is_contiguous()
+                                        or states_copy.numel() != s_.numel()):
+            raise RlxError("mlp_rollout_step: states_copy must be a contiguous float32 tensor shaped like states")
+        st.states, st.eps, st.m = s_.data_ptr(), _ptr(e), M
+        st.action, st.logprob, st.value, st.states_copy = action.data_ptr(), logprob.data_ptr(), value.data_ptr(), _ptr(states_copy)
+    if len(value_jobs) > 2:
+        raise RlxError("at most two value jobs per launch")
+    keep = []
+    for k, j in enumerate(value_jobs):
+        js = _as_f32(j["states"], "value job states")
+        m = js.shape[0]
+        vals, rew, flags = j.get("values"), j.get("rewards"), j.get("flags")
+        if vals is not None and (vals.dtype != torch.float32 or not vals.is_contiguous() or vals.numel() != m * layout.val_dim):
+            raise RlxError("value job: values must be contiguous float32 [m, val_dim]")
+        chunk = 1
+        if rew is not None:
+            if rew.dim() != 2 or rew.dtype != torch.float32 or not rew.is_contiguous() or rew.shape[0] != m:
+                raise RlxError("value job: rewards must be a contiguous float32 [m, C] tensor")
+            flags = _as_u8(flags)
+            if flags is None or tuple(flags.shape) != tuple(rew.shape):
+                raise RlxError("value job: flags must be a bool tensor shaped like rewards")
+            chunk = rew.shape[1]
+        keep += [js, flags]
+        vj = st.value_jobs[k]
+        vj.states, vj.m, vj.values, vj.rewards, vj.flags = js.data_ptr(), m, _ptr(vals), _ptr(rew), _ptr(flags)
+        vj.chunk, vj.gamma = chunk, float(j.get("gamma", 1.0))
+    st.n_value_jobs = len(value_jobs)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_rollout_step(byref(st), _stream_ptr(dev)), "rlx_mlp_rollout_step")
+    return action, logprob, value
+
+
+def ctypes_pointer(layout: MlpLayout):
+    import ctypes
+    return ctypes.pointer(layout)
+
+
+def ppo_step_slabs(layout: MlpLayout, m: int) -> int:
+    return _lib.load().rlx_ppo_step_slabs(byref(layout), int(m))
+
+
+def ppo_step_workspace_bytes(layout: MlpLayout, m: int) -> int:
+    return _lib.load().rlx_ppo_step_workspace_bytes(byref(layout), int(m))
+
+
+def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatch: dict, grads: torch.Tensor,
+             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0):
+    """forward + loss + backward of one micro-batch (two launches).  ``mbatch``: states, action, prev_logprobs,
+    advantages [, prev_values, returns, loss_mask, loss_mask_sum] as flattened minibatch views; ``grads`` [slabs, n]."""
+    lib = _lib.load()
+    dev = params.device
+    a = PpoStepArgs()
+    a.params, a.layout, a.loss = params.data_ptr(), ctypes_pointer(layout), ctypes_pointer(loss)
+    st = mbatch["states"]
+    a.states, a.action = st.data_ptr(), mbatch["action"].data_ptr()
+    a.old_logprobs, a.advantages = mbatch["prev_logprobs"].data_ptr(), mbatch["advantages"].data_ptr()
+    has_critic = bool(loss.has_critic)
+    a.prev_values = mbatch["prev_values"].data_ptr() if has_critic else None
+    a.returns = mbatch["returns"].data_ptr() if has_critic else None
+    lm = mbatch.get("loss_mask")
+    a.loss_mask = None if lm is None else lm.data_ptr()
+    a.loss_mask_sum = _ptr(mbatch.get("loss_mask_sum"))
+    a.m, a.grad_out = st.shape[0], float(grad_out)
+    a.grads, a.slabs, a.out = grads.data_ptr(), grads.shape[0], out_row.data_ptr()
+    a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_ppo_step(byref(a), _stream_ptr(dev)), "rlx_ppo_step")

@@ -4,9 +4,9 @@ recv_rollout_trajectories :186-207, _process_received_rollout_batch :209-284, co
 (rlinf/hybrid_engines/fsdp: optimizer_step fsdp_model_manager.py:429-463, two-group AdamW :501-590).
 
 One optimizer step is a fixed chain of HIP launches on preallocated buffers -- no autograd graph, no
-``.item()``: training forward -> fused loss (+metrics) -> loss backward -> backward-data chain -> split-K weight
-gradients -> [RCCL all-reduce of one flat buffer] -> clip + AdamW -> weight re-pack.  Metrics of every step land
-in one device matrix read back once per ``run_training``.  Because the chain is static it can be captured in a
+``.item()``: [forward + loss + metrics + backward-data, one launch] -> [split-K weight gradients + head gradients +
+metric row, one launch] -> [RCCL all-reduce of one flat buffer] -> clip + AdamW (two launches).  Metrics of every
+step land in one device matrix read back once per ``run_training``.  Because the chain is static it can be captured in a
 hipGraph (``actor.enable_hip_graph``) and replayed: the step counter lives on the device for that reason.
 """
 
@@ -39,6 +39,8 @@ class EmbodiedFSDPActor(Worker):
         self.gradient_accumulation = a.global_batch_size // a.micro_batch_size // self._world_size  # :91-95
         self.critic_warmup_steps = int(a.optim.get("critic_warmup_steps", 0))
         self.enable_hip_graph = bool(a.get("enable_hip_graph", False))
+        # rlx_ppo_step (fused forward + loss + backward); False = the stage-by-stage entry points
+        self.fused_step = bool(a.get("fused_step", True))
         self._graph = None
         self._graph_key = None
 
@@ -133,9 +135,12 @@ class EmbodiedFSDPActor(Worker):
         b = self.rollout_batch
         T, B = b["prev_logprobs"].shape[:2]
         N = T * B
-        g = torch.Generator()
-        g.manual_seed(int(self.cfg.actor.seed) + self._rank)
-        perm = torch.randperm(N, generator=g).to(self.device, non_blocking=True)
+        pkey = ("perm", N)
+        if pkey not in self._ws:  # the reference re-seeds the generator on every call: the permutation never changes
+            g = torch.Generator()
+            g.manual_seed(int(self.cfg.actor.seed) + self._rank)
+            self._ws[pkey] = torch.randperm(N, generator=g).to(self.device)
+        perm = self._ws[pkey]
         names = ["states", "action", "prev_logprobs", "advantages", "prev_values"]
         src = [b["forward_inputs"]["states"], b["forward_inputs"]["action"], b["prev_logprobs"], b["advantages"],
                b["prev_values"][:-1]]
@@ -153,9 +158,13 @@ class EmbodiedFSDPActor(Worker):
         return dict(zip(names, outs)), N
 
     def _minibatch_workspace(self, mb: int):
-        key = ("mb", mb)
+        key = ("mb", mb, self.fused_step)
         if key not in self._ws:
             lay, dev = self.model.layout, self.device
+            if self.fused_step:
+                self._ws[key] = dict(slabs=ops.ppo_step_slabs(lay, mb),
+                                     step_ws=torch.empty(ops.ppo_step_workspace_bytes(lay, mb), dtype=torch.uint8, device=dev))
+                return self._ws[key]
             f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
             slabs = ops.mlp_bwd_slabs(mb)
             lib = ops._lib.load()
@@ -182,6 +191,9 @@ class EmbodiedFSDPActor(Worker):
         m = self.model
         lay = m.layout
         mb = mbatch["states"].shape[0]
+        if self.fused_step:
+            ops.ppo_step(m.flat.data, lay, lp, mbatch, grads, out_row, ws["step_ws"], grad_out=self._grad_out_host)
+            return
         ops.mlp_train_fwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], acts=ws["acts"],
                           out=(ws["logprob"], ws["entropy"], ws["value"], ws["mean"]))
         n_adv = mb * lay.act_dim // lp.raw_per_adv  # advantage elements: [mb, C] (action/token level) or [mb] (chunk level)
@@ -227,6 +239,7 @@ class EmbodiedFSDPActor(Worker):
             self._ws[key] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
             self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
         grads, grad_out = self._ws[key], self._ws["grad_out"]
+        self._grad_out_host = 1.0 / accum
         step = 0
         for _ in range(alg.get("update_epoch", 1)):
             for i in range(n_mb):

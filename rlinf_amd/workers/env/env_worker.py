@@ -88,22 +88,22 @@ class EnvWorker(Worker):
         return None
 
     def _interact_eager(self, eps: torch.Tensor, mode: str = "train"):
+        """Two launches per chunk step: the fused policy launch (which also folds the previous step's bootstrap value
+        into its reward row) and one store of the env outputs into the buffer rows."""
         buf, env, ro = self.buffer, self.env, self.rollout
         buf.reset()
         with self.timer("env/interact"):
             obs, _ = env.reset()
             for t in range(self.n_train_chunk_steps):
-                buf.states[t].copy_(obs["states"])  # forward_inputs.states of step t (return_obs=True)
-                chunk_actions = ro.predict(obs, out=buf.policy_rows(t), eps=None if eps is None else eps[t], mode=mode)
+                # forward_inputs.states of step t (return_obs=True) are written by the policy launch itself
+                chunk_actions = ro.predict(obs, out=buf.policy_rows(t), eps=None if eps is None else eps[t], mode=mode,
+                                           states_copy=buf.states[t])
                 obs, rewards, term, trunc, infos = env.chunk_step(chunk_actions)
                 r_row, d_row, te_row, tr_row = buf.env_rows(t)
-                r_row.copy_(rewards)
-                te_row.copy_(term)
-                tr_row.copy_(trunc)
-                torch.logical_or(term, trunc, out=d_row)
+                ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
                 if self.auto_reset:  # value of the true terminal observation enters through the reward (A.2)
-                    ro.get_bootstrap_values(infos["final_obs"], out=self._bootstrap_v)
-                    self.compute_bootstrap_rewards(r_row, d_row, tr_row, self._bootstrap_v)
+                    flags = d_row if self.bootstrap_type == "always" else tr_row
+                    ro.queue_bootstrap(infos["final_obs"], r_row, flags, self.gamma)
             ro.get_bootstrap_values(obs, out=buf.prev_values[self.n_train_chunk_steps])  # last row: values only
         return None
 

@@ -17,6 +17,7 @@ class MultiStepRolloutWorker(Worker):
         self.hf_model = None
         self.version = 0
         self._shares_actor_weights = False
+        self._pending: list = []  # bootstrap-value jobs waiting for the next launch
 
     def init_worker(self, model=None):
         """``model``: when rollout and learner are collocated (component_placement ``env,rollout,actor: 0``) the
@@ -38,18 +39,43 @@ class MultiStepRolloutWorker(Worker):
             self.hf_model.flat.data.copy_(flat_params)
         self.hf_model.mark_updated()
 
-    def predict(self, env_obs: dict, out=None, eps=None, mode: str = "train"):
-        """-> chunk_actions [B, C, A]; action / logprob / value rows land in ``out`` (the trajectory buffer)."""
+    def predict(self, env_obs: dict, out=None, eps=None, mode: str = "train", states_copy=None):
+        """-> chunk_actions [B, C, A]; action / logprob / value rows land in ``out`` (the trajectory buffer).  ONE launch:
+        bootstrap-value jobs queued by queue_bootstrap() ride in the same grid."""
         m = self.hf_model
         states = env_obs["states"]
         if mode == "train" and eps is None:
             eps = torch.randn((states.shape[0], m.layout.act_dim), dtype=torch.float32, device=states.device)
-        action, _, _ = ops.mlp_rollout(m.flat.data, m.packed(), m.layout, states, eps if mode == "train" else None, out=out)
+        jobs, self._pending = tuple(self._pending), []
+        action, _, _ = ops.mlp_rollout_step(m.flat.data, m.layout, states, eps if mode == "train" else None, out=out,
+                                            states_copy=states_copy, value_jobs=jobs)
         return action.view(-1, m.num_action_chunks, m.action_dim)
 
+    def queue_bootstrap(self, final_obs: dict, rewards: torch.Tensor, flags: torch.Tensor, gamma: float):
+        """get_bootstrap_values + compute_bootstrap_rewards (huggingface_worker.py:612-627, env_worker.py:718-758)
+        deferred into the next launch: rewards[:, -1] += gamma * V(final_obs)[:, 0] where flags[:, -1].  The weights do
+        not change inside a rollout epoch, so running it one launch later changes nothing but the launch count."""
+        if len(self._pending) == 2:
+            self.flush_bootstrap()
+        self._pending.append(dict(states=final_obs["states"], rewards=rewards, flags=flags, gamma=gamma))
+
+    def flush_bootstrap(self):
+        if self._pending:
+            jobs, self._pending = tuple(self._pending), []
+            m = self.hf_model
+            ops.mlp_rollout_step(m.flat.data, m.layout, None, None, value_jobs=jobs)
+
     def get_bootstrap_values(self, final_obs: dict, out=None) -> torch.Tensor:
+        """Value head only (huggingface_worker.py:612-627); carries at most one queued bootstrap job along."""
         m = self.hf_model
-        return ops.mlp_value(m.flat.data, m.packed(), m.layout, final_obs["states"], out=out)[:, :1]
+        st = final_obs["states"]
+        if out is None:
+            out = torch.empty((st.shape[0], m.layout.val_dim), dtype=torch.float32, device=st.device)
+        if len(self._pending) == 2:
+            self.flush_bootstrap()
+        jobs, self._pending = tuple(self._pending) + (dict(states=st, values=out),), []
+        ops.mlp_rollout_step(m.flat.data, m.layout, None, None, value_jobs=jobs)
+        return out[:, :1]
 
     def generate(self, *args, **kwargs):
         """The reference runs this concurrently with EnvWorker.interact over channels; in-process the env worker

@@ -1,0 +1,143 @@
+"""The two fused hot launches (rlinf_amd/csrc/ppo_step.hip) through the C ABI against the CPU oracle:
+rlx_mlp_rollout_step (policy + value-only jobs in one launch) and rlx_ppo_step (forward + loss + backward)."""
+
+import pytest
+import torch
+
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD = dict(rtol=1e-4, atol=1e-5)  # exact-f32 MFMA vs CPU sgemm: summation order only
+
+
+def _policies(seed=7, jitter=0.02):
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(seed)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    with torch.no_grad():
+        for p in ora.parameters():
+            p.add_(torch.randn_like(p) * jitter)
+    pol = MLPPolicy(42, 8, 1, True, False)
+    pol.load_reference_state_dict(ora.state_dict())
+    return ora, pol.to("cuda")
+
+
+@pytest.mark.parametrize("M", [1024, 16, 37, 1])
+def test_rollout_step_policy_and_value_jobs(M):
+    from rlinf_amd import ops
+    ora, pol = _policies()
+    g = torch.Generator().manual_seed(3)
+    states, eps = torch.randn(M, 42, generator=g), torch.randn(M, 8, generator=g)
+    fin, last = torch.randn(M, 42, generator=g), torch.randn(M, 42, generator=g)
+    rewards = torch.rand(M, 1, generator=g)
+    flags = torch.rand(M, 1, generator=g) < 0.3
+    want_a, want_lp, want_v = ora.act(states, eps=eps, mode="train")
+    want_boot = ora.value_head.mlp(fin).detach()[:, :1]
+    want_r = O.bootstrap_rewards(rewards.clone(), flags, want_boot, 0.8)
+    want_last = ora.value_head.mlp(last).detach()
+
+    r_dev = rewards.cuda()
+    copy = torch.zeros(M, 42, device="cuda")
+    last_v = torch.empty(M, 1, device="cuda")
+    a, lp, v = ops.mlp_rollout_step(
+        pol.flat.data, pol.layout, states.cuda(), eps.cuda(), states_copy=copy,
+        value_jobs=(dict(states=fin.cuda(), rewards=r_dev, flags=flags.cuda(), gamma=0.8),
+                    dict(states=last.cuda(), values=last_v)))
+    torch.testing.assert_close(a.cpu(), want_a, **FWD)
+    torch.testing.assert_close(lp.cpu(), want_lp, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(v.cpu(), want_v, **FWD)
+    assert torch.equal(copy.cpu(), states)
+    torch.testing.assert_close(r_dev.cpu(), want_r, **FWD)
+    assert torch.equal(r_dev.cpu()[~flags], rewards[~flags])  # untouched where the env did not finish
+    torch.testing.assert_close(last_v.cpu(), want_last, **FWD)
+    # eval mode: action == mean, value-only launch without a policy job
+    a2, _, _ = ops.mlp_rollout_step(pol.flat.data, pol.layout, states.cuda(), None)
+    torch.testing.assert_close(a2.cpu(), ora.act(states, eps=None, mode="eval")[0], **FWD)
+    only_v = torch.empty(M, 1, device="cuda")
+    ops.mlp_rollout_step(pol.flat.data, pol.layout, None, None, value_jobs=(dict(states=last.cuda(), values=only_v),))
+    assert torch.equal(only_v, last_v)
+
+
+def _minibatch(M, g, with_mask):
+    mb = dict(states=torch.randn(M, 42, generator=g), action=torch.randn(M, 8, generator=g) * 0.6,
+              prev_logprobs=torch.randn(M, 8, generator=g) * 0.1 - 1.0, advantages=torch.randn(M, 1, generator=g),
+              prev_values=torch.randn(M, 1, generator=g), returns=torch.randn(M, 1, generator=g))
+    if with_mask:
+        mb["loss_mask"] = torch.rand(M, 1, generator=g) < 0.7
+    return mb
+
+
+@pytest.mark.parametrize("M,with_mask", [(8192, False), (700, True), (32, False), (5, True)])
+def test_ppo_step_gradients_and_metrics_vs_oracle(M, with_mask):
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
+    ora, pol = _policies(seed=11)
+    g = torch.Generator().manual_seed(5)
+    mb = _minibatch(M, g, with_mask)
+    # make the old log-probs close to the current ones so that ratios straddle the clip range
+    with torch.no_grad():
+        cur = ora.evaluate(mb["states"], mb["action"])["logprobs"]
+    mb["prev_logprobs"] = cur + torch.randn(M, 8, generator=g) * 0.08
+
+    out = ora.evaluate(mb["states"], mb["action"])
+    shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8,
+                                 loss_mask=mb.get("loss_mask"), values=out["values"], prev_values=mb["prev_values"],
+                                 returns=mb["returns"])
+    loss, metrics = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+    (loss * 0.5).backward()  # grad_out = 1 / gradient_accumulation = 0.5
+
+    lay = pol.layout
+    lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
+                             value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
+    slabs = ops.ppo_step_slabs(lay, M)
+    grads = torch.full((slabs, lay.n_params), float("nan"), device="cuda")  # every element must be written
+    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+    row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+    dev_mb = {k: v.cuda().contiguous() for k, v in mb.items()}
+    if with_mask:
+        dev_mb["loss_mask"] = dev_mb["loss_mask"].view(torch.uint8)
+    ops.ppo_step(pol.flat.data, lay, lp, dev_mb, grads, row, ws, grad_out=0.5)
+    got = grads.sum(dim=0).cpu()
+    assert torch.isfinite(got).all()
+    scale = max(float(p.grad.abs().max()) for p in ora.parameters())
+    for name, p in ora.named_parameters():
+        o = pol.offsets[name]
+        w = p.grad.reshape(-1)
+        tol = 3e-4 * max(float(w.abs().max()), 1e-3 * scale) + 1e-7
+        err = float((got[o:o + w.numel()] - w).abs().max())
+        assert err <= tol, (name, err, tol)
+    host = row.cpu()
+    assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(float(loss), rel=2e-4, abs=2e-5)
+    for key in ("actor/policy_loss", "actor/ratio", "actor/clipped_ratio", "actor/approx_kl", "actor/clip_fraction",
+                "critic/value_loss"):
+        assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(float(metrics[key]), rel=5e-4, abs=5e-5), key
+
+
+def test_ppo_step_matches_unfused_chain():
+    """Same micro-batch through the stage-by-stage entry points (train_fwd -> ppo_loss -> train_bwd)."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS
+    _, pol = _policies(seed=3)
+    M = 1000
+    g = torch.Generator().manual_seed(9)
+    mb = {k: v.cuda() for k, v in _minibatch(M, g, True).items()}
+    lay = pol.layout
+    o = pol.default_forward({"states": mb["states"], "action": mb["action"]})
+    loss, out_ref = ops.ppo_loss(o["logprobs"], mb["prev_logprobs"], mb["advantages"], clip_ratio_low=0.2,
+                                 clip_ratio_high=0.2, values=o["values"], prev_values=mb["prev_values"],
+                                 returns=mb["returns"], value_clip=1.0, huber_delta=10.0, loss_mask=mb["loss_mask"],
+                                 max_episode_steps=50)
+    loss.backward()
+    want = pol.flat.grad.clone()
+    lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
+                             value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
+    grads = torch.empty((ops.ppo_step_slabs(lay, M), lay.n_params), device="cuda")
+    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+    row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+    dev_mb = dict(mb)
+    dev_mb["loss_mask"] = mb["loss_mask"].view(torch.uint8)
+    ops.ppo_step(pol.flat.data, lay, lp, dev_mb, grads, row, ws, grad_out=1.0)
+    got = grads.sum(dim=0)
+    torch.testing.assert_close(got, want, rtol=1e-3, atol=float(want.abs().max()) * 2e-4)
+    torch.testing.assert_close(row[:16], out_ref[:16], rtol=2e-4, atol=2e-5)
