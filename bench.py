@@ -51,7 +51,7 @@ def build_cfg(world: int, use_graph: bool):
                             max_episode_steps=50, max_steps_per_rollout_epoch=HORIZON, seed=1234, group_size=1)),
         rollout=dict(pipeline_stage_num=1, enable_cuda_graph=use_graph),
         actor=dict(training_backend="fsdp", micro_batch_size=GLOBAL_BATCH // world, global_batch_size=GLOBAL_BATCH,
-                   seed=1234, enable_hip_graph=use_graph,
+                   seed=1234, enable_hip_graph=use_graph, optimizer_writes_tiles=bool(int(os.environ.get("RLX_BENCH_OPT_TILES", "1"))),
                    model=dict(model_type="mlp_policy", obs_dim=OBS_DIM, action_dim=ACT_DIM, num_action_chunks=1,
                               precision="32", add_value_head=True),
                    optim=dict(lr=3e-4, value_lr=3e-4, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,

@@ -214,6 +214,7 @@ int rlx_gather_rows(const rlx_gather_field* fields, int n_fields, const int64_t*
  * first (split-K weight-gradient slabs); the sum is what gets clipped and applied.
  * ------------------------------------------------------------------------------------------ */
 #define RLX_ADAMW_MAX_GROUPS 8
+struct rlx_mlp_layout; /* below */
 typedef struct rlx_adamw_group {
     int64_t begin, end; /* element range */
     float lr;
@@ -225,6 +226,10 @@ typedef struct rlx_adamw_params {
     int32_t grad_partials;   /* >= 1 */
     float grad_scale;        /* applied to the summed gradient before the norm (e.g. 1/world_size) */
     rlx_adamw_group groups[RLX_ADAMW_MAX_GROUPS];
+    /* optional (both or neither): keep the fragment-tile weight image (rlx_mlp_pack_tiles) in step with the parameters --
+     * every updated weight is also written to its tile slot(s), which saves the re-pack launch before the next forward */
+    const struct rlx_mlp_layout* tile_layout;
+    float* tiles;
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);
 /* out[i] = sum_k grads[k][i] (k < slabs): collapse the split-K slabs before a data-parallel all-reduce. */
@@ -318,8 +323,16 @@ int rlx_mlp_train_bwd(const float* params, const float* packed, const rlx_mlp_la
  *                   with EnvWorker.compute_bootstrap_rewards, env_worker.py:718-758:
  *                   values [m, val_dim] (optional) = V(states); rewards [m, chunk] (optional, in place):
  *                   rewards[b, chunk-1] += gamma * V(states)[b, 0] where flags[b, chunk-1].
- *   Needs act_dim, val_dim <= 16.  No packed weight image: weights are read from the flat parameter buffer.
+ *   Needs obs_dim <= 64, act_dim, val_dim <= 16.
+ *
+ * rlx_mlp_pack_tiles: the weight image the fused launches stream -- every 16 (out) x 16 (in) weight tile stored as one
+ *   contiguous 1 KiB block in MFMA fragment order (first layer zero-padded to 64 inputs; the hidden layers also
+ *   transposed, for the backward-data GEMMs).  rlx_mlp_tiles_bytes() bytes; rebuild after every optimizer step
+ *   (rlx_ppo_step does so itself, into its workspace).
  * ------------------------------------------------------------------------------------------ */
+size_t rlx_mlp_tiles_bytes(const rlx_mlp_layout* layout);
+int rlx_mlp_pack_tiles(const float* params, const rlx_mlp_layout* layout, float* tiles, rlx_stream_t stream);
+
 typedef struct rlx_value_job {
     const float* states;
     int64_t m;
@@ -331,6 +344,7 @@ typedef struct rlx_value_job {
 } rlx_value_job;
 typedef struct rlx_rollout_step {
     const float* params;
+    const float* tiles;   /* fragment-tile weight image: rlx_mlp_pack_tiles() after every change of params */
     const rlx_mlp_layout* layout;
     const float* states;
     const float* eps;
@@ -353,7 +367,7 @@ int rlx_mlp_rollout_step(const rlx_rollout_step* step, rlx_stream_t stream);
  *   grad_out = d(total loss)/d(this micro-batch's loss) = 1 / gradient_accumulation.
  *   grads [slabs][n_params]: split-K gradient slabs, every element written (rlx_clip_adamw_step sums them);
  *   slabs must equal rlx_ppo_step_slabs(layout, m).  out: the rlx_ppo_out metric row (device).
- *   Needs act_dim, val_dim <= 16 and (has_critic) act_dim / raw_per_adv == val_dim. */
+ *   Needs obs_dim <= 64, act_dim, val_dim <= 16 and (has_critic) act_dim / raw_per_adv == val_dim. */
 typedef struct rlx_ppo_step_args {
     const float* params;
     const rlx_mlp_layout* layout;
@@ -373,6 +387,8 @@ typedef struct rlx_ppo_step_args {
     float* out;
     void* workspace;
     size_t workspace_bytes;
+    const float* tiles; /* optional: an up-to-date fragment-tile image of params (rlx_mlp_pack_tiles, or kept fresh by
+                           rlx_clip_adamw_step); NULL = rlx_ppo_step packs one into its workspace first */
 } rlx_ppo_step_args;
 int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);
 size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);

@@ -53,19 +53,20 @@ class AdamwGroup(Structure):
     _fields_ = [("begin", c_int64), ("end", c_int64), ("lr", c_float)]
 
 
-class AdamwParams(Structure):
-    _fields_ = [
-        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
-        ("max_grad_norm", c_float), ("step", c_int32), ("n_groups", c_int32), ("grad_partials", c_int32),
-        ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
-    ]
-
-
 class MlpLayout(Structure):
     _fields_ = [
         ("obs_dim", c_int32), ("act_dim", c_int32), ("val_dim", c_int32), ("hidden", c_int32),
         ("n_params", c_int64), ("off_logstd", c_int64),
         ("off_w", (c_int64 * 4) * 2), ("off_b", (c_int64 * 4) * 2),
+    ]
+
+
+class AdamwParams(Structure):
+    _fields_ = [
+        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+        ("max_grad_norm", c_float), ("step", c_int32), ("n_groups", c_int32), ("grad_partials", c_int32),
+        ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
+        ("tile_layout", POINTER(MlpLayout)), ("tiles", c_void_p),
     ]
 
 
@@ -75,7 +76,7 @@ class ValueJob(Structure):
 
 
 class RolloutStep(Structure):
-    _fields_ = [("params", c_void_p), ("layout", POINTER(MlpLayout)), ("states", c_void_p), ("eps", c_void_p),
+    _fields_ = [("params", c_void_p), ("tiles", c_void_p), ("layout", POINTER(MlpLayout)), ("states", c_void_p), ("eps", c_void_p),
                 ("m", c_int64), ("action", c_void_p), ("logprob", c_void_p), ("value", c_void_p),
                 ("states_copy", c_void_p), ("n_value_jobs", c_int32), ("value_jobs", ValueJob * 2)]
 
@@ -85,7 +86,7 @@ class PpoStepArgs(Structure):
                 ("states", c_void_p), ("action", c_void_p), ("old_logprobs", c_void_p), ("advantages", c_void_p),
                 ("prev_values", c_void_p), ("returns", c_void_p), ("loss_mask", c_void_p), ("loss_mask_sum", c_void_p),
                 ("m", c_int64), ("grad_out", c_float), ("grads", c_void_p), ("slabs", c_int32), ("out", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("tiles", c_void_p)]
 
 
 PPO_OUT_FLOATS = 20
@@ -134,6 +135,8 @@ PROTOTYPES = {
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "rlx_bootstrap_rewards": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rlx_store_env_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rlx_mlp_tiles_bytes": (c_size_t, [POINTER(MlpLayout)]),
+    "rlx_mlp_pack_tiles": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
     "rlx_mlp_rollout_step": (c_int, [POINTER(RolloutStep), c_void_p]),
     "rlx_ppo_step_slabs": (c_int, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),

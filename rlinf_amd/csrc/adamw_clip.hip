@@ -30,7 +30,32 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ gr
     }
     double acc[1] = {0.0};
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // float4 body (slab stride n*4 bytes keeps 16-byte alignment when n % 4 == 0), slabs unrolled four at a time so that
+    // a lane has up to 64 bytes in flight; scalar tail / fallback below
+    const bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
+    const long long n4 = vec ? n / 4 : 0;
+    for (long long i = tid0; i < n4; i += stride) {
+        const float4* gp = reinterpret_cast<const float4*>(grads) + i;
+        float4 g = gp[0];
+        int k = 1;
+        for (; k + 3 < nslab; k += 4) {
+            const float4 x0 = gp[(long long)k * n4], x1 = gp[(long long)(k + 1) * n4], x2 = gp[(long long)(k + 2) * n4],
+                         x3 = gp[(long long)(k + 3) * n4];
+            g.x = (((g.x + x0.x) + x1.x) + x2.x) + x3.x;
+            g.y = (((g.y + x0.y) + x1.y) + x2.y) + x3.y;
+            g.z = (((g.z + x0.z) + x1.z) + x2.z) + x3.z;
+            g.w = (((g.w + x0.w) + x1.w) + x2.w) + x3.w;
+        }
+        for (; k < nslab; ++k) {
+            const float4 x = gp[(long long)k * n4];
+            g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+        }
+        g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
+        if (nslab > 1 || scale != 1.f) reinterpret_cast<float4*>(grads)[i] = g;
+        acc[0] += (double)g.x * (double)g.x + (double)g.y * (double)g.y + (double)g.z * (double)g.z + (double)g.w * (double)g.w;
+    }
+    for (long long i = n4 * 4 + tid0; i < n; i += stride) {
         float g = grads[i];
         for (int k = 1; k < nslab; ++k) g += grads[(long long)k * n + i];
         g *= scale;
@@ -41,10 +66,41 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ gr
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
 
+// Fragment-tile weight image (ppo_step.hip, struct Tiles) kept in step with the flat parameters: the optimizer writes
+// every updated weight to its tile slot(s) as well, so no separate re-pack launch is needed before the next forward.
+__device__ __forceinline__ size_t tile_slot(size_t mat_off, int nit, int n, int k) {
+    return mat_off + ((((size_t)(n >> 4) * nit + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3);
+}
+__device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* __restrict__ tiles, long long i, float val) {
+    constexpr int HIDW = 256, K1P = 64;
+    const size_t per_net = (size_t)HIDW * K1P + 4 * (size_t)HIDW * HIDW;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const long long r0 = i - lay.off_w[y][0];
+        if (r0 >= 0 && r0 < (long long)HIDW * lay.obs_dim) {
+            const int n = (int)(r0 / lay.obs_dim), k = (int)(r0 % lay.obs_dim);
+            tiles[tile_slot(y * per_net, K1P / 32, n, k)] = val;
+            return;
+        }
+#pragma unroll
+        for (int l = 1; l <= 2; ++l) {
+            const long long r = i - lay.off_w[y][l];
+            if (r >= 0 && r < (long long)HIDW * HIDW) {
+                const int o = (int)(r >> 8), in = (int)(r & 255);
+                const size_t base = y * per_net + (size_t)HIDW * K1P;
+                tiles[tile_slot(base + (size_t)(l - 1) * HIDW * HIDW, HIDW / 32, o, in)] = val;       // W_l
+                tiles[tile_slot(base + (size_t)(l + 1) * HIDW * HIDW, HIDW / 32, in, o)] = val;       // W_l^T
+                return;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, rlx_adamw_params a,
                                                          const double* __restrict__ partials, int nparts,
-                                                         float* __restrict__ stats, int* __restrict__ state) {
+                                                         float* __restrict__ stats, int* __restrict__ state,
+                                                         rlx_mlp_layout lay, float* __restrict__ tiles) {
     __shared__ double s_red[4];
     __shared__ float s_coef;
     __shared__ int s_skip;
@@ -94,6 +150,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
+        if (tiles != nullptr) tile_scatter(lay, tiles, i, pi);
     }
 }
 
@@ -152,8 +209,16 @@ extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, 
     hipLaunchKernelGGL(grad_reduce_sqnorm, dim3(nblk), dim3(256), 0, s, grads, (long long)n, p->grad_partials, p->grad_scale,
                        partials, step_state);
     RLX_LAUNCH_CHECK();
+    rlx_mlp_layout lay{};
+    float* tiles = nullptr;
+    if (p->tile_layout != nullptr && p->tiles != nullptr) {
+        lay = *p->tile_layout;
+        tiles = p->tiles;
+        RLX_REQUIRE(lay.hidden == 256 && lay.obs_dim >= 1 && lay.obs_dim <= 64 && lay.n_params == n,
+                    "rlx_clip_adamw_step: tile_layout does not describe these %lld parameters", (long long)n);
+    }
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblk), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long long)n, *p,
-                       partials, nblk, stats, step_state);
+                       partials, nblk, stats, step_state, lay, tiles);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -24,6 +24,8 @@
 // 16-k chunks, one barrier per chunk; two workgroups per CU keep each SIMD's matrix pipe busy while its other wave
 // sits in an epilogue or a barrier.
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ppo_loss_math.h"
@@ -39,10 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int HID = 256;   // hidden width (fixed by the reference: hidden_sizes=(256,256,256))
 constexpr int XS = 264;    // activation slab row stride (floats); stride % 16 == 8 -> conflict-free b128 fragment reads
-constexpr int KC = 16;     // k per weight chunk
-constexpr int WSF = 20;    // forward chunk image  [256 n][KC + 4]
-constexpr int WSB = 260;   // backward chunk image [KC k][256 + 4]
-constexpr int WC_FLOATS = 2 * HID * WSF;  // chunk double buffer (the backward image 2*16*260 is smaller)
+constexpr int KPAD = 32;    // the K loop advances 32 at a time: the slab's k tail is zero-padded to a multiple of it
 constexpr int W4S = 260;   // head weight image row stride
 constexpr int MAX_OUT = 16;  // head outputs supported by the fused kernels (act_dim, val_dim)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
@@ -54,9 +53,63 @@ struct Geo {
     static constexpr int BM = 16 * RT;          // rows per workgroup tile
     static constexpr int NT = 64 * NW;          // threads
     static constexpr int CT = HID / (16 * NW);  // 16-column tiles per wave
-    static constexpr int NLD = 1024 / NT;       // float4 staging loads per thread per weight chunk
-    static constexpr size_t LDS_BYTES = (size_t)(BM * XS + WC_FLOATS) * sizeof(float) + 4096;
+    // LDS: slab [BM][XS] | head image [MAX_OUT][W4S] + bias [MAX_OUT] | 4 x [BM][MAX_OUT] loss scratch | 4 KiB reduction scratch
+    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 4 * BM * MAX_OUT;
+    static constexpr size_t LDS_BYTES = (size_t)(BM * XS + AUX_FLOATS) * sizeof(float) + 4096;
 };
+
+// LDS-only workgroup barrier.  __syncthreads() also fences global memory, i.e. waits vmcnt(0): after a flush of the
+// slab to HBM every barrier would stall for the stores' full round trip.  Nothing a workgroup writes to global memory
+// is read back by it, so only the LDS traffic needs ordering.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// tanh to ~2e-7 absolute: odd polynomial below 0.3, 1 - 2 / (exp(2x) + 1) above (v_exp_f32 + v_rcp_f32), select instead
+// of a branch.  libm's tanhf costs ~4x as many VALU slots; 32-64 of them per lane per layer were a third of the kernel.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float x2 = x * x;
+    const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+    const float e = __expf(2.f * x);
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return fabsf(x) < 0.3f ? poly : big;
+}
+
+// Weight image in MFMA fragment order ("tiles"), rebuilt from the flat parameters after every optimizer step:
+// a 16 (n) x 16 (k) tile is 1 KiB contiguous, float4 number l = kq*16 + r16 of it holds W[n0 + r16][k0 + 4*kq .. +3], so a
+// wave's fragment load is ONE fully coalesced 1 KiB read and consecutive tiles of a column block are consecutive in
+// memory.  Per network: W1 (k zero-padded to 64), W2, W3, W2^T, W3^T (the transposes feed the backward-data GEMMs).
+struct Tiles {
+    static constexpr int K1P = 64;  // first-layer K after padding (obs_dim <= 64 here)
+    __host__ __device__ static constexpr size_t per_net() { return (size_t)HID * K1P + 4 * (size_t)HID * HID; }
+    // m: 0 = W1, 1 = W2, 2 = W3, 3 = W2^T, 4 = W3^T
+    __host__ __device__ static constexpr size_t mat(int y, int m) {
+        return y * per_net() + (m == 0 ? 0 : (size_t)HID * K1P + (size_t)(m - 1) * HID * HID);
+    }
+};
+
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const float* __restrict__ params, rlx_mlp_layout lay,
+                                                         float* __restrict__ tiles) {
+    const size_t total = 2 * Tiles::per_net();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Tiles::per_net());
+        size_t r = i - y * Tiles::per_net();
+        int m = 0, K = Tiles::K1P;
+        if (r >= (size_t)HID * Tiles::K1P) {
+            r -= (size_t)HID * Tiles::K1P;
+            m = 1 + (int)(r / ((size_t)HID * HID));
+            r %= (size_t)HID * HID;
+            K = HID;
+        }
+        // r = ((nb * NIT + it) * 2 + h) * 256 + l * 4 + j
+        const int j = (int)(r & 3), l = (int)((r >> 2) & 63), h = (int)((r >> 8) & 1);
+        const int q = (int)(r >> 9), nit = K / 32, it = q % nit, nb = q / nit;
+        const int n = nb * 16 + (l & 15), k = it * 32 + 16 * h + 4 * (l >> 4) + j;
+        float v;
+        if (m == 0) v = k < lay.obs_dim ? params[lay.off_w[y][0] + (size_t)n * lay.obs_dim + k] : 0.f;
+        else if (m <= 2) v = params[lay.off_w[y][m] + (size_t)n * HID + k];           // W_m[n][k]
+        else v = params[lay.off_w[y][m - 2] + (size_t)k * HID + n];                    // (W_{m-2})^T[n][k] = W[k][n]
+        tiles[i] = v;
+    }
+}
 
 template <int RT, int CT>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][CT]) {
@@ -77,105 +130,94 @@ __device__ __forceinline__ void mfma_step(const f32x4 (&a)[RT], const f32x4 (&b)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], b[ct][q], acc[rt][ct], 0, 0, 0);
 }
 
-// acc = X[0:BM, 0:K] . Wg[0:256, 0:K]^T      Wg row-major [256][ldw]  (a Linear's weight: out x in)
-// VEC: rows are 16-byte aligned and K % 4 == 0 (the hidden layers); otherwise scalar loads with a k < K guard (the
-// first layer: obs_dim = 42 gives 168-byte rows).  All threads must call; ends with a workgroup barrier.
-template <int RT, int NW, bool VEC>
-__device__ __forceinline__ void gemm_fwd(const float* __restrict__ Wg, int ldw, int K, const float* X, float* Wc,
-                                         f32x4 (&acc)[RT][Geo<RT, NW>::CT]) {
+// Phase stamps (development only): block 0 / thread 0 writes the shader clock at phase boundaries into a buffer set
+// with rlx_dev_set_timing_buffer(); the product never sets one.
+struct Stamps {
+    long long* buf;
+    int n;
+    __device__ __forceinline__ void mark() {
+        if (buf != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf[n] = (long long)clock64();
+        ++n;
+    }
+};
+long long* g_timing_buffer = nullptr;
+
+// Ablation switches (development only: tools/bench_step.py times them; the product always runs ABL == 0)
+constexpr int ABL_NO_TANH = 1, ABL_NO_FLUSH = 2, ABL_NO_WLOAD = 4, ABL_NO_MFMA = 8;
+
+// acc = X[0:BM, 0:32*nit] . W^T for one weight matrix given as fragment tiles (struct Tiles).
+// Barrier-free K loop: every wave owns 16*CT output columns, so the weight tiles it needs are its own -- they go
+// L2 -> registers directly (1 KiB coalesced per load instruction), through a ring of PD register stages that keeps PD
+// 32-k iterations of weights in flight.  Only the A operand (the activation slab, read-only during the GEMM) comes
+// from LDS.  The waves of a workgroup never wait for each other inside the loop; one barrier at the end lets the
+// epilogue overwrite the slab.
+// (History, measured on MI355X: weight chunks staged through LDS with a barrier per chunk left the matrix pipe 36 % busy;
+//  row-major weights read as 16 rows x 64 B per instruction cost 75 of 122 us in load issue; a "k < K ? load : 0"
+//  tail select made hipcc serialise 64 L2 round trips.)
+template <int RT, int NW, int PD, int ABL>
+struct RowGemm {
     typedef Geo<RT, NW> G;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-    zero_acc(acc);
-    f32x4 stage[G::NLD];
-    auto gload = [&](int c) {
+    static constexpr int CT = G::CT, KI = 32, MAXIT = HID / KI;
+    f32x4 bq[PD][2][CT];
+    const float* wbase;
+    int nit;
+
+    __device__ __forceinline__ void gload(int it, f32x4 (&b)[2][CT]) {
 #pragma unroll
-        for (int i = 0; i < G::NLD; ++i) {
-            const int f = tid + G::NT * i, n = f >> 2, k = c * KC + (f & 3) * 4;
-            if constexpr (VEC) {
-                stage[i] = k < K ? *reinterpret_cast<const f32x4*>(Wg + (size_t)n * ldw + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-                const float* p = Wg + (size_t)n * ldw + k;
-                f32x4 v;
-                v[0] = k + 0 < K ? p[0] : 0.f;
-                v[1] = k + 1 < K ? p[1] : 0.f;
-                v[2] = k + 2 < K ? p[2] : 0.f;
-                v[3] = k + 3 < K ? p[3] : 0.f;
-                stage[i] = v;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if constexpr (ABL & ABL_NO_WLOAD) b[h][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else b[h][ct] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)(ct * nit + it) * 2 + h) * 256);
+            }
+    }
+    // Issue the first PD iterations of weight loads for matrix P.  Call it BEFORE the epilogue that produces the GEMM's
+    // input: the weights do not depend on it, so their L2 / Infinity-Cache latency hides behind the tanh sweep.
+    __device__ __forceinline__ void prefetch(const float* __restrict__ P, int nit_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        nit = nit_;
+        // tile (nb, it, h) sits at ((nb * nit + it) * 2 + h) * 256 floats; this lane's float4 at + lane * 4
+        wbase = P + ((size_t)(wave * CT) * nit * 2) * 256 + lane * 4;
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d < nit) gload(d, bq[d]);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch loads up here: hipcc otherwise sinks them next to their uses
+    }
+    __device__ __forceinline__ void run(const float* X, f32x4 (&acc)[RT][CT]) {
+        const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+        zero_acc(acc);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if (it >= nit) break;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    a[rt] = *reinterpret_cast<const f32x4*>(X + (rt * 16 + r16) * XS + it * KI + 16 * h + 4 * kq);
+                if constexpr (ABL & ABL_NO_MFMA) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += a[rt] * bq[it % PD][h][ct];
+                } else {
+                    mfma_step(a, bq[it % PD][h], acc);
+                }
+            }
+            if (it + PD < nit) {
+                gload(it + PD, bq[it % PD]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-    };
-    auto swrite = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < G::NLD; ++i) {
-            const int f = tid + G::NT * i;
-            *reinterpret_cast<f32x4*>(buf + (f >> 2) * WSF + (f & 3) * 4) = stage[i];
-        }
-    };
-    const int nchunks = (K + KC - 1) / KC;
-    gload(0);
-    swrite(Wc);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const float* cur = Wc + (c & 1) * HID * WSF;
-        if (c + 1 < nchunks) gload(c + 1);
-        f32x4 a[RT], b[G::CT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(X + (rt * 16 + r16) * XS + c * KC + 4 * kq);
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct)
-            b[ct] = *reinterpret_cast<const f32x4*>(cur + (wave * 16 * G::CT + ct * 16 + r16) * WSF + 4 * kq);
-        mfma_step(a, b, acc);
-        if (c + 1 < nchunks) swrite(Wc + ((c + 1) & 1) * HID * WSF);
-        __syncthreads();
+        lds_barrier();
     }
-}
-
-// acc = X[0:BM, 0:256] . Wg[0:256, 0:256]      (backward-data: dH = dZ . W, W row-major [out = k][in = j])
-template <int RT, int NW>
-__device__ __forceinline__ void gemm_bwd(const float* __restrict__ Wg, const float* X, float* Wc,
-                                         f32x4 (&acc)[RT][Geo<RT, NW>::CT]) {
-    typedef Geo<RT, NW> G;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-    zero_acc(acc);
-    f32x4 stage[G::NLD];
-    auto gload = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < G::NLD; ++i) {
-            const int f = tid + G::NT * i;
-            stage[i] = *reinterpret_cast<const f32x4*>(Wg + (size_t)(c * KC + (f >> 6)) * HID + (f & 63) * 4);
-        }
-    };
-    auto swrite = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < G::NLD; ++i) {
-            const int f = tid + G::NT * i;
-            *reinterpret_cast<f32x4*>(buf + (f >> 6) * WSB + (f & 63) * 4) = stage[i];
-        }
-    };
-    constexpr int nchunks = HID / KC;
-    gload(0);
-    swrite(Wc);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const float* cur = Wc + (c & 1) * KC * WSB;
-        if (c + 1 < nchunks) gload(c + 1);
-        f32x4 a[RT], b[G::CT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(X + (rt * 16 + r16) * XS + c * KC + 4 * kq);
-#pragma unroll
-        for (int ct = 0; ct < G::CT; ++ct)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b[ct][q] = cur[(4 * kq + q) * WSB + wave * 16 * G::CT + ct * 16 + r16];
-        mfma_step(a, b, acc);
-        if (c + 1 < nchunks) swrite(Wc + ((c + 1) & 1) * KC * WSB);
-        __syncthreads();
-    }
-}
+};
 
 // coalesced copy of the slab's first 256 columns to a row-major [M][256] global array (1 KiB per row)
-template <int RT, int NW>
+template <int RT, int NW, int ABL = 0>
 __device__ __forceinline__ void flush_rows(const float* X, float* __restrict__ dst, long long m0, long long M) {
     typedef Geo<RT, NW> G;
+    if constexpr (ABL & ABL_NO_FLUSH) return;
     for (int f = threadIdx.x; f < G::BM * 64; f += G::NT) {
         const int row = f >> 6, c4 = (f & 63) * 4;
         if (m0 + row < M) *reinterpret_cast<f32x4*>(dst + (size_t)(m0 + row) * HID + c4) = *reinterpret_cast<const f32x4*>(X + row * XS + c4);
@@ -188,20 +230,20 @@ template <int RT, int NW>
 __device__ __forceinline__ void load_states(const float* __restrict__ states, float* __restrict__ states_copy, int D,
                                             long long m0, long long M, float* X) {
     typedef Geo<RT, NW> G;
-    const int kp = round_up(D, KC);
+    const int kp = round_up(D, KPAD);
     for (int i = threadIdx.x; i < G::BM * kp; i += G::NT) {
         const int r = i / kp, c = i % kp;
-        float v = 0.f;
-        if (c < D && m0 + r < M) {
-            v = states[(size_t)(m0 + r) * D + c];
-            if (states_copy) states_copy[(size_t)(m0 + r) * D + c] = v;
-        }
-        X[r * XS + c] = v;
+        const bool ok = c < D && m0 + r < M;
+        // clamped, unconditional load (see gemm_rows); rows past M re-read the last row, columns past D the last column
+        const size_t src = (size_t)min(m0 + r, M - 1) * D + min(c, D - 1);
+        const float x = states[src];
+        if (ok && states_copy) states_copy[src] = x;
+        X[r * XS + c] = ok ? x : 0.f;
     }
 }
 
 // forward hidden-layer epilogue: h = tanh(acc + bias) -> slab (in place); KEEP: remember 1 - h^2 per element
-template <int RT, int NW, bool KEEP>
+template <int RT, int NW, bool KEEP, int ABL = 0>
 __device__ __forceinline__ void epilogue_tanh(const f32x4 (&acc)[RT][Geo<RT, NW>::CT], const float* __restrict__ bias, float* X,
                                               f32x4 (*kept)[Geo<RT, NW>::CT]) {
     typedef Geo<RT, NW> G;
@@ -214,12 +256,13 @@ __device__ __forceinline__ void epilogue_tanh(const f32x4 (&acc)[RT][Geo<RT, NW>
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float h = tanhf(acc[rt][ct][r] + b);
+                const float z = acc[rt][ct][r] + b;
+                const float h = (ABL & ABL_NO_TANH) ? fminf(fmaxf(z, -1.f), 1.f) : fast_tanh(z);
                 X[(rt * 16 + 4 * kq + r) * XS + col] = h;
                 if constexpr (KEEP) kept[rt][ct][r] = 1.f - h * h;
             }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // stage the head weight [n_out][256] (+ bias) into LDS with a padded row stride
@@ -261,7 +304,9 @@ struct ValueJob {
     float gamma;
 };
 struct RolloutArgs {
+    long long* stamps;
     const float* params;
+    const float* tiles;
     rlx_mlp_layout lay;
     const float* states;   // policy job (may be nullptr with M == 0)
     const float* eps;
@@ -274,13 +319,13 @@ struct RolloutArgs {
     int tiles_policy, tiles_vj0, tiles_vj1;
 };
 
+template <int PD>
 __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
     constexpr int RT = 1, NW = 8;
     typedef Geo<RT, NW> G;
     extern __shared__ __align__(16) float smem[];
     float* X = smem;
-    float* Wc = smem + G::BM * XS;
-    float* W4s = Wc;                      // the chunk buffer is free once the last GEMM has passed its barrier
+    float* W4s = smem + G::BM * XS;
     float* b4s = W4s + MAX_OUT * W4S;
     const rlx_mlp_layout& lay = a.lay;
     const int D = lay.obs_dim, tid = threadIdx.x;
@@ -298,18 +343,31 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
         if (job == 2) b -= a.tiles_vj0;
         y = 0; m0 = (long long)b * G::BM; M = a.vj[job - 1].m; states = a.vj[job - 1].states;
     }
-    load_states<RT, NW>(states, states_copy, D, m0, M, X);
-    f32x4 acc[RT][G::CT];
-    gemm_fwd<RT, NW, false>(a.params + lay.off_w[y][0], D, D, X, Wc, acc);
-    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][0], X, nullptr);
-    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][1], HID, HID, X, Wc, acc);
-    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][1], X, nullptr);
-    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][2], HID, HID, X, Wc, acc);
-    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][2], X, nullptr);
-
+    Stamps ts{a.stamps, 0};
+    ts.mark();
     const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    RowGemm<RT, NW, PD, 0> gemm;
+    gemm.prefetch(a.tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
+    load_states<RT, NW>(states, states_copy, D, m0, M, X);
     stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
-    __syncthreads();
+    lds_barrier();
+    ts.mark();
+    f32x4 acc[RT][G::CT];
+    gemm.run(X, acc);
+    gemm.prefetch(a.tiles + Tiles::mat(y, 1), HID / 32);
+    ts.mark();
+    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][0], X, nullptr);
+    ts.mark();
+    gemm.run(X, acc);
+    gemm.prefetch(a.tiles + Tiles::mat(y, 2), HID / 32);
+    ts.mark();
+    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][1], X, nullptr);
+    ts.mark();
+    gemm.run(X, acc);
+    ts.mark();
+    epilogue_tanh<RT, NW, false>(acc, a.params + lay.off_b[y][2], X, nullptr);
+    ts.mark();
+
     for (int idx = tid; idx < G::BM * n_out; idx += G::NT) {
         const int row = idx / n_out, o = idx % n_out;
         const float s = head_dot(X + row * XS, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
@@ -337,13 +395,16 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
             }
         }
     }
+    ts.mark();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // fused optimizer-step kernel (1): forward + loss + backward-data for one tile of one network
 // ---------------------------------------------------------------------------------------------------------------
 struct StepArgs {
+    long long* stamps;
     const float* params;
+    const float* tiles;         // fragment-tile weight image (struct Tiles), built by pack_tiles_kernel just before
     rlx_mlp_layout lay;
     const float* states;        // [M, D]
     const float* action;        // [M, act_dim]
@@ -358,28 +419,28 @@ struct StepArgs {
     float grad_out;             // d(total)/d(loss) of this micro-batch (1 / gradient_accumulation)
     float* h;                   // [2 nets][2][M][256]  hidden activations 1, 2   (B operands of the weight gradients)
     float* dz;                  // [2 nets][3][M][256]  pre-activation gradients  (A operands)
-    float* head_part;           // [tiles][2][head_stride]  per-tile head gradients: dW4 [n_out][256], db4 [n_out], dlogstd [n_out]
+    float* head_part;           // [head_parts][2][head_stride]  per-32-row head gradients: dW4 [n_out][256], db4, dlogstd [n_out]
     double* loss_part;          // [tiles][2][NS]
     int head_stride;
 };
 
-template <int RT, int NW>
-__global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_step_fused_kernel(StepArgs a) {
+// OP: head outputs padded to 8 or 16 (compile time): the loops over head outputs run unpredicated on zero padding --
+// a runtime "o < n_out" guard around an LDS read serialises every read behind its own lgkmcnt(0).
+template <int RT, int NW, int PD, int ABL, int OP>
+__global__ __launch_bounds__(64 * NW) void ppo_step_fused_kernel(StepArgs a) {
     typedef Geo<RT, NW> G;
     constexpr int BM = G::BM, CT = G::CT;
     extern __shared__ __align__(16) float smem[];
     float* X = smem;
-    float* Wc = smem + BM * XS;
-    float* W4s = Wc;                                  // [MAX_OUT][W4S]   (chunk buffer reused between the GEMM sweeps)
+    float* W4s = smem + BM * XS;                      // [MAX_OUT][W4S]
     float* b4s = W4s + MAX_OUT * W4S;                 // [MAX_OUT]
     float* sHead = b4s + MAX_OUT;                     // [BM][MAX_OUT] head outputs, then d(loss)/d(head output)
     float* sLp = sHead + BM * MAX_OUT;                // [BM][MAX_OUT] per-dimension log-probs, then per-dim d/d logstd
     float* sG = sLp + BM * MAX_OUT;                   // [BM][MAX_OUT] d(loss)/d(summed log-prob)
     float* sD = sG + BM * MAX_OUT;                    // [BM][MAX_OUT] action - mean
-    double* sRed = reinterpret_cast<double*>(Wc + WC_FLOATS);  // NS * NW doubles of reduction scratch ...
+    double* sRed = reinterpret_cast<double*>(smem + BM * XS + G::AUX_FLOATS);  // NS * NW doubles of reduction scratch ...
     double* sNm = sRed + 256;                         // ... and the mask count (no static __shared__: it would shift the
                                                       // dynamic region off its 16-byte alignment)
-
     const rlx_mlp_layout& lay = a.lay;
     const rlx_ppo_loss_params& p = a.p;
     const int y = blockIdx.y, tile = blockIdx.x, D = lay.obs_dim, tid = threadIdx.x;
@@ -401,23 +462,38 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
     }
 
     // ---- forward -----------------------------------------------------------------------------------------------------
+    Stamps ts{a.stamps, 0};
+    ts.mark();
+    RowGemm<RT, NW, PD, ABL> gemm;
+    gemm.prefetch(a.tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
     load_states<RT, NW>(a.states, nullptr, D, m0, M, X);
+    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    for (int i = tid; i < BM * MAX_OUT; i += G::NT) sHead[i] = 0.f;                       // zero padding for o >= n_out
+    for (int i = n_out * W4S + tid; i < OP * W4S; i += G::NT) W4s[i] = 0.f;
+    lds_barrier();
+    ts.mark();
     f32x4 acc[RT][CT];
     f32x4 kept[3][RT][CT];  // 1 - h_l^2 in the accumulator layout: the backward epilogues need exactly these lanes
     float* hy = a.h + (size_t)(y * 2) * M * HID;
     float* dzy = a.dz + (size_t)(y * 3) * M * HID;
-    gemm_fwd<RT, NW, false>(a.params + lay.off_w[y][0], D, D, X, Wc, acc);
-    epilogue_tanh<RT, NW, true>(acc, a.params + lay.off_b[y][0], X, kept[0]);
-    flush_rows<RT, NW>(X, hy, m0, M);
-    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][1], HID, HID, X, Wc, acc);
-    epilogue_tanh<RT, NW, true>(acc, a.params + lay.off_b[y][1], X, kept[1]);
-    flush_rows<RT, NW>(X, hy + (size_t)M * HID, m0, M);
-    gemm_fwd<RT, NW, true>(a.params + lay.off_w[y][2], HID, HID, X, Wc, acc);
-    epilogue_tanh<RT, NW, true>(acc, a.params + lay.off_b[y][2], X, kept[2]);
+    gemm.run(X, acc);
+    gemm.prefetch(a.tiles + Tiles::mat(y, 1), HID / 32);
+    ts.mark();
+    epilogue_tanh<RT, NW, true, ABL>(acc, a.params + lay.off_b[y][0], X, kept[0]);
+    flush_rows<RT, NW, ABL>(X, hy, m0, M);
+    ts.mark();
+    gemm.run(X, acc);
+    gemm.prefetch(a.tiles + Tiles::mat(y, 2), HID / 32);
+    ts.mark();
+    epilogue_tanh<RT, NW, true, ABL>(acc, a.params + lay.off_b[y][1], X, kept[1]);
+    flush_rows<RT, NW, ABL>(X, hy + (size_t)M * HID, m0, M);
+    ts.mark();
+    gemm.run(X, acc);
+    ts.mark();
+    epilogue_tanh<RT, NW, true, ABL>(acc, a.params + lay.off_b[y][2], X, kept[2]);
+    ts.mark();
 
     // ---- head + loss element math ---------------------------------------------------------------------------------------
-    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
-    __syncthreads();
     const double nm = has_mask ? sNm[0] : 0.0;
     const Denoms den = denominators(p, n_adv, nm, has_mask, has_msum);
     const float half_delta = (float)(0.5 * (double)p.huber_delta);
@@ -430,21 +506,19 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
         const float s = head_dot(X + row * XS, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
         sHead[row * MAX_OUT + o] = s;
         if (y == 1) {
-            const bool valid = m0 + row < M;
-            const size_t g = (size_t)(m0 + row) * n_out + o;
+            const size_t g = (size_t)min(m0 + row, M - 1) * n_out + o;  // clamped (rows past M are discarded below)
             const float stdv = expf(a.params[lay.off_logstd + o]);
-            const float act = valid ? a.action[g] : s;
-            const float d = fsub(act, s);
+            const float d = fsub(a.action[g], s);
             const float var = fmul(stdv, stdv);
             const float log_scale = logf(stdv);
             sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
             sD[row * MAX_OUT + o] = d;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (y == 1) {
-        // one thread per advantage element of the tile: summed log-probs -> ratio / clip / dual clip -> gradient
-        for (int idx = tid; idx < BM * npr; idx += G::NT) {
+        // one lane of wave 0 per advantage element of the tile: summed log-probs -> ratio / clip / dual clip -> gradient
+        for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {  // wave 0 only: its lanes hold every metric sum
             const int row = idx / npr, c = idx % npr;
             if (m0 + row >= M) continue;
             const long long e = (m0 + row) * npr + c;
@@ -464,7 +538,7 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
                 sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int idx = tid; idx < BM * n_out; idx += G::NT) {
             const int row = idx / n_out, o = idx % n_out;
             float dmu = 0.f, dls = 0.f;
@@ -479,7 +553,7 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
             sLp[row * MAX_OUT + o] = dls;
         }
     } else {
-        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+        for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {  // wave 0 only (metric sums)
             const int row = idx / n_out, o = idx % n_out;
             float gv = 0.f;
             if (m0 + row < M && p.has_critic) {
@@ -493,44 +567,58 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
             sHead[row * MAX_OUT + o] = gv;  // overwritten by the thread that read it
         }
     }
-    __syncthreads();
-
-    // ---- head parameter gradients of this tile (h3 is still in the slab) -----------------------------------------------
-    {
-        float* part = a.head_part + ((size_t)tile * 2 + y) * a.head_stride;
-        for (int j = tid; j < HID; j += G::NT) {
-            float s[MAX_OUT];
+    // metric sums of this tile: every contribution sits in wave 0 -> a wave-level reduction, no barrier, no LDS scratch
+    if (wave == 0) {
+        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
 #pragma unroll
-            for (int o = 0; o < MAX_OUT; ++o) s[o] = 0.f;
-            for (int row = 0; row < BM; ++row) {
-                const float hv = X[row * XS + j];
-#pragma unroll
-                for (int o = 0; o < MAX_OUT; ++o)
-                    if (o < n_out) s[o] = fmaf(sHead[row * MAX_OUT + o], hv, s[o]);
-            }
-#pragma unroll
-            for (int o = 0; o < MAX_OUT; ++o)
-                if (o < n_out) part[o * HID + j] = s[o];
-        }
-        if (tid < n_out) {
-            float sb = 0.f, sl = 0.f;
-            for (int row = 0; row < BM; ++row) {
-                sb += sHead[row * MAX_OUT + tid];
-                sl += sLp[row * MAX_OUT + tid];
-            }
-            part[n_out * HID + tid] = sb;
-            part[n_out * HID + n_out + tid] = y == 1 ? sl : 0.f;
+        for (int k = 0; k < NS; ++k) {
+            const double v = wave_sum(lacc[k]);
+            if (lane == 0) lp[k] = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
+    ts.mark();
+
+    // ---- head parameter gradients, per 32-row half tile (h3 is still in the slab): thread = (half, hidden column j) ----
+    for (int u = tid; u < (BM / 32) * HID; u += G::NT) {
+        const int sub = u / HID, j = u % HID, r0 = sub * 32;
+        float* part = a.head_part + ((size_t)(tile * (BM / 32) + sub) * 2 + y) * a.head_stride;
+        float s[OP];
+#pragma unroll
+        for (int o = 0; o < OP; ++o) s[o] = 0.f;
+#pragma unroll 4
+        for (int row = r0; row < r0 + 32; ++row) {
+            const float hv = X[row * XS + j];
+#pragma unroll
+            for (int q = 0; q < OP / 4; ++q) {
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(sHead + row * MAX_OUT + 4 * q);  // same address in every lane
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[4 * q + i] = fmaf(sh[i], hv, s[4 * q + i]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OP; ++o)
+            if (o < n_out) part[o * HID + j] = s[o];
+        if (j < n_out) {
+            float sb = 0.f, sl = 0.f;
+            for (int row = r0; row < r0 + 32; ++row) {
+                sb += sHead[row * MAX_OUT + j];
+                sl += sLp[row * MAX_OUT + j];
+            }
+            part[n_out * HID + j] = sb;
+            part[n_out * HID + n_out + j] = y == 1 ? sl : 0.f;
+        }
+    }
+    ts.mark();
 
     // ---- dZ3 = (dOut . W4) * (1 - h3^2), in the accumulator layout, into the slab ---------------------------------------
+    gemm.prefetch(a.tiles + Tiles::mat(y, 4), HID / 32);  // W3^T tiles for the first backward GEMM
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int col = wave * 16 * CT + ct * 16 + r16;
-        float w4[MAX_OUT];
+        float w4[OP];
 #pragma unroll
-        for (int o = 0; o < MAX_OUT; ++o) w4[o] = o < n_out ? W4s[o * W4S + col] : 0.f;
+        for (int o = 0; o < OP; ++o) w4[o] = W4s[o * W4S + col];  // rows >= n_out are zero
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -538,25 +626,30 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
                 const int row = rt * 16 + 4 * kq + r;
                 float s = 0.f;
 #pragma unroll
-                for (int o = 0; o < MAX_OUT; ++o)
-                    if (o < n_out) s = fmaf(sHead[row * MAX_OUT + o], w4[o], s);
+                for (int q = 0; q < OP / 4; ++q) {
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(sHead + row * MAX_OUT + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s = fmaf(sh[i], w4[4 * q + i], s);
+                }
                 acc[rt][ct][r] = s * kept[2][rt][ct][r];
             }
     }
-    __syncthreads();  // every read of h3 / W4s / sHead is done: the slab and the chunk buffer may be overwritten
+    lds_barrier();  // every read of h3 / sHead is done: the slab may be overwritten
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) X[(rt * 16 + 4 * kq + r) * XS + wave * 16 * CT + ct * 16 + r16] = acc[rt][ct][r];
-    __syncthreads();
-    flush_rows<RT, NW>(X, dzy + 2 * (size_t)M * HID, m0, M);
+    lds_barrier();
+    flush_rows<RT, NW, ABL>(X, dzy + 2 * (size_t)M * HID, m0, M);
+    ts.mark();
 
     // ---- backward-data chain -------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int l = 2; l >= 1; --l) {
-        gemm_bwd<RT, NW>(a.params + lay.off_w[y][l], X, Wc, acc);  // dH_l = dZ_{l+1} . W_{l+1}
+        gemm.run(X, acc);  // dH_l = dZ_{l+1} . W_{l+1}  (W^T tiles, prefetched)
+        if (l == 2) gemm.prefetch(a.tiles + Tiles::mat(y, 3), HID / 32);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -564,17 +657,11 @@ __global__ __launch_bounds__(64 * NW, (RT == 2 && NW == 4) ? 2 : 1) void ppo_ste
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     X[(rt * 16 + 4 * kq + r) * XS + wave * 16 * CT + ct * 16 + r16] = acc[rt][ct][r] * kept[l - 1][rt][ct][r];
-        __syncthreads();
-        flush_rows<RT, NW>(X, dzy + (size_t)(l - 1) * M * HID, m0, M);
+        lds_barrier();
+        flush_rows<RT, NW, ABL>(X, dzy + (size_t)(l - 1) * M * HID, m0, M);
+        ts.mark();
     }
-
-    // ---- metric sums of this tile ----------------------------------------------------------------------------------------------
-    block_sum<NS>(lacc, sRed);
-    if (tid == 0) {
-        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) lp[k] = lacc[k];
-    }
+    ts.mark();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -592,7 +679,8 @@ struct DwArgs {
     long long M;
     int rows_per_slab;       // multiple of 32
     int slabs;
-    int tiles;               // row tiles of the fused kernel
+    int tiles;               // 64-row tiles of the fused kernel (loss partial slots per network)
+    int head_parts;          // 32-row head-gradient partial slots per network
     int head_stride;
     int gemm_items;          // slabs * 20, the grid holds round_up(gemm_items, 8) GEMM blocks
     float* grads;            // [slabs][n_params]
@@ -606,6 +694,7 @@ __device__ __forceinline__ int frag_row32(int r, int khalf) { return (r & 3) + 8
 __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
     __shared__ __align__(16) float As[2][32][128];
     __shared__ __align__(16) float Bs[2][32][128];
+    double* s_red = reinterpret_cast<double*>(&As[0][0][0]);
     const rlx_mlp_layout& lay = a.lay;
     const long long M = a.M;
     const int tid = threadIdx.x;
@@ -615,34 +704,27 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
     if (b >= gemm_blocks) {
         b -= gemm_blocks;
         if (b < a.slabs * 2) {
-            // ---- head gradients: slab s takes the tiles t == s (mod slabs); thread = hidden column j -------------
+            // ---- head gradients: slab s takes the 32-row partials t == s (mod slabs); thread = hidden column j -------------
             const int s = b >> 1, y = b & 1, j = tid;
             const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
             float* slab = a.grads + (size_t)s * lay.n_params;
-            float acc[MAX_OUT];
-#pragma unroll
-            for (int o = 0; o < MAX_OUT; ++o) acc[o] = 0.f;
-            float sb = 0.f, sl = 0.f;
-            for (int t = s; t < a.tiles; t += a.slabs) {
-                const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
-#pragma unroll
-                for (int o = 0; o < MAX_OUT; ++o)
-                    if (o < n_out) acc[o] += part[o * HID + j];
-                if (j < n_out) {
+            for (int o = 0; o < n_out; ++o) {
+                float acc = 0.f;
+                for (int t = s; t < a.head_parts; t += a.slabs) acc += a.head_part[((size_t)t * 2 + y) * a.head_stride + o * HID + j];
+                slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc;
+            }
+            if (j < n_out) {
+                float sb = 0.f, sl = 0.f;
+                for (int t = s; t < a.head_parts; t += a.slabs) {
+                    const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
                     sb += part[n_out * HID + j];
                     sl += part[n_out * HID + n_out + j];
                 }
-            }
-#pragma unroll
-            for (int o = 0; o < MAX_OUT; ++o)
-                if (o < n_out) slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc[o];
-            if (j < n_out) {
                 if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
                 if (y == 1) slab[lay.off_logstd + j] = sl;
             }
         } else {
             // ---- metric row: sum the per-tile partials of both networks ---------------------------------------
-            double* s_red = reinterpret_cast<double*>(&As[0][0][0]);
             double acc[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) acc[k] = 0.0;
@@ -767,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
 int check_layout(const rlx_mlp_layout* lay, const char* who) {
     RLX_REQUIRE(lay != nullptr, "%s: NULL layout", who);
     RLX_REQUIRE(lay->hidden == HID, "%s: hidden=%d is not supported (the reference's MLP policy is 256 wide)", who, lay->hidden);
-    RLX_REQUIRE(lay->obs_dim >= 1 && lay->obs_dim <= 256, "%s: obs_dim=%d out of range [1,256]", who, lay->obs_dim);
+    RLX_REQUIRE(lay->obs_dim >= 1 && lay->obs_dim <= Tiles::K1P, "%s: obs_dim=%d out of range [1,%d]", who, lay->obs_dim, Tiles::K1P);
     RLX_REQUIRE(lay->act_dim >= 1 && lay->act_dim <= MAX_OUT && lay->val_dim >= 1 && lay->val_dim <= MAX_OUT,
                 "%s: act_dim=%d / val_dim=%d out of range [1,%d]", who, lay->act_dim, lay->val_dim, MAX_OUT);
     for (int y = 0; y < 2; ++y)
@@ -782,7 +864,7 @@ int check_layout(const rlx_mlp_layout* lay, const char* who) {
 // once per kernel and process (not a stream operation: keep it out of hipGraph capture regions)
 template <typename K>
 int set_lds(K kern, size_t bytes) {
-    static thread_local const void* done[8] = {};
+    static thread_local const void* done[32] = {};
     const void* key = reinterpret_cast<const void*>(kern);
     for (const void* d : done)
         if (d == key) return RLX_OK;
@@ -792,20 +874,30 @@ int set_lds(K kern, size_t bytes) {
     return RLX_OK;
 }
 
+// development switch: integer environment variable, read once
+int dev_variant(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 int head_stride_of(const rlx_mlp_layout* lay) {
     const int n = std::max(lay->act_dim, lay->val_dim);
     return round_up(n * HID + 2 * n, 4);
 }
 
 struct StepPlan {
-    int tiles, slabs, rows_per_slab, head_stride;
-    size_t off_h, off_dz, off_head, off_loss, bytes;
+    int tiles;        // 64-row tiles of the fused kernel (= loss partial slots per network)
+    int head_parts;   // 32-row head-gradient partial slots per network
+    int slabs, rows_per_slab, head_stride;
+    size_t off_h, off_dz, off_head, off_loss, off_tiles, bytes;
 };
+constexpr int STEP_BM = 64;
 StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m) {
     StepPlan pl{};
-    pl.tiles = ceil_div(m, 32);
+    pl.tiles = ceil_div(m, STEP_BM);
+    pl.head_parts = pl.tiles * (STEP_BM / 32);
     // 20 GEMM items per slab; fill 2 workgroups per CU once (no second, half-empty round)
-    int slabs = std::max(1, std::min(2 * num_cu() / 20, pl.tiles));
+    int slabs = std::max(1, std::min(2 * num_cu() / 20, ceil_div(m, 32)));
     pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
     pl.slabs = ceil_div(m, pl.rows_per_slab);
     pl.head_stride = head_stride_of(lay);
@@ -813,10 +905,17 @@ StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     pl.off_h = take((size_t)4 * m * HID * sizeof(float));
     pl.off_dz = take((size_t)6 * m * HID * sizeof(float));
-    pl.off_head = take((size_t)pl.tiles * 2 * pl.head_stride * sizeof(float));
+    pl.off_head = take((size_t)pl.head_parts * 2 * pl.head_stride * sizeof(float));
     pl.off_loss = take((size_t)pl.tiles * 2 * NS * sizeof(double));
+    pl.off_tiles = take(2 * Tiles::per_net() * sizeof(float));
     pl.bytes = off;
     return pl;
+}
+
+int pack_tiles(const float* params, const rlx_mlp_layout& lay, float* tiles, hipStream_t st) {
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(num_cu() * 4), dim3(256), 0, st, params, lay, tiles);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
 }
 
 }  // namespace
@@ -824,14 +923,18 @@ StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m) {
 
 using namespace rlx;
 
+// development hook (not declared in include/rlx.h): device buffer of >= 32 int64 for the phase stamps, or NULL
+extern "C" void rlx_dev_set_timing_buffer(void* device_ptr) { g_timing_buffer = static_cast<long long*>(device_ptr); }
+
 extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stream) {
     RLX_REQUIRE(r != nullptr, "rlx_mlp_rollout_step: NULL argument struct");
     if (int rc = check_layout(r->layout, "rlx_mlp_rollout_step")) return rc;
-    RLX_REQUIRE(r->params != nullptr, "rlx_mlp_rollout_step: NULL params");
+    RLX_REQUIRE(r->params != nullptr && r->tiles != nullptr, "rlx_mlp_rollout_step: NULL params / tiles");
     RLX_REQUIRE(r->m >= 0 && r->n_value_jobs >= 0 && r->n_value_jobs <= 2, "rlx_mlp_rollout_step: bad sizes");
     RLX_REQUIRE(r->m == 0 || (r->states && r->action && r->logprob && r->value), "rlx_mlp_rollout_step: NULL policy tensor");
     RolloutArgs a{};
-    a.params = r->params; a.lay = *r->layout; a.states = r->states; a.eps = r->eps; a.M = r->m;
+    a.stamps = g_timing_buffer;
+    a.params = r->params; a.tiles = r->tiles; a.lay = *r->layout; a.states = r->states; a.eps = r->eps; a.M = r->m;
     a.action = r->action; a.logprob = r->logprob; a.value = r->value; a.states_copy = r->states_copy;
     a.tiles_policy = ceil_div(r->m, 16);
     int tv[2] = {0, 0};
@@ -846,10 +949,31 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
     const int blocks = 2 * a.tiles_policy + tv[0] + tv[1];
     if (blocks == 0) return RLX_OK;
     const size_t lds = Geo<1, 8>::LDS_BYTES;
-    if (int rc = set_lds(rollout_step_kernel, lds)) return rc;
-    hipLaunchKernelGGL(rollout_step_kernel, dim3(blocks), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int v = dev_variant("RLX_ROLLOUT_PD", 2);
+#define RLX_LAUNCH_ROLLOUT(PDV)                                                                 \
+    do {                                                                                        \
+        if (int rc = set_lds(rollout_step_kernel<PDV>, lds)) return rc;                         \
+        hipLaunchKernelGGL(rollout_step_kernel<PDV>, dim3(blocks), dim3(512), lds, st, a);      \
+    } while (0)
+    if (v == 1) RLX_LAUNCH_ROLLOUT(1);
+    else if (v == 4) RLX_LAUNCH_ROLLOUT(4);
+    else if (v == 8) RLX_LAUNCH_ROLLOUT(8);
+    else RLX_LAUNCH_ROLLOUT(2);
+#undef RLX_LAUNCH_ROLLOUT
     RLX_LAUNCH_CHECK();
     return RLX_OK;
+}
+
+extern "C" size_t rlx_mlp_tiles_bytes(const rlx_mlp_layout* lay) {
+    (void)lay;
+    return 2 * Tiles::per_net() * sizeof(float);
+}
+
+extern "C" int rlx_mlp_pack_tiles(const float* params, const rlx_mlp_layout* lay, float* tiles, rlx_stream_t stream) {
+    if (int rc = check_layout(lay, "rlx_mlp_pack_tiles")) return rc;
+    RLX_REQUIRE(params && tiles, "rlx_mlp_pack_tiles: NULL argument");
+    return pack_tiles(params, *lay, tiles, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rlx_ppo_step_slabs(const rlx_mlp_layout* lay, int64_t m) {
@@ -885,19 +1009,48 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(s->workspace);
     StepArgs a{};
+    a.stamps = g_timing_buffer;
     a.params = s->params; a.lay = lay; a.states = s->states; a.action = s->action; a.old_logprobs = s->old_logprobs;
     a.advantages = s->advantages; a.prev_values = s->prev_values; a.returns = s->returns; a.loss_mask = s->loss_mask;
     a.loss_mask_sum = s->loss_mask_sum; a.M = s->m; a.p = p; a.grad_out = s->grad_out;
     a.h = reinterpret_cast<float*>(ws + pl.off_h); a.dz = reinterpret_cast<float*>(ws + pl.off_dz);
     a.head_part = reinterpret_cast<float*>(ws + pl.off_head); a.loss_part = reinterpret_cast<double*>(ws + pl.off_loss);
     a.head_stride = pl.head_stride;
-    const size_t lds = Geo<2, 4>::LDS_BYTES;
-    if (int rc = set_lds(ppo_step_fused_kernel<2, 4>, lds)) return rc;
-    hipLaunchKernelGGL((ppo_step_fused_kernel<2, 4>), dim3(pl.tiles, 2), dim3(256), lds, st, a);
+    if (s->tiles != nullptr) {
+        a.tiles = s->tiles;
+    } else {
+        float* tiles = reinterpret_cast<float*>(ws + pl.off_tiles);
+        a.tiles = tiles;
+        if (int rc = pack_tiles(s->params, lay, tiles, st)) return rc;
+    }
+    const size_t lds = Geo<4, 8>::LDS_BYTES;
+    const int v = dev_variant("RLX_STEP_VARIANT", 0);  // development: PD * 100 + ablation bits
+    const bool op8 = lay.act_dim <= 8 && lay.val_dim <= 8;
+#define RLX_LAUNCH_FUSED(PDV, ABLV, OPV)                                                                                  \
+    do {                                                                                                                  \
+        if (int rc = set_lds(ppo_step_fused_kernel<4, 8, PDV, ABLV, OPV>, lds)) return rc;                                \
+        hipLaunchKernelGGL((ppo_step_fused_kernel<4, 8, PDV, ABLV, OPV>), dim3(pl.tiles, 2), dim3(512), lds, st, a);      \
+    } while (0)
+    if (!op8) {
+        RLX_LAUNCH_FUSED(2, 0, 16);
+    } else {
+        switch (v) {  // the ablation / prefetch-depth variants exist for 8 padded head outputs only
+            case 201: RLX_LAUNCH_FUSED(2, 1, 8); break;
+            case 202: RLX_LAUNCH_FUSED(2, 2, 8); break;
+            case 204: RLX_LAUNCH_FUSED(2, 4, 8); break;
+            case 208: RLX_LAUNCH_FUSED(2, 8, 8); break;
+            case 200: RLX_LAUNCH_FUSED(2, 0, 8); break;
+            case 400: RLX_LAUNCH_FUSED(4, 0, 8); break;
+            case 300: RLX_LAUNCH_FUSED(3, 0, 8); break;
+            default: RLX_LAUNCH_FUSED(2, 0, 8); break;
+        }
+    }
+#undef RLX_LAUNCH_FUSED
     RLX_LAUNCH_CHECK();
     DwArgs d{};
     d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
-    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_stride = pl.head_stride;
+    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_parts = pl.head_parts;
+    d.head_stride = pl.head_stride;
     d.gemm_items = pl.slabs * 20; d.grads = s->grads; d.p = p; d.has_mask = s->loss_mask != nullptr;
     d.has_msum = s->loss_mask_sum != nullptr; d.out = s->out;
     const int blocks = round_up(d.gemm_items, 8) + pl.slabs * 2 + 1;

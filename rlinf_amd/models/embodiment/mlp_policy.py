@@ -164,9 +164,22 @@ class MLPPolicy(nn.Module):
     def reference_state_dict(self):
         return OrderedDict((name, self.view(name).detach().clone()) for name in self.shapes)
 
-    def mark_updated(self):
-        """Call after the flat parameters change (optimizer step, weight sync): the packed image is rebuilt lazily."""
+    def mark_updated(self, tiles_fresh: bool = False):
+        """Call after the flat parameters change (optimizer step, weight sync): the derived weight images are rebuilt
+        lazily.  ``tiles_fresh``: the optimizer kernel already wrote the new weights into the tile image."""
         self._packed_version = -1
+        if not tiles_fresh:
+            self._tiles_version = -1
+
+    def tiles(self) -> torch.Tensor:
+        """Fragment-tile weight image for the fused launches (ops.mlp_rollout_step / ops.ppo_step); rebuilt lazily, always
+        into the same buffer (captured hipGraphs keep pointing at it)."""
+        ver = self.flat._version
+        t = getattr(self, "_tiles", None)
+        if t is None or t.device != self.flat.device or getattr(self, "_tiles_version", -1) != ver:
+            self._tiles = ops.mlp_pack_tiles(self.flat.data, self.layout, t if (t is not None and t.device == self.flat.device) else None)
+            self._tiles_version = ver
+        return self._tiles
 
     def packed(self) -> torch.Tensor:
         ver = self.flat._version

@@ -398,7 +398,8 @@ def gather_rows(fields: list, index: torch.Tensor, outs: Optional[list] = None) 
 def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                      groups: list, step: int, *, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                      max_grad_norm: float = 0.5, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None,
-                     step_state: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
+                     step_state: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                     tile_layout: Optional[MlpLayout] = None, tiles: Optional[torch.Tensor] = None):
     """In-place clip_grad_norm_ + AdamW over flat f32 buffers.  groups = [(begin, end, lr), ...].
     grads may be [n] or [slabs, n] (split-K slabs, summed first).  Returns stats f32[2] = (norm, applied).
     step_state: device int32[2] keeping the step count on the device (then ``step`` is ignored)."""
@@ -419,6 +420,8 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
     p.step, p.n_groups, p.grad_partials, p.grad_scale = int(step), len(groups), int(slabs), float(grad_scale)
     for k, (b, e, lr) in enumerate(groups):
         p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
+    if tile_layout is not None and tiles is not None:  # keep the fragment-tile weight image in step with the parameters
+        p.tile_layout, p.tiles = ctypes_pointer(tile_layout), tiles.data_ptr()
     if stats is None:
         stats = torch.empty((2,), dtype=torch.float32, device=dev)
     ws_bytes = lib.rlx_adamw_workspace_bytes(n)
@@ -586,15 +589,28 @@ def mlp_train_bwd(params, packed, layout: MlpLayout, states, action, mean, acts,
 # --------------------------------------------------------------------------------------------
 # fused hot launches (ppo_step.hip)
 # --------------------------------------------------------------------------------------------
-def mlp_rollout_step(params: torch.Tensor, layout: MlpLayout, states: Optional[torch.Tensor], eps: Optional[torch.Tensor],
-                     out: Optional[tuple] = None, states_copy: Optional[torch.Tensor] = None, value_jobs: tuple = ()):
+def mlp_pack_tiles(params: torch.Tensor, layout: MlpLayout, tiles: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fragment-tile weight image the fused launches stream (rebuild after every change of ``params``)."""
+    lib = _lib.load()
+    dev = _dev(params)
+    nbytes = lib.rlx_mlp_tiles_bytes(byref(layout))
+    if tiles is None:
+        tiles = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_mlp_pack_tiles(params.data_ptr(), byref(layout), tiles.data_ptr(), _stream_ptr(dev)), "rlx_mlp_pack_tiles")
+    return tiles
+
+
+def mlp_rollout_step(params: torch.Tensor, tiles: torch.Tensor, layout: MlpLayout, states: Optional[torch.Tensor],
+                     eps: Optional[torch.Tensor], out: Optional[tuple] = None, states_copy: Optional[torch.Tensor] = None,
+                     value_jobs: tuple = ()):
     """ONE launch: policy job on ``states`` (-> action, logprob, value rows in ``out``) plus up to two value-only jobs
     ``dict(states=[m,D], values=[m,val]|None, rewards=[m,C]|None, flags=[m,C] bool, gamma=float)``: values <- V(states),
     rewards[:, -1] += gamma * V(states)[:, 0] where flags[:, -1]."""
     lib = _lib.load()
     dev = _dev(params, states, eps, *[j["states"] for j in value_jobs])
     st = RolloutStep()
-    st.params, st.layout = params.data_ptr(), ctypes_pointer(layout)
+    st.params, st.tiles, st.layout = params.data_ptr(), tiles.data_ptr(), ctypes_pointer(layout)
     action = logprob = value = None
     if states is not None:
         s_ = _as_f32(states, "states")
@@ -659,7 +675,7 @@ def ppo_step_workspace_bytes(layout: MlpLayout, m: int) -> int:
 
 
 def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatch: dict, grads: torch.Tensor,
-             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0):
+             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0, tiles: Optional[torch.Tensor] = None):
     """forward + loss + backward of one micro-batch (two launches).  ``mbatch``: states, action, prev_logprobs,
     advantages [, prev_values, returns, loss_mask, loss_mask_sum] as flattened minibatch views; ``grads`` [slabs, n]."""
     lib = _lib.load()
@@ -678,5 +694,6 @@ def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatc
     a.m, a.grad_out = st.shape[0], float(grad_out)
     a.grads, a.slabs, a.out = grads.data_ptr(), grads.shape[0], out_row.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    a.tiles = _ptr(tiles)
     with torch.cuda.device(dev):
         _lib.check(lib.rlx_ppo_step(byref(a), _stream_ptr(dev)), "rlx_ppo_step")

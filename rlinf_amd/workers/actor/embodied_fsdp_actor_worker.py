@@ -41,6 +41,8 @@ class EmbodiedFSDPActor(Worker):
         self.enable_hip_graph = bool(a.get("enable_hip_graph", False))
         # rlx_ppo_step (fused forward + loss + backward); False = the stage-by-stage entry points
         self.fused_step = bool(a.get("fused_step", True))
+        # let the optimizer kernel scatter the new weights into the fragment-tile image (instead of one re-pack launch per step)
+        self.optimizer_writes_tiles = bool(a.get("optimizer_writes_tiles", True))
         self._graph = None
         self._graph_key = None
 
@@ -192,7 +194,8 @@ class EmbodiedFSDPActor(Worker):
         lay = m.layout
         mb = mbatch["states"].shape[0]
         if self.fused_step:
-            ops.ppo_step(m.flat.data, lay, lp, mbatch, grads, out_row, ws["step_ws"], grad_out=self._grad_out_host)
+            ops.ppo_step(m.flat.data, lay, lp, mbatch, grads, out_row, ws["step_ws"], grad_out=self._grad_out_host,
+                         tiles=m.tiles() if self.optimizer_writes_tiles else None)
             return
         ops.mlp_train_fwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], acts=ws["acts"],
                           out=(ws["logprob"], ws["entropy"], ws["value"], ws["mean"]))
@@ -211,8 +214,9 @@ class EmbodiedFSDPActor(Worker):
         ops.mlp_train_bwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], ws["mean"], ws["acts"],
                           ws["d_lp"], None, ws["d_v"], grads=grads, workspace=ws["bwd_ws"])
 
-    def optimizer_step(self, grads: torch.Tensor):
-        """clip_grad_norm_ + AdamW (+ data-parallel mean of the gradient) -> stats (norm, applied) on device."""
+    def optimizer_step(self, grads: torch.Tensor, stats: torch.Tensor | None = None):
+        """clip_grad_norm_ + AdamW (+ data-parallel mean of the gradient) -> stats (norm, applied) on device.  The
+        optimizer kernel also refreshes the fragment-tile weight image the next forward (and the rollout) streams."""
         o = self.cfg.actor.optim
         if self._world_size > 1:
             ops.sum_slabs(grads, out=self.grad_flat)
@@ -220,12 +224,13 @@ class EmbodiedFSDPActor(Worker):
             g, scale = self.grad_flat, 1.0 / self._world_size
         else:
             g, scale = grads, 1.0
+        tiles = self.model.tiles() if (self.fused_step and self.optimizer_writes_tiles) else None
         ops.clip_adamw_step_(self.model.flat.data, g, self.exp_avg, self.exp_avg_sq, self.groups, 0,
                              betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
-                             max_grad_norm=o.clip_grad, grad_scale=scale, stats=self.opt_stats,
-                             step_state=self.step_state, workspace=self.adamw_ws)
-        self.model.flat._version  # noqa: B018  (flat.data was updated in place by the kernel)
-        self.model.mark_updated()
+                             max_grad_norm=o.clip_grad, grad_scale=scale, stats=self.opt_stats if stats is None else stats,
+                             step_state=self.step_state, workspace=self.adamw_ws,
+                             tile_layout=self.model.layout if tiles is not None else None, tiles=tiles)
+        self.model.mark_updated(tiles_fresh=tiles is not None)
         self.optimizer_steps += 1
 
     def _run_update(self, flat: dict, N: int, metrics_dev: torch.Tensor, norms_dev: torch.Tensor):
@@ -249,8 +254,7 @@ class EmbodiedFSDPActor(Worker):
                     mbatch = {k: v[lo:lo + micro] for k, v in flat.items()}
                     self.train_micro_batch(mbatch, ws, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
                                            metrics_dev[step * accum + j], grad_out, lp)
-                self.optimizer_step(grads)
-                norms_dev[step].copy_(self.opt_stats)
+                self.optimizer_step(grads, stats=norms_dev[step])  # (norm, applied) straight into this step's row
                 step += 1
         return step
 

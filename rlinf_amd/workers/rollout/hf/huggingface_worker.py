@@ -31,13 +31,15 @@ class MultiStepRolloutWorker(Worker):
         self.version = step
 
     def sync_model_from_actor(self, flat_params: torch.Tensor | None = None):
-        """Apply the learner's weights (huggingface_worker.py:629-675).  Flat-buffer copy, or nothing when aliased."""
-        if self._shares_actor_weights or flat_params is None:
-            self.hf_model.mark_updated()
-            return
-        with torch.no_grad():
-            self.hf_model.flat.data.copy_(flat_params)
+        """Apply the learner's weights (huggingface_worker.py:629-675).  Flat-buffer copy, or nothing when aliased; then
+        rebuild the fragment-tile weight image HERE, eagerly: the rollout loop may be a replayed hipGraph, which must
+        find fresh tiles in the same buffer (a lazy rebuild inside the captured region would be frozen out of it)."""
+        if not (self._shares_actor_weights or flat_params is None):
+            with torch.no_grad():
+                self.hf_model.flat.data.copy_(flat_params)
         self.hf_model.mark_updated()
+        if self.hf_model.flat.is_cuda:
+            self.hf_model.tiles()
 
     def predict(self, env_obs: dict, out=None, eps=None, mode: str = "train", states_copy=None):
         """-> chunk_actions [B, C, A]; action / logprob / value rows land in ``out`` (the trajectory buffer).  ONE launch:
@@ -47,7 +49,7 @@ class MultiStepRolloutWorker(Worker):
         if mode == "train" and eps is None:
             eps = torch.randn((states.shape[0], m.layout.act_dim), dtype=torch.float32, device=states.device)
         jobs, self._pending = tuple(self._pending), []
-        action, _, _ = ops.mlp_rollout_step(m.flat.data, m.layout, states, eps if mode == "train" else None, out=out,
+        action, _, _ = ops.mlp_rollout_step(m.flat.data, m.tiles(), m.layout, states, eps if mode == "train" else None, out=out,
                                             states_copy=states_copy, value_jobs=jobs)
         return action.view(-1, m.num_action_chunks, m.action_dim)
 
@@ -63,7 +65,7 @@ class MultiStepRolloutWorker(Worker):
         if self._pending:
             jobs, self._pending = tuple(self._pending), []
             m = self.hf_model
-            ops.mlp_rollout_step(m.flat.data, m.layout, None, None, value_jobs=jobs)
+            ops.mlp_rollout_step(m.flat.data, m.tiles(), m.layout, None, None, value_jobs=jobs)
 
     def get_bootstrap_values(self, final_obs: dict, out=None) -> torch.Tensor:
         """Value head only (huggingface_worker.py:612-627); carries at most one queued bootstrap job along."""
@@ -74,7 +76,7 @@ class MultiStepRolloutWorker(Worker):
         if len(self._pending) == 2:
             self.flush_bootstrap()
         jobs, self._pending = tuple(self._pending) + (dict(states=st, values=out),), []
-        ops.mlp_rollout_step(m.flat.data, m.layout, None, None, value_jobs=jobs)
+        ops.mlp_rollout_step(m.flat.data, m.tiles(), m.layout, None, None, value_jobs=jobs)
         return out[:, :1]
 
     def generate(self, *args, **kwargs):

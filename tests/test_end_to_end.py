@@ -21,7 +21,7 @@ def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_e
                        huber_delta=10.0, gamma=gamma, gae_lambda=lam),
         env=dict(train=dict(rollout_epoch=1, total_num_envs=total_envs, auto_reset=auto_reset, ignore_terminations=False,
                             max_episode_steps=5, max_steps_per_rollout_epoch=steps, seed=0, group_size=1)),
-        rollout=dict(pipeline_stage_num=1),
+        rollout=dict(pipeline_stage_num=1, enable_cuda_graph=hip_graph),
         actor=dict(training_backend="fsdp", micro_batch_size=micro_batch or global_batch, global_batch_size=global_batch,
                    seed=1234, enable_hip_graph=hip_graph,
                    model=dict(model_type="mlp_policy", obs_dim=42, action_dim=8, num_action_chunks=1, precision="32",

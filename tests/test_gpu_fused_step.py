@@ -41,7 +41,7 @@ def test_rollout_step_policy_and_value_jobs(M):
     copy = torch.zeros(M, 42, device="cuda")
     last_v = torch.empty(M, 1, device="cuda")
     a, lp, v = ops.mlp_rollout_step(
-        pol.flat.data, pol.layout, states.cuda(), eps.cuda(), states_copy=copy,
+        pol.flat.data, pol.tiles(), pol.layout, states.cuda(), eps.cuda(), states_copy=copy,
         value_jobs=(dict(states=fin.cuda(), rewards=r_dev, flags=flags.cuda(), gamma=0.8),
                     dict(states=last.cuda(), values=last_v)))
     torch.testing.assert_close(a.cpu(), want_a, **FWD)
@@ -52,10 +52,10 @@ def test_rollout_step_policy_and_value_jobs(M):
     assert torch.equal(r_dev.cpu()[~flags], rewards[~flags])  # untouched where the env did not finish
     torch.testing.assert_close(last_v.cpu(), want_last, **FWD)
     # eval mode: action == mean, value-only launch without a policy job
-    a2, _, _ = ops.mlp_rollout_step(pol.flat.data, pol.layout, states.cuda(), None)
+    a2, _, _ = ops.mlp_rollout_step(pol.flat.data, pol.tiles(), pol.layout, states.cuda(), None)
     torch.testing.assert_close(a2.cpu(), ora.act(states, eps=None, mode="eval")[0], **FWD)
     only_v = torch.empty(M, 1, device="cuda")
-    ops.mlp_rollout_step(pol.flat.data, pol.layout, None, None, value_jobs=(dict(states=last.cuda(), values=only_v),))
+    ops.mlp_rollout_step(pol.flat.data, pol.tiles(), pol.layout, None, None, value_jobs=(dict(states=last.cuda(), values=only_v),))
     assert torch.equal(only_v, last_v)
 
 
@@ -141,3 +141,24 @@ def test_ppo_step_matches_unfused_chain():
     got = grads.sum(dim=0)
     torch.testing.assert_close(got, want, rtol=1e-3, atol=float(want.abs().max()) * 2e-4)
     torch.testing.assert_close(row[:16], out_ref[:16], rtol=2e-4, atol=2e-5)
+
+
+def test_optimizer_keeps_tile_image_in_step():
+    """rlx_clip_adamw_step with tile_layout/tiles must leave exactly the image rlx_mlp_pack_tiles would build."""
+    from rlinf_amd import ops
+    _, pol = _policies(seed=5)
+    lay = pol.layout
+    n = lay.n_params
+    tiles = pol.tiles().clone()
+    g = torch.randn(3, n, device="cuda") * 1e-2
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    before = pol.flat.data.clone()
+    ops.clip_adamw_step_(pol.flat.data, g, m, v, pol.group_ranges(3e-3, 1e-3), 1, max_grad_norm=0.5, tile_layout=lay, tiles=tiles)
+    assert not torch.equal(before, pol.flat.data)
+    fresh = ops.mlp_pack_tiles(pol.flat.data, lay)
+    assert torch.equal(tiles, fresh)
+    # a skipped step (non-finite norm) leaves parameters and tiles alone
+    g[0, 7] = float("inf")
+    snap = pol.flat.data.clone()
+    ops.clip_adamw_step_(pol.flat.data, g, m, v, pol.group_ranges(3e-3, 1e-3), 2, max_grad_norm=0.5, tile_layout=lay, tiles=tiles)
+    assert torch.equal(snap, pol.flat.data) and torch.equal(tiles, fresh)

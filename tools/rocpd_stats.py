@@ -26,7 +26,7 @@ def main():
         v = sorted(v)
         wx, vgpr, lds = meta[key]
         blocks = key[1] if by_grid else "-"
-        print(f"{key[0][:70]:70s} {str(blocks):>7s} {len(v):6d} {v[len(v)//2]:9.2f} {v[0]:9.2f} {sum(v)/len(v):9.2f} {sum(v)/1e3:9.3f} {100*sum(v)/tot:6.2f} {wx} {vgpr} {lds}")
+        print(f"{key[0][-70:]:70s} {str(blocks):>7s} {len(v):6d} {v[len(v)//2]:9.2f} {v[0]:9.2f} {sum(v)/len(v):9.2f} {sum(v)/1e3:9.3f} {100*sum(v)/tot:6.2f} {wx} {vgpr} {lds}")
 
 
 if __name__ == "__main__":
