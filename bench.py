@@ -39,7 +39,7 @@ GAMMA, LAMBDA = 0.8, 0.9            # examples/embodiment/config/maniskill_ppo_m
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def build_cfg(world: int, use_graph: bool):
+def build_cfg(world: int, use_graph: bool, precision: str = "32"):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1),
@@ -53,7 +53,7 @@ def build_cfg(world: int, use_graph: bool):
         actor=dict(training_backend="fsdp", micro_batch_size=GLOBAL_BATCH // world, global_batch_size=GLOBAL_BATCH,
                    seed=1234, enable_hip_graph=use_graph, optimizer_writes_tiles=bool(int(os.environ.get("RLX_BENCH_OPT_TILES", "1"))),
                    model=dict(model_type="mlp_policy", obs_dim=OBS_DIM, action_dim=ACT_DIM, num_action_chunks=1,
-                              precision="32", add_value_head=True),
+                              precision=precision, add_value_head=True),
                    optim=dict(lr=3e-4, value_lr=3e-4, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
                               weight_decay=0.01, clip_grad=0.5),
                    fsdp_config=dict(strategy="fsdp", sharding_strategy="no_shard"))))
@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "32"],
+                    help="operand precision of the policy's dense layers: bf16 (BASELINE.json configs[1], f32 accumulate and "
+                         "master weights) or 32 (exact-f32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -201,7 +204,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dev = ctx.device
     use_graph = not args.no_graph
-    runner = build_runner(build_cfg(ctx.world_size, use_graph), ctx)
+    runner = build_runner(build_cfg(ctx.world_size, use_graph, args.precision), ctx)
 
     def barrier():
         if ctx.world_size > 1:
@@ -229,10 +232,10 @@ def main():
             "metric": "env_steps_per_sec", "value": round(ENVS * HORIZON * args.steps / elapsed, 1), "unit": "env-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "ManiSkill PickCube-shaped PPO: 1024 envs x 128 steps, obs 42, act 8, MLP policy "
                                    "(3x256 tanh actor + value head), gamma 0.8 / lambda 0.9, 8 epochs x 16 minibatches "
-                                   "of 8192 (128 optimizer steps), f32 MFMA, synthetic env tensors resident in HBM",
+                                   "of 8192 (128 optimizer steps), " + ("bf16 MFMA operands / f32 accumulate, master weights, losses, GAE, AdamW" if args.precision == "bf16" else "exact-f32 MFMA") + ", synthetic env tensors resident in HBM",
                        "total_envs": ENVS, "horizon": HORIZON, "global_batch": GLOBAL_BATCH, "update_epoch": UPDATE_EPOCH,
                        "parallelism": f"dp{args.gpus}", "hip_graph": use_graph},
             "ppo_updates_per_sec": round(updates * args.steps / elapsed, 1),

@@ -230,6 +230,7 @@ typedef struct rlx_adamw_params {
      * every updated weight is also written to its tile slot(s), which saves the re-pack launch before the next forward */
     const struct rlx_mlp_layout* tile_layout;
     float* tiles;
+    int32_t tiles_bf16;      /* the image is the bf16 one (rlx_mlp_pack_tiles_bf16) */
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);
 /* out[i] = sum_k grads[k][i] (k < slabs): collapse the split-K slabs before a data-parallel all-reduce. */
@@ -332,6 +333,9 @@ int rlx_mlp_train_bwd(const float* params, const float* packed, const rlx_mlp_la
  * ------------------------------------------------------------------------------------------ */
 size_t rlx_mlp_tiles_bytes(const rlx_mlp_layout* layout);
 int rlx_mlp_pack_tiles(const float* params, const rlx_mlp_layout* layout, float* tiles, rlx_stream_t stream);
+/* bf16 variant ("PPO bf16": bf16 operands of the dense layers, f32 accumulate / master weights / everything else):
+ * 16 (out) x 32 (in) bf16 tiles of 1 KiB; needs rlx_mlp_tiles_bytes() / 2 bytes. */
+int rlx_mlp_pack_tiles_bf16(const float* params, const rlx_mlp_layout* layout, void* tiles, rlx_stream_t stream);
 
 typedef struct rlx_value_job {
     const float* states;
@@ -341,6 +345,17 @@ typedef struct rlx_value_job {
     const uint8_t* flags;
     int32_t chunk;
     float gamma;
+    /* optional fused store of the env step's outputs (replaces rlx_store_env_rows + the in-place fold above): when
+     * env_rewards != NULL the job writes, for its rows,  termination_row / truncation_row / done_row (= term | trunc) and
+     * rewards[b, c] = env_rewards[b, c] (+ gamma * V(states)[b, 0] on c = chunk-1 where the flag is set; the flag is
+     * done for flag_is_truncation == 0 (bootstrap_type "always"), truncation otherwise).  `flags` is then ignored. */
+    const float* env_rewards;
+    const uint8_t* env_terminations;
+    const uint8_t* env_truncations;
+    uint8_t* done_row;
+    uint8_t* termination_row;
+    uint8_t* truncation_row;
+    int32_t flag_is_truncation;
 } rlx_value_job;
 typedef struct rlx_rollout_step {
     const float* params;
@@ -355,6 +370,8 @@ typedef struct rlx_rollout_step {
     float* states_copy;
     int32_t n_value_jobs; /* 0..2 */
     rlx_value_job value_jobs[2];
+    int32_t bf16;         /* 0: f32 MFMA, tiles from rlx_mlp_pack_tiles; 1: bf16 MFMA operands (f32 accumulate), tiles
+                             from rlx_mlp_pack_tiles_bf16 */
 } rlx_rollout_step;
 int rlx_mlp_rollout_step(const rlx_rollout_step* step, rlx_stream_t stream);
 
@@ -387,8 +404,9 @@ typedef struct rlx_ppo_step_args {
     float* out;
     void* workspace;
     size_t workspace_bytes;
-    const float* tiles; /* optional: an up-to-date fragment-tile image of params (rlx_mlp_pack_tiles, or kept fresh by
-                           rlx_clip_adamw_step); NULL = rlx_ppo_step packs one into its workspace first */
+    const float* tiles; /* optional: an up-to-date fragment-tile image of params (rlx_mlp_pack_tiles[_bf16], or -- f32 only --
+                           kept fresh by rlx_clip_adamw_step); NULL = rlx_ppo_step packs one into its workspace first */
+    int32_t bf16;       /* 1: bf16 MFMA operands; activations / gradients travel to the weight-gradient kernel as bf16 */
 } rlx_ppo_step_args;
 int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);
 size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);

@@ -66,19 +66,21 @@ class AdamwParams(Structure):
         ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
         ("max_grad_norm", c_float), ("step", c_int32), ("n_groups", c_int32), ("grad_partials", c_int32),
         ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
-        ("tile_layout", POINTER(MlpLayout)), ("tiles", c_void_p),
+        ("tile_layout", POINTER(MlpLayout)), ("tiles", c_void_p), ("tiles_bf16", c_int32),
     ]
 
 
 class ValueJob(Structure):
     _fields_ = [("states", c_void_p), ("m", c_int64), ("values", c_void_p), ("rewards", c_void_p), ("flags", c_void_p),
-                ("chunk", c_int32), ("gamma", c_float)]
+                ("chunk", c_int32), ("gamma", c_float), ("env_rewards", c_void_p), ("env_terminations", c_void_p),
+                ("env_truncations", c_void_p), ("done_row", c_void_p), ("termination_row", c_void_p),
+                ("truncation_row", c_void_p), ("flag_is_truncation", c_int32)]
 
 
 class RolloutStep(Structure):
     _fields_ = [("params", c_void_p), ("tiles", c_void_p), ("layout", POINTER(MlpLayout)), ("states", c_void_p), ("eps", c_void_p),
                 ("m", c_int64), ("action", c_void_p), ("logprob", c_void_p), ("value", c_void_p),
-                ("states_copy", c_void_p), ("n_value_jobs", c_int32), ("value_jobs", ValueJob * 2)]
+                ("states_copy", c_void_p), ("n_value_jobs", c_int32), ("value_jobs", ValueJob * 2), ("bf16", c_int32)]
 
 
 class PpoStepArgs(Structure):
@@ -86,7 +88,7 @@ class PpoStepArgs(Structure):
                 ("states", c_void_p), ("action", c_void_p), ("old_logprobs", c_void_p), ("advantages", c_void_p),
                 ("prev_values", c_void_p), ("returns", c_void_p), ("loss_mask", c_void_p), ("loss_mask_sum", c_void_p),
                 ("m", c_int64), ("grad_out", c_float), ("grads", c_void_p), ("slabs", c_int32), ("out", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("tiles", c_void_p)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("tiles", c_void_p), ("bf16", c_int32)]
 
 
 PPO_OUT_FLOATS = 20
@@ -137,6 +139,7 @@ PROTOTYPES = {
     "rlx_store_env_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_mlp_tiles_bytes": (c_size_t, [POINTER(MlpLayout)]),
     "rlx_mlp_pack_tiles": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
+    "rlx_mlp_pack_tiles_bf16": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
     "rlx_mlp_rollout_step": (c_int, [POINTER(RolloutStep), c_void_p]),
     "rlx_ppo_step_slabs": (c_int, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),

@@ -68,9 +68,18 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ gr
 
 // Fragment-tile weight image (ppo_step.hip, struct Tiles) kept in step with the flat parameters: the optimizer writes
 // every updated weight to its tile slot(s) as well, so no separate re-pack launch is needed before the next forward.
-__device__ __forceinline__ size_t tile_slot(size_t mat_off, int nit, int n, int k) {
+__device__ __forceinline__ size_t tile_slot(size_t mat_off, int nit, int n, int k) {  // f32 tiles: 16 (n) x 16 (k), two per 32 k
     return mat_off + ((((size_t)(n >> 4) * nit + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3);
 }
+__device__ __forceinline__ size_t tile_slot_bf16(size_t mat_off, int nit, int n, int k) {  // bf16 tiles: 16 (n) x 32 (k)
+    return mat_off + (((size_t)(n >> 4) * nit + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
+}
+template <bool BF16>
+__device__ __forceinline__ void tile_store(float* __restrict__ tiles, size_t mat_off, int nit, int n, int k, float val) {
+    if constexpr (BF16) reinterpret_cast<__bf16*>(tiles)[tile_slot_bf16(mat_off, nit, n, k)] = (__bf16)val;
+    else tiles[tile_slot(mat_off, nit, n, k)] = val;
+}
+template <bool BF16>
 __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* __restrict__ tiles, long long i, float val) {
     constexpr int HIDW = 256, K1P = 64;
     const size_t per_net = (size_t)HIDW * K1P + 4 * (size_t)HIDW * HIDW;
@@ -79,7 +88,7 @@ __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* _
         const long long r0 = i - lay.off_w[y][0];
         if (r0 >= 0 && r0 < (long long)HIDW * lay.obs_dim) {
             const int n = (int)(r0 / lay.obs_dim), k = (int)(r0 % lay.obs_dim);
-            tiles[tile_slot(y * per_net, K1P / 32, n, k)] = val;
+            tile_store<BF16>(tiles, y * per_net, K1P / 32, n, k, val);
             return;
         }
 #pragma unroll
@@ -88,8 +97,8 @@ __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* _
             if (r >= 0 && r < (long long)HIDW * HIDW) {
                 const int o = (int)(r >> 8), in = (int)(r & 255);
                 const size_t base = y * per_net + (size_t)HIDW * K1P;
-                tiles[tile_slot(base + (size_t)(l - 1) * HIDW * HIDW, HIDW / 32, o, in)] = val;       // W_l
-                tiles[tile_slot(base + (size_t)(l + 1) * HIDW * HIDW, HIDW / 32, in, o)] = val;       // W_l^T
+                tile_store<BF16>(tiles, base + (size_t)(l - 1) * HIDW * HIDW, HIDW / 32, o, in, val);   // W_l
+                tile_store<BF16>(tiles, base + (size_t)(l + 1) * HIDW * HIDW, HIDW / 32, in, o, val);   // W_l^T
                 return;
             }
         }
@@ -150,7 +159,10 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
-        if (tiles != nullptr) tile_scatter(lay, tiles, i, pi);
+        if (tiles != nullptr) {
+            if (a.tiles_bf16) tile_scatter<true>(lay, tiles, i, pi);
+            else tile_scatter<false>(lay, tiles, i, pi);
+        }
     }
 }
 

@@ -28,63 +28,13 @@
 
 #include <algorithm>
 
-#include "ppo_loss_math.h"
-#include "rlx_common.h"
+#include "ppo_step_common.h"
 
 namespace rlx {
 namespace {
 
 using namespace loss;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int HID = 256;   // hidden width (fixed by the reference: hidden_sizes=(256,256,256))
-constexpr int XS = 264;    // activation slab row stride (floats); stride % 16 == 8 -> conflict-free b128 fragment reads
-constexpr int KPAD = 32;    // the K loop advances 32 at a time: the slab's k tail is zero-padded to a multiple of it
-constexpr int W4S = 260;   // head weight image row stride
-constexpr int MAX_OUT = 16;  // head outputs supported by the fused kernels (act_dim, val_dim)
-constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
-
-__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-
-template <int RT, int NW>
-struct Geo {
-    static constexpr int BM = 16 * RT;          // rows per workgroup tile
-    static constexpr int NT = 64 * NW;          // threads
-    static constexpr int CT = HID / (16 * NW);  // 16-column tiles per wave
-    // LDS: slab [BM][XS] | head image [MAX_OUT][W4S] + bias [MAX_OUT] | 4 x [BM][MAX_OUT] loss scratch | 4 KiB reduction scratch
-    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 4 * BM * MAX_OUT;
-    static constexpr size_t LDS_BYTES = (size_t)(BM * XS + AUX_FLOATS) * sizeof(float) + 4096;
-};
-
-// LDS-only workgroup barrier.  __syncthreads() also fences global memory, i.e. waits vmcnt(0): after a flush of the
-// slab to HBM every barrier would stall for the stores' full round trip.  Nothing a workgroup writes to global memory
-// is read back by it, so only the LDS traffic needs ordering.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// tanh to ~2e-7 absolute: odd polynomial below 0.3, 1 - 2 / (exp(2x) + 1) above (v_exp_f32 + v_rcp_f32), select instead
-// of a branch.  libm's tanhf costs ~4x as many VALU slots; 32-64 of them per lane per layer were a third of the kernel.
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float x2 = x * x;
-    const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
-    const float e = __expf(2.f * x);
-    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-    return fabsf(x) < 0.3f ? poly : big;
-}
-
-// Weight image in MFMA fragment order ("tiles"), rebuilt from the flat parameters after every optimizer step:
-// a 16 (n) x 16 (k) tile is 1 KiB contiguous, float4 number l = kq*16 + r16 of it holds W[n0 + r16][k0 + 4*kq .. +3], so a
-// wave's fragment load is ONE fully coalesced 1 KiB read and consecutive tiles of a column block are consecutive in
-// memory.  Per network: W1 (k zero-padded to 64), W2, W3, W2^T, W3^T (the transposes feed the backward-data GEMMs).
-struct Tiles {
-    static constexpr int K1P = 64;  // first-layer K after padding (obs_dim <= 64 here)
-    __host__ __device__ static constexpr size_t per_net() { return (size_t)HID * K1P + 4 * (size_t)HID * HID; }
-    // m: 0 = W1, 1 = W2, 2 = W3, 3 = W2^T, 4 = W3^T
-    __host__ __device__ static constexpr size_t mat(int y, int m) {
-        return y * per_net() + (m == 0 ? 0 : (size_t)HID * K1P + (size_t)(m - 1) * HID * HID);
-    }
-};
+using namespace step;
 
 __global__ __launch_bounds__(256) void pack_tiles_kernel(const float* __restrict__ params, rlx_mlp_layout lay,
                                                          float* __restrict__ tiles) {
@@ -130,20 +80,7 @@ __device__ __forceinline__ void mfma_step(const f32x4 (&a)[RT], const f32x4 (&b)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], b[ct][q], acc[rt][ct], 0, 0, 0);
 }
 
-// Phase stamps (development only): block 0 / thread 0 writes the shader clock at phase boundaries into a buffer set
-// with rlx_dev_set_timing_buffer(); the product never sets one.
-struct Stamps {
-    long long* buf;
-    int n;
-    __device__ __forceinline__ void mark() {
-        if (buf != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf[n] = (long long)clock64();
-        ++n;
-    }
-};
 long long* g_timing_buffer = nullptr;
-
-// Ablation switches (development only: tools/bench_step.py times them; the product always runs ABL == 0)
-constexpr int ABL_NO_TANH = 1, ABL_NO_FLUSH = 2, ABL_NO_WLOAD = 4, ABL_NO_MFMA = 8;
 
 // acc = X[0:BM, 0:32*nit] . W^T for one weight matrix given as fragment tiles (struct Tiles).
 // Barrier-free K loop: every wave owns 16*CT output columns, so the weight tiles it needs are its own -- they go
@@ -162,13 +99,16 @@ struct RowGemm {
     const float* wbase;
     int nit;
 
+    // (Rotating the k-tile order per workgroup, to spread identical requests over the L2 channels, was measured: no gain,
+    //  and it makes results depend on the block index -- dropped.)
     __device__ __forceinline__ void gload(int it, f32x4 (&b)[2][CT]) {
+        const int itx = it;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 if constexpr (ABL & ABL_NO_WLOAD) b[h][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                else b[h][ct] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)(ct * nit + it) * 2 + h) * 256);
+                else b[h][ct] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)(ct * nit + itx) * 2 + h) * 256);
             }
     }
     // Issue the first PD iterations of weight loads for matrix P.  Call it BEFORE the epilogue that produces the GEMM's
@@ -265,16 +205,6 @@ __device__ __forceinline__ void epilogue_tanh(const f32x4 (&acc)[RT][Geo<RT, NW>
     lds_barrier();
 }
 
-// stage the head weight [n_out][256] (+ bias) into LDS with a padded row stride
-__device__ __forceinline__ void stage_head(const float* __restrict__ W4, const float* __restrict__ b4, int n_out, float* W4s,
-                                           float* b4s, int nthreads) {
-    for (int f = threadIdx.x; f < n_out * 64; f += nthreads) {
-        const int o = f >> 6, c4 = (f & 63) * 4;
-        *reinterpret_cast<f32x4*>(W4s + o * W4S + c4) = *reinterpret_cast<const f32x4*>(W4 + (size_t)o * HID + c4);
-    }
-    if ((int)threadIdx.x < n_out) b4s[threadIdx.x] = b4 ? b4[threadIdx.x] : 0.f;
-}
-
 // head output (row, o): fmaf chain over the 256 hidden units in k order, then the bias
 __device__ __forceinline__ float head_dot(const float* xr, const float* wr, float bias, bool has_bias) {
     float s = 0.f;
@@ -294,31 +224,6 @@ __device__ __forceinline__ float head_dot(const float* xr, const float* wr, floa
 // ---------------------------------------------------------------------------------------------------------------
 // rollout step: RT = 1 (16-row tiles), NW = 8 (512 threads): latency matters, B is ~1024 rows per step
 // ---------------------------------------------------------------------------------------------------------------
-struct ValueJob {
-    const float* states;
-    long long m;
-    float* values;         // [m, val_dim] or nullptr
-    float* rewards;        // [m, chunk] in place, or nullptr
-    const uint8_t* flags;  // [m, chunk]
-    int chunk;
-    float gamma;
-};
-struct RolloutArgs {
-    long long* stamps;
-    const float* params;
-    const float* tiles;
-    rlx_mlp_layout lay;
-    const float* states;   // policy job (may be nullptr with M == 0)
-    const float* eps;
-    long long M;
-    float* action;
-    float* logprob;
-    float* value;
-    float* states_copy;
-    ValueJob vj[2];
-    int tiles_policy, tiles_vj0, tiles_vj1;
-};
-
 template <int PD>
 __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
     constexpr int RT = 1, NW = 8;
@@ -387,12 +292,7 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
             a.logprob[g] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
             a.action[g] = act;
         } else {
-            const ValueJob& v = a.vj[job - 1];
-            if (v.values) v.values[g] = s;
-            if (v.rewards && o == 0) {  // r[:, -1] += gamma * V(final_obs)[:, 0] where flags[:, -1] (env_worker.py:744-758)
-                const size_t i = (size_t)(m0 + row) * v.chunk + (v.chunk - 1);
-                if (v.flags[i]) v.rewards[i] = fadd(v.rewards[i], fmul(v.gamma, s));
-            }
+            value_job_output(a.vj[job - 1], g, (size_t)(m0 + row), o, s);
         }
     }
     ts.mark();
@@ -401,29 +301,6 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // fused optimizer-step kernel (1): forward + loss + backward-data for one tile of one network
 // ---------------------------------------------------------------------------------------------------------------
-struct StepArgs {
-    long long* stamps;
-    const float* params;
-    const float* tiles;         // fragment-tile weight image (struct Tiles), built by pack_tiles_kernel just before
-    rlx_mlp_layout lay;
-    const float* states;        // [M, D]
-    const float* action;        // [M, act_dim]
-    const float* old_logprobs;  // [M, act_dim]
-    const float* advantages;    // [M * adv_per_row]
-    const float* prev_values;   // [M * adv_per_row] (has_critic)
-    const float* returns;
-    const uint8_t* loss_mask;   // [M * adv_per_row] or nullptr
-    const int64_t* loss_mask_sum;
-    long long M;
-    rlx_ppo_loss_params p;
-    float grad_out;             // d(total)/d(loss) of this micro-batch (1 / gradient_accumulation)
-    float* h;                   // [2 nets][2][M][256]  hidden activations 1, 2   (B operands of the weight gradients)
-    float* dz;                  // [2 nets][3][M][256]  pre-activation gradients  (A operands)
-    float* head_part;           // [head_parts][2][head_stride]  per-32-row head gradients: dW4 [n_out][256], db4, dlogstd [n_out]
-    double* loss_part;          // [tiles][2][NS]
-    int head_stride;
-};
-
 // OP: head outputs padded to 8 or 16 (compile time): the loops over head outputs run unpredicated on zero padding --
 // a runtime "o < n_out" guard around an LDS read serialises every read behind its own lgkmcnt(0).
 template <int RT, int NW, int PD, int ABL, int OP>
@@ -669,26 +546,6 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_kernel(StepArgs a) {
 //   1-D grid: [GEMM items (padded to a multiple of 8, XCD-grouped)] [slabs x 2 head-fold blocks] [1 finalise block]
 //   GEMM item = (slab, matrix, 128x128 output tile); 4 waves as 2x2, each 2x2 tiles of v_mfma_f32_32x32x2_f32.
 // ---------------------------------------------------------------------------------------------------------------
-struct DwArgs {
-    rlx_mlp_layout lay;
-    const float* states;
-    const float* h;          // [2][2][M][256]
-    const float* dz;         // [2][3][M][256]
-    const float* head_part;  // [tiles][2][head_stride]
-    const double* loss_part; // [tiles][2][NS]
-    long long M;
-    int rows_per_slab;       // multiple of 32
-    int slabs;
-    int tiles;               // 64-row tiles of the fused kernel (loss partial slots per network)
-    int head_parts;          // 32-row head-gradient partial slots per network
-    int head_stride;
-    int gemm_items;          // slabs * 20, the grid holds round_up(gemm_items, 8) GEMM blocks
-    float* grads;            // [slabs][n_params]
-    rlx_ppo_loss_params p;
-    int has_mask, has_msum;
-    float* out;              // metric row (RLX_PPO_OUT_FLOATS)
-};
-
 __device__ __forceinline__ int frag_row32(int r, int khalf) { return (r & 3) + 8 * (r >> 2) + 4 * khalf; }
 
 __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
@@ -846,72 +703,6 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
     }
 }
 
-int check_layout(const rlx_mlp_layout* lay, const char* who) {
-    RLX_REQUIRE(lay != nullptr, "%s: NULL layout", who);
-    RLX_REQUIRE(lay->hidden == HID, "%s: hidden=%d is not supported (the reference's MLP policy is 256 wide)", who, lay->hidden);
-    RLX_REQUIRE(lay->obs_dim >= 1 && lay->obs_dim <= Tiles::K1P, "%s: obs_dim=%d out of range [1,%d]", who, lay->obs_dim, Tiles::K1P);
-    RLX_REQUIRE(lay->act_dim >= 1 && lay->act_dim <= MAX_OUT && lay->val_dim >= 1 && lay->val_dim <= MAX_OUT,
-                "%s: act_dim=%d / val_dim=%d out of range [1,%d]", who, lay->act_dim, lay->val_dim, MAX_OUT);
-    for (int y = 0; y < 2; ++y)
-        for (int l = 0; l < 4; ++l) {
-            RLX_REQUIRE(lay->off_w[y][l] >= 0 && lay->off_w[y][l] < lay->n_params, "%s: weight offset out of range", who);
-            RLX_REQUIRE(lay->off_w[y][l] % 4 == 0 || l == 0, "%s: weight offsets of layers 2-4 must be 16-byte aligned", who);
-            RLX_REQUIRE(l == 3 || lay->off_b[y][l] >= 0, "%s: hidden layers need a bias", who);
-        }
-    return RLX_OK;
-}
-
-// once per kernel and process (not a stream operation: keep it out of hipGraph capture regions)
-template <typename K>
-int set_lds(K kern, size_t bytes) {
-    static thread_local const void* done[32] = {};
-    const void* key = reinterpret_cast<const void*>(kern);
-    for (const void* d : done)
-        if (d == key) return RLX_OK;
-    RLX_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    for (auto& d : done)
-        if (d == nullptr) { d = key; break; }
-    return RLX_OK;
-}
-
-// development switch: integer environment variable, read once
-int dev_variant(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-int head_stride_of(const rlx_mlp_layout* lay) {
-    const int n = std::max(lay->act_dim, lay->val_dim);
-    return round_up(n * HID + 2 * n, 4);
-}
-
-struct StepPlan {
-    int tiles;        // 64-row tiles of the fused kernel (= loss partial slots per network)
-    int head_parts;   // 32-row head-gradient partial slots per network
-    int slabs, rows_per_slab, head_stride;
-    size_t off_h, off_dz, off_head, off_loss, off_tiles, bytes;
-};
-constexpr int STEP_BM = 64;
-StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m) {
-    StepPlan pl{};
-    pl.tiles = ceil_div(m, STEP_BM);
-    pl.head_parts = pl.tiles * (STEP_BM / 32);
-    // 20 GEMM items per slab; fill 2 workgroups per CU once (no second, half-empty round)
-    int slabs = std::max(1, std::min(2 * num_cu() / 20, ceil_div(m, 32)));
-    pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
-    pl.slabs = ceil_div(m, pl.rows_per_slab);
-    pl.head_stride = head_stride_of(lay);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-    pl.off_h = take((size_t)4 * m * HID * sizeof(float));
-    pl.off_dz = take((size_t)6 * m * HID * sizeof(float));
-    pl.off_head = take((size_t)pl.head_parts * 2 * pl.head_stride * sizeof(float));
-    pl.off_loss = take((size_t)pl.tiles * 2 * NS * sizeof(double));
-    pl.off_tiles = take(2 * Tiles::per_net() * sizeof(float));
-    pl.bytes = off;
-    return pl;
-}
-
 int pack_tiles(const float* params, const rlx_mlp_layout& lay, float* tiles, hipStream_t st) {
     hipLaunchKernelGGL(pack_tiles_kernel, dim3(num_cu() * 4), dim3(256), 0, st, params, lay, tiles);
     RLX_LAUNCH_CHECK();
@@ -941,15 +732,21 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
     for (int k = 0; k < r->n_value_jobs; ++k) {
         const rlx_value_job& j = r->value_jobs[k];
         RLX_REQUIRE(j.m >= 0 && (j.m == 0 || j.states != nullptr), "rlx_mlp_rollout_step: value job %d has no states", k);
-        RLX_REQUIRE(j.rewards == nullptr || (j.flags != nullptr && j.chunk >= 1), "rlx_mlp_rollout_step: value job %d folds rewards without flags", k);
-        a.vj[k] = ValueJob{j.states, j.m, j.values, j.rewards, j.flags, j.chunk, j.gamma};
+        const bool env_store = j.env_rewards != nullptr;
+        RLX_REQUIRE(j.rewards == nullptr || ((env_store || j.flags != nullptr) && j.chunk >= 1),
+                    "rlx_mlp_rollout_step: value job %d folds rewards without flags", k);
+        RLX_REQUIRE(!env_store || (j.rewards && j.env_terminations && j.env_truncations && j.done_row && j.termination_row && j.truncation_row),
+                    "rlx_mlp_rollout_step: value job %d stores env rows but a pointer is NULL", k);
+        a.vj[k] = ValueJob{j.states, j.m, j.values, j.rewards, j.flags, j.chunk, j.gamma, j.env_rewards, j.env_terminations,
+                           j.env_truncations, j.done_row, j.termination_row, j.truncation_row, j.flag_is_truncation};
         tv[k] = ceil_div(j.m, 16);
     }
     a.tiles_vj0 = tv[0]; a.tiles_vj1 = tv[1];
     const int blocks = 2 * a.tiles_policy + tv[0] + tv[1];
     if (blocks == 0) return RLX_OK;
-    const size_t lds = Geo<1, 8>::LDS_BYTES;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (r->bf16) return launch_rollout_bf16(a, blocks, st);
+    const size_t lds = Geo<1, 8>::LDS_BYTES;
     const int v = dev_variant("RLX_ROLLOUT_PD", 2);
 #define RLX_LAUNCH_ROLLOUT(PDV)                                                                 \
     do {                                                                                        \
@@ -976,6 +773,12 @@ extern "C" int rlx_mlp_pack_tiles(const float* params, const rlx_mlp_layout* lay
     return pack_tiles(params, *lay, tiles, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int rlx_mlp_pack_tiles_bf16(const float* params, const rlx_mlp_layout* lay, void* tiles, rlx_stream_t stream) {
+    if (int rc = check_layout(lay, "rlx_mlp_pack_tiles_bf16")) return rc;
+    RLX_REQUIRE(params && tiles, "rlx_mlp_pack_tiles_bf16: NULL argument");
+    return pack_tiles_bf16(params, *lay, tiles, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int rlx_ppo_step_slabs(const rlx_mlp_layout* lay, int64_t m) {
     if (!lay || m <= 0) return 1;
     return plan_step(lay, m).slabs;
@@ -983,7 +786,7 @@ extern "C" int rlx_ppo_step_slabs(const rlx_mlp_layout* lay, int64_t m) {
 
 extern "C" size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* lay, int64_t m) {
     if (!lay || m <= 0) return 256;
-    return plan_step(lay, m).bytes;
+    return std::max(plan_step(lay, m, false).bytes, plan_step(lay, m, true).bytes);  // either precision fits
 }
 
 extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
@@ -1000,7 +803,8 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     RLX_REQUIRE(s->params && s->states && s->action && s->old_logprobs && s->advantages && s->grads && s->out && s->workspace,
                 "rlx_ppo_step: NULL argument");
     RLX_REQUIRE(!p.has_critic || (s->prev_values && s->returns), "rlx_ppo_step: has_critic set but a critic tensor is NULL");
-    const StepPlan pl = plan_step(&lay, s->m);
+    const bool bf16 = s->bf16 != 0;
+    const StepPlan pl = plan_step(&lay, s->m, bf16);
     RLX_REQUIRE(s->slabs == pl.slabs, "rlx_ppo_step: grads holds %d slabs, rlx_ppo_step_slabs() says %d", s->slabs, pl.slabs);
     if (s->workspace_bytes < pl.bytes) {
         set_error("rlx_ppo_step: workspace %zu < %zu bytes", s->workspace_bytes, pl.bytes);
@@ -1016,6 +820,23 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     a.h = reinterpret_cast<float*>(ws + pl.off_h); a.dz = reinterpret_cast<float*>(ws + pl.off_dz);
     a.head_part = reinterpret_cast<float*>(ws + pl.off_head); a.loss_part = reinterpret_cast<double*>(ws + pl.off_loss);
     a.head_stride = pl.head_stride;
+    DwArgs d{};
+    d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
+    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_parts = pl.head_parts;
+    d.head_stride = pl.head_stride;
+    d.gemm_items = pl.slabs * 20; d.grads = s->grads; d.p = p; d.has_mask = s->loss_mask != nullptr;
+    d.has_msum = s->loss_mask_sum != nullptr; d.out = s->out;
+    const int dw_blocks = round_up(d.gemm_items, 8) + pl.slabs * 2 + 1;
+    if (bf16) {
+        if (s->tiles != nullptr) {
+            a.tiles = s->tiles;
+        } else {
+            void* tiles = ws + pl.off_tiles;
+            a.tiles = static_cast<const float*>(tiles);
+            if (int rc = pack_tiles_bf16(s->params, lay, tiles, st)) return rc;
+        }
+        return launch_step_bf16(a, d, ws + pl.off_st, pl.tiles, dw_blocks, lay.act_dim <= 8 && lay.val_dim <= 8, st);
+    }
     if (s->tiles != nullptr) {
         a.tiles = s->tiles;
     } else {
@@ -1047,13 +868,7 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     }
 #undef RLX_LAUNCH_FUSED
     RLX_LAUNCH_CHECK();
-    DwArgs d{};
-    d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
-    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_parts = pl.head_parts;
-    d.head_stride = pl.head_stride;
-    d.gemm_items = pl.slabs * 20; d.grads = s->grads; d.p = p; d.has_mask = s->loss_mask != nullptr;
-    d.has_msum = s->loss_mask_sum != nullptr; d.out = s->out;
-    const int blocks = round_up(d.gemm_items, 8) + pl.slabs * 2 + 1;
+    const int blocks = dw_blocks;
     hipLaunchKernelGGL(ppo_step_dw_kernel, dim3(blocks), dim3(256), 0, st, d);
     RLX_LAUNCH_CHECK();
     return RLX_OK;

@@ -1,0 +1,708 @@
+// ppo_step_bf16.hip -- the fused rollout / optimizer-step launches with bf16 MFMA operands (f32 accumulate), gfx950.
+//
+// "PPO bf16" (BASELINE.json configs[1]; the reference's amp_autocast / precision: bf16 switch, rlinf/hybrid_engines/fsdp/
+// fsdp_model_manager.py:122-142, examples/embodiment/config/maniskill_ppo_mlp.yaml:98,128-131): master weights, biases,
+// heads, log-probs, losses, GAE and the optimizer stay f32; only the operands of the 256-wide dense layers are bf16,
+// accumulated in f32 by v_mfma_f32_16x16x32_bf16 (one instruction per 16x16 tile and 32 k: 1/16 of the f32 MFMA time).
+// Same decomposition as ppo_step.hip; what changes with the element size:
+//   * the activation slab lives in LDS as bf16 (row stride 272 elements: conflict-free 16-byte fragment reads);
+//   * weight tiles are 16 (n) x 32 (k) bf16 = 1 KiB, a fragment load is ONE coalesced b128 per lane;
+//   * activations / pre-activation gradients leave the fused kernel as bf16 in a k-tiled TRANSPOSED layout
+//     (16 columns x 32 batch rows per 1 KiB tile, the weight-gradient GEMM's fragment order), written straight from the
+//     accumulator registers with 512-byte coalesced stores -- the weight-gradient kernel then streams both operands
+//     L2 -> registers with no LDS and no barrier at all.
+
+#include "ppo_step_common.h"
+
+namespace rlx {
+namespace {
+
+using namespace loss;
+using namespace step;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XSB = 272;  // bf16 slab row stride (elements): 136 dwords == 8 (mod 16) -> conflict-free b128 fragment reads
+
+template <int RT, int NW>
+struct GeoB {
+    static constexpr int BM = 16 * RT, NT = 64 * NW, CT = HID / (16 * NW);
+    static constexpr int SLAB_FLOATS = BM * XSB / 2;  // the bf16 slab measured in floats
+    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 4 * BM * MAX_OUT;
+    static constexpr size_t LDS_BYTES = (size_t)(SLAB_FLOATS + AUX_FLOATS) * sizeof(float) + 4096;
+};
+
+// bf16 weight tiles: same matrix list and element offsets as struct Tiles, tile = 16 (n) x 32 (k):
+//   element ((nb * nit + it) * 64 + l) * 8 + j  holds  W[nb*16 + (l & 15)][it*32 + 8*(l >> 4) + j]
+__global__ __launch_bounds__(256) void pack_tiles_bf16_kernel(const float* __restrict__ params, rlx_mlp_layout lay,
+                                                              __bf16* __restrict__ tiles) {
+    const size_t total = 2 * Tiles::per_net();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Tiles::per_net());
+        size_t r = i - y * Tiles::per_net();
+        int m = 0, K = Tiles::K1P;
+        if (r >= (size_t)HID * Tiles::K1P) {
+            r -= (size_t)HID * Tiles::K1P;
+            m = 1 + (int)(r / ((size_t)HID * HID));
+            r %= (size_t)HID * HID;
+            K = HID;
+        }
+        const int j = (int)(r & 7), l = (int)((r >> 3) & 63);
+        const int q = (int)(r >> 9), nit = K / 32, it = q % nit, nb = q / nit;
+        const int n = nb * 16 + (l & 15), k = it * 32 + 8 * (l >> 4) + j;
+        float v;
+        if (m == 0) v = k < lay.obs_dim ? params[lay.off_w[y][0] + (size_t)n * lay.obs_dim + k] : 0.f;
+        else if (m <= 2) v = params[lay.off_w[y][m] + (size_t)n * HID + k];
+        else v = params[lay.off_w[y][m - 2] + (size_t)k * HID + n];
+        tiles[i] = (__bf16)v;
+    }
+}
+
+template <int RT, int CT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][CT]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc = Xb[0:BM, 0:32*nit] . W^T, weights as bf16 fragment tiles streamed L2 -> registers (ring of PD stages), the A operand
+// from the bf16 LDS slab; no barrier inside the loop, one at the end.
+template <int RT, int NW, int PD>
+struct RowGemmB {
+    typedef GeoB<RT, NW> G;
+    static constexpr int CT = G::CT, KI = 32, MAXIT = HID / KI;
+    bf16x8 bq[PD][CT];
+    const __bf16* wbase;
+    int nit;
+
+    // (Rotating the k-tile order per workgroup, to spread identical requests over the L2 channels, was measured: no gain,
+    //  and it makes results depend on the block index -- dropped.)
+    __device__ __forceinline__ void gload(int it, bf16x8 (&b)[CT]) {
+        const int itx = it;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) b[ct] = *reinterpret_cast<const bf16x8*>(wbase + (size_t)(ct * nit + itx) * 512);
+    }
+    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ P, int nit_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        nit = nit_;
+        wbase = P + (size_t)(wave * CT) * nit * 512 + lane * 8;
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+            if (d < nit) gload(d, bq[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void run(const __bf16* Xb, f32x4 (&acc)[RT][CT]) {
+        const int lane = threadIdx.x & 63, r16 = lane & 15, kb = lane >> 4;
+        zero_acc(acc);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if (it >= nit) break;
+            bf16x8 a[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                a[rt] = *reinterpret_cast<const bf16x8*>(Xb + (rt * 16 + r16) * XSB + it * KI + 8 * kb);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt], bq[it % PD][ct], acc[rt][ct], 0, 0, 0);
+            if (it + PD < nit) {
+                gload(it + PD, bq[it % PD]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();
+    }
+};
+
+// k-tiled transposed bf16 image of a [rows][256] matrix (the weight-gradient GEMM's operand layout):
+//   tile (cb = col / 16, rb = row / 32) is 1 KiB at (cb * nrb + rb) * 512 elements; inside it element
+//   ((row % 32) / 8 * 16 + col % 16) * 8 + row % 8.
+// The accumulator layout holds 4 consecutive rows of one column per register quad -> 8 contiguous bytes; the four
+// row-quads x sixteen columns of a wave instruction land in one contiguous 512-byte run.
+template <int RT, int NW>
+__device__ __forceinline__ void store_tiles(const bf16x4 (&v)[RT][GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
+    constexpr int CT = GeoB<RT, NW>::CT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int rb = (int)(m0 >> 5) + (rt >> 1);
+        if (rb >= nrb) continue;
+        const int kblk = 2 * (rt & 1) + (kq >> 1);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int cb = wave * CT + ct;
+            *reinterpret_cast<bf16x4*>(dst + ((size_t)(cb * nrb + rb) * 64 + kblk * 16 + r16) * 8 + 4 * (kq & 1)) = v[rt][ct];
+        }
+    }
+}
+
+// obs-preprocess into the bf16 slab (k tail and rows past M zero); states_copy: f32 copy (trajectory buffer row);
+// st_tiles: k-tiled transposed bf16 image of the states (B operand of the first layers' weight gradients), 4 column blocks.
+template <int RT, int NW>
+__device__ __forceinline__ void load_states_b(const float* __restrict__ states, float* __restrict__ states_copy,
+                                              __bf16* __restrict__ st_tiles, int nrb, int D, long long m0, long long M, __bf16* Xb) {
+    typedef GeoB<RT, NW> G;
+    const int kp = round_up(D, KPAD);
+    for (int i = threadIdx.x; i < G::BM * kp; i += G::NT) {
+        const int r = i / kp, c = i % kp;
+        const bool ok = c < D && m0 + r < M;
+        const size_t src = (size_t)min(m0 + r, M - 1) * D + min(c, D - 1);  // clamped, unconditional load
+        const float x = states[src];
+        if (ok && states_copy) states_copy[src] = x;
+        Xb[r * XSB + c] = (__bf16)(ok ? x : 0.f);
+    }
+    if (st_tiles != nullptr) {
+        lds_barrier();
+        for (int u = threadIdx.x; u < 4 * (G::BM / 8) * 16; u += G::NT) {
+            const int cb = u / ((G::BM / 8) * 16), ko = (u / 16) % (G::BM / 8), c16 = u & 15;
+            const int rb = (int)(m0 >> 5) + (ko >> 2);
+            if (rb >= nrb) continue;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = cb * 16 + c16 < kp ? Xb[(8 * ko + j) * XSB + cb * 16 + c16] : (__bf16)0.f;
+            *reinterpret_cast<bf16x8*>(st_tiles + ((size_t)(cb * nrb + rb) * 64 + (ko & 3) * 16 + c16) * 8) = v;
+        }
+    }
+}
+
+// forward hidden-layer epilogue: h = bf16(tanh(acc + bias)) -> slab; KEEP: 1 - h^2 of the ROUNDED value and the tile store
+template <int RT, int NW, bool KEEP>
+__device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, NW>::CT], const float* __restrict__ bias, __bf16* Xb,
+                                                f32x4 (*kept)[GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
+    typedef GeoB<RT, NW> G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
+    bf16x4 hv[RT][G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) {
+        const int col = wave * 16 * G::CT + ct * 16 + r16;
+        const float b = bias[col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const __bf16 hb = (__bf16)fast_tanh(acc[rt][ct][r] + b);
+                Xb[(rt * 16 + 4 * kq + r) * XSB + col] = hb;
+                hv[rt][ct][r] = hb;
+                if constexpr (KEEP) {
+                    const float hf = (float)hb;
+                    kept[rt][ct][r] = 1.f - hf * hf;
+                }
+            }
+    }
+    if constexpr (KEEP) {
+        if (dst != nullptr) store_tiles<RT, NW>(hv, dst, nrb, m0);
+    }
+    lds_barrier();
+}
+
+__device__ __forceinline__ float head_dot_b(const __bf16* xr, const float* wr, float bias, bool has_bias) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < HID; j += 8) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(xr + j);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + j), w1 = *reinterpret_cast<const f32x4*>(wr + j + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = fmaf((float)x[i], w0[i], s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s = fmaf((float)x[4 + i], w1[i], s);
+    }
+    if (has_bias) s += bias;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rollout step (RT = 1, NW = 8)
+// ---------------------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
+    constexpr int RT = 1, NW = 8;
+    typedef GeoB<RT, NW> G;
+    extern __shared__ __align__(16) float smem[];
+    __bf16* Xb = reinterpret_cast<__bf16*>(smem);
+    float* W4s = smem + G::SLAB_FLOATS;
+    float* b4s = W4s + MAX_OUT * W4S;
+    const rlx_mlp_layout& lay = a.lay;
+    const int D = lay.obs_dim, tid = threadIdx.x;
+    const __bf16* tiles = reinterpret_cast<const __bf16*>(a.tiles);
+
+    int b = blockIdx.x, y, job;
+    long long m0, M;
+    const float* states;
+    float* states_copy = nullptr;
+    if (b < 2 * a.tiles_policy) {
+        job = 0; y = b & 1; m0 = (long long)(b >> 1) * G::BM; M = a.M; states = a.states;
+        if (y == 1) states_copy = a.states_copy;
+    } else {
+        b -= 2 * a.tiles_policy;
+        job = b < a.tiles_vj0 ? 1 : 2;
+        if (job == 2) b -= a.tiles_vj0;
+        y = 0; m0 = (long long)b * G::BM; M = a.vj[job - 1].m; states = a.vj[job - 1].states;
+    }
+    const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    RowGemmB<RT, NW, PD> gemm;
+    gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
+    load_states_b<RT, NW>(states, states_copy, nullptr, 0, D, m0, M, Xb);
+    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    lds_barrier();
+    f32x4 acc[RT][G::CT];
+    gemm.run(Xb, acc);
+    gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
+    epilogue_tanh_b<RT, NW, false>(acc, a.params + lay.off_b[y][0], Xb, nullptr, nullptr, 0, m0);
+    gemm.run(Xb, acc);
+    gemm.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
+    epilogue_tanh_b<RT, NW, false>(acc, a.params + lay.off_b[y][1], Xb, nullptr, nullptr, 0, m0);
+    gemm.run(Xb, acc);
+    epilogue_tanh_b<RT, NW, false>(acc, a.params + lay.off_b[y][2], Xb, nullptr, nullptr, 0, m0);
+
+    for (int idx = tid; idx < G::BM * n_out; idx += G::NT) {
+        const int row = idx / n_out, o = idx % n_out;
+        const float s = head_dot_b(Xb + row * XSB, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
+        if (m0 + row >= M) continue;
+        const size_t g = (size_t)(m0 + row) * n_out + o;
+        if (job == 0 && y == 0) {
+            a.value[g] = s;
+        } else if (job == 0) {
+            const float mean = s;
+            const float stdv = expf(a.params[lay.off_logstd + o]);
+            const float act = a.eps ? fadd(fmul(a.eps[g], stdv), mean) : mean;
+            const float d = fsub(act, mean);
+            const float var = fmul(stdv, stdv);
+            const float log_scale = logf(stdv);
+            a.logprob[g] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            a.action[g] = act;
+        } else {
+            value_job_output(a.vj[job - 1], g, (size_t)(m0 + row), o, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused optimizer-step kernel (1), bf16: StepArgs.h / .dz point at the k-tiled transposed bf16 images
+//   h  : [2 nets][2][16 cb][nrb] tiles    dz : [2 nets][3][16 cb][nrb] tiles    st : [4 cb][nrb] tiles (states)
+// ---------------------------------------------------------------------------------------------------------------
+struct TileGeom {
+    int nrb;
+    __host__ __device__ size_t mat() const { return (size_t)16 * nrb * 512; }  // elements per [M][256] image
+};
+
+template <int RT, int NW, int PD, int OP>
+__global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a, __bf16* st_tiles) {
+    typedef GeoB<RT, NW> G;
+    constexpr int BM = G::BM, CT = G::CT;
+    extern __shared__ __align__(16) float smem[];
+    __bf16* Xb = reinterpret_cast<__bf16*>(smem);
+    float* W4s = smem + G::SLAB_FLOATS;
+    float* b4s = W4s + MAX_OUT * W4S;
+    float* sHead = b4s + MAX_OUT;
+    float* sLp = sHead + BM * MAX_OUT;
+    float* sG = sLp + BM * MAX_OUT;
+    float* sD = sG + BM * MAX_OUT;
+    double* sRed = reinterpret_cast<double*>(smem + G::SLAB_FLOATS + G::AUX_FLOATS);
+    double* sNm = sRed + 256;
+
+    const rlx_mlp_layout& lay = a.lay;
+    const rlx_ppo_loss_params& p = a.p;
+    const int y = blockIdx.y, tile = blockIdx.x, D = lay.obs_dim, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    const long long m0 = (long long)tile * BM, M = a.M;
+    const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    const int K = p.raw_per_adv, S = p.sub_per_adv, R = K / S;
+    const int npr = lay.act_dim / K;
+    const long long n_adv = M * npr;
+    const bool has_mask = a.loss_mask != nullptr, has_msum = a.loss_mask_sum != nullptr;
+    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
+    const TileGeom tg{(int)((M + 31) / 32)};
+    const __bf16* tiles = reinterpret_cast<const __bf16*>(a.tiles);
+    __bf16* hy = reinterpret_cast<__bf16*>(a.h) + (size_t)(y * 2) * tg.mat();
+    __bf16* dzy = reinterpret_cast<__bf16*>(a.dz) + (size_t)(y * 3) * tg.mat();
+
+    if (has_mask) {
+        double cnt[1] = {0.0};
+        for (long long e = tid; e < n_adv; e += G::NT) cnt[0] += a.loss_mask[e] != 0 ? 1.0 : 0.0;
+        block_sum<1>(cnt, sRed);
+        if (tid == 0) sNm[0] = cnt[0];
+    }
+
+    // ---- forward -----------------------------------------------------------------------------------------------------
+    RowGemmB<RT, NW, PD> gemm;
+    gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
+    load_states_b<RT, NW>(a.states, nullptr, y == 1 ? st_tiles : nullptr, tg.nrb, D, m0, M, Xb);
+    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    for (int i = tid; i < BM * MAX_OUT; i += G::NT) sHead[i] = 0.f;
+    for (int i = n_out * W4S + tid; i < OP * W4S; i += G::NT) W4s[i] = 0.f;
+    lds_barrier();
+    f32x4 acc[RT][CT];
+    f32x4 kept[3][RT][CT];
+    gemm.run(Xb, acc);
+    gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
+    epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][0], Xb, kept[0], hy, tg.nrb, m0);
+    gemm.run(Xb, acc);
+    gemm.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
+    epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][1], Xb, kept[1], hy + tg.mat(), tg.nrb, m0);
+    gemm.run(Xb, acc);
+    epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][2], Xb, kept[2], nullptr, tg.nrb, m0);
+
+    // ---- head + loss element math (f32, identical to ppo_step.hip) ------------------------------------------------------
+    const double nm = has_mask ? sNm[0] : 0.0;
+    const Denoms den = denominators(p, n_adv, nm, has_mask, has_msum);
+    const float half_delta = (float)(0.5 * (double)p.huber_delta);
+    double lacc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
+
+    for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+        const int row = idx / n_out, o = idx % n_out;
+        const float s = head_dot_b(Xb + row * XSB, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
+        sHead[row * MAX_OUT + o] = s;
+        if (y == 1) {
+            const size_t g = (size_t)min(m0 + row, M - 1) * n_out + o;
+            const float stdv = expf(a.params[lay.off_logstd + o]);
+            const float d = fsub(a.action[g], s);
+            const float var = fmul(stdv, stdv);
+            const float log_scale = logf(stdv);
+            sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            sD[row * MAX_OUT + o] = d;
+        }
+    }
+    lds_barrier();
+    if (y == 1) {
+        for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {
+            const int row = idx / npr, c = idx % npr;
+            if (m0 + row >= M) continue;
+            const long long e = (m0 + row) * npr + c;
+            const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+            float w = 1.f;
+            if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+            const float adv = a.advantages[e];
+            lacc[S_NM] += on ? 1.0 : 0.0;
+            const float* olp = a.old_logprobs + (size_t)(m0 + row) * lay.act_dim + c * K;
+            for (int s = 0; s < S; ++s) {
+                float lp = 0.f, old = 0.f;
+                for (int j = 0; j < R; ++j) {
+                    lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
+                    old = fadd(old, olp[s * R + j]);
+                }
+                const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
+                sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+            }
+        }
+        lds_barrier();
+        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+            const int row = idx / n_out, o = idx % n_out;
+            float dmu = 0.f, dls = 0.f;
+            if (m0 + row < M) {
+                const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
+                const float stdv = expf(a.params[lay.off_logstd + o]);
+                const float var = stdv * stdv, d = sD[row * MAX_OUT + o];
+                dmu = dlp * d / var;
+                dls = dlp * (d * d / var - 1.f);
+            }
+            sHead[row * MAX_OUT + o] = dmu;
+            sLp[row * MAX_OUT + o] = dls;
+        }
+    } else {
+        for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {
+            const int row = idx / n_out, o = idx % n_out;
+            float gv = 0.f;
+            if (m0 + row < M && p.has_critic) {
+                const long long e = (m0 + row) * n_out + o;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                gv = (a.grad_out * (float)(1.0 / den.critic)) *
+                     critic_elem(p, sHead[row * MAX_OUT + o], a.prev_values[e], a.returns[e], on, w, ratio_mode, half_delta, lacc);
+            }
+            sHead[row * MAX_OUT + o] = gv;
+        }
+    }
+    if (wave == 0) {
+        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const double v = wave_sum(lacc[k]);
+            if (lane == 0) lp[k] = v;
+        }
+    }
+    lds_barrier();
+
+    // ---- head parameter gradients per 32-row half tile (f32 accumulation over the bf16 h3 in the slab) -----------------
+    for (int u = tid; u < (BM / 32) * HID; u += G::NT) {
+        const int sub = u / HID, j = u % HID, r0 = sub * 32;
+        float* part = a.head_part + ((size_t)(tile * (BM / 32) + sub) * 2 + y) * a.head_stride;
+        float s[OP];
+#pragma unroll
+        for (int o = 0; o < OP; ++o) s[o] = 0.f;
+#pragma unroll 4
+        for (int row = r0; row < r0 + 32; ++row) {
+            const float hv = (float)Xb[row * XSB + j];
+#pragma unroll
+            for (int q = 0; q < OP / 4; ++q) {
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(sHead + row * MAX_OUT + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[4 * q + i] = fmaf(sh[i], hv, s[4 * q + i]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OP; ++o)
+            if (o < n_out) part[o * HID + j] = s[o];
+        if (j < n_out) {
+            float sb = 0.f, sl = 0.f;
+            for (int row = r0; row < r0 + 32; ++row) {
+                sb += sHead[row * MAX_OUT + j];
+                sl += sLp[row * MAX_OUT + j];
+            }
+            part[n_out * HID + j] = sb;
+            part[n_out * HID + n_out + j] = y == 1 ? sl : 0.f;
+        }
+    }
+
+    // ---- dZ3 = (dOut . W4) * (1 - h3^2) -> bf16 slab + tiles ---------------------------------------------------------------
+    gemm.prefetch(tiles + Tiles::mat(y, 4), HID / 32);  // W3^T
+    bf16x4 dv[RT][CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = wave * 16 * CT + ct * 16 + r16;
+        float w4[OP];
+#pragma unroll
+        for (int o = 0; o < OP; ++o) w4[o] = W4s[o * W4S + col];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + 4 * kq + r;
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < OP / 4; ++q) {
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(sHead + row * MAX_OUT + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s = fmaf(sh[i], w4[4 * q + i], s);
+                }
+                dv[rt][ct][r] = (__bf16)(s * kept[2][rt][ct][r]);
+            }
+    }
+    lds_barrier();  // every read of h3 / sHead is done: the slab may be overwritten
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = dv[rt][ct][r];
+    store_tiles<RT, NW>(dv, dzy + 2 * tg.mat(), tg.nrb, m0);
+    lds_barrier();
+
+    // ---- backward-data chain ---------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {
+        gemm.run(Xb, acc);
+        if (l == 2) gemm.prefetch(tiles + Tiles::mat(y, 3), HID / 32);  // W2^T
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const __bf16 z = (__bf16)(acc[rt][ct][r] * kept[l - 1][rt][ct][r]);
+                    dv[rt][ct][r] = z;
+                    if (l == 2) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = z;
+                }
+        store_tiles<RT, NW>(dv, dzy + (size_t)(l - 1) * tg.mat(), tg.nrb, m0);
+        if (l == 2) lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused optimizer-step kernel (2), bf16: weight gradients from the k-tiled transposed images, barrier-free.
+//   item = (slab, matrix, 128x128 tile); 4 waves as 2x2, each 4x4 tiles of 16x16 (v_mfma_f32_16x16x32_bf16, K = 32 batch rows)
+// ---------------------------------------------------------------------------------------------------------------
+template <int PD>
+__global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, const __bf16* __restrict__ st_tiles) {
+    __shared__ double s_red[NS * 4];
+    const rlx_mlp_layout& lay = a.lay;
+    const long long M = a.M;
+    const int tid = threadIdx.x;
+    const int gemm_blocks = round_up(a.gemm_items, 8);
+    int b = blockIdx.x;
+
+    if (b >= gemm_blocks) {
+        b -= gemm_blocks;
+        if (b < a.slabs * 2) {
+            const int s = b >> 1, y = b & 1, j = tid;
+            const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+            float* slab = a.grads + (size_t)s * lay.n_params;
+            for (int o = 0; o < n_out; ++o) {
+                float acc = 0.f;
+                for (int t = s; t < a.head_parts; t += a.slabs) acc += a.head_part[((size_t)t * 2 + y) * a.head_stride + o * HID + j];
+                slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc;
+            }
+            if (j < n_out) {
+                float sb = 0.f, sl = 0.f;
+                for (int t = s; t < a.head_parts; t += a.slabs) {
+                    const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
+                    sb += part[n_out * HID + j];
+                    sl += part[n_out * HID + n_out + j];
+                }
+                if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
+                if (y == 1) slab[lay.off_logstd + j] = sl;
+            }
+        } else {
+            double acc[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+            for (int i = tid; i < a.tiles * 2; i += 256) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
+            }
+            block_sum<NS>(acc, s_red);
+            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+        }
+        return;
+    }
+    const int item = (b & 7) * (gemm_blocks >> 3) + (b >> 3);
+    if (item >= a.gemm_items) return;
+    const int s = item / 20, w = item % 20;
+    int y, l, i0, j0;
+    if (w < 16) {
+        const int mat = w >> 2, tile = w & 3;
+        y = mat >> 1; l = 1 + (mat & 1); i0 = (tile >> 1) * 128; j0 = (tile & 1) * 128;
+    } else {
+        y = (w - 16) >> 1; l = 0; i0 = ((w - 16) & 1) * 128; j0 = 0;
+    }
+    const int nrb = (int)((M + 31) / 32);
+    const size_t mat_elems = (size_t)16 * nrb * 512;
+    const int Kin = l == 0 ? lay.obs_dim : HID;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.dz) + (size_t)(y * 3 + l) * mat_elems;
+    const __bf16* Bm = l == 0 ? st_tiles : reinterpret_cast<const __bf16*>(a.h) + (size_t)(y * 2 + l - 1) * mat_elems;
+    const int ncb_b = l == 0 ? 4 : 16;  // column blocks of the B image
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;
+    if (j0 + wj * 64 >= Kin) return;  // first layers: only the first 64-column block holds inputs
+    const int rb0 = (int)((long long)s * a.rows_per_slab / 32);
+    const int rb1 = min(nrb, (int)(((long long)(s + 1) * a.rows_per_slab) / 32));
+    const int nkb = max(0, rb1 - rb0);
+
+    // fragment pointers: A tile (cb = (i0 + wi*64)/16 + ti, rb), B tile (cb = (j0 + wj*64)/16 + tj clamped, rb)
+    const __bf16* ap = A + ((size_t)((i0 + wi * 64) / 16) * nrb + rb0) * 512 + lane * 8;
+    int cbj[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) cbj[tj] = min((j0 + wj * 64) / 16 + tj, ncb_b - 1);
+    const __bf16* bp = Bm + (size_t)rb0 * 512 + lane * 8;
+
+    struct Frag { bf16x8 a[4], b[4]; };
+    Frag ring[PD];
+    auto gload = [&](int kb, Frag& f) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f.a[t] = *reinterpret_cast<const bf16x8*>(ap + ((size_t)t * nrb + kb) * 512);
+            f.b[t] = *reinterpret_cast<const bf16x8*>(bp + ((size_t)cbj[t] * nrb + kb) * 512);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < nkb) gload(d, ring[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kb0 = 0; kb0 < nkb; kb0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int kb = kb0 + d;
+            if (kb < nkb) {
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[d].a[ti], ring[d].b[tj], acc[ti][tj], 0, 0, 0);
+                    float t8 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t8 += (float)ring[d].a[ti][e];
+                    bsum[ti] += t8;
+                }
+                if (kb + PD < nkb) gload(kb + PD, ring[d]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    float* slab = a.grads + (size_t)s * lay.n_params;
+    float* dW = slab + lay.off_w[y][l];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = j0 + wj * 64 + tj * 16 + r16;
+            if (col < Kin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wi * 64 + ti * 16 + 4 * kq + r;
+                    dW[(size_t)row * Kin + col] = acc[ti][tj][r];
+                }
+            }
+        }
+    if (j0 == 0 && wj == 0) {  // bias gradient = column sums of dZ: lane (r16, kq) holds 8 of the 32 rows of column ti*16 + r16
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            float tot = bsum[ti];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (kq == 0) slab[lay.off_b[y][l] + i0 + wi * 64 + ti * 16 + r16] = tot;
+        }
+    }
+}
+
+template <typename K>
+int set_lds_b(K kern, size_t bytes) {
+    static thread_local const void* done[16] = {};
+    const void* key = reinterpret_cast<const void*>(kern);
+    for (const void* d : done)
+        if (d == key) return RLX_OK;
+    RLX_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    for (auto& d : done)
+        if (d == nullptr) { d = key; break; }
+    return RLX_OK;
+}
+
+}  // namespace
+
+namespace step {
+
+int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles, hipStream_t st) {
+    hipLaunchKernelGGL(pack_tiles_bf16_kernel, dim3(num_cu() * 4), dim3(256), 0, st, params, lay, static_cast<__bf16*>(tiles));
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
+    const size_t lds = GeoB<1, 8>::LDS_BYTES;
+    if (int rc = set_lds_b(rollout_step_bf16_kernel<4>, lds)) return rc;
+    hipLaunchKernelGGL(rollout_step_bf16_kernel<4>, dim3(blocks), dim3(512), lds, st, a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+// workspace carve (bytes) of the bf16 step: tiled activation images instead of the f32 row-major ones
+size_t bf16_image_bytes(int64_t m) { return (size_t)16 * ((m + 31) / 32) * 512 * sizeof(__bf16); }
+
+int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, hipStream_t st) {
+    const size_t lds = GeoB<4, 8>::LDS_BYTES;
+    __bf16* stt = static_cast<__bf16*>(st_tiles);
+    if (op8) {
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+    } else {
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+    }
+    RLX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+}  // namespace step
+}  // namespace rlx

@@ -1,0 +1,270 @@
+// ppo_step_common.h -- pieces shared by the f32 (ppo_step.hip) and bf16 (ppo_step_bf16.hip) fused launches:
+// geometry, LDS barrier, fast tanh, kernel argument structs, host-side planning.
+#pragma once
+
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "ppo_loss_math.h"
+#include "rlx_common.h"
+
+namespace rlx {
+namespace step {
+
+using namespace loss;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HID = 256;   // hidden width (fixed by the reference: hidden_sizes=(256,256,256))
+constexpr int XS = 264;    // activation slab row stride (floats); stride % 16 == 8 -> conflict-free b128 fragment reads
+constexpr int KPAD = 32;    // the K loop advances 32 at a time: the slab's k tail is zero-padded to a multiple of it
+constexpr int W4S = 260;   // head weight image row stride
+constexpr int MAX_OUT = 16;  // head outputs supported by the fused kernels (act_dim, val_dim)
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+template <int RT, int NW>
+struct Geo {
+    static constexpr int BM = 16 * RT;          // rows per workgroup tile
+    static constexpr int NT = 64 * NW;          // threads
+    static constexpr int CT = HID / (16 * NW);  // 16-column tiles per wave
+    // LDS: slab [BM][XS] | head image [MAX_OUT][W4S] + bias [MAX_OUT] | 4 x [BM][MAX_OUT] loss scratch | 4 KiB reduction scratch
+    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 4 * BM * MAX_OUT;
+    static constexpr size_t LDS_BYTES = (size_t)(BM * XS + AUX_FLOATS) * sizeof(float) + 4096;
+};
+
+// LDS-only workgroup barrier.  __syncthreads() also fences global memory, i.e. waits vmcnt(0): after a flush of the
+// slab to HBM every barrier would stall for the stores' full round trip.  Nothing a workgroup writes to global memory
+// is read back by it, so only the LDS traffic needs ordering.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// tanh to ~2e-7 absolute: odd polynomial below 0.3, 1 - 2 / (exp(2x) + 1) above (v_exp_f32 + v_rcp_f32), select instead
+// of a branch.  libm's tanhf costs ~4x as many VALU slots; 32-64 of them per lane per layer were a third of the kernel.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float x2 = x * x;
+    const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+    const float e = __expf(2.f * x);
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return fabsf(x) < 0.3f ? poly : big;
+}
+
+// Weight image in MFMA fragment order ("tiles"), rebuilt from the flat parameters after every optimizer step:
+// a 16 (n) x 16 (k) tile is 1 KiB contiguous, float4 number l = kq*16 + r16 of it holds W[n0 + r16][k0 + 4*kq .. +3], so a
+// wave's fragment load is ONE fully coalesced 1 KiB read and consecutive tiles of a column block are consecutive in
+// memory.  Per network: W1 (k zero-padded to 64), W2, W3, W2^T, W3^T (the transposes feed the backward-data GEMMs).
+struct Tiles {
+    static constexpr int K1P = 64;  // first-layer K after padding (obs_dim <= 64 here)
+    __host__ __device__ static constexpr size_t per_net() { return (size_t)HID * K1P + 4 * (size_t)HID * HID; }
+    // m: 0 = W1, 1 = W2, 2 = W3, 3 = W2^T, 4 = W3^T
+    __host__ __device__ static constexpr size_t mat(int y, int m) {
+        return y * per_net() + (m == 0 ? 0 : (size_t)HID * K1P + (size_t)(m - 1) * HID * HID);
+    }
+};
+
+// Phase stamps (development only): block 0 / thread 0 writes the shader clock at phase boundaries into a buffer set
+// with rlx_dev_set_timing_buffer(); the product never sets one.
+struct Stamps {
+    long long* buf;
+    int n;
+    __device__ __forceinline__ void mark() {
+        if (buf != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf[n] = (long long)clock64();
+        ++n;
+    }
+};
+// Ablation switches (development only: tools/bench_step.py times them; the product always runs ABL == 0)
+constexpr int ABL_NO_TANH = 1, ABL_NO_FLUSH = 2, ABL_NO_WLOAD = 4, ABL_NO_MFMA = 8;
+
+// stage the head weight [n_out][256] (+ bias) into LDS with a padded row stride
+__device__ __forceinline__ void stage_head(const float* __restrict__ W4, const float* __restrict__ b4, int n_out, float* W4s,
+                                           float* b4s, int nthreads) {
+    for (int f = threadIdx.x; f < n_out * 64; f += nthreads) {
+        const int o = f >> 6, c4 = (f & 63) * 4;
+        *reinterpret_cast<f32x4*>(W4s + o * W4S + c4) = *reinterpret_cast<const f32x4*>(W4 + (size_t)o * HID + c4);
+    }
+    if ((int)threadIdx.x < n_out) b4s[threadIdx.x] = b4 ? b4[threadIdx.x] : 0.f;
+}
+
+struct ValueJob {
+    const float* states;
+    long long m;
+    float* values;         // [m, val_dim] or nullptr
+    float* rewards;        // [m, chunk] in place, or nullptr
+    const uint8_t* flags;  // [m, chunk]
+    int chunk;
+    float gamma;
+    const float* env_rewards;  // optional fused env-row store (see rlx_value_job)
+    const uint8_t* env_term;
+    const uint8_t* env_trunc;
+    uint8_t* done_row;
+    uint8_t* term_row;
+    uint8_t* trunc_row;
+    int flag_is_trunc;
+};
+
+// value-only job epilogue for output o of row `row` (global row index): value store, bootstrap fold, env-row store
+__device__ __forceinline__ void value_job_output(const ValueJob& v, size_t g, size_t row, int o, float s) {
+    if (v.values) v.values[g] = s;
+    if (o != 0 || v.rewards == nullptr) return;
+    if (v.env_rewards != nullptr) {
+        for (int c = 0; c < v.chunk; ++c) {
+            const size_t i = row * v.chunk + c;
+            const uint8_t te = v.env_term[i] != 0, tr = v.env_trunc[i] != 0;
+            v.term_row[i] = te;
+            v.trunc_row[i] = tr;
+            v.done_row[i] = te | tr;  // dones = terminations | truncations (maniskill_env.py:343-350)
+            float r = v.env_rewards[i];
+            const bool flag = v.flag_is_trunc ? tr != 0 : (te | tr) != 0;
+            if (c == v.chunk - 1 && flag) r = fadd(r, fmul(v.gamma, s));  // env_worker.py:744-758
+            v.rewards[i] = r;
+        }
+    } else {  // r[:, -1] += gamma * V(final_obs)[:, 0] where flags[:, -1]
+        const size_t i = row * v.chunk + (v.chunk - 1);
+        if (v.flags[i]) v.rewards[i] = fadd(v.rewards[i], fmul(v.gamma, s));
+    }
+}
+struct RolloutArgs {
+    long long* stamps;
+    const float* params;
+    const float* tiles;
+    rlx_mlp_layout lay;
+    const float* states;   // policy job (may be nullptr with M == 0)
+    const float* eps;
+    long long M;
+    float* action;
+    float* logprob;
+    float* value;
+    float* states_copy;
+    ValueJob vj[2];
+    int tiles_policy, tiles_vj0, tiles_vj1;
+};
+
+struct StepArgs {
+    long long* stamps;
+    const float* params;
+    const float* tiles;         // fragment-tile weight image (struct Tiles), built by pack_tiles_kernel just before
+    rlx_mlp_layout lay;
+    const float* states;        // [M, D]
+    const float* action;        // [M, act_dim]
+    const float* old_logprobs;  // [M, act_dim]
+    const float* advantages;    // [M * adv_per_row]
+    const float* prev_values;   // [M * adv_per_row] (has_critic)
+    const float* returns;
+    const uint8_t* loss_mask;   // [M * adv_per_row] or nullptr
+    const int64_t* loss_mask_sum;
+    long long M;
+    rlx_ppo_loss_params p;
+    float grad_out;             // d(total)/d(loss) of this micro-batch (1 / gradient_accumulation)
+    float* h;                   // [2 nets][2][M][256]  hidden activations 1, 2   (B operands of the weight gradients)
+    float* dz;                  // [2 nets][3][M][256]  pre-activation gradients  (A operands)
+    float* head_part;           // [head_parts][2][head_stride]  per-32-row head gradients: dW4 [n_out][256], db4, dlogstd [n_out]
+    double* loss_part;          // [tiles][2][NS]
+    int head_stride;
+};
+
+struct DwArgs {
+    rlx_mlp_layout lay;
+    const float* states;
+    const float* h;          // [2][2][M][256]
+    const float* dz;         // [2][3][M][256]
+    const float* head_part;  // [tiles][2][head_stride]
+    const double* loss_part; // [tiles][2][NS]
+    long long M;
+    int rows_per_slab;       // multiple of 32
+    int slabs;
+    int tiles;               // 64-row tiles of the fused kernel (loss partial slots per network)
+    int head_parts;          // 32-row head-gradient partial slots per network
+    int head_stride;
+    int gemm_items;          // slabs * 20, the grid holds round_up(gemm_items, 8) GEMM blocks
+    float* grads;            // [slabs][n_params]
+    rlx_ppo_loss_params p;
+    int has_mask, has_msum;
+    float* out;              // metric row (RLX_PPO_OUT_FLOATS)
+};
+
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+inline int check_layout(const rlx_mlp_layout* lay, const char* who) {
+    RLX_REQUIRE(lay != nullptr, "%s: NULL layout", who);
+    RLX_REQUIRE(lay->hidden == HID, "%s: hidden=%d is not supported (the reference's MLP policy is 256 wide)", who, lay->hidden);
+    RLX_REQUIRE(lay->obs_dim >= 1 && lay->obs_dim <= Tiles::K1P, "%s: obs_dim=%d out of range [1,%d]", who, lay->obs_dim, Tiles::K1P);
+    RLX_REQUIRE(lay->act_dim >= 1 && lay->act_dim <= MAX_OUT && lay->val_dim >= 1 && lay->val_dim <= MAX_OUT,
+                "%s: act_dim=%d / val_dim=%d out of range [1,%d]", who, lay->act_dim, lay->val_dim, MAX_OUT);
+    for (int y = 0; y < 2; ++y)
+        for (int l = 0; l < 4; ++l) {
+            RLX_REQUIRE(lay->off_w[y][l] >= 0 && lay->off_w[y][l] < lay->n_params, "%s: weight offset out of range", who);
+            RLX_REQUIRE(lay->off_w[y][l] % 4 == 0 || l == 0, "%s: weight offsets of layers 2-4 must be 16-byte aligned", who);
+            RLX_REQUIRE(l == 3 || lay->off_b[y][l] >= 0, "%s: hidden layers need a bias", who);
+        }
+    return RLX_OK;
+}
+
+// once per kernel and process (not a stream operation: keep it out of hipGraph capture regions)
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    static thread_local const void* done[32] = {};
+    const void* key = reinterpret_cast<const void*>(kern);
+    for (const void* d : done)
+        if (d == key) return RLX_OK;
+    RLX_HIP_CHECK(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    for (auto& d : done)
+        if (d == nullptr) { d = key; break; }
+    return RLX_OK;
+}
+
+// development switch: integer environment variable, read once
+inline int dev_variant(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+inline int head_stride_of(const rlx_mlp_layout* lay) {
+    const int n = std::max(lay->act_dim, lay->val_dim);
+    return round_up(n * HID + 2 * n, 4);
+}
+
+struct StepPlan {
+    int tiles;        // 64-row tiles of the fused kernel (= loss partial slots per network)
+    int head_parts;   // 32-row head-gradient partial slots per network
+    int slabs, rows_per_slab, head_stride;
+    size_t off_h, off_dz, off_head, off_loss, off_tiles, off_st, bytes;
+};
+constexpr int STEP_BM = 64;
+inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = false) {
+    StepPlan pl{};
+    pl.tiles = ceil_div(m, STEP_BM);
+    pl.head_parts = pl.tiles * (STEP_BM / 32);
+    // 20 GEMM items per slab; fill 2 workgroups per CU once (no second, half-empty round)
+    int slabs = std::max(1, std::min(2 * num_cu() / 20, ceil_div(m, 32)));
+    pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
+    pl.slabs = ceil_div(m, pl.rows_per_slab);
+    pl.head_stride = head_stride_of(lay);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    if (bf16) {  // k-tiled transposed bf16 images: 16 column blocks x ceil(m / 32) row blocks x 1 KiB per [m][256] matrix
+        const size_t img = (size_t)16 * ceil_div(m, 32) * 1024;
+        pl.off_h = take(4 * img);
+        pl.off_dz = take(6 * img);
+        pl.off_st = take(img / 4);  // states: 4 column blocks
+        pl.off_tiles = take(2 * Tiles::per_net() * 2);
+    } else {
+        pl.off_h = take((size_t)4 * m * HID * sizeof(float));
+        pl.off_dz = take((size_t)6 * m * HID * sizeof(float));
+        pl.off_st = off;
+        pl.off_tiles = take(2 * Tiles::per_net() * sizeof(float));
+    }
+    pl.off_head = take((size_t)pl.head_parts * 2 * pl.head_stride * sizeof(float));
+    pl.off_loss = take((size_t)pl.tiles * 2 * NS * sizeof(double));
+    pl.bytes = off;
+    return pl;
+}
+
+// bf16 launches (ppo_step_bf16.hip)
+int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles, hipStream_t st);
+int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st);
+int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, hipStream_t st);
+
+}  // namespace step
+}  // namespace rlx

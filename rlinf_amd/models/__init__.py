@@ -49,7 +49,8 @@ def _build_mlp_policy(cfg, torch_dtype):
     return MLPPolicy(
         obs_dim=int(_cfg_get(cfg, "obs_dim")), action_dim=int(_cfg_get(cfg, "action_dim")),
         num_action_chunks=int(_cfg_get(cfg, "num_action_chunks", 1)),
-        add_value_head=bool(_cfg_get(cfg, "add_value_head", True)), add_q_head=bool(_cfg_get(cfg, "add_q_head", False)))
+        add_value_head=bool(_cfg_get(cfg, "add_value_head", True)), add_q_head=bool(_cfg_get(cfg, "add_q_head", False)),
+        compute_dtype=torch.bfloat16 if torch_dtype == torch.bfloat16 else torch.float32)
 
 
 register_model("mlp_policy", _build_mlp_policy, force=True)

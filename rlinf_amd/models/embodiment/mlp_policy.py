@@ -62,8 +62,14 @@ class _MlpTrainFn(torch.autograd.Function):
 
 class MLPPolicy(nn.Module):
     def __init__(self, obs_dim, action_dim, num_action_chunks, add_value_head, add_q_head, q_head_type="default",
-                 value_granularity="action_level", critic_obs_dim=None):
+                 value_granularity="action_level", critic_obs_dim=None, compute_dtype=torch.float32):
         super().__init__()
+        # operand precision of the 256-wide dense layers on the fused launches: float32 (exact-f32 MFMA) or bfloat16
+        # (bf16 MFMA operands, f32 accumulate; master weights and everything else stay float32) -- the reference's
+        # ``precision`` / amp_autocast switch
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"compute_dtype must be float32 or bfloat16, got {compute_dtype}")
+        self.compute_dtype = compute_dtype
         if add_q_head or not add_value_head:
             raise NotImplementedError("only the PPO configuration (value head, no Q head) is on the hot path")
         self.obs_dim, self.action_dim, self.num_action_chunks = int(obs_dim), int(action_dim), int(num_action_chunks)
@@ -177,7 +183,8 @@ class MLPPolicy(nn.Module):
         ver = self.flat._version
         t = getattr(self, "_tiles", None)
         if t is None or t.device != self.flat.device or getattr(self, "_tiles_version", -1) != ver:
-            self._tiles = ops.mlp_pack_tiles(self.flat.data, self.layout, t if (t is not None and t.device == self.flat.device) else None)
+            self._tiles = ops.mlp_pack_tiles(self.flat.data, self.layout, t if (t is not None and t.device == self.flat.device) else None,
+                                             bf16=self.compute_dtype == torch.bfloat16)
             self._tiles_version = ver
         return self._tiles
 
@@ -224,7 +231,7 @@ class MLPPolicy(nn.Module):
             eps = None
         else:
             raise NotImplementedError(f"{mode=}")
-        action, logprob, value = ops.mlp_rollout(self.flat.data, self.packed(), self.layout, states, eps)
+        action, logprob, value = ops.mlp_rollout_step(self.flat.data, self.tiles(), self.layout, states, eps)
         if not calculate_values:
             value = torch.zeros_like(logprob[..., :1])
         chunk_actions = action.reshape(-1, self.num_action_chunks, self.action_dim)

@@ -422,6 +422,7 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
         p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
     if tile_layout is not None and tiles is not None:  # keep the fragment-tile weight image in step with the parameters
         p.tile_layout, p.tiles = ctypes_pointer(tile_layout), tiles.data_ptr()
+        p.tiles_bf16 = int(tiles.dtype == torch.bfloat16)
     if stats is None:
         stats = torch.empty((2,), dtype=torch.float32, device=dev)
     ws_bytes = lib.rlx_adamw_workspace_bytes(n)
@@ -589,15 +590,17 @@ def mlp_train_bwd(params, packed, layout: MlpLayout, states, action, mean, acts,
 # --------------------------------------------------------------------------------------------
 # fused hot launches (ppo_step.hip)
 # --------------------------------------------------------------------------------------------
-def mlp_pack_tiles(params: torch.Tensor, layout: MlpLayout, tiles: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Fragment-tile weight image the fused launches stream (rebuild after every change of ``params``)."""
+def mlp_pack_tiles(params: torch.Tensor, layout: MlpLayout, tiles: Optional[torch.Tensor] = None, bf16: bool = False) -> torch.Tensor:
+    """Fragment-tile weight image the fused launches stream (rebuild after every change of ``params``); f32 or bf16."""
     lib = _lib.load()
     dev = _dev(params)
-    nbytes = lib.rlx_mlp_tiles_bytes(byref(layout))
-    if tiles is None:
-        tiles = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+    n = lib.rlx_mlp_tiles_bytes(byref(layout)) // 4
+    dt = torch.bfloat16 if bf16 else torch.float32
+    if tiles is None or tiles.dtype != dt:
+        tiles = torch.empty((n,), dtype=dt, device=dev)
+    fn = lib.rlx_mlp_pack_tiles_bf16 if bf16 else lib.rlx_mlp_pack_tiles
     with torch.cuda.device(dev):
-        _lib.check(lib.rlx_mlp_pack_tiles(params.data_ptr(), byref(layout), tiles.data_ptr(), _stream_ptr(dev)), "rlx_mlp_pack_tiles")
+        _lib.check(fn(params.data_ptr(), byref(layout), tiles.data_ptr(), _stream_ptr(dev)), "rlx_mlp_pack_tiles")
     return tiles
 
 
@@ -606,11 +609,14 @@ def mlp_rollout_step(params: torch.Tensor, tiles: torch.Tensor, layout: MlpLayou
                      value_jobs: tuple = ()):
     """ONE launch: policy job on ``states`` (-> action, logprob, value rows in ``out``) plus up to two value-only jobs
     ``dict(states=[m,D], values=[m,val]|None, rewards=[m,C]|None, flags=[m,C] bool, gamma=float)``: values <- V(states),
-    rewards[:, -1] += gamma * V(states)[:, 0] where flags[:, -1]."""
+    rewards[:, -1] += gamma * V(states)[:, 0] where flags[:, -1].  With ``env=(rewards, terminations, truncations)`` and
+    ``rows=(done_row, termination_row, truncation_row)`` the job also stores the env step's outputs into the buffer rows
+    (``rewards`` is then the destination row; the flag is done, or truncation with ``flag_is_truncation``)."""
     lib = _lib.load()
     dev = _dev(params, states, eps, *[j["states"] for j in value_jobs])
     st = RolloutStep()
     st.params, st.tiles, st.layout = params.data_ptr(), tiles.data_ptr(), ctypes_pointer(layout)
+    st.bf16 = int(tiles.dtype == torch.bfloat16)  # the tile image's element type selects the MFMA operand precision
     action = logprob = value = None
     if states is not None:
         s_ = _as_f32(states, "states")
@@ -644,17 +650,31 @@ def mlp_rollout_step(params: torch.Tensor, tiles: torch.Tensor, layout: MlpLayou
         if vals is not None and (vals.dtype != torch.float32 or not vals.is_contiguous() or vals.numel() != m * layout.val_dim):
             raise RlxError("value job: values must be contiguous float32 [m, val_dim]")
         chunk = 1
+        env = j.get("env")
         if rew is not None:
             if rew.dim() != 2 or rew.dtype != torch.float32 or not rew.is_contiguous() or rew.shape[0] != m:
                 raise RlxError("value job: rewards must be a contiguous float32 [m, C] tensor")
-            flags = _as_u8(flags)
-            if flags is None or tuple(flags.shape) != tuple(rew.shape):
-                raise RlxError("value job: flags must be a bool tensor shaped like rewards")
             chunk = rew.shape[1]
+            if env is None:
+                flags = _as_u8(flags)
+                if flags is None or tuple(flags.shape) != tuple(rew.shape):
+                    raise RlxError("value job: flags must be a bool tensor shaped like rewards")
         keep += [js, flags]
         vj = st.value_jobs[k]
         vj.states, vj.m, vj.values, vj.rewards, vj.flags = js.data_ptr(), m, _ptr(vals), _ptr(rew), _ptr(flags)
         vj.chunk, vj.gamma = chunk, float(j.get("gamma", 1.0))
+        if env is not None:
+            if rew is None:
+                raise RlxError("value job: env rows need the destination reward row")
+            er, ete, etr = _as_f32(env[0], "env rewards"), _as_u8(env[1]), _as_u8(env[2])
+            rows = [t if t.dtype == torch.uint8 else t.view(torch.uint8) for t in j["rows"]]
+            for t in (er, ete, etr, *rows):
+                if t.numel() != rew.numel() or not t.is_contiguous():
+                    raise RlxError("value job: env tensors and rows must be contiguous with the reward row's number of elements")
+            keep += [er, ete, etr, *rows]
+            vj.env_rewards, vj.env_terminations, vj.env_truncations = er.data_ptr(), ete.data_ptr(), etr.data_ptr()
+            vj.done_row, vj.termination_row, vj.truncation_row = (t.data_ptr() for t in rows)
+            vj.flag_is_truncation = int(bool(j.get("flag_is_truncation", False)))
     st.n_value_jobs = len(value_jobs)
     with torch.cuda.device(dev):
         _lib.check(lib.rlx_mlp_rollout_step(byref(st), _stream_ptr(dev)), "rlx_mlp_rollout_step")
@@ -675,7 +695,8 @@ def ppo_step_workspace_bytes(layout: MlpLayout, m: int) -> int:
 
 
 def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatch: dict, grads: torch.Tensor,
-             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0, tiles: Optional[torch.Tensor] = None):
+             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0, tiles: Optional[torch.Tensor] = None,
+             bf16: bool = False):
     """forward + loss + backward of one micro-batch (two launches).  ``mbatch``: states, action, prev_logprobs,
     advantages [, prev_values, returns, loss_mask, loss_mask_sum] as flattened minibatch views; ``grads`` [slabs, n]."""
     lib = _lib.load()
@@ -695,5 +716,8 @@ def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatc
     a.grads, a.slabs, a.out = grads.data_ptr(), grads.shape[0], out_row.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
     a.tiles = _ptr(tiles)
+    a.bf16 = int(bool(bf16))
+    if tiles is not None and (tiles.dtype == torch.bfloat16) != bool(bf16):
+        raise RlxError("ppo_step: the tile image's dtype does not match the requested precision")
     with torch.cuda.device(dev):
         _lib.check(lib.rlx_ppo_step(byref(a), _stream_ptr(dev)), "rlx_ppo_step")

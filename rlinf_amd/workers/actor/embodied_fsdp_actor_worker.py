@@ -194,8 +194,9 @@ class EmbodiedFSDPActor(Worker):
         lay = m.layout
         mb = mbatch["states"].shape[0]
         if self.fused_step:
+            bf16 = m.compute_dtype == torch.bfloat16
             ops.ppo_step(m.flat.data, lay, lp, mbatch, grads, out_row, ws["step_ws"], grad_out=self._grad_out_host,
-                         tiles=m.tiles() if self.optimizer_writes_tiles else None)
+                         tiles=m.tiles() if self.optimizer_writes_tiles else None, bf16=bf16)
             return
         ops.mlp_train_fwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], acts=ws["acts"],
                           out=(ws["logprob"], ws["entropy"], ws["value"], ws["mean"]))

@@ -88,8 +88,9 @@ class EnvWorker(Worker):
         return None
 
     def _interact_eager(self, eps: torch.Tensor, mode: str = "train"):
-        """Two launches per chunk step: the fused policy launch (which also folds the previous step's bootstrap value
-        into its reward row) and one store of the env outputs into the buffer rows."""
+        """ONE launch per chunk step with auto_reset: the fused policy launch also carries the value job that stores the
+        previous step's env outputs and folds its bootstrap value into the reward row.  Without auto_reset (no bootstrap)
+        a second, tiny launch stores the env outputs."""
         buf, env, ro = self.buffer, self.env, self.rollout
         buf.reset()
         with self.timer("env/interact"):
@@ -100,10 +101,12 @@ class EnvWorker(Worker):
                                            states_copy=buf.states[t])
                 obs, rewards, term, trunc, infos = env.chunk_step(chunk_actions)
                 r_row, d_row, te_row, tr_row = buf.env_rows(t)
-                ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
-                if self.auto_reset:  # value of the true terminal observation enters through the reward (A.2)
-                    flags = d_row if self.bootstrap_type == "always" else tr_row
-                    ro.queue_bootstrap(infos["final_obs"], r_row, flags, self.gamma)
+                if self.auto_reset:  # value of the true terminal observation enters through the reward (A.2); the job that
+                    # computes it (riding in the next policy launch) also stores this step's env outputs into the rows
+                    ro.queue_bootstrap(infos["final_obs"], r_row, None, self.gamma, env=(rewards, term, trunc),
+                                       rows=(d_row, te_row, tr_row), flag_is_truncation=self.bootstrap_type != "always")
+                else:
+                    ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
             ro.get_bootstrap_values(obs, out=buf.prev_values[self.n_train_chunk_steps])  # last row: values only
         return None
 

@@ -53,13 +53,19 @@ class MultiStepRolloutWorker(Worker):
                                             states_copy=states_copy, value_jobs=jobs)
         return action.view(-1, m.num_action_chunks, m.action_dim)
 
-    def queue_bootstrap(self, final_obs: dict, rewards: torch.Tensor, flags: torch.Tensor, gamma: float):
+    def queue_bootstrap(self, final_obs: dict, rewards: torch.Tensor, flags, gamma: float, env=None, rows=None,
+                        flag_is_truncation: bool = False):
         """get_bootstrap_values + compute_bootstrap_rewards (huggingface_worker.py:612-627, env_worker.py:718-758)
         deferred into the next launch: rewards[:, -1] += gamma * V(final_obs)[:, 0] where flags[:, -1].  The weights do
-        not change inside a rollout epoch, so running it one launch later changes nothing but the launch count."""
+        not change inside a rollout epoch, so running it one launch later changes nothing but the launch count.
+        ``env`` = (rewards, terminations, truncations) of the env step and ``rows`` = (done, termination, truncation)
+        buffer rows: the same job then also stores the step's env outputs (``rewards`` is the destination row)."""
         if len(self._pending) == 2:
             self.flush_bootstrap()
-        self._pending.append(dict(states=final_obs["states"], rewards=rewards, flags=flags, gamma=gamma))
+        job = dict(states=final_obs["states"], rewards=rewards, flags=flags, gamma=gamma)
+        if env is not None:
+            job.update(env=env, rows=rows, flag_is_truncation=flag_is_truncation)
+        self._pending.append(job)
 
     def flush_bootstrap(self):
         if self._pending:

@@ -51,12 +51,21 @@ def test_rollout_step_policy_and_value_jobs(M):
     torch.testing.assert_close(r_dev.cpu(), want_r, **FWD)
     assert torch.equal(r_dev.cpu()[~flags], rewards[~flags])  # untouched where the env did not finish
     torch.testing.assert_close(last_v.cpu(), want_last, **FWD)
+    # the same bootstrap job with the env-row store fused in (what EnvWorker queues): rows written, reward = env + fold
+    r2 = torch.full((M, 1), float("nan"), device="cuda")
+    rows = [torch.zeros(M, 1, dtype=torch.bool, device="cuda") for _ in range(3)]
+    term = torch.zeros(M, 1, dtype=torch.bool)
+    ops.mlp_rollout_step(pol.flat.data, pol.tiles(), pol.layout, None, None,
+                         value_jobs=(dict(states=fin.cuda(), rewards=r2, flags=None, gamma=0.8,
+                                          env=(rewards.cuda(), term.cuda(), flags.cuda()), rows=tuple(rows)),))
+    assert torch.equal(r2, r_dev)
+    assert torch.equal(rows[0].cpu(), flags) and torch.equal(rows[1].cpu(), term) and torch.equal(rows[2].cpu(), flags)
     # eval mode: action == mean, value-only launch without a policy job
     a2, _, _ = ops.mlp_rollout_step(pol.flat.data, pol.tiles(), pol.layout, states.cuda(), None)
     torch.testing.assert_close(a2.cpu(), ora.act(states, eps=None, mode="eval")[0], **FWD)
     only_v = torch.empty(M, 1, device="cuda")
     ops.mlp_rollout_step(pol.flat.data, pol.tiles(), pol.layout, None, None, value_jobs=(dict(states=last.cuda(), values=only_v),))
-    assert torch.equal(only_v, last_v)
+    assert torch.equal(only_v, last_v)  # same tile, same arithmetic, whatever else rides in the grid
 
 
 def _minibatch(M, g, with_mask):
@@ -143,10 +152,11 @@ def test_ppo_step_matches_unfused_chain():
     torch.testing.assert_close(row[:16], out_ref[:16], rtol=2e-4, atol=2e-5)
 
 
-def test_optimizer_keeps_tile_image_in_step():
-    """rlx_clip_adamw_step with tile_layout/tiles must leave exactly the image rlx_mlp_pack_tiles would build."""
+@pytest.mark.parametrize("bf16", [False, True])
+def test_optimizer_keeps_tile_image_in_step(bf16):
+    """rlx_clip_adamw_step with tile_layout/tiles must leave exactly the image rlx_mlp_pack_tiles[_bf16] would build."""
     from rlinf_amd import ops
-    _, pol = _policies(seed=5)
+    _, pol = _bf16_policy(seed=5) if bf16 else _policies(seed=5)
     lay = pol.layout
     n = lay.n_params
     tiles = pol.tiles().clone()
@@ -155,10 +165,115 @@ def test_optimizer_keeps_tile_image_in_step():
     before = pol.flat.data.clone()
     ops.clip_adamw_step_(pol.flat.data, g, m, v, pol.group_ranges(3e-3, 1e-3), 1, max_grad_norm=0.5, tile_layout=lay, tiles=tiles)
     assert not torch.equal(before, pol.flat.data)
-    fresh = ops.mlp_pack_tiles(pol.flat.data, lay)
-    assert torch.equal(tiles, fresh)
+    fresh = ops.mlp_pack_tiles(pol.flat.data, lay, bf16=bf16)
+    assert tiles.dtype == fresh.dtype and torch.equal(tiles, fresh)
     # a skipped step (non-finite norm) leaves parameters and tiles alone
     g[0, 7] = float("inf")
     snap = pol.flat.data.clone()
     ops.clip_adamw_step_(pol.flat.data, g, m, v, pol.group_ranges(3e-3, 1e-3), 2, max_grad_norm=0.5, tile_layout=lay, tiles=tiles)
     assert torch.equal(snap, pol.flat.data) and torch.equal(tiles, fresh)
+
+
+# ---- bf16 MFMA operands ("PPO bf16", BASELINE.json configs[1]): parity against the oracle under bf16 autocast --------------
+BF16 = dict(rtol=2e-2, atol=2e-2)  # "bf16 policy forward compared against the oracle run in bf16 with rtol 2e-2"
+
+
+def _bf16_policy(seed=7):
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(seed)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    with torch.no_grad():
+        for p in ora.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    pol = MLPPolicy(42, 8, 1, True, False, compute_dtype=torch.bfloat16)
+    pol.load_reference_state_dict(ora.state_dict())
+    return ora, pol.to("cuda")
+
+
+@pytest.mark.parametrize("M", [1024, 37])
+def test_rollout_step_bf16_vs_autocast_oracle(M):
+    from rlinf_amd import ops
+    ora, pol = _bf16_policy()
+    assert pol.tiles().dtype == torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    states, eps = torch.randn(M, 42, generator=g), torch.randn(M, 8, generator=g)
+    fin = torch.randn(M, 42, generator=g)
+    rewards, flags = torch.rand(M, 1, generator=g), torch.rand(M, 1, generator=g) < 0.3
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        want_a, want_lp, want_v = ora.act(states, eps=eps, mode="train")
+        want_boot = ora.value_head.mlp(fin).detach().float()[:, :1]
+    f32_a, f32_lp, f32_v = ora.act(states, eps=eps, mode="train")
+    want_r = O.bootstrap_rewards(rewards.clone(), flags, want_boot, 0.8)
+    r_dev = rewards.cuda()
+    a, lp, v = ops.mlp_rollout_step(pol.flat.data, pol.tiles(), pol.layout, states.cuda(), eps.cuda(),
+                                    value_jobs=(dict(states=fin.cuda(), rewards=r_dev, flags=flags.cuda(), gamma=0.8),))
+    torch.testing.assert_close(a.cpu(), want_a.float(), **BF16)
+    torch.testing.assert_close(v.cpu(), want_v.float(), **BF16)
+    torch.testing.assert_close(r_dev.cpu(), want_r, **BF16)
+    # the f32 heads / log-prob epilogue keep us at least as close to the f32 reference as its own autocast run is
+    assert float((a.cpu() - f32_a).abs().max()) <= 1.5 * float((want_a.float() - f32_a).abs().max()) + 1e-3
+    # log-prob of the sampled action: (a - mean) / std is eps itself, whatever the mean's rounding
+    torch.testing.assert_close(lp.cpu(), f32_lp, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,with_mask", [(8192, False), (700, True), (704, False), (5, False)])
+def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask):
+    """bf16 operands perturb the log-probs by ~1e-2, which moves samples across PPO's clip boundary: the actor gradient of
+    ANY bf16 implementation differs from the f32 one by a few percent (norm-wise), discontinuously.  The yardstick is
+    therefore the reference arithmetic itself under bf16 autocast: we must be no further from the f32 gradient than
+    twice its distance; the critic (smooth Huber loss) is held to a tight bound, tensor by tensor."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
+    ora, pol = _bf16_policy(seed=11)
+    g = torch.Generator().manual_seed(5)
+    mb = _minibatch(M, g, with_mask)
+    with torch.no_grad():
+        cur = ora.evaluate(mb["states"], mb["action"])["logprobs"]
+    mb["prev_logprobs"] = cur + torch.randn(M, 8, generator=g) * 0.08
+
+    def oracle_grads(autocast):
+        ora.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            out = ora.evaluate(mb["states"], mb["action"])
+        out = {k: v.float() for k, v in out.items()}
+        shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8,
+                                     loss_mask=mb.get("loss_mask"), values=out["values"], prev_values=mb["prev_values"],
+                                     returns=mb["returns"])
+        loss, metrics = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+        loss.backward()
+        return {n: p.grad.clone() for n, p in ora.named_parameters()}, float(loss), {k: float(v) for k, v in metrics.items()}
+
+    g32, loss32, metrics32 = oracle_grads(False)
+    g16, _, _ = oracle_grads(True)
+    lay = pol.layout
+    lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
+                             value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
+    grads = torch.full((ops.ppo_step_slabs(lay, M), lay.n_params), float("nan"), device="cuda")  # every element must be written
+    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+    row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+    dev_mb = {k: v.cuda().contiguous() for k, v in mb.items()}
+    if with_mask:
+        dev_mb["loss_mask"] = dev_mb["loss_mask"].view(torch.uint8)
+    ops.ppo_step(pol.flat.data, lay, lp, dev_mb, grads, row, ws, grad_out=1.0, bf16=True)
+    got = grads.sum(dim=0).cpu()
+    assert torch.isfinite(got).all()
+    cat = lambda d: torch.cat([d[n].reshape(-1) for n in d])  # noqa: E731
+    w32, w16 = cat(g32), cat(g16)
+    rel_ours = float((got - w32).norm() / w32.norm())
+    rel_auto = float((w16 - w32).norm() / w32.norm())
+    cos = float(torch.dot(got, w32) / (got.norm() * w32.norm()))
+    assert rel_ours <= max(2.0 * rel_auto, 0.05) and cos > 0.99, (rel_ours, rel_auto, cos)
+    for name, w in g32.items():
+        o = pol.offsets[name]
+        gt = got[o:o + w.numel()]
+        err = float((gt - w.reshape(-1)).norm() / (w.norm() + 1e-12))
+        ref = float((g16[name] - w).norm() / (w.norm() + 1e-12))
+        if w.numel() < 64:  # actor_logstd / actor_mean.bias: a handful of +/- sums, bounded against the whole gradient
+            assert float((gt - w.reshape(-1)).norm()) <= 0.05 * float(w32.norm()), name
+            continue
+        bound = 0.05 if name.startswith("value_head") else max(2.5 * ref, 0.08)  # catches a mis-indexed gradient tile
+        assert err <= bound, (name, err, ref)
+    host = row.cpu()
+    assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(loss32, rel=2e-2, abs=2e-3)
+    for key in ("actor/ratio", "actor/clipped_ratio", "critic/value_loss"):
+        assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(metrics32[key], rel=2e-2, abs=2e-3), key
