@@ -74,9 +74,65 @@ def build_runner(cfg, ctx):
     return runner
 
 
-def gae_roofline(device, iters: int = 30):
-    """gae_scan (un-normalised, streaming variant picked by the auto heuristic) on 65536 x 128, rotating over buffer
-    sets larger than the 256 MB Infinity Cache so every launch streams from HBM."""
+def _pmc_pass(counter: str, workdir: str):
+    """One rocprofv3 counter pass (own run, --kernel-trace only: the gpurun rules) over tools/gae_traffic_probe.py ->
+    {kernel-name-prefix: mean counter value per launch} or None when rocprofv3 is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    out = os.path.join(workdir, counter)
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "-f", "csv", "--", sys.executable,
+                        os.path.join(ROOT, "tools", "gae_traffic_probe.py")], env=env, cwd=workdir, check=True, timeout=240,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return None
+    acc = {}
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"]
+            key = "copy" if "dev_stream_copy" in name else ("gae" if "gae_scan" in name else None)
+            if key:
+                tot, n = acc.get(key, (0.0, 0))
+                acc[key] = (tot + float(row["Counter_Value"]), n + 1)
+    return {k: t / n for k, (t, n) in acc.items()} if acc else None
+
+
+def gae_traffic(algo_read: int, algo_write: int):
+    """HBM bytes per gae_scan launch from the TCC_EA-derived counters, one --pmc pass per counter, calibrated as the
+    microarch guide prescribes: FETCH_SIZE / WRITE_SIZE are in KiB-class units whose scale depends on the access width on
+    gfx950, so each is scaled by (known bytes / counter) of a copy kernel with gae_scan's own access pattern (one dword
+    per lane, time-major rows)."""
+    import tempfile
+    cal = 4 * HORIZON * 65536  # the calibration copy reads and writes exactly this many bytes per launch
+    with tempfile.TemporaryDirectory(prefix="rlx_pmc_", dir=os.environ.get("TMPDIR", "/tmp")) as wd:
+        fetch = _pmc_pass("FETCH_SIZE", wd)
+        write = _pmc_pass("WRITE_SIZE", wd)
+    if not fetch or not write or "copy" not in fetch or "gae" not in fetch or "copy" not in write or "gae" not in write:
+        return None, None
+    rd = fetch["gae"] * (cal / fetch["copy"])
+    wr = write["gae"] * (cal / write["copy"])
+    detail = {"read_bytes": round(rd), "write_bytes": round(wr), "raw_FETCH_SIZE": round(fetch["gae"], 1),
+              "raw_WRITE_SIZE": round(write["gae"], 1), "calibration": "dword-per-lane copy of 33.5 MB: "
+              f"FETCH_SIZE {fetch['copy']:.1f}, WRITE_SIZE {write['copy']:.1f} per launch",
+              "algorithmic_read_bytes": algo_read, "algorithmic_write_bytes": algo_write}
+    return round(rd + wr), detail
+
+
+def gae_roofline(device, iters: int = 30, with_traffic: bool = True):
+    """gae_scan (un-normalised, the variant the auto heuristic picks) on 65536 x 128, rotating over buffer sets larger than
+    the 256 MiB Infinity Cache so every launch streams from HBM.  `achieved` = algorithmic bytes / average launch duration,
+    the average taken with HIP events around `iters` back-to-back launches on the launch stream (per-launch event pairs
+    add ~2 us of event overhead to a 28 us kernel; the per-launch numbers are reported next to it)."""
     from rlinf_amd import ops
     T, B, nbuf = HORIZON, 65536, 5
     g = torch.Generator().manual_seed(0)
@@ -86,21 +142,31 @@ def gae_roofline(device, iters: int = 30):
         v = torch.randn(T + 1, B, 1, generator=g).to(device)
         d = (torch.rand(T + 1, B, 1, generator=g) < 0.02).to(device)
         bufs.append((r, v, d, torch.empty_like(r), torch.empty_like(r)))
-    for i in range(3):
+
+    def launch(i):
         r, v, d, a, q = bufs[i % nbuf]
         ops.gae_scan(r, v, d, None, 0.99, 0.95, normalize_advantages=False, out=(a, q))
+
+    for i in range(5):
+        launch(i)
     torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()  # torch's current stream == the stream the C ABI launches on
+    for i in range(iters):
+        launch(i)
+    e1.record()
+    torch.cuda.synchronize(device)
+    avg_us = e0.elapsed_time(e1) * 1e3 / iters
     evs = []
     for i in range(iters):
-        r, v, d, a, q = bufs[i % nbuf]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()  # torch's current stream == the stream the C ABI launches on
-        ops.gae_scan(r, v, d, None, 0.99, 0.95, normalize_advantages=False, out=(a, q))
-        e1.record()
-        evs.append((e0, e1))
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        launch(i)
+        a1.record()
+        evs.append((a0, a1))
     torch.cuda.synchronize(device)
-    us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-    avg_us = sum(us) / len(us)
+    single = sorted(x.elapsed_time(y) * 1e3 for x, y in evs)
+    algo_read, algo_write = 9 * T * B + 5 * B, 8 * T * B  # r 4 + V 4 + done 1 (+ the extra V / done row); adv 4 + ret 4
     algo_bytes = 17 * T * B
     achieved = algo_bytes / avg_us / 1e3  # GB/s
     # contract shape, for reference (launch/latency bound: 2.2 MB)
@@ -108,16 +174,26 @@ def gae_roofline(device, iters: int = 30):
     a, q = torch.empty_like(r), torch.empty_like(r)
     for _ in range(3):
         ops.gae_scan(r, v, d, None, GAMMA, LAMBDA, out=(a, q))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
     for _ in range(20):
         ops.gae_scan(r, v, d, None, GAMMA, LAMBDA, out=(a, q))
-    e1.record()
+    c1.record()
     torch.cuda.synchronize(device)
-    return {"bound": "hbm", "kernel": "gae_scan_c1 (streaming, 65536 envs x 128 steps)", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_us, 2), "min_launch_us": round(us[0], 2),
-            "contract_shape_us_per_call_incl_normalise": round(e0.elapsed_time(e1) * 1e3 / 20, 2)}
+    out = {"bound": "hbm", "kernel": "gae_scan_c1<1,1,64,nt> (streaming scan, 65536 envs x 128 steps)",
+           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+           "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_us, 2),
+           "launches_timed": iters, "single_launch_event_pair_us": {"median": round(single[len(single) // 2], 2), "min": round(single[0], 2)},
+           "frac_of_measured_copy_ceiling_6.29TBps": round(achieved / 6290.0, 4),
+           "contract_shape_us_per_call_incl_normalise": round(c0.elapsed_time(c1) * 1e3 / 20, 2)}
+    del bufs
+    torch.cuda.empty_cache()
+    if with_traffic:
+        traffic, detail = gae_traffic(algo_read, algo_write)
+        out["traffic"] = traffic
+        if detail:
+            out["traffic_detail"] = detail
+    return out
 
 
 def _pick_cpu_threads(pol, budget_s: float = 6.0):
@@ -192,6 +268,7 @@ def main():
                          "master weights) or 32 (exact-f32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     args = ap.parse_args()
 
     from rlinf_amd.scheduler import init_distributed
@@ -244,7 +321,7 @@ def main():
                                       "rollout/rewards")},
         }
         if not args.no_roofline:
-            line["roofline"] = gae_roofline(dev)
+            line["roofline"] = gae_roofline(dev, with_traffic=not args.no_traffic)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -648,6 +648,15 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         }
         if (vec == 0) vec = 1;
         if (nseg == 0) nseg = 1;
+        int rows_sel = rows;
+        bool nt_sel = nt;
+        if (p->variant == 0 && nseg == 1 && a.T >= 128 && a.T % 64 == 0 && ceil_div(batch, 64) >= 4 * num_cu()) {
+            // HBM-regime sweep (profiles/r01_gae_hbm_sweep_stream.txt): with the buffer far larger than the caches, 64-row
+            // register batches (two of them = a 128-step trajectory entirely in flight) + nontemporal accesses is the
+            // fastest streaming variant (60.5 % of 8 TB/s vs 58 %); it only exists for the critic / no-mask case
+            rows_sel = 64;
+            nt_sel = true;
+        }
         const bool regseg = (p->variant >> 26) & 1;  // register-resident 32-step segments, serial carry chain
         if (regseg) {
             RLX_REQUIRE(vec == 1 || vec == 2 || vec == 4, "rlx_gae_scan: regseg vec=%d", vec);
@@ -678,7 +687,7 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         nblk = ceil_div(batch, 64);
         int rc = RLX_ENOSYS;
         switch (nseg) {
-            case 1: rc = dispatch_c1<1>(a, s, nblk, rows ? rows : 8, nt); break;
+            case 1: rc = dispatch_c1<1>(a, s, nblk, rows_sel ? rows_sel : 8, nt_sel); break;
             case 2: rc = dispatch_c1<2>(a, s, nblk); break;
             case 4: rc = dispatch_c1<4>(a, s, nblk); break;
             case 8: rc = dispatch_c1<8>(a, s, nblk); break;

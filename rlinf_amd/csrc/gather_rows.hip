@@ -65,10 +65,28 @@ __global__ __launch_bounds__(256) void store_env_rows_kernel(const float* __rest
     d_row[i] = te | tr;  // dones = terminations | truncations (maniskill_env.py:343-350)
 }
 
+// development / calibration: one dword per lane streaming copy of n floats (known traffic: 4n bytes read, 4n written) --
+// the byte-count reference for rocprofv3's FETCH_SIZE / WRITE_SIZE in the gae_scan access pattern (MI355X_MICROARCH.md:
+// "calibrate on a known byte count in your own access pattern")
+__global__ __launch_bounds__(64) void dev_stream_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows,
+                                                             long long width) {
+    const long long col = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (col >= width) return;
+    for (long long r = 0; r < rows; ++r) dst[r * width + col] = src[r * width + col];
+}
+
 }  // namespace
 }  // namespace rlx
 
 using namespace rlx;
+
+extern "C" int rlx_dev_stream_copy(const float* src, float* dst, int64_t rows, int64_t width, rlx_stream_t stream) {
+    RLX_REQUIRE(src && dst && rows > 0 && width > 0, "rlx_dev_stream_copy: bad argument");
+    hipLaunchKernelGGL(dev_stream_copy_kernel, dim3(ceil_div(width, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), src, dst,
+                       (long long)rows, (long long)width);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
 
 extern "C" int rlx_store_env_rows(const float* rewards, const uint8_t* terminations, const uint8_t* truncations,
                                   float* reward_row, uint8_t* done_row, uint8_t* termination_row, uint8_t* truncation_row,

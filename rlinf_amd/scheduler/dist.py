@@ -44,7 +44,11 @@ def init_distributed(backend: Optional[str] = None, device_type: Optional[str] =
         kw = {}
         if use_cuda:
             kw["device_id"] = device
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world, **kw)
+        # RLX_DIST_BACKEND: override for set-ups where ranks share a device (RCCL needs one device per rank)
+        backend = backend or os.environ.get("RLX_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        if backend != "nccl":
+            kw.pop("device_id", None)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
         ctx.initialized_here = True
     return ctx
 

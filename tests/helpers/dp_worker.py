@@ -1,0 +1,81 @@
+"""One rank of a world_size-2 job (launched by tests/test_distributed.py with RANK / WORLD_SIZE / MASTER_* set).
+
+mode "cpu": host-side data-parallel logic on CPU tensors over gloo (no kernels).
+mode "gpu": the full runner on a (shared) GPU, gradients all-reduced over gloo; dumps what the parent compares.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def cpu_main(out_path):
+    from rlinf_amd.scheduler import (CommMapper, all_reduce_flat_, all_reduce_scalars, build_recv_plan, build_send_plan,
+                                     compute_split_num, env_shard, init_distributed)
+    from rlinf_amd.scheduler.placement import minibatch_plan
+    ctx = init_distributed(device_type="cpu")
+    assert ctx.world_size == 2 and dist.get_backend() == "gloo"
+    res = {"rank": ctx.rank}
+    # env shards are disjoint, contiguous and cover the env axis (env_worker.py:137-140)
+    res["shard"] = env_shard(1024, ctx.world_size, 1, ctx.rank)
+    res["plan"] = minibatch_plan(1024 * 128 // ctx.world_size, 8192, 8192 // ctx.world_size, ctx.world_size)
+    res["split"] = compute_split_num(ctx.world_size, ctx.world_size)
+    # C1: the gradient all-reduce of one flat buffer (mean)
+    g = torch.full((1000,), float(ctx.rank + 1))
+    all_reduce_flat_(g, ctx, average=True)
+    res["grad_mean"] = float(g[0])
+    # C3 + C4: one SUM call and one MAX call for every metric
+    sums = torch.tensor([10.0 * (ctx.rank + 1), 4.0])
+    maxs = torch.tensor([-float(ctx.rank), float(ctx.rank) + 5.0])
+    s, m = all_reduce_scalars(sums, maxs, ctx)
+    res["sums"], res["maxs"] = s.tolist(), m.tolist()
+    # routing maps agree across ranks: what rank r sends to d is what d expects from r
+    send = build_send_plan("env", "actor", ctx.rank, 2, 2, "traj", 64)
+    recv = build_recv_plan("env", "actor", ctx.rank, 2, 2, "traj", 64)
+    res["send"] = [(e.peer_rank, e.batch_size, e.offset) for e in send.entries]
+    res["recv"] = [(e.peer_rank, e.batch_size, e.offset) for e in recv.entries]
+    res["dst_4_to_2"] = CommMapper.get_dst_ranks(64, 4, 2, ctx.rank)
+    json.dump(res, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_main(out_path, precision):
+    import copy
+
+    from oracle import ppo_oracle as O
+    from test_end_to_end import _build, make_cfg
+
+    from oracle import ppo_loop as L
+    os.environ["RLX_DIST_BACKEND"] = "gloo"  # two ranks share the one GPU of the test box: RCCL needs a device per rank
+    T, B, GB = 12, 64, 192
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=GB // 2)
+    cfg.actor.model.precision = precision
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    sd = copy.deepcopy(O.OracleMLPPolicy(42, 8, 1).state_dict())
+    runner = _build(cfg, env, sd)
+    ctx = runner.actor.worker.ctx
+    assert ctx.world_size == 2
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    lo, hi = ctx.rank * (B // 2), (ctx.rank + 1) * (B // 2)
+    metrics = runner.run_step(eps[:, lo:hi].cuda())
+    rb = runner.actor.worker.rollout_batch
+    torch.save(dict(rank=ctx.rank, metrics=metrics, params=runner.actor.worker.model.flat.detach().cpu(),
+                    advantages=rb["advantages"].cpu(), returns=rb["returns"].cpu(), actions=rb["forward_inputs"]["action"].cpu(),
+                    rewards=rb["rewards"].cpu()), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "cpu":
+        cpu_main(sys.argv[2])
+    else:
+        gpu_main(sys.argv[2], sys.argv[3])

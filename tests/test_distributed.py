@@ -1,0 +1,103 @@
+"""The N > 1 path: env axis sharded over ranks, rank-local rollout / GAE / shuffle, ONE gradient
+all-reduce (mean) per optimizer step, metrics reduced once per iteration.  world_size 2:
+  * on CPU over gloo: the host-side arithmetic (shards, minibatch plan, routing maps, the two collectives);
+  * on the GPU box (-m gpu): the whole runner as two processes against a two-shard emulation with the CPU oracle."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+WORKER = os.path.join(ROOT, "tests", "helpers", "dp_worker.py")
+
+
+def _launch(mode, tmp_path, *extra, port=29611, timeout=300):
+    procs, outs = [], []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = str(tmp_path / f"rank{rank}.out")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, WORKER, mode, out, *extra], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(log)
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return outs
+
+
+def test_world_size_2_host_logic_over_gloo(tmp_path):
+    r0, r1 = (json.load(open(o)) for o in _launch("cpu", tmp_path))
+    assert r0["shard"] == [0, 512] and r1["shard"] == [512, 1024]
+    assert r0["plan"] == r1["plan"] == [16, 4096, 1]  # 16 minibatches of 4096 per rank, no accumulation
+    assert r0["split"] == 1
+    assert r0["grad_mean"] == r1["grad_mean"] == 1.5
+    assert r0["sums"] == r1["sums"] == [30.0, 8.0] and r0["maxs"] == r1["maxs"] == [0.0, 6.0]
+    assert r0["send"] == [[0, 32, 0]] and r1["send"] == [[1, 32, 0]] and r0["recv"] == [[0, 32, 0]]
+    assert r0["dst_4_to_2"] == [[0, 16]] and r1["dst_4_to_2"] == [[0, 16]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["32"])
+def test_two_ranks_match_the_sharded_oracle(tmp_path, precision):
+    """Two processes (gloo all-reduce of CUDA tensors, one GPU) against the reference arithmetic applied shard by shard:
+    per-rank rollout on its env half, per-shard advantage normalisation, per-rank shuffle with seed + rank, per-rank
+    minibatches of global_batch / 2, gradient mean, identical clip + AdamW on every rank."""
+    import copy
+
+    from oracle import ppo_loop as L
+    from oracle import ppo_oracle as O
+    outs = [torch.load(o, weights_only=False) for o in _launch("gpu", tmp_path, precision, port=29613, timeout=600)]
+    T, B, GB = 12, 64, 192
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    opt = O.build_adamw(ora)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    shards = []
+    for r in range(2):
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        env_r = {k: v[:, sl].contiguous() for k, v in env.items()}
+        batch = L.advantages(L.rollout(ora, env_r, eps[:, sl], 0.8, True), 0.8, 0.9, True)
+        perm = torch.randperm(T * B // 2, generator=torch.Generator().manual_seed(1234 + r))
+        shards.append((batch, O.flatten_and_shuffle(batch, perm)))
+    n_mb = (T * B // 2) // (GB // 2)
+    for _ in range(2):  # update_epoch
+        chunks = [O.chunk_batch(flat, n_mb) for _, flat in shards]
+        for i in range(n_mb):
+            opt.zero_grad()
+            for r in range(2):
+                mb = chunks[r][i]
+                out = ora.evaluate(mb["forward_inputs"]["states"], mb["forward_inputs"]["action"])
+                shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8,
+                                             values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
+                loss, _ = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+                (loss / 2).backward()  # DDP / FSDP average the per-rank gradients
+            gn = torch.nn.utils.clip_grad_norm_(ora.parameters(), 0.5)
+            if torch.isfinite(gn):
+                opt.step()
+    want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+    for r, o in enumerate(sorted(outs, key=lambda d: d["rank"])):
+        batch = shards[r][0]
+        torch.testing.assert_close(o["actions"], batch["forward_inputs"]["action"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(o["rewards"], batch["rewards"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(o["returns"], batch["returns"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(o["advantages"], batch["advantages"], rtol=1e-3, atol=1e-4)  # normalised per shard
+        diff = (o["params"] - want).abs()
+        steps = 2 * n_mb
+        assert float(diff.max()) <= 2 * 3e-4 * steps + 1e-6
+        assert float((diff > 2e-5).float().mean()) < 0.02
+    assert torch.equal(outs[0]["params"], outs[1]["params"])  # both ranks hold the same weights after the update
