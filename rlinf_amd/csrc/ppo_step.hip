@@ -80,7 +80,6 @@ __device__ __forceinline__ void mfma_step(const f32x4 (&a)[RT], const f32x4 (&b)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q], b[ct][q], acc[rt][ct], 0, 0, 0);
 }
 
-long long* g_timing_buffer = nullptr;
 
 // acc = X[0:BM, 0:32*nit] . W^T for one weight matrix given as fragment tiles (struct Tiles).
 // Barrier-free K loop: every wave owns 16*CT output columns, so the weight tiles it needs are its own -- they go
@@ -710,6 +709,9 @@ int pack_tiles(const float* params, const rlx_mlp_layout& lay, float* tiles, hip
 }
 
 }  // namespace
+namespace step {
+long long* g_timing_buffer = nullptr;
+}
 }  // namespace rlx
 
 using namespace rlx;
@@ -753,10 +755,15 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
         if (int rc = set_lds(rollout_step_kernel<PDV>, lds)) return rc;                         \
         hipLaunchKernelGGL(rollout_step_kernel<PDV>, dim3(blocks), dim3(512), lds, st, a);      \
     } while (0)
+#ifdef RLX_DEV_VARIANTS
     if (v == 1) RLX_LAUNCH_ROLLOUT(1);
     else if (v == 4) RLX_LAUNCH_ROLLOUT(4);
     else if (v == 8) RLX_LAUNCH_ROLLOUT(8);
     else RLX_LAUNCH_ROLLOUT(2);
+#else
+    (void)v;
+    RLX_LAUNCH_ROLLOUT(2);
+#endif
 #undef RLX_LAUNCH_ROLLOUT
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -821,6 +828,7 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     a.head_part = reinterpret_cast<float*>(ws + pl.off_head); a.loss_part = reinterpret_cast<double*>(ws + pl.off_loss);
     a.head_stride = pl.head_stride;
     DwArgs d{};
+    d.stamps = g_timing_buffer ? g_timing_buffer + 32 : nullptr;
     d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
     d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_parts = pl.head_parts;
     d.head_stride = pl.head_stride;
@@ -852,19 +860,24 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
         if (int rc = set_lds(ppo_step_fused_kernel<4, 8, PDV, ABLV, OPV>, lds)) return rc;                                \
         hipLaunchKernelGGL((ppo_step_fused_kernel<4, 8, PDV, ABLV, OPV>), dim3(pl.tiles, 2), dim3(512), lds, st, a);      \
     } while (0)
+    // ablation builds (RLX_STEP_VARIANT, development): compiled only with -DRLX_DEV_VARIANTS, see tools/bench_step.py
     if (!op8) {
         RLX_LAUNCH_FUSED(2, 0, 16);
     } else {
-        switch (v) {  // the ablation / prefetch-depth variants exist for 8 padded head outputs only
+#ifdef RLX_DEV_VARIANTS
+        switch (v) {
             case 201: RLX_LAUNCH_FUSED(2, 1, 8); break;
             case 202: RLX_LAUNCH_FUSED(2, 2, 8); break;
             case 204: RLX_LAUNCH_FUSED(2, 4, 8); break;
             case 208: RLX_LAUNCH_FUSED(2, 8, 8); break;
-            case 200: RLX_LAUNCH_FUSED(2, 0, 8); break;
             case 400: RLX_LAUNCH_FUSED(4, 0, 8); break;
             case 300: RLX_LAUNCH_FUSED(3, 0, 8); break;
             default: RLX_LAUNCH_FUSED(2, 0, 8); break;
         }
+#else
+        (void)v;
+        RLX_LAUNCH_FUSED(2, 0, 8);
+#endif
     }
 #undef RLX_LAUNCH_FUSED
     RLX_LAUNCH_CHECK();

@@ -655,6 +655,171 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradients, LDS-DMA variant: the 16 operand tiles of a k-block (8 of dZ^T, 8 of H^T, 1 KiB each, already in
+// lane-linear fragment order) are copied global -> LDS by `global_load_lds_dwordx4` (four 1 KiB DMAs per wave, no
+// registers involved), every wave then reads its 4 + 4 fragments with conflict-free ds_read_b128.  Each operand byte
+// is fetched ONCE per workgroup (the register-streaming kernel fetches it once per wave pair): the kernel is bound by
+// how fast a CU can pull data that the previous launch produced (~11 B/clk), so halving the bytes is what counts.
+// Ring of 3 LDS buffers, counted vmcnt waits, raw s_barrier (a __syncthreads() would drain the DMAs).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DW_NBUF = 3, DW_BUF_BYTES = 16 * 1024;
+
+__global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, const __bf16* __restrict__ st_tiles) {
+    extern __shared__ __align__(16) char dsm[];
+    const rlx_mlp_layout& lay = a.lay;
+    const long long M = a.M;
+    const int tid = threadIdx.x;
+    const int gemm_blocks = round_up(a.gemm_items, 8);
+    int b = blockIdx.x;
+
+    if (b >= gemm_blocks) {
+        b -= gemm_blocks;
+        if (b < a.slabs * 2) {
+            const int s = b >> 1, y = b & 1, j = tid;
+            const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+            float* slab = a.grads + (size_t)s * lay.n_params;
+            for (int o = 0; o < n_out; ++o) {
+                float acc = 0.f;
+                for (int t = s; t < a.head_parts; t += a.slabs) acc += a.head_part[((size_t)t * 2 + y) * a.head_stride + o * HID + j];
+                slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc;
+            }
+            if (j < n_out) {
+                float sb = 0.f, sl = 0.f;
+                for (int t = s; t < a.head_parts; t += a.slabs) {
+                    const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
+                    sb += part[n_out * HID + j];
+                    sl += part[n_out * HID + n_out + j];
+                }
+                if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
+                if (y == 1) slab[lay.off_logstd + j] = sl;
+            }
+        } else {
+            double* s_red = reinterpret_cast<double*>(dsm);
+            double acc[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+            for (int i = tid; i < a.tiles * 2; i += 256) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
+            }
+            block_sum<NS>(acc, s_red);
+            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+        }
+        return;
+    }
+    const int item = (b & 7) * (gemm_blocks >> 3) + (b >> 3);
+    if (item >= a.gemm_items) return;
+    const int s = item / 20, w = item % 20;
+    int y, l, i0, j0;
+    if (w < 16) {
+        const int mat = w >> 2, tile = w & 3;
+        y = mat >> 1; l = 1 + (mat & 1); i0 = (tile >> 1) * 128; j0 = (tile & 1) * 128;
+    } else {
+        y = (w - 16) >> 1; l = 0; i0 = ((w - 16) & 1) * 128; j0 = 0;
+    }
+    const int nrb = (int)((M + 31) / 32);
+    const size_t mat_elems = (size_t)16 * nrb * 512;
+    const int Kin = l == 0 ? lay.obs_dim : HID;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.dz) + (size_t)(y * 3 + l) * mat_elems;
+    const __bf16* Bm = l == 0 ? st_tiles : reinterpret_cast<const __bf16*>(a.h) + (size_t)(y * 2 + l - 1) * mat_elems;
+    const int ncb_b = l == 0 ? 4 : 16;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int rb0 = (int)((long long)s * a.rows_per_slab / 32);
+    const int rb1 = min(nrb, (int)(((long long)(s + 1) * a.rows_per_slab) / 32));
+    const int nkb = max(0, rb1 - rb0);
+
+    // this wave's DMA duty: A tiles 2w, 2w+1 and B tiles 2w, 2w+1 of every k-block (LDS slots t and 8 + t)
+    const __bf16* src[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int t = 2 * wave + q;
+        src[q] = A + ((size_t)(i0 / 16 + t) * nrb + rb0) * 512 + lane * 8;
+        src[2 + q] = Bm + ((size_t)min(j0 / 16 + t, ncb_b - 1) * nrb + rb0) * 512 + lane * 8;
+    }
+    auto dma = [&](int kb, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = (q < 2 ? 0 : 8) + 2 * wave + (q & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + (size_t)kb * 512),
+                                             (__attribute__((address_space(3))) void*)(dsm + buf * DW_BUF_BYTES + slot * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool live = j0 + wj * 64 < Kin;  // first layers: only the first 64-column block holds inputs (the wave still copies)
+
+    // stamps by the workgroup that owns GEMM item 0
+    long long* stp = (a.stamps != nullptr && item == 0 && tid == 0) ? a.stamps : nullptr;
+    if (stp) stp[0] = clock64();
+    if (nkb > 0) dma(0, 0);
+    if (nkb > 1) dma(1, 1);
+    for (int kb = 0; kb < nkb; ++kb) {
+        // this wave's copies of k-block kb have landed once at most the 4 of k-block kb+1 are still in flight
+        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody's copies of kb landed; everybody finished reading kb - 1
+        asm volatile("" ::: "memory");
+        if (stp && kb < 12) stp[1 + kb] = clock64();
+        if (kb + 2 < nkb) dma(kb + 2, (kb + 2) % DW_NBUF);  // into the buffer k-block kb - 1 just vacated
+        const char* buf = dsm + (kb % DW_NBUF) * DW_BUF_BYTES + lane * 16;
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            fa[t] = *reinterpret_cast<const bf16x8*>(buf + (wi * 4 + t) * 1024);
+            fb[t] = *reinterpret_cast<const bf16x8*>(buf + (8 + wj * 4 + t) * 1024);
+        }
+        if (live) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ti], fb[tj], acc[ti][tj], 0, 0, 0);
+                float t8 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t8 += (float)fa[ti][e];
+                bsum[ti] += t8;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment reads are done before this wave arrives at the next barrier
+    }
+    if (stp) stp[14] = clock64();
+    if (!live) return;
+    float* slab = a.grads + (size_t)s * lay.n_params;
+    float* dW = slab + lay.off_w[y][l];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = j0 + wj * 64 + tj * 16 + r16;
+            if (col < Kin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wi * 64 + ti * 16 + 4 * kq + r;
+                    dW[(size_t)row * Kin + col] = acc[ti][tj][r];
+                }
+            }
+        }
+    if (j0 == 0 && wj == 0) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            float tot = bsum[ti];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (kq == 0) slab[lay.off_b[y][l] + i0 + wi * 64 + ti * 16 + r16] = tot;
+        }
+    }
+    if (stp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[15] = clock64();
+    }
+}
+
 template <typename K>
 int set_lds_b(K kern, size_t bytes) {
     static thread_local const void* done[16] = {};
@@ -699,7 +864,13 @@ int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int til
         hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
     }
     RLX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
+    if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)
+        hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
+    } else {
+        const size_t dlds = (size_t)DW_NBUF * DW_BUF_BYTES;
+        if (int rc = set_lds_b(ppo_step_dw_bf16_lds_kernel, dlds)) return rc;
+        hipLaunchKernelGGL(ppo_step_dw_bf16_lds_kernel, dim3(dw_blocks), dim3(256), dlds, st, d, static_cast<const __bf16*>(stt));
+    }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

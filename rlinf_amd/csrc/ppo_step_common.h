@@ -165,6 +165,7 @@ struct StepArgs {
 };
 
 struct DwArgs {
+    long long* stamps;
     rlx_mlp_layout lay;
     const float* states;
     const float* h;          // [2][2][M][256]
@@ -237,7 +238,9 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     pl.tiles = ceil_div(m, STEP_BM);
     pl.head_parts = pl.tiles * (STEP_BM / 32);
     // 20 GEMM items per slab; fill 2 workgroups per CU once (no second, half-empty round)
-    int slabs = std::max(1, std::min(2 * num_cu() / 20, ceil_div(m, 32)));
+    int want = 2 * num_cu() / 20;
+    if (const char* e = getenv("RLX_DW_SLABS")) want = std::max(1, atoi(e));  // development: tools/bench_step.py sweeps it
+    int slabs = std::max(1, std::min(want, ceil_div(m, 32)));
     pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
     pl.slabs = ceil_div(m, pl.rows_per_slab);
     pl.head_stride = head_stride_of(lay);
@@ -260,6 +263,8 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     pl.bytes = off;
     return pl;
 }
+
+extern long long* g_timing_buffer;  // development: phase stamps (rlx_dev_set_timing_buffer)
 
 // bf16 launches (ppo_step_bf16.hip)
 int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles, hipStream_t st);

@@ -721,3 +721,62 @@ def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatc
         raise RlxError("ppo_step: the tile image's dtype does not match the requested precision")
     with torch.cuda.device(dev):
         _lib.check(lib.rlx_ppo_step(byref(a), _stream_ptr(dev)), "rlx_ppo_step")
+
+
+# --------------------------------------------------------------------------------------------
+# prepared launches: marshal once, replay with one ctypes call (the update loop issues ~500 launches per iteration;
+# building the argument structs in Python every time costs more host time than the kernels take on the GPU)
+# --------------------------------------------------------------------------------------------
+class PreparedPpoStep:
+    """rlx_ppo_step with every pointer fixed (persistent minibatch views and workspaces)."""
+
+    def __init__(self, params, layout, loss, mbatch, grads, out_row, workspace, grad_out=1.0, tiles=None, bf16=False):
+        self._lib = _lib.load()
+        self._keep = (params, layout, loss, dict(mbatch), grads, out_row, workspace, tiles)
+        a = PpoStepArgs()
+        a.params, a.layout, a.loss = params.data_ptr(), ctypes_pointer(layout), ctypes_pointer(loss)
+        st = mbatch["states"]
+        a.states, a.action = st.data_ptr(), mbatch["action"].data_ptr()
+        a.old_logprobs, a.advantages = mbatch["prev_logprobs"].data_ptr(), mbatch["advantages"].data_ptr()
+        has_critic = bool(loss.has_critic)
+        a.prev_values = mbatch["prev_values"].data_ptr() if has_critic else None
+        a.returns = mbatch["returns"].data_ptr() if has_critic else None
+        lm = mbatch.get("loss_mask")
+        a.loss_mask = None if lm is None else lm.data_ptr()
+        a.loss_mask_sum = _ptr(mbatch.get("loss_mask_sum"))
+        a.m, a.grad_out = st.shape[0], float(grad_out)
+        a.grads, a.slabs, a.out = grads.data_ptr(), grads.shape[0], out_row.data_ptr()
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
+        a.tiles, a.bf16 = _ptr(tiles), int(bool(bf16))
+        self._args = a
+        self._ref = byref(a)
+
+    def __call__(self, stream: int):
+        rc = self._lib.rlx_ppo_step(self._ref, stream)
+        if rc:
+            _lib.check(rc, "rlx_ppo_step")
+
+
+class PreparedAdamw:
+    """rlx_clip_adamw_step with every pointer fixed; ``stats`` is this step's (norm, applied) row."""
+
+    def __init__(self, params, grads, exp_avg, exp_avg_sq, groups, *, betas, eps, weight_decay, max_grad_norm, grad_scale,
+                 stats, step_state, workspace, tile_layout=None, tiles=None):
+        self._lib = _lib.load()
+        n = params.numel()
+        p = AdamwParams()
+        p.beta1, p.beta2, p.eps, p.weight_decay = float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+        p.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        p.step, p.n_groups, p.grad_partials, p.grad_scale = 0, len(groups), grads.numel() // n, float(grad_scale)
+        for k, (b, e, lr) in enumerate(groups):
+            p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
+        if tile_layout is not None and tiles is not None:
+            p.tile_layout, p.tiles, p.tiles_bf16 = ctypes_pointer(tile_layout), tiles.data_ptr(), int(tiles.dtype == torch.bfloat16)
+        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p)
+        self._argv = (params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, byref(p), stats.data_ptr(),
+                      step_state.data_ptr(), workspace.data_ptr(), workspace.numel())
+
+    def __call__(self, stream: int):
+        rc = self._lib.rlx_clip_adamw_step(*self._argv, stream)
+        if rc:
+            _lib.check(rc, "rlx_clip_adamw_step")

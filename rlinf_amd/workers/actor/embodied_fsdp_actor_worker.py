@@ -246,6 +246,8 @@ class EmbodiedFSDPActor(Worker):
             self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
         grads, grad_out = self._ws[key], self._ws["grad_out"]
         self._grad_out_host = 1.0 / accum
+        if self.fused_step and self.critic_warmup_steps == 0:
+            return self._run_update_prepared(flat, N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro)
         step = 0
         for _ in range(alg.get("update_epoch", 1)):
             for i in range(n_mb):
@@ -258,6 +260,54 @@ class EmbodiedFSDPActor(Worker):
                 self.optimizer_step(grads, stats=norms_dev[step])  # (norm, applied) straight into this step's row
                 step += 1
         return step
+
+    def _run_update_prepared(self, flat, N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro):
+        """The same loop with every launch marshalled once: all buffers are persistent, so an optimizer step is a handful of
+        ctypes calls (+ one torch.distributed all-reduce when world_size > 1) -- the eager path of multi-GPU runs is
+        otherwise bound by Python argument marshalling, not by the GPU."""
+        m, o = self.model, self.cfg.actor.optim
+        epochs = self.cfg.algorithm.get("update_epoch", 1)
+        pkey = ("prepared", N, micro, accum, epochs, tuple(t.data_ptr() for t in flat.values()), metrics_dev.data_ptr())
+        if self._ws.get("prepared_key") != pkey:
+            bf16 = m.compute_dtype == torch.bfloat16
+            tiles = m.tiles() if self.optimizer_writes_tiles else None
+            lp = self._loss_params(False)
+            multi = self._world_size > 1
+            plan, step = [], 0
+            for _ in range(epochs):
+                for i in range(n_mb):
+                    micro_calls = []
+                    for j in range(accum):
+                        lo = i * per_rank + j * micro
+                        mbatch = {k: v[lo:lo + micro] for k, v in flat.items()}
+                        micro_calls.append(ops.PreparedPpoStep(
+                            m.flat.data, m.layout, lp, mbatch, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
+                            metrics_dev[step * accum + j], ws["step_ws"], grad_out=self._grad_out_host, tiles=tiles, bf16=bf16))
+                    adam = ops.PreparedAdamw(
+                        m.flat.data, self.grad_flat if multi else grads, self.exp_avg, self.exp_avg_sq, self.groups,
+                        betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
+                        max_grad_norm=o.clip_grad, grad_scale=1.0 / self._world_size if multi else 1.0, stats=norms_dev[step],
+                        step_state=self.step_state, workspace=self.adamw_ws, tile_layout=m.layout if tiles is not None else None,
+                        tiles=tiles)
+                    plan.append((micro_calls, adam))
+                    step += 1
+            self._ws["prepared_key"], self._ws["prepared_plan"] = pkey, plan
+        plan = self._ws["prepared_plan"]
+        tiles_fresh = self.optimizer_writes_tiles
+        if tiles_fresh:
+            m.tiles()  # make sure the image is current before the first forward (no-op when the optimizer kept it fresh)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            for micro_calls, adam in plan:
+                for call in micro_calls:
+                    call(stream)
+                if self._world_size > 1:
+                    ops.sum_slabs(grads, out=self.grad_flat)
+                    all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1)
+                adam(stream)
+        m.mark_updated(tiles_fresh=tiles_fresh)
+        self.optimizer_steps += len(plan)
+        return len(plan)
 
     def run_training(self) -> dict:
         a, alg = self.cfg.actor, self.cfg.algorithm

@@ -33,17 +33,21 @@ def main():
     mb = {k: v.cuda() for k, v in mb.items()}
     lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
                              value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
-    grads = torch.empty((ops.ppo_step_slabs(lay, M), lay.n_params), device="cuda")
-    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
     row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
-    names = {0: "PD2 (product)", 300: "PD3", 400: "PD4", 201: "PD2 no-tanh", 202: "PD2 no-flush", 204: "PD2 no-weight-loads",
-             208: "PD2 no-mfma"}
-    print(f"ppo_step (fused + dw launches) at M={M}, slabs={grads.shape[0]}")
-    for rep in range(2):
-        for v, name in names.items():
-            os.environ["RLX_STEP_VARIANT"] = str(v)
-            t = timeit(lambda: ops.ppo_step(pol.flat.data, lay, lp, mb, grads, row, ws, grad_out=1.0))
-            print(f"  rep{rep} variant {v:4d} {name:22s} {t:8.2f} us per step (both launches)")
+    print(f"ppo_step (pack + fused + dw launches) at M={M}")
+    for prec in ("bf16", "f32"):
+        for slabs in (24, 16, 12, 8):
+            os.environ["RLX_DW_SLABS"] = str(slabs)
+            grads = torch.empty((ops.ppo_step_slabs(lay, M), lay.n_params), device="cuda")
+            ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+            m_, v_ = torch.zeros(lay.n_params, device="cuda"), torch.zeros(lay.n_params, device="cuda")
+            p2 = pol.flat.data.clone()
+            def step():
+                ops.ppo_step(p2, lay, lp, mb, grads, row, ws, grad_out=1.0, bf16=prec == "bf16")
+                ops.clip_adamw_step_(p2, grads, m_, v_, pol.group_ranges(3e-4, 3e-4), 1, max_grad_norm=0.5)
+            t = timeit(step)
+            print(f"  {prec} slabs={grads.shape[0]:3d}: {t:8.2f} us per optimizer step (pack + fused + dw + sqnorm + adamw, eager)")
+    os.environ.pop("RLX_DW_SLABS", None)
     os.environ["RLX_STEP_VARIANT"] = "0"
     B = 1024
     states, eps = torch.randn(B, 42, device="cuda"), torch.randn(B, 8, device="cuda")
@@ -51,7 +55,7 @@ def main():
     rew, flags = torch.rand(B, 1, device="cuda"), torch.rand(B, 1, device="cuda") < 0.3
     out = (torch.empty(B, 8, device="cuda"), torch.empty(B, 8, device="cuda"), torch.empty(B, 1, device="cuda"))
     for rep in range(2):
-        for pd in (1, 2, 4, 8):
+        for pd in (2,):
             os.environ["RLX_ROLLOUT_PD"] = str(pd)
             t = timeit(lambda: ops.mlp_rollout_step(pol.flat.data, pol.tiles(), lay, states, eps, out=out,
                                                     value_jobs=(dict(states=fin, rewards=rew, flags=flags, gamma=0.8),)), iters=50)
