@@ -15,6 +15,8 @@ Extra objects on that line:
   roofline      gae_scan (the kernel BASELINE.json grades against the HBM roofline), timed live with HIP events on the
                 launch stream at the scaled shape 65536 envs x 128 steps (the 1024 x 128 buffer is 2.2 MB and lives in
                 L2); algorithmic bytes = 17 B per env-step.
+  roofline_token_tier  (N = 1) the widening row, SURVEY.md 8f item 1: token_logprob fwd / bwd at 4096 tokens x 151936
+                vocab, bf16 logits, same HIP-event method.
   cpu_baseline  the CPU oracle (a port of the reference's torch-CPU path, oracle/ppo_loop.py) on this box's host
                 cores, on a bounded sample, N = 1 only.
 """
@@ -196,6 +198,45 @@ def gae_roofline(device, iters: int = 30, with_traffic: bool = True):
     return out
 
 
+def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: int = 10):
+    """SURVEY.md 8f item 1 (the widening after rows a-e): the reasoning learner's logits -> log-prob/entropy kernel and
+    its backward at a Qwen-size vocabulary, bf16 logits, timed with HIP events on the launch stream.  Algorithmic bytes:
+    forward = tokens * vocab * 2 (one read); backward = twice that (one read + one write)."""
+    from rlinf_amd import token_ops
+
+    g = torch.Generator(device=device).manual_seed(1)
+    x = torch.empty(tokens, vocab, dtype=torch.bfloat16, device=device)
+    for i in range(0, tokens, 1024):
+        x[i:i + 1024] = (torch.randn(min(1024, tokens - i), vocab, device=device, generator=g) * 4).to(torch.bfloat16)
+    labels = torch.randint(0, vocab, (tokens,), device=device, generator=g)
+    dlp = torch.randn(tokens, device=device, generator=g)
+    out = torch.empty_like(x)
+    _, _, lse = token_ops.token_logprob_fwd(x, labels)
+
+    def avg_us(fn):
+        for _ in range(2):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize(device)
+        return sum(a.elapsed_time(b) for a, b in evs) / iters * 1e3
+
+    rows = []
+    by = tokens * vocab * 2
+    for name, fn, nbytes in (("token_logprob_fwd", lambda: token_ops.token_logprob_fwd(x, labels), by),
+                             ("token_logprob_bwd", lambda: token_ops.token_logprob_bwd(x, labels, lse, None, dlp, None, out=out),
+                              2 * by)):
+        us = avg_us(fn)
+        gbps = nbytes / us / 1e3
+        rows.append({"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(gbps / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1), "algorithmic_bytes": nbytes,
+                     "shape": f"{tokens} tokens x {vocab} vocab, bf16 logits"})
+    return rows
+
+
 def _pick_cpu_threads(pol, budget_s: float = 6.0):
     """torch's default (one thread per logical core) oversubscribes the small GEMMs of this path badly on a
     many-core host (256 threads: ~2.7 s per rollout step).  Time one minibatch-sized forward at a few thread counts and
@@ -268,6 +309,7 @@ def main():
                          "master weights) or 32 (exact-f32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-token-tier", action="store_true", help="skip the token-tier (LLM logits) roofline rows")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     args = ap.parse_args()
 
@@ -322,6 +364,8 @@ def main():
         }
         if not args.no_roofline:
             line["roofline"] = gae_roofline(dev, with_traffic=not args.no_traffic)
+            if args.gpus == 1 and not args.no_token_tier:
+                line["roofline_token_tier"] = token_tier_roofline(dev)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -412,6 +412,108 @@ int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);
 size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);
 int rlx_ppo_step(const rlx_ppo_step_args* args, rlx_stream_t stream);
 
+/* ==========================================================================================
+ * Token tier: the reasoning (LLM) learner's per-token path over vocabulary logits.
+ * ========================================================================================== */
+
+/* ------------------------------------------------------------------------------------------
+ * t1  token_logprob  <- compute_logprobs_from_logits (op_type="torch") rlinf/utils/utils.py:454-492,
+ *                       compute_entropy_from_logits rlinf/utils/utils.py:495-512,
+ *                       logits.div_(temperature) rlinf/workers/actor/fsdp_actor_worker.py:476-498
+ *   logits   n_tokens rows of `vocab` elements (f32 or bf16); row i starts at element
+ *            (i / rows_per_seq) * seq_stride + (i % rows_per_seq) * row_stride, so the reference's
+ *            response slice logits[:, -resp-1:-1, :] is addressed in place (no reshape copy).
+ *   labels   [n_tokens] i64; -100 (torch's ignore_index) gives logprob -0.0, any other out-of-range label NaN
+ *            (torch raises there; a kernel cannot).
+ *   logprob  [n_tokens] f32 = x[label] - logsumexp(x),  x = logits / temperature
+ *   entropy  [n_tokens] f32 = logsumexp(x) - sum softmax(x) * x      (optional, NULL skips it)
+ *   lse      [n_tokens] f32 logsumexp(x), kept for the backward pass
+ * One pass over the logits (online softmax): algorithmic bytes = n_tokens * vocab * sizeof(dtype).  All arithmetic
+ * in f32; temperature != 1 divides in the logits' dtype (bf16 logits are re-rounded to bf16, as div_ does);
+ * round_outputs rounds logprob to the logits dtype the way torch's cross_entropy in that dtype does.
+ *
+ * token_logprob_bwd: d_logits[i,v] = ( d_logprob[i] * (1[v==label_i] - p_iv)
+ *                                    - d_entropy[i] * p_iv * (log p_iv + H_i) ) / temperature
+ * written in the logits dtype with its own strides; d_logits may alias logits (in-place).  Rows whose
+ * d_logprob and d_entropy are both zero are written as zeros without reading their logits.
+ * ------------------------------------------------------------------------------------------ */
+enum rlx_dtype { RLX_DTYPE_F32 = 0, RLX_DTYPE_BF16 = 1 };
+typedef struct rlx_token_rows {
+    int64_t n_tokens;
+    int32_t vocab;
+    int32_t dtype;          /* rlx_dtype of logits and d_logits */
+    int64_t rows_per_seq;   /* >= 1; n_tokens for a flat contiguous matrix */
+    int64_t seq_stride;     /* elements */
+    int64_t row_stride;     /* elements, >= vocab */
+    float temperature;      /* > 0; 1.0 = no scaling */
+    int32_t round_outputs;  /* 1: logprob rounded to `dtype` (no-op for f32) */
+} rlx_token_rows;
+int rlx_token_logprob_fwd(const void* logits, const int64_t* labels, const rlx_token_rows* rows, float* logprob,
+                          float* entropy, float* lse, rlx_stream_t stream);
+int rlx_token_logprob_bwd(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const float* lse,
+                          const float* entropy, const float* d_logprob, const float* d_entropy, void* d_logits,
+                          int64_t d_seq_stride, int64_t d_row_stride, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * t2  token_loss  <- the micro-batch loss of FSDPActor.training_step, rlinf/workers/actor/fsdp_actor_worker.py:694-781:
+ *        compute_ppo_actor_loss(loss_agg_func=..., fast_path_zero_loss_mask=True) rlinf/algorithms/losses.py:170-312
+ *        - entropy_bonus * agg(entropy) + kl_beta * agg(kl_penalty(ref_logprobs, logprobs, type))
+ *      with agg = get_loss_agg_func(loss_agg) rlinf/utils/utils.py:337-381 and kl_penalty rlinf/algorithms/utils.py:26-64.
+ *   logprobs / old_logprobs / advantages / ref_logprobs / entropy [bsz, seq] f32, loss_mask [bsz, seq] u8 (NULL = all on)
+ *   out          [RLX_TOK_OUT_FLOATS] f32 (enum below)
+ *   g_logp       [bsz, seq] f32  d(sum-form loss)/d logprob per token (policy + kl_beta * kl), unscaled
+ *   g_entropy    [bsz, seq] f32  -entropy_bonus * mask (only when use_entropy and entropy_bonus != 0, else may be NULL)
+ *   row_weight   [bsz] f32       the aggregation's per-sequence weight (1/count, 1/bsz or 1/(bsz*count_row))
+ * token_loss_bwd: d_logprobs = grad_out * row_weight[row] * g_logp (same for d_entropy), grad_out a device scalar
+ * (the learner's 1/gradient_accumulation rides in it).
+ * fast_path_zero_loss_mask reproduces the reference's check of the FIRST sequence only (losses.py:206): when
+ * loss_mask[0] is all zero the policy term and its metrics are zero and out[RLX_TOK_POLICY_ON] = 0.
+ * ------------------------------------------------------------------------------------------ */
+enum rlx_loss_agg { RLX_AGG_TOKEN_MEAN = 0, RLX_AGG_SEQ_MEAN_TOKEN_SUM = 1, RLX_AGG_SEQ_MEAN_TOKEN_MEAN = 2 };
+enum rlx_kl_type { RLX_KL_NONE = 0, RLX_KL_K1 = 1, RLX_KL_ABS = 2, RLX_KL_K2 = 3, RLX_KL_K3 = 4 };
+enum rlx_tok_out {
+    RLX_TOK_LOSS = 0,          /* policy - entropy_bonus*entropy_loss + kl_beta*kl_loss ("actor/final_loss") */
+    RLX_TOK_POLICY_LOSS,
+    RLX_TOK_POLICY_LOSS_ABS,
+    RLX_TOK_RATIO,
+    RLX_TOK_RATIO_ABS,
+    RLX_TOK_CLIPPED_RATIO,
+    RLX_TOK_DUAL_CLIPPED_RATIO,
+    RLX_TOK_APPROX_KL,
+    RLX_TOK_CLIP_FRACTION,
+    RLX_TOK_ENTROPY_LOSS,
+    RLX_TOK_KL_LOSS,
+    RLX_TOK_TOKEN_NUM,         /* loss_mask.count_nonzero() */
+    RLX_TOK_POLICY_ON,         /* 0 when the zero-loss-mask fast path fired */
+    RLX_TOK_OUT_FLOATS = 16
+};
+typedef struct rlx_token_loss_params {
+    rlx_ppo_loss_params ppo;   /* ratio_lo/hi, dual clip, log-ratio clamps, critic_warmup; critic fields ignored */
+    int32_t loss_agg;          /* rlx_loss_agg */
+    int32_t fast_path_zero_loss_mask;
+    int32_t kl_type;           /* rlx_kl_type; RLX_KL_NONE or ref_logprobs == NULL skips the term */
+    float kl_beta;
+    int32_t use_entropy;       /* entropy != NULL and the learner's calculate_entropy */
+    float entropy_bonus;       /* 0 = entropy is only reported */
+} rlx_token_loss_params;
+size_t rlx_token_loss_workspace_bytes(int64_t bsz, int64_t seq);
+int rlx_token_loss_fwd(const float* logprobs, const float* old_logprobs, const float* advantages,
+                       const float* ref_logprobs, const float* entropy, const uint8_t* loss_mask, int64_t bsz,
+                       int64_t seq, const rlx_token_loss_params* params, float* g_logp, float* g_entropy,
+                       float* row_weight, float* out, void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+int rlx_token_loss_bwd(const float* g_logp, const float* g_entropy, const float* row_weight, const float* grad_out,
+                       float* d_logprobs, float* d_entropy, int64_t bsz, int64_t seq, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * t3  grpo_seq_adv  <- preprocess_reasoning_advantages_inputs (adv_type="grpo") rlinf/algorithms/utils.py:177-262
+ *                      + compute_grpo_advantages rlinf/algorithms/advantages.py:89-121
+ *                      + postprocess_reasoning_advantages_outputs rlinf/algorithms/utils.py:265-277
+ *   rewards [bsz] f32, loss_mask [bsz, seq] u8 -> advantages [bsz, seq] f32 in the sequence-major layout
+ *   (the reference transposes to [seq, bsz], broadcasts, and transposes back with a copy).
+ * ------------------------------------------------------------------------------------------ */
+int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, float* advantages, int64_t bsz, int64_t seq,
+                     int group_size, float eps, rlx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

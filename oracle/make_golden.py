@@ -197,6 +197,76 @@ def make_shuffle(ref):
     torch.save(dict(batch=batch, perm=perm, out=out), os.path.join(OUT, "shuffle.pt"))
 
 
+def token_batch(seed, bsz, seq, vocab, p_on=0.7, zero_first=False, scale=3.0):
+    """Seeded reasoning micro-batch: response-aligned logits, sampled-ish labels, rollout-time stats."""
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(bsz, seq, vocab, generator=g) * scale
+    labels = torch.randint(0, vocab, (bsz, seq), generator=g)
+    best = logits.argmax(-1)
+    labels = torch.where(torch.rand(bsz, seq, generator=g) < 0.5, best, labels)  # half the tokens are the mode
+    old = torch.log_softmax(logits, -1).gather(-1, labels[..., None])[..., 0] + 0.3 * torch.randn(bsz, seq, generator=g)
+    ref_lp = old + 0.2 * torch.randn(bsz, seq, generator=g)
+    adv = torch.randn(bsz, seq, generator=g)
+    lens = torch.randint(1, seq + 1, (bsz,), generator=g)
+    mask = (torch.arange(seq)[None, :] < lens[:, None]) & (torch.rand(bsz, seq, generator=g) < p_on + 0.3)
+    if zero_first:
+        mask[0] = False
+    rewards = torch.randn(bsz, generator=g)
+    return dict(logits=logits, labels=labels, old_logprobs=old, ref_logprobs=ref_lp, advantages=adv,
+                loss_mask=mask, rewards=rewards)
+
+
+TOKEN_GRID = [  # (seed, bsz, seq, vocab, zero_first, agg, temperature, entropy_bonus, kl_beta, kl_type, clip_c, clips)
+    (31, 8, 12, 517, False, "token-mean", 1.0, 0.0, 0.0, "low_var_kl", 3.0, (None, None)),
+    (32, 8, 12, 517, False, "seq-mean-token-sum", 0.7, 0.01, 0.05, "low_var_kl", 3.0, (None, None)),
+    (33, 8, 12, 517, False, "seq-mean-token-mean", 1.3, 0.02, 0.1, "k2", None, (-0.5, 0.4)),
+    (34, 4, 9, 1000, True, "token-mean", 1.0, 0.01, 0.02, "k1", 3.0, (None, None)),
+    (35, 4, 9, 1000, False, "token-mean", 0.6, 0.0, 0.03, "abs", 2.0, (None, 0.3)),
+]
+
+
+def make_token_path(ref):
+    """t1-t6 of oracle/token_oracle.py: every piece produced by the reference's own functions; the micro-batch
+    composition follows FSDPActor.training_step line by line (fsdp_actor_worker.py:694-781) using them."""
+    U, A, L, R = ref.utils, ref.algo_utils, ref.losses, ref.registry
+    cases = []
+    for seed, bsz, seq, vocab, zero_first, agg_name, temp, bonus, beta, kl_type, clip_c, (cmin, cmax) in TOKEN_GRID:
+        b = token_batch(seed, bsz, seq, vocab, zero_first=zero_first)
+        agg = U.get_loss_agg_func(agg_name)
+        out = {}
+        for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            logits = b["logits"].to(dt).clone().requires_grad_(True)
+            scaled = logits / temp
+            logprobs = U.compute_logprobs_from_logits(scaled, b["labels"])
+            entropy = U.compute_entropy_from_logits(scaled)
+            loss, metrics = L.compute_ppo_actor_loss(
+                logprobs=logprobs, old_logprobs=b["old_logprobs"], advantages=b["advantages"], clip_ratio_low=0.2,
+                clip_ratio_high=0.28, loss_mask=b["loss_mask"], clip_ratio_c=clip_c, loss_agg_func=agg,
+                clip_log_ratio_min=cmin, clip_log_ratio_max=cmax, fast_path_zero_loss_mask=True)
+            entropy_loss = agg(entropy, mask=b["loss_mask"])
+            if bonus > 0:
+                loss = loss - bonus * entropy_loss
+            kl_loss = torch.tensor(0.0)
+            if beta > 0:
+                kld = A.kl_penalty(b["ref_logprobs"], logprobs, kl_type)
+                kl_loss = agg(kld, b["loss_mask"])
+                loss = loss + kl_loss * beta
+            final = loss.detach().clone()
+            (loss / 2).backward()
+            out[tag] = dict(logprobs=logprobs.detach(), entropy=entropy.detach(), final_loss=final,
+                            entropy_loss=entropy_loss.detach(), kl_loss=kl_loss.detach(),
+                            metrics={k: v.detach().clone() for k, v in metrics.items()}, d_logits=logits.grad.clone())
+        adv = R.calculate_adv_and_returns(task_type="reasoning", adv_type="grpo", rewards=b["rewards"],
+                                          loss_mask=b["loss_mask"], group_size=4)
+        kls = {k: A.kl_penalty(b["ref_logprobs"], b["old_logprobs"], k) for k in ("k1", "abs", "k2", "k3")}
+        cases.append(dict(params=dict(seed=seed, bsz=bsz, seq=seq, vocab=vocab, zero_first=zero_first, loss_agg=agg_name,
+                                      temperature=temp, entropy_bonus=bonus, kl_beta=beta, kl_penalty_type=kl_type,
+                                      clip_ratio_c=clip_c, clip_log_ratio_min=cmin, clip_log_ratio_max=cmax,
+                                      clip_ratio_low=0.2, clip_ratio_high=0.28, gradient_accumulation=2, group_size=4),
+                          out=out, grpo_advantages=adv[0], kl_terms=kls))
+    torch.save(cases, os.path.join(OUT, "token_path.pt"))
+
+
 def main():
     ref = reference_loader.load()
     os.makedirs(OUT, exist_ok=True)
@@ -205,6 +275,7 @@ def main():
     make_losses(ref)
     make_policy(ref)
     make_shuffle(ref)
+    make_token_path(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

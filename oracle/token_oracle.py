@@ -1,0 +1,206 @@
+"""CPU restatement of the reference's reasoning (LLM) token path.  TEST INFRASTRUCTURE ONLY.
+
+SURVEY.md 8f item 1: per-token log-prob / entropy from vocabulary logits, the KL penalty, the three loss
+aggregations, the reasoning pre/post-processing around the advantage registry and the composition of the
+micro-batch loss in the reasoning learner.  Same rules as ``ppo_oracle.py``: stock torch CPU ops in the
+reference's evaluation order, each function citing the file:line it follows (paths relative to
+/root/reference); pinned against the real reference by ``tests/test_oracle_vs_reference.py`` (build
+container) and against ``tests/golden/token_path.pt`` (everywhere).
+
+Nothing under ``rlinf_amd/`` imports this file.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------
+# t1  log-prob / entropy from logits     rlinf/utils/utils.py:454-512
+# --------------------------------------------------------------------------------------------
+def logprobs_from_logits(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """op_type="torch": cross entropy in the logits' dtype, result cast to fp32 (utils.py:454-492)."""
+    lead = logits.shape[:-1]
+    flat = logits.reshape(-1, logits.shape[-1])
+    out = -F.cross_entropy(flat, target.reshape(-1), reduction="none")
+    return out.view(*lead).float()
+
+
+def entropy_from_logits(logits: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """H = -sum p log p via log_softmax, zero-probability terms dropped (utils.py:495-512)."""
+    logp = F.log_softmax(logits, dim=dim)
+    p = logp.exp()
+    term = torch.where(p > 0, p * logp, 0.0)
+    return -term.sum(dim=dim)
+
+
+# --------------------------------------------------------------------------------------------
+# t2  aggregations                        rlinf/utils/utils.py:307-381
+# --------------------------------------------------------------------------------------------
+def masked_mean(values, mask, axis=None):
+    if mask is None:
+        return values.mean() if axis is None else values.mean(dim=axis)
+    tot = (values * mask).sum() if axis is None else (values * mask).sum(dim=axis)
+    if (~mask).all():
+        return tot
+    return tot / (mask.sum() if axis is None else mask.sum(dim=axis))
+
+
+def seq_mean_token_sum(values, mask, dim: int = -1):
+    return torch.mean(torch.sum(values * mask, dim=-1))
+
+
+def seq_mean_token_mean(values, mask, dim: int = -1):
+    return torch.mean(torch.sum(values * mask, dim=-1) / torch.sum(mask, dim=-1))
+
+
+def get_loss_agg_func(name: str) -> Callable:
+    table = {"seq-mean-token-sum": seq_mean_token_sum, "seq-mean-token-mean": seq_mean_token_mean,
+             "token-mean": masked_mean}
+    if name not in table:
+        raise ValueError(f"Unsupported loss aggregation method: {name}")
+    return table[name]
+
+
+# --------------------------------------------------------------------------------------------
+# t3  KL penalty                          rlinf/algorithms/utils.py:26-64
+# --------------------------------------------------------------------------------------------
+def kl_penalty(logprob, ref_logprob, kind: str):
+    if kind in ("kl", "k1"):
+        return logprob - ref_logprob
+    if kind == "abs":
+        return (logprob - ref_logprob).abs()
+    if kind in ("mse", "k2"):
+        return 0.5 * (logprob - ref_logprob).square()
+    if kind in ("low_var_kl", "k3"):
+        kl = torch.clamp(ref_logprob - logprob, min=-20, max=20)
+        kld = (torch.exp(kl) - kl - 1).contiguous()
+        return torch.clamp(kld, min=-10, max=10)
+    raise NotImplementedError(kind)
+
+
+# --------------------------------------------------------------------------------------------
+# t4  actor loss with a caller-chosen aggregation   rlinf/algorithms/losses.py:170-312
+# --------------------------------------------------------------------------------------------
+ZERO_MASK_KEYS = ("actor/token_num", "actor/policy_loss", "actor/policy_loss_mbs_mean", "actor/policy_loss_abs",
+                  "actor/ratio", "actor/clipped_ratio", "actor/dual_cliped_ratio", "actor/approx_kl",
+                  "actor/clip_fraction")
+
+
+def token_actor_loss(logprobs, old_logprobs, advantages, clip_ratio_low, clip_ratio_high, loss_mask=None,
+                     clip_ratio_c=None, loss_agg_func=masked_mean, clip_log_ratio_min=None,
+                     clip_log_ratio_max=None, fast_path_zero_loss_mask=False, critic_warmup=False):
+    if fast_path_zero_loss_mask and loss_mask is not None and loss_mask[0].sum() == 0.0:  # losses.py:206-219
+        return torch.tensor(0.0), {k: torch.tensor(0.0) for k in ZERO_MASK_KEYS}
+    if loss_mask is None:
+        loss_mask = torch.ones_like(logprobs).bool()
+    n_valid = loss_mask.count_nonzero() or 1
+    log_ratio = logprobs - old_logprobs
+    if clip_log_ratio_min is not None:
+        log_ratio = torch.clamp(log_ratio, min=clip_log_ratio_min)
+    if clip_log_ratio_max is not None:
+        log_ratio = torch.clamp(log_ratio, max=clip_log_ratio_max)
+    ratio = torch.where(loss_mask, torch.exp(log_ratio), 0)
+    kl_terms = torch.where(loss_mask, log_ratio.detach(), 0.0)
+    clipped = torch.clamp(ratio, 1.0 - clip_ratio_low, 1.0 + clip_ratio_high)
+    surr1 = -advantages * ratio
+    surr2 = -advantages * clipped
+    is_clipped = surr1.detach() < surr2.detach()
+    per_tok = torch.max(surr1, surr2)
+    if clip_ratio_c is not None:
+        surr3 = torch.sign(advantages) * clip_ratio_c * advantages
+        is_dual = surr3.detach() < per_tok.detach()
+        per_tok = torch.min(per_tok, surr3)
+    else:
+        is_dual = torch.zeros_like(is_clipped)
+    loss_abs = loss_agg_func(per_tok.abs(), loss_mask, None)
+    loss = loss_agg_func(per_tok, loss_mask, None)
+    is_dual = (is_dual * loss_mask).bool()
+    clip_fraction = (is_clipped * loss_mask).sum() / float(n_valid)
+    approx_kl = -torch.sum(kl_terms) / float(n_valid)
+    dual_ratio = torch.where(is_dual, ratio, 0)
+    if critic_warmup:
+        loss = torch.tensor(0.0)
+    metrics = {
+        "actor/policy_loss": loss.detach(),
+        "actor/policy_loss_abs": loss_abs.detach(),
+        "actor/ratio": masked_mean(ratio.detach(), loss_mask),
+        "actor/ratio_abs": masked_mean((ratio - 1).abs().detach(), loss_mask),
+        "actor/clipped_ratio": masked_mean(clipped.detach(), loss_mask),
+        "actor/dual_cliped_ratio": masked_mean(dual_ratio.detach(), loss_mask),
+        "actor/approx_kl": approx_kl.detach(),
+        "actor/clip_fraction": clip_fraction.detach(),
+    }
+    return loss, metrics
+
+
+# --------------------------------------------------------------------------------------------
+# t5  the reasoning learner's micro-batch loss   rlinf/workers/actor/fsdp_actor_worker.py:476-508,694-790
+# --------------------------------------------------------------------------------------------
+def reasoning_micro_batch_loss(logits, responses, old_logprobs, advantages, loss_mask, *, temperature=1.0,
+                               loss_agg="token-mean", clip_ratio_low=0.2, clip_ratio_high=0.2, clip_ratio_c=3.0,
+                               clip_log_ratio_min=None, clip_log_ratio_max=None, calculate_entropy=False,
+                               entropy_bonus=0.0, ref_logprobs=None, kl_beta=0.0, kl_penalty_type="low_var_kl",
+                               gradient_accumulation=1):
+    """logits [bsz, resp, V] are the response-aligned slice (``logits[:, -resp-1:-1]``); returns
+    (loss_for_backward, metrics) — the loss already divided by ``gradient_accumulation``."""
+    agg = get_loss_agg_func(loss_agg)
+    logits = logits / temperature  # the reference divides in place (fsdp_actor_worker.py:478)
+    logprobs = logprobs_from_logits(logits, responses)
+    entropy = entropy_from_logits(logits) if calculate_entropy else None
+    loss, metrics = token_actor_loss(
+        logprobs, old_logprobs, advantages, clip_ratio_low, clip_ratio_high, loss_mask=loss_mask,
+        clip_ratio_c=clip_ratio_c, loss_agg_func=agg, clip_log_ratio_min=clip_log_ratio_min,
+        clip_log_ratio_max=clip_log_ratio_max, fast_path_zero_loss_mask=True)
+    entropy_loss = torch.tensor(0.0)
+    if calculate_entropy:
+        entropy_loss = agg(entropy, mask=loss_mask)
+        if entropy_bonus != 0.0:  # calculate_entropy_loss (fsdp_actor_worker.py:134-137)
+            loss = loss - entropy_bonus * entropy_loss
+    kl_loss = torch.tensor(0.0)
+    if kl_beta > 0 and ref_logprobs is not None:
+        kld = kl_penalty(ref_logprobs, logprobs, kl_penalty_type)
+        kl_loss = agg(kld, loss_mask)
+        loss = loss + kl_loss * kl_beta
+    metrics.update({"actor/final_loss": loss.detach(), "actor/entropy_loss": entropy_loss.detach(),
+                    "actor/kl_loss": kl_loss.detach()})
+    return loss / gradient_accumulation, metrics, logprobs, entropy
+
+
+# --------------------------------------------------------------------------------------------
+# t6  reasoning advantage shaping        rlinf/algorithms/utils.py:177-277, advantages.py:89-121
+# --------------------------------------------------------------------------------------------
+def preprocess_reasoning(rewards, loss_mask, adv_type, values=None, group_size=None):
+    """-> dict(rewards, loss_mask [seq,bsz], dones [seq+1,bsz], values [seq+1,bsz] or absent)."""
+    bsz, seq = loss_mask.shape
+    out = {"loss_mask": loss_mask.transpose(0, 1)}
+    assert rewards.ndim == 1
+    if adv_type == "gae":
+        expanded = torch.zeros((seq, bsz), dtype=rewards.dtype)
+        expanded[-1] = rewards
+        out["rewards"] = expanded
+    elif adv_type == "grpo":
+        out["rewards"] = rewards.reshape(-1, group_size).contiguous()
+    else:
+        raise AssertionError(adv_type)
+    if values is not None:
+        v = values.transpose(0, 1)
+        out["values"] = torch.cat([v, torch.zeros((1, v.shape[-1]), dtype=v.dtype)], dim=0)
+    dones = torch.zeros(seq + 1, bsz, dtype=torch.bool)
+    dones[-1] = True
+    out["dones"] = dones
+    return out
+
+
+def grpo_reasoning_advantages(rewards, loss_mask, group_size: int):
+    """rewards [bsz], loss_mask [bsz, seq] -> advantages [bsz, seq] (pre + advantages.py:89-121 + post)."""
+    pre = preprocess_reasoning(rewards, loss_mask, "grpo", group_size=group_size)
+    grouped = pre["rewards"].view(-1, group_size)
+    mean = grouped.mean(dim=-1, keepdim=True).expand_as(grouped)
+    std = grouped.std(dim=-1, keepdim=True).expand_as(grouped)
+    adv = (grouped - mean) / (std + 1e-6)
+    adv = (torch.zeros_like(pre["loss_mask"]) + adv.view(1, -1)) * pre["loss_mask"]
+    return adv.transpose(0, 1).contiguous()

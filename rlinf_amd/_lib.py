@@ -99,6 +99,25 @@ PPO_OUT_NAMES = {
     "ev/returns_sq_sum": 13, "ev/errors_sum": 14, "ev/errors_sq_sum": 15,
 }
 
+
+class TokenRows(Structure):  # include/rlx.h: rlx_token_rows
+    _fields_ = [("n_tokens", c_int64), ("vocab", c_int32), ("dtype", c_int32), ("rows_per_seq", c_int64),
+                ("seq_stride", c_int64), ("row_stride", c_int64), ("temperature", c_float), ("round_outputs", c_int32)]
+
+
+class TokenLossParams(Structure):  # include/rlx.h: rlx_token_loss_params
+    _fields_ = [("ppo", PpoLossParams), ("loss_agg", c_int32), ("fast_path_zero_loss_mask", c_int32),
+                ("kl_type", c_int32), ("kl_beta", c_float), ("use_entropy", c_int32), ("entropy_bonus", c_float)]
+
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+LOSS_AGG = {"token-mean": 0, "seq-mean-token-sum": 1, "seq-mean-token-mean": 2}
+KL_TYPE = {None: 0, "kl": 1, "k1": 1, "abs": 2, "mse": 3, "k2": 3, "low_var_kl": 4, "k3": 4}
+TOK_OUT_FLOATS = 16
+TOK_OUT_NAMES = {"loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, "actor/ratio": 3, "actor/ratio_abs": 4,
+                 "actor/clipped_ratio": 5, "actor/dual_cliped_ratio": 6, "actor/approx_kl": 7, "actor/clip_fraction": 8,
+                 "actor/entropy_loss": 9, "actor/kl_loss": 10, "actor/token_num": 11, "policy_on": 12}
+
 # name -> (restype, argtypes); kept in one table so tests can check it against include/rlx.h
 PROTOTYPES = {
     "rlx_version": (c_int, []),
@@ -144,6 +163,15 @@ PROTOTYPES = {
     "rlx_ppo_step_slabs": (c_int, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step": (c_int, [POINTER(PpoStepArgs), c_void_p]),
+    "rlx_token_logprob_fwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rlx_token_logprob_bwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_int64, c_int64, c_void_p]),
+    "rlx_token_loss_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "rlx_token_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                   POINTER(TokenLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    "rlx_token_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ from typing import Optional
 
 import torch
 
-from .. import ops
+from .. import ops, token_ops
 from . import utils as _u
 from .registry import _mark_native_adv, register_advantage
 
@@ -82,5 +82,16 @@ def _native_grpo(*, rewards, dones, loss_mask=None, group_size=8, reward_type="a
     return {"advantages": _u.unstage(adv, rewards)}
 
 
+def _native_grpo_reasoning(*, rewards, loss_mask, group_size, **kwargs):
+    """Reasoning GRPO: rewards [bsz], loss_mask [bsz, seq] -> (advantages [bsz, seq], None); replaces
+    preprocess_reasoning_advantages_inputs + compute_grpo_advantages + postprocess (utils.py:177-277)."""
+    if rewards.ndim != 1:
+        raise AssertionError(f"Unsupported reward shape {rewards.shape}")
+    dev = _u.compute_device(rewards, loss_mask)
+    adv = token_ops.grpo_seq_adv(_u.stage(rewards, dev).float(), _u.stage(loss_mask, dev), int(group_size))
+    return _u.unstage(adv, loss_mask), None
+
+
 _mark_native_adv("gae", _native_gae)
 _mark_native_adv("grpo", _native_grpo)
+_mark_native_adv("grpo", _native_grpo_reasoning, task_type="reasoning")

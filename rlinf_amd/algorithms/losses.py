@@ -15,8 +15,8 @@ from typing import Optional
 
 import torch
 
-from .. import ops
-from .._lib import PPO_OUT_NAMES
+from .. import ops, token_ops
+from .._lib import PPO_OUT_NAMES, TOK_OUT_NAMES
 from . import utils as _u
 from .registry import _mark_native_loss, register_policy_loss
 
@@ -95,6 +95,96 @@ def _fused(kw: dict, has_critic: bool):
     return loss, LossMetrics(out, has_critic)
 
 
+# ---- reasoning (token) tier ---------------------------------------------------------------------------------
+_TOKEN_KEYS = _ACTOR_KEYS
+# the reference's zero-loss-mask fast path returns a different key set (losses.py:206-219)
+_TOKEN_KEYS_ZERO = ("actor/token_num", "actor/policy_loss", "actor/policy_loss_mbs_mean", "actor/policy_loss_abs",
+                    "actor/ratio", "actor/clipped_ratio", "actor/dual_cliped_ratio", "actor/approx_kl",
+                    "actor/clip_fraction")
+_TOKEN_FUSED_KEYS = ("actor/final_loss", "actor/entropy_loss", "actor/kl_loss")
+
+
+class TokenLossMetrics(Mapping):
+    """Metrics of the fused token loss over the kernel's f32[16] output; one D2H copy on first read.  The key set
+    follows the reference: the fast-path keys when the first sequence's mask was empty, the usual eight otherwise,
+    plus final/entropy/kl when those terms were fused in."""
+
+    def __init__(self, out: torch.Tensor, fused_terms: bool):
+        self.device_vector = out
+        self._fused = fused_terms
+        self._host = None
+        self._extra = {}
+
+    def _load(self):
+        if self._host is None:
+            self._host = self.device_vector.tolist()
+        return self._host
+
+    def _kernel_keys(self):
+        on = self._load()[TOK_OUT_NAMES["policy_on"]] != 0.0
+        return (_TOKEN_KEYS if on else _TOKEN_KEYS_ZERO) + (_TOKEN_FUSED_KEYS if self._fused else ())
+
+    def __getitem__(self, key):
+        if key in self._extra:
+            return self._extra[key]
+        if key not in self._kernel_keys():
+            raise KeyError(key)
+        host = self._load()
+        if key == "actor/final_loss":
+            return host[TOK_OUT_NAMES["loss"]]
+        if host[TOK_OUT_NAMES["policy_on"]] == 0.0 and key not in _TOKEN_FUSED_KEYS:
+            return 0.0
+        return host[TOK_OUT_NAMES[key]]
+
+    def __setitem__(self, key, value):
+        self._extra[key] = value
+
+    def update(self, other):  # the learner adds actor/final_loss etc. (fsdp_actor_worker.py:773-779)
+        self._extra.update(other)
+
+    def __iter__(self):
+        for k in self._kernel_keys():
+            if k not in self._extra:
+                yield k
+        yield from self._extra
+
+    def __len__(self):
+        return len(set(self._kernel_keys()) | set(self._extra))
+
+
+def _token_fused(kw: dict):
+    """compute_ppo_actor_loss on [bsz, seq] token tensors with a caller-chosen aggregation (losses.py:170-312), plus --
+    when the caller hands them over -- the entropy bonus and KL penalty the reasoning learner adds right after
+    (fsdp_actor_worker.py:750-766)."""
+    agg = kw.get("loss_agg_func")
+    agg_name = kw.get("loss_agg") or getattr(agg, "rlx_agg", None) or ("token-mean" if agg is None else None)
+    if agg_name is None:
+        raise NotImplementedError("policy_loss(task_type='reasoning'): loss_agg_func must come from "
+                                  "rlinf_amd.utils.utils.get_loss_agg_func (or pass loss_agg='token-mean'|...)")
+    if kw.get("max_episode_steps") is not None and kw.get("loss_mask_sum") is not None:
+        raise NotImplementedError("masked_mean_ratio is an embodied aggregation; not used by the token path")
+    logprobs = kw["logprobs"]
+    dev = _u.compute_device(logprobs)
+    st = lambda name: _u.stage(kw.get(name), dev)  # noqa: E731
+    entropy, ref = st("entropy"), st("ref_logprobs")
+    kl_beta = float(kw.get("kl_beta") or 0.0)
+    fused_terms = entropy is not None or (ref is not None and kl_beta > 0)
+    params = token_ops.make_token_loss_params(
+        loss_agg=agg_name, clip_ratio_low=kw["clip_ratio_low"], clip_ratio_high=kw["clip_ratio_high"],
+        clip_ratio_c=kw.get("clip_ratio_c"), clip_log_ratio_min=kw.get("clip_log_ratio_min"),
+        clip_log_ratio_max=kw.get("clip_log_ratio_max"), critic_warmup=bool(kw.get("critic_warmup", False)),
+        fast_path_zero_loss_mask=bool(kw.get("fast_path_zero_loss_mask", False)),
+        kl_penalty_type=kw.get("kl_penalty_type", "low_var_kl") if ref is not None and kl_beta > 0 else None,
+        kl_beta=kl_beta if ref is not None else 0.0, use_entropy=entropy is not None,
+        entropy_bonus=float(kw.get("entropy_bonus") or 0.0))
+    lp = _u.stage(logprobs, dev)
+    shape2d = lp.shape if lp.dim() == 2 else (1, lp.numel())
+    as2d = lambda t: None if t is None else t.reshape(shape2d)  # noqa: E731
+    loss, out = token_ops.token_loss(as2d(lp), as2d(st("old_logprobs")), as2d(st("advantages")), as2d(st("loss_mask")),
+                                     params, entropy=as2d(entropy), ref_logprobs=as2d(ref))
+    return loss, TokenLossMetrics(out, fused_terms)
+
+
 @register_policy_loss("actor_critic")
 def compute_ppo_actor_critic_loss(**kwargs) -> tuple[torch.Tensor, Mapping]:
     """PPO clipped surrogate + clipped-Huber value loss (losses.py:397-425) on RAW per-dimension inputs."""
@@ -103,7 +193,10 @@ def compute_ppo_actor_critic_loss(**kwargs) -> tuple[torch.Tensor, Mapping]:
 
 @register_policy_loss("actor")
 def compute_grpo_actor_loss_fn(**kwargs) -> tuple[torch.Tensor, Mapping]:
-    """Actor-only clipped surrogate used by GRPO (losses.py:513-535)."""
+    """Actor-only clipped surrogate used by GRPO (losses.py:513-535): the embodied per-dimension kernel, or the
+    token kernel for reasoning batches."""
+    if kwargs.get("task_type", "embodied") != "embodied" or kwargs.get("single_action_dim") is None:
+        return _token_fused(kwargs)
     return _fused(kwargs, has_critic=False)
 
 

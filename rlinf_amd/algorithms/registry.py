@@ -22,6 +22,7 @@ ADV_REGISTRY: dict[str, Callable] = {}
 LOSS_REGISTRY: dict[str, Callable] = {}
 # names whose registered callee is one of ours -> the native [n,B,C] fast path may be used
 _NATIVE_ADV: dict[str, Callable] = {}
+_NATIVE_ADV_REASONING: dict[str, Callable] = {}
 _NATIVE_LOSS: dict[str, Callable] = {}
 
 
@@ -35,6 +36,7 @@ def register_advantage(name: str):
 
         ADV_REGISTRY[name.lower()] = wrapper
         _NATIVE_ADV.pop(name.lower(), None)
+        _NATIVE_ADV_REASONING.pop(name.lower(), None)
         return wrapper
 
     return decorator
@@ -65,8 +67,8 @@ def get_policy_loss(name: str):
     return LOSS_REGISTRY[name]
 
 
-def _mark_native_adv(name: str, native: Callable):
-    _NATIVE_ADV[name] = native
+def _mark_native_adv(name: str, native: Callable, task_type: str = "embodied"):
+    (_NATIVE_ADV if task_type == "embodied" else _NATIVE_ADV_REASONING)[name] = native
 
 
 def _mark_native_loss(name: str, native: Callable):
@@ -109,6 +111,9 @@ def calculate_adv_and_returns(**kwargs):
             kwargs = _u.calculate_scores(**kwargs)
         advantages, returns = fn(**kwargs)
         return _u.postprocess_embodied_advantages_outputs(advantages=advantages, returns=returns, **kwargs)
+    native = _NATIVE_ADV_REASONING.get(adv_type.lower())
+    if native is not None:
+        return native(**kwargs)  # reads the [bsz, seq] layout directly: no transposes, no copies
     kwargs = _u.preprocess_reasoning_advantages_inputs(**kwargs)
     advantages, returns = fn(**kwargs)
     return _u.postprocess_reasoning_advantages_outputs(advantages, returns)

@@ -78,13 +78,66 @@ def postprocess_embodied_advantages_outputs(advantages, num_chunk, chunk_size, r
     return res
 
 
-def preprocess_reasoning_advantages_inputs(**kwargs):
-    raise NotImplementedError("the reasoning (LLM) advantage branch is the next tier (SURVEY.md 8f item 1); "
-                              "only task_type='embodied' is served in this round")
+def preprocess_reasoning_advantages_inputs(rewards, loss_mask, values=None, logprob=None, ref_logprob=None, **kwargs):
+    """Reasoning -> time-major shaping for registered advantage callees (utils.py:177-262).  Views only, except
+    the reward row the GAE branch has to materialise; the built-in "grpo" never comes here (its kernel reads the
+    [bsz, seq] layout directly)."""
+    bsz, seq_len = loss_mask.shape
+    if rewards.ndim != 1:
+        raise AssertionError(f"Unsupported reward shape {rewards.shape}")
+    adv_type = kwargs["adv_type"]
+    if adv_type == "gae":
+        last_token = rewards.new_zeros((seq_len, bsz))
+        last_token[-1] = rewards  # the scalar reward sits on the final token
+        shaped = last_token
+    elif adv_type == "grpo":
+        shaped = rewards.reshape(-1, kwargs["group_size"]).contiguous()
+    elif adv_type == "grpo_dynamic":
+        shaped = rewards.reshape(-1, kwargs["num_sequence"]).transpose(0, 1).contiguous()
+    elif adv_type == "reinpp":
+        shaped = rewards.unsqueeze(0)
+    elif adv_type == "raw":
+        shaped = rewards
+    else:
+        raise AssertionError(f"Unsupported adv_type {adv_type}")
+    kwargs["rewards"] = shaped
+    if values is not None:
+        if values.ndim != 2:
+            raise AssertionError(f"Unsupported values shape {values.shape}")
+        vt = values.transpose(0, 1)
+        kwargs["values"] = torch.cat([vt, vt.new_zeros((1, bsz))], dim=0)  # zero bootstrap row
+    if logprob is not None:
+        kwargs["logprob"] = logprob.transpose(0, 1)
+    if ref_logprob is not None:
+        kwargs["ref_logprob"] = ref_logprob.transpose(0, 1)
+    dones = torch.zeros(seq_len + 1, bsz, dtype=torch.bool, device=rewards.device)
+    dones[-1] = True  # one episode per sequence, ending after its last token
+    kwargs["dones"] = dones
+    kwargs["loss_mask"] = loss_mask.transpose(0, 1)
+    return kwargs
 
 
 def postprocess_reasoning_advantages_outputs(advantages, returns=None):
-    raise NotImplementedError("the reasoning (LLM) advantage branch is the next tier (SURVEY.md 8f item 1)")
+    """Back to [bsz, seq], contiguous (utils.py:265-277)."""
+    advantages = advantages.transpose(0, 1).contiguous()
+    if returns is not None:
+        returns = returns.transpose(0, 1).contiguous()
+    return advantages, returns
+
+
+def kl_penalty(logprob: torch.Tensor, ref_logprob: torch.Tensor, kl_penalty: str) -> torch.Tensor:
+    """Per-token KL estimators (utils.py:26-64) for callers outside the fused token loss, which has them built in."""
+    diff = logprob - ref_logprob
+    if kl_penalty in ("kl", "k1"):
+        return diff
+    if kl_penalty == "abs":
+        return diff.abs()
+    if kl_penalty in ("mse", "k2"):
+        return 0.5 * diff.square()
+    if kl_penalty in ("low_var_kl", "k3"):
+        neg = torch.clamp(ref_logprob - logprob, min=-20, max=20)
+        return torch.clamp((torch.exp(neg) - neg - 1).contiguous(), min=-10, max=10)
+    raise NotImplementedError
 
 
 # ---- loss-input shaping for user-registered loss callees (utils.py:280-376) ------------------------------

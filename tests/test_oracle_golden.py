@@ -110,3 +110,37 @@ def test_shuffle_golden():
         _eq(out[k], G["out"][k])
     for k in ("states", "action"):
         _eq(out["forward_inputs"][k], G["out"]["forward_inputs"][k])
+
+
+def test_token_path_golden():
+    """oracle/token_oracle.py against the reference's outputs for the reasoning micro-batch (t1-t6)."""
+    from oracle import token_oracle as TO
+    from oracle.make_golden import token_batch
+
+    for case in _load("token_path.pt"):
+        p = case["params"]
+        b = token_batch(p["seed"], p["bsz"], p["seq"], p["vocab"], zero_first=p["zero_first"])
+        for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            want = case["out"][tag]
+            logits = b["logits"].to(dt).clone().requires_grad_(True)
+            loss, metrics, logprobs, entropy = TO.reasoning_micro_batch_loss(
+                logits, b["labels"], b["old_logprobs"], b["advantages"], b["loss_mask"], temperature=p["temperature"],
+                loss_agg=p["loss_agg"], clip_ratio_low=p["clip_ratio_low"], clip_ratio_high=p["clip_ratio_high"],
+                clip_ratio_c=p["clip_ratio_c"], clip_log_ratio_min=p["clip_log_ratio_min"],
+                clip_log_ratio_max=p["clip_log_ratio_max"], calculate_entropy=True, entropy_bonus=p["entropy_bonus"],
+                ref_logprobs=b["ref_logprobs"], kl_beta=p["kl_beta"], kl_penalty_type=p["kl_penalty_type"],
+                gradient_accumulation=p["gradient_accumulation"])
+            loss.backward()
+            _eq(logprobs.detach(), want["logprobs"])
+            _eq(entropy.detach(), want["entropy"])
+            _eq(metrics["actor/final_loss"], want["final_loss"])
+            _eq(metrics["actor/entropy_loss"], want["entropy_loss"])
+            _eq(metrics["actor/kl_loss"], want["kl_loss"])
+            _eq(logits.grad, want["d_logits"])
+            assert set(k for k in metrics if k not in ("actor/final_loss", "actor/entropy_loss", "actor/kl_loss")) == \
+                set(want["metrics"])
+            for k, v in want["metrics"].items():
+                _eq(metrics[k], v)
+        _eq(TO.grpo_reasoning_advantages(b["rewards"], b["loss_mask"], p["group_size"]), case["grpo_advantages"])
+        for k, v in case["kl_terms"].items():
+            _eq(TO.kl_penalty(b["ref_logprobs"], b["old_logprobs"], k), v)

@@ -253,3 +253,64 @@ def test_flatten_and_shuffle(ref):
     for i in range(4):
         _eq(w[i]["forward_inputs"]["states"], o[i]["forward_inputs"]["states"])
         _eq(w[i]["rewards"], o[i]["rewards"])
+
+
+# ---- token tier (oracle/token_oracle.py) -----------------------------------------------------------------
+from oracle import token_oracle as TO  # noqa: E402
+from oracle.make_golden import token_batch  # noqa: E402
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("vocab", [7, 517, 4096])
+def test_token_logprob_entropy(ref, dtype, vocab):
+    b = token_batch(101, 4, 6, vocab)
+    x = b["logits"].to(dtype)
+    _eq(ref.utils.compute_logprobs_from_logits(x, b["labels"]), TO.logprobs_from_logits(x, b["labels"]))
+    _eq(ref.utils.compute_entropy_from_logits(x), TO.entropy_from_logits(x))
+
+
+@pytest.mark.parametrize("kind", ["kl", "k1", "abs", "mse", "k2", "low_var_kl", "k3"])
+def test_token_kl_penalty(ref, kind):
+    b = token_batch(102, 4, 16, 11)
+    a, c = b["ref_logprobs"] * 9, b["old_logprobs"]  # wide enough to hit both clamps of k3
+    _eq(ref.algo_utils.kl_penalty(a, c, kind), TO.kl_penalty(a, c, kind))
+
+
+@pytest.mark.parametrize("agg", ["token-mean", "seq-mean-token-sum", "seq-mean-token-mean"])
+@pytest.mark.parametrize("zero_first", [False, True])
+@pytest.mark.parametrize("clip_c", [None, 3.0])
+def test_token_actor_loss(ref, agg, zero_first, clip_c):
+    b = token_batch(103, 8, 10, 13, zero_first=zero_first)
+    lp0 = b["old_logprobs"] + 0.4 * torch.randn(8, 10, generator=torch.Generator().manual_seed(5))
+    outs = []
+    for mod, fn, aggs in ((ref, ref.losses.compute_ppo_actor_loss, ref.utils.get_loss_agg_func),
+                          (TO, TO.token_actor_loss, TO.get_loss_agg_func)):
+        lp = lp0.clone().requires_grad_(True)
+        loss, metrics = fn(logprobs=lp, old_logprobs=b["old_logprobs"], advantages=b["advantages"], clip_ratio_low=0.2,
+                           clip_ratio_high=0.28, loss_mask=b["loss_mask"], clip_ratio_c=clip_c,
+                           loss_agg_func=aggs(agg), fast_path_zero_loss_mask=True, clip_log_ratio_max=0.5)
+        g = torch.autograd.grad(loss, lp)[0] if loss.requires_grad else None
+        outs.append((loss.detach(), metrics, g))
+    (l0, m0, g0), (l1, m1, g1) = outs
+    _eq(l0, l1)
+    assert set(m0) == set(m1)
+    for k in m0:
+        _eq(m0[k], m1[k])
+    assert (g0 is None) == (g1 is None)
+    if g0 is not None:
+        _eq(g0, g1)
+
+
+def test_token_reasoning_shaping(ref):
+    b = token_batch(104, 8, 10, 5)
+    values = torch.randn(8, 10)
+    for adv_type in ("gae", "grpo"):
+        want = ref.algo_utils.preprocess_reasoning_advantages_inputs(
+            rewards=b["rewards"], loss_mask=b["loss_mask"], values=values, adv_type=adv_type, group_size=4)
+        got = TO.preprocess_reasoning(b["rewards"], b["loss_mask"], adv_type, values=values, group_size=4)
+        for k in ("rewards", "loss_mask", "dones", "values"):
+            _eq(want[k], got[k])
+    want = ref.registry.calculate_adv_and_returns(task_type="reasoning", adv_type="grpo", rewards=b["rewards"],
+                                                  loss_mask=b["loss_mask"], group_size=4)
+    _eq(want[0], TO.grpo_reasoning_advantages(b["rewards"], b["loss_mask"], 4))
+    assert want[1] is None

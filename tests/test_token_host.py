@@ -1,0 +1,120 @@
+"""Host-side logic of the token tier (no GPU): the mirrors of rlinf/utils/utils.py and rlinf/algorithms/utils.py
+against the CPU oracle, the registry's reasoning dispatch, the learner-step config mapping, loud failure without HIP."""
+
+import pytest
+import torch
+
+from oracle import token_oracle as TO
+from oracle.make_golden import token_batch
+from rlinf_amd import _lib
+from rlinf_amd.algorithms import registry
+from rlinf_amd.algorithms import utils as AU
+from rlinf_amd.utils import utils as UU
+from rlinf_amd.workers.actor.fsdp_actor_worker import TokenLearnerStep
+
+
+@pytest.mark.parametrize("agg", ["token-mean", "seq-mean-token-sum", "seq-mean-token-mean"])
+def test_agg_funcs_match_oracle_and_are_tagged(agg):
+    b = token_batch(201, 6, 9, 5)
+    v = b["advantages"]
+    fn = UU.get_loss_agg_func(agg)
+    assert fn.rlx_agg == agg
+    assert torch.equal(fn(v, b["loss_mask"]), TO.get_loss_agg_func(agg)(v, b["loss_mask"]))
+    with pytest.raises(ValueError, match="Unsupported loss aggregation"):
+        UU.get_loss_agg_func("mean")
+
+
+def test_masked_mean_all_false_is_the_plain_sum():
+    v = torch.randn(3, 4)
+    m = torch.zeros(3, 4, dtype=torch.bool)
+    assert float(UU.masked_mean(v, m)) == 0.0
+    assert torch.equal(UU.masked_mean(v, None), v.mean())
+    assert torch.equal(UU.masked_sum(v, ~m), v.sum())
+
+
+@pytest.mark.parametrize("kind", ["kl", "k1", "abs", "mse", "k2", "low_var_kl", "k3"])
+def test_kl_penalty_mirror(kind):
+    b = token_batch(202, 4, 16, 5)
+    a, c = b["ref_logprobs"] * 9, b["old_logprobs"]
+    assert torch.equal(AU.kl_penalty(a, c, kind), TO.kl_penalty(a, c, kind))
+    with pytest.raises(NotImplementedError):
+        AU.kl_penalty(a, c, "full")
+
+
+def test_reasoning_shaping_mirror():
+    b = token_batch(203, 8, 10, 5)
+    values = torch.randn(8, 10)
+    for adv_type in ("gae", "grpo"):
+        got = AU.preprocess_reasoning_advantages_inputs(rewards=b["rewards"], loss_mask=b["loss_mask"], values=values,
+                                                        adv_type=adv_type, group_size=4)
+        want = TO.preprocess_reasoning(b["rewards"], b["loss_mask"], adv_type, values=values, group_size=4)
+        for k in ("rewards", "loss_mask", "dones", "values"):
+            assert torch.equal(got[k], want[k]), (adv_type, k)
+        assert got["adv_type"] == adv_type
+    adv, ret = AU.postprocess_reasoning_advantages_outputs(torch.arange(6.).reshape(3, 2), torch.ones(3, 2))
+    assert adv.shape == (2, 3) and adv.is_contiguous() and ret.is_contiguous()
+    with pytest.raises(AssertionError, match="Unsupported adv_type"):
+        AU.preprocess_reasoning_advantages_inputs(rewards=b["rewards"], loss_mask=b["loss_mask"], adv_type="nope")
+    with pytest.raises(AssertionError, match="Unsupported reward shape"):
+        AU.preprocess_reasoning_advantages_inputs(rewards=b["rewards"][None], loss_mask=b["loss_mask"], adv_type="raw")
+
+
+def test_user_registered_reasoning_advantage_gets_reference_shapes():
+    seen = {}
+    b = token_batch(204, 8, 10, 5)
+    registry.register_advantage("probe_reasoning")(lambda **kw: (None, None))
+    with pytest.raises(AssertionError, match="Unsupported adv_type"):  # the reference's assert (utils.py:222)
+        registry.calculate_adv_and_returns(task_type="reasoning", adv_type="probe_reasoning", rewards=b["rewards"],
+                                           loss_mask=b["loss_mask"])
+    registry.ADV_REGISTRY.pop("probe_reasoning")
+
+    @registry.register_advantage("raw")
+    def raw(rewards, loss_mask, dones, **kw):
+        seen.update(rewards=rewards.shape, loss_mask=loss_mask.shape, dones=dones.shape)
+        return torch.zeros(loss_mask.shape), None
+
+    adv, ret = registry.calculate_adv_and_returns(task_type="reasoning", adv_type="raw", rewards=b["rewards"],
+                                                  loss_mask=b["loss_mask"])
+    registry.ADV_REGISTRY.pop("raw")
+    assert seen == dict(rewards=(8,), loss_mask=(10, 8), dones=(11, 8))
+    assert adv.shape == (8, 10) and ret is None
+
+
+def test_learner_step_from_cfg():
+    cfg = {"algorithm": {"ratio_clip_eps": 0.2, "clip_ratio_high": 0.28, "loss_agg_func": "seq-mean-token-mean",
+                         "calculate_entropy": True, "entropy_bonus": 0.01, "kl_beta": 0.05, "kl_penalty_type": "k2",
+                         "sampling_params": {"temperature": 0.6}},
+           "actor": {"model": {"encoder_seq_length": 3072}}, "data": {"max_prompt_length": 1024},
+           "runner": {"task_type": "reasoning"}}
+    s = TokenLearnerStep.from_cfg(cfg)
+    assert (s.response_len, s.clip_ratio_low, s.clip_ratio_high, s.clip_ratio_c) == (2048, 0.2, 0.28, 3.0)
+    assert (s.loss_agg, s.temperature, s.kl_penalty_type, s.calculate_entropy) == ("seq-mean-token-mean", 0.6, "k2", True)
+
+
+def test_token_param_validation():
+    from rlinf_amd import token_ops
+    with pytest.raises(ValueError, match="Unsupported loss aggregation"):
+        token_ops.make_token_loss_params(loss_agg="mean", clip_ratio_low=0.2, clip_ratio_high=0.2)
+    with pytest.raises(AssertionError, match="clip_ratio_c"):
+        token_ops.make_token_loss_params(loss_agg="token-mean", clip_ratio_low=0.2, clip_ratio_high=0.2, clip_ratio_c=1.0)
+    with pytest.raises(NotImplementedError):
+        token_ops.make_token_loss_params(loss_agg="token-mean", clip_ratio_low=0.2, clip_ratio_high=0.2,
+                                         kl_penalty_type="full", kl_beta=0.1)
+    p = token_ops.make_token_loss_params(loss_agg="token-mean", clip_ratio_low=0.2, clip_ratio_high=0.28, clip_ratio_c=3.0,
+                                         kl_penalty_type="low_var_kl", kl_beta=0.1, use_entropy=True, entropy_bonus=0.01)
+    assert (p.loss_agg, p.kl_type, p.ppo.use_dual_clip, p.use_entropy) == (0, 4, 1, 1)
+    assert abs(p.ppo.ratio_hi - 1.28) < 1e-6
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_token_ops_fail_loudly_without_hip():
+    b = token_batch(205, 4, 6, 33)
+    with pytest.raises(_lib.RlxError, match="no CPU fallback|HIP"):
+        UU.compute_logprobs_from_logits(b["logits"], b["labels"])
+    with pytest.raises(_lib.RlxError):
+        registry.calculate_adv_and_returns(task_type="reasoning", adv_type="grpo", rewards=b["rewards"],
+                                           loss_mask=b["loss_mask"], group_size=4)
+    with pytest.raises(_lib.RlxError):
+        registry.policy_loss(task_type="reasoning", loss_type="actor", loss_agg_func=UU.masked_mean,
+                             logprobs=b["old_logprobs"], old_logprobs=b["old_logprobs"], advantages=b["advantages"],
+                             clip_ratio_low=0.2, clip_ratio_high=0.2, loss_mask=b["loss_mask"])
