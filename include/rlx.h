@@ -514,6 +514,22 @@ int rlx_token_loss_bwd(const float* g_logp, const float* g_entropy, const float*
 int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, float* advantages, int64_t bsz, int64_t seq,
                      int group_size, float eps, rlx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * t4  categorical_sample (K2)  <- OpenVLA-OFT's discrete action head: _discrete_prediction's sampling branch and
+ *       _compute_logprobs_and_entropy, rlinf/models/embodiment/openvla_oft/official/openvla_oft_action_model.py:258-287,363-414
+ *   logits   n rows of K <= 1024 action-bin logits (the n_action_bins window of the vocabulary; rows addressed like t1,
+ *            so the window is read in place out of the model's [B, seq, V] output)
+ *   noise    [n, K] dense, same dtype: the Exp(1) draw q of torch.multinomial(num_samples=1), which returns
+ *            argmax(softmax(x) / q); NULL = do_sample False (argmax of the raw logits, no temperature / top-k)
+ *   x = logits / temperature (in the tensor's dtype), then transformers' TopKLogitsWarper (scores below the k-th
+ *   largest -> -inf; top_k <= 0 or >= K disables it)
+ *   tokens   [n] i64 bin index in [0, K);  logprob [n] f32 = log softmax(x)[token] (optional; rounded to the dtype when
+ *            rows->round_outputs);  actions [n] f32 = bin_centers[clamp(K - token - 1, 0, n_centers - 1)] (optional)
+ * ------------------------------------------------------------------------------------------ */
+int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k,
+                           const float* bin_centers, int n_centers, int64_t* tokens, float* logprob, float* actions,
+                           rlx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

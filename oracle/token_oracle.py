@@ -204,3 +204,34 @@ def grpo_reasoning_advantages(rewards, loss_mask, group_size: int):
     adv = (grouped - mean) / (std + 1e-6)
     adv = (torch.zeros_like(pre["loss_mask"]) + adv.view(1, -1)) * pre["loss_mask"]
     return adv.transpose(0, 1).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# t7  categorical action sampling (K2)   rlinf/models/embodiment/openvla_oft/official/openvla_oft_action_model.py:363-414
+#     (_discrete_prediction's sampling branch + _compute_logprobs_and_entropy :258-287)
+# --------------------------------------------------------------------------------------------
+def categorical_sample(action_logits, noise=None, temperature=1.0, top_k=-1, bin_centers=None):
+    """action_logits [..., K] (the n_action_bins window of the vocabulary) -> (tokens, logprobs, processed logits,
+    normalized actions or None).  ``noise`` is the Exp(1) draw torch.multinomial makes internally: for num_samples=1 it
+    returns argmax(probs / q) with q = empty_like(probs).exponential_(1) (verified against torch.multinomial with the
+    same generator state in tests/test_oracle_vs_reference.py), so passing q in makes the choice a pure function.
+    ``noise=None`` is do_sample=False (argmax of the raw logits)."""
+    if noise is None:
+        tokens = action_logits.argmax(dim=-1)
+        processed = action_logits
+    else:
+        assert temperature > 0
+        processed = action_logits / temperature
+        k = min(top_k, processed.size(-1))
+        if k > 0:  # transformers.TopKLogitsWarper: everything below the k-th largest score becomes -inf
+            kth = torch.topk(processed, k)[0][..., -1, None]
+            processed = processed.masked_fill(processed < kth, float("-inf"))
+        probs = torch.softmax(processed, dim=-1)
+        tokens = (probs / noise).argmax(dim=-1)
+    logprobs = logprobs_from_logits(processed, tokens)
+    actions = None
+    if bin_centers is not None:  # :397-403: token -> bin index counted from the end of the vocabulary
+        nbins = action_logits.shape[-1]
+        disc = torch.clamp(nbins - tokens - 1, min=0, max=bin_centers.shape[0] - 1)
+        actions = bin_centers[disc]
+    return tokens, logprobs, processed, actions

@@ -171,6 +171,8 @@ PROTOTYPES = {
                                    POINTER(TokenLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
     "rlx_token_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "rlx_categorical_sample": (c_int, [c_void_p, POINTER(TokenRows), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
 }
 

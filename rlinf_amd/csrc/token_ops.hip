@@ -531,6 +531,142 @@ __global__ __launch_bounds__(256) void grpo_seq_adv_kernel(const float* __restri
         adv[b * S + j] = fmul(a, m[b * S + j] ? 1.f : 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// categorical action sampling (K2): one wave per row of K <= 64*EPL action-bin logits
+// ---------------------------------------------------------------------------------------------------------
+struct CatArgs {
+    const void* logits;
+    const void* noise;  // Exp(1) draws, same dtype and [n, K] dense layout; NULL = argmax (do_sample False)
+    RowGeom g;
+    int top_k;
+    const float* bin_centers;
+    int n_centers;
+    long long* tokens;
+    float* logprob;
+    float* actions;
+};
+
+__device__ __forceinline__ uint32_t order_key(float f) {  // monotone float -> uint (NaN-free inputs)
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, RLX_WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, RLX_WAVE));
+    return v;
+}
+
+template <typename T, int EPL, bool SCALE>
+__global__ __launch_bounds__(256) void categorical_sample_kernel(CatArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.g.n_tokens) return;
+    const int K = a.g.vocab;
+    const T* base = static_cast<const T*>(a.logits) + row_offset(a.g, row, a.g.seq_stride, a.g.row_stride);
+    const float NEG_INF = -__builtin_inff();
+    const bool sample = a.noise != nullptr;
+    float x[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int idx = lane + 64 * j;
+        const float raw = Elem<T>::load(base + (idx < K ? idx : 0));
+        x[j] = idx < K ? (sample ? prep<T, SCALE>(raw, a.g.temp, a.g.rtemp) : raw) : NEG_INF;
+    }
+    if (sample && a.top_k > 0 && a.top_k < K) {
+        // k-th largest score = the largest t with count(key >= t) >= k, built bit by bit
+        uint32_t key[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) key[j] = (lane + 64 * j) < K ? order_key(x[j]) : 0u;
+        uint32_t t = 0;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t cand = t | (1u << b);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) c += key[j] >= cand ? 1 : 0;
+            if (wave_sum_i(c) >= a.top_k) t = cand;
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (key[j] < t) x[j] = NEG_INF;  // TopKLogitsWarper: scores < kth -> -inf (ties with the k-th are kept)
+    }
+    float m = x[0];
+#pragma unroll
+    for (int j = 1; j < EPL; ++j) m = fmaxf(m, x[j]);
+    m = wave_max_f(m);
+    float e[EPL], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        e[j] = expf(x[j] - m);
+        s += e[j];
+    }
+    s = wave_sum(s);
+    // the race: argmax_v softmax(x)_v / q_v (torch.multinomial, num_samples = 1), or argmax_v x_v without sampling;
+    // the lowest index wins ties, as torch.argmax does
+    float best = NEG_INF;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx >= K) continue;
+        float score;
+        if (sample) {
+            const float p = Elem<T>::round(e[j] / s);  // softmax output in the tensor's dtype
+            const float q = Elem<T>::load(static_cast<const T*>(a.noise) + row * K + idx);
+            score = Elem<T>::round(p / q);
+        } else {
+            score = x[j];
+        }
+        if (score > best || (score == best && idx < bidx)) best = score, bidx = idx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, RLX_WAVE);
+        const int oi = __shfl_xor(bidx, off, RLX_WAVE);
+        if (ob > best || (ob == best && oi < bidx)) best = ob, bidx = oi;
+    }
+    // the owner of the winning element reports
+    if ((bidx & 63) == lane) {
+        float xt = NEG_INF;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if (bidx == lane + 64 * j) xt = x[j];
+        a.tokens[row] = bidx;
+        if (a.logprob) {
+            float lp = (xt - m) - logf(s);
+            if (a.g.round_outputs) lp = Elem<T>::round(lp);
+            a.logprob[row] = lp;
+        }
+        if (a.actions) {
+            int d = K - bidx - 1;
+            d = d < 0 ? 0 : (d > a.n_centers - 1 ? a.n_centers - 1 : d);
+            a.actions[row] = a.bin_centers[d];
+        }
+    }
+}
+
+template <typename T, int EPL>
+int launch_cat(const CatArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.g.n_tokens + 3) / 4)), block(256);
+    if (a.noise && a.g.temp != 1.0f)
+        hipLaunchKernelGGL((categorical_sample_kernel<T, EPL, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((categorical_sample_kernel<T, EPL, false>), grid, block, 0, s, a);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+template <typename T>
+int dispatch_cat(const CatArgs& a, hipStream_t s) {
+    const int K = a.g.vocab;
+    if (K <= 256) return launch_cat<T, 4>(a, s);
+    if (K <= 512) return launch_cat<T, 8>(a, s);
+    return launch_cat<T, 16>(a, s);
+}
+
 int check_rows(const rlx_token_rows* r, const char* who) {
     RLX_REQUIRE(r != nullptr, "%s: NULL rows", who);
     RLX_REQUIRE(r->n_tokens >= 0 && r->vocab >= 1, "%s: bad sizes", who);
@@ -681,4 +817,19 @@ extern "C" int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, 
                        rewards, loss_mask, advantages, (long long)seq, group_size, eps);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
+}
+
+extern "C" int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k,
+                                      const float* bin_centers, int n_centers, int64_t* tokens, float* logprob,
+                                      float* actions, rlx_stream_t stream) {
+    if (int rc = check_rows(rows, "rlx_categorical_sample")) return rc;
+    RLX_REQUIRE(rows->vocab <= 1024, "rlx_categorical_sample: at most 1024 categories per row (got %d)", rows->vocab);
+    if (rows->n_tokens == 0) return RLX_OK;
+    RLX_REQUIRE(logits && tokens, "rlx_categorical_sample: NULL argument");
+    RLX_REQUIRE(actions == nullptr || (bin_centers != nullptr && n_centers >= 1), "rlx_categorical_sample: actions need bin_centers");
+    CatArgs a;
+    a.logits = logits, a.noise = noise, a.g = geom_of(rows), a.top_k = top_k, a.bin_centers = bin_centers;
+    a.n_centers = n_centers, a.tokens = reinterpret_cast<long long*>(tokens), a.logprob = logprob, a.actions = actions;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return rows->dtype == RLX_DTYPE_BF16 ? dispatch_cat<__bf16>(a, s) : dispatch_cat<float>(a, s);
 }

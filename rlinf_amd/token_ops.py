@@ -219,3 +219,30 @@ def grpo_seq_adv(rewards: torch.Tensor, loss_mask: torch.Tensor, group_size: int
         _lib.check(_lib.load().rlx_grpo_seq_adv(r.data_ptr(), m.data_ptr(), adv.data_ptr(), bsz, seq, int(group_size),
                                                 float(eps), _stream_ptr(dev)), "rlx_grpo_seq_adv")
     return adv
+
+
+def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = None, *, temperature: float = 1.0,
+                       top_k: int = -1, bin_centers: Optional[torch.Tensor] = None, with_logprob: bool = True,
+                       round_outputs: bool = True):
+    """logits [..., K<=1024] (a view into the model's logits is fine) -> (tokens i64, logprobs f32 or None,
+    actions f32 or None), each of shape ``logits.shape[:-1]``.  ``noise``: Exp(1) draws of the logits' dtype and
+    shape (what torch.multinomial draws internally); None = argmax."""
+    dev = _dev(logits, noise, bin_centers)
+    lead = logits.shape[:-1]
+    x, rows = _rows_of(logits, temperature if noise is not None else 1.0, round_outputs)
+    if rows.vocab > 1024:
+        raise RlxError(f"categorical_sample handles up to 1024 categories per row (got {rows.vocab})")
+    if noise is not None:
+        if noise.dtype != logits.dtype or noise.shape != logits.shape:
+            raise RlxError("noise must match the logits in dtype and shape")
+        noise = noise.contiguous()
+    centers = _as_f32(bin_centers, "bin_centers")
+    tokens = torch.empty(lead, dtype=torch.int64, device=dev)
+    logprob = torch.empty(lead, dtype=torch.float32, device=dev) if with_logprob else None
+    actions = torch.empty(lead, dtype=torch.float32, device=dev) if centers is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rlx_categorical_sample(x.data_ptr(), byref(rows), _ptr(noise), int(top_k), _ptr(centers),
+                                                      0 if centers is None else centers.numel(), tokens.data_ptr(),
+                                                      _ptr(logprob), _ptr(actions), _stream_ptr(dev)),
+                   "rlx_categorical_sample")
+    return tokens, logprob, actions

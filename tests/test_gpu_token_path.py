@@ -331,3 +331,61 @@ def test_llm_vocab_properties(dtype):
     x2 = x.clone()
     token_ops.token_logprob_bwd(x2, labels, lse, None, dlp, None, out=x2)
     assert torch.equal(x2, d)
+
+
+# ---- K2: categorical action sampling ------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("K", [256, 100, 1000])
+@pytest.mark.parametrize("temperature,top_k", [(1.0, -1), (0.7, 50), (1.6, 1), (1.0, 5000)])
+def test_categorical_sample_vs_oracle(dtype, K, temperature, top_k):
+    g = torch.Generator().manual_seed(K)
+    B, A, V, pad = 6, 14, K + 200, 64
+    full = (torch.randn(B, A, V, generator=g) * 2).to(dtype)
+    window = full[..., V - pad - K:V - pad]
+    q = torch.empty(B, A, K, dtype=dtype).exponential_(1, generator=g)
+    centers = torch.linspace(-1, 1, K - 1)
+    wtok, wlp, processed, wact = TO.categorical_sample(window, q, temperature, top_k, bin_centers=centers)
+    dwin = full.to(DEV)[..., V - pad - K:V - pad]
+    tok, lp, act = token_ops.categorical_sample(dwin, q.to(DEV), temperature=temperature, top_k=top_k,
+                                                bin_centers=centers.to(DEV))
+    same = tok.cpu() == wtok
+    # a different exp / division rounding can only flip a choice between two candidates whose race scores tie to f32
+    # rounding; in bf16 the scores are rounded to 8 bits on both sides and the first-index tie rule decides
+    assert same.float().mean() >= 0.995, float(same.float().mean())
+    if dtype == torch.float32:
+        close(lp[same.to(DEV)], wlp[same], 2e-5, what="logprob")
+    else:
+        exact = TO.logprobs_from_logits(processed.float(), wtok).bfloat16().float()
+        assert ((lp.cpu() - exact).abs()[same] <= exact.abs()[same] * 2.0 ** -7 + 1e-6).all()
+    assert torch.equal(act.cpu()[same], wact[same])
+    # argmax mode: bit-exact including the first-index tie rule (bf16 logits tie often)
+    tok0, lp0, _ = token_ops.categorical_sample(dwin, None, temperature=temperature, top_k=top_k)
+    assert torch.equal(tok0.cpu(), window.argmax(-1))
+
+
+def test_categorical_sample_follows_the_distribution():
+    """10^5 draws from one 256-bin distribution: empirical frequencies within 5 sigma of softmax(x / T) under top-k."""
+    from rlinf_amd.models.embodiment.openvla_oft import DiscreteActionHead
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    head = DiscreteActionHead(n_action_bins=256, pad_to_multiple_of=64, action_dim=7, num_action_chunks=8)
+    row = torch.randn(32064, device=DEV, generator=g) * 1.5
+    n = 7 * 8 * 2000
+    logits = row.expand(2000, 56, 32064)
+    actions, tokens, logprobs = head.predict(logits, do_sample=True, temperature=0.8, top_k=40, generator=g)
+    assert actions.shape == (2000 * 8, 7) and tokens.shape == (2000, 56)
+    x = head.action_logits(row[None, None])[0, 0].cpu() / 0.8
+    kth = torch.topk(x, 40)[0][-1]
+    p = torch.softmax(x.masked_fill(x < kth, float("-inf")), -1)
+    freq = torch.bincount(tokens.reshape(-1).cpu(), minlength=256).float() / n
+    sigma = (p * (1 - p) / n).sqrt()
+    assert ((freq - p).abs() <= 5 * sigma + 1e-6).all()
+    assert (freq[p == 0] == 0).all()
+    close(logprobs.reshape(-1), torch.log(p)[tokens.reshape(-1).cpu()], 2e-5)
+    centers = head.bin_centers
+    assert torch.equal(actions.reshape(-1).cpu(), centers[(256 - tokens.reshape(-1).cpu() - 1).clamp(0, 254)])
+    # training-time recomputation over the same window is differentiable and agrees with the rollout log-probs
+    lg = logits[:4].clone().requires_grad_(True)
+    out = head.logprobs_and_entropy(lg, tokens[:4], compute_entropy=True, temperature=1.0)
+    out["logprobs"].sum().backward()
+    assert lg.grad is not None and float(lg.grad[..., :32064 - 64 - 256].abs().max()) == 0.0

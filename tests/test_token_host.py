@@ -118,3 +118,28 @@ def test_token_ops_fail_loudly_without_hip():
         registry.policy_loss(task_type="reasoning", loss_type="actor", loss_agg_func=UU.masked_mean,
                              logprobs=b["old_logprobs"], old_logprobs=b["old_logprobs"], advantages=b["advantages"],
                              clip_ratio_low=0.2, clip_ratio_high=0.2, loss_mask=b["loss_mask"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("temperature,top_k", [(1.0, -1), (0.7, 50), (1.6, 1), (1.0, 300)])
+def test_categorical_oracle_is_torch_multinomial(dtype, temperature, top_k):
+    """The K2 oracle against the very calls the reference makes (openvla_oft_action_model.py:379-392):
+    TopKLogitsWarper, softmax, torch.multinomial -- with the generator rewound, the injected Exp(1) noise reproduces
+    multinomial's choice exactly."""
+    from transformers import TopKLogitsWarper
+
+    g = torch.Generator().manual_seed(1)
+    logits = (torch.randn(16, 56, 256, generator=g) * 2).to(dtype)
+    x = logits / temperature
+    k = min(top_k, 256)
+    if k > 0:
+        x = TopKLogitsWarper(k)(None, x)
+    probs = torch.softmax(x, dim=-1)
+    flat = probs.reshape(-1, 256)
+    ids = torch.multinomial(flat, num_samples=1, replacement=True, generator=torch.Generator().manual_seed(7)).view(16, 56)
+    q = torch.empty_like(flat).exponential_(1, generator=torch.Generator().manual_seed(7)).view(16, 56, 256)
+    tok, lp, processed, _ = TO.categorical_sample(logits, q, temperature, top_k)
+    assert torch.equal(tok, ids) and torch.equal(processed, x)
+    assert torch.equal(lp, TO.logprobs_from_logits(x, ids))
+    tok0, lp0, _, act = TO.categorical_sample(logits, None, bin_centers=torch.arange(255.))
+    assert torch.equal(tok0, logits.argmax(-1)) and torch.equal(act, (255 - tok0).clamp(0, 254).float())
