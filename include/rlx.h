@@ -412,6 +412,48 @@ int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);
 size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);
 int rlx_ppo_step(const rlx_ppo_step_args* args, rlx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a19b  decoupled_loss  <- compute_decoupled_ppo_actor_loss rlinf/algorithms/losses.py:27-167 and
+ *        compute_decoupled_ppo_actor_critic_loss :383-393 (registry name "decoupled_actor_critic"), after
+ *        preprocess_loss_inputs incl. its proximal_logprobs / versions branches (rlinf/algorithms/utils.py:310-352).
+ * Same element geometry, critic, workspace protocol and BACKWARD as a18-a21 (use rlx_ppo_loss_bwd with this `out`).
+ *   proximal_logprobs [n_adv * raw_per_adv] f32   RLX_PROX_GIVEN
+ *   versions          [n_adv * raw_per_adv] f32   behaviour-policy version per raw entry (the first entry of each loss
+ *                                                 element's slice is used); needed for RLX_PROX_FROM_VERSIONS, optional
+ *                                                 otherwise (feeds out[RLX_DPPO_AVERAGE_VERSION])
+ * ------------------------------------------------------------------------------------------ */
+enum rlx_proximal_mode {
+    RLX_PROX_GIVEN = 0,          /* proximal_logprobs supplied */
+    RLX_PROX_IS_OLD = 1,         /* proximal = old_logprobs (neither proximal_logprobs nor versions/current_version) */
+    RLX_PROX_FROM_VERSIONS = 2   /* old + clamp((v_theta-1-v_b)/(v_theta-v_b), 0, 1) * (logprobs - old), losses.py:72-89 */
+};
+enum rlx_dppo_out {             /* slots 0-8 of the RLX_PPO_OUT_FLOATS row; 9-18 are the same as rlx_ppo_out */
+    RLX_DPPO_LOSS = 0,
+    RLX_DPPO_POLICY_LOSS = 1,
+    RLX_DPPO_PROXIMAL_RATIO = 2,
+    RLX_DPPO_CLIPPED_PROXIMAL_RATIO = 3,
+    RLX_DPPO_DUAL_CLIP_FRACTION = 4,
+    RLX_DPPO_BEHAV_CLIP_FRACTION = 5,
+    RLX_DPPO_PROXIMAL_APPROX_KL = 6,
+    RLX_DPPO_BEHAV_APPROX_KL = 7,
+    RLX_DPPO_CLIP_FRACTION = 8,
+    RLX_DPPO_AVERAGE_VERSION = 19
+};
+typedef struct rlx_decoupled_loss_params {
+    rlx_ppo_loss_params ppo;       /* clip_log_ratio_* are not part of this loss and ignored */
+    int32_t proximal_mode;         /* rlx_proximal_mode */
+    float current_version;
+    int32_t use_behave_threshold;
+    float behave_weight_threshold;
+} rlx_decoupled_loss_params;
+size_t rlx_decoupled_loss_workspace_bytes(int64_t n_adv);
+int rlx_decoupled_loss_fwd(const float* logprobs, const float* old_logprobs, const float* proximal_logprobs,
+                           const float* versions, const float* advantages, const float* values,
+                           const float* prev_values, const float* returns, const uint8_t* loss_mask,
+                           const int64_t* loss_mask_sum, int64_t n_adv, const rlx_decoupled_loss_params* params,
+                           float* g_logp, float* g_value, float* out, void* workspace, size_t workspace_bytes,
+                           rlx_stream_t stream);
+
 /* ==========================================================================================
  * Token tier: the reasoning (LLM) learner's per-token path over vocabulary logits.
  * ========================================================================================== */

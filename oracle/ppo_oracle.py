@@ -475,3 +475,104 @@ def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, va
     metrics["actor/grad_norm"] = gnorm.detach()
     metrics["actor/total_loss"] = loss.detach()
     return metrics
+
+
+# --------------------------------------------------------------------------------------------
+# a19b  decoupled PPO actor loss   rlinf/algorithms/losses.py:27-167 (+ :383-393 with the critic)
+# --------------------------------------------------------------------------------------------
+def decoupled_actor_loss(logprobs, old_logprobs, clip_ratio_low, clip_ratio_high, advantages, proximal_logprobs=None,
+                         versions=None, current_version=None, loss_mask=None, clip_ratio_c=None, max_episode_steps=None,
+                         loss_mask_sum=None, critic_warmup=False, behave_weight_threshold=None):
+    if loss_mask is None:
+        loss_mask = torch.ones_like(logprobs).bool()
+    agg_ratio = None
+    if max_episode_steps is not None and loss_mask_sum is not None and loss_mask is not None:
+        agg_ratio = (loss_mask_sum * 1.0) / max_episode_steps
+    if proximal_logprobs is None:
+        if versions is None or current_version is None:
+            proximal_logprobs = old_logprobs.detach()
+        else:  # interpolate the proximal policy between behaviour and current by version distance (:72-89)
+            v_b = versions.float()
+            v_t = float(current_version)
+            diff, gap = v_t - v_b, (v_t - 1.0) - v_b
+            alpha = torch.where((diff > 0) & (versions >= 0), gap / diff, torch.zeros_like(v_b))
+            while alpha.dim() < logprobs.dim():
+                alpha = alpha.unsqueeze(-1)
+            alpha = torch.clamp(alpha, 0.0, 1.0)
+            proximal_logprobs = (old_logprobs + alpha * (logprobs - old_logprobs)).detach()
+    n_valid = loss_mask.count_nonzero() or 1
+    prox_ratio = torch.where(loss_mask, torch.exp(logprobs - proximal_logprobs), 0.0)
+    clipped = torch.clamp(prox_ratio, 1.0 - clip_ratio_low, 1.0 + clip_ratio_high)
+    surr1 = -advantages * prox_ratio
+    surr2 = -advantages * clipped
+    per_elem = torch.max(surr1, surr2)
+    if clip_ratio_c is not None:
+        assert clip_ratio_c > 1.0, clip_ratio_c
+        surr3 = torch.sign(advantages) * clip_ratio_c * advantages
+        is_dual = surr3.detach() < per_elem.detach()
+        per_elem = torch.min(per_elem, surr3)
+    else:
+        is_dual = torch.zeros_like(per_elem, dtype=torch.bool)
+    behav_weight = torch.exp(proximal_logprobs - old_logprobs)
+    behav_mask = ((behav_weight <= behave_weight_threshold).logical_and(loss_mask)
+                  if behave_weight_threshold is not None else loss_mask)
+    n_behav = behav_mask.count_nonzero() or 1
+    weighted = per_elem * behav_weight
+    loss = masked_mean(weighted, behav_mask) if agg_ratio is None else masked_mean_ratio(weighted, behav_mask, agg_ratio)
+    if critic_warmup:
+        loss = torch.tensor(0.0)
+    with torch.no_grad():
+        clip_fraction = (surr1 < surr2).logical_and(loss_mask).count_nonzero() / n_valid
+        dual_clip_fraction = is_dual.logical_and(loss_mask).count_nonzero() / n_valid
+        prox_kl = -torch.where(loss_mask, logprobs - proximal_logprobs, 0.0).sum() / n_valid
+        behav_kl = -torch.where(behav_mask, proximal_logprobs - old_logprobs, 0.0).sum() / n_behav
+        behav_clip_fraction = 1.0 - (n_behav / n_valid)
+    metrics = {
+        "actor/policy_loss": loss.detach(),
+        "actor/proximal_ratio": masked_mean(prox_ratio.detach(), loss_mask),
+        "actor/clipped_proximal_ratio": masked_mean(clipped.detach(), loss_mask),
+        "actor/clip_fraction": clip_fraction,
+        "actor/dual_clip_fraction": dual_clip_fraction,
+        "actor/behav_clip_fraction": behav_clip_fraction,
+        "actor/proximal_approx_kl": prox_kl,
+        "actor/behav_approx_kl": behav_kl,
+    }
+    if versions is not None and current_version is not None and versions.shape == loss_mask.shape and loss_mask.any():
+        metrics["actor/average_version"] = versions[loss_mask].float().mean()
+        metrics["actor/current_version"] = torch.tensor(float(current_version))
+    return loss, metrics
+
+
+def shape_decoupled_inputs(proximal_logprobs, versions, logprob_type, action_dim, bsz, target_shape):
+    """The proximal / versions part of preprocess_loss_inputs (rlinf/algorithms/utils.py:310-352)."""
+    if logprob_type == "token_level":
+        if proximal_logprobs is not None:
+            proximal_logprobs = proximal_logprobs.reshape(bsz, -1, action_dim)
+        if versions is not None:
+            versions = versions.reshape(bsz, -1, action_dim)
+    elif logprob_type == "action_level":
+        if proximal_logprobs is not None:
+            proximal_logprobs = proximal_logprobs.reshape(bsz, -1, action_dim).sum(dim=-1)
+        if versions is not None:
+            versions = versions.reshape(bsz, -1, action_dim)[..., 0]
+    elif logprob_type == "chunk_level":
+        if proximal_logprobs is not None:
+            proximal_logprobs = proximal_logprobs.reshape(bsz, -1, action_dim).sum(dim=[1, 2])
+        if versions is not None:
+            versions = versions.reshape(bsz, -1, action_dim)[:, 0, 0]
+    return proximal_logprobs, _pad_dims(versions, target_shape)
+
+
+def decoupled_actor_critic_loss(*, proximal_logprobs=None, versions=None, current_version=None,
+                                behave_weight_threshold=None, **kw):
+    actor_kw = {k: kw[k] for k in ("logprobs", "old_logprobs", "advantages", "clip_ratio_low", "clip_ratio_high")}
+    for k in ("loss_mask", "clip_ratio_c", "max_episode_steps", "loss_mask_sum", "critic_warmup"):
+        if k in kw:
+            actor_kw[k] = kw[k]
+    a_loss, a_m = decoupled_actor_loss(proximal_logprobs=proximal_logprobs, versions=versions,
+                                       current_version=current_version,
+                                       behave_weight_threshold=behave_weight_threshold, **actor_kw)
+    c_loss, c_m = ppo_critic_loss(kw["values"], kw["returns"], kw["prev_values"], kw["value_clip"], kw["huber_delta"],
+                                  loss_mask=kw.get("loss_mask"), max_episode_steps=kw.get("max_episode_steps"),
+                                  loss_mask_sum=kw.get("loss_mask_sum"))
+    return a_loss + c_loss, {**a_m, **c_m}

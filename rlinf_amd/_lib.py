@@ -100,6 +100,21 @@ PPO_OUT_NAMES = {
 }
 
 
+class DecoupledLossParams(Structure):  # include/rlx.h: rlx_decoupled_loss_params
+    _fields_ = [("ppo", PpoLossParams), ("proximal_mode", c_int32), ("current_version", c_float),
+                ("use_behave_threshold", c_int32), ("behave_weight_threshold", c_float)]
+
+
+PROX_GIVEN, PROX_IS_OLD, PROX_FROM_VERSIONS = 0, 1, 2
+DPPO_OUT_NAMES = {
+    "loss": 0, "actor/policy_loss": 1, "actor/proximal_ratio": 2, "actor/clipped_proximal_ratio": 3,
+    "actor/dual_clip_fraction": 4, "actor/behav_clip_fraction": 5, "actor/proximal_approx_kl": 6,
+    "actor/behav_approx_kl": 7, "actor/clip_fraction": 8, "critic/value_loss": 9, "critic/value_clip_ratio": 10,
+    "ev/count": 11, "ev/returns_sum": 12, "ev/returns_sq_sum": 13, "ev/errors_sum": 14, "ev/errors_sq_sum": 15,
+    "mask_count": 18, "actor/average_version": 19,
+}
+
+
 class TokenRows(Structure):  # include/rlx.h: rlx_token_rows
     _fields_ = [("n_tokens", c_int64), ("vocab", c_int32), ("dtype", c_int32), ("rows_per_seq", c_int64),
                 ("seq_stride", c_int64), ("row_stride", c_int64), ("temperature", c_float), ("round_outputs", c_int32)]
@@ -163,6 +178,9 @@ PROTOTYPES = {
     "rlx_ppo_step_slabs": (c_int, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step": (c_int, [POINTER(PpoStepArgs), c_void_p]),
+    "rlx_decoupled_loss_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_decoupled_loss_fwd": (c_int, [c_void_p] * 10 + [c_int64, POINTER(DecoupledLossParams), c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
     "rlx_token_logprob_fwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_token_logprob_bwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_int64, c_void_p]),

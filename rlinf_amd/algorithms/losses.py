@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from .. import ops, token_ops
-from .._lib import PPO_OUT_NAMES, TOK_OUT_NAMES
+from .._lib import DPPO_OUT_NAMES, PPO_OUT_NAMES, TOK_OUT_NAMES
 from . import utils as _u
 from .registry import _mark_native_loss, register_policy_loss
 
@@ -33,9 +33,10 @@ _CRITIC_KEYS = ("critic/value_loss", "critic/value_clip_ratio")
 class LossMetrics(Mapping):
     """Read-only metrics dict over the kernel's f32[20] output; one D2H copy on first access."""
 
-    def __init__(self, out: torch.Tensor, has_critic: bool):
+    def __init__(self, out: torch.Tensor, has_critic: bool, actor_keys=_ACTOR_KEYS, names=PPO_OUT_NAMES):
         self.device_vector = out
-        self._keys = list(_ACTOR_KEYS) + (list(_CRITIC_KEYS) + list(_EV_MAP.values()) if has_critic else [])
+        self._keys = list(actor_keys) + (list(_CRITIC_KEYS) + list(_EV_MAP.values()) if has_critic else [])
+        self._names = names
         self._host = None
         self._extra = {}
 
@@ -51,7 +52,7 @@ class LossMetrics(Mapping):
             raise KeyError(key)
         host = self._load()
         inv = {v: k for k, v in _EV_MAP.items()}
-        return host[PPO_OUT_NAMES[inv.get(key, key)]]
+        return host[self._names[inv.get(key, key)]]
 
     def __setitem__(self, key, value):  # the learner adds actor/entropy_loss, actor/total_loss
         self._extra[key] = value
@@ -185,6 +186,73 @@ def _token_fused(kw: dict):
     return loss, TokenLossMetrics(out, fused_terms)
 
 
+_DECOUPLED_KEYS = ("actor/policy_loss", "actor/proximal_ratio", "actor/clipped_proximal_ratio", "actor/clip_fraction",
+                   "actor/dual_clip_fraction", "actor/behav_clip_fraction", "actor/proximal_approx_kl",
+                   "actor/behav_approx_kl")
+
+
+class DecoupledLossMetrics(LossMetrics):
+    """Adds the two version metrics the reference reports only when versions and loss_mask share a shape and some
+    element is unmasked (losses.py:156-165)."""
+
+    def __init__(self, out, has_critic, current_version, versions_match_mask: bool):
+        super().__init__(out, has_critic, actor_keys=_DECOUPLED_KEYS, names=DPPO_OUT_NAMES)
+        self._current_version = current_version
+        self._versions_match = versions_match_mask
+        self._versions_resolved = False
+
+    def _resolve(self):
+        if not self._versions_resolved:
+            self._versions_resolved = True
+            if self._versions_match and self._load()[DPPO_OUT_NAMES["mask_count"]] > 0:
+                self._keys += ["actor/average_version", "actor/current_version"]
+
+    def __getitem__(self, key):
+        self._resolve()
+        if key == "actor/current_version" and key in self._keys:
+            return float(self._current_version)
+        return super().__getitem__(key)
+
+    def __iter__(self):
+        self._resolve()
+        return super().__iter__()
+
+    def __len__(self):
+        self._resolve()
+        return super().__len__()
+
+
+@register_policy_loss("decoupled_actor_critic")
+def compute_decoupled_ppo_actor_critic_loss(**kwargs) -> tuple[torch.Tensor, Mapping]:
+    """Decoupled (async) PPO: clip against the proximal policy, importance-weight by exp(prox - behaviour)
+    (losses.py:27-167,383-393) on RAW per-dimension inputs; the proximal policy is ``proximal_logprobs`` when given,
+    else interpolated from ``versions`` / ``current_version``, else the behaviour policy."""
+    kw = kwargs
+    logprobs = kw["logprobs"]
+    dev = _u.compute_device(logprobs)
+    st = lambda name: _u.stage(kw.get(name), dev)  # noqa: E731
+    logprob_type = kw.get("logprob_type") or "action_level"
+    action_dim = kw.get("single_action_dim")
+    if action_dim is None:
+        raise TypeError("policy_loss(loss_type='decoupled_actor_critic') needs single_action_dim")
+    if kw.get("reward_type") == "chunk_level" and logprob_type != "chunk_level":
+        raise NotImplementedError("reward_type='chunk_level' is only fused together with logprob_type='chunk_level'")
+    versions, current_version = st("versions"), kw.get("current_version")
+    loss, out = ops.ppo_loss(
+        _u.stage(logprobs, dev), st("old_logprobs"), st("advantages"), logprob_type=logprob_type,
+        action_dim=int(action_dim), clip_ratio_low=kw["clip_ratio_low"], clip_ratio_high=kw["clip_ratio_high"],
+        values=st("values"), prev_values=st("prev_values"), returns=st("returns"), value_clip=kw.get("value_clip"),
+        huber_delta=kw.get("huber_delta"), loss_mask=st("loss_mask"), loss_mask_sum=st("loss_mask_sum"),
+        max_episode_steps=kw.get("max_episode_steps"), clip_ratio_c=kw.get("clip_ratio_c"),
+        critic_warmup=bool(kw.get("critic_warmup", False)), has_critic=True,
+        decoupled=dict(proximal_logprobs=st("proximal_logprobs"), versions=versions, current_version=current_version,
+                       behave_weight_threshold=kw.get("behave_weight_threshold")))
+    # versions.shape == loss_mask.shape after the reference's shaping <=> one loss element per advantage element
+    match = (versions is not None and current_version is not None
+             and (logprob_type != "token_level" or kw.get("loss_mask") is None))
+    return loss, DecoupledLossMetrics(out, True, current_version, match)
+
+
 @register_policy_loss("actor_critic")
 def compute_ppo_actor_critic_loss(**kwargs) -> tuple[torch.Tensor, Mapping]:
     """PPO clipped surrogate + clipped-Huber value loss (losses.py:397-425) on RAW per-dimension inputs."""
@@ -202,6 +270,7 @@ def compute_grpo_actor_loss_fn(**kwargs) -> tuple[torch.Tensor, Mapping]:
 
 _mark_native_loss("actor_critic", compute_ppo_actor_critic_loss)
 _mark_native_loss("actor", compute_grpo_actor_loss_fn)
+_mark_native_loss("decoupled_actor_critic", compute_decoupled_ppo_actor_critic_loss)
 
 
 def explained_variance_from_stats(stats: Mapping) -> float:

@@ -257,7 +257,8 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
              huber_delta: Optional[float] = None, loss_mask: Optional[torch.Tensor] = None,
              loss_mask_sum: Optional[torch.Tensor] = None, max_episode_steps: Optional[int] = None,
              clip_ratio_c: Optional[float] = None, clip_log_ratio_min: Optional[float] = None,
-             clip_log_ratio_max: Optional[float] = None, critic_warmup: bool = False, has_critic: bool = True):
+             clip_log_ratio_max: Optional[float] = None, critic_warmup: bool = False, has_critic: bool = True,
+             decoupled: Optional[dict] = None):
     """Fused actor(+critic) PPO loss.  Inputs are the RAW per-dimension tensors the reference hands to
     policy_loss (before preprocess_loss_inputs); returns (loss 0-dim tensor with grad, out f32[20] on device,
     see _lib.PPO_OUT_NAMES).  losses.py asserts float32 inputs (:232-240); so do we."""
@@ -307,9 +308,73 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
     p.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
     p.raw_per_adv, p.sub_per_adv = raw, sub
     v = values.contiguous() if has_critic else None
+    if decoupled is not None:
+        dp, prox, versions = _decoupled_params(p, logprobs, **decoupled)
+        return _DecoupledLossFn.apply(logprobs, v, old_logprobs.contiguous(), advantages.contiguous(),
+                                      prev_values.contiguous() if has_critic else None,
+                                      returns.contiguous() if has_critic else None, m8, msum, prox, versions, dp, n_adv)
     return _PpoLossFn.apply(logprobs, v, old_logprobs.contiguous(), advantages.contiguous(),
                             prev_values.contiguous() if has_critic else None,
                             returns.contiguous() if has_critic else None, m8, msum, p, n_adv)
+
+
+def _decoupled_params(p: PpoLossParams, logprobs, proximal_logprobs=None, versions=None, current_version=None,
+                      behave_weight_threshold=None):
+    """rlx_decoupled_loss_params + the two optional raw tensors (losses.py:68-89: which proximal policy applies)."""
+    dp = _lib.DecoupledLossParams()
+    dp.ppo = p
+    for name, t in (("proximal_logprobs", proximal_logprobs), ("versions", versions)):
+        if t is not None and t.numel() != logprobs.numel():
+            raise RlxError(f"{name} must have the shape of logprobs")
+    if proximal_logprobs is not None:
+        if proximal_logprobs.dtype != torch.float32:
+            raise AssertionError("proximal_logprobs must be float32 to keep numerical stability")
+        dp.proximal_mode = _lib.PROX_GIVEN
+    elif versions is None or current_version is None:
+        dp.proximal_mode = _lib.PROX_IS_OLD
+    else:
+        dp.proximal_mode = _lib.PROX_FROM_VERSIONS
+    dp.current_version = float(current_version) if current_version is not None else 0.0
+    dp.use_behave_threshold = int(behave_weight_threshold is not None)
+    dp.behave_weight_threshold = float(behave_weight_threshold) if behave_weight_threshold is not None else 0.0
+    prox = proximal_logprobs.contiguous() if proximal_logprobs is not None else None
+    ver = versions.float().contiguous() if (versions is not None and current_version is not None) else None
+    return dp, prox, ver
+
+
+class _DecoupledLossFn(torch.autograd.Function):
+    """rlx_decoupled_loss_fwd + the shared rlx_ppo_loss_bwd."""
+
+    @staticmethod
+    def forward(ctx, logprobs, values, old_logprobs, advantages, prev_values, returns, loss_mask, loss_mask_sum,
+                proximal_logprobs, versions, dp, n_adv: int):
+        lib = _lib.load()
+        dev = logprobs.device
+        params = dp.ppo
+        lp = logprobs.contiguous()
+        g_lp = torch.empty((n_adv * params.sub_per_adv,), dtype=torch.float32, device=dev)
+        g_v = torch.empty((n_adv,), dtype=torch.float32, device=dev) if params.has_critic else None
+        out = torch.empty((_lib.PPO_OUT_FLOATS,), dtype=torch.float32, device=dev)
+        ws_bytes = lib.rlx_decoupled_loss_workspace_bytes(n_adv)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.rlx_decoupled_loss_fwd(
+                lp.data_ptr(), old_logprobs.data_ptr(), _ptr(proximal_logprobs), _ptr(versions), advantages.data_ptr(),
+                _ptr(values), _ptr(prev_values), _ptr(returns), _ptr(loss_mask), _ptr(loss_mask_sum), n_adv, byref(dp),
+                g_lp.data_ptr(), _ptr(g_v), out.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(dev)),
+                "rlx_decoupled_loss_fwd")
+        ctx.save_for_backward(g_lp, g_v if g_v is not None else out, out)
+        ctx.has_critic = bool(params.has_critic)
+        ctx.geom = (n_adv, params.raw_per_adv, params.sub_per_adv)
+        ctx.lp_shape = logprobs.shape
+        ctx.v_shape = None if values is None else values.shape
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_out):
+        d_lp, d_v = _PpoLossFn.backward(ctx, grad_loss, _grad_out)[:2]
+        return (d_lp, d_v) + (None,) * 10
 
 
 def make_ppo_params(*, logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low, clip_ratio_high,

@@ -200,3 +200,59 @@ def test_clip_adamw_matches_torch(slabs):
     bad[5] = float("inf")
     stats = ops.clip_adamw_step_(flat, bad, m, v, groups, 5, max_grad_norm=0.5)
     assert float(stats[1]) == 0.0 and torch.equal(flat, before)
+
+
+# ---- decoupled (async) PPO loss: registry name "decoupled_actor_critic" -------------------------------------
+@pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
+@pytest.mark.parametrize("prox_mode", ["given", "old", "versions"])
+@pytest.mark.parametrize("masked,thr,warmup", [(False, None, False), (True, None, False), (True, 1.05, False),
+                                               (True, 1.02, True)])
+def test_decoupled_loss_vs_oracle(logprob_type, prox_mode, masked, thr, warmup):
+    from rlinf_amd.algorithms import registry
+
+    g = torch.Generator().manual_seed(17)
+    bsz, C, A = 300, 2, 4
+    lp0 = torch.randn(bsz, C * A, generator=g) * 0.3
+    old = lp0 + 0.1 * torch.randn(bsz, C * A, generator=g)
+    prox = lp0 + 0.05 * torch.randn(bsz, C * A, generator=g) if prox_mode == "given" else None
+    versions = None
+    if prox_mode != "old":
+        versions = torch.randint(-1, 6, (bsz, 1), generator=g).float().expand(bsz, C * A).contiguous()
+    n_adv = (bsz,) if logprob_type == "chunk_level" else (bsz, C)
+    adv = torch.randn(*n_adv, generator=g)
+    vals, pv, ret = (torch.randn(*n_adv, generator=g) for _ in range(3))
+    lm = lms = None
+    if masked:
+        lm = torch.rand(*n_adv, generator=g) < 0.7
+        lms = lm.sum(dim=0, keepdim=True).expand_as(lm).contiguous()
+    common = dict(clip_ratio_low=0.2, clip_ratio_high=0.28, clip_ratio_c=3.0, value_clip=0.5, huber_delta=1.0,
+                  max_episode_steps=80, critic_warmup=warmup)
+    lp = lp0.clone().requires_grad_(True)
+    v = vals.clone().requires_grad_(True)
+    shaped = O.shape_loss_inputs(lp, old, adv, logprob_type, A, loss_mask=lm, loss_mask_sum=lms, values=v, prev_values=pv,
+                                 returns=ret)
+    p2, v2 = O.shape_decoupled_inputs(prox, versions, logprob_type, A, bsz, shaped["logprobs"].shape)
+    wloss, wm = O.decoupled_actor_critic_loss(proximal_logprobs=p2, versions=v2, current_version=5,
+                                              behave_weight_threshold=thr, **common, **shaped)
+    (wloss * 0.5).backward()
+
+    dlp = lp0.cuda().requires_grad_(True)
+    dv = vals.cuda().requires_grad_(True)
+    loss, metrics = registry.policy_loss(
+        task_type="embodied", loss_type="decoupled_actor_critic", logprob_type=logprob_type, reward_type=
+        "chunk_level" if logprob_type == "chunk_level" else "action_level", single_action_dim=A, logprobs=dlp, values=dv,
+        old_logprobs=_c(old), advantages=_c(adv), returns=_c(ret), prev_values=_c(pv), proximal_logprobs=_c(prox),
+        versions=_c(versions), current_version=5, behave_weight_threshold=thr, loss_mask=_c(lm), loss_mask_sum=_c(lms),
+        **common)
+    (loss * 0.5).backward()
+    tag = (logprob_type, prox_mode, masked, thr, warmup)
+    torch.testing.assert_close(loss.detach().cpu(), wloss.detach(), rtol=RTOL, atol=ATOL, msg=lambda m: f"{tag}: {m}")
+    want_g = torch.zeros_like(lp0) if lp.grad is None else lp.grad
+    torch.testing.assert_close(dlp.grad.cpu(), want_g, rtol=RTOL, atol=1e-7, msg=lambda m: f"{tag} d_logprobs: {m}")
+    torch.testing.assert_close(dv.grad.cpu(), v.grad, rtol=RTOL, atol=1e-7, msg=lambda m: f"{tag} d_values: {m}")
+    want_keys = {k for k in wm if k.startswith("actor/")}
+    got_keys = {k for k in metrics if k.startswith("actor/")}
+    assert want_keys == got_keys, (tag, want_keys ^ got_keys)
+    for k in sorted(want_keys) + ["critic/value_loss", "critic/value_clip_ratio"]:
+        torch.testing.assert_close(torch.tensor(float(metrics[k])), torch.as_tensor(wm[k]).float(), rtol=RTOL, atol=ATOL,
+                                   msg=lambda m: f"{tag} {k}: {m}")

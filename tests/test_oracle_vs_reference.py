@@ -314,3 +314,55 @@ def test_token_reasoning_shaping(ref):
                                                   loss_mask=b["loss_mask"], group_size=4)
     _eq(want[0], TO.grpo_reasoning_advantages(b["rewards"], b["loss_mask"], 4))
     assert want[1] is None
+
+
+# ---- decoupled PPO (oracle a19b) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
+@pytest.mark.parametrize("prox_mode", ["given", "old", "versions"])
+@pytest.mark.parametrize("masked,thr", [(False, None), (True, None), (True, 1.05)])
+def test_decoupled_actor_critic_loss(ref, logprob_type, prox_mode, masked, thr):
+    g = torch.Generator().manual_seed(17)
+    bsz, C, A = 48, 2, 4
+    lp0 = torch.randn(bsz, C * A, generator=g) * 0.3
+    old = lp0 + 0.1 * torch.randn(bsz, C * A, generator=g)
+    prox = lp0 + 0.05 * torch.randn(bsz, C * A, generator=g) if prox_mode == "given" else None
+    versions = None
+    if prox_mode == "versions":
+        versions = torch.randint(-1, 6, (bsz, 1), generator=g).float().expand(bsz, C * A).contiguous()
+    n_adv = (bsz,) if logprob_type == "chunk_level" else (bsz, C)
+    adv = torch.randn(*n_adv, generator=g)
+    vals, pv, ret = (torch.randn(*n_adv, generator=g) for _ in range(3))
+    lm = lms = None
+    if masked:
+        lm = torch.rand(*n_adv, generator=g) < 0.7
+        lms = lm.sum(dim=0, keepdim=True).expand_as(lm).contiguous()
+    common = dict(clip_ratio_low=0.2, clip_ratio_high=0.28, clip_ratio_c=3.0, value_clip=0.5, huber_delta=1.0,
+                  max_episode_steps=80, critic_warmup=False)
+    outs = []
+    for which in ("ref", "oracle"):
+        lp = lp0.clone().requires_grad_(True)
+        v = vals.clone().requires_grad_(True)
+        if which == "ref":
+            kw = ref.algo_utils.preprocess_loss_inputs(
+                logprobs=lp, old_logprobs=old, advantages=adv, logprob_type=logprob_type, single_action_dim=A,
+                loss_mask=lm, loss_mask_sum=lms, values=v, prev_values=pv, returns=ret, versions=versions,
+                proximal_logprobs=prox, current_version=5, behave_weight_threshold=thr, **common)
+            loss, m = ref.losses.compute_decoupled_ppo_actor_critic_loss(**kw)
+        else:
+            shaped = O.shape_loss_inputs(lp, old, adv, logprob_type, A, loss_mask=lm, loss_mask_sum=lms, values=v,
+                                         prev_values=pv, returns=ret)
+            p2, v2 = O.shape_decoupled_inputs(prox, versions, logprob_type, A, bsz, shaped["logprobs"].shape)
+            loss, m = O.decoupled_actor_critic_loss(proximal_logprobs=p2, versions=v2, current_version=5,
+                                                    behave_weight_threshold=thr, **common, **shaped)
+        g_lp, g_v = torch.autograd.grad(loss, [lp, v])
+        outs.append((loss.detach(), m, g_lp, g_v))
+    (l0, m0, a0, b0), (l1, m1, a1, b1) = outs
+    _eq(l0, l1), _eq(a0, a1), _eq(b0, b1)
+    actor = lambda m: {k for k in m if k.startswith("actor/")}  # noqa: E731  (the critic's keys are pinned elsewhere)
+    assert actor(m0) == actor(m1)
+    for k in sorted(actor(m0)) + ["critic/value_loss", "critic/value_clip_ratio"]:
+        x, y = m0[k], m1[k]
+        if isinstance(x, torch.Tensor):
+            _eq(x, y)
+        else:
+            assert x == y, k
