@@ -116,6 +116,14 @@ int rlx_grpo_from_scores(const float* scores, const uint8_t* loss_mask, float* a
 int rlx_episode_scores(const float* rewards, const uint8_t* dones, float* scores, int n_chunk, int batch,
                        int chunk, rlx_stream_t stream);
 
+/* reward filter  <- EmbodiedFSDPActor._process_received_rollout_batch, rlinf/workers/actor/embodied_fsdp_actor_worker.py:235-281
+ *   (same code in preprocess_embodied_batch, rlinf/utils/utils.py:801-832)
+ *   rewards [n_chunk, B, C] f32, loss_mask [n_chunk, B, C] u8 or NULL.  For every group of `group_size` consecutive envs:
+ *   keep = lower <= mean_over_group( sum_t,c rewards * loss_mask ) <= upper
+ *   out_mask = keep & loss_mask  [n_chunk, B, C]   (loss_mask given)   or   keep  [n_chunk, B, 1]  (loss_mask NULL) */
+int rlx_reward_filter_mask(const float* rewards, const uint8_t* loss_mask, uint8_t* out_mask, int n_chunk, int batch,
+                           int chunk, int group_size, float lower, float upper, rlx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * a18-a21  ppo_loss  <- preprocess_loss_inputs (rlinf/algorithms/utils.py:280-376),
  *                       compute_ppo_actor_loss (rlinf/algorithms/losses.py:170-312),
@@ -479,7 +487,8 @@ int rlx_decoupled_loss_fwd(const float* logprobs, const float* old_logprobs, con
  * written in the logits dtype with its own strides; d_logits may alias logits (in-place).  Rows whose
  * d_logprob and d_entropy are both zero are written as zeros without reading their logits.
  * ------------------------------------------------------------------------------------------ */
-enum rlx_dtype { RLX_DTYPE_F32 = 0, RLX_DTYPE_BF16 = 1 };
+enum rlx_dtype { RLX_DTYPE_F32 = 0, RLX_DTYPE_BF16 = 1, RLX_DTYPE_F16 = 2,
+                 RLX_DTYPE_RAW8 = 3, RLX_DTYPE_RAW16 = 4, RLX_DTYPE_RAW32 = 5, RLX_DTYPE_RAW64 = 6 /* integer / bool tensors by width */ };
 typedef struct rlx_token_rows {
     int64_t n_tokens;
     int32_t vocab;
@@ -571,6 +580,36 @@ int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, float* adva
 int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k,
                            const float* bin_centers, int n_centers, int64_t* tokens, float* logprob, float* actions,
                            rlx_stream_t stream);
+
+/* ==========================================================================================
+ * Weight-sync tier: the sparse weight patch of the actor -> rollout push.
+ *   w1 patch_scan / w2 patch_emit  <- GPUSnapshotPatchBuilder.create_patch, rlinf/hybrid_engines/weight_syncer/patch_syncer.py:648-774
+ *                                     (to(snapshot dtype) -> ne -> nonzero -> gather -> snapshot[rows, cols] = values)
+ *                                     + PatchBuilder.delta_encode :290-327
+ *   w3 patch_apply                 <- the per-tensor body of PatchWeightSyncer.apply :1040-1137 + PatchBuilder.delta_decode :329-370
+ * One tensor per call, seen through its 2-D COO view (as_coo_2d_view :60-95): n_elems = rows * cols, row-major.
+ *   scan : ONE read of value (value_dtype) and snapshot (snapshot_dtype; equal, or f32 -> bf16 / f16 when the receiver
+ *          holds a narrower copy); writes nnz[0] (device i64) = number of elements with value.to(dtype) != snapshot under
+ *          torch.ne (NaN != NaN, +0 == -0); keeps a bit mask and block offsets in `workspace`.
+ *   emit : after the host has read nnz (the reference synchronises on nonzero() at the same point) and allocated
+ *          out_rows / out_cols [nnz] i64 and out_values [nnz] of the snapshot dtype: fills them in nonzero() order --
+ *          absolute indices, or PatchBuilder.delta_encode's deltas -- updates the snapshot in place and raises
+ *          maxima[0] / maxima[1] (device u64, zeroed by the caller) to the largest emitted row / column code, which is what
+ *          downscale_nonnegative_indices :35-57 needs to pick uint8 / int32 / int64.
+ *   apply: target[r, c] = value for every entry, indices given in any of the three index dtypes (code 0 u8, 1 i32, 2 i64),
+ *          absolute or delta-encoded.
+ * Integer / byte work: bit-exact.
+ * ========================================================================================== */
+size_t rlx_patch_workspace_bytes(int64_t n_elems);
+int rlx_patch_scan(const void* value, int value_dtype, const void* snapshot, int snapshot_dtype, int64_t n_elems,
+                   void* workspace, size_t workspace_bytes, int64_t* nnz, rlx_stream_t stream);
+int rlx_patch_emit(const void* value, int value_dtype, void* snapshot, int snapshot_dtype, int64_t n_elems, int64_t cols,
+                   int delta_encoding, const void* workspace, int64_t* out_rows, int64_t* out_cols, void* out_values,
+                   uint64_t* maxima, rlx_stream_t stream);
+size_t rlx_patch_apply_workspace_bytes(int64_t nnz);
+int rlx_patch_apply(void* target, int dtype, int64_t target_rows, int64_t target_cols, const void* rows,
+                    int rows_index_dtype, const void* cols, int cols_index_dtype, int delta_encoded, const void* values,
+                    int64_t nnz, void* workspace, size_t workspace_bytes, rlx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -267,6 +267,60 @@ def make_token_path(ref):
     torch.save(cases, os.path.join(OUT, "token_path.pt"))
 
 
+def patch_states(seed, scale=1):
+    """Seeded (before, after) state dicts for the weight-patch fixtures: mixed dtypes and ranks, a NaN (resent on every
+    sync: NaN != NaN), a sign flip of zero (not a change under torch.ne), an untouched tensor, a dense and a sparse update."""
+    g = torch.Generator().manual_seed(seed)
+    R = 37 * scale
+    before = {
+        "backbone.weight": torch.randn(R, 300, generator=g),
+        "backbone.bias": torch.randn(300, generator=g),
+        "logstd": torch.tensor(-0.5),
+        "conv": torch.randn(4, 5, 6, generator=g).bfloat16(),
+        "steps": torch.arange(40).reshape(4, 10),
+        "head.weight": torch.randn(600 * scale, 70, generator=g).half(),
+        "frozen": torch.randn(11, 13, generator=g),
+        "flags": torch.rand(9, 31, generator=g) < 0.5,
+    }
+    before["backbone.weight"][5, 5] = 0.0
+    after = {k: v.clone() for k, v in before.items()}
+    after["backbone.weight"][torch.rand(R, 300, generator=g) < 0.01] += 1
+    after["backbone.weight"][3, 7] = float("nan")
+    after["backbone.weight"][5, 5] = -0.0
+    after["backbone.bias"][299] = 7.0
+    after["logstd"] = torch.tensor(-0.25)
+    after["conv"][1, 2, 3] = 5
+    after["steps"][2, 3] = -7
+    after["head.weight"][torch.rand(600 * scale, 70, generator=g) < 0.3] *= 2
+    after["flags"][8, 30] = ~after["flags"][8, 30]
+    return before, after
+
+
+def make_weight_patches():
+    """tests/golden/weight_patch.pt: what the reference's own GPUSnapshotPatchBuilder (run on CPU tensors through
+    oracle/reference_loader.load_weight_syncer) emits for patch_states(seed), delta encoding on and off, two syncs each
+    (the second contains only the NaN entry), plus a sender whose receiver holds bf16 copies."""
+    m = reference_loader.load_weight_syncer()
+    cases = []
+    for seed, delta, narrow in ((1, True, False), (1, False, False), (2, True, True)):
+        before, after = patch_states(seed)
+        keys = list(before)
+        names = [k for k in keys if k != "frozen"] + ["frozen"]
+        snap = {}
+        for k, v in before.items():
+            view = m.as_coo_2d_view(v)[0]
+            snap[k] = view.to(torch.bfloat16 if (narrow and v.dtype == torch.float32) else view.dtype, copy=True)
+        builder = m.GPUSnapshotPatchBuilder(snap, keys, names, {k: v.shape for k, v in before.items()},
+                                            torch.device("cpu"), delta)
+        patches = []
+        for version in (11, 12):
+            p = builder.create_patch(after, version)
+            patches.append({f: getattr(p, f).clone() for f in ("version", "ordinals", "nnz_per_tensor", "rows", "cols",
+                                                                "values")})
+        cases.append(dict(params=dict(seed=seed, delta=delta, narrow=narrow, keys=keys, names=names), patches=patches))
+    torch.save(cases, os.path.join(OUT, "weight_patch.pt"))
+
+
 def main():
     ref = reference_loader.load()
     os.makedirs(OUT, exist_ok=True)
@@ -276,6 +330,7 @@ def main():
     make_policy(ref)
     make_shuffle(ref)
     make_token_path(ref)
+    make_weight_patches()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -95,3 +95,42 @@ def load() -> SimpleNamespace:
         value_head=mods["rlinf.models.embodiment.modules.value_head"],
     )
     return _cache
+
+
+_ws_cache = None
+
+
+def load_weight_syncer():
+    """The reference's patch weight syncer (rlinf/hybrid_engines/weight_syncer/patch_syncer.py and what it imports),
+    executed from /root/reference.  ``Worker.torch_device_type`` is stubbed to "cpu" so that the reference's
+    GPUSnapshotPatchBuilder -- the same-device snapshot path the HIP kernels replace -- runs on CPU tensors here."""
+    global _ws_cache
+    if _ws_cache is not None:
+        return _ws_cache
+    import logging
+
+    load()
+    sched = sys.modules["rlinf.scheduler"]
+    sched.CollectiveGroupOptions = type("CollectiveGroupOptions", (), {})
+
+    class _Stream:
+        def synchronize(self):
+            pass
+
+    class _Platform:
+        @staticmethod
+        def current_stream():
+            return _Stream()
+
+    sched.Worker.torch_device_type = "cpu"
+    sched.Worker.torch_platform = _Platform
+    _stub("rlinf.hybrid_engines", _rlx_stub=True)
+    _stub("rlinf.hybrid_engines.weight_syncer", _rlx_stub=True)
+    if "omegaconf" not in sys.modules:
+        _stub("omegaconf", DictConfig=dict, OmegaConf=type("OmegaConf", (), {}), _rlx_stub=True)
+    _stub("rlinf.utils.logging", get_logger=lambda *a, **k: logging.getLogger("rlinf-reference"), _rlx_stub=True)
+    mods = {}
+    for name in ("base", "compressor", "bucket_syncer", "patch_syncer"):
+        mods[name] = _exec(f"rlinf.hybrid_engines.weight_syncer.{name}", f"rlinf/hybrid_engines/weight_syncer/{name}.py")
+    _ws_cache = mods["patch_syncer"]
+    return _ws_cache

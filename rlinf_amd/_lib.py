@@ -125,7 +125,7 @@ class TokenLossParams(Structure):  # include/rlx.h: rlx_token_loss_params
                 ("kl_type", c_int32), ("kl_beta", c_float), ("use_entropy", c_int32), ("entropy_bonus", c_float)]
 
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_RAW8, DTYPE_RAW16, DTYPE_RAW32, DTYPE_RAW64 = range(7)
 LOSS_AGG = {"token-mean": 0, "seq-mean-token-sum": 1, "seq-mean-token-mean": 2}
 KL_TYPE = {None: 0, "kl": 1, "k1": 1, "abs": 2, "mse": 3, "k2": 3, "low_var_kl": 4, "k3": 4}
 TOK_OUT_FLOATS = 16
@@ -148,6 +148,7 @@ PROTOTYPES = {
                                    c_float, c_void_p]),
     "rlx_grpo_from_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rlx_episode_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rlx_reward_filter_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "rlx_ppo_loss_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_ppo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                  POINTER(PpoLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -191,6 +192,13 @@ PROTOTYPES = {
     "rlx_token_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rlx_categorical_sample": (c_int, [c_void_p, POINTER(TokenRows), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
+    "rlx_patch_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_patch_scan": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "rlx_patch_emit": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p]),
+    "rlx_patch_apply_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_patch_apply": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64,
+                                c_void_p, c_size_t, c_void_p]),
     "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
 }
 

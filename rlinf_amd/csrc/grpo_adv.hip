@@ -89,10 +89,57 @@ __global__ __launch_bounds__(256) void grpo_broadcast(const float* __restrict__ 
     }
 }
 
+
+// reward filter (EmbodiedFSDPActor._process_received_rollout_batch, embodied_fsdp_actor_worker.py:235-281): a prompt group
+// whose mean (masked) episode reward falls outside [lower, upper] is dropped from the loss.  One block per group:
+// reduce, decide, then write the group's mask columns.
+__global__ __launch_bounds__(256) void reward_filter_kernel(const float* __restrict__ r, const uint8_t* __restrict__ m,
+                                                            uint8_t* __restrict__ out, int n_chunk, int B, int C, int G,
+                                                            int out_c, float lower, float upper) {
+    __shared__ double scratch[4];
+    __shared__ int s_keep;
+    const int grp = blockIdx.x;
+    const int width = G * C;  // contiguous floats of this group in every time row
+    const size_t row_stride = (size_t)B * C;
+    const size_t base = (size_t)grp * width;
+    double acc[1] = {0.0};
+    for (long long i = threadIdx.x; i < (long long)n_chunk * width; i += blockDim.x) {
+        const size_t idx = (size_t)(i / width) * row_stride + base + (size_t)(i % width);
+        const float v = r[idx];
+        acc[0] += (double)(m ? fmul(v, m[idx] ? 1.f : 0.f) : v);
+    }
+    block_sum<1>(acc, scratch);
+    if (threadIdx.x == 0) {
+        const float mean = (float)(acc[0] / (double)G);
+        s_keep = (mean >= lower && mean <= upper) ? 1 : 0;
+    }
+    __syncthreads();
+    const uint8_t keep = (uint8_t)s_keep;
+    const int owidth = G * out_c;
+    const size_t orow = (size_t)B * out_c, obase = (size_t)grp * owidth;
+    for (long long i = threadIdx.x; i < (long long)n_chunk * owidth; i += blockDim.x) {
+        const size_t t = (size_t)(i / owidth), j = (size_t)(i % owidth);
+        out[t * orow + obase + j] = m ? (uint8_t)(keep & (m[t * row_stride + base + j] ? 1 : 0)) : keep;
+    }
+}
+
 }  // namespace
 }  // namespace rlx
 
 using namespace rlx;
+
+extern "C" int rlx_reward_filter_mask(const float* rewards, const uint8_t* loss_mask, uint8_t* out_mask, int n_chunk,
+                                      int batch, int chunk, int group_size, float lower, float upper,
+                                      rlx_stream_t stream) {
+    RLX_REQUIRE(n_chunk >= 0 && batch >= 0 && chunk >= 1, "rlx_reward_filter_mask: bad sizes");
+    RLX_REQUIRE(group_size >= 1 && batch % group_size == 0, "batch %d not divisible by group_size %d", batch, group_size);
+    if (batch == 0 || n_chunk == 0) return RLX_OK;
+    RLX_REQUIRE(rewards && out_mask, "rlx_reward_filter_mask: NULL argument");
+    hipLaunchKernelGGL(reward_filter_kernel, dim3(batch / group_size), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       rewards, loss_mask, out_mask, n_chunk, batch, chunk, group_size, loss_mask ? chunk : 1, lower, upper);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
 
 static int launch_scores(const float* rewards, const uint8_t* dones, float* scores, int n_chunk, int batch, int chunk,
                          hipStream_t s) {

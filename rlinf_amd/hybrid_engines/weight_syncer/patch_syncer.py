@@ -1,0 +1,316 @@
+"""Sparse weight-patch sync, same wire format and call surface as rlinf/hybrid_engines/weight_syncer/patch_syncer.py
+(``WeightPatch`` fields :130-205, ``PatchBuilder.delta_encode/decode`` :290-370, ``GPUSnapshotPatchBuilder.create_patch``
+:648-774, ``PatchWeightSyncer`` :777-1137), with the per-tensor work on weight_patch.hip:
+
+    sender   scan (one read of tensor + snapshot) -> [host reads nnz, as the reference does after nonzero()] -> emit
+    receiver decode + scatter in one pass
+
+What is mirrored is the same-device ("GPU snapshot") builder with ``compression: none`` -- nvCOMP, the reference's only
+compressor, is NVIDIA-only -- and the init handshake (receiver announces key order, shapes and
+dtypes; the sender snapshots in the RECEIVER's dtypes, :950-1010).  Transport is any pair of send / recv callables, as in
+the reference; ``rlinf_amd.scheduler.dist`` supplies RCCL broadcast ones.  A patch built here is applied by the
+reference's receiver and vice versa (tests/test_gpu_weight_patch.py checks both against the oracle byte for byte).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from ... import _lib
+from ..._lib import RlxError
+from ...ops import _stream_ptr
+
+_FLOAT_CODES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
+_RAW_BY_SIZE = {1: _lib.DTYPE_RAW8, 2: _lib.DTYPE_RAW16, 4: _lib.DTYPE_RAW32, 8: _lib.DTYPE_RAW64}
+_INDEX_CODES = {torch.uint8: 0, torch.int32: 1, torch.int64: 2}
+
+
+def _dtype_code(dtype: torch.dtype) -> int:
+    if dtype in _FLOAT_CODES:
+        return _FLOAT_CODES[dtype]
+    if dtype.is_floating_point or dtype.is_complex:
+        raise RlxError(f"weight patch: unsupported floating dtype {dtype}")
+    return _RAW_BY_SIZE[torch.empty((), dtype=dtype).element_size()]
+
+
+def downscale_nonnegative_indices(tensor: torch.Tensor) -> torch.Tensor:
+    """uint8 / int32 / int64 by the largest value (:35-57); empty tensors become uint8."""
+    if tensor.numel() == 0:
+        return tensor.to(torch.uint8)
+    return tensor.to(_index_dtype_for(int(tensor.max().item())))
+
+
+def _index_dtype_for(max_value: int) -> torch.dtype:
+    if max_value <= 255:
+        return torch.uint8
+    if max_value <= torch.iinfo(torch.int32).max:
+        return torch.int32
+    return torch.int64
+
+
+def as_coo_2d_view(tensor: torch.Tensor):
+    """(2-D view, original shape) (:60-95): scalar -> (1,1), vector -> (1,N), rank >= 3 -> (shape[0], rest)."""
+    shape = tensor.shape
+    if tensor.ndim == 0:
+        return tensor.unsqueeze(0).unsqueeze(0), shape
+    if tensor.ndim == 1:
+        return tensor.unsqueeze(0), shape
+    if tensor.ndim == 2:
+        return tensor, shape
+    try:
+        return tensor.view(tensor.shape[0], -1), shape
+    except RuntimeError as err:
+        raise ValueError("PatchWeightSyncer only supports ndim>=3 tensors whose trailing dimensions can be flattened as a "
+                         f"view. Got shape={tuple(tensor.shape)}, stride={tuple(tensor.stride())}.") from err
+
+
+@dataclass
+class EmptyWeightPatch:
+    version: torch.Tensor
+
+    def to(self, device, non_blocking: bool = False) -> "EmptyWeightPatch":
+        return EmptyWeightPatch(self.version.to(device=device, non_blocking=non_blocking))
+
+    def tensors(self) -> list:
+        return [self.version]
+
+
+@dataclass
+class WeightPatch:
+    version: torch.Tensor          # i64 scalar
+    ordinals: torch.Tensor         # i32 [k]   which state-dict entries changed (receiver key order)
+    nnz_per_tensor: torch.Tensor   # i32 [k]
+    rows: torch.Tensor             # u8 / i32 / i64 [sum nnz]  absolute or delta-encoded
+    cols: torch.Tensor
+    values: torch.Tensor           # u8, the changed values' bytes in the receiver's dtypes
+
+    def to(self, device, non_blocking: bool = False) -> "WeightPatch":
+        return WeightPatch(*[t.to(device=device, non_blocking=non_blocking) for t in self.tensors()])
+
+    def tensors(self) -> list:
+        return [self.version, self.ordinals, self.nnz_per_tensor, self.rows, self.cols, self.values]
+
+
+class PatchBuilder:
+    """Same-device snapshot builder (the reference's GPUSnapshotPatchBuilder)."""
+
+    def __init__(self, snapshot: Optional[dict], ordered_keys: list, param_names_need_sync: list, original_shapes: dict,
+                 transport_device, delta_encoding: bool):
+        if not param_names_need_sync:
+            raise ValueError("param_names_need_sync must not be empty")
+        if not ordered_keys:
+            raise ValueError("ordered_keys must not be empty")
+        self.snapshot, self.ordered_keys = snapshot, ordered_keys
+        self.param_names_need_sync, self.original_shapes = param_names_need_sync, original_shapes
+        self.transport_device = torch.device(transport_device) if transport_device is not None else None
+        self.delta_encoding = bool(delta_encoding)
+        wanted = set(param_names_need_sync)
+        self.param_names_need_sync_ordinals = {k: i for i, k in enumerate(ordered_keys) if k in wanted}
+        self._ws: dict = {}
+
+    # the two index codecs, for callers that hold decoded indices (:290-370); the kernels do both on the fly
+    @staticmethod
+    def delta_encode(rows: torch.Tensor, cols: torch.Tensor):
+        assert rows.numel() > 0, "No indices to encode"
+        assert rows.numel() == cols.numel(), "Rows and columns must have the same number of elements"
+        if rows.numel() == 1:
+            return rows, cols
+        dr, dc = torch.empty_like(rows), torch.empty_like(cols)
+        dr[0], dc[0] = rows[0], cols[0]
+        dr[1:] = rows[1:] - rows[:-1]
+        dc[1:] = torch.where(rows[1:] == rows[:-1], cols[1:] - cols[:-1], cols[1:])
+        return dr, dc
+
+    @staticmethod
+    def delta_decode(rows_delta: torch.Tensor, cols_delta: torch.Tensor):
+        if rows_delta.numel() == 0:
+            raise ValueError("No indices to decode")
+        if rows_delta.numel() != cols_delta.numel():
+            raise ValueError("Rows and columns must have the same number of elements")
+        rows = torch.cumsum(rows_delta, dim=0, dtype=torch.int64)
+        start = torch.zeros_like(rows_delta, dtype=torch.bool)
+        start[0] = True
+        start[1:] = rows_delta[1:] != 0
+        idx = torch.arange(rows_delta.numel(), device=rows_delta.device, dtype=torch.int64)
+        seg = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), dim=0).values
+        cum = torch.cumsum(cols_delta, dim=0, dtype=torch.int64)
+        return rows, cum - (cum - cols_delta)[seg]
+
+    def _workspace(self, dev, nbytes: int) -> torch.Tensor:
+        ws = self._ws.get(dev)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[dev] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws
+
+    @torch.no_grad()
+    def create_patch(self, state_dict: dict, version):
+        if set(state_dict.keys()) != set(self.ordered_keys):
+            raise ValueError("State dict keys do not match snapshot keys")
+        if self.snapshot is None:  # an inactive sender still answers, with an empty patch (:658-669)
+            return EmptyWeightPatch(torch.as_tensor(version, dtype=torch.int64, device=self.transport_device))
+        lib = _lib.load()
+        staged = []  # (ordinal, snapshot 2-D view, value 2-D view, nnz counter, workspace)
+        dev = None
+        for name in self.param_names_need_sync:
+            value = state_dict[name]
+            if value.shape != self.original_shapes[name]:
+                raise ValueError(f"Shape mismatch for key {name}: expected {self.original_shapes[name]}, got {value.shape}")
+            value2d, _ = as_coo_2d_view(value.detach())
+            snap = self.snapshot[name]
+            if not value2d.is_cuda or not snap.is_cuda:
+                raise ValueError(f"PatchBuilder requires sender tensors and snapshots on the accelerator (key={name})")
+            if snap.device != value2d.device:
+                raise ValueError(f"GPU snapshot and state tensor must be on the same accelerator (key={name})")
+            dev = snap.device
+            value2d = value2d.contiguous()
+            try:
+                vcode, scode = _dtype_code(value2d.dtype), _dtype_code(snap.dtype)
+                supported = vcode == scode or (vcode == _lib.DTYPE_F32 and scode in (_lib.DTYPE_BF16, _lib.DTYPE_F16))
+            except (RlxError, KeyError):
+                supported = False
+            if not supported:  # rare dtype pairs: cast first (one extra pass), then the same-dtype kernels
+                value2d = value2d.to(snap.dtype)
+                vcode = scode = _dtype_code(snap.dtype)
+            n = value2d.numel()
+            if n == 0:
+                continue
+            nbytes = lib.rlx_patch_workspace_bytes(n)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)  # one per tensor: all scans run before the first readback
+            nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rlx_patch_scan(value2d.data_ptr(), vcode, snap.data_ptr(), scode, n, ws.data_ptr(), nbytes,
+                                              nnz.data_ptr(), _stream_ptr(dev)), "rlx_patch_scan")
+            staged.append((self.param_names_need_sync_ordinals[name], snap, value2d, vcode, scode, nnz, ws))
+        if dev is None:
+            raise RuntimeError("Snapshot contains no tensors")
+        counts = torch.cat([s[5] for s in staged]).tolist() if staged else []  # ONE readback for the whole state dict
+        ords, nnzs, rows_l, cols_l, vals_l = [], [], [], [], []
+        maxima = torch.zeros(2, dtype=torch.int64, device=dev)
+        for (ordinal, snap, value2d, vcode, scode, _, ws), nnz in zip(staged, counts):
+            if nnz == 0:
+                continue
+            rows = torch.empty(nnz, dtype=torch.int64, device=dev)
+            cols = torch.empty(nnz, dtype=torch.int64, device=dev)
+            vals = torch.empty(nnz, dtype=snap.dtype, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rlx_patch_emit(value2d.data_ptr(), vcode, snap.data_ptr(), scode, value2d.numel(),
+                                              snap.shape[1], int(self.delta_encoding), ws.data_ptr(), rows.data_ptr(),
+                                              cols.data_ptr(), vals.data_ptr(), maxima.data_ptr(), _stream_ptr(dev)),
+                           "rlx_patch_emit")
+            ords.append(ordinal), nnzs.append(nnz), rows_l.append(rows), cols_l.append(cols)
+            vals_l.append(vals.view(torch.uint8))
+        tdev = self.transport_device or dev
+        if not rows_l:
+            return EmptyWeightPatch(torch.tensor(version, dtype=torch.int64, device=tdev))
+        max_r, max_c = maxima.tolist()  # the reference reads .max().item() of the concatenated indices here
+        return WeightPatch(
+            version=torch.tensor(version, dtype=torch.int64, device=tdev),
+            ordinals=torch.tensor(ords, dtype=torch.int32, device=tdev),
+            nnz_per_tensor=torch.tensor(nnzs, dtype=torch.int32, device=tdev),
+            rows=torch.cat(rows_l).to(_index_dtype_for(max_r)).to(tdev),
+            cols=torch.cat(cols_l).to(_index_dtype_for(max_c)).to(tdev),
+            values=torch.cat(vals_l).to(tdev))
+
+
+class PatchWeightSyncer:
+    """init_receiver / init_sender / sync / apply with the reference's semantics; send / recv are plain callables (or
+    awaitables are not needed here: workers of one rank share a process and cross-rank transport is a collective)."""
+
+    def __init__(self, snapshot_device="cuda", transport_device=None, delta_encoding: bool = True,
+                 compression_algorithm: str = "none"):
+        if compression_algorithm != "none":
+            raise NotImplementedError("only compression_algorithm='none' exists on MI355X (nvCOMP is NVIDIA-only)")
+        if torch.device(snapshot_device).type != "cuda":
+            raise NotImplementedError("the HIP patch builder keeps its snapshot on the accelerator (snapshot_device='cuda')")
+        self.snapshot = None
+        self.ordered_keys: Optional[list] = None
+        self.original_shapes: Optional[dict] = None
+        self.patch_builder: Optional[PatchBuilder] = None
+        self.delta_encoding = bool(delta_encoding)
+        self.transport_device = None if transport_device is None else torch.device(transport_device)
+        self._sender_initialized = self._receiver_initialized = False
+
+    def sender_initialized(self) -> bool:
+        return self._sender_initialized
+
+    def receiver_initialized(self) -> bool:
+        return self._receiver_initialized
+
+    def init_receiver(self, state_dict: dict, recv: Optional[Callable], send: Callable) -> None:
+        assert not self._receiver_initialized, "Receiver already initialized"
+        if state_dict is None:
+            raise ValueError("PatchWeightSyncer receiver init requires a state_dict")
+        self.ordered_keys, self.original_shapes, dtypes = [], {}, {}
+        for key, tensor in state_dict.items():
+            view, shape = as_coo_2d_view(tensor)
+            self.ordered_keys.append(key)
+            self.original_shapes[key] = shape
+            dtypes[key] = view.dtype
+        send({"ordered_keys": self.ordered_keys, "original_shapes": self.original_shapes, "receiver_dtypes": dtypes})
+        self._receiver_initialized = True
+
+    @torch.no_grad()
+    def init_sender(self, state_dict: dict, param_names_need_sync: list, send: Optional[Callable], recv: Callable,
+                    is_sender: bool = True) -> None:
+        assert not self._sender_initialized, "Sender already initialized"
+        meta = recv()
+        self.ordered_keys, self.original_shapes = meta["ordered_keys"], meta["original_shapes"]
+        dtypes = meta["receiver_dtypes"]
+        if set(state_dict.keys()) != set(self.ordered_keys):
+            raise ValueError("Sender state dict keys do not match receiver keys")
+        snapshot = {}
+        for key in param_names_need_sync:
+            view, shape = as_coo_2d_view(state_dict[key].detach())
+            if shape != self.original_shapes[key]:
+                raise ValueError(f"Shape mismatch for key {key}: expected {self.original_shapes[key]}, got {shape}")
+            if is_sender:
+                snapshot[key] = view.to(dtype=dtypes[key], copy=True).contiguous()
+        self.snapshot = snapshot if is_sender else None
+        self.patch_builder = PatchBuilder(self.snapshot, self.ordered_keys, list(param_names_need_sync),
+                                          self.original_shapes, self.transport_device, self.delta_encoding)
+        self._sender_initialized = True
+
+    def create_patch(self, state_dict: dict, version):
+        if self.patch_builder is None:
+            raise RuntimeError("Sender not initialized")
+        return self.patch_builder.create_patch(state_dict, version)
+
+    def sync(self, state_dict: dict, send: Callable, version) -> None:
+        send(self.create_patch(state_dict, version))
+
+    @torch.no_grad()
+    def apply(self, model_or_state_dict, recv: Callable) -> int:
+        assert self.ordered_keys is not None and self.original_shapes is not None, "Snapshot info not initialized"
+        payload = recv()
+        if isinstance(payload, EmptyWeightPatch):
+            return int(payload.version.item())
+        state = model_or_state_dict.state_dict() if hasattr(model_or_state_dict, "state_dict") else model_or_state_dict
+        nnzs = payload.nnz_per_tensor.tolist()
+        ords = payload.ordinals.tolist()
+        total = sum(nnzs)
+        assert payload.rows.numel() == payload.cols.numel() == total, "Patch payload size does not match nnz_per_tensor"
+        lib = _lib.load()
+        off = voff = 0
+        for ordinal, nnz in zip(ords, nnzs):
+            key = self.ordered_keys[ordinal]
+            target, _ = as_coo_2d_view(state[key])
+            assert state[key].shape == self.original_shapes[key], f"Shape mismatch for key {key}"
+            if not target.is_cuda or not target.is_contiguous():
+                raise RlxError(f"patch apply needs contiguous accelerator tensors (key={key})")
+            dev = target.device
+            rows = payload.rows[off:off + nnz].to(dev)
+            cols = payload.cols[off:off + nnz].to(dev)
+            es = target.element_size()
+            vals = payload.values[voff:voff + nnz * es].to(dev)
+            off, voff = off + nnz, voff + nnz * es
+            ws_bytes = lib.rlx_patch_apply_workspace_bytes(nnz)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rlx_patch_apply(target.data_ptr(), _dtype_code(target.dtype), target.shape[0], target.shape[1],
+                                               rows.data_ptr(), _INDEX_CODES[rows.dtype], cols.data_ptr(),
+                                               _INDEX_CODES[cols.dtype], int(self.delta_encoding), vals.data_ptr(), nnz,
+                                               ws.data_ptr(), ws_bytes, _stream_ptr(dev)), "rlx_patch_apply")
+        return int(payload.version.item())

@@ -170,6 +170,26 @@ def grpo_from_scores(scores: torch.Tensor, loss_mask: torch.Tensor, group_size: 
     return adv
 
 
+def reward_filter_mask(rewards: torch.Tensor, loss_mask: Optional[torch.Tensor], group_size: int, lower: float,
+                       upper: float) -> torch.Tensor:
+    """rewards [n, B, C] f32 (+ loss_mask [n, B, C] bool) -> the filtered loss mask (bool): [n, B, C] with a mask,
+    [n, B, 1] without (embodied_fsdp_actor_worker.py:235-281)."""
+    dev = _dev(rewards, loss_mask)
+    n, B, C = _nbc(rewards, "rewards")
+    r = _as_f32(rewards, "rewards")
+    m = _as_u8(loss_mask)
+    if m is not None and m.shape != r.shape:
+        raise RlxError("loss_mask must have the shape of rewards")
+    if group_size < 1 or B % group_size != 0:
+        raise AssertionError(f"batch {B} not divisible by group_size {group_size}")
+    out = torch.empty((n, B, C if m is not None else 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rlx_reward_filter_mask(r.data_ptr(), _ptr(m), out.data_ptr(), n, B, C, int(group_size),
+                                                      float(lower), float(upper), _stream_ptr(dev)),
+                   "rlx_reward_filter_mask")
+    return out.view(torch.bool)
+
+
 def episode_scores(rewards: torch.Tensor, dones: torch.Tensor) -> torch.Tensor:
     """rewards [n,B,C], dones [n+1,B,C] -> per-env first-episode return [B] (utils.py:134-152)."""
     lib = _lib.load()

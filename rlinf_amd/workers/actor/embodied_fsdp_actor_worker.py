@@ -91,6 +91,14 @@ class EmbodiedFSDPActor(Worker):
                 loss_mask = loss_mask.any(dim=-1, keepdim=True)
                 loss_mask_sum = loss_mask_sum[..., -1:]
             batch["loss_mask"], batch["loss_mask_sum"] = loss_mask, loss_mask_sum
+        alg = self.cfg.algorithm
+        if alg.get("filter_rewards", False):  # :235-281: drop prompt groups whose mean reward is out of bounds
+            mask = batch.get("loss_mask")
+            rewards = batch["rewards"].contiguous()
+            if mask is not None and mask.shape != rewards.shape:
+                mask = mask.expand_as(rewards).contiguous()
+            batch["loss_mask"] = ops.reward_filter_mask(rewards, mask, int(alg.group_size), float(alg.rewards_lower_bound),
+                                                        float(alg.rewards_upper_bound))
         return batch
 
     def compute_advantages_and_returns(self) -> dict:
@@ -150,8 +158,11 @@ class EmbodiedFSDPActor(Worker):
             names.append("returns")
             src.append(b["returns"])
         if b.get("loss_mask") is not None:
-            names += ["loss_mask", "loss_mask_sum"]
-            src += [b["loss_mask"], b["loss_mask_sum"].contiguous()]
+            names.append("loss_mask")
+            src.append(b["loss_mask"])
+        if b.get("loss_mask_sum") is not None:
+            names.append("loss_mask_sum")
+            src.append(b["loss_mask_sum"].contiguous())
         flat = [t.reshape(N, *t.shape[2:]).contiguous() for t in src]
         key = ("shuf", N)
         if key not in self._ws:

@@ -207,3 +207,26 @@ def test_scaled_buffer_streaming_vs_segmented_agree():
         adv, ret = ops.gae_scan(rc, vc, dc, None, 0.99, 0.95, normalize_advantages=False, variant=variant)
         torch.testing.assert_close(adv, base_adv, rtol=RTOL, atol=ATOL)
         torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+@pytest.mark.parametrize("masked", [False, True])
+def test_reward_filter_mask(C, masked):
+    """embodied_fsdp_actor_worker.py:235-281 restated with the reference's own tensor expressions."""
+    from rlinf_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, B, G = 17, 64, 8
+    rewards = torch.rand(n, B, C, generator=g)
+    rewards[:, 8:16] *= 3.0   # one group clearly above the upper bound
+    rewards[:, 24:32] *= 0.1  # one clearly below the lower bound
+    lm = (torch.rand(n, B, C, generator=g) < 0.8) if masked else None
+    lo, hi = 0.2 * n * C, 0.7 * n * C
+    r = rewards * lm if masked else rewards
+    per_env = r.transpose(0, 1).reshape(B, -1).reshape(B // G, G, -1).sum(dim=-1)
+    keep = ((per_env.mean(dim=1) >= lo) & (per_env.mean(dim=1) <= hi)).repeat_interleave(G)
+    want = keep.unsqueeze(0).expand(n, -1).unsqueeze(-1)
+    want = (want & lm) if masked else want
+    got = ops.reward_filter_mask(rewards.cuda(), None if lm is None else lm.cuda(), G, lo, hi)
+    assert got.dtype == torch.bool and got.shape == want.shape
+    assert torch.equal(got.cpu(), want)
+    assert 0 < int(keep.sum()) < B

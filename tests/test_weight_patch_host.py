@@ -1,0 +1,109 @@
+"""Weight-patch wire format without a GPU: the oracle against the committed reference patches (bit for bit), against
+the real reference classes where the reference tree exists, the host-side codecs of the mirror, and the known-answer
+cases of the reference's own unit tests (tests/unit_tests/test_weight_syncer.py:284-327 -- as_coo_2d_view ranks,
+downscale dtype selection)."""
+
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import patch_oracle as PO
+from oracle.make_golden import patch_states
+from rlinf_amd.hybrid_engines.weight_syncer import (PatchBuilder, PatchWeightSyncer, as_coo_2d_view,
+                                                    downscale_nonnegative_indices)
+
+FIELDS = ("version", "ordinals", "nnz_per_tensor", "rows", "cols", "values")
+
+
+def _snapshot(before, narrow):
+    return {k: PO.coo_2d_view(v).to(torch.bfloat16 if (narrow and v.dtype == torch.float32) else v.dtype, copy=True)
+            for k, v in before.items()}
+
+
+def test_oracle_reproduces_reference_patches():
+    for case in torch.load(os.path.join(GOLDEN_DIR, "weight_patch.pt"), weights_only=False):
+        p = case["params"]
+        before, after = patch_states(p["seed"])
+        snap = _snapshot(before, p["narrow"])
+        for version, want in zip((11, 12), case["patches"]):
+            got = PO.create_patch(after, snap, p["keys"], p["names"], version, p["delta"])
+            for f in FIELDS:
+                assert got[f].dtype == want[f].dtype and torch.equal(got[f], want[f]), (p, version, f)
+        # the receiver side: applying the first patch to a copy of `before` reproduces `after` in the receiver's dtypes
+        target = {k: v.clone() for k, v in _snapshot(before, p["narrow"]).items()}
+        assert PO.apply_patch(target, p["keys"], case["patches"][0], p["delta"]) == 11
+        for k, v in after.items():
+            want = PO.coo_2d_view(v).to(target[k].dtype)
+            same = (target[k] == want) | (target[k] != target[k]) & (want != want) if want.is_floating_point() else target[k] == want
+            assert bool(same.all()), k
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("delta", [True, False])
+def test_oracle_vs_reference_builder(delta):
+    from oracle import reference_loader
+    if not reference_loader.available():
+        pytest.skip("reference tree not present")
+    m = reference_loader.load_weight_syncer()
+    before, after = patch_states(7)
+    keys = list(before)
+    names = list(reversed(keys))
+    snap_ref, snap_or = _snapshot(before, False), _snapshot(before, False)
+    builder = m.GPUSnapshotPatchBuilder(snap_ref, keys, names, {k: v.shape for k, v in before.items()},
+                                        torch.device("cpu"), delta)
+    for version in (3, 4):
+        want = builder.create_patch(after, version)
+        got = PO.create_patch(after, snap_or, keys, names, version, delta)
+        for f in FIELDS:
+            a = getattr(want, f)
+            assert a.dtype == got[f].dtype and torch.equal(a, got[f]), (version, f)
+    r, c = torch.tensor([0, 0, 2, 2, 2, 5]), torch.tensor([1, 4, 0, 3, 9, 2])
+    for fn_ref, fn_or in ((m.PatchBuilder.delta_encode, PO.delta_encode),):
+        assert all(torch.equal(x, y) for x, y in zip(fn_ref(r, c), fn_or(r, c)))
+    enc = PO.delta_encode(r, c)
+    assert all(torch.equal(x, y) for x, y in zip(m.PatchBuilder.delta_decode(*enc), PO.delta_decode(*enc)))
+    assert m.downscale_nonnegative_indices(torch.tensor([0, 256])).dtype == PO.downscale(torch.tensor([0, 256])).dtype
+
+
+def test_mirror_codecs_match_oracle():
+    g = torch.Generator().manual_seed(0)
+    flat = torch.sort(torch.randperm(5000, generator=g)[:700]).values
+    rows, cols = flat // 50, flat % 50
+    enc = PatchBuilder.delta_encode(rows, cols)
+    want = PO.delta_encode(rows, cols)
+    assert torch.equal(enc[0], want[0]) and torch.equal(enc[1], want[1])
+    dec = PatchBuilder.delta_decode(*enc)
+    assert torch.equal(dec[0], rows) and torch.equal(dec[1], cols)
+    one = PatchBuilder.delta_encode(rows[:1], cols[:1])
+    assert torch.equal(one[0], rows[:1]) and torch.equal(one[1], cols[:1])
+    with pytest.raises(ValueError, match="No indices to decode"):
+        PatchBuilder.delta_decode(rows[:0], cols[:0])
+
+
+def test_known_answers_of_the_reference_unit_tests():
+    # as_coo_2d_view (reference tests/unit_tests/test_weight_syncer.py:284-309)
+    for t, shape in ((torch.tensor(3.0), (1, 1)), (torch.arange(5.), (1, 5)), (torch.arange(6.).view(2, 3), (2, 3)),
+                     (torch.arange(24.).view(2, 3, 4), (2, 12))):
+        view, orig = as_coo_2d_view(t)
+        assert view.shape == shape and orig == t.shape
+    with pytest.raises(ValueError, match="can be flattened as a view"):
+        as_coo_2d_view(torch.arange(24.).view(2, 3, 4).transpose(1, 2))
+    # downscale_nonnegative_indices (:312-327)
+    assert downscale_nonnegative_indices(torch.empty(0, dtype=torch.int64)).dtype == torch.uint8
+    assert downscale_nonnegative_indices(torch.tensor([0, 7, 255])).dtype == torch.uint8
+    assert downscale_nonnegative_indices(torch.tensor([0, 256, 1024])).dtype == torch.int32
+    assert downscale_nonnegative_indices(torch.tensor([0, torch.iinfo(torch.int32).max + 1])).dtype == torch.int64
+
+
+def test_syncer_argument_checks():
+    with pytest.raises(NotImplementedError, match="nvCOMP"):
+        PatchWeightSyncer(compression_algorithm="nvcomp_lz4")
+    with pytest.raises(NotImplementedError, match="accelerator"):
+        PatchWeightSyncer(snapshot_device="cpu")
+    with pytest.raises(ValueError, match="must not be empty"):
+        PatchBuilder({}, ["a"], [], {}, None, True)
+    s = PatchWeightSyncer()
+    with pytest.raises(RuntimeError, match="Sender not initialized"):
+        s.create_patch({}, 1)
