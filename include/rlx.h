@@ -566,6 +566,17 @@ int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, float* adva
                      int group_size, float eps, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * t5  gae_seq  <- adv_type "gae" on reasoning batches: preprocess_reasoning_advantages_inputs rlinf/algorithms/utils.py:177-262
+ *                 + compute_gae_advantages_and_returns rlinf/algorithms/advantages.py:24-86
+ *                 + postprocess_reasoning_advantages_outputs rlinf/algorithms/utils.py:265-277
+ *   values [bsz, seq] f32, rewards [bsz] f32 (the scalar reward sits on the LAST position of the row, as the reference
+ *   places it) -> advantages, returns [bsz, seq] f32, un-normalised; gamma_lambda = (float)((double)gamma * gae_lambda).
+ *   Normalisation is rlx_masked_standardize over the [bsz, seq] buffer with the loss mask (layout-agnostic).
+ * ------------------------------------------------------------------------------------------ */
+int rlx_gae_seq(const float* values, const float* rewards, float* advantages, float* returns, int64_t bsz, int64_t seq,
+                float gamma, float gamma_lambda, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * t4  categorical_sample (K2)  <- OpenVLA-OFT's discrete action head: _discrete_prediction's sampling branch and
  *       _compute_logprobs_and_entropy, rlinf/models/embodiment/openvla_oft/official/openvla_oft_action_model.py:258-287,363-414
  *   logits   n rows of K <= 1024 action-bin logits (the n_action_bins window of the vocabulary; rows addressed like t1,

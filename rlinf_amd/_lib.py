@@ -199,6 +199,7 @@ PROTOTYPES = {
     "rlx_patch_apply_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_patch_apply": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64,
                                 c_void_p, c_size_t, c_void_p]),
+    "rlx_gae_seq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p]),
     "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
 }
 

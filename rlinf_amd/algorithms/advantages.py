@@ -92,6 +92,27 @@ def _native_grpo_reasoning(*, rewards, loss_mask, group_size, **kwargs):
     return _u.unstage(adv, loss_mask), None
 
 
+def _native_gae_reasoning(*, rewards, loss_mask, values=None, gamma=1.0, gae_lambda=1.0, normalize_advantages=True,
+                          normalize_returns=False, **kwargs):
+    """Reasoning GAE on [bsz, seq] tensors: (advantages, returns) -- the scan runs along the contiguous axis, nothing is
+    transposed or padded (utils.py:177-277 + advantages.py:24-86)."""
+    if rewards.ndim != 1:
+        raise AssertionError(f"Unsupported reward shape {rewards.shape}")
+    if values is None:  # critic-free GAE forces gamma = lambda = 1 and delta = r: the generic route handles it
+        return None
+    if values.ndim != 2:
+        raise AssertionError(f"Unsupported values shape {values.shape}")
+    dev = _u.compute_device(rewards, loss_mask, values)
+    adv, ret = token_ops.gae_seq(_u.stage(values, dev).float(), _u.stage(rewards, dev).float(), gamma, gae_lambda)
+    mask = _u.stage(loss_mask, dev)
+    if normalize_advantages:
+        ops.masked_standardize_(adv, mask)
+    if normalize_returns:
+        ops.masked_standardize_(ret, mask)
+    return _u.unstage(adv, values), _u.unstage(ret, values)
+
+
 _mark_native_adv("gae", _native_gae)
 _mark_native_adv("grpo", _native_grpo)
+_mark_native_adv("gae", _native_gae_reasoning, task_type="reasoning")
 _mark_native_adv("grpo", _native_grpo_reasoning, task_type="reasoning")

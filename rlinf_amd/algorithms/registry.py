@@ -113,7 +113,9 @@ def calculate_adv_and_returns(**kwargs):
         return _u.postprocess_embodied_advantages_outputs(advantages=advantages, returns=returns, **kwargs)
     native = _NATIVE_ADV_REASONING.get(adv_type.lower())
     if native is not None:
-        return native(**kwargs)  # reads the [bsz, seq] layout directly: no transposes, no copies
+        out = native(**kwargs)  # reads the [bsz, seq] layout directly: no transposes, no copies
+        if out is not None:
+            return out
     kwargs = _u.preprocess_reasoning_advantages_inputs(**kwargs)
     advantages, returns = fn(**kwargs)
     return _u.postprocess_reasoning_advantages_outputs(advantages, returns)

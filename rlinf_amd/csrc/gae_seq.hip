@@ -1,0 +1,187 @@
+// gae_seq.hip -- GAE for reasoning (LLM PPO) batches in their own [bsz, seq] layout, gfx950.
+//
+// Replaces, for adv_type = "gae" on task_type = "reasoning":
+//   preprocess_reasoning_advantages_inputs   rlinf/algorithms/utils.py:177-262  (transposes to [seq, bsz], a [seq, bsz]
+//       reward matrix that is zero except its last row, a zero bootstrap row under the values, dones = last row only)
+//   compute_gae_advantages_and_returns       rlinf/algorithms/advantages.py:24-86 (a Python loop of seq iterations)
+//   postprocess_reasoning_advantages_outputs rlinf/algorithms/utils.py:265-277  (transposes back, contiguous copies)
+// With that shaping the recurrence of sequence b is, for t = seq-1 .. 0,
+//     delta_t = (t == seq-1 ? r_b : gamma * V[b,t+1]) - V[b,t]        g_t = delta_t + (gamma*lambda) * g_{t+1},  g_seq = 0
+//     returns = g + V,   advantages = returns - V
+// i.e. a first-order linear recurrence ALONG THE CONTIGUOUS AXIS: a wavefront segmented scan.  One workgroup per sequence
+// walks it in segments of up to SEG tokens from the end; a segment is staged in LDS with coalesced loads, every lane
+// owns a contiguous chunk, reduces it to the affine map g_in -> K * g_in + G, the 256 maps are composed right-to-left
+// through LDS, and each lane then replays its chunk sequentially from its exact carry-in, writing through LDS so that the
+// stores are coalesced too.  13 B per token (values 4 + advantages 4 + returns 4 + mask 1 in the normalisation).
+//
+// The replay uses the reference's own operations in its order, so a result differs from the sequential loop only
+// through the carry-in of its chunk (affine composition instead of a chain: a few f32 ulp).
+
+#include "rlx_common.h"
+
+namespace rlx {
+namespace {
+
+constexpr int ST = 512;    // threads per sequence
+constexpr int SEG = 8192;  // tokens staged per pass: 2 * (SEG + SEG/32 padding) floats = 66 KB of LDS
+
+__device__ __forceinline__ int pad(int i) { return i + (i >> 5); }  // chunk starts land in distinct banks
+
+__global__ __launch_bounds__(ST) void gae_seq_kernel(const float* __restrict__ values, const float* __restrict__ rewards,
+                                                     float* __restrict__ adv, float* __restrict__ ret, int seq,
+                                                     float gamma, float gamma_lambda) {
+    extern __shared__ float lds[];
+    float* sv = lds;                      // values of the segment, plus one look-ahead value
+    const int seg_cap = seq < SEG ? seq : SEG;
+    float* sg = lds + pad(seg_cap + 1) + 1;  // g of the segment (LDS is sized for the longest segment of THIS launch)
+    __shared__ float sK[ST], sG[ST], sIn[ST];
+    const long long row = blockIdx.x;
+    const float* v = values + row * (long long)seq;
+    const float r = rewards[row];
+    float carry = 0.f;                    // g at the first token AFTER the current segment
+    for (int hi = seq; hi > 0; hi -= SEG) {
+        const int lo = hi > SEG ? hi - SEG : 0, len = hi - lo;
+        // stage the segment: every global load is unconditional (clamped address) and issued before the first LDS store
+        // -- a bounds test around each load would put an s_waitcnt vmcnt(0) between them (2 us of HBM latency apiece)
+        const bool vec = ((reinterpret_cast<uintptr_t>(v + lo) & 15u) == 0) && (len % 4 == 0);
+        if (vec) {
+            const int nq = len / 4;
+            const float4* v4 = reinterpret_cast<const float4*>(v + lo);
+            constexpr int QI = SEG / 4 / ST;  // 8
+            float4 q[QI];
+#pragma unroll
+            for (int k = 0; k < QI; ++k) q[k] = v4[min(k * ST + (int)threadIdx.x, nq - 1)];
+#pragma unroll
+            for (int k = 0; k < QI; ++k) {
+                const int qi = k * ST + threadIdx.x;
+                if (qi < nq) {
+                    sv[pad(4 * qi)] = q[k].x, sv[pad(4 * qi + 1)] = q[k].y;
+                    sv[pad(4 * qi + 2)] = q[k].z, sv[pad(4 * qi + 3)] = q[k].w;
+                }
+            }
+        } else {
+            constexpr int SI = 8;
+            for (int i0 = 0; i0 < len; i0 += SI * ST) {
+                float x[SI];
+#pragma unroll
+                for (int k = 0; k < SI; ++k) x[k] = v[lo + min(i0 + k * ST + (int)threadIdx.x, len - 1)];
+#pragma unroll
+                for (int k = 0; k < SI; ++k) {
+                    const int i = i0 + k * ST + threadIdx.x;
+                    if (i < len) sv[pad(i)] = x[k];
+                }
+            }
+        }
+        if (threadIdx.x == 0) sv[pad(len)] = hi < seq ? v[hi] : 0.f;  // the look-ahead V[hi] (0 past the end)
+        __syncthreads();
+        const int per = (len + ST - 1) / ST;
+        // lane tid owns the chunk (ST-1-tid): lane order = the order in which the recurrence visits the chunks
+        const int chunk = ST - 1 - (int)threadIdx.x;
+        const int c0 = min(len, chunk * per), c1 = min(len, c0 + per);
+        // chunk -> affine map g_in -> K * g_in + G
+        float K = 1.f, G = 0.f;
+        {
+            float vnext = sv[pad(c1)];
+            for (int i = c1 - 1; i >= c0; --i) {
+                const int t = lo + i;
+                const float vi = sv[pad(i)];
+                const float nxt = (t == seq - 1) ? r : fmul(gamma, vnext);
+                const float delta = fsub(nxt, vi);
+                const float k = (t == seq - 1) ? 0.f : gamma_lambda;  // ~dones[seq] cuts the recurrence at the end
+                G = fadd(delta, fmul(k, G));
+                K = fmul(K, k);
+                vnext = vi;
+            }
+        }
+        // exclusive scan of the maps in lane order (later-applied map on the left): wave shuffles, then the 4 wave totals
+        float iK = K, iG = G;
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float oK = __shfl_up(iK, off, 64), oG = __shfl_up(iG, off, 64);
+            if (lane >= off) {
+                iG = fadd(iG, fmul(iK, oG));  // mine after theirs: K_m K_o g + (K_m G_o + G_m)
+                iK = fmul(iK, oK);
+            }
+        }
+        if (lane == 63) sK[wid] = iK, sG[wid] = iG;
+        __syncthreads();
+        float bK = 1.f, bG = 0.f;  // composition of all earlier waves
+        for (int w = 0; w < wid; ++w) {
+            bG = fadd(sG[w], fmul(sK[w], bG));
+            bK = fmul(sK[w], bK);
+        }
+        float eK = __shfl_up(iK, 1, 64), eG = __shfl_up(iG, 1, 64);  // exclusive within the wave
+        if (lane == 0) eK = 1.f, eG = 0.f;
+        const float tK = fmul(eK, bK), tG = fadd(eG, fmul(eK, bG));   // everything visited before this chunk
+        const float g_in = fadd(tG, fmul(tK, carry));
+        if (threadIdx.x == ST - 1) {  // the last lane's inclusive map gives g at the segment's first token
+            const float aK = fmul(iK, bK), aG = fadd(iG, fmul(iK, bG));
+            sIn[0] = fadd(aG, fmul(aK, carry));
+        }
+        __syncthreads();
+        {
+            float g = g_in, vnext = sv[pad(c1)];
+            for (int i = c1 - 1; i >= c0; --i) {
+                const int t = lo + i;
+                const float vi = sv[pad(i)];
+                const float nxt = (t == seq - 1) ? r : fmul(gamma, vnext);
+                const float delta = fsub(nxt, vi);
+                const float k = (t == seq - 1) ? 0.f : gamma_lambda;
+                g = fadd(delta, fmul(k, g));
+                sg[pad(i)] = g;
+                vnext = vi;
+            }
+        }
+        carry = sIn[0];
+        __syncthreads();
+        float* ro = ret + row * (long long)seq + lo;
+        float* ao = adv + row * (long long)seq + lo;
+        if (vec && ((reinterpret_cast<uintptr_t>(ro) | reinterpret_cast<uintptr_t>(ao)) & 15u) == 0) {
+            for (int qi = threadIdx.x; qi < len / 4; qi += ST) {
+                float rt[4], at[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gi = sg[pad(4 * qi + j)], vi = sv[pad(4 * qi + j)];
+                    rt[j] = fadd(gi, vi);       // returns[t] = gae + values[t]
+                    at[j] = fsub(rt[j], vi);    // advantages = returns - values[:-1]
+                }
+                reinterpret_cast<float4*>(ro)[qi] = make_float4(rt[0], rt[1], rt[2], rt[3]);
+                reinterpret_cast<float4*>(ao)[qi] = make_float4(at[0], at[1], at[2], at[3]);
+            }
+        } else {
+            for (int i = threadIdx.x; i < len; i += ST) {
+                const float gi = sg[pad(i)], vi = sv[pad(i)];
+                const float rt = fadd(gi, vi);
+                ro[i] = rt;
+                ao[i] = fsub(rt, vi);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* advantages, float* returns, int64_t bsz,
+                           int64_t seq, float gamma, float gamma_lambda, rlx_stream_t stream) {
+    RLX_REQUIRE(bsz >= 0 && seq >= 0 && bsz < (1ll << 31) && seq < (1ll << 31), "rlx_gae_seq: bad sizes");
+    if (bsz == 0 || seq == 0) return RLX_OK;
+    RLX_REQUIRE(values && rewards && advantages && returns, "rlx_gae_seq: NULL argument");
+    static bool attr_set = false;
+    const size_t lds_max = (size_t)(2 * (SEG + 1 + (SEG + 1) / 32) + 8) * sizeof(float);
+    const int seg_cap = (int)(seq < SEG ? seq : SEG);
+    const size_t lds_bytes = (size_t)(2 * (seg_cap + 1 + (seg_cap + 1) / 32) + 8) * sizeof(float);
+    if (!attr_set) {
+        RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gae_seq_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gae_seq_kernel, dim3((unsigned)bsz), dim3(ST), lds_bytes, static_cast<hipStream_t>(stream), values,
+                       rewards, advantages, returns, (int)seq, gamma, gamma_lambda);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}

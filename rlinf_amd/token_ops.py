@@ -246,3 +246,18 @@ def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = Non
                                                       _ptr(logprob), _ptr(actions), _stream_ptr(dev)),
                    "rlx_categorical_sample")
     return tokens, logprob, actions
+
+
+def gae_seq(values: torch.Tensor, rewards: torch.Tensor, gamma: float = 1.0, gae_lambda: float = 1.0):
+    """Reasoning GAE in the [bsz, seq] layout: values [bsz, seq] f32, rewards [bsz] -> (advantages, returns), un-normalised."""
+    dev = _dev(values, rewards)
+    if values.dim() != 2 or rewards.numel() != values.shape[0]:
+        raise RlxError("gae_seq: values [bsz, seq], rewards [bsz]")
+    v = _as_f32(values, "values")
+    r = _as_f32(rewards.reshape(-1), "rewards")
+    bsz, seq = v.shape
+    adv, ret = torch.empty_like(v), torch.empty_like(v)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rlx_gae_seq(v.data_ptr(), r.data_ptr(), adv.data_ptr(), ret.data_ptr(), bsz, seq, float(gamma),
+                                           float(gamma * gae_lambda), _stream_ptr(dev)), "rlx_gae_seq")
+    return adv, ret

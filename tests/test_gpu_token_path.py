@@ -389,3 +389,35 @@ def test_categorical_sample_follows_the_distribution():
     out = head.logprobs_and_entropy(lg, tokens[:4], compute_entropy=True, temperature=1.0)
     out["logprobs"].sum().backward()
     assert lg.grad is not None and float(lg.grad[..., :32064 - 64 - 256].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("seq", [1, 5, 300, 8192, 8193, 20000])
+@pytest.mark.parametrize("gl", [(1.0, 0.95), (0.99, 0.9), (1.0, 1.0)])
+def test_gae_seq_vs_oracle(seq, gl):
+    """Reasoning GAE along the contiguous axis against the reference's shaping + its sequential loop (the oracle's
+    gae_tb on [seq, bsz]); one / several LDS segments, chunked lanes, the reward on the row's last position."""
+    from oracle import ppo_oracle as PO
+    gamma, lam = gl
+    bsz = 6 if seq > 1000 else 32
+    g = torch.Generator().manual_seed(seq)
+    values = torch.randn(bsz, seq, generator=g)
+    rewards = torch.randn(bsz, generator=g)
+    mask = torch.rand(bsz, seq, generator=g) < 0.8
+    pre = TO.preprocess_reasoning(rewards, mask, "gae", values=values)
+    wadv, wret = PO.gae_tb(pre["rewards"], pre["dones"], values=pre["values"], gamma=gamma, gae_lambda=lam,
+                           normalize_advantages=False)
+    adv, ret = token_ops.gae_seq(values.to(DEV), rewards.to(DEV), gamma, lam)
+    # both sides run the recurrence in f32; the reference's chain of seq dependent additions accumulates ~sqrt(seq)
+    # roundings (with gamma*lambda = 1 nothing decays), the kernel's chunked replay accumulates them in another order
+    scale = float(wret.abs().max()) + 1.0
+    atol = (4e-6 + 2e-7 * seq ** 0.5) * scale
+    close(ret, wret.transpose(0, 1), atol, 1e-5, "returns")
+    close(adv, wadv.transpose(0, 1), atol, 1e-5, "advantages")
+    out = registry.calculate_adv_and_returns(task_type="reasoning", adv_type="gae", rewards=rewards.to(DEV),
+                                             loss_mask=mask.to(DEV), values=values.to(DEV), gamma=gamma, gae_lambda=lam,
+                                             normalize_advantages=True)
+    nadv, _ = PO.gae_tb(pre["rewards"], pre["dones"], values=pre["values"], gamma=gamma, gae_lambda=lam,
+                        normalize_advantages=True, loss_mask=pre["loss_mask"])
+    if int(mask.sum()) > 1:
+        close(out[0], nadv.transpose(0, 1), 2e-5 + 10 * atol, 2e-5, "normalised advantages")
+    assert out[0].is_contiguous() and out[1].is_contiguous()
