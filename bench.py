@@ -237,6 +237,23 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     return rows
 
 
+def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936):
+    """The CPU oracle of the token tier (torch CPU ops in the reference's order: cross_entropy log-prob, log_softmax entropy,
+    autograd backward) on a bounded sample of the same shape, all host cores torch picks."""
+    from oracle import token_oracle as TO
+
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(rows, vocab, generator=g) * 4).to(torch.bfloat16).requires_grad_(True)
+    labels = torch.randint(0, vocab, (rows,), generator=g)
+    t0 = time.perf_counter()
+    lp = TO.logprobs_from_logits(x, labels)
+    ent = TO.entropy_from_logits(x)
+    (lp.sum() - 0.01 * ent.float().sum()).backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(rows / dt, 1), "unit": "tokens/s (log-prob + entropy forward and backward)",
+            "cores": torch.get_num_threads(), "kind": "port", "sample": f"{rows} tokens x {vocab} vocab, bf16 logits"}
+
+
 def _pick_cpu_threads(pol, budget_s: float = 6.0):
     """torch's default (one thread per logical core) oversubscribes the small GEMMs of this path badly on a
     many-core host (256 threads: ~2.7 s per rollout step).  Time one minibatch-sized forward at a few thread counts and
@@ -368,6 +385,8 @@ def main():
                 line["roofline_token_tier"] = token_tier_roofline(dev)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            if "roofline_token_tier" in line:
+                line["cpu_baseline_token_tier"] = token_tier_cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if ctx.world_size > 1:

@@ -1,17 +1,16 @@
 """Roofline probe of the token tier: token_logprob fwd / bwd at LLM sizes.
 
-    python tools/bench_token.py [--tokens 8192] [--vocab 151936] [--dtype bf16] [--iters 20] [--cpu-rows 64]
+    python tools/bench_token.py [--tokens 8192] [--vocab 151936] [--dtype bf16] [--iters 20]
 
 Prints one JSON line per kernel: algorithmic bytes (fwd: tokens*vocab*sizeof; bwd: twice that), the average launch
-duration from HIP events on the launch stream, GB/s and the fraction of the 8 TB/s HBM peak.  ``--cpu-rows`` also times
-the CPU oracle (torch CPU ops, the reference's own arithmetic) on that many rows for the cpu_baseline figure.
+duration from HIP events on the launch stream, GB/s and the fraction of the 8 TB/s HBM peak.  (The CPU baseline of
+this tier is timed by bench.py, the only place outside tests/ and smoke() that runs the oracle.)
 """
 
 import argparse
 import json
 import os
 import sys
-import time
 
 import torch
 
@@ -43,7 +42,6 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--mask-frac", type=float, default=1.0, help="fraction of tokens with a non-zero gradient")
     ap.add_argument("--temperature", type=float, default=1.0)
-    ap.add_argument("--cpu-rows", type=int, default=0)
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = "cuda"
@@ -73,18 +71,6 @@ def main():
         res.append(dict(kernel="token_logprob_bwd", entropy=ent, dtype=args.dtype, tokens=N, vocab=V, bytes=by,
                         live_rows=live, us=mean * 1e6, us_min=best * 1e6, us_median=med * 1e6, GBps=by / mean / 1e9,
                         frac=by / mean / HBM_PEAK))
-    if args.cpu_rows:
-        from oracle import token_oracle as TO
-        rows = args.cpu_rows
-        xc = x[:rows].cpu().requires_grad_(True)
-        lc = labels[:rows].cpu()
-        t0 = time.perf_counter()
-        lpc = TO.logprobs_from_logits(xc, lc)
-        entc = TO.entropy_from_logits(xc)
-        (lpc.sum() - 0.01 * entc.float().sum()).backward()
-        dtc = time.perf_counter() - t0
-        res.append(dict(kernel="cpu_oracle_fwd_bwd", rows=rows, threads=torch.get_num_threads(), seconds=dtc,
-                        tokens_per_s=rows / dtc))
     for r in res:
         print(json.dumps(r))
 

@@ -14,7 +14,7 @@ echo "prof $prec rc=$?"; tail -1 gpurun_out/bench_prof_$prec.log | cut -c1-200
 DB=$(ls gpurun_out/prof_bench_$prec/*.db gpurun_out/prof_bench_$prec/*/*.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_stats.py "$DB" > gpurun_out/bench_kernels_$prec.txt 2>&1; head -12 gpurun_out/bench_kernels_$prec.txt; fi
 done
-timeout 600 python tools/bench_token.py --tokens 8192 --vocab 151936 --dtype bf16 --cpu-rows 64 > gpurun_out/token_bench_bf16.jsonl 2>/dev/null; cat gpurun_out/token_bench_bf16.jsonl
+timeout 600 python tools/bench_token.py --tokens 8192 --vocab 151936 --dtype bf16 > gpurun_out/token_bench_bf16.jsonl 2>/dev/null; cat gpurun_out/token_bench_bf16.jsonl
 timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log
 timeout 600 python bench.py --precision 32 --no-cpu-baseline --no-roofline > gpurun_out/bench_f32.log 2>&1; tail -1 gpurun_out/bench_f32.log | cut -c1-300
 timeout 600 python bench.py --no-graph --no-cpu-baseline --no-roofline > gpurun_out/bench_nograph.log 2>&1; tail -1 gpurun_out/bench_nograph.log | cut -c1-300

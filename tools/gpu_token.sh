@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_token_path.py -m gpu -x -q > gpurun_out/pytest_token.log 2>&1; echo "pytest rc=$?"
 tail -25 gpurun_out/pytest_token.log
-timeout 600 python tools/bench_token.py --tokens 8192 --vocab 151936 --dtype bf16 --cpu-rows 64 > gpurun_out/token_bench_bf16.jsonl 2>gpurun_out/token_bench_bf16.err; echo "bench bf16 rc=$?"
+timeout 600 python tools/bench_token.py --tokens 8192 --vocab 151936 --dtype bf16 > gpurun_out/token_bench_bf16.jsonl 2>gpurun_out/token_bench_bf16.err; echo "bench bf16 rc=$?"
 cat gpurun_out/token_bench_bf16.jsonl; tail -3 gpurun_out/token_bench_bf16.err
 timeout 600 python tools/bench_token.py --tokens 4096 --vocab 151936 --dtype f32 > gpurun_out/token_bench_f32.jsonl 2>gpurun_out/token_bench_f32.err; echo "bench f32 rc=$?"
 cat gpurun_out/token_bench_f32.jsonl
