@@ -64,6 +64,23 @@ def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: floa
                 forward_inputs=dict(states=states, action=action))
 
 
+def rollout_epochs(policy, env: dict, eps: torch.Tensor, gamma: float, rollout_epoch: int, auto_reset: bool = True):
+    """``rollout_epoch`` back-to-back epochs of T steps each (EnvWorker._run_interact_once's outer loop,
+    env_worker.py:1074: every epoch opens with its own all-False bootstrap row and closes with its own value row),
+    stacked on the time axis as the trajectory builder does and folded into the batch axis by
+    process_nested_dict_for_adv (embodied_fsdp_actor_worker.py:208-216).  env holds rollout_epoch * T steps; epoch e
+    plays steps [e*T, (e+1)*T)."""
+    T = env["rewards"].shape[0] // rollout_epoch
+    parts = []
+    for e in range(rollout_epoch):
+        sl = dict(obs=env["obs"][e * T:(e + 1) * T + 1], final_obs=env["final_obs"][e * T:(e + 1) * T],
+                  rewards=env["rewards"][e * T:(e + 1) * T], dones=env["dones"][e * T:(e + 1) * T + 1])
+        parts.append(rollout(policy, sl, eps[e * T:(e + 1) * T], gamma, auto_reset))
+    stacked = {k: (dict((kk, torch.cat([p[k][kk] for p in parts], 0)) for kk in parts[0][k]) if isinstance(parts[0][k], dict)
+                   else torch.cat([p[k] for p in parts], 0)) for k in parts[0]}
+    return O.fold_rollout_epochs(stacked, rollout_epoch)
+
+
 def advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = True):
     lm = lms = None
     if not auto_reset:  # embodied_fsdp_actor_worker.py:219-233
@@ -102,9 +119,10 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
 
 
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
-              max_update_steps=None, timings=None):
+              max_update_steps=None, timings=None, rollout_epoch: int = 1):
     t0 = time.perf_counter()
-    batch = rollout(policy, env, eps, gamma, auto_reset)
+    batch = (rollout(policy, env, eps, gamma, auto_reset) if rollout_epoch == 1
+             else rollout_epochs(policy, env, eps, gamma, rollout_epoch, auto_reset))
     t1 = time.perf_counter()
     batch = advantages(batch, gamma, gae_lambda, auto_reset)
     t2 = time.perf_counter()

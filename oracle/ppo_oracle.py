@@ -576,3 +576,18 @@ def decoupled_actor_critic_loss(*, proximal_logprobs=None, versions=None, curren
                                   loss_mask=kw.get("loss_mask"), max_episode_steps=kw.get("max_episode_steps"),
                                   loss_mask_sum=kw.get("loss_mask_sum"))
     return a_loss + c_loss, {**a_m, **c_m}
+
+
+# --------------------------------------------------------------------------------------------
+# a8  rollout-epoch fold     rlinf/utils/nested_dict_process.py:251-269
+# --------------------------------------------------------------------------------------------
+def fold_rollout_epochs(nested: dict, rollout_epoch: int) -> dict:
+    """[rollout_epoch * n, bsz, ...] -> [n, rollout_epoch * bsz, ...] for every tensor (recursively)."""
+    out = {}
+    for key, value in nested.items():
+        if isinstance(value, torch.Tensor):
+            v = value.reshape(rollout_epoch, -1, *value.shape[1:]).transpose(0, 1)
+            out[key] = v.reshape(v.shape[0], -1, *v.shape[3:])
+        elif isinstance(value, dict):
+            out[key] = fold_rollout_epochs(value, rollout_epoch)
+    return out

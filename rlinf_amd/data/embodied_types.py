@@ -99,13 +99,16 @@ class TrajectoryBuffer:
         self.truncations[0] = False
 
     # ---- zero-copy write targets -------------------------------------------------------------------------
-    def policy_rows(self, t: int):
-        """(action, logprob, value) rows the rollout kernel writes step t into."""
-        return self.actions[t], self.prev_logprobs[t], self.prev_values[t]
+    def policy_rows(self, t: int, cols: slice = slice(None)):
+        """(action, logprob, value) rows the rollout kernel writes step t into.  ``cols``: a block of batch columns --
+        rollout epoch e owns columns [e*B_env, (e+1)*B_env), which IS process_nested_dict_for_adv's folded layout
+        [n, rollout_epoch * bsz, ...] (nested_dict_process.py:251-269), written in place instead of reshaped into."""
+        return self.actions[t, cols], self.prev_logprobs[t, cols], self.prev_values[t, cols]
 
-    def env_rows(self, t: int):
+    def env_rows(self, t: int, cols: slice = slice(None)):
         """(rewards[t], dones[t+1], terminations[t+1], truncations[t+1]) written after env step t."""
-        return self.rewards[t], self.dones[t + 1], self.terminations[t + 1], self.truncations[t + 1]
+        return (self.rewards[t, cols], self.dones[t + 1, cols], self.terminations[t + 1, cols],
+                self.truncations[t + 1, cols])
 
     # ---- reference-style append (copies; kept for API compatibility) ----------------------------------------
     def append_step_result(self, result: ChunkStepResult):

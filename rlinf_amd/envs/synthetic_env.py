@@ -50,9 +50,11 @@ class SyntheticManiSkillEnv:
         self.t = 0
         self._false = torch.zeros(self.num_envs, 1, dtype=torch.bool, device=device)
 
-    def reset(self):
-        self.t = 0
-        return {"states": self.obs[0]}, {}
+    def reset(self, start_step: int = 0):
+        """``start_step``: where in the pre-generated horizon this episode batch begins (rollout epoch e of T steps
+        starts at e * T, so that every epoch sees fresh transitions)."""
+        self.t = int(start_step)
+        return {"states": self.obs[self.t]}, {}
 
     def chunk_step(self, chunk_actions: torch.Tensor):
         """-> (obs dict, rewards [B,C], terminations [B,C], truncations [B,C], infos)."""

@@ -82,7 +82,8 @@ class EmbodiedFSDPActor(Worker):
 
     def _process_received_rollout_batch(self, batch: dict) -> dict:
         tr = self.cfg.env.train
-        assert tr.get("rollout_epoch", 1) == 1, "rollout_epoch > 1: next tier"
+        # rollout_epoch > 1: the env worker already wrote epoch e into batch columns [e*B, (e+1)*B), i.e. the layout
+        # process_nested_dict_for_adv folds to (:208-216); nothing to move
         if not tr.get("auto_reset", False) and not tr.get("ignore_terminations", False):  # :219-233
             dones = batch["dones"].contiguous()
             loss_mask, mask_sum = ops.done_prefix_mask(dones)

@@ -27,7 +27,6 @@ class EnvWorker(Worker):
         self.num_envs = self.train_cfg.total_num_envs // self._world_size // self.stage_num  # env_worker.py:137-140
         self.n_train_chunk_steps = (self.train_cfg.max_steps_per_rollout_epoch // cfg.actor.model.num_action_chunks)
         self.rollout_epoch = self.train_cfg.get("rollout_epoch", 1)
-        assert self.rollout_epoch == 1, "rollout_epoch > 1 is folded by the learner; the env worker runs one epoch"
         self.gamma = float(cfg.algorithm.get("gamma", 1))
         self.bootstrap_type = cfg.algorithm.get("bootstrap_type", "standard")
         self.auto_reset = bool(self.train_cfg.get("auto_reset", False))
@@ -44,12 +43,13 @@ class EnvWorker(Worker):
         m = self.cfg.actor.model
         begin, end = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank)
         if env_tensors is None:
-            env_tensors = generate_tensors(int(self.train_cfg.get("seed", 0)), self.n_train_chunk_steps,
+            env_tensors = generate_tensors(int(self.train_cfg.get("seed", 0)), self.n_train_chunk_steps * self.rollout_epoch,
                                            self.train_cfg.total_num_envs, m.obs_dim,
                                            int(self.train_cfg.get("max_episode_steps", 50)),
                                            mode=self.train_cfg.get("synthetic_done_mode", "periodic"))
         self.env = SyntheticManiSkillEnv(env_tensors, self.device, m.num_action_chunks, self.auto_reset, slice(begin, end))
-        self.buffer = TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs, m.obs_dim, m.action_dim,
+        # rollout epochs are laid out side by side on the batch axis: the learner's fold (a8) costs nothing
+        self.buffer = TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs * self.rollout_epoch, m.obs_dim, m.action_dim,
                                        m.num_action_chunks, device=self.device,
                                        max_episode_length=int(self.train_cfg.get("max_episode_steps", 0)))
         self._bootstrap_v = torch.zeros(self.num_envs, self.buffer.V, device=self.device)
@@ -66,10 +66,11 @@ class EnvWorker(Worker):
         return ops.bootstrap_rewards_(rewards, flags, bootstrap_values, self.gamma)
 
     def interact(self, eps: torch.Tensor | None = None, mode: str = "train"):
-        """One rollout epoch: T chunk steps + the closing value row.  ``eps`` [T, B, A] injects the N(0,1) draws
-        (drawn on the device otherwise)."""
+        """``rollout_epoch`` epochs of T chunk steps + a closing value row each.  ``eps`` [rollout_epoch * T, B, A] injects
+        the N(0,1) draws (drawn on the device otherwise)."""
         if self._eps is None:
-            self._eps = torch.empty(self.n_train_chunk_steps, self.num_envs, self.buffer.A, device=self.device)
+            self._eps = torch.empty(self.n_train_chunk_steps * self.rollout_epoch, self.num_envs, self.buffer.A,
+                                    device=self.device)
         if eps is None:
             self._eps.normal_()
         else:
@@ -93,21 +94,25 @@ class EnvWorker(Worker):
         a second, tiny launch stores the env outputs."""
         buf, env, ro = self.buffer, self.env, self.rollout
         buf.reset()
+        T = self.n_train_chunk_steps
         with self.timer("env/interact"):
-            obs, _ = env.reset()
-            for t in range(self.n_train_chunk_steps):
-                # forward_inputs.states of step t (return_obs=True) are written by the policy launch itself
-                chunk_actions = ro.predict(obs, out=buf.policy_rows(t), eps=None if eps is None else eps[t], mode=mode,
-                                           states_copy=buf.states[t])
-                obs, rewards, term, trunc, infos = env.chunk_step(chunk_actions)
-                r_row, d_row, te_row, tr_row = buf.env_rows(t)
-                if self.auto_reset:  # value of the true terminal observation enters through the reward (A.2); the job that
-                    # computes it (riding in the next policy launch) also stores this step's env outputs into the rows
-                    ro.queue_bootstrap(infos["final_obs"], r_row, None, self.gamma, env=(rewards, term, trunc),
-                                       rows=(d_row, te_row, tr_row), flag_is_truncation=self.bootstrap_type != "always")
-                else:
-                    ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
-            ro.get_bootstrap_values(obs, out=buf.prev_values[self.n_train_chunk_steps])  # last row: values only
+            for epoch in range(self.rollout_epoch):  # env_worker.py:1074
+                cols = slice(epoch * self.num_envs, (epoch + 1) * self.num_envs)
+                obs, _ = env.reset(epoch * T)  # bootstrap_step (:898-952): dones row 0 of this block stays all-False
+                for t in range(T):
+                    # forward_inputs.states of step t (return_obs=True) are written by the policy launch itself
+                    chunk_actions = ro.predict(obs, out=buf.policy_rows(t, cols),
+                                               eps=None if eps is None else eps[epoch * T + t], mode=mode,
+                                               states_copy=buf.states[t, cols])
+                    obs, rewards, term, trunc, infos = env.chunk_step(chunk_actions)
+                    r_row, d_row, te_row, tr_row = buf.env_rows(t, cols)
+                    if self.auto_reset:  # value of the true terminal observation enters through the reward (A.2); the job
+                        # that computes it (riding in the next policy launch) also stores this step's env outputs
+                        ro.queue_bootstrap(infos["final_obs"], r_row, None, self.gamma, env=(rewards, term, trunc),
+                                           rows=(d_row, te_row, tr_row), flag_is_truncation=self.bootstrap_type != "always")
+                    else:
+                        ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
+                ro.get_bootstrap_values(obs, out=buf.prev_values[T, cols])  # closing row of the epoch: values only
         return None
 
     def send_rollout_trajectories(self, actor_world_size: int | None = None) -> list:

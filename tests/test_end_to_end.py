@@ -11,7 +11,7 @@ from oracle import ppo_oracle as O
 
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
-             auto_reset=True, hip_graph=False):
+             auto_reset=True, hip_graph=False, rollout_epoch=1):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1),
@@ -19,7 +19,7 @@ def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_e
                        logprob_type="action_level", entropy_type="action_level", adv_type="gae", loss_type="actor_critic",
                        bootstrap_type="always", entropy_bonus=0, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
                        huber_delta=10.0, gamma=gamma, gae_lambda=lam),
-        env=dict(train=dict(rollout_epoch=1, total_num_envs=total_envs, auto_reset=auto_reset, ignore_terminations=False,
+        env=dict(train=dict(rollout_epoch=rollout_epoch, total_num_envs=total_envs, auto_reset=auto_reset, ignore_terminations=False,
                             max_episode_steps=5, max_steps_per_rollout_epoch=steps, seed=0, group_size=1)),
         rollout=dict(pipeline_stage_num=1, enable_cuda_graph=hip_graph),
         actor=dict(training_backend="fsdp", micro_batch_size=micro_batch or global_batch, global_batch_size=global_batch,
@@ -74,10 +74,13 @@ def _build(cfg, env_tensors, state_dict):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [dict(total_envs=8, steps=16, global_batch=32),                      # configs[0]: 8 envs
                                    dict(total_envs=64, steps=20, global_batch=320, micro_batch=160),   # grad accumulation
-                                   dict(total_envs=32, steps=12, global_batch=96, hip_graph=True)])
+                                   dict(total_envs=32, steps=12, global_batch=96, hip_graph=True),
+                                   dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=3),    # a8: epochs fold
+                                   dict(total_envs=16, steps=8, global_batch=64, rollout_epoch=2, hip_graph=True)])
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
-    T, B = shape["steps"], shape["total_envs"]
+    E = shape.get("rollout_epoch", 1)
+    T, B = shape["steps"] * E, shape["total_envs"]   # T: steps over all rollout epochs
     env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
     torch.manual_seed(11)
     ora = O.OracleMLPPolicy(42, 8, 1)
@@ -88,7 +91,7 @@ def test_iteration_matches_oracle(shape):
     for it in range(n_iter):
         eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234,
-                                global_batch=shape["global_batch"], update_epoch=2)
+                                global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E)
         metrics = runner.run_step(eps.cuda())
         rb = runner.actor.worker.rollout_batch
         tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)  # later iterations inherit Adam's drift

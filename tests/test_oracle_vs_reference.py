@@ -366,3 +366,17 @@ def test_decoupled_actor_critic_loss(ref, logprob_type, prox_mode, masked, thr):
             _eq(x, y)
         else:
             assert x == y, k
+
+
+def test_fold_rollout_epochs(ref):
+    """oracle a8 against process_nested_dict_for_adv (rlinf/utils/nested_dict_process.py:251-269)."""
+    g = torch.Generator().manual_seed(0)
+    E, n, B = 3, 5, 4
+    nested = {"rewards": torch.randn(E * n, B, 2, generator=g), "dones": torch.rand(E * (n + 1), B, 2, generator=g) < 0.3,
+              "forward_inputs": {"states": torch.randn(E * n, B, 7, generator=g)}}
+    want = ref.nested.process_nested_dict_for_adv(nested, E)
+    got = O.fold_rollout_epochs(nested, E)
+    _eq(want["rewards"], got["rewards"]), _eq(want["dones"], got["dones"])
+    _eq(want["forward_inputs"]["states"], got["forward_inputs"]["states"])
+    # epoch e of the stacked time axis lands in batch columns [e*B, (e+1)*B): the layout the env worker writes in place
+    assert torch.equal(got["rewards"][:, B:2 * B], nested["rewards"][n:2 * n])
