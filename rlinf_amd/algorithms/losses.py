@@ -82,10 +82,9 @@ def _fused(kw: dict, has_critic: bool):
     action_dim = kw.get("single_action_dim")
     if action_dim is None:
         raise TypeError("policy_loss(task_type='embodied') needs single_action_dim")
-    if kw.get("reward_type") == "chunk_level" and logprob_type != "chunk_level":
-        raise NotImplementedError("reward_type='chunk_level' is only fused together with logprob_type='chunk_level'")
     loss, out = ops.ppo_loss(
         _u.stage(logprobs, dev), st("old_logprobs"), st("advantages"), logprob_type=logprob_type,
+        reward_type=kw.get("reward_type"),
         action_dim=int(action_dim), clip_ratio_low=kw["clip_ratio_low"], clip_ratio_high=kw["clip_ratio_high"],
         values=st("values") if has_critic else None, prev_values=st("prev_values") if has_critic else None,
         returns=st("returns") if has_critic else None, value_clip=kw.get("value_clip"),
@@ -235,11 +234,10 @@ def compute_decoupled_ppo_actor_critic_loss(**kwargs) -> tuple[torch.Tensor, Map
     action_dim = kw.get("single_action_dim")
     if action_dim is None:
         raise TypeError("policy_loss(loss_type='decoupled_actor_critic') needs single_action_dim")
-    if kw.get("reward_type") == "chunk_level" and logprob_type != "chunk_level":
-        raise NotImplementedError("reward_type='chunk_level' is only fused together with logprob_type='chunk_level'")
     versions, current_version = st("versions"), kw.get("current_version")
     loss, out = ops.ppo_loss(
         _u.stage(logprobs, dev), st("old_logprobs"), st("advantages"), logprob_type=logprob_type,
+        reward_type=kw.get("reward_type"),
         action_dim=int(action_dim), clip_ratio_low=kw["clip_ratio_low"], clip_ratio_high=kw["clip_ratio_high"],
         values=st("values"), prev_values=st("prev_values"), returns=st("returns"), value_clip=kw.get("value_clip"),
         huber_delta=kw.get("huber_delta"), loss_mask=st("loss_mask"), loss_mask_sum=st("loss_mask_sum"),

@@ -212,8 +212,10 @@ def episode_scores(rewards: torch.Tensor, dones: torch.Tensor) -> torch.Tensor:
 _LEVELS = ("action_level", "token_level", "chunk_level")
 
 
-def _loss_geometry(logprobs: torch.Tensor, logprob_type: str, action_dim: int):
-    """(n_adv, raw_per_adv, sub_per_adv) for a [bsz, C*A] log-prob tensor (algorithms/utils.py:325-356)."""
+def _loss_geometry(logprobs: torch.Tensor, logprob_type: str, action_dim: int, reward_type: Optional[str] = None):
+    """(n_adv, raw_per_adv, sub_per_adv) for a [bsz, C*A] log-prob tensor (algorithms/utils.py:325-356).  With
+    reward_type='chunk_level' the advantage / mask / value tensors are per env-step ([bsz], utils.py:296-308) while
+    token-level log-probs keep one loss element per action dimension of every chunk: bsz x (C*A) x (C*A)."""
     bsz = logprobs.shape[0]
     per_row = logprobs.numel() // max(bsz, 1)
     if logprob_type not in _LEVELS:
@@ -221,6 +223,12 @@ def _loss_geometry(logprobs: torch.Tensor, logprob_type: str, action_dim: int):
     if per_row % action_dim != 0:
         raise RlxError(f"logprobs row of {per_row} elements is not a multiple of action_dim={action_dim}")
     chunks = per_row // action_dim
+    if reward_type == "chunk_level" and logprob_type == "token_level":
+        return bsz, per_row, per_row
+    if reward_type == "chunk_level" and logprob_type == "action_level" and chunks > 1:
+        # ratio [bsz, C] against a [bsz, 1] mask: the reference's metric denominators are the un-broadcast mask count
+        # here (no expand_as, losses.py:288-290) -- a third denominator rule no shipped config exercises
+        raise RlxError("reward_type='chunk_level' with logprob_type='action_level' is not fused")
     if logprob_type == "action_level":
         return bsz * chunks, action_dim, 1
     if logprob_type == "token_level":
@@ -278,7 +286,7 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
              loss_mask_sum: Optional[torch.Tensor] = None, max_episode_steps: Optional[int] = None,
              clip_ratio_c: Optional[float] = None, clip_log_ratio_min: Optional[float] = None,
              clip_log_ratio_max: Optional[float] = None, critic_warmup: bool = False, has_critic: bool = True,
-             decoupled: Optional[dict] = None):
+             decoupled: Optional[dict] = None, reward_type: Optional[str] = None):
     """Fused actor(+critic) PPO loss.  Inputs are the RAW per-dimension tensors the reference hands to
     policy_loss (before preprocess_loss_inputs); returns (loss 0-dim tensor with grad, out f32[20] on device,
     see _lib.PPO_OUT_NAMES).  losses.py asserts float32 inputs (:232-240); so do we."""
@@ -286,7 +294,7 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
     for name, t in (("logprobs", logprobs), ("old_logprobs", old_logprobs), ("advantages", advantages)):
         if t.dtype != torch.float32:
             raise RlxError(f"{name} must be float32 to keep numerical stability")
-    n_adv, raw, sub = _loss_geometry(logprobs, logprob_type, action_dim)
+    n_adv, raw, sub = _loss_geometry(logprobs, logprob_type, action_dim, reward_type)
     if old_logprobs.numel() != logprobs.numel():
         raise RlxError("old_logprobs must have the shape of logprobs")
     if advantages.numel() != n_adv:

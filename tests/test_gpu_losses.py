@@ -256,3 +256,55 @@ def test_decoupled_loss_vs_oracle(logprob_type, prox_mode, masked, thr, warmup):
     for k in sorted(want_keys) + ["critic/value_loss", "critic/value_clip_ratio"]:
         torch.testing.assert_close(torch.tensor(float(metrics[k])), torch.as_tensor(wm[k]).float(), rtol=RTOL, atol=ATOL,
                                    msg=lambda m: f"{tag} {k}: {m}")
+
+
+@pytest.mark.parametrize("loss_type", ["actor_critic", "actor", "decoupled_actor_critic"])
+@pytest.mark.parametrize("masked", [False, True])
+def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked):
+    """reward_type='chunk_level' + logprob_type='token_level' (six shipped configs, e.g. the OpenVLA GRPO ones): advantages,
+    mask and values are per env-step ([bsz, 1] flattened, utils.py:296-308) while every action dimension of every chunk
+    keeps its own ratio."""
+    from rlinf_amd.algorithms import registry
+
+    g = torch.Generator().manual_seed(23)
+    bsz, C, A = 200, 3, 4
+    lp0 = torch.randn(bsz, C * A, generator=g) * 0.3
+    old = lp0 + 0.1 * torch.randn(bsz, C * A, generator=g)
+    adv, vals, pv, ret = (torch.randn(bsz, 1, generator=g) for _ in range(4))
+    lm = lms = None
+    if masked:
+        lm = torch.rand(bsz, 1, generator=g) < 0.7
+        lms = lm.sum(dim=0, keepdim=True).expand_as(lm).contiguous()
+    common = dict(clip_ratio_low=0.2, clip_ratio_high=0.28, clip_ratio_c=3.0, max_episode_steps=80)
+    critic = dict(value_clip=0.5, huber_delta=1.0)
+    lp = lp0.clone().requires_grad_(True)
+    v = vals.clone().requires_grad_(True)
+    shaped = O.shape_loss_inputs(lp, old, adv, "token_level", A, loss_mask=lm, loss_mask_sum=lms, values=v, prev_values=pv,
+                                 returns=ret, reward_type="chunk_level")
+    if loss_type == "actor_critic":
+        wloss, wm = O.ppo_actor_critic_loss(**common, **critic, **shaped)
+    elif loss_type == "actor":
+        wloss, wm = O.ppo_actor_loss(**{k: shaped[k] for k in ("logprobs", "old_logprobs", "advantages", "loss_mask",
+                                                               "loss_mask_sum")}, **common)
+    else:
+        wloss, wm = O.decoupled_actor_critic_loss(behave_weight_threshold=1.05, **common, **critic, **shaped)
+    wloss.backward()
+    dlp = lp0.cuda().requires_grad_(True)
+    dv = vals.cuda().requires_grad_(True)
+    kw = dict(task_type="embodied", loss_type=loss_type, logprob_type="token_level", reward_type="chunk_level",
+              single_action_dim=A, logprobs=dlp, old_logprobs=_c(old), advantages=_c(adv), loss_mask=_c(lm),
+              loss_mask_sum=_c(lms), **common)
+    if loss_type != "actor":
+        kw.update(values=dv, returns=_c(ret), prev_values=_c(pv), **critic)
+    if loss_type == "decoupled_actor_critic":
+        kw.update(behave_weight_threshold=1.05)
+    loss, metrics = registry.policy_loss(**kw)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), wloss.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(dlp.grad.cpu(), lp.grad, rtol=RTOL, atol=1e-7)
+    if loss_type != "actor":
+        torch.testing.assert_close(dv.grad.cpu(), v.grad, rtol=RTOL, atol=1e-7)
+    for k, want in wm.items():
+        if k.startswith("actor/") or k in ("critic/value_loss", "critic/value_clip_ratio"):
+            torch.testing.assert_close(torch.tensor(float(metrics[k])), torch.as_tensor(want).float(), rtol=RTOL, atol=ATOL,
+                                       msg=lambda m: f"{k}: {m}")
