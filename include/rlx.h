@@ -192,6 +192,15 @@ int rlx_ppo_loss_bwd(const float* g_logp, const float* g_value, const float* out
                      float* d_logprobs, float* d_values, int64_t n_adv, int raw_per_adv, int sub_per_adv,
                      rlx_stream_t stream);
 
+/* a22 entropy bonus of the Gaussian MLP policy  <- EmbodiedFSDPActor.train_micro_batch, rlinf/workers/actor/embodied_fsdp_actor_worker.py:679-690
+ *   (+ reshape_entropy rlinf/utils/utils.py:384-408, masked_mean :323-330).  The entropy of Normal(mu, exp(logstd)) is
+ *   state-independent, so after rlx_ppo_loss_fwd / rlx_ppo_step have written out_row:
+ *     ent = elem_scale * sum_a (0.5 + 0.5 log 2pi + logstd_a)   (0 when a loss mask is present and empty: out_row[18] == 0)
+ *     out_row[RLX_PPO_LOSS] -= entropy_bonus * ent;  out_row[19] = ent ("actor/entropy_loss");
+ *     grad_logstd[a] -= entropy_bonus * grad_scale * elem_scale        (grad_scale = 1 / gradient_accumulation) */
+int rlx_gaussian_entropy_bonus(const float* logstd, int n_act, float* grad_logstd, float* out_row, float entropy_bonus,
+                               float grad_scale, int has_mask, float elem_scale, rlx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * a16  shuffle_gather  <- process_nested_dict_for_train, rlinf/utils/nested_dict_process.py:272-285
  *   for every field f:  dst_f[i, :] = src_f[index[i], :]   (rows of row_bytes_f bytes; the caller has

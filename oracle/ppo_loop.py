@@ -96,7 +96,7 @@ def advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = 
 
 
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
-           value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None):
+           value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0):
     T, B = batch["prev_logprobs"].shape[:2]
     perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
     flat = O.flatten_and_shuffle(batch, perm)
@@ -110,7 +110,7 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
                                   prev_logprobs=mb["prev_logprobs"], advantages=mb["advantages"],
                                   prev_values=mb["prev_values"], returns=mb["returns"], loss_mask=mb.get("loss_mask")),
                 clip_low=clip_low, clip_high=clip_high, value_clip=value_clip, huber_delta=huber_delta,
-                clip_grad=clip_grad, action_dim=policy.action_dim)
+                clip_grad=clip_grad, action_dim=policy.action_dim, entropy_bonus=entropy_bonus)
             metrics.append(m)
             steps += 1
             if max_steps is not None and steps >= max_steps:
@@ -119,7 +119,7 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
 
 
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
-              max_update_steps=None, timings=None, rollout_epoch: int = 1):
+              max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0):
     t0 = time.perf_counter()
     batch = (rollout(policy, env, eps, gamma, auto_reset) if rollout_epoch == 1
              else rollout_epochs(policy, env, eps, gamma, rollout_epoch, auto_reset))
@@ -127,7 +127,7 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     batch = advantages(batch, gamma, gae_lambda, auto_reset)
     t2 = time.perf_counter()
     metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
-                     max_steps=max_update_steps)
+                     max_steps=max_update_steps, entropy_bonus=entropy_bonus)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))

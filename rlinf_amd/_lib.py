@@ -96,7 +96,7 @@ PPO_OUT_NAMES = {
     "loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, "actor/ratio": 3, "actor/ratio_abs": 4,
     "actor/clipped_ratio": 5, "actor/dual_cliped_ratio": 6, "actor/approx_kl": 7, "actor/clip_fraction": 8,
     "critic/value_loss": 9, "critic/value_clip_ratio": 10, "ev/count": 11, "ev/returns_sum": 12,
-    "ev/returns_sq_sum": 13, "ev/errors_sum": 14, "ev/errors_sq_sum": 15,
+    "ev/returns_sq_sum": 13, "ev/errors_sum": 14, "ev/errors_sq_sum": 15, "actor/entropy_loss": 19,
 }
 
 
@@ -148,6 +148,7 @@ PROTOTYPES = {
                                    c_float, c_void_p]),
     "rlx_grpo_from_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rlx_episode_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rlx_gaussian_entropy_bonus": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_void_p]),
     "rlx_reward_filter_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "rlx_ppo_loss_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_ppo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

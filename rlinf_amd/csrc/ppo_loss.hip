@@ -123,6 +123,28 @@ __global__ __launch_bounds__(256) void ppo_loss_bwd_kernel(const float* g_lp, co
     }
 }
 
+// The Gaussian policy's entropy does not depend on the state: per row it is sum_a (0.5 + 0.5 log 2pi + logstd_a), so
+//   loss -= entropy_bonus * masked_mean(entropy)    (embodied_fsdp_actor_worker.py:679-690, reshape_entropy utils.py:384-408)
+// is a constant push on the logstd gradient plus one scalar for the metrics.  elem_scale = 1, or 1/A when entropy_type is
+// "token_level" and there is no loss mask (the mean then runs over the [mb, A] elements).
+__global__ __launch_bounds__(64) void entropy_bonus_kernel(const float* __restrict__ logstd, int n_act,
+                                                           float* __restrict__ grad_logstd, float* __restrict__ out_row,
+                                                           float bonus, float grad_scale, int has_mask, float elem_scale) {
+    const int a = threadIdx.x;
+    const float on = (!has_mask || out_row[18] > 0.f) ? 1.f : 0.f;  // masked_mean over an all-False mask is the (zero) sum
+    float e = 0.f;
+    if (a < n_act) {
+        e = 0.5f + 0.91893853320467274178f + logf(expf(logstd[a]));  // Normal.entropy() on scale = exp(logstd)
+        grad_logstd[a] -= bonus * grad_scale * elem_scale * on;
+    }
+    e = wave_sum(e);
+    if (a == 0) {
+        const float ent_loss = e * elem_scale * on;
+        out_row[19] = ent_loss;                                  // actor/entropy_loss
+        out_row[RLX_PPO_LOSS] -= bonus * ent_loss;
+    }
+}
+
 constexpr int kMaxLossBlocks = 1024;
 
 int loss_grid(long long n) {
@@ -188,6 +210,16 @@ extern "C" int rlx_ppo_loss_bwd(const float* g_logp, const float* g_value, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(ppo_loss_bwd_kernel, dim3(loss_grid(n_adv * raw_per_adv)), dim3(256), 0, s, g_logp, g_value, out,
                        grad_out, d_logprobs, d_values, (long long)n_adv, raw_per_adv, sub_per_adv);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_gaussian_entropy_bonus(const float* logstd, int n_act, float* grad_logstd, float* out_row,
+                                          float entropy_bonus, float grad_scale, int has_mask, float elem_scale,
+                                          rlx_stream_t stream) {
+    RLX_REQUIRE(logstd && grad_logstd && out_row && n_act >= 1 && n_act <= 64, "rlx_gaussian_entropy_bonus: bad argument");
+    hipLaunchKernelGGL(entropy_bonus_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), logstd, n_act,
+                       grad_logstd, out_row, entropy_bonus, grad_scale, has_mask, elem_scale);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -170,6 +170,21 @@ def grpo_from_scores(scores: torch.Tensor, loss_mask: torch.Tensor, group_size: 
     return adv
 
 
+def gaussian_entropy_bonus_(params: torch.Tensor, layout: MlpLayout, grads_slab0: torch.Tensor, out_row: torch.Tensor,
+                            entropy_bonus: float, grad_scale: float, has_mask: bool, elem_scale: float = 1.0):
+    """a22 for the Gaussian MLP policy: fold -entropy_bonus * masked_mean(entropy) into the loss row and the logstd
+    gradient (see include/rlx.h).  ``grads_slab0`` is the first gradient slab [n_params]."""
+    dev = _dev(params, grads_slab0, out_row)
+    off, A = int(layout.off_logstd), int(layout.act_dim)
+    logstd = params[off:off + A]
+    g = grads_slab0[off:off + A]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rlx_gaussian_entropy_bonus(logstd.data_ptr(), A, g.data_ptr(), out_row.data_ptr(),
+                                                          float(entropy_bonus), float(grad_scale), int(bool(has_mask)),
+                                                          float(elem_scale), _stream_ptr(dev)),
+                   "rlx_gaussian_entropy_bonus")
+
+
 def reward_filter_mask(rewards: torch.Tensor, loss_mask: Optional[torch.Tensor], group_size: int, lower: float,
                        upper: float) -> torch.Tensor:
     """rewards [n, B, C] f32 (+ loss_mask [n, B, C] bool) -> the filtered loss mask (bool): [n, B, C] with a mask,

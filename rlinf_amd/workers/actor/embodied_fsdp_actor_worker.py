@@ -227,6 +227,17 @@ class EmbodiedFSDPActor(Worker):
         ops.mlp_train_bwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], ws["mean"], ws["acts"],
                           ws["d_lp"], None, ws["d_v"], grads=grads, workspace=ws["bwd_ws"])
 
+    def _entropy_bonus(self, mbatch: dict, grads: torch.Tensor, out_row: torch.Tensor, critic_warmup: bool = False):
+        """loss -= entropy_bonus * masked_mean(entropy) (:679-690); a no-op at the default entropy_bonus = 0."""
+        alg = self.cfg.algorithm
+        bonus = float(alg.get("entropy_bonus", 0) or 0)
+        if bonus <= 0 or critic_warmup:
+            return
+        has_mask = mbatch.get("loss_mask") is not None
+        per_elem = alg.get("entropy_type", "action_level") == "token_level" and not has_mask
+        ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
+                                    has_mask, 1.0 / self.model.layout.act_dim if per_elem else 1.0)
+
     def optimizer_step(self, grads: torch.Tensor, stats: torch.Tensor | None = None):
         """clip_grad_norm_ + AdamW (+ data-parallel mean of the gradient) -> stats (norm, applied) on device.  The
         optimizer kernel also refreshes the fragment-tile weight image the next forward (and the rollout) streams."""
@@ -269,6 +280,8 @@ class EmbodiedFSDPActor(Worker):
                     mbatch = {k: v[lo:lo + micro] for k, v in flat.items()}
                     self.train_micro_batch(mbatch, ws, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
                                            metrics_dev[step * accum + j], grad_out, lp)
+                    self._entropy_bonus(mbatch, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]], metrics_dev[step * accum + j],
+                                        bool(lp.critic_warmup))
                 self.optimizer_step(grads, stats=norms_dev[step])  # (norm, applied) straight into this step's row
                 step += 1
         return step
@@ -295,6 +308,9 @@ class EmbodiedFSDPActor(Worker):
                         micro_calls.append(ops.PreparedPpoStep(
                             m.flat.data, m.layout, lp, mbatch, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
                             metrics_dev[step * accum + j], ws["step_ws"], grad_out=self._grad_out_host, tiles=tiles, bf16=bf16))
+                        if float(self.cfg.algorithm.get("entropy_bonus", 0) or 0) > 0:
+                            micro_calls.append(lambda _stream, mb=mbatch, g=grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
+                                               row=metrics_dev[step * accum + j]: self._entropy_bonus(mb, g, row))
                     adam = ops.PreparedAdamw(
                         m.flat.data, self.grad_flat if multi else grads, self.exp_avg, self.exp_avg_sq, self.groups,
                         betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
@@ -375,7 +391,7 @@ class EmbodiedFSDPActor(Worker):
             stats = {name: host[PPO_OUT_FLOATS + i] for i, name in enumerate(_EV_MAP.values())}
             out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(stats)
         out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
-        out["actor/entropy_loss"] = 0.0
+        out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
         out["actor/grad_norm"] = host[-1]
         out["actor/lr"] = float(self.cfg.actor.optim.lr)
         out["critic/lr"] = float(self.cfg.actor.optim.value_lr)

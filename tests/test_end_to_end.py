@@ -11,13 +11,13 @@ from oracle import ppo_oracle as O
 
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
-             auto_reset=True, hip_graph=False, rollout_epoch=1):
+             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1),
         algorithm=dict(update_epoch=update_epoch, normalize_advantages=True, group_size=1, reward_type="action_level",
                        logprob_type="action_level", entropy_type="action_level", adv_type="gae", loss_type="actor_critic",
-                       bootstrap_type="always", entropy_bonus=0, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
+                       bootstrap_type="always", entropy_bonus=entropy_bonus, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
                        huber_delta=10.0, gamma=gamma, gae_lambda=lam),
         env=dict(train=dict(rollout_epoch=rollout_epoch, total_num_envs=total_envs, auto_reset=auto_reset, ignore_terminations=False,
                             max_episode_steps=5, max_steps_per_rollout_epoch=steps, seed=0, group_size=1)),
@@ -76,7 +76,9 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=64, steps=20, global_batch=320, micro_batch=160),   # grad accumulation
                                    dict(total_envs=32, steps=12, global_batch=96, hip_graph=True),
                                    dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=3),    # a8: epochs fold
-                                   dict(total_envs=16, steps=8, global_batch=64, rollout_epoch=2, hip_graph=True)])
+                                   dict(total_envs=16, steps=8, global_batch=64, rollout_epoch=2, hip_graph=True),
+                                   dict(total_envs=16, steps=12, global_batch=96, micro_batch=48, entropy_bonus=0.02),  # a22
+                                   dict(total_envs=16, steps=12, global_batch=96, entropy_bonus=0.02, hip_graph=True)])
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
@@ -91,7 +93,8 @@ def test_iteration_matches_oracle(shape):
     for it in range(n_iter):
         eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234,
-                                global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E)
+                                global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E,
+                                entropy_bonus=shape.get("entropy_bonus", 0.0))
         metrics = runner.run_step(eps.cuda())
         rb = runner.actor.worker.rollout_batch
         tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)  # later iterations inherit Adam's drift
@@ -104,6 +107,9 @@ def test_iteration_matches_oracle(shape):
         torch.testing.assert_close(rb["advantages"].cpu(), batch["advantages"], rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
         want_loss = sum(float(m["actor/total_loss"]) for m in om) / len(om) / max(cfg.actor.global_batch_size // cfg.actor.micro_batch_size, 1)
         assert metrics["train/actor/total_loss"] == pytest.approx(want_loss, rel=2e-3, abs=2e-4)
+        if shape.get("entropy_bonus"):
+            want_ent = sum(float(m["actor/entropy_loss"]) for m in om) / len(om)
+            assert metrics["train/actor/entropy_loss"] == pytest.approx(want_ent, rel=1e-4)
         want_gn = sum(float(m["actor/grad_norm"]) for m in om) / len(om)
         assert metrics["train/actor/grad_norm"] == pytest.approx(want_gn, rel=2e-3)
         assert metrics["rollout/rewards"] == pytest.approx(float(batch["rewards"].mean()), rel=1e-4)
