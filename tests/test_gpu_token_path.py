@@ -421,3 +421,35 @@ def test_gae_seq_vs_oracle(seq, gl):
     if int(mask.sum()) > 1:
         close(out[0], nadv.transpose(0, 1), 2e-5 + 10 * atol, 2e-5, "normalised advantages")
     assert out[0].is_contiguous() and out[1].is_contiguous()
+
+
+def test_empty_and_degenerate_inputs():
+    """Zero tokens / sequences, a one-entry vocabulary, a one-bin categorical head, an empty tensor inside a synced state
+    dict: defined results, no launches with zero-sized grids."""
+    from rlinf_amd.hybrid_engines.weight_syncer import EmptyWeightPatch, PatchWeightSyncer
+
+    x = torch.empty(0, 100, device=DEV)
+    lp, ent, lse = token_ops.token_logprob_fwd(x, torch.empty(0, dtype=torch.int64, device=DEV), with_entropy=True)
+    assert lp.shape == ent.shape == lse.shape == (0,)
+    d = token_ops.token_logprob_bwd(x, torch.empty(0, dtype=torch.int64, device=DEV), lse, None, lp, None)
+    assert d.shape == (0, 100)
+    one = torch.randn(5, 1, device=DEV)
+    lp, ent, _ = token_ops.token_logprob_fwd(one, torch.zeros(5, dtype=torch.int64, device=DEV), with_entropy=True)
+    assert float(lp.abs().max()) < 1e-6 and float(ent.abs().max()) < 1e-6  # a certain outcome (exp2/log2 round trip)
+    tok, clp, _ = token_ops.categorical_sample(one, torch.ones(5, 1, device=DEV))
+    assert int(tok.abs().max()) == 0 and float(clp.abs().max()) < 1e-6
+    adv = token_ops.grpo_seq_adv(torch.empty(0, device=DEV), torch.empty(0, 7, dtype=torch.bool, device=DEV), 4)
+    assert adv.shape == (0, 7)
+    a, r = token_ops.gae_seq(torch.empty(0, 9, device=DEV), torch.empty(0, device=DEV))
+    assert a.shape == r.shape == (0, 9)
+    a, r = token_ops.gae_seq(torch.randn(3, 1, device=DEV), torch.ones(3, device=DEV), 0.9, 0.9)
+    assert a.shape == (3, 1) and torch.allclose(r, torch.ones(3, 1, device=DEV))  # one token: return = reward
+    state = {"w": torch.randn(4, 4, device=DEV), "empty": torch.empty(0, 3, device=DEV)}
+    q = []
+    rx, tx = PatchWeightSyncer(), PatchWeightSyncer()
+    rx.init_receiver({k: v.clone() for k, v in state.items()}, q.pop, q.append)
+    tx.init_sender(state, ["w", "empty"], q.append, lambda: q.pop(0))
+    assert isinstance(tx.create_patch(state, 1), EmptyWeightPatch)
+    state["w"][1, 2] += 1
+    p = tx.create_patch(state, 2)
+    assert p.nnz_per_tensor.tolist() == [1] and p.ordinals.tolist() == [0]
