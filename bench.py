@@ -15,8 +15,9 @@ Extra objects on that line:
   roofline      gae_scan (the kernel BASELINE.json grades against the HBM roofline), timed live with HIP events on the
                 launch stream at the scaled shape 65536 envs x 128 steps (the 1024 x 128 buffer is 2.2 MB and lives in
                 L2); algorithmic bytes = 17 B per env-step.
-  roofline_token_tier  (N = 1) the widening row, SURVEY.md 8f item 1: token_logprob fwd / bwd at 4096 tokens x 151936
-                vocab, bf16 logits, same HIP-event method.
+  roofline_widening  (N = 1) the kernels of the widening rows: token_logprob fwd / bwd at 4096 tokens x
+                151936 vocab (bf16 logits), gae_seq at 4096 x 8192, patch_scan over a 622 M-element bf16 tensor; same
+                HIP-event method.
   cpu_baseline  the CPU oracle (a port of the reference's torch-CPU path, oracle/ppo_loop.py) on this box's host
                 cores, on a bounded sample, N = 1 only.
 """
@@ -234,7 +235,32 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
         rows.append({"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(gbps / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1), "algorithmic_bytes": nbytes,
                      "shape": f"{tokens} tokens x {vocab} vocab, bf16 logits"})
+    # reasoning GAE along the contiguous axis (12 B/token) and the weight-patch scan (tensor + snapshot read once)
+    v = torch.randn(4096, 8192, device=device, generator=g)
+    r = torch.randn(4096, device=device, generator=g)
+    adv, ret = torch.empty_like(v), torch.empty_like(v)
+    lib = _lib_handle()
+    st = torch.cuda.current_stream(device).cuda_stream
+    us = avg_us(lambda: lib.rlx_gae_seq(v.data_ptr(), r.data_ptr(), adv.data_ptr(), ret.data_ptr(), 4096, 8192, 1.0, 0.95, st))
+    nb = v.numel() * 12
+    rows.append({"kernel": "gae_seq", "bound": "hbm", "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1), "algorithmic_bytes": nb,
+                 "shape": "4096 sequences x 8192 tokens, f32 values"})
+    n = x.numel()
+    wsb = lib.rlx_patch_workspace_bytes(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    nnz = torch.zeros(1, dtype=torch.int64, device=device)
+    us = avg_us(lambda: lib.rlx_patch_scan(x.data_ptr(), 1, out.data_ptr(), 1, n, ws.data_ptr(), wsb, nnz.data_ptr(), st))
+    nb = 2 * n * 2
+    rows.append({"kernel": "patch_scan (+ offsets)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK_GBPS,
+                 "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
+                 "algorithmic_bytes": nb, "shape": f"{n} bf16 elements against their snapshot"})
     return rows
+
+
+def _lib_handle():
+    from rlinf_amd import _lib
+    return _lib.load()
 
 
 def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936):
@@ -382,10 +408,10 @@ def main():
         if not args.no_roofline:
             line["roofline"] = gae_roofline(dev, with_traffic=not args.no_traffic)
             if args.gpus == 1 and not args.no_token_tier:
-                line["roofline_token_tier"] = token_tier_roofline(dev)
+                line["roofline_widening"] = token_tier_roofline(dev)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-            if "roofline_token_tier" in line:
+            if "roofline_widening" in line:
                 line["cpu_baseline_token_tier"] = token_tier_cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
