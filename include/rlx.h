@@ -624,8 +624,8 @@ size_t rlx_patch_workspace_bytes(int64_t n_elems);
 int rlx_patch_scan(const void* value, int value_dtype, const void* snapshot, int snapshot_dtype, int64_t n_elems,
                    void* workspace, size_t workspace_bytes, int64_t* nnz, rlx_stream_t stream);
 int rlx_patch_emit(const void* value, int value_dtype, void* snapshot, int snapshot_dtype, int64_t n_elems, int64_t cols,
-                   int delta_encoding, const void* workspace, int64_t* out_rows, int64_t* out_cols, void* out_values,
-                   uint64_t* maxima, rlx_stream_t stream);
+                   int delta_encoding, const void* workspace, int64_t nnz /* what scan reported: sizes of the outputs */,
+                   int64_t* out_rows, int64_t* out_cols, void* out_values, uint64_t* maxima, rlx_stream_t stream);
 size_t rlx_patch_apply_workspace_bytes(int64_t nnz);
 int rlx_patch_apply(void* target, int dtype, int64_t target_rows, int64_t target_cols, const void* rows,
                     int rows_index_dtype, const void* cols, int cols_index_dtype, int delta_encoded, const void* values,

@@ -195,8 +195,8 @@ PROTOTYPES = {
                                        c_void_p, c_void_p]),
     "rlx_patch_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_patch_scan": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "rlx_patch_emit": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p]),
+    "rlx_patch_emit": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "rlx_patch_apply_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_patch_apply": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64,
                                 c_void_p, c_size_t, c_void_p]),

@@ -229,7 +229,9 @@ __global__ __launch_bounds__(GT) void patch_offsets_groups_kernel(long long* __r
 }
 
 // ---- pass C: emit ---------------------------------------------------------------------------------------------------
-template <typename SRC, typename DST>
+// EW = mask words per thread (one emit workgroup spans EW scan blocks): 8 for sparse patches, where the block scans dominate,
+// 1 for dense ones, where the scattered index / value stores do and more lanes in flight help
+template <typename SRC, typename DST, int EW>
 __global__ __launch_bounds__(PT) void patch_emit_kernel(const SRC* __restrict__ value, DST* __restrict__ snap, long long n,
                                                         long long cols, int delta, const uint8_t* __restrict__ mask,
                                                         const long long* __restrict__ block_offset,
@@ -240,53 +242,91 @@ __global__ __launch_bounds__(PT) void patch_emit_kernel(const SRC* __restrict__ 
                                                         DST* __restrict__ out_values, long long* __restrict__ block_max_r,
                                                         long long* __restrict__ block_max_c) {
     __shared__ long long lds[2 * (PT / 64) + 2];
-    const long long w = (long long)blockIdx.x * PT + threadIdx.x;  // mask word = elements [64 w, 64 w + 64)
+    __shared__ unsigned long long s_mx[2 * (PT / 64)];
+    // EW consecutive mask words (EW * 64 elements) per thread: one block scan per EW scan blocks instead of one each -- at
+    // 0.1 % density the kernel is bound by the scans, not by the mask bytes it reads
+    const long long w0 = ((long long)blockIdx.x * PT + threadIdx.x) * EW;
     const long long nbytes = (n + 7) >> 3;
-    unsigned long long word = 0;
-    if ((w + 1) * 8 <= nbytes) {
-        word = *reinterpret_cast<const unsigned long long*>(mask + w * 8);
+    unsigned long long words[EW];
+    if ((w0 + EW) * 8 <= nbytes) {
+        if constexpr (EW == 1) {
+            words[0] = *reinterpret_cast<const unsigned long long*>(mask + w0 * 8);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EW; j += 2) {
+                const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(mask + (w0 + j) * 8);
+                words[j] = q.x, words[j + 1] = q.y;
+            }
+        }
     } else {
-        for (long long b = w * 8; b < nbytes; ++b) word |= (unsigned long long)mask[b] << (8 * (b - w * 8));
+#pragma unroll
+        for (int j = 0; j < EW; ++j) {
+            words[j] = 0;
+            for (long long bq = (w0 + j) * 8; bq < nbytes && bq < (w0 + j + 1) * 8; ++bq)
+                words[j] |= (unsigned long long)mask[bq] << (8 * (bq - (w0 + j) * 8));
+        }
     }
-    const int pc = __popcll(word);
-    const long long my_last = word ? w * WORD + (63 - __clzll(word)) : -1;
+    int pc = 0;
+    long long my_last = -1;
+#pragma unroll
+    for (int j = 0; j < EW; ++j) {
+        pc += __popcll(words[j]);
+        if (words[j]) my_last = (w0 + j) * WORD + (63 - __clzll(words[j]));
+    }
     const ScanOut s = block_scan_sum_max(pc, my_last, lds);
-    const long long grp = blockIdx.x / GROUP;
-    long long pos = group_base[grp] + block_offset[blockIdx.x] + s.ex_sum;
-    const long long gp = group_prev[grp], lp = block_prev[blockIdx.x];
+    const long long sb0 = (long long)blockIdx.x * EW;  // first scan block under this workgroup (GROUP % EW == 0)
+    const long long grp = sb0 / GROUP;
+    long long pos = group_base[grp] + block_offset[sb0] + s.ex_sum;
+    const long long gp = group_prev[grp], lp = block_prev[sb0];
     const long long bp = gp > lp ? gp : lp;
-    long long prev = bp > s.ex_max ? bp : s.ex_max;  // last changed element before this word (-1: none)
+    long long prev = bp > s.ex_max ? bp : s.ex_max;  // last changed element before this thread's words (-1: none)
     unsigned long long max_r = 0, max_c = 0;
     const bool small = n <= 0xffffffffll;
-    while (word) {
-        const int bit = __ffsll((long long)word) - 1;
-        word &= word - 1;
-        const long long idx = w * WORD + bit;
-        long long r, c, pr = -1, pcx = 0;
-        if (small) {
-            r = (unsigned)idx / (unsigned)cols, c = (unsigned)idx % (unsigned)cols;
-            if (prev >= 0) pr = (unsigned)prev / (unsigned)cols, pcx = (unsigned)prev % (unsigned)cols;
-        } else {
-            r = idx / cols, c = idx % cols;
-            if (prev >= 0) pr = prev / cols, pcx = prev % cols;
+#pragma unroll 1
+    for (int j = 0; j < EW; ++j) {
+        unsigned long long word = words[j];
+        while (word) {
+            const int bit = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            const long long idx = (w0 + j) * WORD + bit;
+            long long r, c, pr = -1, pcx = 0;
+            if (small) {
+                r = (unsigned)idx / (unsigned)cols, c = (unsigned)idx % (unsigned)cols;
+                if (prev >= 0) pr = (unsigned)prev / (unsigned)cols, pcx = (unsigned)prev % (unsigned)cols;
+            } else {
+                r = idx / cols, c = idx % cols;
+                if (prev >= 0) pr = prev / cols, pcx = prev % cols;
+            }
+            long long er = r, ec = c;
+            if (delta && prev >= 0) {  // PatchBuilder.delta_encode: first entry absolute, column restarts on a new row
+                er = r - pr;
+                ec = (r == pr) ? c - pcx : c;
+            }
+            const DST v = Conv<SRC, DST>::cvt(value[idx]);
+            out_rows[pos] = er, out_cols[pos] = ec, out_values[pos] = v;
+            snap[idx] = v;
+            max_r = (unsigned long long)er > max_r ? (unsigned long long)er : max_r;
+            max_c = (unsigned long long)ec > max_c ? (unsigned long long)ec : max_c;
+            prev = idx;
+            ++pos;
         }
-        long long er = r, ec = c;
-        if (delta && prev >= 0) {  // PatchBuilder.delta_encode: first entry absolute, column restarts on a new row
-            er = r - pr;
-            ec = (r == pr) ? c - pcx : c;
-        }
-        const DST v = Conv<SRC, DST>::cvt(value[idx]);
-        out_rows[pos] = er, out_cols[pos] = ec, out_values[pos] = v;
-        snap[idx] = v;
-        max_r = (unsigned long long)er > max_r ? (unsigned long long)er : max_r;
-        max_c = (unsigned long long)ec > max_c ? (unsigned long long)ec : max_c;
-        prev = idx;
-        ++pos;
     }
     // per-block maxima (a same-address atomic per wave serialises: measured 10 ms for 5e5 waves); reduced by patch_maxima
-    const ScanOut mr = block_scan_sum_max(0, (long long)max_r, lds);
-    const ScanOut mc = block_scan_sum_max(0, (long long)max_c, lds);
-    if (threadIdx.x == 0) block_max_r[blockIdx.x] = mr.total_max, block_max_c[blockIdx.x] = mc.total_max;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long orr = __shfl_xor(max_r, off, 64), occ = __shfl_xor(max_c, off, 64);
+        max_r = orr > max_r ? orr : max_r, max_c = occ > max_c ? occ : max_c;
+    }
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = max_r, s_mx[PT / 64 + (threadIdx.x >> 6)] = max_c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long mr = 0, mc = 0;
+        for (int wv = 0; wv < PT / 64; ++wv) {
+            mr = s_mx[wv] > mr ? s_mx[wv] : mr;
+            mc = s_mx[PT / 64 + wv] > mc ? s_mx[PT / 64 + wv] : mc;
+        }
+        block_max_r[blockIdx.x] = (long long)mr, block_max_c[blockIdx.x] = (long long)mc;
+    }
 }
 
 __global__ __launch_bounds__(1024) void patch_maxima_kernel(const long long* __restrict__ block_max_r,
@@ -457,18 +497,25 @@ int run_scan(const void* value, const void* snap, long long n, const Scratch& s,
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
-template <typename SRC, typename DST>
-int run_emit(const void* value, void* snap, long long n, long long cols, int delta, const Scratch& s, void* rows, void* colsb,
-             void* values, void* maxima, hipStream_t st) {
-    hipLaunchKernelGGL((patch_emit_kernel<SRC, DST>), dim3((unsigned)s.nblocks), dim3(PT), 0, st, static_cast<const SRC*>(value),
+template <typename SRC, typename DST, int EW>
+int launch_emit(const void* value, void* snap, long long n, long long cols, int delta, const Scratch& s, void* rows, void* colsb,
+                void* values, void* maxima, hipStream_t st) {
+    const long long eblocks = (s.nblocks + EW - 1) / EW;
+    hipLaunchKernelGGL((patch_emit_kernel<SRC, DST, EW>), dim3((unsigned)eblocks), dim3(PT), 0, st, static_cast<const SRC*>(value),
                        static_cast<DST*>(snap), n, cols, delta, s.mask, s.block_offset, s.block_prev, s.group_sum, s.group_max,
                        static_cast<long long*>(rows), static_cast<long long*>(colsb), static_cast<DST*>(values), s.block_last,
                        s.block_max_c);
     RLX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(patch_maxima_kernel, dim3(1), dim3(1024), 0, st, s.block_last, s.block_max_c, s.nblocks,
+    hipLaunchKernelGGL(patch_maxima_kernel, dim3(1), dim3(1024), 0, st, s.block_last, s.block_max_c, eblocks,
                        static_cast<unsigned long long*>(maxima));
     RLX_LAUNCH_CHECK();
     return RLX_OK;
+}
+template <typename SRC, typename DST>
+int run_emit(const void* value, void* snap, long long n, long long cols, int delta, const Scratch& s, void* rows, void* colsb,
+             void* values, void* maxima, long long nnz, hipStream_t st) {
+    if (nnz * 64 < n) return launch_emit<SRC, DST, 8>(value, snap, n, cols, delta, s, rows, colsb, values, maxima, st);
+    return launch_emit<SRC, DST, 1>(value, snap, n, cols, delta, s, rows, colsb, values, maxima, st);
 }
 
 // dispatch over (value dtype, snapshot dtype): equal dtypes, or an f32 sender feeding a bf16 / f16 receiver
@@ -531,8 +578,9 @@ extern "C" int rlx_patch_scan(const void* value, int value_dtype, const void* sn
 }
 
 extern "C" int rlx_patch_emit(const void* value, int value_dtype, void* snapshot, int snapshot_dtype, int64_t n_elems,
-                              int64_t cols, int delta_encoding, const void* workspace, int64_t* out_rows, int64_t* out_cols,
-                              void* out_values, uint64_t* maxima, rlx_stream_t stream) {
+                              int64_t cols, int delta_encoding, const void* workspace, int64_t nnz, int64_t* out_rows,
+                              int64_t* out_cols, void* out_values, uint64_t* maxima, rlx_stream_t stream) {
+    RLX_REQUIRE(nnz >= 1 && nnz <= n_elems, "rlx_patch_emit: nnz %lld out of range", (long long)nnz);
     RLX_REQUIRE(n_elems >= 1 && cols >= 1 && n_elems % cols == 0, "rlx_patch_emit: bad 2-D view (%lld elements, %lld cols)",
                 (long long)n_elems, (long long)cols);
     RLX_REQUIRE(value && snapshot && workspace && out_rows && out_cols && out_values && maxima, "rlx_patch_emit: NULL argument");
@@ -540,7 +588,7 @@ extern "C" int rlx_patch_emit(const void* value, int value_dtype, void* snapshot
     const int src = value_dtype, dst = snapshot_dtype;
     hipStream_t st = static_cast<hipStream_t>(stream);
     RLX_PATCH_DISPATCH(run_emit, value, snapshot, (long long)n_elems, (long long)cols, delta_encoding, s, out_rows, out_cols,
-                       out_values, maxima, st);
+                       out_values, maxima, (long long)nnz, st);
 }
 
 extern "C" size_t rlx_patch_apply_workspace_bytes(int64_t nnz) {

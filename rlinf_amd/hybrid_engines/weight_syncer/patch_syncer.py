@@ -197,7 +197,7 @@ class PatchBuilder:
             vals = torch.empty(nnz, dtype=snap.dtype, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(lib.rlx_patch_emit(value2d.data_ptr(), vcode, snap.data_ptr(), scode, value2d.numel(),
-                                              snap.shape[1], int(self.delta_encoding), ws.data_ptr(), rows.data_ptr(),
+                                              snap.shape[1], int(self.delta_encoding), ws.data_ptr(), nnz, rows.data_ptr(),
                                               cols.data_ptr(), vals.data_ptr(), maxima.data_ptr(), _stream_ptr(dev)),
                            "rlx_patch_emit")
             ords.append(ordinal), nnzs.append(nnz), rows_l.append(rows), cols_l.append(cols)

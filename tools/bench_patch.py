@@ -66,7 +66,7 @@ def main():
     mx = torch.zeros(2, dtype=torch.int64, device=dev)
     snap2 = snap.clone()
     emit = lambda: _lib.check(lib.rlx_patch_emit(new.data_ptr(), code, snap2.data_ptr(), code, n, args.cols, 1, ws.data_ptr(),  # noqa: E731
-                                                 r.data_ptr(), c.data_ptr(), v.data_ptr(), mx.data_ptr(), st), "emit")
+                                                 count, r.data_ptr(), c.data_ptr(), v.data_ptr(), mx.data_ptr(), st), "emit")
     t_emit = ev_time(emit)
     es = snap.element_size()
     out = {"kernel": "patch_scan+offsets", "dtype": args.dtype, "elems": n, "nnz": count, "bytes": 2 * n * es,
