@@ -99,6 +99,19 @@ int rlx_masked_standardize(float* x, const uint8_t* mask, size_t n, float eps,
                            void* workspace, size_t workspace_bytes, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a12b  global advantage statistics (pipeline mode, SURVEY.md 8f item 2: "global advantage stats")
+ *   masked_stats         <- rlinf/utils/distributed.py:942-954: stats[0..2] (f64, device) = count, sum, sum of squares of x[mask]
+ *                           (mask NULL = all); accumulate != 0 adds to what stats already holds (several batches of one rank)
+ *   normalize_from_stats <- rlinf/utils/distributed.py:957-965: out = (x - mean) * rsqrt(max(var, 0) + 1e-5) in f64 -> f32,
+ *                           count clamped to >= 1, variance uncorrected -- the stats are summed across ranks in between
+ *                           (EnvWorker.send_rollout_trajectories_pipeline, rlinf/workers/env/env_worker.py:1548-1572)
+ * ------------------------------------------------------------------------------------------ */
+size_t rlx_masked_stats_workspace_bytes(int64_t n);
+int rlx_masked_stats(const float* x, const uint8_t* mask, int64_t n, double* stats, int accumulate, void* workspace,
+                     size_t workspace_bytes, rlx_stream_t stream);
+int rlx_normalize_from_stats(const float* x, const double* stats, float* out, int64_t n, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a13  grpo_group_adv  <- calculate_scores, rlinf/algorithms/utils.py:134-152
  *                         + compute_grpo_advantages, rlinf/algorithms/advantages.py:89-121
  *   rewards [n_chunk,B,C] f32, dones [n_chunk+1,B,C] u8, loss_mask [n_chunk,B,C] u8 (required)

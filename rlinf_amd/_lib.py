@@ -144,6 +144,9 @@ PROTOTYPES = {
                              c_int, c_int, c_int, POINTER(GaeParams), c_void_p]),
     "rlx_standardize_workspace_bytes": (c_size_t, [c_size_t]),
     "rlx_masked_standardize": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p, c_size_t, c_void_p]),
+    "rlx_masked_stats_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_masked_stats": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "rlx_normalize_from_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_grpo_group_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_void_p]),
     "rlx_grpo_from_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -133,6 +133,40 @@ def masked_standardize_(x: torch.Tensor, mask: Optional[torch.Tensor] = None, ep
     return x
 
 
+def masked_stats(x: torch.Tensor, mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 accumulate: bool = False) -> torch.Tensor:
+    """(count, sum, sum of squares) of x[mask] as a device float64[3] (rlinf/utils/distributed.py:942-954);
+    ``accumulate`` adds into ``out`` (several batches of one rank before the cross-rank sum)."""
+    lib = _lib.load()
+    dev = _dev(x, mask)
+    xf = _as_f32(x, "x")
+    m8 = _as_u8(mask)
+    if m8 is not None and m8.numel() != xf.numel():
+        raise AssertionError((tuple(mask.shape), tuple(x.shape)))
+    if out is None:
+        out = torch.zeros(3, dtype=torch.float64, device=dev)
+    ws_bytes = lib.rlx_masked_stats_workspace_bytes(xf.numel())
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_masked_stats(xf.data_ptr(), _ptr(m8), xf.numel(), out.data_ptr(), int(bool(accumulate)),
+                                        ws.data_ptr(), ws_bytes, _stream_ptr(dev)), "rlx_masked_stats")
+    return out
+
+
+def normalize_from_stats(x: torch.Tensor, stats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(x - mean) * rsqrt(var + 1e-5) from (count, sum, sumsq), f64 arithmetic -> f32 (rlinf/utils/distributed.py:957-965)."""
+    dev = _dev(x, stats)
+    xf = _as_f32(x, "x")
+    if stats.dtype != torch.float64 or stats.numel() != 3:
+        raise RlxError("stats must be float64[3]")
+    if out is None:
+        out = torch.empty_like(xf)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rlx_normalize_from_stats(xf.data_ptr(), stats.contiguous().data_ptr(), out.data_ptr(),
+                                                        xf.numel(), _stream_ptr(dev)), "rlx_normalize_from_stats")
+    return out.view(x.shape)
+
+
 def grpo_group_adv(rewards: torch.Tensor, dones: torch.Tensor, loss_mask: torch.Tensor, group_size: int,
                    eps: float = 1e-6):
     """rewards [n,B,C], dones [n+1,B,C], loss_mask [n,B,C] -> (advantages [n,B,C], scores [B]).  a13."""

@@ -230,3 +230,35 @@ def test_reward_filter_mask(C, masked):
     assert got.dtype == torch.bool and got.shape == want.shape
     assert torch.equal(got.cpu(), want)
     assert 0 < int(keep.sum()) < B
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_global_advantage_stats(masked):
+    """masked_stats / normalize_from_stats (rlinf/utils/distributed.py:942-965), restated with the reference's tensor
+    expressions: two 'ranks' reduce their own batches, the three numbers are summed, both normalise with the global ones."""
+    from rlinf_amd import ops
+    g = torch.Generator().manual_seed(9)
+    parts = [torch.randn(37, 64, 1, generator=g) * 3 + 1, torch.randn(50, 16, 1, generator=g) - 2]
+    masks = [(torch.rand_like(p) < 0.7) if masked else None for p in parts]
+
+    def ref_stats(x, m):
+        x = x.double()
+        x = x[m.bool()] if m is not None else x.reshape(-1)
+        return torch.tensor([x.numel(), x.sum(), x.square().sum()], dtype=torch.float64)
+
+    want_stats = sum(ref_stats(p, m) for p, m in zip(parts, masks))
+    dev_stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for p, m in zip(parts, masks):
+        ops.masked_stats(p.cuda(), None if m is None else m.cuda(), out=dev_stats, accumulate=True)
+    torch.testing.assert_close(dev_stats.cpu(), want_stats, rtol=1e-12, atol=1e-9)
+    count = want_stats[0].clamp_min(1.0)
+    mean = want_stats[1] / count
+    var = want_stats[2] / count - mean.square()
+    for p in parts:
+        want = ((p.double() - mean) * torch.rsqrt(var.clamp_min(0.0) + 1e-5)).float()
+        got = ops.normalize_from_stats(p.cuda(), dev_stats)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-6, atol=1e-7)
+    empty = ops.masked_stats(parts[0].cuda(), torch.zeros_like(parts[0], dtype=torch.bool).cuda())
+    assert empty.tolist() == [0.0, 0.0, 0.0]
+    torch.testing.assert_close(ops.normalize_from_stats(parts[0].cuda(), empty).cpu(),
+                               (parts[0].double() * torch.rsqrt(torch.tensor(1e-5, dtype=torch.float64))).float())
