@@ -157,7 +157,12 @@ def _token_fused(kw: dict):
     when the caller hands them over -- the entropy bonus and KL penalty the reasoning learner adds right after
     (fsdp_actor_worker.py:750-766)."""
     agg = kw.get("loss_agg_func")
-    agg_name = kw.get("loss_agg") or getattr(agg, "rlx_agg", None) or ("token-mean" if agg is None else None)
+    # our own aggregation helpers carry a tag; the reference's (rlinf.utils.utils) are recognised by name, which is how
+    # the RLINF_EXT_MODULE route sees them
+    by_name = {"masked_mean": "token-mean", "seq_mean_token_sum": "seq-mean-token-sum",
+               "seq_mean_token_mean": "seq-mean-token-mean"}
+    agg_name = (kw.get("loss_agg") or getattr(agg, "rlx_agg", None) or by_name.get(getattr(agg, "__name__", None))
+                or ("token-mean" if agg is None else None))
     if agg_name is None:
         raise NotImplementedError("policy_loss(task_type='reasoning'): loss_agg_func must come from "
                                   "rlinf_amd.utils.utils.get_loss_agg_func (or pass loss_agg='token-mean'|...)")

@@ -308,3 +308,82 @@ def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked):
         if k.startswith("actor/") or k in ("critic/value_loss", "critic/value_clip_ratio"):
             torch.testing.assert_close(torch.tensor(float(metrics[k])), torch.as_tensor(want).float(), rtol=RTOL, atol=ATOL,
                                        msg=lambda m: f"{k}: {m}")
+
+
+def test_ext_hook_callees_behind_a_reference_shaped_registry():
+    """RLINF_EXT_MODULE route: rlinf_amd.ext.register() re-registers its callees in (a stand-in for) RLinf's registry;
+    RLinf then calls them with the tensors its own preprocess_loss_inputs shaped and, for reasoning, with its own
+    loss_agg_func objects -- exactly what the oracle's shaping produces here."""
+    import sys
+    import types
+
+    from oracle import token_oracle as TO
+    from oracle.make_golden import token_batch
+
+    captured = {"adv": {}, "loss": {}}
+    fake = types.ModuleType("rlinf.algorithms.registry")
+    fake.register_advantage = lambda name: (lambda fn: captured["adv"].__setitem__(name, fn) or fn)
+    fake.register_policy_loss = lambda name: (lambda fn: captured["loss"].__setitem__(name, fn) or fn)
+    saved = {k: sys.modules.get(k) for k in ("rlinf", "rlinf.algorithms", "rlinf.algorithms.registry")}
+    pkg, sub = types.ModuleType("rlinf"), types.ModuleType("rlinf.algorithms")
+    pkg.__path__, sub.__path__ = [], []
+    pkg.algorithms, sub.registry = sub, fake
+    sys.modules.update({"rlinf": pkg, "rlinf.algorithms": sub, "rlinf.algorithms.registry": fake})
+    try:
+        from rlinf_amd import ext
+        ext.register()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert set(captured["adv"]) == {"gae", "grpo"}
+    assert set(captured["loss"]) == {"actor_critic", "actor", "decoupled_actor_critic"}
+
+    # reasoning "actor": the learner's kwargs, the REFERENCE-named aggregation function object
+    b = token_batch(91, 8, 21, 5)
+    lp0 = b["old_logprobs"] + 0.3 * torch.randn(8, 21, generator=torch.Generator().manual_seed(1))
+    for agg in (TO.masked_mean, TO.seq_mean_token_sum, TO.seq_mean_token_mean):
+        lp = lp0.clone().requires_grad_(True)
+        wloss, wm = TO.token_actor_loss(lp, b["old_logprobs"], b["advantages"], 0.2, 0.28, loss_mask=b["loss_mask"],
+                                        clip_ratio_c=3.0, loss_agg_func=agg, fast_path_zero_loss_mask=True)
+        wloss.backward()
+        dlp = lp0.cuda().requires_grad_(True)
+        loss, metrics = captured["loss"]["actor"](
+            task_type="reasoning", loss_type="actor", loss_agg_func=agg, logprobs=dlp, old_logprobs=_c(b["old_logprobs"]),
+            advantages=_c(b["advantages"]), clip_ratio_c=3.0, clip_ratio_low=0.2, clip_ratio_high=0.28,
+            loss_mask=_c(b["loss_mask"]), clip_log_ratio_min=None, clip_log_ratio_max=None, fast_path_zero_loss_mask=True)
+        loss.backward()
+        torch.testing.assert_close(loss.detach().cpu(), wloss.detach(), rtol=RTOL, atol=ATOL)
+        torch.testing.assert_close(dlp.grad.cpu(), lp.grad, rtol=RTOL, atol=1e-8)
+        assert set(metrics) == set(wm)
+        for k in wm:
+            torch.testing.assert_close(metrics[k].cpu(), wm[k].float(), rtol=RTOL, atol=ATOL, msg=lambda m: f"{k}: {m}")
+
+    # decoupled_actor_critic on reference-shaped tensors (action level: [bsz, C])
+    g = torch.Generator().manual_seed(4)
+    bsz, C, A = 120, 2, 4
+    raw, old = torch.randn(bsz, C * A, generator=g) * 0.3, None
+    old = raw + 0.1 * torch.randn(bsz, C * A, generator=g)
+    versions = torch.randint(0, 6, (bsz, 1), generator=g).float().expand(bsz, C * A).contiguous()
+    adv, vals, pv, ret = (torch.randn(bsz, C, generator=g) for _ in range(4))
+    lm = torch.rand(bsz, C, generator=g) < 0.7
+    lp = raw.clone().requires_grad_(True)
+    shaped = O.shape_loss_inputs(lp, old, adv, "action_level", A, loss_mask=lm, values=vals, prev_values=pv, returns=ret)
+    _, v2 = O.shape_decoupled_inputs(None, versions, "action_level", A, bsz, shaped["logprobs"].shape)
+    common = dict(clip_ratio_low=0.2, clip_ratio_high=0.28, clip_ratio_c=3.0, value_clip=0.5, huber_delta=1.0)
+    wloss, wm = O.decoupled_actor_critic_loss(versions=v2, current_version=5, behave_weight_threshold=1.04, **common, **shaped)
+    wloss.backward()
+    d_raw = raw.cuda().requires_grad_(True)
+    dshaped = O.shape_loss_inputs(d_raw, old.cuda(), adv.cuda(), "action_level", A, loss_mask=lm.cuda(), values=vals.cuda(),
+                                  prev_values=pv.cuda(), returns=ret.cuda())
+    loss, metrics = captured["loss"]["decoupled_actor_critic"](versions=v2.cuda(), current_version=5,
+                                                              behave_weight_threshold=1.04, **common, **dshaped)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), wloss.detach(), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(d_raw.grad.cpu(), lp.grad, rtol=RTOL, atol=1e-7)
+    for k in wm:
+        if k.startswith("actor/"):
+            torch.testing.assert_close(metrics[k].cpu().float(), torch.as_tensor(wm[k]).float(), rtol=RTOL, atol=ATOL,
+                                       msg=lambda m: f"{k}: {m}")
