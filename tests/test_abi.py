@@ -68,3 +68,39 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_argument_validation_of_the_widening_entries(lib):
+    """Same rule for the token / patch / decoupled entries: bad arguments come back as -22 with a message, before any
+    HIP call; empty problems return 0."""
+    from rlinf_amd._lib import DecoupledLossParams, TokenLossParams, TokenRows
+    rows = TokenRows(n_tokens=4, vocab=0, dtype=0, rows_per_seq=4, seq_stride=0, row_stride=8, temperature=1.0)
+    assert lib.rlx_token_logprob_fwd(None, None, ctypes.byref(rows), None, None, None, None) == -22
+    assert b"bad sizes" in lib.rlx_last_error()
+    rows.vocab, rows.temperature = 8, 0.0
+    assert lib.rlx_token_logprob_fwd(None, None, ctypes.byref(rows), None, None, None, None) == -22
+    assert b"temperature" in lib.rlx_last_error()
+    rows.temperature, rows.n_tokens = 1.0, 0
+    assert lib.rlx_token_logprob_fwd(None, None, ctypes.byref(rows), None, None, None, None) == 0  # nothing to do
+    rows.n_tokens, rows.vocab, rows.row_stride = 4, 2000, 2000
+    assert lib.rlx_categorical_sample(None, ctypes.byref(rows), None, -1, None, 0, None, None, None, None) == -22
+    assert b"1024" in lib.rlx_last_error()
+    tp = TokenLossParams()
+    tp.loss_agg = 7
+    one = ctypes.c_float(0)
+    ptr = ctypes.addressof(one)
+    assert lib.rlx_token_loss_fwd(ptr, ptr, ptr, None, None, None, 1, 1, ctypes.byref(tp), ptr, None, ptr, ptr, ptr, 64,
+                                  None) == -22
+    assert b"loss_agg" in lib.rlx_last_error()
+    assert lib.rlx_grpo_seq_adv(None, None, None, 10, 4, 4, 1e-6, None) == -22 and b"group_size" in lib.rlx_last_error()
+    assert lib.rlx_gae_seq(None, None, None, None, 0, 16, 1.0, 0.95, None) == 0
+    assert lib.rlx_gae_seq(None, None, None, None, 4, 16, 1.0, 0.95, None) == -22
+    assert lib.rlx_patch_scan(None, 1, None, 1, 0, None, 0, None, None) == -22
+    assert lib.rlx_patch_apply(None, 99, 1, 1, ptr, 0, ptr, 0, 0, ptr, 1, None, 0, None) == -22
+    dp = DecoupledLossParams()
+    dp.ppo.raw_per_adv, dp.ppo.sub_per_adv, dp.proximal_mode = 4, 1, 9
+    assert lib.rlx_decoupled_loss_fwd(ptr, ptr, None, None, ptr, None, None, None, None, None, 1, ctypes.byref(dp), ptr, None,
+                                      ptr, ptr, 1 << 20, None) == -22
+    assert b"proximal_mode" in lib.rlx_last_error()
+    assert lib.rlx_reward_filter_mask(None, None, None, 4, 10, 1, 4, 0.0, 1.0, None) == -22
+    assert lib.rlx_patch_workspace_bytes(1 << 20) > (1 << 20) // 8
