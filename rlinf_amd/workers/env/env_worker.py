@@ -22,9 +22,13 @@ class EnvWorker(Worker):
     def __init__(self, cfg, ctx=None):
         super().__init__(cfg, ctx)
         self.train_cfg = cfg.env.train
-        self.stage_num = cfg.rollout.get("pipeline_stage_num", 1)
-        assert self.stage_num == 1, "pipeline stages are the next tier (SURVEY.md 8f item 2)"
-        self.num_envs = self.train_cfg.total_num_envs // self._world_size // self.stage_num  # env_worker.py:137-140
+        # rollout.pipeline_stage_num (env_worker.py:137-140): the reference splits a rank's envs into stages so that one
+        # stage's simulator step overlaps another stage's policy forward.  Rows are independent and a rank's stages are
+        # contiguous env blocks (env_shard), so here the stages of a step ride in ONE policy launch over all of them; only
+        # the trajectory hand-off keeps the per-stage split the learner counts on (send_num = world * stage_num).
+        self.stage_num = int(cfg.rollout.get("pipeline_stage_num", 1))
+        self.stage_envs = self.train_cfg.total_num_envs // self._world_size // self.stage_num
+        self.num_envs = self.stage_envs * self.stage_num
         self.n_train_chunk_steps = (self.train_cfg.max_steps_per_rollout_epoch // cfg.actor.model.num_action_chunks)
         self.rollout_epoch = self.train_cfg.get("rollout_epoch", 1)
         self.gamma = float(cfg.algorithm.get("gamma", 1))
@@ -41,7 +45,8 @@ class EnvWorker(Worker):
 
     def init_worker(self, env_tensors: dict | None = None):
         m = self.cfg.actor.model
-        begin, end = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank)
+        begin, _ = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank, 0)
+        _, end = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank, self.stage_num - 1)
         if env_tensors is None:
             env_tensors = generate_tensors(int(self.train_cfg.get("seed", 0)), self.n_train_chunk_steps * self.rollout_epoch,
                                            self.train_cfg.total_num_envs, m.obs_dim,
@@ -118,4 +123,4 @@ class EnvWorker(Worker):
     def send_rollout_trajectories(self, actor_world_size: int | None = None) -> list:
         """to_splited_trajectories(actor_split_num) (env_worker.py:1026,1463-1467): views, no copies."""
         split = compute_split_num(actor_world_size or self._world_size, self._world_size * self.stage_num)
-        return self.buffer.to_splited_trajectories(split)
+        return self.buffer.to_splited_trajectories(split * self.stage_num)

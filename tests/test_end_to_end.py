@@ -11,7 +11,7 @@ from oracle import ppo_oracle as O
 
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
-             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0):
+             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1),
@@ -21,7 +21,7 @@ def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_e
                        huber_delta=10.0, gamma=gamma, gae_lambda=lam),
         env=dict(train=dict(rollout_epoch=rollout_epoch, total_num_envs=total_envs, auto_reset=auto_reset, ignore_terminations=False,
                             max_episode_steps=5, max_steps_per_rollout_epoch=steps, seed=0, group_size=1)),
-        rollout=dict(pipeline_stage_num=1, enable_cuda_graph=hip_graph),
+        rollout=dict(pipeline_stage_num=stage_num, enable_cuda_graph=hip_graph),
         actor=dict(training_backend="fsdp", micro_batch_size=micro_batch or global_batch, global_batch_size=global_batch,
                    seed=1234, enable_hip_graph=hip_graph,
                    model=dict(model_type="mlp_policy", obs_dim=42, action_dim=8, num_action_chunks=1, precision="32",
@@ -78,7 +78,8 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=3),    # a8: epochs fold
                                    dict(total_envs=16, steps=8, global_batch=64, rollout_epoch=2, hip_graph=True),
                                    dict(total_envs=16, steps=12, global_batch=96, micro_batch=48, entropy_bonus=0.02),  # a22
-                                   dict(total_envs=16, steps=12, global_batch=96, entropy_bonus=0.02, hip_graph=True)])
+                                   dict(total_envs=16, steps=12, global_batch=96, entropy_bonus=0.02, hip_graph=True),
+                                   dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=2, stage_num=2)])   # stages
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
