@@ -64,6 +64,9 @@ class Trajectory:
     prev_values: Optional[torch.Tensor] = None
     versions: Optional[torch.Tensor] = None
     forward_inputs: dict = field(default_factory=dict)
+    # (buffer, begin, end) when this is a column range of a resident TrajectoryBuffer: adjacent ranges of one buffer are
+    # merged back into a single view by convert_trajectories_to_batch instead of being concatenated (copied)
+    origin: Optional[tuple] = field(default=None, repr=False, compare=False)
 
     _TENSOR_FIELDS = ("actions", "rewards", "terminations", "truncations", "dones", "prev_logprobs", "prev_values",
                       "versions")
@@ -139,8 +142,10 @@ class TrajectoryBuffer:
 
     # ---- views in the reference's layout ------------------------------------------------------------------
     def to_trajectory(self, begin: int = 0, end: Optional[int] = None) -> Trajectory:
-        sl = slice(begin, self.B if end is None else end)
+        end = self.B if end is None else end
+        sl = slice(begin, end)
         return Trajectory(
+            origin=(self, begin, end),
             max_episode_length=self.max_episode_length, actions=self.actions[:, sl], rewards=self.rewards[:, sl],
             terminations=self.terminations[:, sl], truncations=self.truncations[:, sl], dones=self.dones[:, sl],
             prev_logprobs=self.prev_logprobs[:, sl], prev_values=self.prev_values[:, sl], versions=self.versions[:, sl],
@@ -158,6 +163,14 @@ def convert_trajectories_to_batch(trajectories: list) -> dict:
     A single trajectory is passed through as views (no copy)."""
     if not trajectories:
         return {}
+    if len(trajectories) > 1 and all(t.origin is not None for t in trajectories):
+        buf, begin, end = trajectories[0].origin
+        contiguous = True
+        for t in trajectories[1:]:
+            contiguous &= t.origin[0] is buf and t.origin[1] == end
+            end = t.origin[2]
+        if contiguous:  # e.g. the per-stage / per-actor splits of one rank's buffer: still views, nothing moves
+            trajectories = [buf.to_trajectory(begin, end)]
     cat = (lambda ts: ts[0]) if len(trajectories) == 1 else (lambda ts: torch.cat(ts, dim=1))
     batch: dict = {}
     if trajectories[0].forward_inputs:

@@ -79,7 +79,8 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=16, steps=8, global_batch=64, rollout_epoch=2, hip_graph=True),
                                    dict(total_envs=16, steps=12, global_batch=96, micro_batch=48, entropy_bonus=0.02),  # a22
                                    dict(total_envs=16, steps=12, global_batch=96, entropy_bonus=0.02, hip_graph=True),
-                                   dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=2, stage_num=2)])   # stages
+                                   dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=2, stage_num=2),   # stages
+                                   dict(total_envs=16, steps=10, global_batch=80, stage_num=2, hip_graph=True)])
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
