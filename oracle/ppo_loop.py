@@ -95,10 +95,44 @@ def advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = 
     return batch
 
 
+def pipeline_advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = True):
+    """runner.use_training_pipeline: the env side computes un-normalised GAE per stage batch and normalises with the
+    (count, sum, sumsq) statistics summed over the batches that feed one learner rank
+    (EnvWorker.compute_advantages_and_returns / send_rollout_trajectories_pipeline, env_worker.py:1469-1572).  GAE and the
+    loss mask are per-column, so one pass over the rank's whole buffer equals the per-stage passes."""
+    lm = lms = None
+    if not auto_reset:
+        lm, lms = O.loss_mask_from_dones(batch["dones"])
+    out = O.embodied_adv_and_returns(adv_type="gae", rewards=batch["rewards"], dones=batch["dones"],
+                                     values=batch["prev_values"], gamma=gamma, gae_lambda=gae_lambda, loss_mask=lm,
+                                     loss_mask_sum=lms, normalize_advantages=False)
+    adv = out["advantages"].contiguous()
+    batch = dict(batch)
+    batch.update(advantages=O.normalize_from_stats(adv, O.masked_stats(adv, lm)), returns=out["returns"].contiguous())
+    if lm is not None:
+        batch.update(loss_mask=lm.contiguous(), loss_mask_sum=lms.contiguous())
+    return batch
+
+
+def pipeline_permutation(T: int, B: int, stage_num: int, generator: torch.Generator) -> torch.Tensor:
+    """Row order in which the learner sees one rank's [T, B] buffer in pipeline mode: every stage's [T, B/stage_num] block
+    is flattened and shuffled on its own with the rank's STATEFUL generator (pack_pipeline_micro_batches,
+    env_worker.py:1519-1537; seeded once in _init_pipeline_params :355-361), stage after stage.  Returned as indices
+    into the rank's flattened [T*B] buffer."""
+    n = B // stage_num
+    parts = []
+    for s in range(stage_num):
+        local = torch.randperm(T * n, generator=generator)
+        parts.append((local // n) * B + s * n + (local % n))
+    return torch.cat(parts)
+
+
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
-           value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0):
+           value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0,
+           perm: torch.Tensor | None = None):
     T, B = batch["prev_logprobs"].shape[:2]
-    perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
+    if perm is None:
+        perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
     flat = O.flatten_and_shuffle(batch, perm)
     n_mb = (T * B) // global_batch
     assert (T * B) % global_batch == 0
@@ -119,15 +153,26 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
 
 
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
-              max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0):
+              max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0,
+              pipeline: dict | None = None):
+    """``pipeline`` = dict(stage_num=..., generator=<the rank's stateful shuffle generator>) selects
+    runner.use_training_pipeline's data path: global-statistics normalisation, per-stage shuffles, and -- every
+    micro-batch being available at once here -- the epoch-major schedule PipelineEmbodiedFSDPActor.run_training reduces
+    to (fsdp_actor_worker_pipeline.py:84-160: fixed global batches, epoch 1 in arrival order, then each again)."""
     t0 = time.perf_counter()
     batch = (rollout(policy, env, eps, gamma, auto_reset) if rollout_epoch == 1
              else rollout_epochs(policy, env, eps, gamma, rollout_epoch, auto_reset))
     t1 = time.perf_counter()
-    batch = advantages(batch, gamma, gae_lambda, auto_reset)
+    perm = None
+    if pipeline is None:
+        batch = advantages(batch, gamma, gae_lambda, auto_reset)
+    else:
+        batch = pipeline_advantages(batch, gamma, gae_lambda, auto_reset)
+        T_, B_ = batch["prev_logprobs"].shape[:2]
+        perm = pipeline_permutation(T_, B_, pipeline["stage_num"], pipeline["generator"])
     t2 = time.perf_counter()
     metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
-                     max_steps=max_update_steps, entropy_bonus=entropy_bonus)
+                     max_steps=max_update_steps, entropy_bonus=entropy_bonus, perm=perm)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))

@@ -591,3 +591,20 @@ def fold_rollout_epochs(nested: dict, rollout_epoch: int) -> dict:
         elif isinstance(value, dict):
             out[key] = fold_rollout_epochs(value, rollout_epoch)
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# a12b  advantage normalisation from sufficient statistics   rlinf/utils/distributed.py:942-965
+# --------------------------------------------------------------------------------------------
+def masked_stats(x, mask=None):
+    x = x.to(dtype=torch.float64)
+    x = x[mask.bool()] if mask is not None else x.reshape(-1)
+    return torch.tensor([x.numel(), x.sum(), x.square().sum()], dtype=torch.float64)
+
+
+def normalize_from_stats(x, stats):
+    stats = stats.to(dtype=torch.float64)
+    count = stats[0].clamp_min(1.0)
+    mean = stats[1] / count
+    var = stats[2] / count - mean.square()
+    return ((x.to(dtype=torch.float64) - mean) * torch.rsqrt(var.clamp_min(0.0) + 1e-5)).float()

@@ -134,3 +134,22 @@ def load_weight_syncer():
         mods[name] = _exec(f"rlinf.hybrid_engines.weight_syncer.{name}", f"rlinf/hybrid_engines/weight_syncer/{name}.py")
     _ws_cache = mods["patch_syncer"]
     return _ws_cache
+
+
+_du_cache = None
+
+
+def load_distributed_utils():
+    """rlinf/utils/distributed.py (masked_stats / normalize_from_stats and friends), executed in place behind stubs for
+    the scheduler's Tracer and the timers module."""
+    global _du_cache
+    if _du_cache is not None:
+        return _du_cache
+    load()
+    sched = sys.modules["rlinf.scheduler"]
+    if not hasattr(sched, "Tracer"):
+        sched.Tracer = type("Tracer", (), {})
+    if "rlinf.utils.timers" not in sys.modules:
+        _stub("rlinf.utils.timers", NamedTimer=type("NamedTimer", (), {}), _rlx_stub=True)
+    _du_cache = _exec("rlinf.utils.distributed", "rlinf/utils/distributed.py")
+    return _du_cache

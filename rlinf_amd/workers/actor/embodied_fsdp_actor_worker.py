@@ -45,6 +45,19 @@ class EmbodiedFSDPActor(Worker):
         self.optimizer_writes_tiles = bool(a.get("optimizer_writes_tiles", True))
         self._graph = None
         self._graph_key = None
+        # runner.use_training_pipeline (embodied_runner.py:479, env_worker.py:1469-1572, fsdp_actor_worker_pipeline.py): the
+        # env side normalises advantages from (count, sum, sumsq) statistics and hands the learner per-stage shuffled
+        # micro-batches.  With rollout and learner sharing the resident buffer nothing streams; what remains is the data
+        # path: that normalisation, the per-stage shuffles with the rank's stateful generator, fixed global batches.
+        self.use_training_pipeline = bool(cfg.runner.get("use_training_pipeline", False))
+        if self.use_training_pipeline:
+            assert cfg.algorithm.adv_type == "gae", ("algorithm.adv_type only supports 'gae' now"
+                                                     "when runner.use_training_pipeline is True.")  # config.py:992-996
+            assert cfg.env.train.get("rollout_epoch", 1) == 1, "the pipeline batch is prepared per rollout epoch (:1512)"
+            # _init_pipeline_params (:355-361): seed = actor.seed + actor_rank + env_rank * actor_world_size, and with one
+            # env rank feeding the learner rank of the same process both ranks are this rank
+            self._pipe_gen = torch.Generator().manual_seed(int(a.get("seed", 1234)) + self._rank + self._rank * self._world_size)
+            self._pipe_shuffle = bool(cfg.algorithm.get("shuffle_rollout", True))
 
     # ---- set-up ---------------------------------------------------------------------------------------------
     def init_worker(self):
@@ -109,7 +122,15 @@ class EmbodiedFSDPActor(Worker):
                 task_type=self.cfg.runner.task_type, adv_type=alg.adv_type, rewards=b["rewards"], dones=b["dones"],
                 values=b.get("prev_values"), gamma=alg.get("gamma", 1), gae_lambda=alg.get("gae_lambda", 1),
                 group_size=alg.get("group_size", 8), reward_type=alg.reward_type, loss_mask=b.get("loss_mask"),
-                loss_mask_sum=b.get("loss_mask_sum"))
+                loss_mask_sum=b.get("loss_mask_sum"),
+                **({"normalize_advantages": False} if self.use_training_pipeline else {}))
+            if self.use_training_pipeline and alg.get("normalize_advantages", True):
+                adv = out["advantages"].contiguous()
+                mask = b.get("loss_mask")
+                if mask is not None and mask.shape != adv.shape:
+                    mask = mask.expand_as(adv).contiguous()
+                stats = ops.masked_stats(adv, mask)  # this rank's stage batches together; one env rank feeds one learner
+                out["advantages"] = ops.normalize_from_stats(adv, stats)
             b.update(out)
             return self._rollout_metrics(b)
 
@@ -147,7 +168,21 @@ class EmbodiedFSDPActor(Worker):
         T, B = b["prev_logprobs"].shape[:2]
         N = T * B
         pkey = ("perm", N)
-        if pkey not in self._ws:  # the reference re-seeds the generator on every call: the permutation never changes
+        if self.use_training_pipeline:
+            # pack_pipeline_micro_batches (env_worker.py:1519-1537): every stage's [T, B/stages] block flattened and shuffled
+            # on its own, stage after stage, with a generator that is seeded ONCE -- a new order every iteration, written
+            # into the same device buffer so that captured graphs keep reading the right rows
+            stages = int(self.cfg.rollout.get("pipeline_stage_num", 1))
+            n = B // stages
+            parts = []
+            for st in range(stages):
+                local = torch.randperm(T * n, generator=self._pipe_gen) if self._pipe_shuffle else torch.arange(T * n)
+                parts.append((local // n) * B + st * n + (local % n))
+            host_perm = torch.cat(parts)
+            if pkey not in self._ws:
+                self._ws[pkey] = torch.empty(N, dtype=torch.int64, device=self.device)
+            self._ws[pkey].copy_(host_perm, non_blocking=False)
+        elif pkey not in self._ws:  # the reference re-seeds the generator on every call: the permutation never changes
             g = torch.Generator()
             g.manual_seed(int(self.cfg.actor.seed) + self._rank)
             self._ws[pkey] = torch.randperm(N, generator=g).to(self.device)

@@ -11,10 +11,10 @@ from oracle import ppo_oracle as O
 
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
-             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1):
+             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
-        runner=dict(task_type="embodied", max_epochs=1, max_steps=-1),
+        runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline),
         algorithm=dict(update_epoch=update_epoch, normalize_advantages=True, group_size=1, reward_type="action_level",
                        logprob_type="action_level", entropy_type="action_level", adv_type="gae", loss_type="actor_critic",
                        bootstrap_type="always", entropy_bonus=entropy_bonus, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
@@ -80,7 +80,9 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=16, steps=12, global_batch=96, micro_batch=48, entropy_bonus=0.02),  # a22
                                    dict(total_envs=16, steps=12, global_batch=96, entropy_bonus=0.02, hip_graph=True),
                                    dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=2, stage_num=2),   # stages
-                                   dict(total_envs=16, steps=10, global_batch=80, stage_num=2, hip_graph=True)])
+                                   dict(total_envs=16, steps=10, global_batch=80, stage_num=2, hip_graph=True),
+                                   dict(total_envs=16, steps=10, global_batch=80, micro_batch=40, stage_num=2, pipeline=True),
+                                   dict(total_envs=16, steps=10, global_batch=80, pipeline=True, hip_graph=True)])
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
@@ -92,11 +94,14 @@ def test_iteration_matches_oracle(shape):
     opt = O.build_adamw(ora)
     runner = _build(cfg, env, sd)
     n_iter = 3 if shape.get("hip_graph") else 2  # graph: eager warm-up, capture+replay, replay
+    pipe = None
+    if shape.get("pipeline"):  # the rank's stateful shuffle generator, seeded like _init_pipeline_params (rank 0 of 1)
+        pipe = dict(stage_num=shape.get("stage_num", 1), generator=torch.Generator().manual_seed(1234))
     for it in range(n_iter):
         eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234,
                                 global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E,
-                                entropy_bonus=shape.get("entropy_bonus", 0.0))
+                                entropy_bonus=shape.get("entropy_bonus", 0.0), pipeline=pipe)
         metrics = runner.run_step(eps.cuda())
         rb = runner.actor.worker.rollout_batch
         tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)  # later iterations inherit Adam's drift

@@ -380,3 +380,17 @@ def test_fold_rollout_epochs(ref):
     _eq(want["forward_inputs"]["states"], got["forward_inputs"]["states"])
     # epoch e of the stacked time axis lands in batch columns [e*B, (e+1)*B): the layout the env worker writes in place
     assert torch.equal(got["rewards"][:, B:2 * B], nested["rewards"][n:2 * n])
+
+
+def test_stats_normalisation(ref):
+    """oracle a12b against rlinf/utils/distributed.py:942-965."""
+    from oracle import reference_loader
+    du = reference_loader.load_distributed_utils()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(9, 33, 1, generator=g) * 2 + 0.5
+    for mask in (None, torch.rand(9, 33, 1, generator=g) < 0.6, torch.zeros(9, 33, 1, dtype=torch.bool)):
+        s0, s1 = du.masked_stats(x, mask), O.masked_stats(x, mask)
+        _eq(s0, s1)
+        _eq(du.normalize_from_stats(x, s0), O.normalize_from_stats(x, s1))
+    two = du.masked_stats(x[:4]) + du.masked_stats(x[4:])
+    _eq(du.normalize_from_stats(x, two), O.normalize_from_stats(x, O.masked_stats(x[:4]) + O.masked_stats(x[4:])))
