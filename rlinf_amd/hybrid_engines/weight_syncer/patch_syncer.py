@@ -8,7 +8,8 @@
 What is mirrored is the same-device ("GPU snapshot") builder with ``compression: none`` -- nvCOMP, the reference's only
 compressor, is NVIDIA-only -- and the init handshake (receiver announces key order, shapes and
 dtypes; the sender snapshots in the RECEIVER's dtypes, :950-1010).  Transport is any pair of send / recv callables, as in
-the reference; ``rlinf_amd.scheduler.dist`` supplies RCCL broadcast ones.  A patch built here is applied by the
+the reference; ``rlinf_amd.scheduler.dist.broadcast_weight_patch`` is the RCCL broadcast of a patch from the
+actor rank to the rollout ranks.  A patch built here is applied by the
 reference's receiver and vice versa (tests/test_gpu_weight_patch.py checks both against the oracle byte for byte).
 """
 

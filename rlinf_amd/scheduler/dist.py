@@ -70,3 +70,42 @@ def all_reduce_scalars(sums: torch.Tensor, maxs: Optional[torch.Tensor], ctx: Di
         if maxs is not None:
             dist.all_reduce(maxs, op=dist.ReduceOp.MAX)
     return sums, maxs
+
+
+# ---- weight-patch transport: the reference sends patches with Worker.broadcast from actor rank 0 to the rollout ranks
+# (embodied_fsdp_actor_worker.py:142-154); here that is a header + the patch tensors over torch.distributed.broadcast ----
+_PATCH_DTYPES = [torch.uint8, torch.int32, torch.int64]
+
+
+def broadcast_weight_patch(patch, ctx: DistContext, src: int = 0, device: Optional[torch.device] = None):
+    """Rank ``src`` passes the EmptyWeightPatch / WeightPatch it built, every other rank passes None; all ranks return the
+    same patch object (tensors on ``device``, default: the context's device).  One small header broadcast (sizes and
+    index dtypes) and one broadcast per patch tensor -- RCCL over xGMI for device tensors, gloo for CPU ones."""
+    from ..hybrid_engines.weight_syncer.patch_syncer import EmptyWeightPatch, WeightPatch
+
+    dev = device or ctx.device or torch.device("cpu")
+    header = torch.zeros(8, dtype=torch.int64, device=dev)
+    if ctx.rank == src:
+        if isinstance(patch, WeightPatch):
+            header = torch.tensor([1, int(patch.version), patch.ordinals.numel(), patch.rows.numel(), patch.values.numel(),
+                                   _PATCH_DTYPES.index(patch.rows.dtype), _PATCH_DTYPES.index(patch.cols.dtype), 0],
+                                  dtype=torch.int64, device=dev)
+        else:
+            header = torch.tensor([0, int(patch.version), 0, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev)
+    if ctx.world_size > 1:
+        dist.broadcast(header, src=src)
+    kind, version, k, nnz, nbytes, rcode, ccode, _ = header.tolist()
+    vt = torch.tensor(version, dtype=torch.int64, device=dev)
+    if kind == 0:
+        return EmptyWeightPatch(vt)
+    if ctx.rank == src:
+        fields = [t.to(dev).contiguous() for t in (patch.ordinals, patch.nnz_per_tensor, patch.rows, patch.cols, patch.values)]
+    else:
+        fields = [torch.empty(k, dtype=torch.int32, device=dev), torch.empty(k, dtype=torch.int32, device=dev),
+                  torch.empty(nnz, dtype=_PATCH_DTYPES[rcode], device=dev), torch.empty(nnz, dtype=_PATCH_DTYPES[ccode], device=dev),
+                  torch.empty(nbytes, dtype=torch.uint8, device=dev)]
+    if ctx.world_size > 1:
+        for t in fields:
+            if t.numel():
+                dist.broadcast(t, src=src)
+    return WeightPatch(vt, *fields)

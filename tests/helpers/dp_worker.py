@@ -41,6 +41,16 @@ def cpu_main(out_path):
     res["send"] = [(e.peer_rank, e.batch_size, e.offset) for e in send.entries]
     res["recv"] = [(e.peer_rank, e.batch_size, e.offset) for e in recv.entries]
     res["dst_4_to_2"] = CommMapper.get_dst_ranks(64, 4, 2, ctx.rank)
+    # weight-patch transport: rank 0 broadcasts a reference-built patch (the committed fixture), rank 1 receives it intact
+    from rlinf_amd.scheduler.dist import broadcast_weight_patch
+    from rlinf_amd.hybrid_engines.weight_syncer import EmptyWeightPatch, WeightPatch
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "weight_patch.pt"), weights_only=False)[0]["patches"]
+    fields = ("version", "ordinals", "nnz_per_tensor", "rows", "cols", "values")
+    sent = WeightPatch(**{f: fx[0][f] for f in fields}) if ctx.rank == 0 else None
+    got = broadcast_weight_patch(sent, ctx, src=0, device=torch.device("cpu"))
+    res["patch_ok"] = all(getattr(got, f).dtype == fx[0][f].dtype and torch.equal(getattr(got, f), fx[0][f]) for f in fields)
+    empty = broadcast_weight_patch(EmptyWeightPatch(torch.tensor(7)) if ctx.rank == 0 else None, ctx, device=torch.device("cpu"))
+    res["empty_ok"] = isinstance(empty, EmptyWeightPatch) and int(empty.version) == 7
     json.dump(res, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()

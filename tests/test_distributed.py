@@ -48,6 +48,8 @@ def test_world_size_2_host_logic_over_gloo(tmp_path):
     assert r0["sums"] == r1["sums"] == [30.0, 8.0] and r0["maxs"] == r1["maxs"] == [0.0, 6.0]
     assert r0["send"] == [[0, 32, 0]] and r1["send"] == [[1, 32, 0]] and r0["recv"] == [[0, 32, 0]]
     assert r0["dst_4_to_2"] == [[0, 16]] and r1["dst_4_to_2"] == [[0, 16]]
+    # the weight patch the actor rank broadcasts arrives byte for byte (header + one broadcast per field)
+    assert r0["patch_ok"] and r1["patch_ok"] and r0["empty_ok"] and r1["empty_ok"]
 
 
 @pytest.mark.gpu
