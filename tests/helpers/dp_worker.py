@@ -77,9 +77,32 @@ def gpu_main(out_path, precision):
     lo, hi = ctx.rank * (B // 2), (ctx.rank + 1) * (B // 2)
     metrics = runner.run_step(eps[:, lo:hi].cuda())
     rb = runner.actor.worker.rollout_batch
+    # actor -> rollout weight sync over the sparse patch format: rank 0 plays the learner, rank 1 a rollout replica that
+    # holds bf16 copies; handshake and patch both travel over torch.distributed (gloo here, RCCL with a GPU per rank)
+    from rlinf_amd.hybrid_engines.weight_syncer import PatchWeightSyncer
+    from rlinf_amd.scheduler.dist import broadcast_weight_patch
+    gsync = torch.Generator().manual_seed(5)
+    master = {"w": torch.randn(96, 130, generator=gsync).cuda(), "b": torch.randn(130, generator=gsync).cuda()}
+    replica = {k: v.to(torch.bfloat16) for k, v in master.items()}
+    syncer = PatchWeightSyncer()
+    box = [None]
+    if ctx.rank == 1:
+        syncer.init_receiver(replica, None, lambda meta: box.__setitem__(0, meta))
+    dist.broadcast_object_list(box, src=1)
+    if ctx.rank == 0:
+        syncer.init_sender(master, ["w", "b"], None, lambda: box[0])
+        master["w"][::3, ::7] += 0.5
+        master["b"][5] = -2.0
+    patch = broadcast_weight_patch(syncer.create_patch(master, 3) if ctx.rank == 0 else None, ctx, src=0)
+    version = None
+    if ctx.rank == 1:
+        version = syncer.apply(replica, lambda: patch)
+    dist.broadcast(master["w"], src=0), dist.broadcast(master["b"], src=0)
+    sync_ok = ctx.rank == 0 or all(torch.equal(replica[k], master[k].to(torch.bfloat16)) for k in master)
     torch.save(dict(rank=ctx.rank, metrics=metrics, params=runner.actor.worker.model.flat.detach().cpu(),
                     advantages=rb["advantages"].cpu(), returns=rb["returns"].cpu(), actions=rb["forward_inputs"]["action"].cpu(),
-                    rewards=rb["rewards"].cpu()), out_path)
+                    rewards=rb["rewards"].cpu(), sync_ok=bool(sync_ok), sync_version=version,
+                    patch_nnz=patch.nnz_per_tensor.tolist()), out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -63,6 +63,9 @@ def test_two_ranks_match_the_sharded_oracle(tmp_path, precision):
     from oracle import ppo_loop as L
     from oracle import ppo_oracle as O
     outs = [torch.load(o, weights_only=False) for o in _launch("gpu", tmp_path, precision, port=29613, timeout=600)]
+    # the weight patch built by rank 0's kernels, broadcast, applied by rank 1's kernels onto its bf16 replica
+    assert all(o["sync_ok"] for o in outs) and outs[1]["sync_version"] == 3
+    assert outs[0]["patch_nnz"] == outs[1]["patch_nnz"] and sum(outs[0]["patch_nnz"]) > 0
     T, B, GB = 12, 64, 192
     env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
     torch.manual_seed(11)
