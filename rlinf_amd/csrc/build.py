@@ -47,6 +47,7 @@ def _compile(src: str, force: bool, save_temps: bool) -> str:
         return obj
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
            "-Wall", "-Wno-unused-function", f"-I{INCLUDE}", f"-I{HERE}", "-c", src, "-o", obj]
+    cmd[1:1] = os.environ.get("RLX_CXXFLAGS", "").split()  # dev: extra -D switches for kernel variant sweeps
     if save_temps:
         cmd.insert(1, "-save-temps=obj")
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=BUILD)

@@ -27,7 +27,16 @@ constexpr float D_FLOOR = -1.0e30f; // x = -inf: d is clamped so that 2^d * d = 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 256;  // threads per row
-constexpr int UNROLL = 4;
+#ifndef RLX_TOK_UNROLL
+#define RLX_TOK_UNROLL 4
+#endif
+#ifndef RLX_TOK_BWD_NT_STORE
+#define RLX_TOK_BWD_NT_STORE 1
+#endif
+#ifndef RLX_TOK_BWD_NT_LOAD
+#define RLX_TOK_BWD_NT_LOAD 1
+#endif
+constexpr int UNROLL = RLX_TOK_UNROLL;
 
 template <typename T>
 struct Elem;
@@ -302,7 +311,9 @@ __global__ __launch_bounds__(NT) void token_logprob_bwd_kernel(const T* logits, 
         for (int gi = 0; gi < nfull; ++gi) {
             u32x4 q[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) q[u] = __builtin_nontemporal_load(vb + (size_t)gi * group + u * NT + tid);
+            for (int u = 0; u < UNROLL; ++u)
+                q[u] = RLX_TOK_BWD_NT_LOAD ? __builtin_nontemporal_load(vb + (size_t)gi * group + u * NT + tid)
+                                           : vb[(size_t)gi * group + u * NT + tid];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 float xv[VEC];
@@ -310,7 +321,8 @@ __global__ __launch_bounds__(NT) void token_logprob_bwd_kernel(const T* logits, 
                 prep_vec<T, SCALE, VEC>(xv, g.temp, g.rtemp);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) xv[i] = grad(xv[i]);
-                __builtin_nontemporal_store(Elem<T>::pack(xv), ov + (size_t)gi * group + u * NT + tid);
+                if (RLX_TOK_BWD_NT_STORE) __builtin_nontemporal_store(Elem<T>::pack(xv), ov + (size_t)gi * group + u * NT + tid);
+                else ov[(size_t)gi * group + u * NT + tid] = Elem<T>::pack(xv);
             }
         }
         for (int v = nfull * group + tid; v < nvec; v += NT) {
