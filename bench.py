@@ -405,15 +405,25 @@ def main():
                              if k in ("train/actor/total_loss", "train/actor/grad_norm", "train/actor/approx_kl",
                                       "rollout/rewards")},
         }
+        def extra(key, fn):
+            """The headline fields above are already measured: a failure in a secondary probe is reported in the line
+            instead of costing it."""
+            try:
+                line[key] = fn()
+            except Exception as e:  # noqa: BLE001
+                line[key] = None
+                line.setdefault("probe_errors", {})[key] = f"{type(e).__name__}: {e}"[:300]
+
         if not args.no_roofline:
-            line["roofline"] = gae_roofline(dev, with_traffic=not args.no_traffic)
+            extra("roofline", lambda: gae_roofline(dev, with_traffic=not args.no_traffic))
             if args.gpus == 1 and not args.no_token_tier:
-                line["roofline_widening"] = token_tier_roofline(dev)
+                extra("roofline_widening", lambda: token_tier_roofline(dev))
         if args.gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-            if "roofline_widening" in line:
-                line["cpu_baseline_token_tier"] = token_tier_cpu_baseline()
-            line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+            extra("cpu_baseline", cpu_baseline)
+            if line.get("roofline_widening"):
+                extra("cpu_baseline_token_tier", token_tier_cpu_baseline)
+            if line.get("cpu_baseline"):
+                line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if ctx.world_size > 1:
         dist.barrier()
