@@ -107,11 +107,15 @@ class MLPPolicy(nn.Module):
         shp = self.shapes[name]
         return self.flat.data[o:o + math.prod(shp)].view(shp)
 
-    def group_ranges(self, lr: float, value_lr: float):
+    def group_ranges(self, lr: float, value_lr: float, train_value_head: bool = True):
         """Contiguous (begin, end, lr) ranges: names containing 'value_head' use value_lr
-        (rlinf/hybrid_engines/fsdp/fsdp_model_manager.py:533-560)."""
+        (rlinf/hybrid_engines/fsdp/fsdp_model_manager.py:533-560).  ``train_value_head=False`` leaves the value head out:
+        under an actor-only loss the reference never computes values (embodied_fsdp_actor_worker.py:620-630), their
+        gradients stay None and torch's AdamW does not touch such parameters -- no decay, no moments."""
         out = []
         for name, shp in self.shapes.items():
+            if not train_value_head and "value_head" in name:
+                continue
             b = self.offsets[name]
             e = b + math.prod(shp)
             r = value_lr if "value_head" in name else lr

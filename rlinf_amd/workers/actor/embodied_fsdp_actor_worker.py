@@ -73,7 +73,8 @@ class EmbodiedFSDPActor(Worker):
         self.opt_stats = torch.zeros(2, device=dev)
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
         self.grad_flat = torch.zeros(n, device=dev)
-        self.groups = self.model.group_ranges(a.optim.lr, a.optim.value_lr)
+        self.groups = self.model.group_ranges(a.optim.lr, a.optim.value_lr,
+                                              train_value_head=self.cfg.algorithm.loss_type != "actor")
         self._ws = {}
 
     def set_global_step(self, global_step: int):

@@ -167,3 +167,32 @@ def test_example_entry_point_runs_the_shipped_config(precision):
         assert all(v == v and abs(v) < 1e9 for k, v in l.items() if isinstance(v, float)), l
     assert lines[0]["train/actor/total_loss"] != lines[2]["train/actor/total_loss"]
     assert lines[2]["perf/env_steps_per_sec"] > 1e5
+
+
+@pytest.mark.gpu
+def test_embodied_grpo_iteration():
+    """adv_type grpo + loss_type actor on the MLP policy (the reference's libero_spatial_0_grpo_mlp.yaml pairing): the
+    advantages match the oracle's GRPO on the rollout the runner produced, the actor trains, and the value head -- whose
+    gradients are None in the reference (values are only computed for adv_type gae, :623) -- is left bit-for-bit alone."""
+    cfg = make_cfg(total_envs=32, steps=10, global_batch=160, auto_reset=False)
+    cfg.algorithm.adv_type, cfg.algorithm.loss_type, cfg.algorithm.group_size = "grpo", "actor", 4
+    cfg.env.train.group_size = 4
+    env = L.synthetic_env_tensors(3, 10, 32, 42, mode="bernoulli", p_done=0.06)
+    torch.manual_seed(5)
+    sd = O.OracleMLPPolicy(42, 8, 1).state_dict()
+    runner = _build(cfg, env, sd)
+    model = runner.actor.worker.model
+    before = model.flat.detach().clone()
+    vh = [(model.offsets[n], model.offsets[n] + model.view(n).numel()) for n in model.shapes if "value_head" in n]
+    m = runner.run_step(torch.randn(10, 32, 8).cuda())
+    rb = runner.actor.worker.rollout_batch
+    lm, lms = O.loss_mask_from_dones(rb["dones"].cpu())
+    want = O.embodied_adv_and_returns(adv_type="grpo", rewards=rb["rewards"].cpu(), dones=rb["dones"].cpu(), loss_mask=lm,
+                                      loss_mask_sum=lms, group_size=4)
+    torch.testing.assert_close(rb["advantages"].cpu(), want["advantages"].contiguous(), rtol=1e-5, atol=1e-6)
+    after = model.flat.detach()
+    for b, e in vh:
+        assert torch.equal(after[b:e], before[b:e])
+    assert float((after - before).abs().max()) > 0
+    assert all(v == v for k, v in m.items() if isinstance(v, float) and "explained_variance" not in k), m
+    assert "train/critic/value_loss" not in m
