@@ -454,27 +454,38 @@ def build_adamw(policy: nn.Module, lr=3e-4, value_lr=3e-4, betas=(0.9, 0.999), e
 
 def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, value_clip=1.0,
                        huber_delta=10.0, entropy_bonus=0.0, clip_grad=0.5, action_dim=8,
-                       logprob_type="action_level"):
+                       logprob_type="action_level", critic_warmup=False):
     """forward -> actor_critic loss -> backward -> clip_grad_norm_ -> AdamW (skipped if norm non-finite)."""
     opt.zero_grad()
     out = policy.evaluate(mb["states"], mb["action"])
     shaped = shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type,
                                action_dim, loss_mask=mb.get("loss_mask"), values=out["values"],
                                prev_values=mb["prev_values"], returns=mb["returns"])
-    loss, metrics = ppo_actor_critic_loss(clip_ratio_low=clip_low, clip_ratio_high=clip_high,
+    loss, metrics = ppo_actor_critic_loss(clip_ratio_low=clip_low, clip_ratio_high=clip_high, critic_warmup=critic_warmup,
                                           value_clip=value_clip, huber_delta=huber_delta, **shaped)
-    if entropy_bonus > 0:
+    if entropy_bonus > 0 and not critic_warmup:  # embodied_fsdp_actor_worker.py:680
         ent = out["entropy"].reshape(out["logprobs"].shape[0], -1, action_dim).sum(dim=-1)
         ent_loss = masked_mean(ent, shaped["loss_mask"])
         loss = loss - entropy_bonus * ent_loss
         metrics["actor/entropy_loss"] = ent_loss.detach()
     loss.backward()
+    if critic_warmup:  # build_optimizer(enable_critic_warmup=True) froze everything but the value head
+        for n, p in policy.named_parameters():  # (fsdp_model_manager.py:523-531): no gradient, no norm share, no update
+            if "value_head" not in n:
+                p.grad = None
     gnorm = torch.nn.utils.clip_grad_norm_(policy.parameters(), clip_grad)
     if torch.isfinite(gnorm):
         opt.step()
     metrics["actor/grad_norm"] = gnorm.detach()
     metrics["actor/total_loss"] = loss.detach()
     return metrics
+
+
+def restart_optimizer(opt):
+    """What the step that ends the critic warm-up does (fsdp_model_manager.py:451-459): a NEW AdamW over all parameters,
+    i.e. every moment and step count back to zero.  Clearing the state of the existing one is the same thing (torch
+    re-initialises a parameter's state lazily when it is empty)."""
+    opt.state.clear()
 
 
 # --------------------------------------------------------------------------------------------

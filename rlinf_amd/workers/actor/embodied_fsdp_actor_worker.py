@@ -274,10 +274,18 @@ class EmbodiedFSDPActor(Worker):
         ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
                                     has_mask, 1.0 / self.model.layout.act_dim if per_elem else 1.0)
 
-    def optimizer_step(self, grads: torch.Tensor, stats: torch.Tensor | None = None):
+    def optimizer_step(self, grads: torch.Tensor, stats: torch.Tensor | None = None, critic_warmup: bool = False):
         """clip_grad_norm_ + AdamW (+ data-parallel mean of the gradient) -> stats (norm, applied) on device.  The
-        optimizer kernel also refreshes the fragment-tile weight image the next forward (and the rollout) streams."""
+        optimizer kernel also refreshes the fragment-tile weight image the next forward (and the rollout) streams.
+        Critic warm-up (fsdp_model_manager.py:523-531, :451-459): the optimizer holds the value head only (everything else
+        has requires_grad False), and after step ``critic_warmup_steps`` the reference builds a NEW optimizer over all
+        parameters -- every moment and every step count starts again from zero, the value head's included."""
         o = self.cfg.actor.optim
+        groups = self.groups
+        if critic_warmup:
+            vh = [(self.model.offsets[n], self.model.offsets[n] + self.model.view(n).numel())
+                  for n in self.model.shapes if "value_head" in n]
+            groups = [(max(b, vb), min(e, ve), lr) for (b, e, lr) in self.groups for (vb, ve) in vh if max(b, vb) < min(e, ve)]
         if self._world_size > 1:
             ops.sum_slabs(grads, out=self.grad_flat)
             all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1)
@@ -285,13 +293,16 @@ class EmbodiedFSDPActor(Worker):
         else:
             g, scale = grads, 1.0
         tiles = self.model.tiles() if (self.fused_step and self.optimizer_writes_tiles) else None
-        ops.clip_adamw_step_(self.model.flat.data, g, self.exp_avg, self.exp_avg_sq, self.groups, 0,
+        ops.clip_adamw_step_(self.model.flat.data, g, self.exp_avg, self.exp_avg_sq, groups, 0,
                              betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
                              max_grad_norm=o.clip_grad, grad_scale=scale, stats=self.opt_stats if stats is None else stats,
                              step_state=self.step_state, workspace=self.adamw_ws,
                              tile_layout=self.model.layout if tiles is not None else None, tiles=tiles)
         self.model.mark_updated(tiles_fresh=tiles is not None)
         self.optimizer_steps += 1
+        if self.critic_warmup_steps > 0 and self.optimizer_steps >= self.critic_warmup_steps:
+            self.exp_avg.zero_(), self.exp_avg_sq.zero_(), self.step_state.zero_()  # build_optimizer(model) anew (:453-455)
+            self.critic_warmup_steps = 0
 
     def _run_update(self, flat: dict, N: int, metrics_dev: torch.Tensor, norms_dev: torch.Tensor):
         a, alg = self.cfg.actor, self.cfg.algorithm
@@ -318,7 +329,8 @@ class EmbodiedFSDPActor(Worker):
                                            metrics_dev[step * accum + j], grad_out, lp)
                     self._entropy_bonus(mbatch, grads[j * ws["slabs"]:(j + 1) * ws["slabs"]], metrics_dev[step * accum + j],
                                         bool(lp.critic_warmup))
-                self.optimizer_step(grads, stats=norms_dev[step])  # (norm, applied) straight into this step's row
+                self.optimizer_step(grads, stats=norms_dev[step],  # (norm, applied) straight into this step's row
+                                    critic_warmup=bool(lp.critic_warmup))
                 step += 1
         return step
 

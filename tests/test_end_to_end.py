@@ -12,7 +12,8 @@ from oracle import ppo_oracle as O
 
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
-             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False):
+             auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False,
+             critic_warmup_steps=0):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline),
@@ -28,7 +29,7 @@ def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_e
                    model=dict(model_type="mlp_policy", obs_dim=42, action_dim=8, num_action_chunks=1, precision="32",
                               add_value_head=True),
                    optim=dict(lr=3e-4, value_lr=3e-4, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
-                              weight_decay=0.01, clip_grad=0.5),
+                              weight_decay=0.01, clip_grad=0.5, critic_warmup_steps=critic_warmup_steps),
                    fsdp_config=dict(strategy="fsdp", sharding_strategy="no_shard"))))
 
 
@@ -83,7 +84,8 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=16, steps=10, global_batch=80, rollout_epoch=2, stage_num=2),   # stages
                                    dict(total_envs=16, steps=10, global_batch=80, stage_num=2, hip_graph=True),
                                    dict(total_envs=16, steps=10, global_batch=80, micro_batch=40, stage_num=2, pipeline=True),
-                                   dict(total_envs=16, steps=10, global_batch=80, pipeline=True, hip_graph=True)])
+                                   dict(total_envs=16, steps=10, global_batch=80, pipeline=True, hip_graph=True),
+                                   dict(total_envs=16, steps=10, global_batch=40, critic_warmup_steps=5)])  # 8 steps / iteration
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
@@ -95,14 +97,16 @@ def test_iteration_matches_oracle(shape):
     opt = O.build_adamw(ora)
     runner = _build(cfg, env, sd)
     n_iter = 3 if shape.get("hip_graph") else 2  # graph: eager warm-up, capture+replay, replay
-    pipe = None
+    pipe, steps_done = None, 0
     if shape.get("pipeline"):  # the rank's stateful shuffle generator, seeded like _init_pipeline_params (rank 0 of 1)
         pipe = dict(stage_num=shape.get("stage_num", 1), generator=torch.Generator().manual_seed(1234))
     for it in range(n_iter):
         eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234,
                                 global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E,
-                                entropy_bonus=shape.get("entropy_bonus", 0.0), pipeline=pipe)
+                                entropy_bonus=shape.get("entropy_bonus", 0.0), pipeline=pipe,
+                                critic_warmup_steps=shape.get("critic_warmup_steps", 0), steps_done=steps_done)
+        steps_done += len(om)
         metrics = runner.run_step(eps.cuda())
         rb = runner.actor.worker.rollout_batch
         tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)  # later iterations inherit Adam's drift
@@ -129,7 +133,8 @@ def test_iteration_matches_oracle(shape):
         steps_taken = len(om) * (it + 1)
         assert float(diff.max()) <= 2 * 3e-4 * steps_taken + 1e-6
         assert float((diff > 2e-5 * (it + 1)).float().mean()) < 0.02, float((diff > 2e-5).float().mean())
-    assert int(runner.actor.worker.step_state.sum()) == runner.actor.worker.optimizer_steps
+    # the device-side Adam step counter restarts when the warm-up ends (a new optimizer in the reference)
+    assert int(runner.actor.worker.step_state.sum()) == runner.actor.worker.optimizer_steps - shape.get("critic_warmup_steps", 0)
 
 
 @pytest.mark.gpu
