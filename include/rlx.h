@@ -644,6 +644,31 @@ int rlx_patch_apply(void* target, int dtype, int64_t target_rows, int64_t target
                     int rows_index_dtype, const void* cols, int cols_index_dtype, int delta_encoded, const void* values,
                     int64_t nnz, void* workspace, size_t workspace_bytes, rlx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * w4  copy_segments  <- the bucket weight syncer's per-parameter casts and copies:
+ *       sender    iter_named_tensor_buckets, rlinf/hybrid_engines/weight_syncer/bucket_syncer.py:110-121
+ *                 (tensor.to(device=bucket_device, dtype=transport_dtype) per parameter)
+ *       receiver  BucketWeightSyncer.apply :296-323 (load_state_dict: param.copy_(received) per parameter)
+ * One launch moves every tensor of a bucket between its own storage and one flat transport buffer.
+ *   table   n_segments x (src, dst, n elements, src dtype, dst dtype); dtype pairs: equal dtypes (raw copy by width) and
+ *           any pair of f32 / bf16 / f16 (c10's conversions: round to nearest even, canonical NaN).  Integer / bool / f64
+ *           tensors never change dtype on this path (the reference only re-types floating tensors, :199-201).
+ *   plan    HOST function: validates the table and fills first_chunk (RLX_COPY_CHUNK elements per workgroup);
+ *           the caller then places the table in device memory.
+ *   run     asynchronous on `stream`; src / dst ranges of different segments must not overlap.
+ * Byte work: bit-exact against torch's .to(dtype).
+ * ------------------------------------------------------------------------------------------ */
+#define RLX_COPY_CHUNK 4096
+typedef struct rlx_copy_segment {
+    const void* src;
+    void* dst;
+    int64_t n;                    /* elements */
+    int32_t src_dtype, dst_dtype; /* enum rlx_dtype */
+    int64_t first_chunk;          /* filled by rlx_copy_segments_plan */
+} rlx_copy_segment;
+int rlx_copy_segments_plan(rlx_copy_segment* table_host, int32_t n_segments, int64_t* total_chunks);
+int rlx_copy_segments(const rlx_copy_segment* table_dev, int32_t n_segments, int64_t total_chunks, rlx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

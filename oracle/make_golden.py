@@ -321,6 +321,51 @@ def make_weight_patches():
     torch.save(cases, os.path.join(OUT, "weight_patch.pt"))
 
 
+BUCKET_CASES = (dict(seed=1, bucket_size=1, bucket_dtype=None, is_agent=False),          # every tensor its own bucket
+                dict(seed=1, bucket_size=50_000, bucket_dtype="bf16", is_agent=False),   # a few tensors per bucket
+                dict(seed=2, bucket_size=10 ** 9, bucket_dtype="fp16", is_agent=True),   # one bucket, agent key rewrite
+                dict(seed=3, bucket_size=20_000, bucket_dtype="fp32", is_agent=True))
+
+
+def bucket_state(seed):
+    """The sender's state dict of the bucket fixtures: patch_states' "after" (mixed dtypes and ranks, a NaN, a 0-dim
+    tensor, bool and int64 tensors) plus the keys the bucket syncer treats specially."""
+    state = patch_states(seed)[1]
+    g = torch.Generator().manual_seed(100 + seed)
+    state["model.language_model.layers.0.w"] = torch.randn(16, 24, generator=g)
+    state["model.visual.proj"] = torch.randn(8, 8, generator=g).bfloat16()
+    state["decoder._extra_state"] = torch.zeros(3)
+    state["empty"] = torch.zeros(0, 4)
+    names = [k for k in state if k != "frozen"] + ["not_in_state"]
+    return state, names
+
+
+def make_weight_buckets():
+    """tests/golden/weight_bucket.pt: the buckets the reference's own BucketWeightSyncer.sync sends (bucket_device cpu,
+    run through oracle/reference_loader.load_weight_syncer) for bucket_state(seed) under BUCKET_CASES."""
+    import asyncio
+    import sys
+
+    reference_loader.load_weight_syncer()
+    m = sys.modules["rlinf.hybrid_engines.weight_syncer.bucket_syncer"]
+    cases = []
+    for case in BUCKET_CASES:
+        state, names = bucket_state(case["seed"])
+        syncer = m.BucketWeightSyncer(case["bucket_size"], case["bucket_dtype"], "cpu", is_agent=case["is_agent"])
+        sent = []
+
+        async def send(bucket):
+            sent.append({k: v.clone() for k, v in bucket.items()})
+
+        async def run():
+            await syncer.init_sender(state, names, send)
+            await syncer.sync(state, send, 7)
+
+        asyncio.run(run())
+        cases.append(dict(params=dict(case), buckets=sent))
+    torch.save(cases, os.path.join(OUT, "weight_bucket.pt"))
+
+
 def main():
     ref = reference_loader.load()
     os.makedirs(OUT, exist_ok=True)
@@ -331,6 +376,7 @@ def main():
     make_shuffle(ref)
     make_token_path(ref)
     make_weight_patches()
+    make_weight_buckets()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

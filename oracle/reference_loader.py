@@ -119,8 +119,12 @@ def load_weight_syncer():
 
     class _Platform:
         @staticmethod
-        def current_stream():
+        def current_stream(*_a):
             return _Stream()
+
+        @staticmethod
+        def is_initialized():
+            return True
 
     sched.Worker.torch_device_type = "cpu"
     sched.Worker.torch_platform = _Platform

@@ -53,6 +53,11 @@ class AdamwGroup(Structure):
     _fields_ = [("begin", c_int64), ("end", c_int64), ("lr", c_float)]
 
 
+class CopySegment(Structure):  # rlx_copy_segment
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("n", c_int64), ("src_dtype", c_int32), ("dst_dtype", c_int32),
+                ("first_chunk", c_int64)]
+
+
 class MlpLayout(Structure):
     _fields_ = [
         ("obs_dim", c_int32), ("act_dim", c_int32), ("val_dim", c_int32), ("hidden", c_int32),
@@ -203,6 +208,8 @@ PROTOTYPES = {
     "rlx_patch_apply_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_patch_apply": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64,
                                 c_void_p, c_size_t, c_void_p]),
+    "rlx_copy_segments_plan": (c_int, [POINTER(CopySegment), c_int32, POINTER(c_int64)]),
+    "rlx_copy_segments": (c_int, [c_void_p, c_int32, c_int64, c_void_p]),
     "rlx_gae_seq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p]),
     "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
 }

@@ -1,3 +1,11 @@
+from .base import WeightSyncer  # noqa: F401
+from .bucket_syncer import (  # noqa: F401
+    BucketWeightSyncer,
+    WeightBucket,
+    iter_named_tensor_buckets,
+    load_bucket,
+    plan_buckets,
+)
 from .patch_syncer import (  # noqa: F401
     EmptyWeightPatch,
     PatchBuilder,

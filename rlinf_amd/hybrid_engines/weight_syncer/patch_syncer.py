@@ -221,7 +221,8 @@ class PatchWeightSyncer:
     awaitables are not needed here: workers of one rank share a process and cross-rank transport is a collective)."""
 
     def __init__(self, snapshot_device="cuda", transport_device=None, delta_encoding: bool = True,
-                 compression_algorithm: str = "none"):
+                 compression_algorithm: str = "none", init_sync_enabled: bool = False, init_sync_prefixes=None,
+                 init_sync_bucket_size: int = 128 * 1024 * 1024):
         if compression_algorithm != "none":
             raise NotImplementedError("only compression_algorithm='none' exists on MI355X (nvCOMP is NVIDIA-only)")
         if torch.device(snapshot_device).type != "cuda":
@@ -233,6 +234,64 @@ class PatchWeightSyncer:
         self.delta_encoding = bool(delta_encoding)
         self.transport_device = None if transport_device is None else torch.device(transport_device)
         self._sender_initialized = self._receiver_initialized = False
+        self._comm_options = None
+        # init sync (:784-805): one full copy of (a prefix-selected part of) the weights, in the RECEIVER's dtypes, sent as
+        # buckets before the first patch so that sender snapshot and receiver state start out equal
+        self.init_sync_enabled = bool(init_sync_enabled)
+        self.init_sync_prefixes = None if init_sync_prefixes is None else [str(p) for p in init_sync_prefixes]
+        if self.init_sync_enabled and self.init_sync_prefixes == []:
+            raise ValueError("Patch init sync prefixes must not be empty")
+        self.init_sync_bucket_size = init_sync_bucket_size
+
+    @property
+    def comm_options(self):
+        return self._comm_options
+
+    def _select_init_sync_weights(self, state_dict: dict) -> list:
+        """:811-840 -- every entry, or those whose key is a listed prefix / lies under one; an unmatched prefix is an error."""
+        if self.init_sync_prefixes is None:
+            return list(state_dict.items())
+        matched = dict.fromkeys(self.init_sync_prefixes, False)
+        selected = []
+        for key, value in state_dict.items():
+            for prefix in self.init_sync_prefixes:
+                if key == prefix or key.startswith(f"{prefix}."):
+                    matched[prefix] = True
+                    selected.append((key, value))
+                    break
+        unmatched = [p for p, hit in matched.items() if not hit]
+        if unmatched:
+            raise ValueError(f"Patch init sync prefixes did not match any state_dict keys: {unmatched}")
+        return selected
+
+    def _sync_init_weights(self, state_dict: dict, receiver_dtypes: dict, send: Callable) -> None:
+        from .bucket_syncer import iter_named_tensor_buckets
+
+        selected = self._select_init_sync_weights(state_dict)
+        for key, _ in selected:
+            if key not in receiver_dtypes:
+                raise ValueError(f"Patch init sync sender key {key} does not exist on receiver")
+        for bucket in iter_named_tensor_buckets(selected, 0, bucket_size=self.init_sync_bucket_size,
+                                                bucket_device=self.transport_device or "cuda",
+                                                dtype_resolver=lambda key, _dtype: receiver_dtypes[key]):
+            send(bucket)
+
+    def _apply_init_weights(self, state_dict: dict, recv: Callable) -> None:
+        from .bucket_syncer import SYNCER_VERSION_KEY, TOTAL_BUCKETS_KEY, load_bucket
+
+        total = None
+        while total is None or total > 0:
+            bucket = recv()
+            if not isinstance(bucket, dict):
+                raise TypeError("Patch init sync receiver expected a bucket payload dictionary")
+            if total is None:
+                total = int(bucket.pop(TOTAL_BUCKETS_KEY).item())
+                bucket.pop(SYNCER_VERSION_KEY)
+            for key in bucket:
+                if key not in state_dict:
+                    raise ValueError(f"Patch init sync receiver key {key} does not exist in state_dict")
+            load_bucket(state_dict, bucket)
+            total -= 1
 
     def sender_initialized(self) -> bool:
         return self._sender_initialized
@@ -251,6 +310,8 @@ class PatchWeightSyncer:
             self.original_shapes[key] = shape
             dtypes[key] = view.dtype
         send({"ordered_keys": self.ordered_keys, "original_shapes": self.original_shapes, "receiver_dtypes": dtypes})
+        if self.init_sync_enabled:
+            self._apply_init_weights(state_dict, recv)
         self._receiver_initialized = True
 
     @torch.no_grad()
@@ -262,6 +323,8 @@ class PatchWeightSyncer:
         dtypes = meta["receiver_dtypes"]
         if set(state_dict.keys()) != set(self.ordered_keys):
             raise ValueError("Sender state dict keys do not match receiver keys")
+        if self.init_sync_enabled:
+            self._sync_init_weights(state_dict, dtypes, send)
         snapshot = {}
         for key in param_names_need_sync:
             view, shape = as_coo_2d_view(state_dict[key].detach())

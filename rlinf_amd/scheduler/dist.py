@@ -109,3 +109,25 @@ def broadcast_weight_patch(patch, ctx: DistContext, src: int = 0, device: Option
             if t.numel():
                 dist.broadcast(t, src=src)
     return WeightPatch(vt, *fields)
+
+
+def broadcast_weight_bucket(bucket, ctx: DistContext, src: int = 0, device: Optional[torch.device] = None):
+    """Rank ``src`` passes a WeightBucket (bucket_syncer.pack_bucket), every other rank None; all ranks return an equal
+    bucket on ``device``.  The layout (names, dtypes, shapes, offsets: a few hundred bytes per tensor) travels as one
+    pickled object, the payload as ONE broadcast of the flat byte buffer -- the reference sends a dict of separately
+    allocated tensors, one transfer each (bucket_syncer.py:262-275 through Worker.send)."""
+    from ..hybrid_engines.weight_syncer.bucket_syncer import SYNCER_VERSION_KEY, TOTAL_BUCKETS_KEY, WeightBucket
+
+    dev = device or ctx.device or torch.device("cpu")
+    head = [None]
+    if ctx.rank == src:
+        meta = {k: int(bucket[k]) for k in (TOTAL_BUCKETS_KEY, SYNCER_VERSION_KEY) if k in bucket}
+        head[0] = (bucket.layout, meta, bucket.flat.numel())
+    if ctx.world_size > 1:
+        dist.broadcast_object_list(head, src=src)
+    layout, meta, nbytes = head[0]
+    flat = bucket.flat.to(dev) if ctx.rank == src else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if ctx.world_size > 1:
+        dist.broadcast(flat, src=src)
+    return WeightBucket.from_flat(flat, layout, {k: torch.tensor(v, dtype=torch.int32, device=dev) for k, v in meta.items()})
+

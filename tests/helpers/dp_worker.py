@@ -51,6 +51,19 @@ def cpu_main(out_path):
     res["patch_ok"] = all(getattr(got, f).dtype == fx[0][f].dtype and torch.equal(getattr(got, f), fx[0][f]) for f in fields)
     empty = broadcast_weight_patch(EmptyWeightPatch(torch.tensor(7)) if ctx.rank == 0 else None, ctx, device=torch.device("cpu"))
     res["empty_ok"] = isinstance(empty, EmptyWeightPatch) and int(empty.version) == 7
+    # bucket transport: layout as one pickled object + ONE broadcast of the flat payload
+    from rlinf_amd.hybrid_engines.weight_syncer import WeightBucket
+    from rlinf_amd.scheduler.dist import broadcast_weight_bucket
+    layout = (("w", torch.bfloat16, (3, 5), 0), ("steps", torch.int64, (), 256), ("flags", torch.bool, (7,), 512))
+    sent_b = None
+    if ctx.rank == 0:
+        sent_b = WeightBucket.from_flat(torch.zeros(768, dtype=torch.uint8), layout,
+                                        {"total_buckets": torch.tensor(1, dtype=torch.int32), "syncer_version": torch.tensor(9, dtype=torch.int32)})
+        sent_b["w"].copy_(torch.arange(15).reshape(3, 5)), sent_b["steps"].fill_(-4), sent_b["flags"][::2].fill_(True)
+    got_b = broadcast_weight_bucket(sent_b, ctx, src=0, device=torch.device("cpu"))
+    res["bucket_ok"] = (list(got_b) == ["total_buckets", "syncer_version", "w", "steps", "flags"] and int(got_b["syncer_version"]) == 9
+                        and got_b["w"].dtype == torch.bfloat16 and got_b["w"].float().flatten().tolist() == list(range(15))
+                        and int(got_b["steps"]) == -4 and got_b["flags"].tolist() == [True, False] * 3 + [True])
     json.dump(res, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()

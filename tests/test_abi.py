@@ -97,6 +97,18 @@ def test_argument_validation_of_the_widening_entries(lib):
     assert lib.rlx_gae_seq(None, None, None, None, 4, 16, 1.0, 0.95, None) == -22
     assert lib.rlx_patch_scan(None, 1, None, 1, 0, None, 0, None, None) == -22
     assert lib.rlx_patch_apply(None, 99, 1, 1, ptr, 0, ptr, 0, 0, ptr, 1, None, 0, None) == -22
+    # copy_segments: the plan is a host function -- it validates and numbers the chunks without a GPU
+    from rlinf_amd._lib import CopySegment
+    table = (CopySegment * 4)(CopySegment(4096, 8192, 10000, 0, 1, -1), CopySegment(0, 0, 0, 3, 3, -1),
+                              CopySegment(256, 512, 4096, 6, 6, -1), CopySegment(64, 128, 1, 2, 0, -1))
+    total = ctypes.c_int64(-1)
+    assert lib.rlx_copy_segments_plan(table, 4, ctypes.byref(total)) == 0
+    assert [t.first_chunk for t in table] == [0, 3, 3, 4] and total.value == 5  # ceil(10000/4096), 0, 1, 1
+    table[0].dst_dtype = 6  # f32 -> 8-byte raw: no such conversion
+    assert lib.rlx_copy_segments_plan(table, 4, ctypes.byref(total)) == -22
+    table[0].dst_dtype, table[0].src = 1, 4098  # f32 source at a 2-byte boundary
+    assert lib.rlx_copy_segments_plan(table, 4, ctypes.byref(total)) == -22
+    assert lib.rlx_copy_segments(None, 0, 0, None) == 0 and lib.rlx_copy_segments(None, 3, 5, None) == -22
     dp = DecoupledLossParams()
     dp.ppo.raw_per_adv, dp.ppo.sub_per_adv, dp.proximal_mode = 4, 1, 9
     assert lib.rlx_decoupled_loss_fwd(ptr, ptr, None, None, ptr, None, None, None, None, None, 1, ctypes.byref(dp), ptr, None,

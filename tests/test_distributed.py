@@ -50,6 +50,7 @@ def test_world_size_2_host_logic_over_gloo(tmp_path):
     assert r0["dst_4_to_2"] == [[0, 16]] and r1["dst_4_to_2"] == [[0, 16]]
     # the weight patch the actor rank broadcasts arrives byte for byte (header + one broadcast per field)
     assert r0["patch_ok"] and r1["patch_ok"] and r0["empty_ok"] and r1["empty_ok"]
+    assert r0["bucket_ok"] and r1["bucket_ok"]  # a weight bucket: pickled layout + one broadcast of the flat byte buffer
 
 
 @pytest.mark.gpu
