@@ -255,6 +255,27 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     rows.append({"kernel": "patch_scan (+ offsets)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK_GBPS,
                  "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
                  "algorithmic_bytes": nb, "shape": f"{n} bf16 elements against their snapshot"})
+    # Reinforce++ advantages (returns pass 13 B/token + normalisation 8 B/token; three launches timed together)
+    from rlinf_amd import token_ops as _t
+    lp = -torch.rand(4096, 8192, device=device, generator=g) * 3
+    rlp = lp + 0.3 * torch.randn(4096, 8192, device=device, generator=g)
+    msk = torch.ones(4096, 8192, dtype=torch.bool, device=device)
+    us = avg_us(lambda: _t.reinpp_seq_adv(r, msk, lp, rlp, 0.001, "low_var_kl"))
+    nb = lp.numel() * 21
+    rows.append({"kernel": "reinpp_seq_adv (returns + finalize + normalize)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
+                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
+                 "algorithmic_bytes": nb, "shape": "4096 sequences x 8192 tokens, k3 KL penalty"})
+    del lp, rlp, msk
+    # bucket weight sync: 16 f32 masters of 4096 x 8192 -> one flat bf16 transport buffer (6 B per element, one launch)
+    from rlinf_amd.hybrid_engines.weight_syncer.bucket_syncer import BucketPacker
+    masters = [(f"w{i}", torch.randn(4096, 8192, device=device, generator=g), torch.bfloat16) for i in range(16)]
+    packer = BucketPacker(masters)
+    dev_t = torch.device(device)
+    us = avg_us(lambda: packer.pack(masters, dev_t, None, persistent=True))
+    nb = 16 * 4096 * 8192 * 6
+    rows.append({"kernel": "copy_segments (bucket pack f32 -> bf16)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
+                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
+                 "algorithmic_bytes": nb, "shape": "16 tensors x 4096 x 8192 f32 into one bf16 bucket"})
     return rows
 
 

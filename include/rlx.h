@@ -588,6 +588,21 @@ int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, float* adva
                      int group_size, float eps, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * t3b  reinpp_seq_adv  <- adv_type "reinpp" on reasoning batches: preprocess_reasoning_advantages_inputs
+ *                         rlinf/algorithms/utils.py:218-219,245-251 + compute_reinpp_advantages rlinf/algorithms/advantages.py:300-364
+ *                         (use_reinpp_baseline False) + postprocess_reasoning_advantages_outputs rlinf/algorithms/utils.py:265-277
+ *   rewards [bsz] f32, loss_mask [bsz, seq] u8, logprob / ref_logprob [bsz, seq] f32 (read only when kl_beta > 0; the
+ *   per-token reward is then -kl_beta * kl_penalty(logprob, ref_logprob, kl_type)) -> advantages [bsz, seq] f32 =
+ *   (return-to-go - masked mean) * rsqrt(max(masked variance, 1e-8)), every position (not only masked ones), like the
+ *   reference.  The scalar reward of sequence b sits at seq-1 minus the index of the first True of sequence bsz-1-b's mask
+ *   (the reference flips the batch axis when it looks for the last valid token) -- seq-1 for masks that start with True.
+ * ------------------------------------------------------------------------------------------ */
+size_t rlx_reinpp_workspace_bytes(int64_t bsz);
+int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask, const float* logprob, const float* ref_logprob,
+                       int kl_type, float kl_beta, float* advantages, int64_t bsz, int64_t seq, void* workspace,
+                       size_t workspace_bytes, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * t5  gae_seq  <- adv_type "gae" on reasoning batches: preprocess_reasoning_advantages_inputs rlinf/algorithms/utils.py:177-262
  *                 + compute_gae_advantages_and_returns rlinf/algorithms/advantages.py:24-86
  *                 + postprocess_reasoning_advantages_outputs rlinf/algorithms/utils.py:265-277

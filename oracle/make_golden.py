@@ -366,6 +366,46 @@ def make_weight_buckets():
     torch.save(cases, os.path.join(OUT, "weight_bucket.pt"))
 
 
+REINPP_GRID = (dict(seed=1, bsz=8, seq=6, kl_beta=0.0, kl="", masks="prefix"),
+               dict(seed=2, bsz=8, seq=37, kl_beta=0.001, kl="low_var_kl", masks="ragged"),   # first position False in places
+               dict(seed=3, bsz=12, seq=1100, kl_beta=0.5, kl="kl", masks="ragged"),          # more than one 1024-token tile
+               dict(seed=4, bsz=4, seq=64, kl_beta=0.05, kl="abs", masks="empty_rows"),
+               dict(seed=5, bsz=6, seq=20, kl_beta=0.2, kl="mse", masks="all_false"))
+
+
+def reinpp_batch(seed, bsz, seq, masks, **_):
+    """rewards [bsz], loss_mask [bsz, seq], logprob / ref_logprob [bsz, seq] for the Reinforce++ fixtures."""
+    g = torch.Generator().manual_seed(seed)
+    rewards = torch.randn(bsz, generator=g)
+    lens = torch.randint(1, seq + 1, (bsz,), generator=g)
+    mask = torch.arange(seq)[None, :] < lens[:, None]
+    if masks in ("ragged", "empty_rows"):
+        start = torch.randint(0, 3, (bsz,), generator=g)  # some masks do not start at position 0 (prompt tokens in the window)
+        mask &= torch.arange(seq)[None, :] >= start[:, None]
+    if masks == "empty_rows":
+        mask[1] = False
+    if masks == "all_false":
+        mask[:] = False
+    logprob = -torch.rand(bsz, seq, generator=g) * 3
+    ref_logprob = logprob + 0.3 * torch.randn(bsz, seq, generator=g)
+    return rewards, mask, logprob, ref_logprob
+
+
+def make_reinpp(ref):
+    """tests/golden/reinpp.pt: calculate_adv_and_returns(task_type="reasoning", adv_type="reinpp") of the reference."""
+    import sys
+    reg = sys.modules["rlinf.algorithms.registry"]
+    cases = []
+    for p in REINPP_GRID:
+        rewards, mask, lp, rlp = reinpp_batch(**p)
+        adv, ret = reg.calculate_adv_and_returns(task_type="reasoning", adv_type="reinpp", rewards=rewards.clone(), loss_mask=mask,
+                                                 group_size=2, kl_beta=p["kl_beta"], logprob=lp, ref_logprob=rlp,
+                                                 kl_penalty_type=p["kl"], use_reinpp_baseline=False)
+        assert ret is None
+        cases.append(dict(params=dict(p), advantages=adv.clone()))
+    torch.save(cases, os.path.join(OUT, "reinpp.pt"))
+
+
 def main():
     ref = reference_loader.load()
     os.makedirs(OUT, exist_ok=True)
@@ -377,6 +417,7 @@ def main():
     make_token_path(ref)
     make_weight_patches()
     make_weight_buckets()
+    make_reinpp(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -206,6 +206,35 @@ def grpo_reasoning_advantages(rewards, loss_mask, group_size: int):
     return adv.transpose(0, 1).contiguous()
 
 
+def reinpp_reasoning_advantages(rewards, loss_mask, group_size: int, use_reinpp_baseline: bool = False, kl_beta: float = 0.0,
+                                logprob=None, ref_logprob=None, kl_penalty_type: str = ""):
+    """Reinforce++ on reasoning batches: rewards [bsz], loss_mask / logprob / ref_logprob [bsz, seq] -> advantages [bsz, seq]
+    (preprocess utils.py:218-219,245-251 + compute_reinpp_advantages advantages.py:300-364 + post utils.py:265-277).
+
+    Restated as written, including what looks unintended: the "position of the last True" is read off ``fliplr`` of the
+    [seq, bsz] mask -- a flip of the BATCH axis -- so sequence b's reward lands at seq-1 minus the index of the FIRST True
+    of sequence bsz-1-b's mask (seq-1 whenever that mask starts with True, which response masks do); and
+    ``use_reinpp_baseline`` ends in a 1-D ``src`` for a 2-D scatter index, which torch rejects."""
+    assert rewards.ndim == 1
+    mask = loss_mask.transpose(0, 1)  # [seq, bsz]
+    rewards = rewards.unsqueeze(0)
+    if use_reinpp_baseline:
+        grouped = rewards.view(-1, group_size)
+        grouped -= grouped.mean(dim=1, keepdims=True)  # (in place: the caller's rewards change, as in the reference)
+        rewards = grouped.view(-1)
+    r = torch.zeros_like(mask).float()
+    seq = mask.size(0)
+    eos = seq - 1 - mask.long().fliplr().argmax(dim=0, keepdim=True)
+    r = r.scatter_(dim=0, index=eos, src=rewards)
+    if kl_beta > 0:
+        r -= kl_beta * kl_penalty(logprob.transpose(0, 1), ref_logprob.transpose(0, 1), kl_penalty_type)
+    ret = torch.cumsum(r.flip(dims=[0]), dim=0).flip(dims=[0])
+    mean = masked_mean(ret, mask)
+    var = masked_mean((ret - mean).pow(2), mask)
+    adv = (ret - mean) * var.clamp(min=1e-8).rsqrt()
+    return adv.transpose(0, 1).contiguous()
+
+
 # --------------------------------------------------------------------------------------------
 # t7  categorical action sampling (K2)   rlinf/models/embodiment/openvla_oft/official/openvla_oft_action_model.py:363-414
 #     (_discrete_prediction's sampling branch + _compute_logprobs_and_entropy :258-287)

@@ -112,7 +112,40 @@ def _native_gae_reasoning(*, rewards, loss_mask, values=None, gamma=1.0, gae_lam
     return _u.unstage(adv, values), _u.unstage(ret, values)
 
 
+def _native_reinpp_reasoning(*, rewards, loss_mask, group_size=None, use_reinpp_baseline=False, kl_beta=0.0, logprob=None,
+                             ref_logprob=None, kl_penalty_type="", **kwargs):
+    """Reinforce++ on [bsz, seq] tensors -> (advantages, None): replaces preprocess_reasoning_advantages_inputs +
+    compute_reinpp_advantages (advantages.py:300-364) + postprocess, reward placement as the reference computes it."""
+    if rewards.ndim != 1:
+        raise AssertionError(f"Unsupported reward shape {rewards.shape}")
+    if use_reinpp_baseline:
+        # advantages.py:329-332,343: the group-centred rewards come back 1-D and scatter_ then rejects them against the
+        # 2-D index -- the reference cannot run this option; fail the same way rather than guess what was meant
+        raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1) -- use_reinpp_baseline "
+                         "fails at the reward scatter in the reference (rlinf/algorithms/advantages.py:343)")
+    dev = _u.compute_device(rewards, loss_mask, logprob, ref_logprob)
+    kl = float(kl_beta) > 0
+    adv = token_ops.reinpp_seq_adv(_u.stage(rewards, dev).float(), _u.stage(loss_mask, dev),
+                                   _u.stage(logprob, dev).float() if kl else None,
+                                   _u.stage(ref_logprob, dev).float() if kl else None, float(kl_beta), kl_penalty_type if kl else None)
+    return _u.unstage(adv, loss_mask), None
+
+
+@register_advantage("reinpp")
+def compute_reinpp_advantages(rewards: torch.Tensor, loss_mask: torch.Tensor, group_size: int, use_reinpp_baseline: bool = False,
+                              kl_beta: float = 0.0, logprob=None, ref_logprob=None, kl_penalty_type: str = "", **kwargs):
+    """The reference's own signature (advantages.py:300-364): rewards [1, B], loss_mask / logprob / ref_logprob [L, B] ->
+    (advantages [L, B], None).  The kernel works on sequence-major rows, so this entry transposes on the way in and out;
+    ``calculate_adv_and_returns`` skips it and hands the [bsz, seq] tensors over untouched."""
+    t = lambda x: None if x is None else x.transpose(0, 1)  # noqa: E731
+    adv, _ = _native_reinpp_reasoning(rewards=rewards.reshape(-1), loss_mask=t(loss_mask), group_size=group_size,
+                                      use_reinpp_baseline=use_reinpp_baseline, kl_beta=kl_beta, logprob=t(logprob),
+                                      ref_logprob=t(ref_logprob), kl_penalty_type=kl_penalty_type)
+    return adv.transpose(0, 1), None
+
+
 _mark_native_adv("gae", _native_gae)
 _mark_native_adv("grpo", _native_grpo)
 _mark_native_adv("gae", _native_gae_reasoning, task_type="reasoning")
 _mark_native_adv("grpo", _native_grpo_reasoning, task_type="reasoning")
+_mark_native_adv("reinpp", _native_reinpp_reasoning, task_type="reasoning")

@@ -1,0 +1,230 @@
+// reinpp_adv.hip -- Reinforce++ advantages on reasoning batches in the sequence-major [bsz, seq] layout, gfx950.
+//
+// Replaces preprocess_reasoning_advantages_inputs (rlinf/algorithms/utils.py:218-219,245-251: transposes to [seq, bsz]),
+// compute_reinpp_advantages (rlinf/algorithms/advantages.py:300-364: reward scatter, KL penalty, flip-cumsum-flip,
+// masked mean / variance, normalise) and postprocess_reasoning_advantages_outputs (utils.py:265-277: transpose + copy):
+//
+//   returns   one workgroup per sequence: locate the reward position, suffix-sum r[t] = [t == eos] reward - beta * kl[t]
+//             from the right in 1024-element tiles (coalesced 16-byte loads, wave-shuffle scans, f64 carries), write the
+//             return-to-go, accumulate (count, sum, sum of squares) of the masked returns -> per-sequence partials
+//   finalize  one workgroup: partials -> mean, rsqrt(max(var, 1e-8))
+//   normalize adv = (ret - mean) * rstd over the whole buffer, float4
+//
+// HBM-bound: 4 (logprob) + 4 (ref) + 1 (mask) read + 4 written, then 4 + 4 for the normalisation = 21 B per token.
+//
+// The reward position follows the reference as written: "eos" of sequence b is seq-1 minus the index of the FIRST True in
+// the mask of sequence bsz-1-b (advantages.py:337-341 flips the batch axis of the [seq, bsz] mask, not the time axis).
+// Response masks start with True, for which this is seq-1: the scalar reward sits on the last position of the row.
+
+#include "rlx_common.h"
+
+namespace rlx {
+namespace {
+
+constexpr int RT = 256;
+constexpr int TILE = RT * 4;
+
+__device__ __forceinline__ float kl_value(int kind, float lp, float ref) {  // kl_penalty(logprob, ref_logprob), utils.py:26-64
+    const float diff = fsub(lp, ref);
+    switch (kind) {
+        case RLX_KL_K1: return diff;
+        case RLX_KL_ABS: return fabsf(diff);
+        case RLX_KL_K2: return fmul(0.5f, fmul(diff, diff));
+        default: {
+            const float kl = fminf(fmaxf(fsub(ref, lp), -20.f), 20.f);
+            return fminf(fmaxf(fsub(fsub(expf(kl), kl), 1.f), -10.f), 10.f);
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_incl_scan_from_right(double v, int lane) {
+    // inclusive sum over lanes >= this lane (suffix), wave64
+#pragma unroll
+    for (int off = 1; off < RLX_WAVE; off <<= 1) {
+        const double o = __shfl_down(v, off, RLX_WAVE);
+        if (lane + off < RLX_WAVE) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ mask,
+                                                            const float* __restrict__ logprob, const float* __restrict__ ref,
+                                                            int kl_kind, float kl_beta, float* __restrict__ ret,
+                                                            double* __restrict__ partials, long long B, long long S, int aligned) {
+    __shared__ long long s_first;
+    __shared__ double s_wave[RT / RLX_WAVE];
+    __shared__ double s_red[3][RT / RLX_WAVE];
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & (RLX_WAVE - 1), wave = tid / RLX_WAVE;
+    // ---- reward position (see the header): first True of the mirrored sequence's mask; none -> argmax's 0
+    if (tid == 0) s_first = S;
+    __syncthreads();
+    {
+        const uint8_t* mm = mask + (B - 1 - b) * S;
+        long long first = S;
+        for (long long t = tid; t < S && first == S; t += RT)
+            if (mm[t]) first = t;
+        // lanes stop at their own first hit; the block minimum is the row's first True
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long o = __shfl_xor(first, off, RLX_WAVE);
+            first = o < first ? o : first;
+        }
+        if (lane == 0 && first < S) atomicMin(&s_first, first);
+    }
+    __syncthreads();
+    const long long eos = S - 1 - (s_first == S ? 0 : s_first);
+    const float reward = rewards[b];
+    const bool has_kl = kl_beta > 0.f;
+    const float* lp = logprob + b * S;
+    const float* rf = ref + b * S;
+    const uint8_t* m = mask + b * S;
+    float* out = ret + b * S;
+    const bool vec_ok = aligned && (S % 4 == 0);  // every row then starts 16-byte aligned
+    double carry = 0.0;                // sum of r over everything to the right of the current tile
+    double cnt = 0.0, sum = 0.0, sq = 0.0;
+    const long long n_tiles = (S + TILE - 1) / TILE;
+    for (long long tile = n_tiles - 1; tile >= 0; --tile) {
+        const long long t0 = tile * TILE + (long long)tid * 4;
+        float r[4];
+        uint8_t mk[4];
+        if (vec_ok && t0 + 4 <= S) {
+            if (has_kl) {
+                const float4 a = *reinterpret_cast<const float4*>(lp + t0);
+                const float4 c = *reinterpret_cast<const float4*>(rf + t0);
+                r[0] = -fmul(kl_beta, kl_value(kl_kind, a.x, c.x)), r[1] = -fmul(kl_beta, kl_value(kl_kind, a.y, c.y));
+                r[2] = -fmul(kl_beta, kl_value(kl_kind, a.z, c.z)), r[3] = -fmul(kl_beta, kl_value(kl_kind, a.w, c.w));
+            } else {
+                r[0] = r[1] = r[2] = r[3] = 0.f;
+            }
+            const uint32_t mw = *reinterpret_cast<const uint32_t*>(m + t0);
+            mk[0] = mw & 0xff, mk[1] = (mw >> 8) & 0xff, mk[2] = (mw >> 16) & 0xff, mk[3] = (mw >> 24) & 0xff;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long t = t0 + j;
+                const bool in = t < S;
+                r[j] = (in && has_kl) ? -fmul(kl_beta, kl_value(kl_kind, lp[t], rf[t])) : 0.f;
+                mk[j] = in ? m[t] : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (t0 + j == eos) r[j] = has_kl ? fadd(reward, r[j]) : reward;  // r_matrix[eos] = reward, then -= beta * kl
+        // suffix sums: within the lane, across the wave, across the block's waves, plus the carry from the tiles to the right
+        const double l3 = (double)r[3], l2 = l3 + (double)r[2], l1 = l2 + (double)r[1], l0 = l1 + (double)r[0];
+        const double incl = wave_incl_scan_from_right(l0, lane);  // lanes >= this one
+        if (lane == 0) s_wave[wave] = incl;
+        __syncthreads();
+        double right = carry;  // everything right of this lane's 4 elements
+        for (int w = wave + 1; w < RT / RLX_WAVE; ++w) right += s_wave[w];
+        right += incl - l0;
+        double tile_total = 0.0;
+        for (int w = 0; w < RT / RLX_WAVE; ++w) tile_total += s_wave[w];
+        const float v[4] = {(float)(right + l0), (float)(right + l1), (float)(right + l2), (float)(right + l3)};
+        if (vec_ok && t0 + 4 <= S) {
+            *reinterpret_cast<float4*>(out + t0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t0 + j < S) out[t0 + j] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (mk[j]) cnt += 1.0, sum += (double)v[j], sq += (double)v[j] * (double)v[j];
+        carry += tile_total;
+        __syncthreads();  // s_wave is rewritten by the next tile
+    }
+    double red[3] = {cnt, sum, sq};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        red[k] = wave_sum(red[k]);
+        if (lane == 0) s_red[k][wave] = red[k];
+    }
+    __syncthreads();
+    if (tid < 3) {
+        double t = 0.0;
+        for (int w = 0; w < RT / RLX_WAVE; ++w) t += s_red[tid][w];
+        partials[b * 3 + tid] = t;
+    }
+}
+
+__global__ __launch_bounds__(RT) void reinpp_finalize_kernel(const double* __restrict__ partials, long long B, float* __restrict__ stats) {
+    __shared__ double s_red[3][RT / RLX_WAVE];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (long long b = threadIdx.x; b < B; b += RT) {
+        acc[0] += partials[b * 3], acc[1] += partials[b * 3 + 1], acc[2] += partials[b * 3 + 2];
+    }
+    const int lane = threadIdx.x & (RLX_WAVE - 1), wave = threadIdx.x / RLX_WAVE;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        acc[k] = wave_sum(acc[k]);
+        if (lane == 0) s_red[k][wave] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0, s = 0.0, q = 0.0;
+        for (int w = 0; w < RT / RLX_WAVE; ++w) c += s_red[0][w], s += s_red[1][w], q += s_red[2][w];
+        // masked_mean of an all-False mask is the (zero) sum itself (utils/utils.py:327-328)
+        const double mean = c > 0.0 ? s / c : 0.0;
+        double var = c > 0.0 ? q / c - mean * mean : 0.0;
+        var = var > 1e-8 ? var : 1e-8;
+        stats[0] = (float)mean;
+        stats[1] = (float)(1.0 / sqrt(var));
+    }
+}
+
+__global__ __launch_bounds__(RT) void reinpp_normalize_kernel(float* __restrict__ x, long long n, const float* __restrict__ stats) {
+    const float mean = stats[0], rstd = stats[1];
+    const long long n4 = n / 4;
+    const long long stride = (long long)gridDim.x * RT;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    if (reinterpret_cast<uintptr_t>(x) & 15) {  // a view at an odd offset: element-wise
+        for (long long i = (long long)blockIdx.x * RT + threadIdx.x; i < n; i += stride) x[i] = fmul(fsub(x[i], mean), rstd);
+        return;
+    }
+    for (long long i = (long long)blockIdx.x * RT + threadIdx.x; i < n4; i += stride) {
+        float4 v = x4[i];
+        v.x = fmul(fsub(v.x, mean), rstd), v.y = fmul(fsub(v.y, mean), rstd);
+        v.z = fmul(fsub(v.z, mean), rstd), v.w = fmul(fsub(v.w, mean), rstd);
+        x4[i] = v;
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * RT + threadIdx.x; i < n; i += stride) x[i] = fmul(fsub(x[i], mean), rstd);
+}
+
+}  // namespace
+}  // namespace rlx
+
+using namespace rlx;
+
+extern "C" size_t rlx_reinpp_workspace_bytes(int64_t bsz) { return (size_t)(bsz > 0 ? bsz : 0) * 3 * sizeof(double) + 256; }
+
+extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask, const float* logprob, const float* ref_logprob,
+                                  int kl_type, float kl_beta, float* advantages, int64_t bsz, int64_t seq, void* workspace,
+                                  size_t workspace_bytes, rlx_stream_t stream) {
+    RLX_REQUIRE(bsz >= 0 && seq >= 0, "rlx_reinpp_seq_adv: negative size");
+    if (bsz == 0 || seq == 0) return RLX_OK;
+    RLX_REQUIRE(rewards && loss_mask && advantages && workspace, "rlx_reinpp_seq_adv: NULL argument");
+    RLX_REQUIRE(!(kl_beta > 0.f) || (logprob && ref_logprob && kl_type >= RLX_KL_K1 && kl_type <= RLX_KL_K3),
+                "rlx_reinpp_seq_adv: kl_beta > 0 needs logprob, ref_logprob and a kl type (got %d)", kl_type);
+    if (workspace_bytes < rlx_reinpp_workspace_bytes(bsz)) {
+        set_error("rlx_reinpp_seq_adv: workspace too small");
+        return RLX_ENOSPC;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* partials = static_cast<double*>(workspace);
+    float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)bsz * 3 * sizeof(double));
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(loss_mask) | reinterpret_cast<uintptr_t>(advantages) |
+                           (kl_beta > 0.f ? (reinterpret_cast<uintptr_t>(logprob) | reinterpret_cast<uintptr_t>(ref_logprob)) : 0);
+    hipLaunchKernelGGL(reinpp_returns_kernel, dim3((unsigned)bsz), dim3(RT), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
+                       kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
+    RLX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reinpp_finalize_kernel, dim3(1), dim3(RT), 0, st, partials, (long long)bsz, stats);
+    RLX_LAUNCH_CHECK();
+    const long long n = (long long)bsz * seq;
+    long long blocks = (n / 4 + RT - 1) / RT;
+    const long long cap = (long long)num_cu() * 16;
+    blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+    hipLaunchKernelGGL(reinpp_normalize_kernel, dim3((unsigned)blocks), dim3(RT), 0, st, advantages, n, stats);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}

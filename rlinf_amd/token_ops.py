@@ -221,6 +221,39 @@ def grpo_seq_adv(rewards: torch.Tensor, loss_mask: torch.Tensor, group_size: int
     return adv
 
 
+def reinpp_seq_adv(rewards: torch.Tensor, loss_mask: torch.Tensor, logprob: Optional[torch.Tensor] = None,
+                   ref_logprob: Optional[torch.Tensor] = None, kl_beta: float = 0.0, kl_penalty_type: Optional[str] = None
+                   ) -> torch.Tensor:
+    """Reinforce++ (no group baseline): rewards [bsz] f32, loss_mask [bsz, seq] bool, logprob / ref_logprob [bsz, seq] f32
+    (only with kl_beta > 0) -> normalised advantages [bsz, seq] f32 (advantages.py:300-364 incl. the pre / post shaping)."""
+    dev = _dev(rewards, loss_mask, logprob, ref_logprob)
+    if loss_mask.dim() != 2 or rewards.numel() != loss_mask.shape[0]:
+        raise RlxError("reinpp_seq_adv: rewards [bsz], loss_mask [bsz, seq]")
+    bsz, seq = loss_mask.shape
+    r = _as_f32(rewards.reshape(-1), "rewards")
+    m = _as_u8(loss_mask)
+    lp = rp = None
+    kind = 0
+    if kl_beta > 0:
+        if logprob is None or ref_logprob is None:
+            raise RlxError("reinpp_seq_adv: kl_beta > 0 needs logprob and ref_logprob")
+        if kl_penalty_type not in _lib.KL_TYPE or kl_penalty_type is None:
+            raise NotImplementedError(kl_penalty_type)  # kl_penalty raises the same for "full" / unknown (utils.py:58-64)
+        kind = _lib.KL_TYPE[kl_penalty_type]
+        lp, rp = _as_f32(logprob, "logprob"), _as_f32(ref_logprob, "ref_logprob")
+        if tuple(lp.shape) != (bsz, seq) or tuple(rp.shape) != (bsz, seq):
+            raise RlxError("reinpp_seq_adv: logprob / ref_logprob must be [bsz, seq]")
+    adv = torch.empty((bsz, seq), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws_bytes = lib.rlx_reinpp_workspace_bytes(bsz)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_reinpp_seq_adv(r.data_ptr(), m.data_ptr(), None if lp is None else lp.data_ptr(),
+                                          None if rp is None else rp.data_ptr(), kind, float(kl_beta), adv.data_ptr(), bsz, seq,
+                                          ws.data_ptr(), ws_bytes, _stream_ptr(dev)), "rlx_reinpp_seq_adv")
+    return adv
+
+
 def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = None, *, temperature: float = 1.0,
                        top_k: int = -1, bin_centers: Optional[torch.Tensor] = None, with_logprob: bool = True,
                        round_outputs: bool = True):

@@ -453,3 +453,100 @@ def test_empty_and_degenerate_inputs():
     state["w"][1, 2] += 1
     p = tx.create_patch(state, 2)
     assert p.nnz_per_tensor.tolist() == [1] and p.ordinals.tolist() == [0]
+
+
+# ---- Reinforce++ on reasoning batches (rlx_reinpp_seq_adv) ----------------------------------------------------------------
+def _reinpp_close(got, want, seq, what=""):
+    # the reference sums the per-token rewards sequentially in f32 (cumsum), the kernel in f64 tiles: ~sqrt(seq) roundings
+    scale = float(want.abs().max()) + 1.0
+    close(got, want, (4e-6 + 3e-7 * seq ** 0.5) * scale, 2e-5, what)
+
+
+def test_reinpp_matches_reference_fixture():
+    from oracle.make_golden import reinpp_batch
+    for case in torch.load(os.path.join(GOLDEN_DIR, "reinpp.pt"), weights_only=False):
+        p = case["params"]
+        rewards, mask, lp, rlp = reinpp_batch(**p)
+        adv, ret = registry.calculate_adv_and_returns(
+            task_type="reasoning", adv_type="reinpp", rewards=rewards.to(DEV), loss_mask=mask.to(DEV), group_size=2,
+            kl_beta=p["kl_beta"], logprob=lp.to(DEV), ref_logprob=rlp.to(DEV), kl_penalty_type=p["kl"], use_reinpp_baseline=False)
+        assert ret is None and adv.is_cuda and adv.is_contiguous()
+        _reinpp_close(adv, case["advantages"], p["seq"], str(p))
+
+
+@pytest.mark.parametrize("seq", [1, 3, 64, 1023, 1024, 1025, 4100])
+@pytest.mark.parametrize("kl,beta", [("", 0.0), ("kl", 0.02), ("abs", 0.1), ("mse", 0.1), ("low_var_kl", 0.001)])
+@pytest.mark.parametrize("masks", ["prefix", "ragged"])
+def test_reinpp_vs_oracle(seq, kl, beta, masks):
+    from oracle.make_golden import reinpp_batch
+    bsz = 9
+    rewards, mask, lp, rlp = reinpp_batch(1000 + seq, bsz, seq, masks)
+    want = TO.reinpp_reasoning_advantages(rewards.clone(), mask, 3, False, beta, lp, rlp, kl)
+    got = token_ops.reinpp_seq_adv(rewards.to(DEV), mask.to(DEV), lp.to(DEV), rlp.to(DEV), beta, kl or None)
+    _reinpp_close(got, want, seq)
+    # the reference's own signature ([1, B] rewards, [L, B] tensors) through the registered function
+    fn = registry.get_adv_and_returns("reinpp")
+    adv, ret = fn(rewards=rewards.unsqueeze(0).to(DEV), loss_mask=mask.t().to(DEV), group_size=3, kl_beta=beta,
+                  logprob=lp.t().to(DEV), ref_logprob=rlp.t().to(DEV), kl_penalty_type=kl)
+    assert ret is None and tuple(adv.shape) == (seq, bsz)
+    _reinpp_close(adv.t(), want, seq)
+
+
+def test_reinpp_reward_position_follows_the_mirrored_mask():
+    """The reference reads the 'last valid token' off the batch-flipped mask: sequence b's reward goes to seq-1 minus the
+    first-True index of sequence bsz-1-b.  With kl_beta = 0 the return-to-go is the reward up to that position and 0 after."""
+    bsz, seq = 4, 10
+    mask = torch.ones(bsz, seq, dtype=torch.bool)
+    mask[3, :4] = False   # mirrored partner of sequence 0 starts at 4 -> sequence 0's reward at 9 - 4 = 5
+    mask[1, :] = False    # mirrored partner of sequence 2 is empty -> argmax 0 -> position 9
+    rewards = torch.tensor([1.0, 2.0, 3.0, 4.0])
+    want = TO.reinpp_reasoning_advantages(rewards.clone(), mask, 2)
+    got = token_ops.reinpp_seq_adv(rewards.to(DEV), mask.to(DEV))
+    _reinpp_close(got, want, seq)
+    row0 = got[0].cpu()
+    assert torch.allclose(row0[:6], row0[0].expand(6)) and torch.allclose(row0[6:], row0[6].expand(4)) and row0[0] != row0[6]
+
+
+def test_reinpp_baseline_and_bad_kl_fail_like_the_reference():
+    mask = torch.ones(4, 6, dtype=torch.bool, device=DEV)
+    r = torch.randn(4, device=DEV)
+    with pytest.raises(IndexError, match="Dimension out of range"):
+        registry.calculate_adv_and_returns(task_type="reasoning", adv_type="reinpp", rewards=r, loss_mask=mask, group_size=2,
+                                           use_reinpp_baseline=True)
+    with pytest.raises(NotImplementedError):
+        registry.calculate_adv_and_returns(task_type="reasoning", adv_type="reinpp", rewards=r, loss_mask=mask, group_size=2,
+                                           kl_beta=0.1, logprob=torch.zeros(4, 6, device=DEV), ref_logprob=torch.zeros(4, 6, device=DEV),
+                                           kl_penalty_type="full")
+
+
+def test_reinpp_llm_size_properties():
+    """512 sequences x 8192 tokens: without a KL term every position of a row up to the reward carries the same value --
+    the normalised reward -- and the masked moments of the output are 0 / 1; with one, the kernel agrees with the f64
+    evaluation of the same formulas better than the reference's f32 cumsum does."""
+    bsz, seq = 512, 8192
+    g = torch.Generator().manual_seed(5)
+    rewards = torch.randn(bsz, generator=g)
+    lens = torch.randint(1, seq + 1, (bsz,), generator=g)
+    mask = torch.arange(seq)[None, :] < lens[:, None]
+    adv = token_ops.reinpp_seq_adv(rewards.to(DEV), mask.to(DEV)).cpu()
+    assert torch.equal(adv, adv[:, :1].expand(-1, seq))  # reward at seq-1: constant rows
+    sel = adv[mask].double()
+    assert abs(float(sel.mean())) < 1e-5 and abs(float(sel.var(unbiased=False)) - 1.0) < 1e-4
+    w = mask.sum(1).double()
+    mu = float((rewards.double() * w).sum() / w.sum())
+    sd = float(((rewards.double() - mu) ** 2 * w).sum() / w.sum()) ** 0.5
+    close(adv[:, 0], ((rewards.double() - mu) / sd).float(), 2e-5, 2e-5)
+    lp = -torch.rand(bsz, seq, generator=g) * 3
+    rlp = lp + 0.3 * torch.randn(bsz, seq, generator=g)
+    got = token_ops.reinpp_seq_adv(rewards.to(DEV), mask.to(DEV), lp.to(DEV), rlp.to(DEV), 0.001, "low_var_kl").cpu().double()
+    kl = torch.clamp(torch.exp(torch.clamp((rlp - lp), -20, 20)) - torch.clamp((rlp - lp), -20, 20) - 1, -10, 10).double()
+    r = -(torch.tensor(0.001, dtype=torch.float32).double()) * kl
+    r[:, -1] += rewards.double()
+    ret = torch.flip(torch.cumsum(torch.flip(r, [1]), 1), [1])
+    m = mask.double()
+    mean = (ret * m).sum() / m.sum()
+    var = (((ret - mean) ** 2) * m).sum() / m.sum()
+    exact = (ret - mean) / var.sqrt()
+    ref32 = TO.reinpp_reasoning_advantages(rewards.clone(), mask, 2, False, 0.001, lp, rlp, "low_var_kl").double()
+    err_kernel, err_ref = float((got - exact).abs().max()), float((ref32 - exact).abs().max())
+    assert err_kernel < 2e-5 and err_kernel <= err_ref + 1e-6, (err_kernel, err_ref)

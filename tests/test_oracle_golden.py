@@ -144,3 +144,19 @@ def test_token_path_golden():
         _eq(TO.grpo_reasoning_advantages(b["rewards"], b["loss_mask"], p["group_size"]), case["grpo_advantages"])
         for k, v in case["kl_terms"].items():
             _eq(TO.kl_penalty(b["ref_logprobs"], b["old_logprobs"], k), v)
+
+
+def test_reinpp_golden():
+    """Reinforce++ on reasoning batches (reward placement as the reference computes it, KL penalty, flip-cumsum-flip,
+    masked normalisation) against the reference's outputs, bit for bit."""
+    from oracle import token_oracle as TO
+    from oracle.make_golden import REINPP_GRID, reinpp_batch
+
+    cases = _load("reinpp.pt")
+    assert [c["params"] for c in cases] == [dict(p) for p in REINPP_GRID]
+    for case in cases:
+        p = case["params"]
+        rewards, mask, lp, rlp = reinpp_batch(**p)
+        _eq(TO.reinpp_reasoning_advantages(rewards, mask, 2, False, p["kl_beta"], lp, rlp, p["kl"]), case["advantages"])
+    with pytest.raises(IndexError):
+        TO.reinpp_reasoning_advantages(rewards, mask, 2, True)

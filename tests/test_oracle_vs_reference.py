@@ -316,6 +316,23 @@ def test_token_reasoning_shaping(ref):
     assert want[1] is None
 
 
+@pytest.mark.parametrize("kl,beta", [("", 0.0), ("kl", 0.01), ("abs", 0.3), ("mse", 0.3), ("low_var_kl", 0.001)])
+@pytest.mark.parametrize("masks", ["prefix", "ragged", "empty_rows", "all_false"])
+def test_reinpp_reasoning(ref, kl, beta, masks):
+    from oracle.make_golden import reinpp_batch
+    rewards, mask, lp, rlp = reinpp_batch(21, 10, 29, masks)
+    want = ref.registry.calculate_adv_and_returns(task_type="reasoning", adv_type="reinpp", rewards=rewards.clone(), loss_mask=mask,
+                                                  group_size=5, kl_beta=beta, logprob=lp, ref_logprob=rlp, kl_penalty_type=kl)
+    _eq(want[0], TO.reinpp_reasoning_advantages(rewards.clone(), mask, 5, False, beta, lp, rlp, kl))
+    assert want[1] is None
+    # the group baseline cannot run in the reference (1-D src against a 2-D scatter index); the restatement fails alike
+    for fn in (lambda: ref.registry.calculate_adv_and_returns(task_type="reasoning", adv_type="reinpp", rewards=rewards.clone(),
+                                                              loss_mask=mask, group_size=5, use_reinpp_baseline=True),
+               lambda: TO.reinpp_reasoning_advantages(rewards.clone(), mask, 5, True)):
+        with pytest.raises(IndexError):
+            fn()
+
+
 # ---- decoupled PPO (oracle a19b) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
 @pytest.mark.parametrize("prox_mode", ["given", "old", "versions"])
