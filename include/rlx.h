@@ -110,6 +110,11 @@ size_t rlx_masked_stats_workspace_bytes(int64_t n);
 int rlx_masked_stats(const float* x, const uint8_t* mask, int64_t n, double* stats, int accumulate, void* workspace,
                      size_t workspace_bytes, rlx_stream_t stream);
 int rlx_normalize_from_stats(const float* x, const double* stats, float* out, int64_t n, rlx_stream_t stream);
+/* a12c  masked_normalization (async PPO learner, rlinf/utils/distributed.py:866-937 with its defaults: f64, biased
+ *       variance, eps outside the root): out = ((mask ? x : 0) - mean) / (sqrt(var) + eps) from stats = (count, sum, sumsq)
+ *       of x[mask] -- rlx_masked_stats output, summed over ranks in between (the reference all-reduces the three sums). */
+int rlx_masked_normalize(const float* x, const uint8_t* mask, const double* stats, double eps, float* out, int64_t n,
+                         rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a13  grpo_group_adv  <- calculate_scores, rlinf/algorithms/utils.py:134-152

@@ -155,6 +155,58 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
     return metrics
 
 
+def async_update(policy, opt, batch: dict, *, seed: int, global_batch: int, micro_batch: int, update_epoch: int, version: int,
+                 clip_low=0.2, clip_high=0.2, clip_ratio_c=3.0, value_clip=1.0, huber_delta=10.0, clip_grad=0.5,
+                 entropy_bonus: float = 0.0, behave_weight_threshold=None, normalize_advantages: bool = True,
+                 logprob_type: str = "action_level", max_episode_steps=None):
+    """AsyncPPOEmbodiedFSDPActor.run_training (rlinf/workers/actor/async_ppo_fsdp_worker.py:274-497), one rank: shuffle the
+    flattened batch (randperm seeded actor.seed + rank), masked_normalization of the advantages over all of it, fixed global
+    batches cut into micro-batches, decoupled actor-critic loss with current_version = version + 1 and dual clip, entropy
+    bonus, loss / gradient_accumulation, clip_grad_norm_ + AdamW per global batch.  -> per-micro-batch metrics, grad norms."""
+    T, B = batch["prev_logprobs"].shape[:2]
+    perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
+    flat = O.flatten_and_shuffle(batch, perm)
+    if normalize_advantages:
+        flat["advantages"] = O.masked_normalization(flat["advantages"], flat.get("loss_mask"))
+    accum = global_batch // micro_batch
+    n_global = (T * B) // global_batch
+    assert (T * B) % global_batch == 0 and global_batch % micro_batch == 0
+    A = policy.action_dim
+    metrics, norms = [], []
+    for _ in range(update_epoch):
+        for gb in O.chunk_batch(flat, n_global):
+            opt.zero_grad()
+            for mb in O.chunk_batch(gb, accum):
+                out = policy.evaluate(mb["forward_inputs"]["states"], mb["forward_inputs"]["action"])
+                bsz = out["logprobs"].shape[0]
+                shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type, A,
+                                             loss_mask=mb.get("loss_mask"), loss_mask_sum=mb.get("loss_mask_sum"),
+                                             values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
+                prox, ver = O.shape_decoupled_inputs(mb.get("proximal_logprobs"), mb.get("versions"), logprob_type, A, bsz,
+                                                     shaped["logprobs"].shape)
+                loss, m = O.decoupled_actor_critic_loss(
+                    proximal_logprobs=prox, versions=ver, current_version=version + 1,
+                    behave_weight_threshold=behave_weight_threshold, clip_ratio_low=clip_low, clip_ratio_high=clip_high,
+                    clip_ratio_c=clip_ratio_c, value_clip=value_clip, huber_delta=huber_delta,
+                    max_episode_steps=max_episode_steps, critic_warmup=False, **shaped)
+                m = dict(m)
+                ent_loss = torch.tensor(0.0)
+                if entropy_bonus > 0:
+                    ent = out["entropy"].reshape(bsz, -1, A).sum(dim=-1)
+                    ent_loss = O.masked_mean(ent, shaped["loss_mask"])
+                    loss = loss - entropy_bonus * ent_loss
+                loss = loss / accum
+                loss.backward()
+                m["actor/entropy_loss"] = float(ent_loss.detach())
+                m["actor/total_loss"] = float(loss.detach())
+                metrics.append(m)
+            gn = torch.nn.utils.clip_grad_norm_(policy.parameters(), clip_grad)
+            if torch.isfinite(gn):
+                opt.step()
+            norms.append(float(gn))
+    return metrics, norms
+
+
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
               max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0,
               pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0):

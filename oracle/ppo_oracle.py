@@ -607,6 +607,22 @@ def fold_rollout_epochs(nested: dict, rollout_epoch: int) -> dict:
 # --------------------------------------------------------------------------------------------
 # a12b  advantage normalisation from sufficient statistics   rlinf/utils/distributed.py:942-965
 # --------------------------------------------------------------------------------------------
+def masked_normalization(x, mask=None, eps=1e-5):
+    """rlinf/utils/distributed.py:866-937 with the defaults the async learner uses (dim=None, biased variance,
+    high_precision, one process): masked-out elements enter as ZERO, statistics in float64, eps outside the root."""
+    x = x.to(torch.float64).clone()
+    if mask is None:
+        factor = torch.tensor(float(x.numel()), dtype=torch.float64)
+    else:
+        mask = mask.to(torch.float64)
+        assert mask.shape == x.shape, (mask.shape, x.shape)
+        x = x * mask
+        factor = mask.sum()
+    mean = x.sum() / factor
+    var = x.square().sum() / factor - mean ** 2
+    return ((x - mean) / (var.sqrt() + eps)).float()
+
+
 def masked_stats(x, mask=None):
     x = x.to(dtype=torch.float64)
     x = x[mask.bool()] if mask is not None else x.reshape(-1)

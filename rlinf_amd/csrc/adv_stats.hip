@@ -57,6 +57,22 @@ __global__ __launch_bounds__(256) void normalize_from_stats_kernel(const float* 
         out[i] = (float)(((double)x[i] - mean) * rstd);
 }
 
+// masked_normalization's last line (rlinf/utils/distributed.py:917-937, high_precision): masked-out elements enter as 0,
+// mean = sum / count, var = sumsq / count - mean^2 (biased), out = (x - mean) / (sqrt(var) + eps), all in f64 -> f32.
+// count == 0 or a rounding-negative variance give NaN there, and here.
+__global__ __launch_bounds__(256) void masked_normalize_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                               const double* __restrict__ stats, double eps,
+                                                               float* __restrict__ out, long long n) {
+    const double mean = stats[1] / stats[0];
+    const double var = stats[2] / stats[0] - mean * mean;
+    const double denom = sqrt(var) + eps;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = (mask == nullptr || mask[i]) ? (double)x[i] : 0.0;
+        out[i] = (float)((v - mean) / denom);
+    }
+}
+
 int stat_grid(long long n) {
     return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, std::min<long long>(kStatBlocks, (long long)num_cu() * 4)));
 }
@@ -95,6 +111,17 @@ extern "C" int rlx_normalize_from_stats(const float* x, const double* stats, flo
     RLX_REQUIRE(x && out, "rlx_normalize_from_stats: NULL argument");
     hipLaunchKernelGGL(normalize_from_stats_kernel, dim3(stat_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, stats,
                        out, (long long)n);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_masked_normalize(const float* x, const uint8_t* mask, const double* stats, double eps, float* out, int64_t n,
+                                    rlx_stream_t stream) {
+    RLX_REQUIRE(n >= 0 && stats, "rlx_masked_normalize: bad argument");
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(x && out, "rlx_masked_normalize: NULL argument");
+    hipLaunchKernelGGL(masked_normalize_kernel, dim3(stat_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, mask, stats,
+                       eps, out, (long long)n);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -167,6 +167,25 @@ def normalize_from_stats(x: torch.Tensor, stats: torch.Tensor, out: Optional[tor
     return out.view(x.shape)
 
 
+def masked_normalize(x: torch.Tensor, mask: Optional[torch.Tensor], stats: torch.Tensor, eps: float = 1e-5,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """masked_normalization's elementwise part (rlinf/utils/distributed.py:917-937) from (count, sum, sumsq):
+    ((mask ? x : 0) - mean) / (sqrt(var_biased) + eps), f64 arithmetic -> f32."""
+    dev = _dev(x, mask, stats)
+    xf = _as_f32(x, "x")
+    m8 = _as_u8(mask)
+    if m8 is not None and m8.numel() != xf.numel():
+        raise AssertionError((tuple(mask.shape), tuple(x.shape)))
+    if stats.dtype != torch.float64 or stats.numel() != 3:
+        raise RlxError("stats must be float64[3]")
+    if out is None:
+        out = torch.empty_like(xf)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().rlx_masked_normalize(xf.data_ptr(), _ptr(m8), stats.contiguous().data_ptr(), float(eps),
+                                                    out.data_ptr(), xf.numel(), _stream_ptr(dev)), "rlx_masked_normalize")
+    return out.view(x.shape)
+
+
 def grpo_group_adv(rewards: torch.Tensor, dones: torch.Tensor, loss_mask: torch.Tensor, group_size: int,
                    eps: float = 1e-6):
     """rewards [n,B,C], dones [n+1,B,C], loss_mask [n,B,C] -> (advantages [n,B,C], scores [B]).  a13."""

@@ -1,0 +1,171 @@
+"""The learner of asynchronous (decoupled) PPO: same method names and data path as
+rlinf/workers/actor/async_ppo_fsdp_worker.py -- ``compute_advantages_and_returns`` (:185-213), ``compute_proximal_logprobs``
+(:215-272) and ``run_training`` (:274-497).
+
+What differs from the synchronous learner (embodied_fsdp_actor_worker.py) is data, not machinery: trajectories carry the
+policy ``versions`` they were sampled with; the loss is ``decoupled_actor_critic`` (clip against a proximal policy given,
+recomputed, or interpolated from the version distance; importance-weight by exp(proximal - behaviour)); advantages are
+normalised a second time over the whole shuffled buffer with cross-rank statistics (``masked_normalization``); dual clip is
+on by default (clip_ratio_c 3.0).  The reference's receive thread, rollout store and staleness bookkeeping (:84-183) are
+control plane and not mirrored: ``recv_rollout_trajectories`` of the base class fills ``rollout_batch`` directly.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from ... import ops
+from ..._lib import DPPO_OUT_NAMES, PPO_OUT_FLOATS
+from ...algorithms.losses import _CRITIC_KEYS, _DECOUPLED_KEYS, _EV_MAP, explained_variance_from_stats
+from ...algorithms.registry import calculate_adv_and_returns
+from ...scheduler import all_reduce_flat_
+from .embodied_fsdp_actor_worker import CRITIC_EXPLAINED_VARIANCE_KEY, EmbodiedFSDPActor
+
+
+class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
+    """Embodied learner for async PPO / decoupled actor-critic training."""
+
+    def compute_advantages_and_returns(self) -> dict:
+        """:185-213 -- GAE against the proximal values when the batch carries them."""
+        alg, b = self.cfg.algorithm, self.rollout_batch
+        proximal_values = b.get("proximal_values")
+        out = calculate_adv_and_returns(
+            task_type=self.cfg.runner.task_type, adv_type=alg.adv_type, rewards=b["rewards"], dones=b["dones"],
+            values=proximal_values if proximal_values is not None else b.get("prev_values"), gamma=alg.get("gamma", 1),
+            gae_lambda=alg.get("gae_lambda", 1), group_size=alg.get("group_size", 8), reward_type=alg.reward_type,
+            loss_mask=b.get("loss_mask"), loss_mask_sum=b.get("loss_mask_sum"))
+        b.update(out)
+        return self._rollout_metrics(b)
+
+    @torch.no_grad()
+    def compute_proximal_logprobs(self) -> None:
+        """:215-272 -- log-probs of the stored actions under the CURRENT weights, in micro-batch sized pieces, un-shuffled."""
+        b, m = self.rollout_batch, self.model
+        T, B = b["prev_logprobs"].shape[:2]
+        states = b["forward_inputs"]["states"].reshape(T * B, -1)
+        action = b["forward_inputs"]["action"].reshape(T * B, -1)
+        out = torch.empty((T * B, m.layout.act_dim), dtype=torch.float32, device=self.device)
+        step = int(self.cfg.actor.micro_batch_size)
+        for lo in range(0, T * B, step):
+            lp = ops.mlp_train_fwd(m.flat.data, m.packed(), m.layout, states[lo:lo + step], action[lo:lo + step])[0]
+            out[lo:lo + lp.shape[0]] = lp
+        b["proximal_logprobs"] = out.view(T, B, *b["prev_logprobs"].shape[2:])
+
+    # ---- update ---------------------------------------------------------------------------------------------------
+    def _flatten_shuffle_normalize(self):
+        """flatten_rollout_batch_for_train (:42-69) with one randperm seeded actor.seed + rank (:283-285), then
+        masked_normalization of the advantages over the whole buffer, statistics summed over ranks (:292-296)."""
+        b = self.rollout_batch
+        T, B = b["prev_logprobs"].shape[:2]
+        N = T * B
+        pkey = ("perm", N)
+        if pkey not in self._ws:
+            g = torch.Generator()
+            g.manual_seed(int(self.cfg.actor.seed) + self._rank)
+            self._ws[pkey] = torch.randperm(N, generator=g).to(self.device)
+        fields = {"states": b["forward_inputs"]["states"], "action": b["forward_inputs"]["action"],
+                  "prev_logprobs": b["prev_logprobs"], "advantages": b["advantages"], "prev_values": b["prev_values"][:-1],
+                  "returns": b.get("returns"), "loss_mask": b.get("loss_mask"), "versions": b.get("versions"),
+                  "proximal_logprobs": b.get("proximal_logprobs"), "proximal_values": b.get("proximal_values")}
+        if b.get("loss_mask_sum") is not None:
+            fields["loss_mask_sum"] = b["loss_mask_sum"].contiguous()
+        fields = {k: v for k, v in fields.items() if v is not None}
+        src = [v.reshape(N, *v.shape[2:]).contiguous() for v in fields.values()]
+        flat = dict(zip(fields, ops.gather_rows(src, self._ws[pkey])))
+        if self.cfg.algorithm.get("normalize_advantages", True):
+            adv, mask = flat["advantages"], flat.get("loss_mask")
+            if mask is not None:
+                assert mask.dim() == adv.dim() and mask.shape == adv.shape, (mask.shape, adv.shape)
+            stats = ops.masked_stats(adv, mask)
+            all_reduce_flat_(stats, self.ctx)  # factor, x_sum, x_sum_sq in ONE call (the reference issues three)
+            flat["advantages"] = ops.masked_normalize(adv, mask, stats)
+        return flat, N
+
+    def run_training(self) -> dict:
+        a, alg, m = self.cfg.actor, self.cfg.algorithm, self.model
+        assert alg.adv_type == "gae", "decoupled_actor_critic needs values: compute_values = (adv_type == 'gae') (:374)"
+        lay = m.layout
+        with self.timer("run_training"):
+            flat, N = self._flatten_shuffle_normalize()
+            world, gbs, micro = self._world_size, int(a.global_batch_size), int(a.micro_batch_size)
+            assert gbs % (micro * world) == 0, (f"global_batch_size {gbs} must be divisible by micro_batch_size {micro} * "
+                                                f"world_size {world}")
+            per_rank = gbs // world
+            accum = per_rank // micro
+            self.gradient_accumulation = accum
+            assert N % per_rank == 0, f"Flattened rollout size {N} must be divisible by per-rank batch size {per_rank}"
+            n_global = N // per_rank
+            n_steps = n_global * int(alg.get("update_epoch", 1))
+            slabs = ops.mlp_bwd_slabs(micro)
+            grads = torch.empty((slabs * accum, m.n_params), dtype=torch.float32, device=self.device)
+            bwd_ws = torch.empty(ops._lib.load().rlx_mlp_bwd_workspace_bytes(ops.byref(lay), micro), dtype=torch.uint8,
+                                 device=self.device)
+            rows = torch.zeros(n_steps * accum, PPO_OUT_FLOATS + 2, device=self.device)  # + total loss, entropy loss
+            norms = torch.zeros(n_steps, 2, device=self.device)
+            ent_row = torch.zeros(PPO_OUT_FLOATS, device=self.device)
+            self._grad_out_host = 1.0 / accum
+            bonus = float(alg.get("entropy_bonus", 0) or 0)
+            step = 0
+            for _ in range(int(alg.get("update_epoch", 1))):
+                for i in range(n_global):
+                    warm = self.optimizer_steps < self.critic_warmup_steps
+                    for j in range(accum):
+                        lo = i * per_rank + j * micro
+                        mb = {k: v[lo:lo + micro] for k, v in flat.items()}
+                        row = rows[step * accum + j]
+                        g = grads[j * slabs:(j + 1) * slabs]
+                        logprob, _, value, mean, acts = ops.mlp_train_fwd(m.flat.data, m.packed(), lay, mb["states"], mb["action"])
+                        lp, v = logprob.requires_grad_(True), value.requires_grad_(True)
+                        prox_v = mb.get("proximal_values")
+                        loss, out = ops.ppo_loss(
+                            lp, mb["prev_logprobs"], mb["advantages"], logprob_type=alg.logprob_type, reward_type=alg.reward_type,
+                            action_dim=int(a.model.get("action_dim", 7)), clip_ratio_low=alg.clip_ratio_low,
+                            clip_ratio_high=alg.clip_ratio_high, values=v,
+                            prev_values=prox_v if prox_v is not None else mb["prev_values"], returns=mb["returns"],
+                            value_clip=alg.get("value_clip"), huber_delta=alg.get("huber_delta"), loss_mask=mb.get("loss_mask"),
+                            loss_mask_sum=mb.get("loss_mask_sum"), max_episode_steps=self.cfg.env.train.get("max_episode_steps"),
+                            clip_ratio_c=alg.get("clip_ratio_c", 3.0), critic_warmup=warm, has_critic=True,
+                            decoupled=dict(proximal_logprobs=mb.get("proximal_logprobs"), versions=mb.get("versions"),
+                                           current_version=int(self.version) + 1,
+                                           behave_weight_threshold=alg.get("behave_weight_threshold")))
+                        (loss / accum).backward()
+                        ops.mlp_train_bwd(m.flat.data, m.packed(), lay, mb["states"], mb["action"], mean, acts, lp.grad, None,
+                                          v.grad, grads=g, workspace=bwd_ws)
+                        row[:PPO_OUT_FLOATS] = out
+                        row[PPO_OUT_FLOATS] = out[0]
+                        if bonus > 0 and not warm:  # :449-462; the decoupled row keeps slot 19 for the average version
+                            ent_row.zero_()
+                            ent_row[18] = out[DPPO_OUT_NAMES["mask_count"]]
+                            self._entropy_bonus(mb, g, ent_row)
+                            row[PPO_OUT_FLOATS] += ent_row[0]
+                            row[PPO_OUT_FLOATS + 1] = ent_row[19]
+                    self.optimizer_step(grads, stats=norms[step], critic_warmup=warm)
+                    step += 1
+            return self._collect_decoupled_metrics(rows, norms, accum, flat.get("versions") is not None)
+
+    def _collect_decoupled_metrics(self, rows, norms, accum: int, has_versions: bool) -> dict:
+        """Means over micro-batches (the version metrics only over those that reported them: some element unmasked,
+        losses.py:156-165), AVG over ranks; EV sufficient statistics summed (:477-496).  One D2H copy."""
+        m = rows.mean(dim=0)
+        counted = (rows[:, DPPO_OUT_NAMES["mask_count"]] > 0).float()
+        ver = (rows[:, DPPO_OUT_NAMES["actor/average_version"]] * counted).sum() / counted.sum().clamp_min(1.0)
+        ev = rows[:, DPPO_OUT_NAMES["ev/count"]:DPPO_OUT_NAMES["ev/errors_sq_sum"] + 1].sum(dim=0)
+        avg = torch.cat([m, ver.view(1), norms[:, 0].mean().view(1)])
+        if self._world_size > 1:
+            all_reduce_flat_(avg, self.ctx, average=True)
+            all_reduce_flat_(ev, self.ctx)
+        host, any_counted = torch.cat([avg, ev, counted.sum().view(1)]).tolist(), None
+        any_counted = host[-1] > 0
+        out = {k: host[DPPO_OUT_NAMES[k]] for k in _DECOUPLED_KEYS + _CRITIC_KEYS}
+        if has_versions and any_counted:
+            out["actor/average_version"] = host[PPO_OUT_FLOATS + 2]
+            out["actor/current_version"] = float(int(self.version) + 1)
+        n0 = PPO_OUT_FLOATS + 4
+        out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(
+            {name: host[n0 + i] for i, name in enumerate(_EV_MAP.values())})
+        out["actor/total_loss"] = host[PPO_OUT_FLOATS] / max(accum, 1)
+        out["actor/entropy_loss"] = host[PPO_OUT_FLOATS + 1]
+        out["actor/grad_norm"] = host[PPO_OUT_FLOATS + 3]
+        out["actor/lr"] = float(self.cfg.actor.optim.lr)
+        out["critic/lr"] = float(self.cfg.actor.optim.value_lr)
+        return out

@@ -80,6 +80,9 @@ class EnvWorker(Worker):
             self._eps.normal_()
         else:
             self._eps.copy_(eps)
+        # PolicyOutput.versions = full_like(prev_logprobs, version) (huggingface_worker.py:579-610): the weights do not change
+        # inside a rollout, so one fill per rollout -- outside the captured step loop, the value changes every iteration
+        self.buffer.versions.fill_(float(self.rollout.version))
         if not (self.use_graph and mode == "train" and self.device.type == "cuda"):
             return self._interact_eager(self._eps, mode)
         if self._graph is None:

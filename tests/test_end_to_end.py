@@ -138,6 +138,81 @@ def test_iteration_matches_oracle(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("auto_reset,entropy_bonus", [(True, 0.0), (True, 0.01), (False, 0.0)])
+def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus):
+    """AsyncPPOEmbodiedFSDPActor (decoupled actor-critic) behind the ordinary runner: two iterations whose trajectories carry
+    the version they were sampled with (proximal policy interpolated from the version distance), then the same buffer trained
+    again with half of it marked one version older and the proximal log-probs recomputed from the current weights."""
+    from rlinf_amd.config import validate_cfg
+    from rlinf_amd.runners import EmbodiedRunner
+    from rlinf_amd.scheduler import init_distributed
+    from rlinf_amd.workers.actor.async_ppo_fsdp_worker import AsyncPPOEmbodiedFSDPActor
+    from rlinf_amd.workers.env import EnvWorker
+    from rlinf_amd.workers.rollout.hf import MultiStepRolloutWorker
+    T, B, GB, MB = 10, 16, 80, 40
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=MB, auto_reset=auto_reset, entropy_bonus=entropy_bonus)
+    cfg.algorithm.loss_type = "decoupled_actor_critic"
+    cfg.algorithm.normalize_advantages = True
+    cfg = validate_cfg(cfg)
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    sd = copy.deepcopy(ora.state_dict())
+    opt = O.build_adamw(ora)
+    ctx = init_distributed()
+    actor = AsyncPPOEmbodiedFSDPActor.create_group(cfg, ctx).launch(None, name="ActorGroup")
+    runner = EmbodiedRunner(cfg, actor, MultiStepRolloutWorker.create_group(cfg, ctx).launch(None, name="RolloutGroup"),
+                            EnvWorker.create_group(cfg, ctx).launch(None, name="EnvGroup"))
+    runner.init_workers(env_tensors=env)
+    w = actor.worker
+    w.model.load_reference_state_dict(sd)
+    kw = dict(seed=1234, global_batch=GB, micro_batch=MB, update_epoch=2, entropy_bonus=entropy_bonus,
+              max_episode_steps=cfg.env.train.get("max_episode_steps"))
+
+    def check(metrics, om, norms, steps, it):
+        mean = lambda k: sum(float(m[k]) for m in om) / len(om)  # noqa: E731
+        tol = dict(rel=2e-3, abs=3e-4) if it == 0 else dict(rel=2e-2, abs=3e-3)
+        for k in ("actor/policy_loss", "actor/proximal_ratio", "actor/clipped_proximal_ratio", "actor/clip_fraction",
+                  "actor/dual_clip_fraction", "actor/proximal_approx_kl", "actor/behav_approx_kl", "critic/value_loss",
+                  "critic/value_clip_ratio", "actor/total_loss", "actor/entropy_loss", "actor/average_version",
+                  "actor/current_version"):
+            assert metrics[k] == pytest.approx(mean(k), **tol), (it, k)
+        assert metrics["actor/grad_norm"] == pytest.approx(sum(norms) / len(norms), rel=2e-3 if it == 0 else 2e-2)
+        got = w.model.flat.detach().cpu()
+        want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+        diff = (got - want).abs()
+        assert float(diff.max()) <= 2 * 3e-4 * steps + 1e-6
+        assert float((diff > 2e-5 * (it + 1)).float().mean()) < 0.02, float((diff > 2e-5).float().mean())
+
+    steps, batch = 0, None
+    for it in range(2):
+        eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
+        batch = L.advantages(L.rollout(ora, env, eps, 0.8, auto_reset), 0.8, 0.9, auto_reset)
+        batch["versions"] = torch.full_like(batch["prev_logprobs"], float(it))
+        om, norms = L.async_update(ora, opt, batch, version=it, **kw)
+        metrics = runner.run_step(eps.cuda())
+        rb = w.rollout_batch
+        assert torch.equal(rb["versions"].cpu(), batch["versions"])
+        torch.testing.assert_close(rb["advantages"].cpu(), batch["advantages"], rtol=1e-3 * (1 + 4 * it), atol=1e-4 * (1 + 4 * it))
+        steps += len(norms)
+        check({k[len("train/"):]: v for k, v in metrics.items() if k.startswith("train/")}, om, norms, steps, it)
+    # the same buffer once more, half of it one version staler, proximal policy = the CURRENT weights, recomputed
+    w.set_global_step(2)
+    w.rollout_batch["versions"][: T // 2] -= 1.0
+    batch["versions"][: T // 2] -= 1.0
+    w.compute_proximal_logprobs()
+    with torch.no_grad():
+        flat_lp = ora.evaluate(batch["forward_inputs"]["states"].reshape(T * B, -1),
+                               batch["forward_inputs"]["action"].reshape(T * B, -1))["logprobs"]
+    batch["proximal_logprobs"] = flat_lp.view(T, B, -1)
+    torch.testing.assert_close(w.rollout_batch["proximal_logprobs"].cpu(), batch["proximal_logprobs"], rtol=5e-3, atol=5e-4)
+    om, norms = L.async_update(ora, opt, batch, version=2, **kw)
+    metrics = w.run_training()
+    steps += len(norms)
+    check(metrics, om, norms, steps, 2)
+
+
+@pytest.mark.gpu
 def test_non_auto_reset_builds_loss_mask_and_trains():
     """auto_reset=False -> loss mask + mask_sum ratio aggregation (embodied_fsdp_actor_worker.py:219-233, losses.py:219-227)."""
     cfg = make_cfg(total_envs=16, steps=12, global_batch=64, auto_reset=False)

@@ -333,6 +333,18 @@ def test_reinpp_reasoning(ref, kl, beta, masks):
             fn()
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_masked_normalization(ref, masked, monkeypatch):
+    """rlinf/utils/distributed.py:866-937 moves its inputs with .cuda(); neutralised here so that it runs on CPU tensors."""
+    from oracle import reference_loader
+    du = reference_loader.load_distributed_utils()
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(400, 3, generator=g) * 2 + 0.5
+    mask = (torch.rand(400, 3, generator=g) < 0.6) if masked else None
+    _eq(du.masked_normalization(x, mask), O.masked_normalization(x, mask))
+
+
 # ---- decoupled PPO (oracle a19b) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
 @pytest.mark.parametrize("prox_mode", ["given", "old", "versions"])
