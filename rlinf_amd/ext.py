@@ -27,6 +27,7 @@ def register() -> None:
 
     ref_registry.register_advantage("gae")(adv.compute_gae_advantages_and_returns)
     ref_registry.register_advantage("grpo")(adv.compute_grpo_advantages)
+    ref_registry.register_advantage("reinpp")(adv.compute_reinpp_advantages)  # reasoning: [1, B] rewards, [L, B] tensors
 
     def _reasoning_actor(kw):
         """task_type='reasoning': [bsz, seq] token tensors and the learner's loss_agg_func (fsdp_actor_worker.py:736-750)."""

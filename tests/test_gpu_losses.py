@@ -338,7 +338,7 @@ def test_ext_hook_callees_behind_a_reference_shaped_registry():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
-    assert set(captured["adv"]) == {"gae", "grpo"}
+    assert set(captured["adv"]) == {"gae", "grpo", "reinpp"}
     assert set(captured["loss"]) == {"actor_critic", "actor", "decoupled_actor_critic"}
 
     # reasoning "actor": the learner's kwargs, the REFERENCE-named aggregation function object
