@@ -24,7 +24,8 @@ from typing import Mapping, Optional
 
 import torch
 
-from ...algorithms.registry import policy_loss
+from ... import ops
+from ...algorithms.registry import calculate_adv_and_returns, policy_loss
 from ...utils.utils import compute_logprobs_and_entropy_from_logits, compute_logprobs_from_logits
 
 
@@ -56,6 +57,12 @@ class TokenLearnerStep:
     importance_sampling_clip: Optional[float] = None
     logprob_op_type: str = "torch"   # "torch" rounds like the reference's default, "flash_attn" keeps fp32
     inplace_grad: bool = False       # let backward overwrite the logits buffer with d_logits
+    # advantage stage (fsdp_actor_worker.py:900-907,941-978)
+    adv_type: str = "grpo"
+    group_size: int = 1
+    reinpp_kl_beta: float = 0.0
+    use_reinpp_baseline: bool = False
+    normalize_advantages: bool = False
 
     @classmethod
     def from_cfg(cfg_cls, cfg) -> "TokenLearnerStep":
@@ -77,7 +84,41 @@ class TokenLearnerStep:
             kl_penalty_type=_get(algo, "kl_penalty_type", "low_var_kl"),
             importance_sampling_fix=bool(_get(algo, "importance_sampling_fix", False)),
             importance_sampling_clip=_get(algo, "importance_sampling_clip"),
-            logprob_op_type=_get(algo, "logprob_op_type", "torch"))
+            logprob_op_type=_get(algo, "logprob_op_type", "torch"),
+            adv_type=_get(algo, "adv_type", "grpo"), group_size=int(_get(algo, "group_size", 1)),
+            reinpp_kl_beta=float(_get(algo, "reinpp_kl_beta", 0.0)),
+            use_reinpp_baseline=bool(_get(algo, "use_reinpp_baseline", False)),
+            normalize_advantages=bool(_get(algo, "normalize_advantages", False)))
+
+    # fsdp_actor_worker.py:941-978
+    def compute_advantages_and_returns(self, batch: dict) -> dict:
+        """Fill ``batch["advantages"]`` ([bsz, response_len]) unless the rollout already did: GRPO, or Reinforce++ with its
+        per-token KL reward from (recomputed | rollout) log-probs against the reference policy's."""
+        if batch.get("advantages") is None:
+            mask = batch["response_mask"][:, -self.response_len:]
+            logprob = batch.get("recomputed_logprobs")
+            if logprob is None:
+                logprob = batch.get("rollout_logprobs")
+            advantages, _ = calculate_adv_and_returns(
+                task_type=self.task_type, adv_type=self.adv_type, rewards=batch["rewards"], loss_mask=mask,
+                group_size=self.group_size, kl_beta=self.reinpp_kl_beta, kl_penalty_type=self.kl_penalty_type, logprob=logprob,
+                ref_logprob=batch.get("ref_logprobs"), use_reinpp_baseline=self.use_reinpp_baseline)
+            batch["advantages"] = advantages
+        return batch
+
+    # fsdp_actor_worker.py:900-907
+    def normalize_batch_advantages(self, batch: dict, ctx=None) -> dict:
+        """``algorithm.normalize_advantages``: masked_normalization over the data-parallel group -- (count, sum, sumsq) of the
+        masked advantages in one f64[3] all-reduce (the reference issues three), then one elementwise pass."""
+        if self.normalize_advantages:
+            from ...scheduler import all_reduce_flat_
+            adv = batch["advantages"]
+            mask = batch["response_mask"][:, -self.response_len:].contiguous()
+            stats = ops.masked_stats(adv, mask)
+            if ctx is not None:
+                all_reduce_flat_(stats, ctx)
+            batch["advantages"] = ops.masked_normalize(adv, mask, stats)
+        return batch
 
     # fsdp_actor_worker.py:476-505 (the fixed-length branch)
     def logprobs_and_entropy(self, logits: torch.Tensor, input_ids: torch.Tensor):

@@ -550,3 +550,28 @@ def test_reinpp_llm_size_properties():
     ref32 = TO.reinpp_reasoning_advantages(rewards.clone(), mask, 2, False, 0.001, lp, rlp, "low_var_kl").double()
     err_kernel, err_ref = float((got - exact).abs().max()), float((ref32 - exact).abs().max())
     assert err_kernel < 2e-5 and err_kernel <= err_ref + 1e-6, (err_kernel, err_ref)
+
+
+@pytest.mark.parametrize("adv_type", ["grpo", "reinpp"])
+def test_reasoning_advantage_stage(adv_type):
+    """FSDPActor.compute_advantages_and_returns + the normalize_advantages step of run_training (fsdp_actor_worker.py:
+    900-907,941-978) as TokenLearnerStep exposes them: mask = the response window, log-probs = recomputed | rollout."""
+    from oracle import ppo_oracle as PO
+    resp, bsz = 21, 8
+    b = token_batch(95, bsz, resp, 5)
+    pad = torch.zeros(bsz, 4, dtype=torch.bool)
+    batch = {"response_mask": torch.cat([pad, b["loss_mask"]], dim=1).to(DEV), "rewards": b["rewards"].to(DEV),
+             "rollout_logprobs": b["old_logprobs"].to(DEV), "ref_logprobs": b["ref_logprobs"].to(DEV)}
+    step = TokenLearnerStep(response_len=resp, adv_type=adv_type, group_size=4, reinpp_kl_beta=0.01, kl_penalty_type="low_var_kl",
+                            normalize_advantages=True)
+    step.compute_advantages_and_returns(batch)
+    if adv_type == "grpo":
+        want = TO.grpo_reasoning_advantages(b["rewards"], b["loss_mask"], 4)
+    else:
+        want = TO.reinpp_reasoning_advantages(b["rewards"].clone(), b["loss_mask"], 4, False, 0.01, b["old_logprobs"],
+                                              b["ref_logprobs"], "low_var_kl")
+    close(batch["advantages"], want, 2e-5, 2e-5, "advantages")
+    given = batch["advantages"]
+    assert step.compute_advantages_and_returns(batch)["advantages"] is given  # already there: left alone
+    step.normalize_batch_advantages(batch)
+    close(batch["advantages"], PO.masked_normalization(want, b["loss_mask"]), 5e-5, 5e-5, "normalised")
