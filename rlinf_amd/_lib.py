@@ -12,7 +12,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librlx_hip.so")
+# RLX_LIB_TAG=<tag>: load librlx_hip_<tag>.so, a variant build of the same sources (see csrc/build.py); dev sweeps only
+_TAG = os.environ.get("RLX_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, "librlx_hip" + ("_" + _TAG if _TAG else "") + ".so")
 
 
 class RlxError(RuntimeError):

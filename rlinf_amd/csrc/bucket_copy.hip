@@ -15,6 +15,10 @@
 #include "rlx_common.h"
 #include "rlx_convert.h"
 
+#ifndef RLX_COPY_NT_STORE
+#define RLX_COPY_NT_STORE 0  // dev switch: streaming stores into the transport buffer
+#endif
+
 namespace rlx {
 namespace {
 
@@ -46,13 +50,21 @@ __device__ __forceinline__ void store_lane(void* p, const uint32_t (&w)[BYTES / 
     if constexpr (BYTES == 8) {
         u32x2 q;
         q.x = w[0], q.y = w[1];
+#if RLX_COPY_NT_STORE
+        __builtin_nontemporal_store(q, (RLX_GLOBAL u32x2*)p);
+#else
         *(RLX_GLOBAL u32x2*)p = q;
+#endif
     } else {
 #pragma unroll
         for (int j = 0; j < BYTES / 16; ++j) {
             u32x4 q;
             q.x = w[4 * j], q.y = w[4 * j + 1], q.z = w[4 * j + 2], q.w = w[4 * j + 3];
+#if RLX_COPY_NT_STORE
+            __builtin_nontemporal_store(q, (RLX_GLOBAL u32x4*)p + j);
+#else
             *((RLX_GLOBAL u32x4*)p + j) = q;
+#endif
         }
     }
 }

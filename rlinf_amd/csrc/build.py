@@ -19,8 +19,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 INCLUDE = os.path.join(ROOT, "include")
-BUILD = os.path.join(HERE, "_build")
-LIB = os.path.join(os.path.dirname(HERE), "librlx_hip.so")
+# dev: RLX_BUILD_TAG=nt builds librlx_hip_nt.so from objects in _build_nt (variant sweeps: pair with RLX_CXXFLAGS here and
+# RLX_LIB_TAG at run time); unset = the product library
+_TAG = os.environ.get("RLX_BUILD_TAG", "")
+BUILD = os.path.join(HERE, "_build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(os.path.dirname(HERE), "librlx_hip" + ("_" + _TAG if _TAG else "") + ".so")
 ARCH = "gfx950"
 
 

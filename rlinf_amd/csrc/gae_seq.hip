@@ -19,6 +19,10 @@
 
 #include "rlx_common.h"
 
+#ifndef RLX_GAESEQ_NT
+#define RLX_GAESEQ_NT 0  // dev switch: streaming (non-temporal) loads of the values and stores of both outputs
+#endif
+
 namespace rlx {
 namespace {
 
@@ -50,7 +54,15 @@ __global__ __launch_bounds__(ST) void gae_seq_kernel(const float* __restrict__ v
             for (int q0 = 0; q0 < nq; q0 += QI * ST) {
                 float4 q[QI];
 #pragma unroll
-                for (int k = 0; k < QI; ++k) q[k] = v4[min(q0 + k * ST + (int)threadIdx.x, nq - 1)];
+                for (int k = 0; k < QI; ++k) {
+#if RLX_GAESEQ_NT
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v4) + min(q0 + k * ST + (int)threadIdx.x, nq - 1));
+                    q[k] = make_float4(t.x, t.y, t.z, t.w);
+#else
+                    q[k] = v4[min(q0 + k * ST + (int)threadIdx.x, nq - 1)];
+#endif
+                }
 #pragma unroll
                 for (int k = 0; k < QI; ++k) {
                     const int qi = q0 + k * ST + threadIdx.x;
@@ -147,8 +159,15 @@ __global__ __launch_bounds__(ST) void gae_seq_kernel(const float* __restrict__ v
                     rt[j] = fadd(gi, vi);       // returns[t] = gae + values[t]
                     at[j] = fsub(rt[j], vi);    // advantages = returns - values[:-1]
                 }
+#if RLX_GAESEQ_NT
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 r4 = {rt[0], rt[1], rt[2], rt[3]}, a4 = {at[0], at[1], at[2], at[3]};
+                __builtin_nontemporal_store(r4, reinterpret_cast<f32x4*>(ro) + qi);
+                __builtin_nontemporal_store(a4, reinterpret_cast<f32x4*>(ao) + qi);
+#else
                 reinterpret_cast<float4*>(ro)[qi] = make_float4(rt[0], rt[1], rt[2], rt[3]);
                 reinterpret_cast<float4*>(ao)[qi] = make_float4(at[0], at[1], at[2], at[3]);
+#endif
             }
         } else {
             for (int i = threadIdx.x; i < len; i += ST) {

@@ -7,8 +7,8 @@
 //   returns   one workgroup per sequence: locate the reward position, suffix-sum r[t] = [t == eos] reward - beta * kl[t]
 //             from the right in 1024-element tiles (coalesced 16-byte loads, wave-shuffle scans, f64 carries), write the
 //             return-to-go, accumulate (count, sum, sum of squares) of the masked returns -> per-sequence partials
-//   finalize  one workgroup: partials -> mean, rsqrt(max(var, 1e-8))
-//   normalize adv = (ret - mean) * rstd over the whole buffer, float4
+//   reduce    <= 64 workgroups: per-sequence partials -> group sums
+//   normalize every workgroup folds the group sums into mean, rsqrt(max(var, 1e-8)) itself; adv = (ret - mean) * rstd, float4
 //
 // HBM-bound: 4 (logprob) + 4 (ref) + 1 (mask) read + 4 written, then 4 + 4 for the normalisation = 21 B per token.
 //
@@ -16,7 +16,13 @@
 // the mask of sequence bsz-1-b (advantages.py:337-341 flips the batch axis of the [seq, bsz] mask, not the time axis).
 // Response masks start with True, for which this is seq-1: the scalar reward sits on the last position of the row.
 
+#include <algorithm>
+
 #include "rlx_common.h"
+
+#ifndef RLX_REINPP_NT
+#define RLX_REINPP_NT 1  // streaming loads of logprob / ref_logprob, streaming store of the normalised output (+6 %, measured)
+#endif
 
 namespace rlx {
 namespace {
@@ -62,8 +68,16 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
     {
         const uint8_t* mm = mask + (B - 1 - b) * S;
         long long first = S;
-        for (long long t = tid; t < S && first == S; t += RT)
-            if (mm[t]) first = t;
+        if (aligned && S % 4 == 0) {  // four mask bytes per lane and load (bool bytes are 0 / 1: the lowest set bit names the byte)
+            const uint32_t* m4 = reinterpret_cast<const uint32_t*>(mm);
+            for (long long w = tid; w < S / 4 && first == S; w += RT) {
+                const uint32_t x = m4[w];
+                if (x) first = w * 4 + (__ffs((int)x) - 1) / 8;
+            }
+        } else {
+            for (long long t = tid; t < S && first == S; t += RT)
+                if (mm[t]) first = t;
+        }
         // lanes stop at their own first hit; the block minimum is the row's first True
         for (int off = 32; off > 0; off >>= 1) {
             const long long o = __shfl_xor(first, off, RLX_WAVE);
@@ -89,8 +103,14 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
         uint8_t mk[4];
         if (vec_ok && t0 + 4 <= S) {
             if (has_kl) {
+#if RLX_REINPP_NT
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(lp + t0));
+                const f32x4 c = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rf + t0));
+#else
                 const float4 a = *reinterpret_cast<const float4*>(lp + t0);
                 const float4 c = *reinterpret_cast<const float4*>(rf + t0);
+#endif
                 r[0] = -fmul(kl_beta, kl_value(kl_kind, a.x, c.x)), r[1] = -fmul(kl_beta, kl_value(kl_kind, a.y, c.y));
                 r[2] = -fmul(kl_beta, kl_value(kl_kind, a.z, c.z)), r[3] = -fmul(kl_beta, kl_value(kl_kind, a.w, c.w));
             } else {
@@ -148,10 +168,15 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(RT) void reinpp_finalize_kernel(const double* __restrict__ partials, long long B, float* __restrict__ stats) {
+// partials [B][3] -> groups [G][3]: block g sums sequences g, g + G, ... (one single workgroup walking 3 B doubles was
+// 50 us at 32768 sequences)
+constexpr int MAX_GROUPS = 64;
+
+__global__ __launch_bounds__(RT) void reinpp_reduce_kernel(const double* __restrict__ partials, long long B,
+                                                           double* __restrict__ groups) {
     __shared__ double s_red[3][RT / RLX_WAVE];
     double acc[3] = {0.0, 0.0, 0.0};
-    for (long long b = threadIdx.x; b < B; b += RT) {
+    for (long long b = (long long)blockIdx.x * RT + threadIdx.x; b < B; b += (long long)gridDim.x * RT) {
         acc[0] += partials[b * 3], acc[1] += partials[b * 3 + 1], acc[2] += partials[b * 3 + 2];
     }
     const int lane = threadIdx.x & (RLX_WAVE - 1), wave = threadIdx.x / RLX_WAVE;
@@ -161,20 +186,29 @@ __global__ __launch_bounds__(RT) void reinpp_finalize_kernel(const double* __res
         if (lane == 0) s_red[k][wave] = acc[k];
     }
     __syncthreads();
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int w = 0; w < RT / RLX_WAVE; ++w) t += s_red[threadIdx.x][w];
+        groups[blockIdx.x * 3 + threadIdx.x] = t;
+    }
+}
+
+// every workgroup folds the (at most 64) group sums itself, in the same order -- no third launch, identical statistics
+__global__ __launch_bounds__(RT) void reinpp_normalize_kernel(float* __restrict__ x, long long n, const double* __restrict__ groups,
+                                                              int n_groups) {
+    __shared__ float s_stats[2];
     if (threadIdx.x == 0) {
         double c = 0.0, s = 0.0, q = 0.0;
-        for (int w = 0; w < RT / RLX_WAVE; ++w) c += s_red[0][w], s += s_red[1][w], q += s_red[2][w];
+        for (int g = 0; g < n_groups; ++g) c += groups[g * 3], s += groups[g * 3 + 1], q += groups[g * 3 + 2];
         // masked_mean of an all-False mask is the (zero) sum itself (utils/utils.py:327-328)
         const double mean = c > 0.0 ? s / c : 0.0;
         double var = c > 0.0 ? q / c - mean * mean : 0.0;
         var = var > 1e-8 ? var : 1e-8;
-        stats[0] = (float)mean;
-        stats[1] = (float)(1.0 / sqrt(var));
+        s_stats[0] = (float)mean;
+        s_stats[1] = (float)(1.0 / sqrt(var));
     }
-}
-
-__global__ __launch_bounds__(RT) void reinpp_normalize_kernel(float* __restrict__ x, long long n, const float* __restrict__ stats) {
-    const float mean = stats[0], rstd = stats[1];
+    __syncthreads();
+    const float mean = s_stats[0], rstd = s_stats[1];
     const long long n4 = n / 4;
     const long long stride = (long long)gridDim.x * RT;
     float4* x4 = reinterpret_cast<float4*>(x);
@@ -186,7 +220,13 @@ __global__ __launch_bounds__(RT) void reinpp_normalize_kernel(float* __restrict_
         float4 v = x4[i];
         v.x = fmul(fsub(v.x, mean), rstd), v.y = fmul(fsub(v.y, mean), rstd);
         v.z = fmul(fsub(v.z, mean), rstd), v.w = fmul(fsub(v.w, mean), rstd);
+#if RLX_REINPP_NT
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 o = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(x) + i);
+#else
         x4[i] = v;
+#endif
     }
     for (long long i = n4 * 4 + (long long)blockIdx.x * RT + threadIdx.x; i < n; i += stride) x[i] = fmul(fsub(x[i], mean), rstd);
 }
@@ -196,7 +236,9 @@ __global__ __launch_bounds__(RT) void reinpp_normalize_kernel(float* __restrict_
 
 using namespace rlx;
 
-extern "C" size_t rlx_reinpp_workspace_bytes(int64_t bsz) { return (size_t)(bsz > 0 ? bsz : 0) * 3 * sizeof(double) + 256; }
+extern "C" size_t rlx_reinpp_workspace_bytes(int64_t bsz) {
+    return (size_t)(bsz > 0 ? bsz : 0) * 3 * sizeof(double) + (size_t)MAX_GROUPS * 3 * sizeof(double) + 256;
+}
 
 extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask, const float* logprob, const float* ref_logprob,
                                   int kl_type, float kl_beta, float* advantages, int64_t bsz, int64_t seq, void* workspace,
@@ -212,19 +254,20 @@ extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partials = static_cast<double*>(workspace);
-    float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + (size_t)bsz * 3 * sizeof(double));
+    double* groups = partials + (size_t)bsz * 3;
     const uintptr_t bits = reinterpret_cast<uintptr_t>(loss_mask) | reinterpret_cast<uintptr_t>(advantages) |
                            (kl_beta > 0.f ? (reinterpret_cast<uintptr_t>(logprob) | reinterpret_cast<uintptr_t>(ref_logprob)) : 0);
     hipLaunchKernelGGL(reinpp_returns_kernel, dim3((unsigned)bsz), dim3(RT), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
                        kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
     RLX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reinpp_finalize_kernel, dim3(1), dim3(RT), 0, st, partials, (long long)bsz, stats);
+    const int n_groups = (int)std::min<long long>(MAX_GROUPS, (bsz + RT - 1) / RT);
+    hipLaunchKernelGGL(reinpp_reduce_kernel, dim3(n_groups), dim3(RT), 0, st, partials, (long long)bsz, groups);
     RLX_LAUNCH_CHECK();
     const long long n = (long long)bsz * seq;
     long long blocks = (n / 4 + RT - 1) / RT;
     const long long cap = (long long)num_cu() * 16;
     blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
-    hipLaunchKernelGGL(reinpp_normalize_kernel, dim3((unsigned)blocks), dim3(RT), 0, st, advantages, n, stats);
+    hipLaunchKernelGGL(reinpp_normalize_kernel, dim3((unsigned)blocks), dim3(RT), 0, st, advantages, n, groups, n_groups);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
