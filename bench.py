@@ -262,7 +262,7 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     msk = torch.ones(4096, 8192, dtype=torch.bool, device=device)
     us = avg_us(lambda: _t.reinpp_seq_adv(r, msk, lp, rlp, 0.001, "low_var_kl"))
     nb = lp.numel() * 21
-    rows.append({"kernel": "reinpp_seq_adv (returns + finalize + normalize)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
+    rows.append({"kernel": "reinpp_seq_adv (returns + reduce + normalize)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
                  "algorithmic_bytes": nb, "shape": "4096 sequences x 8192 tokens, k3 KL penalty"})
     del lp, rlp, msk
