@@ -117,7 +117,7 @@ def test_ppo_step_gradients_and_metrics_vs_oracle(M, with_mask):
         err = float((got[o:o + w.numel()] - w).abs().max())
         assert err <= tol, (name, err, tol)
     host = row.cpu()
-    assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(float(loss), rel=2e-4, abs=2e-5)
+    assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(float(loss.detach()), rel=2e-4, abs=2e-5)
     for key in ("actor/policy_loss", "actor/ratio", "actor/clipped_ratio", "actor/approx_kl", "actor/clip_fraction",
                 "critic/value_loss"):
         assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(float(metrics[key]), rel=5e-4, abs=5e-5), key
