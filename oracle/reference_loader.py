@@ -157,3 +157,20 @@ def load_distributed_utils():
         _stub("rlinf.utils.timers", NamedTimer=type("NamedTimer", (), {}), _rlx_stub=True)
     _du_cache = _exec("rlinf.utils.distributed", "rlinf/utils/distributed.py")
     return _du_cache
+
+
+def load_function(rel_path: str, name: str, **globs):
+    """One top-level function of a reference file whose module cannot be imported here (heavy third-party imports):
+    its own source, parsed where it lies and compiled on its own.  ``globs`` supplies the names it refers to."""
+    import ast
+
+    path = os.path.join(REFERENCE_ROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    node.returns, node.decorator_list = None, []
+    for a in node.args.args + node.args.kwonlyargs:
+        a.annotation = None
+    ns = dict(globs)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+

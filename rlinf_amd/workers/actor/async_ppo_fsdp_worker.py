@@ -141,7 +141,9 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                             row[PPO_OUT_FLOATS + 1] = ent_row[19]
                     self.optimizer_step(grads, stats=norms[step], critic_warmup=warm)
                     step += 1
-            return self._collect_decoupled_metrics(rows, norms, accum, flat.get("versions") is not None)
+            out = self._collect_decoupled_metrics(rows, norms, accum, flat.get("versions") is not None)
+            self._step_lr_scheduler()  # :467
+            return out
 
     def _collect_decoupled_metrics(self, rows, norms, accum: int, has_versions: bool) -> dict:
         """Means over micro-batches (the version metrics only over those that reported them: some element unmasked,
@@ -166,6 +168,5 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
         out["actor/total_loss"] = host[PPO_OUT_FLOATS] / max(accum, 1)
         out["actor/entropy_loss"] = host[PPO_OUT_FLOATS + 1]
         out["actor/grad_norm"] = host[PPO_OUT_FLOATS + 3]
-        out["actor/lr"] = float(self.cfg.actor.optim.lr)
-        out["critic/lr"] = float(self.cfg.actor.optim.value_lr)
+        out["actor/lr"], out["critic/lr"] = self._lrs
         return out

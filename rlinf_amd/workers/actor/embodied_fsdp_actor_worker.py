@@ -23,6 +23,7 @@ from ...data import convert_trajectories_to_batch
 from ...models import get_model
 from ...scheduler.dist import all_reduce_flat_, all_reduce_scalars
 from ...scheduler.placement import compute_split_num, minibatch_plan
+from ...utils.lr_scheduler import LearnerLRScheduler
 from ..common import Worker
 
 CRITIC_EXPLAINED_VARIANCE_KEY = "critic/explained_variance"
@@ -73,9 +74,28 @@ class EmbodiedFSDPActor(Worker):
         self.opt_stats = torch.zeros(2, device=dev)
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
         self.grad_flat = torch.zeros(n, device=dev)
-        self.groups = self.model.group_ranges(a.optim.lr, a.optim.value_lr,
-                                              train_value_head=self.cfg.algorithm.loss_type != "actor")
         self._ws = {}
+        self._build_lr_scheduler()
+
+    def _build_lr_scheduler(self):
+        """build_lr_scheduler (fsdp_model_manager.py:464-498): a fresh schedule over (lr, value_lr)."""
+        o = self.cfg.actor.optim
+        self.lr_scheduler = LearnerLRScheduler(o, [o.lr, o.value_lr])
+        self._apply_lrs()
+
+    def _apply_lrs(self):
+        """The schedule's current learning rates -> the AdamW ranges; launch plans and graphs that captured the old values
+        are dropped."""
+        self._lrs = self.lr_scheduler.get_last_lr()
+        self.groups = self.model.group_ranges(self._lrs[0], self._lrs[1], train_value_head=self.cfg.algorithm.loss_type != "actor")
+        self._ws.pop("prepared_key", None)
+        self._graph = None
+
+    def _step_lr_scheduler(self):
+        """lr_scheduler.step() once per run_training (embodied_fsdp_actor_worker.py:568)."""
+        self.lr_scheduler.step()
+        if self.lr_scheduler.get_last_lr() != self._lrs:
+            self._apply_lrs()
 
     def set_global_step(self, global_step: int):
         self.version = global_step
@@ -303,6 +323,7 @@ class EmbodiedFSDPActor(Worker):
         if self.critic_warmup_steps > 0 and self.optimizer_steps >= self.critic_warmup_steps:
             self.exp_avg.zero_(), self.exp_avg_sq.zero_(), self.step_state.zero_()  # build_optimizer(model) anew (:453-455)
             self.critic_warmup_steps = 0
+            self._build_lr_scheduler()  # ... and a new scheduler over it (:456-459)
 
     def _run_update(self, flat: dict, N: int, metrics_dev: torch.Tensor, norms_dev: torch.Tensor):
         a, alg = self.cfg.actor, self.cfg.algorithm
@@ -396,11 +417,13 @@ class EmbodiedFSDPActor(Worker):
                 self._ws[key] = (torch.zeros(n_steps * accum, PPO_OUT_FLOATS, device=self.device),
                                  torch.zeros(n_steps, 2, device=self.device))
             metrics_dev, norms_dev = self._ws[key]
-            if self.enable_hip_graph and self._world_size == 1 and self.critic_warmup_steps == 0:
+            if self.enable_hip_graph and self._world_size == 1 and self.critic_warmup_steps == 0 and self.lr_scheduler.is_static:
                 self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
             else:
                 self._run_update(flat, N, metrics_dev, norms_dev)
-            return self._collect_metrics(metrics_dev, norms_dev, accum)
+            out = self._collect_metrics(metrics_dev, norms_dev, accum)
+            self._step_lr_scheduler()
+            return out
 
     def _replay_or_capture(self, flat, N, metrics_dev, norms_dev, n_steps):
         """hipGraph of the whole update phase (all epochs x minibatches): every buffer is persistent and the step
@@ -441,6 +464,5 @@ class EmbodiedFSDPActor(Worker):
         out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
         out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
         out["actor/grad_norm"] = host[-1]
-        out["actor/lr"] = float(self.cfg.actor.optim.lr)
-        out["critic/lr"] = float(self.cfg.actor.optim.value_lr)
+        out["actor/lr"], out["critic/lr"] = self._lrs  # the rates the steps of this run_training used
         return out

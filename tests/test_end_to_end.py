@@ -13,7 +13,7 @@ from oracle import ppo_oracle as O
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
              auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False,
-             critic_warmup_steps=0):
+             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline),
@@ -29,7 +29,8 @@ def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_e
                    model=dict(model_type="mlp_policy", obs_dim=42, action_dim=8, num_action_chunks=1, precision="32",
                               add_value_head=True),
                    optim=dict(lr=3e-4, value_lr=3e-4, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
-                              weight_decay=0.01, clip_grad=0.5, critic_warmup_steps=critic_warmup_steps),
+                              weight_decay=0.01, clip_grad=0.5, critic_warmup_steps=critic_warmup_steps,
+                              **({"lr_scheduler": lr_scheduler, "total_training_steps": total_training_steps} if lr_scheduler else {})),
                    fsdp_config=dict(strategy="fsdp", sharding_strategy="no_shard"))))
 
 
@@ -85,7 +86,10 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=16, steps=10, global_batch=80, stage_num=2, hip_graph=True),
                                    dict(total_envs=16, steps=10, global_batch=80, micro_batch=40, stage_num=2, pipeline=True),
                                    dict(total_envs=16, steps=10, global_batch=80, pipeline=True, hip_graph=True),
-                                   dict(total_envs=16, steps=10, global_batch=40, critic_warmup_steps=5)])  # 8 steps / iteration
+                                   dict(total_envs=16, steps=10, global_batch=40, critic_warmup_steps=5),  # 8 steps / iteration
+                                   # a schedule that moves every iteration: graphs / prepared plans must follow it
+                                   dict(total_envs=16, steps=10, global_batch=80, hip_graph=True, lr_scheduler="torch_cosine",
+                                        total_training_steps=3)])
 def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
@@ -98,6 +102,9 @@ def test_iteration_matches_oracle(shape):
     runner = _build(cfg, env, sd)
     n_iter = 3 if shape.get("hip_graph") else 2  # graph: eager warm-up, capture+replay, replay
     pipe, steps_done = None, 0
+    sched = None
+    if shape.get("lr_scheduler") == "torch_cosine":  # what get_lr_scheduler builds for that name (fsdp/utils.py:594-602)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=shape["total_training_steps"], eta_min=1e-6)
     if shape.get("pipeline"):  # the rank's stateful shuffle generator, seeded like _init_pipeline_params (rank 0 of 1)
         pipe = dict(stage_num=shape.get("stage_num", 1), generator=torch.Generator().manual_seed(1234))
     for it in range(n_iter):
@@ -108,6 +115,9 @@ def test_iteration_matches_oracle(shape):
                                 critic_warmup_steps=shape.get("critic_warmup_steps", 0), steps_done=steps_done)
         steps_done += len(om)
         metrics = runner.run_step(eps.cuda())
+        assert metrics["train/actor/lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
+        if sched is not None:
+            sched.step()  # once per run_training
         rb = runner.actor.worker.rollout_batch
         tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)  # later iterations inherit Adam's drift
         torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), batch["forward_inputs"]["action"], **tol)
