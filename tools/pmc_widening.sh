@@ -18,7 +18,8 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
             if row.get("Counter_Name") != C:
                 continue
             name = row["Kernel_Name"]
-            for key in ("copyBuffer", "bfloat16_copy", "token_logprob_fwd", "token_logprob_bwd", "patch_scan", "gae_seq"):
+            for key in ("copyBuffer", "bfloat16_copy", "token_logprob_fwd", "token_logprob_bwd", "patch_scan", "gae_seq",
+                        "reinpp_returns", "reinpp_normalize", "copy_segments"):
                 if key in name:
                     acc[key].append(float(row["Counter_Value"]))
     for k, v in acc.items():
@@ -32,5 +33,7 @@ for k, v in res.items():
     wr = w * NB / cal["WRITE_SIZE"] / 1e6 if cal and cal.get("WRITE_SIZE") else float("nan")
     print(f"{k:20s} {f:12.1f} {w:12.1f} {rd:10.1f} {wr:10.1f}")
 print("algorithmic MB: fwd read", NB / 1e6, "; bwd read+write", NB / 1e6, "each; patch_scan read", 2 * NB / 1e6,
-      "; gae_seq read", 4096 * 8192 * 4 / 1e6, "write", 4096 * 8192 * 8 / 1e6)
+      "; gae_seq read", 4096 * 8192 * 4 / 1e6, "write", 4096 * 8192 * 8 / 1e6,
+      "; reinpp_returns read", 4096 * 8192 * 10 / 1e6, "write", 4096 * 8192 * 4 / 1e6, "; reinpp_normalize read = write",
+      4096 * 8192 * 4 / 1e6, "; copy_segments read", 8 * 4096 * 8192 * 4 / 1e6, "write", 8 * 4096 * 8192 * 2 / 1e6)
 PY

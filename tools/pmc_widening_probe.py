@@ -1,5 +1,5 @@
 """Workload for the --pmc passes over the widening kernels: a device-to-device copy of known size (calibration for the
-16-byte-per-lane access width), then token_logprob fwd / bwd, patch_scan and gae_seq, each a few launches."""
+16-byte-per-lane access width), then token_logprob fwd / bwd, patch_scan, gae_seq, the three reinpp launches and copy_segments, each a few launches."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,5 +37,17 @@ v = torch.randn(4096, 8192, device=dev, generator=g)
 r = torch.randn(4096, device=dev, generator=g)
 for _ in range(3):
     token_ops.gae_seq(v, r, 1.0, 0.95)
+torch.cuda.synchronize()
+lp2 = -torch.rand(4096, 8192, device=dev, generator=g) * 3
+rlp2 = lp2 + 0.3 * torch.randn(4096, 8192, device=dev, generator=g)
+msk = torch.ones(4096, 8192, dtype=torch.bool, device=dev)
+for _ in range(3):
+    token_ops.reinpp_seq_adv(r, msk, lp2, rlp2, 0.001, "low_var_kl")   # reinpp_returns / _reduce / _normalize
+torch.cuda.synchronize()
+from rlinf_amd.hybrid_engines.weight_syncer.bucket_syncer import BucketPacker
+masters = [(f"w{i}", torch.randn(4096, 8192, device=dev, generator=g), torch.bfloat16) for i in range(8)]
+packer = BucketPacker(masters)
+for _ in range(3):
+    packer.pack(masters, torch.device(dev), None, persistent=True)      # copy_segments: 8 x 128 MiB f32 -> bf16
 torch.cuda.synchronize()
 print("bytes", N * V * 2, "gae_seq tokens", v.numel())
