@@ -143,3 +143,36 @@ def test_categorical_oracle_is_torch_multinomial(dtype, temperature, top_k):
     assert torch.equal(lp, TO.logprobs_from_logits(x, ids))
     tok0, lp0, _, act = TO.categorical_sample(logits, None, bin_centers=torch.arange(255.))
     assert torch.equal(tok0, logits.argmax(-1)) and torch.equal(act, (255 - tok0).clamp(0, 254).float())
+
+
+def test_async_entry_point_selects_the_learner_by_loss_type():
+    """examples/embodiment/train_async.py: config loading / validation and the reference's loss_type -> learner rule
+    (examples/embodiment/train_async.py:49-80); also with the reference's own YAML where its tree exists."""
+    import importlib.util
+    import os
+
+    from rlinf_amd.config import load_config, validate_cfg
+    from rlinf_amd.workers.actor import AsyncPPOEmbodiedFSDPActor, EmbodiedFSDPActor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_async", os.path.join(root, "examples", "embodiment", "train_async.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg_dir = os.path.join(root, "examples", "embodiment", "config")
+    cfg = validate_cfg(load_config(os.path.join(cfg_dir, "maniskill_async_ppo_mlp.yaml"), overrides=["runner.max_epochs=2"],
+                                   search_paths=[cfg_dir]))
+    assert cfg.algorithm.loss_type == "decoupled_actor_critic" and cfg.runner.max_epochs == 2
+    cls = mod.select_actor_cls(cfg)
+    assert cls is AsyncPPOEmbodiedFSDPActor and issubclass(cls, EmbodiedFSDPActor)
+    n = cfg.env.train.total_num_envs * cfg.env.train.max_steps_per_rollout_epoch
+    assert n % cfg.actor.global_batch_size == 0 and cfg.actor.global_batch_size % cfg.actor.micro_batch_size == 0
+    cfg.algorithm.loss_type = "embodied_sac"
+    with pytest.raises(NotImplementedError, match="only the decoupled-PPO learner"):
+        mod.select_actor_cls(cfg)
+    cfg.algorithm.loss_type = "actor_critic"
+    with pytest.raises(ValueError, match="Unsupported loss type actor_critic for async embodied runner"):
+        mod.select_actor_cls(cfg)
+    ref_dir = "/root/reference/examples/embodiment/config"
+    if os.path.exists(os.path.join(ref_dir, "maniskill_async_ppo_mlp.yaml")):
+        ref_cfg = validate_cfg(load_config(os.path.join(ref_dir, "maniskill_async_ppo_mlp.yaml"), search_paths=[ref_dir]))
+        assert ref_cfg.algorithm.loss_type == "decoupled_actor_critic"
+        assert mod.select_actor_cls(ref_cfg) is AsyncPPOEmbodiedFSDPActor
