@@ -345,6 +345,29 @@ def test_masked_normalization(ref, masked, monkeypatch):
     _eq(du.masked_normalization(x, mask), O.masked_normalization(x, mask))
 
 
+def test_async_flatten_rollout_batch(ref):
+    """flatten_rollout_batch_for_train (async_ppo_fsdp_worker.py:42-69): its module needs the whole FSDP stack, so the function
+    is compiled from its source on its own; it is the same flatten-and-gather the synchronous learner uses."""
+    from typing import Optional
+
+    from oracle import reference_loader
+    fn = reference_loader.load_function("rlinf/workers/actor/async_ppo_fsdp_worker.py", "flatten_rollout_batch_for_train",
+                                        torch=torch, Optional=Optional)
+    d = synth_rollout(T=6, B=5, C=1)
+    batch = dict(rewards=d["rewards"], dones=d["dones"], prev_values=d["values"], prev_logprobs=torch.randn(6, 5, 8),
+                 versions=torch.full((6, 5, 8), 3.0), loss_mask=None,
+                 forward_inputs=dict(states=torch.randn(6, 5, 42), action=torch.randn(6, 5, 8)))
+    perm = torch.randperm(30, generator=torch.Generator().manual_seed(2))
+    want, got = fn(batch, perm), O.flatten_and_shuffle(batch, perm)
+    assert set(want) == set(got) and want["loss_mask"] is None and got["loss_mask"] is None
+    for k in ("rewards", "dones", "prev_values", "prev_logprobs", "versions"):
+        _eq(want[k], got[k])
+    for k in ("states", "action"):
+        _eq(want["forward_inputs"][k], got["forward_inputs"][k])
+    plain = fn(batch, None)
+    _eq(plain["prev_values"], d["values"][:-1].reshape(30, 1))
+
+
 # ---- decoupled PPO (oracle a19b) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
 @pytest.mark.parametrize("prox_mode", ["given", "old", "versions"])
