@@ -160,13 +160,17 @@ def load_distributed_utils():
 
 
 def load_function(rel_path: str, name: str, **globs):
-    """One top-level function of a reference file whose module cannot be imported here (heavy third-party imports):
+    """One top-level function (or ``Class.method``) of a reference file whose module cannot be imported here (heavy third-party imports):
     its own source, parsed where it lies and compiled on its own.  ``globs`` supplies the names it refers to."""
     import ast
 
     path = os.path.join(REFERENCE_ROOT, rel_path)
     tree = ast.parse(open(path).read(), filename=path)
-    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    body = tree.body
+    *owners, name = name.split(".")  # "Class.method": the method as a plain function taking ``self``
+    for owner in owners:
+        body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == owner).body
+    node = next(n for n in body if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef)) and n.name == name)
     node.returns, node.decorator_list = None, []
     for a in node.args.args + node.args.kwonlyargs:
         a.annotation = None

@@ -345,6 +345,60 @@ def test_masked_normalization(ref, masked, monkeypatch):
     _eq(du.masked_normalization(x, mask), O.masked_normalization(x, mask))
 
 
+@pytest.mark.parametrize("bootstrap_type", ["always", "standard"])
+def test_bootstrap_rewards(ref, bootstrap_type):
+    """EnvWorker.compute_bootstrap_rewards (env_worker.py:718-758), the method compiled on its own and called with a stand-in
+    ``self``: r[:, -1] += gamma * V(final_obs) where the last sub-step was done ("always") / truncated ("standard")."""
+    from types import SimpleNamespace
+
+    from oracle import reference_loader
+    fn = reference_loader.load_function("rlinf/workers/env/env_worker.py", "EnvWorker.compute_bootstrap_rewards", torch=torch)
+    g = torch.Generator().manual_seed(8)
+    B, C = 12, 3
+    rewards = torch.rand(B, C, generator=g)
+    term, trunc = torch.rand(B, C, generator=g) < 0.3, torch.rand(B, C, generator=g) < 0.3
+    values = torch.randn(B, 1, generator=g)
+    alg = {"bootstrap_type": bootstrap_type}
+    me = SimpleNamespace(cfg=SimpleNamespace(env=SimpleNamespace(train=SimpleNamespace(auto_reset=True)),
+                                             algorithm=SimpleNamespace(get=alg.get, gamma=0.8)))
+    env_out = SimpleNamespace(rewards=rewards, dones=term | trunc, truncations=trunc)
+    want = fn(me, env_out, values, None)
+    flags = env_out.dones if bootstrap_type == "always" else trunc
+    _eq(want, O.bootstrap_rewards(rewards, flags, values, 0.8))
+    assert fn(me, SimpleNamespace(rewards=None), values, None) is None  # the bootstrap row carries no reward (A.1)
+
+
+def test_pipeline_stage_shuffles(ref):
+    """EnvWorker.pack_pipeline_micro_batches (env_worker.py:1519-1537), compiled on its own: every stage batch is flattened
+    and shuffled with the rank's stateful generator, stage after stage -- the row order oracle.ppo_loop.pipeline_permutation
+    hands the learner, as indices into the rank's [T, B] buffer whose stages are contiguous env blocks."""
+    from types import SimpleNamespace
+
+    from oracle import ppo_loop as L
+    from oracle import reference_loader
+    fn = reference_loader.load_function("rlinf/workers/env/env_worker.py", "EnvWorker.pack_pipeline_micro_batches", torch=torch,
+                                        flatten_embodied_batch=ref.utils.flatten_embodied_batch, pack_batch=ref.utils.pack_batch,
+                                        split_dict_to_chunk=ref.nested.split_dict_to_chunk)
+    T, B, stages, micro = 6, 8, 2, 12
+    n = B // stages
+    ids = torch.arange(T * B, dtype=torch.float32).view(T, B, 1)  # every row of the rank's buffer carries its flat index
+    me = SimpleNamespace(shuffle_rollout=True, shuffle_generators={0: torch.Generator().manual_seed(1234)},
+                         cfg=SimpleNamespace(actor=SimpleNamespace(micro_batch_size=micro)))
+    seen = []
+    for st in range(stages):
+        stage_batch = {"prev_logprobs": ids[:, st * n:(st + 1) * n], "forward_inputs": {"states": ids[:, st * n:(st + 1) * n].clone()},
+                       "prev_values": torch.zeros(T + 1, n, 1), "loss_mask": None}
+        for mb in fn(me, stage_batch, 0):
+            assert set(mb) == {"prev_logprobs", "forward_inputs::states", "prev_values"} and mb["prev_values"].shape[0] == micro
+            seen.append(mb["prev_logprobs"].reshape(-1))
+    want = torch.cat(seen).long()
+    got = L.pipeline_permutation(T, B, stages, torch.Generator().manual_seed(1234))
+    assert torch.equal(want, got)
+    me.shuffle_rollout = False
+    plain = torch.cat([mb["prev_logprobs"].reshape(-1) for mb in fn(me, {"prev_logprobs": ids[:, :n]}, 0)]).long()
+    assert torch.equal(plain, ids[:, :n].reshape(-1).long())
+
+
 def test_async_flatten_rollout_batch(ref):
     """flatten_rollout_batch_for_train (async_ppo_fsdp_worker.py:42-69): its module needs the whole FSDP stack, so the function
     is compiled from its source on its own; it is the same flatten-and-gather the synchronous learner uses."""
