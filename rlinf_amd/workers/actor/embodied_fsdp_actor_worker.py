@@ -174,11 +174,14 @@ class EmbodiedFSDPActor(Worker):
         out = {}
         for i, key in enumerate(names):
             cnt = s[2 * i + 1]
-            mean = s[2 * i] / cnt if cnt > 0 else float("nan")
+            if cnt > 0:
+                mean, vmax, vmin = s[2 * i] / cnt, m[2 * i + 1], -m[2 * i]
+            else:  # nothing selected on any rank: all three are NaN (metric_utils.py:458-460)
+                mean = vmax = vmin = float("nan")
             if key == "rewards":
                 out["rewards"] = mean
             else:
-                out[f"{key}_mean"], out[f"{key}_max"], out[f"{key}_min"] = mean, m[2 * i + 1], -m[2 * i]
+                out[f"{key}_mean"], out[f"{key}_max"], out[f"{key}_min"] = mean, vmax, vmin
         return out
 
     # ---- update -------------------------------------------------------------------------------------------------

@@ -368,6 +368,46 @@ def test_bootstrap_rewards(ref, bootstrap_type):
     assert fn(me, SimpleNamespace(rewards=None), values, None) is None  # the bootstrap row carries no reward (A.1)
 
 
+@pytest.mark.parametrize("masked", [False, True, "empty"])
+def test_rollout_metrics(ref, masked, monkeypatch):
+    """a15: compute_rollout_metrics (metric_utils.py:422-506) in a one-rank gloo group against the learner's
+    _rollout_metrics (pure torch reductions, so it runs on CPU tensors too): masked mean / min / max, NaN when nothing
+    is selected, the [T, B] mask broadcast over the trailing dim."""
+    import math
+    import sys
+    import types
+
+    import torch.distributed as dist
+
+    from rlinf_amd.workers.actor import EmbodiedFSDPActor
+    from test_end_to_end import make_cfg
+    platform = types.SimpleNamespace(current_device=lambda: torch.device("cpu"))
+    wmod = types.ModuleType("rlinf.scheduler.worker.worker")
+    wmod.Worker = types.SimpleNamespace(torch_platform=platform)
+    monkeypatch.setitem(sys.modules, "rlinf.scheduler.worker", types.ModuleType("rlinf.scheduler.worker"))
+    monkeypatch.setitem(sys.modules, "rlinf.scheduler.worker.worker", wmod)
+    started = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1)
+        started = True
+    try:
+        g = torch.Generator().manual_seed(3)
+        T, B = 7, 6
+        batch = dict(rewards=torch.rand(T, B, 1, generator=g), advantages=torch.randn(T, B, 1, generator=g),
+                     returns=torch.randn(T, B, 1, generator=g))
+        if masked:
+            batch["loss_mask"] = (torch.rand(T, B, 1, generator=g) < 0.5) if masked is True else torch.zeros(T, B, 1, dtype=torch.bool)
+        want = ref.metric_utils.compute_rollout_metrics(dict(batch))
+        got = EmbodiedFSDPActor(make_cfg())._rollout_metrics(dict(batch))
+        assert set(want) == set(got) == {"rewards", "advantages_mean", "advantages_max", "advantages_min", "returns_mean",
+                                         "returns_max", "returns_min"}
+        for k, v in want.items():
+            assert (math.isnan(v) and math.isnan(got[k])) or got[k] == pytest.approx(v, rel=1e-6, abs=1e-7), (k, v, got[k])
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
 def test_pipeline_stage_shuffles(ref):
     """EnvWorker.pack_pipeline_micro_batches (env_worker.py:1519-1537), compiled on its own: every stage batch is flattened
     and shuffled with the rank's stateful generator, stage after stage -- the row order oracle.ppo_loop.pipeline_permutation
