@@ -124,3 +124,53 @@ def test_policy_loss_entry_and_lazy_metrics():
     assert len(stats) == 5 and EV_PREFIX + "count" not in metrics
     want_ev = O.explained_variance({k.split("/")[-1]: val for k, val in stats.items()})
     assert explained_variance_from_stats(stats) == pytest.approx(want_ev, rel=1e-5)
+
+
+# ---- routing maps: the known answers of the reference's tests/unit_tests/test_comm_mapper.py:40-150 -------------------------
+_SEND = [("env", "rollout", 0, 2, 3, 12, [(0, 4), (1, 2)]), ("env", "rollout", 1, 2, 3, 12, [(1, 2), (2, 4)]),
+         ("rollout", "env", 0, 3, 2, 12, [(0, 4)]), ("rollout", "env", 1, 3, 2, 12, [(0, 2), (1, 2)]),
+         ("rollout", "env", 2, 3, 2, 12, [(1, 4)])]
+_RECV = [("env", "rollout", 0, 2, 3, 12, [(0, 4)]), ("env", "rollout", 1, 2, 3, 12, [(0, 2), (1, 2)]),
+         ("env", "rollout", 2, 2, 3, 12, [(1, 4)])]
+
+
+def test_route_plans_known_answers():
+    from rlinf_amd.scheduler import build_recv_plan, build_send_plan
+    for src, dst, rank, sw, dw, bs, want in _SEND:
+        plan = build_send_plan(src_group_name=src, dst_group_name=dst, src_rank=rank, src_world_size=sw, dst_world_size=dw,
+                               tag="train", batch_size=bs)
+        assert [(e.peer_rank, e.batch_size) for e in plan.entries] == want
+        assert [e.offset for e in plan.entries] == [sum(s for _, s in want[:i]) for i in range(len(want))]
+    for src, dst, rank, sw, dw, bs, want in _RECV:
+        plan = build_recv_plan(src_group_name=src, dst_group_name=dst, dst_rank=rank, src_world_size=sw, dst_world_size=dw,
+                               tag="train", batch_size=bs)
+        assert [(e.peer_rank, e.batch_size) for e in plan.entries] == want
+
+
+@pytest.mark.reference
+def test_comm_mapper_vs_reference_on_a_grid():
+    """CommMapper.get_dst_ranks / get_src_ranks (rlinf/scheduler/worker/routing.py:132-196), the reference's static methods
+    compiled from their source, on every (batch, src world, dst world, rank) of a grid; and what a source sends to a
+    destination is what that destination expects from it."""
+    from oracle import reference_loader
+    from rlinf_amd.scheduler import CommMapper
+    if not reference_loader.available():
+        pytest.skip("reference tree not present")
+    dst_ref = reference_loader.load_function("rlinf/scheduler/worker/routing.py", "CommMapper.get_dst_ranks")
+    src_ref = reference_loader.load_function("rlinf/scheduler/worker/routing.py", "CommMapper.get_src_ranks",
+                                             CommMapper=type("CommMapper", (), {"get_dst_ranks": staticmethod(dst_ref)}))
+    for sw in (1, 2, 3, 4, 6, 8):
+        for dw in (1, 2, 3, 4, 6, 8):
+            for mult in (1, 5):
+                bs = sw * dw * mult * 2
+                sent = {}
+                for r in range(sw):
+                    got = CommMapper.get_dst_ranks(bs, sw, dw, r)
+                    assert got == dst_ref(bs, sw, dw, r)
+                    sent.update({(r, d): n for d, n in got})
+                for r in range(dw):
+                    got = CommMapper.get_src_ranks(bs, sw, dw, r)
+                    assert got == src_ref(bs, sw, dw, r)
+                    assert all(sent[(s, r)] == n for s, n in got)
+    with pytest.raises(AssertionError, match="must be divisible by src_world_size"):
+        CommMapper.get_dst_ranks(10, 4, 2, 0)
