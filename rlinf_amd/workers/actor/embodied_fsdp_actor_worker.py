@@ -293,6 +293,10 @@ class EmbodiedFSDPActor(Worker):
         if bonus <= 0 or critic_warmup:
             return
         has_mask = mbatch.get("loss_mask") is not None
+        if has_mask and alg.get("entropy_type", "action_level") == "chunk_level":
+            # reshape_entropy (utils.py:406-407) leaves a [bsz] vector that masked_mean then multiplies with a [bsz, C] mask:
+            # an outer product for C = 1 (entropy_loss comes out bsz times larger), a shape error otherwise
+            raise NotImplementedError("entropy_type='chunk_level' together with a loss mask is not reproduced (see the comment)")
         per_elem = alg.get("entropy_type", "action_level") == "token_level" and not has_mask
         ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
                                     has_mask, 1.0 / self.model.layout.act_dim if per_elem else 1.0)
