@@ -345,6 +345,45 @@ def test_masked_normalization(ref, masked, monkeypatch):
     _eq(du.masked_normalization(x, mask), O.masked_normalization(x, mask))
 
 
+@pytest.mark.parametrize("warmup", [False, True])
+def test_build_optimizer_groups(ref, warmup):
+    """FSDPModelManager.build_optimizer (fsdp_model_manager.py:501-590), the method compiled on its own with a stand-in
+    ``self``: two AdamW groups -- names containing value_head at value_lr, the rest at lr -- or the value head alone while
+    the critic warms up (everything else frozen); its state-initialising empty step leaves parameters and step counts as
+    they were, so a fresh torch AdamW over the same groups (the oracle's build_adamw) is the same optimizer."""
+    from types import SimpleNamespace
+
+    from oracle import reference_loader
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    fn = reference_loader.load_function(
+        "rlinf/hybrid_engines/fsdp/fsdp_model_manager.py", "FSDPModelManager.build_optimizer", torch=torch,
+        warmup_optimizer_state=ref.utils.warmup_optimizer_state,
+        Worker=SimpleNamespace(torch_device_type="cpu", torch_platform=SimpleNamespace(is_available=lambda: False)))
+    me = SimpleNamespace(_cfg=Cfg(optim=Cfg(adam_beta1=0.9, adam_beta2=0.999, lr=3e-4, value_lr=1e-3),
+                                  fsdp_config={"sharding_strategy": "no_shard"}),
+                         _logger=SimpleNamespace(info=lambda *a: None), store_requires_grad_param_name=[])
+    torch.manual_seed(0)
+    pol = O.OracleMLPPolicy(42, 8, 1)
+    before = [p.detach().clone() for p in pol.parameters()]
+    opt = fn(me, pol, enable_critic_warmup=warmup)
+    assert all(torch.equal(a, b) for a, b in zip(before, pol.parameters()))
+    assert all(int(opt.state[p]["step"]) == 0 and not opt.state[p]["exp_avg"].any() for g in opt.param_groups for p in g["params"])
+    names = {id(p): n for n, p in pol.named_parameters()}
+    got = [(sorted(names[id(p)] for p in g["params"]), g["lr"], g["betas"], g["eps"], g["weight_decay"]) for g in opt.param_groups]
+    critic = sorted(n for n in names.values() if "value_head" in n)
+    actor = sorted(n for n in names.values() if "value_head" not in n)
+    if warmup:
+        assert got == [(critic, 1e-3, (0.9, 0.999), 1e-8, 1e-2)]
+        assert all(p.requires_grad == ("value_head" in n) for n, p in pol.named_parameters())
+        return
+    ours = O.build_adamw(pol, lr=3e-4, value_lr=1e-3)
+    want = [(sorted(names[id(p)] for p in g["params"]), g["lr"], g["betas"], g["eps"], g["weight_decay"]) for g in ours.param_groups]
+    assert got == want == [(actor, 3e-4, (0.9, 0.999), 1e-8, 1e-2), (critic, 1e-3, (0.9, 0.999), 1e-8, 1e-2)]
+
+
 @pytest.mark.parametrize("bootstrap_type", ["always", "standard"])
 def test_bootstrap_rewards(ref, bootstrap_type):
     """EnvWorker.compute_bootstrap_rewards (env_worker.py:718-758), the method compiled on its own and called with a stand-in
