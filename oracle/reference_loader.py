@@ -178,3 +178,19 @@ def load_function(rel_path: str, name: str, **globs):
     exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
     return ns[name]
 
+
+_tb_cache = None
+
+
+def load_trajectory_builder():
+    """rlinf/data/schema/embodied_types.py and embodied_trajectory_builder.py (torch / numpy only) behind stub packages."""
+    global _tb_cache
+    if _tb_cache is None:
+        load()
+        _stub("rlinf.data", _rlx_stub=True)
+        _stub("rlinf.data.schema", _rlx_stub=True)
+        types_mod = _exec("rlinf.data.schema.embodied_types", "rlinf/data/schema/embodied_types.py")
+        builder_mod = _exec("rlinf.data.schema.embodied_trajectory_builder", "rlinf/data/schema/embodied_trajectory_builder.py")
+        _tb_cache = SimpleNamespace(types=types_mod, builder=builder_mod)
+    return _tb_cache
+

@@ -345,6 +345,59 @@ def test_masked_normalization(ref, masked, monkeypatch):
     _eq(du.masked_normalization(x, mask), O.masked_normalization(x, mask))
 
 
+@pytest.mark.parametrize("splits", [1, 2])
+def test_trajectory_buffer_row_alignment(ref, splits):
+    """a7 / SURVEY A.1: the same sequence of ChunkStepResults -- a bootstrap row without reward, T rows that pair step t's
+    policy output with step t-1's env output, one closing row with env output and a value only -- appended to the
+    reference's EmbodiedTrajectoryBuilder and to the resident TrajectoryBuffer (on CPU tensors here); trajectories, their
+    batch-dim splits and the converted batch agree field by field, and the oracle's rollout() lays its rows out the same."""
+    from oracle import ppo_loop as L
+    from oracle import reference_loader
+    from rlinf_amd.data import embodied_types as mine
+    m = reference_loader.load_trajectory_builder()
+    T, B, A, D = 5, 4, 8, 42
+    env = L.synthetic_env_tensors(0, T, B, D, max_episode_steps=3)
+    torch.manual_seed(5)
+    pol = O.OracleMLPPolicy(D, A, 1)
+    eps = torch.randn(T, B, A, generator=torch.Generator().manual_seed(1))
+    ref_builder = m.builder.EmbodiedTrajectoryBuilder(max_episode_length=3)
+    buf = mine.TrajectoryBuffer(T, B, D, A, 1, device="cpu", max_episode_length=3)
+    obs = env["obs"][0]
+    prev_env = dict(dones=torch.zeros(B, 1, dtype=torch.bool), terminations=torch.zeros(B, 1, dtype=torch.bool),
+                    truncations=torch.zeros(B, 1, dtype=torch.bool), rewards=None)  # bootstrap_step: no reward yet
+    for t in range(T + 1):
+        fields = dict(prev_env)
+        if t < T:
+            a, lp, v = pol.act(obs, eps=eps[t], mode="train")
+            fields.update(actions=a, prev_logprobs=lp, prev_values=v, versions=torch.full_like(lp, 2.0),
+                          forward_inputs={"states": obs.clone(), "action": a.clone()})
+        else:
+            fields.update(prev_values=pol.value_head.mlp(obs).detach())
+        ref_builder.append_step_result(m.types.ChunkStepResult(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in fields.items()}))
+        buf.append_step_result(mine.ChunkStepResult(**fields))
+        if t < T:
+            d = env["dones"][t + 1].unsqueeze(-1)
+            prev_env = dict(dones=d, terminations=d.clone(), truncations=torch.zeros_like(d), rewards=env["rewards"][t].unsqueeze(-1).clone())
+            obs = env["obs"][t + 1]
+    want_trajs = ref_builder.to_splited_trajectories(splits)
+    got_trajs = buf.to_splited_trajectories(splits)
+    names = ("actions", "rewards", "terminations", "truncations", "dones", "prev_logprobs", "prev_values", "versions")
+    for w, g in zip(want_trajs, got_trajs):
+        for n in names:
+            _eq(getattr(w, n), getattr(g, n).contiguous())
+        for k in ("states", "action"):
+            _eq(w.forward_inputs[k], g.forward_inputs[k].contiguous())
+    want = m.types.convert_trajectories_to_batch(want_trajs)
+    got = mine.convert_trajectories_to_batch(got_trajs)
+    for n in names:
+        _eq(want[n], got[n].contiguous())
+    assert got["prev_values"].shape[0] == T + 1 and got["rewards"].shape[0] == T and not got["dones"][0].any()
+    batch = L.rollout(pol, env, eps, 0.8, auto_reset=False)  # no bootstrap term: rewards are the env's
+    for n in ("rewards", "dones", "prev_values", "prev_logprobs"):
+        _eq(batch[n], got[n].contiguous())
+    _eq(batch["forward_inputs"]["states"], got["forward_inputs"]["states"].contiguous())
+
+
 @pytest.mark.parametrize("warmup", [False, True])
 def test_build_optimizer_groups(ref, warmup):
     """FSDPModelManager.build_optimizer (fsdp_model_manager.py:501-590), the method compiled on its own with a stand-in
