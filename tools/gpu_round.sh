@@ -18,3 +18,5 @@ timeout 600 python tools/bench_token.py --tokens 8192 --vocab 151936 --dtype bf1
 timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log
 timeout 600 python bench.py --precision 32 --no-cpu-baseline --no-roofline > gpurun_out/bench_f32.log 2>&1; tail -1 gpurun_out/bench_f32.log | cut -c1-300
 timeout 600 python bench.py --no-graph --no-cpu-baseline --no-roofline > gpurun_out/bench_nograph.log 2>&1; tail -1 gpurun_out/bench_nograph.log | cut -c1-300
+timeout 300 python tools/bench_widening.py > gpurun_out/widening_bench.jsonl 2>/dev/null; cat gpurun_out/widening_bench.jsonl
+timeout 300 python tools/bench_bucket.py > gpurun_out/bucket_bench.jsonl 2>/dev/null; tail -4 gpurun_out/bucket_bench.jsonl
