@@ -129,7 +129,7 @@ def pipeline_permutation(T: int, B: int, stage_num: int, generator: torch.Genera
 
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
            value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0,
-           perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0):
+           perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None):
     T, B = batch["prev_logprobs"].shape[:2]
     if perm is None:
         perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
@@ -142,9 +142,10 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
             m = O.ppo_minibatch_step(
                 policy, opt, dict(states=mb["forward_inputs"]["states"], action=mb["forward_inputs"]["action"],
                                   prev_logprobs=mb["prev_logprobs"], advantages=mb["advantages"],
-                                  prev_values=mb["prev_values"], returns=mb["returns"], loss_mask=mb.get("loss_mask")),
+                                  prev_values=mb["prev_values"], returns=mb["returns"], loss_mask=mb.get("loss_mask"),
+                                  loss_mask_sum=mb.get("loss_mask_sum")),
                 clip_low=clip_low, clip_high=clip_high, value_clip=value_clip, huber_delta=huber_delta,
-                clip_grad=clip_grad, action_dim=policy.action_dim, entropy_bonus=entropy_bonus,
+                clip_grad=clip_grad, action_dim=policy.action_dim, entropy_bonus=entropy_bonus, max_episode_steps=max_episode_steps,
                 critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
             metrics.append(m)
             steps += 1

@@ -454,15 +454,18 @@ def build_adamw(policy: nn.Module, lr=3e-4, value_lr=3e-4, betas=(0.9, 0.999), e
 
 def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, value_clip=1.0,
                        huber_delta=10.0, entropy_bonus=0.0, clip_grad=0.5, action_dim=8,
-                       logprob_type="action_level", critic_warmup=False):
-    """forward -> actor_critic loss -> backward -> clip_grad_norm_ -> AdamW (skipped if norm non-finite)."""
+                       logprob_type="action_level", critic_warmup=False, max_episode_steps=None):
+    """forward -> actor_critic loss -> backward -> clip_grad_norm_ -> AdamW (skipped if norm non-finite).
+    ``loss_mask_sum`` + ``max_episode_steps`` (both present when auto_reset is off) switch the aggregation to
+    masked_mean_ratio, as train_micro_batch's loss_kwargs do (embodied_fsdp_actor_worker.py:641-662, losses.py:219-227)."""
     opt.zero_grad()
     out = policy.evaluate(mb["states"], mb["action"])
     shaped = shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type,
-                               action_dim, loss_mask=mb.get("loss_mask"), values=out["values"],
-                               prev_values=mb["prev_values"], returns=mb["returns"])
+                               action_dim, loss_mask=mb.get("loss_mask"), loss_mask_sum=mb.get("loss_mask_sum"),
+                               values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
     loss, metrics = ppo_actor_critic_loss(clip_ratio_low=clip_low, clip_ratio_high=clip_high, critic_warmup=critic_warmup,
-                                          value_clip=value_clip, huber_delta=huber_delta, **shaped)
+                                          value_clip=value_clip, huber_delta=huber_delta, max_episode_steps=max_episode_steps,
+                                          **shaped)
     if entropy_bonus > 0 and not critic_warmup:  # embodied_fsdp_actor_worker.py:680
         ent = out["entropy"].reshape(out["logprobs"].shape[0], -1, action_dim).sum(dim=-1)
         ent_loss = masked_mean(ent, shaped["loss_mask"])

@@ -1,0 +1,141 @@
+"""The oracle's UPDATE LOOP against the reference's own learner methods, executed on CPU.
+
+rlinf/workers/actor/embodied_fsdp_actor_worker.py cannot be imported here (Ray, FSDP, hydra), so `run_training` (:483-589),
+`train_micro_batch` (:591-700) and `FSDPModelManager.optimizer_step` / `build_optimizer`
+(rlinf/hybrid_engines/fsdp/fsdp_model_manager.py:429-463,501-590) are compiled from their source on their own and run as
+plain functions over a stand-in ``self`` that supplies what FSDP would: the REAL reference MLPPolicy as ``model``, a
+pass-through gradient scaler, ``clip_grad_norm_`` = torch's (the no_shard branch, strategy/fsdp.py:363-369), no-op device
+moves.  Everything that computes -- shuffling, chunking, policy_loss, entropy bonus, accumulation, clipping, AdamW, critic
+warm-up with its optimizer rebuild, metric averaging -- is the reference's code.  oracle.ppo_loop.update must land on the same
+parameters and the same metrics: the GPU end-to-end tests compare the HIP learner with that oracle loop.
+"""
+
+import contextlib
+import copy
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import ppo_loop as L
+from oracle import ppo_oracle as O
+
+pytestmark = pytest.mark.reference
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _learner(ref, policy, batch, *, global_batch, micro_batch, update_epoch, entropy_bonus, critic_warmup_steps, auto_reset):
+    from oracle import reference_loader as R
+    mu, utils, nested = ref.metric_utils, ref.utils, ref.nested
+    worker_stub = SimpleNamespace(torch_device_type="cpu", timer=lambda *_a, **_k: (lambda f: f),
+                                  torch_platform=SimpleNamespace(current_device=lambda: torch.device("cpu"), is_available=lambda: False))
+    models = SimpleNamespace(OPENVLA="openvla", OPENVLA_OFT="openvla_oft", GR00T="gr00t", GR00T_N1D6="gr00t_n1d6",
+                             GR00T_N1D7="gr00t_n1d7", ABOT_M0="abot_m0")
+    supported = type("SupportedModel", (), {"__new__": staticmethod(lambda cls, name: name), **vars(models)})
+    actor_py = "rlinf/workers/actor/embodied_fsdp_actor_worker.py"
+    manager_py = "rlinf/hybrid_engines/fsdp/fsdp_model_manager.py"
+    run_training = R.load_function(
+        actor_py, "EmbodiedFSDPActor.run_training", torch=torch, np=np, process_nested_dict_for_train=nested.process_nested_dict_for_train,
+        split_dict_to_chunk=nested.split_dict_to_chunk, append_to_dict=mu.append_to_dict, clear_memory=lambda: None,
+        pop_critic_explained_variance_stats=mu.pop_critic_explained_variance_stats, all_reduce_dict=lambda d, op=None: d,
+        compute_critic_explained_variance_from_stats=mu.compute_critic_explained_variance_from_stats,
+        CRITIC_EXPLAINED_VARIANCE_KEY=mu.CRITIC_EXPLAINED_VARIANCE_KEY)
+    train_micro_batch = R.load_function(
+        actor_py, "EmbodiedFSDPActor.train_micro_batch", torch=torch, put_tensor_device=lambda d, _dev: d, SupportedModel=supported,
+        policy_loss=ref.registry.policy_loss, Worker=worker_stub, reshape_entropy=utils.reshape_entropy, masked_mean=utils.masked_mean,
+        append_to_dict=mu.append_to_dict)
+    optimizer_step = R.load_function(manager_py, "FSDPModelManager.optimizer_step", torch=torch)
+    build_optimizer = R.load_function(manager_py, "FSDPModelManager.build_optimizer", torch=torch, Worker=worker_stub,
+                                      warmup_optimizer_state=utils.warmup_optimizer_state)
+    optim = Cfg(lr=3e-4, value_lr=3e-4, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, weight_decay=0.01, clip_grad=0.5,
+                critic_warmup_steps=critic_warmup_steps)
+    alg = Cfg(loss_type="actor_critic", logprob_type="action_level", reward_type="action_level", entropy_type="action_level",
+              adv_type="gae", entropy_bonus=entropy_bonus, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0, huber_delta=10.0,
+              update_epoch=update_epoch)
+    cfg = Cfg(algorithm=alg, runner=Cfg(task_type="embodied"), env=Cfg(train=Cfg(max_episode_steps=5, auto_reset=auto_reset)),
+              rollout=Cfg(), actor=Cfg(seed=1234, global_batch_size=global_batch, micro_batch_size=micro_batch, optim=optim,
+                                       model=Cfg(model_type="mlp_policy", action_dim=8)))
+    me = SimpleNamespace(
+        cfg=cfg, _cfg=Cfg(optim=optim, fsdp_config={"sharding_strategy": "no_shard"}), model=policy, rollout_batch=batch, _rank=0,
+        _world_size=1, device="cpu", is_weight_offloaded=False, is_optimizer_offloaded=False, enable_sft_co_train=False,
+        gradient_accumulation=global_batch // micro_batch, optimizer_steps=0, critic_warmup_steps=critic_warmup_steps,
+        amp_context=contextlib.nullcontext(), before_micro_batch=lambda *_a, **_k: contextlib.nullcontext(),
+        torch_platform=SimpleNamespace(empty_cache=lambda: None), store_requires_grad_param_name=[],
+        _logger=SimpleNamespace(info=lambda *a: None, warning=lambda *a: None),
+        grad_scaler=SimpleNamespace(scale=lambda loss: loss, unscale_=lambda _opt: None, update=lambda: None,
+                                    step=lambda optimizer: optimizer.step()),
+        _strategy=SimpleNamespace(clip_grad_norm_=lambda model: float(torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5, 2.0))),
+        lr_scheduler=SimpleNamespace(step=lambda: None), build_lr_scheduler=lambda **_k: SimpleNamespace(step=lambda: None))
+    me.build_optimizer = lambda model, enable_critic_warmup=False: build_optimizer(me, model, enable_critic_warmup)
+    me.optimizer = me.build_optimizer(policy, enable_critic_warmup=critic_warmup_steps > 0)  # fsdp_model_manager.py:304-306
+    me.optimizer_step = lambda: optimizer_step(me)
+    me.train_micro_batch = lambda micro_batch, metrics, is_last: train_micro_batch(me, micro_batch, metrics, is_last=is_last)
+    me.run_training = lambda: run_training(me)
+    return me
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29633", rank=0, world_size=1)
+    yield
+    if started:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [dict(global_batch=40, micro_batch=40), dict(global_batch=80, micro_batch=20),
+                                   dict(global_batch=40, micro_batch=40, entropy_bonus=0.01),
+                                   dict(global_batch=40, micro_batch=40, auto_reset=False),
+                                   dict(global_batch=40, micro_batch=20, critic_warmup_steps=5)])
+def test_update_loop_matches_the_reference_learner(ref, one_rank_group, shape):
+    T, B, epochs = 10, 16, 2
+    auto_reset = shape.get("auto_reset", True)
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    theirs = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+    ours = O.OracleMLPPolicy(42, 8, 1)
+    ours.load_state_dict(copy.deepcopy(theirs.state_dict()), strict=True)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    batch = L.advantages(L.rollout(ours, env, eps, 0.8, auto_reset), 0.8, 0.9, auto_reset)
+    cw = shape.get("critic_warmup_steps", 0)
+    me = _learner(ref, theirs, copy.deepcopy(batch), global_batch=shape["global_batch"], micro_batch=shape["micro_batch"],
+                  update_epoch=epochs, entropy_bonus=shape.get("entropy_bonus", 0.0), critic_warmup_steps=cw, auto_reset=auto_reset)
+    want = me.run_training()
+    opt = O.build_adamw(ours)
+    accum = shape["global_batch"] // shape["micro_batch"]
+    if accum == 1:
+        om = L.update(ours, opt, batch, seed=1234, global_batch=shape["global_batch"], update_epoch=epochs,
+                      entropy_bonus=shape.get("entropy_bonus", 0.0), critic_warmup_steps=cw, max_episode_steps=5)
+        steps = len(om)
+    else:  # gradient accumulation: the oracle's async loop has it; the loss here is the plain actor-critic one
+        steps = None
+    n_steps = (T * B // shape["global_batch"]) * epochs
+    assert me.optimizer_steps == n_steps
+    if steps is not None:
+        assert steps == n_steps
+        for (n, p), (_, q) in zip(theirs.named_parameters(), ours.named_parameters()):
+            assert torch.equal(p.detach(), q.detach()), n
+        mean = lambda k: float(np.mean([float(m[k]) for m in om]))  # noqa: E731
+        for k in ("actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "critic/value_loss", "actor/grad_norm",
+                  "actor/entropy_loss"):
+            if k in om[0]:
+                assert want[k] == pytest.approx(mean(k), rel=1e-6, abs=1e-9), k
+        assert want["actor/total_loss"] == pytest.approx(mean("actor/total_loss"), rel=1e-6, abs=1e-9)
+    else:
+        # accumulation: the same global batches cut into micro-batches must give (to rounding) the parameters of the
+        # un-accumulated run -- mean-of-means over equal micro-batches equals the mean over the global batch when no loss mask
+        # re-weights them
+        fresh = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+        fresh.load_state_dict(copy.deepcopy(ours.state_dict()), strict=True)  # `ours` still holds the initial weights
+        single = _learner(ref, fresh, copy.deepcopy(batch), global_batch=shape["global_batch"],
+                          micro_batch=shape["global_batch"], update_epoch=epochs, entropy_bonus=0.0, critic_warmup_steps=cw,
+                          auto_reset=auto_reset)
+        single.run_training()
+        for (n, p), (_, q) in zip(theirs.named_parameters(), single.model.named_parameters()):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-4, atol=2e-6, msg=n)
