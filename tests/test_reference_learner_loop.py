@@ -139,3 +139,76 @@ def test_update_loop_matches_the_reference_learner(ref, one_rank_group, shape):
         single.run_training()
         for (n, p), (_, q) in zip(theirs.named_parameters(), single.model.named_parameters()):
             torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-4, atol=2e-6, msg=n)
+
+
+class _TorchOnCpu:
+    """``torch`` as the async learner's module sees it, minus the two CUDA calls it makes (current_device / empty_cache)."""
+
+    cuda = SimpleNamespace(current_device=lambda: "cpu", empty_cache=lambda: None)
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+
+@pytest.mark.parametrize("shape", [dict(global_batch=40, micro_batch=40), dict(global_batch=80, micro_batch=20, entropy_bonus=0.01),
+                                   dict(global_batch=40, micro_batch=20, auto_reset=False),
+                                   dict(global_batch=80, micro_batch=40, stale=True, threshold=1.02)])
+def test_async_update_loop_matches_the_reference_learner(ref, one_rank_group, shape, monkeypatch):
+    """AsyncPPOEmbodiedFSDPActor.run_training (async_ppo_fsdp_worker.py:274-497) compiled on its own over the stand-in learner
+    above (real MLPPolicy, real policy_loss / masked_normalization / optimizer_step): oracle.ppo_loop.async_update -- what the
+    HIP async learner is compared with on the GPU -- must reproduce its parameters and metrics, with gradient accumulation,
+    entropy bonus, a loss mask (ratio aggregation), mixed policy versions and a behaviour-weight threshold."""
+    import os
+    from typing import Any
+
+    from oracle import reference_loader as R
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)  # masked_normalization moves its inputs
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    du = R.load_distributed_utils()
+    T, B, epochs = 10, 16, 2
+    auto_reset = shape.get("auto_reset", True)
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    theirs = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+    ours = O.OracleMLPPolicy(42, 8, 1)
+    ours.load_state_dict(copy.deepcopy(theirs.state_dict()), strict=True)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    batch = L.advantages(L.rollout(ours, env, eps, 0.8, auto_reset), 0.8, 0.9, auto_reset)
+    batch["versions"] = torch.full_like(batch["prev_logprobs"], 3.0)
+    if shape.get("stale"):
+        batch["versions"][: T // 2] = 1.0
+        batch["prev_logprobs"] = batch["prev_logprobs"] + 0.05 * torch.randn(T, B, 8, generator=torch.Generator().manual_seed(7))
+    thr = shape.get("threshold")
+    me = _learner(ref, theirs, copy.deepcopy(batch), global_batch=shape["global_batch"], micro_batch=shape["micro_batch"],
+                  update_epoch=epochs, entropy_bonus=shape.get("entropy_bonus", 0.0), critic_warmup_steps=0, auto_reset=auto_reset)
+    me.cfg.algorithm.update(loss_type="decoupled_actor_critic", normalize_advantages=True, **({"behave_weight_threshold": thr} if thr else {}))
+    me.version = 3
+    flatten = R.load_function("rlinf/workers/actor/async_ppo_fsdp_worker.py", "flatten_rollout_batch_for_train", torch=torch,
+                              Optional=__import__("typing").Optional)
+    models = SimpleNamespace(OPENVLA="openvla", OPENVLA_OFT="openvla_oft", GR00T="gr00t", ABOT_M0="abot_m0")
+    supported = type("SupportedModel", (), {"__new__": staticmethod(lambda cls, name: name), **vars(models)})
+    mu, utils = ref.metric_utils, ref.utils
+    run_training = R.load_function(
+        "rlinf/workers/actor/async_ppo_fsdp_worker.py", "AsyncPPOEmbodiedFSDPActor.run_training", torch=_TorchOnCpu(), np=np, os=os,
+        Any=Any, flatten_rollout_batch_for_train=flatten, masked_normalization=du.masked_normalization,
+        split_dict_to_chunk=ref.nested.split_dict_to_chunk, put_tensor_device=lambda d, _dev: d, SupportedModel=supported,
+        policy_loss=ref.registry.policy_loss, reshape_entropy=utils.reshape_entropy, masked_mean=utils.masked_mean,
+        append_to_dict=mu.append_to_dict, clear_memory=lambda: None, all_reduce_dict=lambda d, op=None: d,
+        pop_critic_explained_variance_stats=mu.pop_critic_explained_variance_stats,
+        compute_critic_explained_variance_from_stats=mu.compute_critic_explained_variance_from_stats,
+        CRITIC_EXPLAINED_VARIANCE_KEY=mu.CRITIC_EXPLAINED_VARIANCE_KEY)
+    want = run_training(me)
+    opt = O.build_adamw(ours)
+    om, norms = L.async_update(ours, opt, batch, seed=1234, global_batch=shape["global_batch"], micro_batch=shape["micro_batch"],
+                               update_epoch=epochs, version=3, entropy_bonus=shape.get("entropy_bonus", 0.0),
+                               behave_weight_threshold=thr, max_episode_steps=5)
+    assert me.optimizer_steps == len(norms) == (T * B // shape["global_batch"]) * epochs
+    for (n, p), (_, q) in zip(theirs.named_parameters(), ours.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), n
+    mean = lambda k: float(np.mean([float(m[k]) for m in om if k in m]))  # noqa: E731
+    for k in ("actor/policy_loss", "actor/proximal_ratio", "actor/clipped_proximal_ratio", "actor/clip_fraction",
+              "actor/dual_clip_fraction", "actor/behav_clip_fraction", "actor/proximal_approx_kl", "actor/behav_approx_kl",
+              "actor/average_version", "actor/current_version", "critic/value_loss", "critic/value_clip_ratio",
+              "actor/entropy_loss", "actor/total_loss"):
+        assert want[k] == pytest.approx(mean(k), rel=1e-6, abs=1e-9), k
+    assert want["actor/grad_norm"] == pytest.approx(float(np.mean(norms)), rel=1e-6)
