@@ -212,3 +212,69 @@ def test_async_update_loop_matches_the_reference_learner(ref, one_rank_group, sh
               "actor/entropy_loss", "actor/total_loss"):
         assert want[k] == pytest.approx(mean(k), rel=1e-6, abs=1e-9), k
     assert want["actor/grad_norm"] == pytest.approx(float(np.mean(norms)), rel=1e-6)
+
+
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_pipeline_data_path_matches_the_reference_env_worker(ref, auto_reset):
+    """runner.use_training_pipeline: EnvWorker.send_rollout_trajectories_pipeline with prepare_pipeline_batch,
+    compute_advantages_and_returns and pack_pipeline_micro_batches (env_worker.py:1469-1600), compiled on their own and run
+    over REAL EmbodiedTrajectoryBuilders (one per stage) -- un-normalised GAE per stage batch, (count, sum, sumsq) summed
+    over the stages of the rank, normalisation from those, per-stage stateful shuffles, micro-batches in channel order --
+    against oracle.ppo_loop.pipeline_advantages + pipeline_permutation, which the HIP pipeline path is compared with."""
+    import asyncio
+    from collections import defaultdict
+
+    from oracle import reference_loader as R
+    m = R.load_trajectory_builder()
+    du = R.load_distributed_utils()
+    env_py = "rlinf/workers/env/env_worker.py"
+    T, B, stages, micro = 10, 16, 2, 20
+    n = B // stages
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    pol = O.OracleMLPPolicy(42, 8, 1)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    raw = L.rollout(pol, env, eps, 0.8, auto_reset)
+    # the reference's per-stage builders, filled with the rows of the rank's buffer that belong to the stage (SURVEY A.1 order)
+    builders = []
+    for st in range(stages):
+        sl = slice(st * n, (st + 1) * n)
+        b = m.builder.EmbodiedTrajectoryBuilder(max_episode_length=5)
+        for t in range(T + 1):
+            fields = dict(dones=raw["dones"][t, sl].clone(), terminations=raw["dones"][t, sl].clone(),
+                          truncations=torch.zeros(n, 1, dtype=torch.bool), rewards=None if t == 0 else raw["rewards"][t - 1, sl].clone(),
+                          prev_values=raw["prev_values"][t, sl].clone())
+            if t < T:
+                fields.update(actions=raw["forward_inputs"]["action"][t, sl].clone(), prev_logprobs=raw["prev_logprobs"][t, sl].clone(),
+                              forward_inputs={"states": raw["forward_inputs"]["states"][t, sl].clone(),
+                                              "action": raw["forward_inputs"]["action"][t, sl].clone()})
+            b.append_step_result(m.types.ChunkStepResult(**fields))
+        builders.append(b)
+    alg = Cfg(adv_type="gae", gamma=0.8, gae_lambda=0.9, group_size=1, reward_type="action_level", normalize_advantages=True)
+    cfg = Cfg(algorithm=alg, runner=Cfg(task_type="embodied"), env=Cfg(train=Cfg(auto_reset=auto_reset, ignore_terminations=False)),
+              actor=Cfg(micro_batch_size=micro, model=Cfg(num_action_chunks=1)))
+    sent = []
+    me = SimpleNamespace(cfg=cfg, use_training_pipeline=True, shuffle_rollout=True, _rank=0, _group_name="env",
+                         shuffle_generators={0: torch.Generator().manual_seed(1234)}, pipeline_actor_env_ranks={0: [0]},
+                         pipeline_actor_keys={0: "actor0"}, pipeline_stage_actor_splits={st: [(0, n)] for st in range(stages)},
+                         worker_timer=lambda *_a: contextlib.nullcontext(), broadcast=lambda obj, groups=None, src=None: obj)
+    bind = lambda name, **g: (lambda f: (lambda *a, **k: f(me, *a, **k)))(R.load_function(env_py, f"EnvWorker.{name}", torch=torch, **g))  # noqa: E731
+    me.compute_advantages_and_returns = bind("compute_advantages_and_returns", calculate_adv_and_returns=ref.registry.calculate_adv_and_returns)
+    me.prepare_pipeline_batch = bind("prepare_pipeline_batch", convert_trajectories_to_batch=m.types.convert_trajectories_to_batch,
+                                     preprocess_embodied_batch=ref.utils.preprocess_embodied_batch)
+    me.pack_pipeline_micro_batches = bind("pack_pipeline_micro_batches", flatten_embodied_batch=ref.utils.flatten_embodied_batch,
+                                          pack_batch=ref.utils.pack_batch, split_dict_to_chunk=ref.nested.split_dict_to_chunk)
+    send = bind("send_rollout_trajectories_pipeline", defaultdict=defaultdict, masked_stats=du.masked_stats,
+                normalize_from_stats=du.normalize_from_stats)
+    channel = SimpleNamespace(put=lambda item, key=None, async_op=False: sent.append((key, item)))
+    asyncio.run(send(builders, channel))
+    assert [k for k, _ in sent] == ["actor0"] * (T * B // micro)
+    # the oracle: one pass over the rank's whole [T, B] buffer, then the per-stage permutation
+    batch = L.pipeline_advantages(raw, 0.8, 0.9, auto_reset)
+    perm = L.pipeline_permutation(T, B, stages, torch.Generator().manual_seed(1234))
+    flat = O.flatten_and_shuffle(batch, perm)
+    keys = ["advantages", "returns", "prev_logprobs", "prev_values", "rewards", "dones"] + ([] if auto_reset else ["loss_mask", "loss_mask_sum"])
+    for k in keys:
+        got = torch.cat([item[k] for _, item in sent])
+        assert got.shape == flat[k].shape and torch.equal(got, flat[k]), k
+    assert torch.equal(torch.cat([item["forward_inputs::states"] for _, item in sent]), flat["forward_inputs"]["states"])
