@@ -210,7 +210,7 @@ def async_update(policy, opt, batch: dict, *, seed: int, global_batch: int, micr
 
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
               max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0,
-              pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0):
+              pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None):
     """``pipeline`` = dict(stage_num=..., generator=<the rank's stateful shuffle generator>) selects
     runner.use_training_pipeline's data path: global-statistics normalisation, per-stage shuffles, and -- every
     micro-batch being available at once here -- the epoch-major schedule PipelineEmbodiedFSDPActor.run_training reduces
@@ -229,7 +229,7 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     t2 = time.perf_counter()
     metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
                      max_steps=max_update_steps, entropy_bonus=entropy_bonus, perm=perm,
-                     critic_warmup_steps=critic_warmup_steps, steps_done=steps_done)
+                     critic_warmup_steps=critic_warmup_steps, steps_done=steps_done, max_episode_steps=max_episode_steps)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))

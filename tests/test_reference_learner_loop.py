@@ -278,3 +278,65 @@ def test_pipeline_data_path_matches_the_reference_env_worker(ref, auto_reset):
         got = torch.cat([item[k] for _, item in sent])
         assert got.shape == flat[k].shape and torch.equal(got, flat[k]), k
     assert torch.equal(torch.cat([item["forward_inputs::states"] for _, item in sent]), flat["forward_inputs"]["states"])
+
+
+@pytest.mark.parametrize("auto_reset,rollout_epoch", [(True, 1), (False, 1), (True, 2)])
+def test_whole_iteration_matches_the_reference_learner(ref, one_rank_group, auto_reset, rollout_epoch, monkeypatch):
+    """One whole learner iteration by the reference's own methods: _process_received_rollout_batch (epoch fold, loss mask) ->
+    compute_advantages_and_returns (+ compute_rollout_metrics) -> run_training, fed from real trajectory builders; against
+    oracle.ppo_loop.iteration on the same rollout -- batch tensors, rollout metrics and final parameters."""
+    import sys
+    import types
+
+    from oracle import reference_loader as R
+    m = R.load_trajectory_builder()
+    wmod = types.ModuleType("rlinf.scheduler.worker.worker")
+    wmod.Worker = SimpleNamespace(torch_platform=SimpleNamespace(current_device=lambda: torch.device("cpu")))
+    monkeypatch.setitem(sys.modules, "rlinf.scheduler.worker", types.ModuleType("rlinf.scheduler.worker"))
+    monkeypatch.setitem(sys.modules, "rlinf.scheduler.worker.worker", wmod)
+    T, B, E, GB = 10, 8, rollout_epoch, 40
+    env = L.synthetic_env_tensors(0, T * E, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    theirs = ref.mlp_policy.MLPPolicy(42, 8, 1, True, False)
+    ours = O.OracleMLPPolicy(42, 8, 1)
+    ours.load_state_dict(copy.deepcopy(theirs.state_dict()), strict=True)
+    eps = torch.randn(T * E, B, 8, generator=torch.Generator().manual_seed(100))
+    # what the env worker appends: E epochs of (bootstrap row, T step rows, closing row) stacked on the time axis
+    builder = m.builder.EmbodiedTrajectoryBuilder(max_episode_length=5)
+    for e in range(E):
+        sl = dict(obs=env["obs"][e * T:(e + 1) * T + 1], final_obs=env["final_obs"][e * T:(e + 1) * T],
+                  rewards=env["rewards"][e * T:(e + 1) * T], dones=env["dones"][e * T:(e + 1) * T + 1])
+        raw = L.rollout(ours, sl, eps[e * T:(e + 1) * T], 0.8, auto_reset)
+        for t in range(T + 1):
+            fields = dict(dones=raw["dones"][t].clone(), terminations=raw["dones"][t].clone(), truncations=torch.zeros(B, 1, dtype=torch.bool),
+                          rewards=None if t == 0 else raw["rewards"][t - 1].clone(), prev_values=raw["prev_values"][t].clone())
+            if t < T:
+                fields.update(actions=raw["forward_inputs"]["action"][t].clone(), prev_logprobs=raw["prev_logprobs"][t].clone(),
+                              forward_inputs={k: v[t].clone() for k, v in raw["forward_inputs"].items()})
+            builder.append_step_result(m.types.ChunkStepResult(**fields))
+    me = _learner(ref, theirs, None, global_batch=GB, micro_batch=GB, update_epoch=2, entropy_bonus=0.0, critic_warmup_steps=0,
+                  auto_reset=auto_reset)
+    me.cfg.env.train.update(rollout_epoch=E, ignore_terminations=False)
+    me.cfg.algorithm.update(gamma=0.8, gae_lambda=0.9, group_size=1)
+    me.cfg.actor.model.update(num_action_chunks=1)
+    actor_py = "rlinf/workers/actor/embodied_fsdp_actor_worker.py"
+    process = R.load_function(actor_py, "EmbodiedFSDPActor._process_received_rollout_batch", torch=torch,
+                              process_nested_dict_for_adv=ref.nested.process_nested_dict_for_adv,
+                              compute_loss_mask=ref.metric_utils.compute_loss_mask)
+    compute_adv = R.load_function(actor_py, "EmbodiedFSDPActor.compute_advantages_and_returns", torch=torch,
+                                  calculate_adv_and_returns=ref.registry.calculate_adv_and_returns,
+                                  compute_rollout_metrics=ref.metric_utils.compute_rollout_metrics)
+    me.rollout_batch = process(me, m.types.convert_trajectories_to_batch([builder.to_trajectory()]))
+    want_rollout_metrics = compute_adv(me)
+    want_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in me.rollout_batch.items()}
+    want_train = me.run_training()
+    opt = O.build_adamw(ours)
+    batch, om = L.iteration(ours, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234, global_batch=GB, update_epoch=2,
+                            auto_reset=auto_reset, rollout_epoch=E, max_episode_steps=5)
+    for k in ("rewards", "dones", "prev_values", "prev_logprobs", "advantages", "returns") + (() if auto_reset else ("loss_mask", "loss_mask_sum")):
+        assert want_batch[k].shape == batch[k].shape and torch.equal(want_batch[k], batch[k]), k
+    assert want_rollout_metrics["rewards"] == pytest.approx(float(batch["rewards"][batch["loss_mask"]].mean() if not auto_reset
+                                                                  else batch["rewards"].mean()), rel=1e-6)
+    for (n, p), (_, q) in zip(theirs.named_parameters(), ours.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), n
+    assert want_train["actor/total_loss"] == pytest.approx(float(np.mean([float(x["actor/total_loss"]) for x in om])), rel=1e-6)
