@@ -340,3 +340,85 @@ def test_whole_iteration_matches_the_reference_learner(ref, one_rank_group, auto
     for (n, p), (_, q) in zip(theirs.named_parameters(), ours.named_parameters()):
         assert torch.equal(p.detach(), q.detach()), n
     assert want_train["actor/total_loss"] == pytest.approx(float(np.mean([float(x["actor/total_loss"]) for x in om])), rel=1e-6)
+
+
+@pytest.mark.parametrize("case", [dict(loss_agg="token-mean", temperature=1.0), dict(loss_agg="seq-mean-token-sum", temperature=0.7, entropy_bonus=0.01),
+                                  dict(loss_agg="seq-mean-token-mean", temperature=1.3, kl_beta=0.05, kl="low_var_kl"),
+                                  dict(loss_agg="token-mean", temperature=1.0, dtype=torch.bfloat16, entropy_bonus=0.02, kl_beta=0.1, kl="k2")])
+def test_reasoning_training_step_matches_the_reference_learner(ref, one_rank_group, case):
+    """FSDPActor.training_step + forward_batch (fsdp_actor_worker.py:434-505,659-813), compiled on their own; the model is a
+    stand-in that returns given logits (the transformer is out of this path), two micro-batches of gradient accumulation:
+    d(loss)/d(logits) and the step's metrics against oracle.token_oracle.reasoning_micro_batch_loss, which the HIP token
+    kernels are compared with."""
+    from oracle import reference_loader as R
+    from oracle import token_oracle as TO
+    from oracle.make_golden import token_batch
+    bsz, resp, prompt, vocab = 8, 12, 5, 37
+    dt = case.get("dtype", torch.float32)
+    b = token_batch(301, bsz, resp, vocab)
+    g = torch.Generator().manual_seed(9)
+    full_logits = (torch.randn(bsz, prompt + resp, vocab, generator=g) * 2).to(dt)
+    full_logits[:, -resp - 1:-1] = b["logits"].to(dt)  # the response window the learner slices out
+    input_ids = torch.randint(0, vocab, (bsz, prompt + resp), generator=g)
+    input_ids[:, -resp:] = b["labels"]
+    fwd_py = "rlinf/workers/actor/fsdp_actor_worker.py"
+    worker_stub = SimpleNamespace(torch_device_type="cpu", torch_platform=SimpleNamespace(current_device=lambda: torch.device("cpu")))
+
+    class Model(torch.nn.Module):
+        def __init__(self, logits):
+            super().__init__()
+            self.logits = torch.nn.Parameter(logits.clone())
+            self.cursor = 0
+
+        def forward(self, input_ids=None, **_kw):
+            n = input_ids.shape[0]
+            out = self.logits[self.cursor:self.cursor + n] * 1  # a non-leaf: the learner divides it by the temperature in place
+            self.cursor += n
+            return SimpleNamespace(logits=out)
+
+    model = Model(full_logits)
+    bonus, beta = case.get("entropy_bonus", 0.0), case.get("kl_beta", 0.0)
+    alg = Cfg(sampling_params=Cfg(temperature=case["temperature"]), ratio_clip_eps=0.2, clip_ratio_high=0.28, loss_type="actor",
+              entropy_bonus=bonus)
+    me = SimpleNamespace(
+        cfg=Cfg(algorithm=alg), model=model, response_len=resp, enable_dynamic_batch_size=False, variable_seq_lengths=False,
+        amp_context=contextlib.nullcontext(), before_micro_batch=lambda *_a, **_k: contextlib.nullcontext(), task_type="reasoning",
+        loss_agg_func=ref.utils.get_loss_agg_func(case["loss_agg"]), calculate_entropy=bonus > 0, calculate_entropy_loss=bonus > 0,
+        kl_beta=beta, kl_penalty_type=case.get("kl", "low_var_kl"), entropy_op_type="torch", micro_batch_size=4,
+        total_batch_size_per_dp=bsz, n_mini_batches=1, gradient_accumulation=None, lr_sched_sync_with_optim=False,
+        optimizer=SimpleNamespace(zero_grad=lambda: None), optimizer_step=lambda: (1.5, [1e-6]),
+        grad_scaler=SimpleNamespace(scale=lambda loss: loss))
+    me.compute_logprobs = lambda logits, target: ref.utils.compute_logprobs_from_logits(logits, target, op_type="torch")
+    forward_batch = R.load_function(fwd_py, "FSDPActor.forward_batch", torch=torch, Worker=worker_stub,
+                                    compute_entropy_from_logits=ref.utils.compute_entropy_from_logits)
+    me.forward_batch = lambda m_batch, calculate_entropy=False: forward_batch(me, m_batch, calculate_entropy)
+    mu = ref.metric_utils
+    training_step = R.load_function(
+        fwd_py, "FSDPActor.training_step", torch=torch, Worker=worker_stub, policy_loss=ref.registry.policy_loss,
+        kl_penalty=ref.algo_utils.kl_penalty, append_to_dict=mu.append_to_dict, compute_rollout_train_kl=lambda *_a: None,
+        pop_critic_explained_variance_stats=mu.pop_critic_explained_variance_stats, all_reduce_dict=lambda d, op=None: d,
+        compute_critic_explained_variance_from_stats=mu.compute_critic_explained_variance_from_stats,
+        CRITIC_EXPLAINED_VARIANCE_KEY=mu.CRITIC_EXPLAINED_VARIANCE_KEY, BatchResizingIterator=type("BatchResizingIterator", (), {}))
+    rows = lambda lo, hi: {"input_ids": input_ids[lo:hi], "attention_mask": torch.ones(hi - lo, prompt + resp, dtype=torch.bool),  # noqa: E731
+                           "position_ids": torch.arange(prompt + resp).expand(hi - lo, -1), "rollout_logprobs": b["old_logprobs"][lo:hi],
+                           "advantages": b["advantages"][lo:hi], "ref_logprobs": b["ref_logprobs"][lo:hi],
+                           "response_mask": torch.cat([torch.zeros(hi - lo, prompt, dtype=torch.bool), b["loss_mask"][lo:hi]], dim=1)}
+    want = training_step(me, iter([rows(0, 4), rows(4, 8)]))
+    want_grad = model.logits.grad[:, -resp - 1:-1].float()
+    assert not model.logits.grad[:, :-resp - 1].any() and not model.logits.grad[:, -1].any()
+    # the oracle, micro-batch by micro-batch on the response window
+    window = full_logits[:, -resp - 1:-1].clone().requires_grad_(True)
+    metrics = []
+    for lo, hi in ((0, 4), (4, 8)):
+        loss, mt, _, _ = TO.reasoning_micro_batch_loss(
+            window[lo:hi], b["labels"][lo:hi], b["old_logprobs"][lo:hi], b["advantages"][lo:hi], b["loss_mask"][lo:hi],
+            temperature=case["temperature"], loss_agg=case["loss_agg"], clip_ratio_low=0.2, clip_ratio_high=0.28, clip_ratio_c=3.0,
+            calculate_entropy=bonus > 0, entropy_bonus=bonus, ref_logprobs=b["ref_logprobs"][lo:hi], kl_beta=beta,
+            kl_penalty_type=case.get("kl", "low_var_kl"), gradient_accumulation=2)
+        loss.backward()
+        metrics.append(mt)
+    assert torch.equal(window.grad.float(), want_grad)
+    for k in ("actor/final_loss", "actor/entropy_loss", "actor/kl_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction"):
+        got = torch.mean(torch.stack([torch.as_tensor(mt[k], dtype=torch.float32) for mt in metrics]))
+        assert float(want[k]) == pytest.approx(float(got), rel=1e-6, abs=1e-9), k
+    assert want["actor/grad_norm"] == 1.5 and want["actor/lr"] == 1e-6
