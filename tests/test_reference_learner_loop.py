@@ -422,3 +422,42 @@ def test_reasoning_training_step_matches_the_reference_learner(ref, one_rank_gro
         got = torch.mean(torch.stack([torch.as_tensor(mt[k], dtype=torch.float32) for mt in metrics]))
         assert float(want[k]) == pytest.approx(float(got), rel=1e-6, abs=1e-9), k
     assert want["actor/grad_norm"] == 1.5 and want["actor/lr"] == 1e-6
+
+
+@pytest.mark.parametrize("do_sample,temperature,top_k", [(True, 1.0, -1), (True, 0.7, 50), (True, 1.6, 1), (False, 1.0, -1)])
+def test_discrete_action_head_matches_the_reference_model_method(ref, do_sample, temperature, top_k):
+    """OpenVLA-OFT's ``_discrete_prediction`` (openvla_oft_action_model.py:315-414) compiled on its own; the language model is
+    a stand-in that returns given logits.  Its own gather of the action positions, vocabulary window, temperature, top-k
+    warper, softmax, torch.multinomial and bin-centre lookup against oracle.token_oracle.categorical_sample (the K2 oracle the
+    HIP sampler is compared with), the multinomial draw reproduced from the same generator state."""
+    pytest.importorskip("transformers")
+    from transformers import TopKLogitsWarper
+
+    from oracle import reference_loader as R
+    from oracle import token_oracle as TO
+    fn = R.load_function("rlinf/models/embodiment/openvla_oft/official/openvla_oft_action_model.py",
+                         "OpenVLAOFTForRLActionPrediction._discrete_prediction", torch=torch, np=np, TopKLogitsWarper=TopKLogitsWarper)
+    B, A, C, bins, pad, vocab = 6, 7, 2, 256, 64, 1024
+    g = torch.Generator().manual_seed(3)
+    n_prefix = torch.tensor([3, 5, 4, 3, 6, 5])
+    seq = int(n_prefix.max()) + 2 + A * C + 4
+    logits = torch.randn(B, seq, vocab, generator=g) * 2
+    centers = np.linspace(-1, 1, bins - 1).astype(np.float32)
+    lm = lambda **_kw: SimpleNamespace(logits=logits, hidden_states=[torch.zeros(B, seq, 4)])  # noqa: E731
+    me = SimpleNamespace(language_model=lm, action_dim=A, num_action_chunks=C, vocab_size=vocab, bin_centers=centers,
+                         config=SimpleNamespace(n_action_bins=bins, pad_to_multiple_of=pad))
+    torch.manual_seed(7)
+    actions, processed, tokens, _ = fn(me, None, None, None, n_prefix, torch.full((B,), 2), do_sample=do_sample,
+                                       temperature=temperature, top_k=top_k)
+    # what the head is handed on this repo's path: the [B, A*C, bins] window of the same positions
+    pos = (n_prefix + 2).unsqueeze(1) + torch.arange(A * C).unsqueeze(0)
+    window = logits[torch.arange(B).unsqueeze(-1), pos][..., -bins - pad:-pad]
+    q = None
+    if do_sample:
+        torch.manual_seed(7)
+        q = torch.empty(B * A * C, bins).exponential_(1).view(B, A * C, bins)  # the draw torch.multinomial makes internally
+    tok, _, proc, act = TO.categorical_sample(window, q, temperature, top_k, bin_centers=torch.from_numpy(centers))
+    assert torch.equal(tok, tokens)
+    if do_sample:
+        assert torch.equal(proc, processed)
+    assert np.array_equal(act.reshape(-1, A).numpy(), actions)
