@@ -107,3 +107,78 @@ def test_syncer_argument_checks():
     s = PatchWeightSyncer()
     with pytest.raises(RuntimeError, match="Sender not initialized"):
         s.create_patch({}, 1)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("delta", [True, False])
+def test_full_protocol_reference_sender_to_reference_receiver_vs_oracle(delta, monkeypatch):
+    """The reference's whole handshake on CPU tensors -- receiver announces key order / shapes / dtypes, sender snapshots in
+    the receiver's dtypes, two syncs, PatchWeightSyncer.apply into an nn.Module holding bf16 copies -- next to the oracle's
+    create_patch / apply_patch on the same states: identical wire patches, identical receiver contents, identical versions."""
+    import asyncio
+
+    from oracle import reference_loader
+    if not reference_loader.available():
+        pytest.skip("reference tree not present")
+    m = reference_loader.load_weight_syncer()
+    import sys
+    # the same-device ("GPU snapshot") builder is chosen when snapshot_device names the worker's accelerator type; with that
+    # type set to "cuda" and an index-less device the snapshot lands wherever the sender's tensors live -- the CPU, here
+    monkeypatch.setattr(sys.modules["rlinf.scheduler"].Worker, "torch_device_type", "cuda")
+    before, after = patch_states(13)
+    names = list(before)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, state):
+            super().__init__()
+            for k, v in state.items():
+                self.register_buffer(k.replace(".", "_"), v.clone())
+
+    rename = {k: k.replace(".", "_") for k in before}
+    narrow = lambda v: v.to(torch.bfloat16) if v.dtype == torch.float32 else v  # noqa: E731
+    receiver_model = Holder({k: narrow(v) for k, v in before.items()})
+    sender_state = {rename[k]: v.clone() for k, v in before.items()}
+    tx = m.PatchWeightSyncer(snapshot_device="cuda", transport_device="cpu", delta_encoding=delta)
+    rx = m.PatchWeightSyncer(snapshot_device="cuda", transport_device="cpu", delta_encoding=delta)
+    wire = []
+
+    async def run():
+        box = []
+
+        async def to_sender(meta):
+            box.append(meta)
+
+        async def from_receiver():
+            return box[0]
+
+        async def to_receiver(payload):
+            wire.append(payload)
+
+        async def from_sender():
+            return wire[-1]
+
+        await rx.init_receiver(receiver_model.state_dict(), from_sender, to_sender)
+        await tx.init_sender(sender_state, [rename[k] for k in names], to_receiver, from_receiver)
+        assert type(tx.patch_builder).__name__ == "GPUSnapshotPatchBuilder"
+        monkeypatch.setattr(sys.modules["rlinf.scheduler"].Worker, "torch_device_type", "cpu")  # create_patch checks the tensors' device
+        versions = []
+        for version, state in ((5, after), (6, after)):
+            await tx.sync({rename[k]: v.clone() for k, v in state.items()}, to_receiver, version)
+            versions.append(await rx.apply(receiver_model, from_sender))
+        return versions
+
+    assert asyncio.run(run()) == [5, 6]
+    keys = [rename[k] for k in names]
+    snap = {rename[k]: PO.coo_2d_view(narrow(v)).clone() for k, v in before.items()}
+    target = {rename[k]: narrow(v).clone() for k, v in before.items()}
+    for version, payload in zip((5, 6), wire):
+        got = PO.create_patch({rename[k]: v for k, v in after.items()}, snap, keys, keys, version, delta)
+        for f in FIELDS:
+            a = getattr(payload, f)
+            assert a.dtype == got[f].dtype and torch.equal(a, got[f]), (version, f)
+        assert PO.apply_patch(target, keys, got, delta) == version
+    for k in names:
+        have = receiver_model.state_dict()[rename[k]]
+        want = target[rename[k]]
+        same = (have == want) | ((have != have) & (want != want)) if want.is_floating_point() else have == want
+        assert have.dtype == want.dtype and bool(same.all()), k
