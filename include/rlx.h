@@ -252,10 +252,11 @@ int rlx_gather_rows(const rlx_gather_field* fields, int n_fields, const int64_t*
 struct rlx_mlp_layout; /* below */
 typedef struct rlx_adamw_group {
     int64_t begin, end; /* element range */
-    float lr;
+    double lr;          /* double like torch's python scalars: the kernel forms lr / bias_correction1 and 1 - lr * wd in double */
 } rlx_adamw_group;
 typedef struct rlx_adamw_params {
-    float beta1, beta2, eps, weight_decay, max_grad_norm; /* max_grad_norm <= 0: no clipping */
+    double beta1, beta2, eps, weight_decay; /* doubles: 1 - beta ** step is formed in double from the exact python values */
+    float max_grad_norm;     /* <= 0: no clipping */
     int32_t step;            /* 1-based step count of THIS update */
     int32_t n_groups;
     int32_t grad_partials;   /* >= 1 */

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RLX_LIB_TAG=<tag>: load librlx_hip_<tag>.so, a variant build of the same sources (see csrc/build.py); dev sweeps only
@@ -52,7 +52,7 @@ ADAMW_MAX_GROUPS = 8
 
 
 class AdamwGroup(Structure):
-    _fields_ = [("begin", c_int64), ("end", c_int64), ("lr", c_float)]
+    _fields_ = [("begin", c_int64), ("end", c_int64), ("lr", c_double)]
 
 
 class CopySegment(Structure):  # rlx_copy_segment
@@ -70,7 +70,7 @@ class MlpLayout(Structure):
 
 class AdamwParams(Structure):
     _fields_ = [
-        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
+        ("beta1", c_double), ("beta2", c_double), ("eps", c_double), ("weight_decay", c_double),
         ("max_grad_norm", c_float), ("step", c_int32), ("n_groups", c_int32), ("grad_partials", c_int32),
         ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
         ("tile_layout", POINTER(MlpLayout)), ("tiles", c_void_p), ("tiles_bf16", c_int32),

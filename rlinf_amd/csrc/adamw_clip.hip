@@ -5,8 +5,8 @@
 //   + torch.optim.AdamW.step with the actor / value_head parameter groups (fsdp_model_manager.py:501-590),
 //   including "skip the step when the norm is non-finite".
 // Two launches per optimizer step: (1) sum the split-K gradient slabs, scale, write the reduced gradient
-// and per-block sum-of-squares partials; (2) every block re-reduces the (<= 1024) partials, derives the
-// clip coefficient and applies clip + AdamW to its slice.  HBM-bound: 28 B per parameter (+4 B per extra
+// and per-block sum-of-squares partials (one thread also forms the step's scalars in double); (2) every block
+// re-reduces the (<= 1024) partials, derives the clip coefficient and applies clip + AdamW to its float4 slice.  HBM-bound: 28 B per parameter (+4 B per extra
 // gradient slab); at 287 504 parameters it is launch-latency bound, which is why it is only two launches.
 // (A single persistent launch around a device-wide barrier was measured: 33-49 us against 7 + 11 us here -- on an 8-XCD part
 // the arrivals are serialised same-address device-scope atomics and every poll crosses to the memory-side coherence point.)
@@ -23,12 +23,23 @@ constexpr int kMaxParts = 1024;
 // state (device, int32[2]): [0] = optimizer steps applied so far, [1] = "the previous call applied a step"
 // (folded into [0] here, i.e. strictly after that call's update kernel and before this call's), so that a
 // captured hipGraph can be replayed without host-side step bookkeeping.
+struct AdamScalars;
+__device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step, AdamScalars* sc);
+
 __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ grads, long long n, int nslab, float scale,
-                                                          double* __restrict__ partials, int* __restrict__ state) {
+                                                          double* __restrict__ partials, int* __restrict__ state,
+                                                          rlx_adamw_params a, AdamScalars* __restrict__ scalars) {
     __shared__ double s_red[4];
-    if (state != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && state[1] != 0) {
-        state[0] += 1;
-        state[1] = 0;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {  // the last block has the shortest (or no) slice
+        int step = a.step;
+        if (state != nullptr) {
+            if (state[1] != 0) {
+                state[0] += 1;
+                state[1] = 0;
+            }
+            step = state[0] + 1;
+        }
+        form_scalars(a, step, scalars);
     }
     double acc[1] = {0.0};
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -107,17 +118,78 @@ __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* _
     }
 }
 
+// Per-step scalars of the update, formed ONCE (block 0 of grad_reduce_sqnorm, overlapped with the slab sums) in double like
+// torch's python scalars -- bias corrections from beta ** step with the betas as DOUBLES (a float 0.999 is 0.99900001...:
+// 1 - beta2 ** t would be off by 1e-5 relative at early steps) -- then narrowed to f32 exactly where torch narrows them
+// (a python scalar meeting a float tensor).
+struct AdamScalars {
+    float bc2_sqrt, one_m_b1, one_m_b2, beta2, eps;
+    float step_size[RLX_ADAMW_MAX_GROUPS], decay[RLX_ADAMW_MAX_GROUPS];
+};
+
+__device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step, AdamScalars* sc) {
+    const double bc1 = 1.0 - pow(a.beta1, (double)step);
+    const double bc2 = 1.0 - pow(a.beta2, (double)step);
+    sc->bc2_sqrt = (float)sqrt(bc2);                 // bias_correction2 ** 0.5
+    sc->one_m_b1 = (float)(1.0 - a.beta1);           // lerp weight
+    sc->one_m_b2 = (float)(1.0 - a.beta2);           // addcmul value
+    sc->beta2 = (float)a.beta2;
+    sc->eps = (float)a.eps;
+    for (int k = 0; k < RLX_ADAMW_MAX_GROUPS; ++k) {
+        const double lr = k < a.n_groups ? a.groups[k].lr : 0.0;
+        sc->step_size[k] = (float)(lr / bc1);
+        sc->decay[k] = (float)(1.0 - lr * a.weight_decay);
+    }
+}
+
+__device__ __forceinline__ int group_of(const rlx_adamw_params& a, long long i) {
+    int grp = -1;
+#pragma unroll
+    for (int k = 0; k < RLX_ADAMW_MAX_GROUPS; ++k)
+        if (k < a.n_groups && i >= a.groups[k].begin && i < a.groups[k].end) grp = k;
+    return grp;
+}
+
+__device__ __forceinline__ void adamw_elem(float& pi, float& gi, float& mi, float& vi, float coef, int grp, bool skip,
+                                           const AdamScalars& sc) {
+    gi = gi * coef;  // grads.mul_(clip_coef_clamped): always applied
+    if (skip || grp < 0) return;
+    pi = pi * sc.decay[grp];                                  // param.mul_(1 - lr*wd)
+    mi = mi + (gi - mi) * sc.one_m_b1;                        // exp_avg.lerp_(grad, 1-b1)
+    vi = vi * sc.beta2 + sc.one_m_b2 * gi * gi;               // mul_(b2).addcmul_(g,g,1-b2)
+    const float denom = sqrtf(vi) / sc.bc2_sqrt + sc.eps;
+    pi = pi - sc.step_size[grp] * (mi / denom);               // addcdiv_(m, denom, -step_size)
+}
+
+// One float4 of parameters per thread (p, g, m, v: four 16-byte loads in flight per lane); the (<= 1024) norm partials are
+// re-reduced by every block (a device-wide "last block" finalisation would serialise one memory-side atomic per block).
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, rlx_adamw_params a,
                                                          const double* __restrict__ partials, int nparts,
+                                                         const AdamScalars* __restrict__ scalars,
                                                          float* __restrict__ stats, int* __restrict__ state,
                                                          rlx_mlp_layout lay, float* __restrict__ tiles) {
     __shared__ double s_red[4];
-    __shared__ float s_coef, s_bc2_sqrt, s_one_m_b1, s_one_m_b2;
-    __shared__ float s_step_size[RLX_ADAMW_MAX_GROUPS], s_decay[RLX_ADAMW_MAX_GROUPS];
+    __shared__ float s_coef;
     __shared__ int s_skip;
+    __shared__ AdamScalars s_sc;
+    // issue this thread's loads before the norm is known: they do not depend on it
+    const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                                       reinterpret_cast<uintptr_t>(v)) % 16 == 0);
+    const long long n4 = vec ? n / 4 : 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
+    if (i0 < n4) {
+        p4 = reinterpret_cast<const float4*>(p)[i0];
+        g4 = reinterpret_cast<const float4*>(g)[i0];
+        m4 = reinterpret_cast<const float4*>(m)[i0];
+        v4 = reinterpret_cast<const float4*>(v)[i0];
+    }
     double acc[1] = {0.0};
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc[0] += partials[i];
+    if (threadIdx.x < (int)(sizeof(AdamScalars) / sizeof(float)))
+        reinterpret_cast<float*>(&s_sc)[threadIdx.x] = reinterpret_cast<const float*>(scalars)[threadIdx.x];
     block_sum<1>(acc, s_red);
     if (threadIdx.x == 0) {
         const float total_norm = (float)sqrt(acc[0]);
@@ -130,39 +202,48 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
             stats[1] = s_skip ? 0.f : 1.f;
             if (state != nullptr) state[1] = s_skip ? 0 : 1;
         }
-        // every scalar of the update is formed once per block, in double like torch's python scalars
-        const int step = state != nullptr ? state[0] + 1 : a.step;  // state[0] is stable for the whole launch
-        const double bc1 = 1.0 - pow((double)a.beta1, (double)step);
-        const double bc2 = 1.0 - pow((double)a.beta2, (double)step);
-        s_bc2_sqrt = (float)sqrt(bc2);
-        s_one_m_b1 = (float)(1.0 - (double)a.beta1);
-        s_one_m_b2 = (float)(1.0 - (double)a.beta2);
-        for (int k = 0; k < RLX_ADAMW_MAX_GROUPS; ++k) {
-            const double lr = k < a.n_groups ? (double)a.groups[k].lr : 0.0;
-            s_step_size[k] = (float)(lr / bc1);
-            s_decay[k] = (float)(1.0 - lr * (double)a.weight_decay);
-        }
     }
     __syncthreads();
     const float coef = s_coef;
     const bool skip = s_skip != 0;
-    const float bc2_sqrt = s_bc2_sqrt, one_m_b1 = s_one_m_b1, one_m_b2 = s_one_m_b2;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        int grp = -1;
+    for (long long i = i0; i < n4; i += stride) {
+        if (i != i0) {
+            p4 = reinterpret_cast<const float4*>(p)[i];
+            g4 = reinterpret_cast<const float4*>(g)[i];
+            m4 = reinterpret_cast<const float4*>(m)[i];
+            v4 = reinterpret_cast<const float4*>(v)[i];
+        }
+        float pe[4] = {p4.x, p4.y, p4.z, p4.w}, ge[4] = {g4.x, g4.y, g4.z, g4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w},
+              ve[4] = {v4.x, v4.y, v4.z, v4.w};
+        int grp[4];
+        const int g_first = group_of(a, 4 * i), g_last = group_of(a, 4 * i + 3);
 #pragma unroll
-        for (int k = 0; k < RLX_ADAMW_MAX_GROUPS; ++k)
-            if (k < a.n_groups && i >= a.groups[k].begin && i < a.groups[k].end) grp = k;
-        const bool in_group = grp >= 0;
-        const float gi = g[i] * coef;  // grads.mul_(clip_coef_clamped): always applied
+        for (int e = 0; e < 4; ++e) {
+            grp[e] = (e == 0) ? g_first : (e == 3 ? g_last : (g_first == g_last ? g_first : group_of(a, 4 * i + e)));
+            adamw_elem(pe[e], ge[e], me[e], ve[e], coef, grp[e], skip, s_sc);
+        }
+        reinterpret_cast<float4*>(g)[i] = float4{ge[0], ge[1], ge[2], ge[3]};
+        if (skip) continue;
+        if (g_first >= 0 || g_last >= 0 || grp[1] >= 0 || grp[2] >= 0) {
+            reinterpret_cast<float4*>(p)[i] = float4{pe[0], pe[1], pe[2], pe[3]};
+            reinterpret_cast<float4*>(m)[i] = float4{me[0], me[1], me[2], me[3]};
+            reinterpret_cast<float4*>(v)[i] = float4{ve[0], ve[1], ve[2], ve[3]};
+            if (tiles != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (grp[e] < 0) continue;
+                    if (a.tiles_bf16) tile_scatter<true>(lay, tiles, 4 * i + e, pe[e]);
+                    else tile_scatter<false>(lay, tiles, 4 * i + e, pe[e]);
+                }
+            }
+        }
+    }
+    for (long long i = n4 * 4 + i0; i < n; i += stride) {  // scalar tail / unaligned fallback
+        const int grp = group_of(a, i);
+        float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+        adamw_elem(pi, gi, mi, vi, coef, grp, skip, s_sc);
         g[i] = gi;
-        if (skip || !in_group) continue;
-        const float step_size = s_step_size[grp];
-        float pi = p[i] * s_decay[grp];                           // param.mul_(1 - lr*wd)
-        const float mi = m[i] + (gi - m[i]) * one_m_b1;           // exp_avg.lerp_(grad, 1-b1)
-        const float vi = v[i] * a.beta2 + one_m_b2 * gi * gi;     // mul_(b2).addcmul_(g,g,1-b2)
-        const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
-        pi = pi - step_size * (mi / denom);                                          // addcdiv_(m, denom, -step_size)
+        if (skip || grp < 0) continue;
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
@@ -182,8 +263,8 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     }
 }
 
-int grid_for(long long n) {
-    return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, std::min<long long>(kMaxParts, (long long)num_cu() * 4)));
+int grid_for(long long n) {  // one float4 per thread up to kMaxParts blocks, grid-stride beyond
+    return (int)std::max<long long>(1, std::min<long long>((n / 4 + 255) / 256 + 1, (long long)kMaxParts));
 }
 
 }  // namespace
@@ -193,7 +274,7 @@ using namespace rlx;
 
 extern "C" size_t rlx_adamw_workspace_bytes(int64_t n) {
     (void)n;
-    return (size_t)kMaxParts * sizeof(double);
+    return (size_t)kMaxParts * sizeof(double) + 256;  // norm partials | AdamScalars
 }
 
 extern "C" int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* out, rlx_stream_t stream) {
@@ -225,8 +306,9 @@ extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* partials = static_cast<double*>(workspace);
     const int nblk = grid_for(n);
+    AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + (size_t)kMaxParts * sizeof(double));
     hipLaunchKernelGGL(grad_reduce_sqnorm, dim3(nblk), dim3(256), 0, s, grads, (long long)n, p->grad_partials, p->grad_scale,
-                       partials, step_state);
+                       partials, step_state, *p, scalars);
     RLX_LAUNCH_CHECK();
     rlx_mlp_layout lay{};
     float* tiles = nullptr;
@@ -237,7 +319,7 @@ extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, 
                     "rlx_clip_adamw_step: tile_layout does not describe these %lld parameters", (long long)n);
     }
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblk), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long long)n, *p,
-                       partials, nblk, stats, step_state, lay, tiles);
+                       partials, nblk, scalars, stats, step_state, lay, tiles);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

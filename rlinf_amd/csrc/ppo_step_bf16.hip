@@ -327,6 +327,8 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     }
 
     // ---- forward -----------------------------------------------------------------------------------------------------
+    Stamps ts{a.stamps, 0};  // development: phase stamps of block (0, 0), see tools/phase_times.py
+    ts.mark();
     RowGemmB<RT, NW, PD> gemm;
     gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
     load_states_b<RT, NW>(a.states, nullptr, y == 1 ? st_tiles : nullptr, tg.nrb, D, m0, M, Xb);
@@ -334,16 +336,23 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     for (int i = tid; i < BM * MAX_OUT; i += G::NT) sHead[i] = 0.f;
     for (int i = n_out * W4S + tid; i < OP * W4S; i += G::NT) W4s[i] = 0.f;
     lds_barrier();
+    ts.mark();
     f32x4 acc[RT][CT];
     f32x4 kept[3][RT][CT];
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
+    ts.mark();
     epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][0], Xb, kept[0], hy, tg.nrb, m0);
+    ts.mark();
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
+    ts.mark();
     epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][1], Xb, kept[1], hy + tg.mat(), tg.nrb, m0);
+    ts.mark();
     gemm.run(Xb, acc);
+    ts.mark();
     epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][2], Xb, kept[2], nullptr, tg.nrb, m0);
+    ts.mark();
 
     // ---- head + loss element math (f32, identical to ppo_step.hip) ------------------------------------------------------
     const double nm = has_mask ? sNm[0] : 0.0;
@@ -427,6 +436,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
         }
     }
     lds_barrier();
+    ts.mark();
 
     // ---- head parameter gradients per 32-row half tile (f32 accumulation over the bf16 h3 in the slab) -----------------
     for (int u = tid; u < (BM / 32) * HID; u += G::NT) {
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
         }
     }
 
+    ts.mark();
     // ---- dZ3 = (dOut . W4) * (1 - h3^2) -> bf16 slab + tiles ---------------------------------------------------------------
     gemm.prefetch(tiles + Tiles::mat(y, 4), HID / 32);  // W3^T
     bf16x4 dv[RT][CT];
@@ -492,6 +503,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
             for (int r = 0; r < 4; ++r) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = dv[rt][ct][r];
     store_tiles<RT, NW>(dv, dzy + 2 * tg.mat(), tg.nrb, m0);
     lds_barrier();
+    ts.mark();
 
     // ---- backward-data chain ---------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -510,6 +522,11 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
                 }
         store_tiles<RT, NW>(dv, dzy + (size_t)(l - 1) * tg.mat(), tg.nrb, m0);
         if (l == 2) lds_barrier();
+        ts.mark();
+    }
+    if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.stamps[ts.n] = (long long)clock64();  // ... and the stores have drained
     }
 }
 

@@ -241,6 +241,20 @@ def iter_named_tensor_buckets(items: Iterable, version, *, bucket_size: int, buc
         yield packer.pack(bucket_items, bucket_device, meta if k == 0 else None, persistent and packers is not None)
 
 
+def target_state(model_or_state_dict) -> dict:
+    """The tensors an apply() writes into: a module's state_dict() (aliasing its parameters, as torch's does -- MLPPolicy
+    hands out reference-named views into its flat buffer) or the dict itself."""
+    return model_or_state_dict.state_dict() if hasattr(model_or_state_dict, "state_dict") else model_or_state_dict
+
+
+def weights_changed(model_or_state_dict) -> None:
+    """Raw-pointer kernels wrote into the model's parameters: derived weight images (fragment tiles, packed layouts) are
+    stale now.  Models that keep such images expose mark_updated()."""
+    mark = getattr(model_or_state_dict, "mark_updated", None)
+    if callable(mark):
+        mark()
+
+
 def load_bucket(state: dict, bucket: dict) -> None:
     """load_state_dict(bucket, strict=False) for the tensors of one bucket (:296-323): keys the target does not have are
     ignored, a shape mismatch raises like torch does, the copy converts to the target's dtype -- in one launch."""
@@ -260,6 +274,10 @@ def load_bucket(state: dict, bucket: dict) -> None:
     if errors:
         raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(errors))
     if not segments:
+        payload = [k for k in bucket.keys() if k not in (TOTAL_BUCKETS_KEY, SYNCER_VERSION_KEY)]
+        if payload:  # strict=False ignores unknown keys one by one; a whole bucket that lands nowhere is a wiring error
+            raise RlxError(f"weight bucket with {len(payload)} tensors (first: {payload[0]!r}) matches no key of the target "
+                           f"state dict (first target keys: {list(state)[:3]})")
         return
     flat = getattr(bucket, "flat", None)
     if flat is not None and not flat.is_cuda:  # host-staged flat bucket: one host-to-device copy, then re-view
@@ -358,7 +376,7 @@ class BucketWeightSyncer:
         """Receive ``total_buckets`` buckets and load each into the model.  ``load_instant=False`` defers the loads until
         every bucket has arrived (the reference stages them in host memory for that; with 288 GB of HBM they simply stay
         where they were received)."""
-        state = model_or_state_dict.state_dict() if hasattr(model_or_state_dict, "state_dict") else model_or_state_dict
+        state = target_state(model_or_state_dict)
         bucket = recv()
         total_buckets = int(bucket.pop(self._TOTAL_BUCKETS_KEY).item())
         applied_version = int(bucket.pop(self._SYNCER_VERSION_KEY).item())
@@ -372,4 +390,5 @@ class BucketWeightSyncer:
                 held.append(bucket)
         for bucket in held:
             load_bucket(state, bucket)
+        weights_changed(model_or_state_dict)
         return applied_version

@@ -351,7 +351,8 @@ class PatchWeightSyncer:
         payload = recv()
         if isinstance(payload, EmptyWeightPatch):
             return int(payload.version.item())
-        state = model_or_state_dict.state_dict() if hasattr(model_or_state_dict, "state_dict") else model_or_state_dict
+        from .bucket_syncer import target_state, weights_changed
+        state = target_state(model_or_state_dict)
         nnzs = payload.nnz_per_tensor.tolist()
         ords = payload.ordinals.tolist()
         total = sum(nnzs)
@@ -377,4 +378,5 @@ class PatchWeightSyncer:
                                                rows.data_ptr(), _INDEX_CODES[rows.dtype], cols.data_ptr(),
                                                _INDEX_CODES[cols.dtype], int(self.delta_encoding), vals.data_ptr(), nnz,
                                                ws.data_ptr(), ws_bytes, _stream_ptr(dev)), "rlx_patch_apply")
+        weights_changed(model_or_state_dict)
         return int(payload.version.item())

@@ -174,6 +174,31 @@ class MLPPolicy(nn.Module):
     def reference_state_dict(self):
         return OrderedDict((name, self.view(name).detach().clone()) for name in self.shapes)
 
+    def named_views(self):
+        """Reference-named VIEWS into the flat buffer (what nn.Module.state_dict() hands out in the reference: detached
+        tensors aliasing the parameters).  Writing through them changes the weights -- call mark_updated() afterwards."""
+        return OrderedDict((name, self.view(name).detach()) for name in self.shapes)
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """The reference's names and shapes, aliasing ``flat`` like torch's own state_dict aliases parameters: checkpoints,
+        weight-sync buckets and patches written for the reference's MLPPolicy apply to this one unchanged."""
+        out = OrderedDict() if destination is None else destination
+        for name, t in self.named_views().items():
+            out[prefix + name] = t
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Accepts the reference's key set (or the single-key {'flat': ...} form older checkpoints of this package used)."""
+        if set(state_dict.keys()) == {"flat"}:
+            with torch.no_grad():
+                self.flat.data.copy_(state_dict["flat"].to(self.flat.device, torch.float32).reshape(-1))
+            self.mark_updated()
+            return torch.nn.modules.module._IncompatibleKeys([], [])
+        if not strict:
+            state_dict = {k: state_dict.get(k, self.view(k)) for k in self.shapes}
+        self.load_reference_state_dict(state_dict)
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
     def mark_updated(self, tiles_fresh: bool = False):
         """Call after the flat parameters change (optimizer step, weight sync): the derived weight images are rebuilt
         lazily.  ``tiles_fresh``: the optimizer kernel already wrote the new weights into the tile image."""

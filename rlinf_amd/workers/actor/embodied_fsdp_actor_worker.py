@@ -46,6 +46,7 @@ class EmbodiedFSDPActor(Worker):
         self.optimizer_writes_tiles = bool(a.get("optimizer_writes_tiles", True))
         self._graph = None
         self._graph_key = None
+        self._lr_log: list = []
         # runner.use_training_pipeline (embodied_runner.py:479, env_worker.py:1469-1572, fsdp_actor_worker_pipeline.py): the
         # env side normalises advantages from (count, sum, sumsq) statistics and hands the learner per-stage shuffled
         # micro-batches.  With rollout and learner sharing the resident buffer nothing streams; what remains is the data
@@ -224,7 +225,9 @@ class EmbodiedFSDPActor(Worker):
             names.append("loss_mask_sum")
             src.append(b["loss_mask_sum"].contiguous())
         flat = [t.reshape(N, *t.shape[2:]).contiguous() for t in src]
-        key = ("shuf", N)
+        # the field set can change between calls with the same N (a loss mask or returns appearing): the cached output
+        # buffers are keyed by every field's name, row shape and dtype, never zipped against a different list
+        key = ("shuf", N, tuple((n, tuple(t.shape[1:]), t.dtype) for n, t in zip(names, flat)))
         if key not in self._ws:
             self._ws[key] = [torch.empty_like(t) for t in flat]
         outs = ops.gather_rows(flat, perm, self._ws[key])
@@ -327,6 +330,9 @@ class EmbodiedFSDPActor(Worker):
                              tile_layout=self.model.layout if tiles is not None else None, tiles=tiles)
         self.model.mark_updated(tiles_fresh=tiles is not None)
         self.optimizer_steps += 1
+        # lr_list of FSDPModelManager.optimizer_step (:451-461): while the critic warms up the optimizer holds ONE group and
+        # reports 0.0 for it (-> actor/lr = 0.0, no critic/lr entry for this step), the scheduled rates afterwards
+        self._lr_log.append((0.0, None) if self.critic_warmup_steps > 0 else (self._lrs[0], self._lrs[1]))
         if self.critic_warmup_steps > 0 and self.optimizer_steps >= self.critic_warmup_steps:
             self.exp_avg.zero_(), self.exp_avg_sq.zero_(), self.step_state.zero_()  # build_optimizer(model) anew (:453-455)
             self.critic_warmup_steps = 0
@@ -411,6 +417,7 @@ class EmbodiedFSDPActor(Worker):
                 adam(stream)
         m.mark_updated(tiles_fresh=tiles_fresh)
         self.optimizer_steps += len(plan)
+        self._lr_log.extend([(self._lrs[0], self._lrs[1])] * len(plan))
         return len(plan)
 
     def run_training(self) -> dict:
@@ -424,6 +431,7 @@ class EmbodiedFSDPActor(Worker):
                 self._ws[key] = (torch.zeros(n_steps * accum, PPO_OUT_FLOATS, device=self.device),
                                  torch.zeros(n_steps, 2, device=self.device))
             metrics_dev, norms_dev = self._ws[key]
+            self._lr_log = []  # (actor lr, critic lr or None) per optimizer step of this call
             if self.enable_hip_graph and self._world_size == 1 and self.critic_warmup_steps == 0 and self.lr_scheduler.is_static:
                 self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
             else:
@@ -447,6 +455,9 @@ class EmbodiedFSDPActor(Worker):
             self._graph, self._graph_key = g, gkey
             return
         self._graph.replay()
+        # the raw-pointer kernels do not bump flat._version: tell the model which derived images are stale now (the tile
+        # image is kept fresh by the optimizer kernel only with fused_step + optimizer_writes_tiles)
+        self.model.mark_updated(tiles_fresh=self.fused_step and self.optimizer_writes_tiles)
         self.optimizer_steps += n_steps
 
     def _collect_metrics(self, metrics_dev, norms_dev, accum) -> dict:
@@ -471,5 +482,11 @@ class EmbodiedFSDPActor(Worker):
         out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
         out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
         out["actor/grad_norm"] = host[-1]
-        out["actor/lr"], out["critic/lr"] = self._lrs  # the rates the steps of this run_training used
+        # averaged per optimizer step like every other entry of the reference's metric lists (append_to_dict + np.mean);
+        # a replayed graph ran every step at the current rates and logs nothing per step
+        log = self._lr_log or [(self._lrs[0], self._lrs[1])]
+        out["actor/lr"] = float(np.mean([a for a, _ in log]))
+        critic = [c for _, c in log if c is not None]
+        if critic:
+            out["critic/lr"] = float(np.mean(critic))
         return out

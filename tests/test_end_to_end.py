@@ -13,7 +13,7 @@ from oracle import ppo_oracle as O
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
              auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False,
-             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0):
+             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0, done_mode=None):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline),
@@ -87,6 +87,13 @@ def _build(cfg, env_tensors, state_dict):
                                    dict(total_envs=16, steps=10, global_batch=80, micro_batch=40, stage_num=2, pipeline=True),
                                    dict(total_envs=16, steps=10, global_batch=80, pipeline=True, hip_graph=True),
                                    dict(total_envs=16, steps=10, global_batch=40, critic_warmup_steps=5),  # 8 steps / iteration
+                                   # synchronous learner WITHOUT auto-reset: loss mask + loss_mask_sum / max_episode_steps ratio
+                                   # aggregation (embodied_fsdp_actor_worker.py:219-233, losses.py:219-227), whole iteration
+                                   dict(total_envs=32, steps=12, global_batch=96, auto_reset=False, done_mode="bernoulli"),
+                                   dict(total_envs=32, steps=12, global_batch=192, micro_batch=96, auto_reset=False,
+                                        done_mode="bernoulli", entropy_bonus=0.02),
+                                   dict(total_envs=32, steps=12, global_batch=96, auto_reset=False, done_mode="bernoulli",
+                                        hip_graph=True),
                                    # a schedule that moves every iteration: graphs / prepared plans must follow it
                                    dict(total_envs=16, steps=10, global_batch=80, hip_graph=True, lr_scheduler="torch_cosine",
                                         total_training_steps=3)])
@@ -94,7 +101,8 @@ def test_iteration_matches_oracle(shape):
     cfg = make_cfg(**shape)
     E = shape.get("rollout_epoch", 1)
     T, B = shape["steps"] * E, shape["total_envs"]   # T: steps over all rollout epochs
-    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    auto_reset = shape.get("auto_reset", True)
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5, mode=shape.get("done_mode") or "periodic", p_done=0.08)
     torch.manual_seed(11)
     ora = O.OracleMLPPolicy(42, 8, 1)
     sd = copy.deepcopy(ora.state_dict())
@@ -112,10 +120,14 @@ def test_iteration_matches_oracle(shape):
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234,
                                 global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E,
                                 entropy_bonus=shape.get("entropy_bonus", 0.0), pipeline=pipe,
-                                critic_warmup_steps=shape.get("critic_warmup_steps", 0), steps_done=steps_done)
+                                critic_warmup_steps=shape.get("critic_warmup_steps", 0), steps_done=steps_done,
+                                auto_reset=auto_reset, max_episode_steps=None if auto_reset else 5)
         steps_done += len(om)
         metrics = runner.run_step(eps.cuda())
-        assert metrics["train/actor/lr"] == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
+        # lr_list is 0.0 for every step taken while the critic warms up, the ending step included (fsdp_model_manager.py:451-461)
+        warm = max(0, min(len(om), shape.get("critic_warmup_steps", 0) - (steps_done - len(om))))
+        assert metrics["train/actor/lr"] == pytest.approx(opt.param_groups[0]["lr"] * (len(om) - warm) / len(om), rel=1e-12)
+        assert ("train/critic/lr" in metrics) == (warm < len(om))
         if sched is not None:
             sched.step()  # once per run_training
         rb = runner.actor.worker.rollout_batch
@@ -134,7 +146,15 @@ def test_iteration_matches_oracle(shape):
             assert metrics["train/actor/entropy_loss"] == pytest.approx(want_ent, rel=1e-4)
         want_gn = sum(float(m["actor/grad_norm"]) for m in om) / len(om)
         assert metrics["train/actor/grad_norm"] == pytest.approx(want_gn, rel=2e-3)
-        assert metrics["rollout/rewards"] == pytest.approx(float(batch["rewards"].mean()), rel=1e-4)
+        if auto_reset:
+            assert metrics["rollout/rewards"] == pytest.approx(float(batch["rewards"].mean()), rel=1e-4)
+        else:  # the loss mask and its per-env sums are integer work: bit-exact; metrics are masked (metric_utils.py:447-460)
+            assert torch.equal(rb["loss_mask"].cpu(), batch["loss_mask"]) and torch.equal(rb["loss_mask_sum"].cpu(), batch["loss_mask_sum"])
+            assert metrics["rollout/rewards"] == pytest.approx(float(batch["rewards"][batch["loss_mask"]].mean()), rel=1e-4)
+            assert metrics["rollout/advantages_max"] == pytest.approx(float(batch["advantages"][batch["loss_mask"]].max()), rel=1e-3)
+            for k in ("actor/policy_loss", "critic/value_loss", "actor/approx_kl", "actor/clip_fraction"):
+                want_k = sum(float(m[k]) for m in om) / len(om)
+                assert metrics["train/" + k] == pytest.approx(want_k, rel=5e-3, abs=5e-5), k
         # parameters after the updates: Adam turns a sign flip of a ~0 gradient into a 2*lr difference, so bound the
         # bulk tightly and the worst element by the number of steps taken
         got = runner.actor.worker.model.flat.detach().cpu()

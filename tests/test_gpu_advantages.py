@@ -205,8 +205,14 @@ def test_scaled_buffer_streaming_vs_segmented_agree():
     assert torch.equal(base_adv.cpu()[..., 0], want_adv) and torch.equal(base_ret.cpu()[..., 0], want_ret)
     for variant in (1 | (2 << 8), 1 | (4 << 8), 1 | (8 << 8), 1 | (16 << 8), 0):
         adv, ret = ops.gae_scan(rc, vc, dc, None, 0.99, 0.95, normalize_advantages=False, variant=variant)
-        torch.testing.assert_close(adv, base_adv, rtol=RTOL, atol=ATOL)
-        torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
+        if (variant >> 8) <= 1:
+            # the streaming scan in every tuning variant -- variant 0 is what the auto heuristic picks at this shape, the
+            # `gae_scan_c1<1,1,64,nt>` kernel bench.py's roofline is quoted on -- runs the CPU loop's own operation order:
+            # bit for bit
+            assert torch.equal(adv, base_adv) and torch.equal(ret, base_ret), variant
+        else:  # segmented scans compose affine maps: same recurrence, different association
+            torch.testing.assert_close(adv, base_adv, rtol=RTOL, atol=ATOL)
+            torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("C", [1, 3])

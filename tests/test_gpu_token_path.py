@@ -339,7 +339,7 @@ def test_llm_vocab_properties(dtype):
 @pytest.mark.parametrize("temperature,top_k", [(1.0, -1), (0.7, 50), (1.6, 1), (1.0, 5000)])
 def test_categorical_sample_vs_oracle(dtype, K, temperature, top_k):
     g = torch.Generator().manual_seed(K)
-    B, A, V, pad = 6, 14, K + 200, 64
+    B, A, V, pad = 96, 14, K + 200, 64   # 1344 draws per case
     full = (torch.randn(B, A, V, generator=g) * 2).to(dtype)
     window = full[..., V - pad - K:V - pad]
     q = torch.empty(B, A, K, dtype=dtype).exponential_(1, generator=g)
@@ -349,9 +349,18 @@ def test_categorical_sample_vs_oracle(dtype, K, temperature, top_k):
     tok, lp, act = token_ops.categorical_sample(dwin, q.to(DEV), temperature=temperature, top_k=top_k,
                                                 bin_centers=centers.to(DEV))
     same = tok.cpu() == wtok
-    # a different exp / division rounding can only flip a choice between two candidates whose race scores tie to f32
-    # rounding; in bf16 the scores are rounded to 8 bits on both sides and the first-index tie rule decides
-    assert same.float().mean() >= 0.995, float(same.float().mean())
+    # No unexplained mismatch: the choice is argmax(p / q).  A different exp / division rounding can only flip it between
+    # candidates whose race scores tie to rounding, so every row where the kernel's token differs from the oracle's must
+    # be such a tie IN THE ORACLE'S OWN SCORES: score[kernel token] within 2 ulp (of the scores' dtype: f32 2^-23,
+    # bf16 2^-8 relative) of the winning score.  Anything else fails, however rare.
+    if not bool(same.all()):
+        score = (torch.softmax(processed, dim=-1) / q).float()
+        best = score.max(dim=-1).values
+        mine = score.gather(-1, tok.cpu()[..., None])[..., 0]
+        ulp = 2.0 ** -23 if dtype == torch.float32 else 2.0 ** -8
+        bad = ~same & ~(mine >= best * (1 - 2 * ulp))
+        assert not bool(bad.any()), (int(bad.sum()), float(((best - mine) / best)[bad].max()))
+    assert same.float().mean() >= (0.999 if dtype == torch.float32 else 0.98), float(same.float().mean())
     if dtype == torch.float32:
         close(lp[same.to(DEV)], wlp[same], 2e-5, what="logprob")
     else:

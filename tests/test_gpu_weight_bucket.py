@@ -213,3 +213,48 @@ def test_full_size_property():
     assert n_buckets[0] == 5  # four 128 MiB tensors close a bucket: 16 of them -> 4 buckets, the two small ones ride in a 5th
     for k, v in state.items():
         assert torch.equal(replica[k], v.bfloat16()), k
+
+
+@pytest.mark.parametrize("syncer_kind", ["bucket", "patch"])
+def test_apply_into_mlp_policy_changes_weights_and_derived_images(syncer_kind):
+    """A rollout replica that does NOT alias the learner's model: reference-named buckets / patches applied through
+    ``apply(model)`` must land in MLPPolicy's flat buffer (its state_dict() hands out reference-named views) and the cached
+    fragment-tile image must follow -- an apply that matches nothing raises instead of silently keeping the old weights."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import RlxError
+    from rlinf_amd.hybrid_engines.weight_syncer import BucketWeightSyncer, PatchWeightSyncer
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(0)
+    actor = MLPPolicy(42, 8, 1, True, False).cuda()
+    torch.manual_seed(1)
+    replica = MLPPolicy(42, 8, 1, True, False).cuda()
+    assert not torch.equal(actor.flat, replica.flat)
+    stale_tiles = replica.tiles().clone()
+    names = list(actor.shapes)
+    if syncer_kind == "bucket":
+        tx, rx = BucketWeightSyncer(1 << 20, None, "cuda"), BucketWeightSyncer(1 << 20, None, "cuda")
+        tx.init_sender(actor.state_dict(), names)
+        sent = []
+        tx.sync(actor.state_dict(), sent.append, 3)
+        assert len(sent) > 1
+        it = iter(sent)
+        assert rx.apply(replica, lambda: next(it)) == 3
+    else:
+        tx = PatchWeightSyncer(snapshot_device="cuda", transport_device="cuda", delta_encoding=True)
+        rx = PatchWeightSyncer(snapshot_device="cuda", transport_device="cuda", delta_encoding=True)
+        to_rx, to_tx = [], []
+        # both start from the replica's weights (init sync off), then the actor's weights travel as one patch
+        start = {k: v.clone() for k, v in replica.state_dict().items()}
+        rx.init_receiver(replica.state_dict(), None, to_tx.append)
+        tx.init_sender(start, names, None, lambda: to_tx.pop(0))
+        tx.sync(actor.state_dict(), to_rx.append, 3)
+        assert rx.apply(replica, lambda: to_rx.pop(0)) == 3
+    assert torch.equal(actor.flat, replica.flat)
+    fresh = ops.mlp_pack_tiles(actor.flat.data, actor.layout)
+    assert torch.equal(replica.tiles(), fresh) and not torch.equal(stale_tiles, fresh)
+    if syncer_kind == "bucket":  # a bucket that lands nowhere is a wiring error, not a no-op
+        from rlinf_amd.hybrid_engines.weight_syncer.bucket_syncer import WeightBucket, load_bucket
+        last = sent[-1]
+        bogus = WeightBucket.from_flat(last.flat, [("nowhere." + k, d, sh, o) for (k, d, sh, o) in last.layout])
+        with pytest.raises(RlxError, match="matches no key"):
+            load_bucket(replica.state_dict(), bogus)

@@ -187,3 +187,24 @@ def test_cpu_tensors_are_refused_loudly():
     s.init_sender({}, ["w"])
     with pytest.raises(RlxError, match="no CPU path"):
         s.sync({"w": torch.zeros(4, 4)}, lambda b: None, 1)
+
+
+def test_mlp_policy_state_dict_hands_out_reference_named_views():
+    """syncers apply through model.state_dict(); MLPPolicy keeps ONE flat parameter, so its state_dict must hand
+    out the reference's names as views that alias it (what torch's own state_dict does for ordinary modules)."""
+    from oracle import ppo_oracle as O
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(0)
+    pol = MLPPolicy(42, 8, 1, True, False)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    sd = pol.state_dict()
+    assert list(sd) == list(ora.state_dict()) and all(sd[k].shape == v.shape for k, v in ora.state_dict().items())
+    sd["backbone.2.weight"].fill_(0.25)  # writes through
+    o = pol.offsets["backbone.2.weight"]
+    assert bool((pol.flat.data[o:o + 256 * 256] == 0.25).all())
+    pol.load_state_dict(ora.state_dict())
+    assert all(torch.equal(pol.state_dict()[k], v) for k, v in ora.state_dict().items())
+    ora.load_state_dict(pol.state_dict())  # and the reference-shaped module accepts it back
+    clone = MLPPolicy(42, 8, 1, True, False)
+    clone.load_state_dict({"flat": pol.flat.detach().clone()})
+    assert torch.equal(clone.flat, pol.flat)

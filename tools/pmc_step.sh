@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   rm -rf gpurun_out/pmc/p$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc/p$i -o pmc -f csv -- python tools/run_step_once.py ${1:-8192} > gpurun_out/pmc/p$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc/p$i -o pmc -f csv -- python tools/run_step_once.py ${1:-8192} ${2:-f32} > gpurun_out/pmc/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python - <<'PY'
