@@ -690,6 +690,41 @@ typedef struct rlx_copy_segment {
 int rlx_copy_segments_plan(rlx_copy_segment* table_host, int32_t n_segments, int64_t* total_chunks);
 int rlx_copy_segments(const rlx_copy_segment* table_dev, int32_t n_segments, int64_t total_chunks, rlx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * e  data-parallel gradient all-reduce over xGMI  <- FSDP NO_SHARD gradient synchronisation,
+ *      rlinf/hybrid_engines/fsdp/strategy/fsdp.py:480-496 (sync_grad / no_sync around backward), the averaged gradient that
+ *      FSDPModelManager.optimizer_step then clips and applies (fsdp_model_manager.py:429-463).
+ * One process per GPU.  Every rank owns a fine-grained device buffer (two staging slots of n_max floats + a flag per rank),
+ * exported with hipIpcGetMemHandle and mapped by every peer.  An all-reduce is two launches, no host involvement, no
+ * RCCL call -- so the whole optimizer step stays one hipGraph-capturable kernel chain:
+ *   stage   sum this rank's split-K gradient slabs into its staging slot (seq + 1) & 1
+ *   reduce  publish "slot complete" to every peer's flag array, wait for every peer's flag, then read all W staged
+ *           gradients over xGMI and add them IN RANK ORDER (every rank forms bit-identical sums), scale by grad_scale,
+ *           write the reduced gradient locally with the squared-norm partials the AdamW launch needs.
+ * The sequence number lives on the device and is advanced by the launch that consumes the result (graph replay needs no
+ * host bookkeeping).  A wait that exceeds timeout_ms sets the status word (rlx_xgmi_status) instead of hanging the GPU.
+ * 1.15 MB x 7 peers at ~50 GB/s per xGMI link is ~25 us of wire time; RCCL's ring needs 2 (W - 1) latency-bound steps.
+ * ------------------------------------------------------------------------------------------ */
+#define RLX_XGMI_MAX_RANKS 8
+#define RLX_XGMI_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
+typedef struct rlx_xgmi_comm rlx_xgmi_comm;
+/* create: allocates this rank's buffer; `handle_out` (RLX_XGMI_HANDLE_BYTES) is what the peers need -- exchange the handles
+ * out of band (torch.distributed all_gather_object / the reference's Worker.send) and call connect with all of them
+ * (world x RLX_XGMI_HANDLE_BYTES, own slot ignored).  mem_kind: 0 fine-grained (default), 1 uncached, 2 plain hipMalloc. */
+int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_ms, int mem_kind, rlx_xgmi_comm** comm, void* handle_out);
+int rlx_xgmi_connect(rlx_xgmi_comm* comm, const void* all_handles);
+int rlx_xgmi_destroy(rlx_xgmi_comm* comm);
+/* 0 = ok, 1 = a peer wait timed out since the last call (cleared by the call; synchronises the stream's device first). */
+int rlx_xgmi_status(rlx_xgmi_comm* comm);
+/* out[i] = scale * sum_r in_r[i]; `in` is this rank's contribution ([slabs][n], summed first), out a local buffer. */
+int rlx_xgmi_allreduce_f32(rlx_xgmi_comm* comm, const float* in, int slabs, float* out, int64_t n, float scale,
+                           void* workspace, size_t workspace_bytes /* rlx_adamw_workspace_bytes(n) */, rlx_stream_t stream);
+/* rlx_clip_adamw_step with the all-reduce in front: grads [p->grad_partials][n] are this rank's slabs, grad_flat [n]
+ * receives the reduced gradient (scaled by p->grad_scale = 1 / world for the data-parallel mean), then clip + AdamW. */
+int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* comm, float* params, const float* grads, float* grad_flat, float* exp_avg,
+                             float* exp_avg_sq, int64_t n, const rlx_adamw_params* p, float* stats, int32_t* step_state,
+                             void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

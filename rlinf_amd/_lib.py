@@ -218,7 +218,15 @@ PROTOTYPES = {
     "rlx_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_int64, c_void_p]),
     "rlx_gae_seq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p]),
     "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
+    "rlx_xgmi_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, POINTER(c_void_p), c_void_p]),
+    "rlx_xgmi_connect": (c_int, [c_void_p, c_void_p]),
+    "rlx_xgmi_destroy": (c_int, [c_void_p]),
+    "rlx_xgmi_status": (c_int, [c_void_p]),
+    "rlx_xgmi_allreduce_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
+    "rlx_xgmi_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                         POINTER(AdamwParams), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
+XGMI_HANDLE_BYTES, XGMI_MAX_RANKS = 64, 8
 
 _lib = None
 

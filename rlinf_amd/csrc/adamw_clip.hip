@@ -13,24 +13,45 @@
 
 #include <algorithm>
 
-#include "rlx_common.h"
+#include "opt_common.h"
 
 namespace rlx {
 namespace {
 
-constexpr int kMaxParts = 1024;
+using namespace opt;
 
 // state (device, int32[2]): [0] = optimizer steps applied so far, [1] = "the previous call applied a step"
 // (folded into [0] here, i.e. strictly after that call's update kernel and before this call's), so that a
 // captured hipGraph can be replayed without host-side step bookkeeping.
-struct AdamScalars;
 __device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step, AdamScalars* sc);
 
-__global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ grads, long long n, int nslab, float scale,
+// publish + wait (see opt_common.h, PeerWait).  Called by every block: thread r < world handles rank r.
+__device__ __forceinline__ void peer_handshake(const PeerWait& w) {
+    if (w.world <= 1) return;
+    const unsigned s = *w.seq + 1u;
+    if ((int)threadIdx.x < w.world) {
+        const int r = threadIdx.x;
+        if (blockIdx.x == 0)  // this rank's staged gradient s is complete (the staging launch ended before this one began)
+            __hip_atomic_store(w.flags_peer[r] + w.rank, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(w.flags_mine + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - s) < 0) {
+            if (wall_clock64() - t0 > w.timeout_ticks) {
+                *w.status = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: nothing of the peers' buffers may be served from a stale line
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* __restrict__ out, long long n, float scale,
                                                           double* __restrict__ partials, int* __restrict__ state,
-                                                          rlx_adamw_params a, AdamScalars* __restrict__ scalars) {
+                                                          rlx_adamw_params a, AdamScalars* __restrict__ scalars, PeerWait wait) {
     __shared__ double s_red[4];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {  // the last block has the shortest (or no) slice
+    if (ADAM && blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {  // the last block has the shortest (or no) slice
         int step = a.step;
         if (state != nullptr) {
             if (state[1] != 0) {
@@ -41,38 +62,60 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(float* __restrict__ gr
         }
         form_scalars(a, step, scalars);
     }
+    peer_handshake(wait);
+    if (src.seq != nullptr) {
+        const size_t off = (size_t)((*src.seq + 1u) & 1u) * (size_t)src.slot_stride;
+#pragma unroll
+        for (int b = 0; b < kMaxRanks; ++b) src.base[b] += off;
+    }
     double acc[1] = {0.0};
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nslab = src.nslab, nbase = src.nbase;
+    const bool inplace_single = nbase == 1 && nslab == 1 && scale == 1.f && out == src.base[0];
     // float4 body (slab stride n*4 bytes keeps 16-byte alignment when n % 4 == 0), slabs unrolled four at a time so that
     // a lane has up to 64 bytes in flight; scalar tail / fallback below
-    const bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(grads) % 16 == 0);
+    bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    for (int b = 0; b < nbase; ++b) vec = vec && (reinterpret_cast<uintptr_t>(src.base[b]) % 16 == 0);
     const long long n4 = vec ? n / 4 : 0;
     for (long long i = tid0; i < n4; i += stride) {
-        const float4* gp = reinterpret_cast<const float4*>(grads) + i;
-        float4 g = gp[0];
-        int k = 1;
-        for (; k + 3 < nslab; k += 4) {
-            const float4 x0 = gp[(long long)k * n4], x1 = gp[(long long)(k + 1) * n4], x2 = gp[(long long)(k + 2) * n4],
-                         x3 = gp[(long long)(k + 3) * n4];
-            g.x = (((g.x + x0.x) + x1.x) + x2.x) + x3.x;
-            g.y = (((g.y + x0.y) + x1.y) + x2.y) + x3.y;
-            g.z = (((g.z + x0.z) + x1.z) + x2.z) + x3.z;
-            g.w = (((g.w + x0.w) + x1.w) + x2.w) + x3.w;
-        }
-        for (; k < nslab; ++k) {
-            const float4 x = gp[(long long)k * n4];
-            g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+        float4 g;
+        if (nbase == 1) {
+            const float4* gp = reinterpret_cast<const float4*>(src.base[0]) + i;
+            g = gp[0];
+            int k = 1;
+            for (; k + 3 < nslab; k += 4) {
+                const float4 x0 = gp[(long long)k * n4], x1 = gp[(long long)(k + 1) * n4], x2 = gp[(long long)(k + 2) * n4],
+                             x3 = gp[(long long)(k + 3) * n4];
+                g.x = (((g.x + x0.x) + x1.x) + x2.x) + x3.x;
+                g.y = (((g.y + x0.y) + x1.y) + x2.y) + x3.y;
+                g.z = (((g.z + x0.z) + x1.z) + x2.z) + x3.z;
+                g.w = (((g.w + x0.w) + x1.w) + x2.w) + x3.w;
+            }
+            for (; k < nslab; ++k) {
+                const float4 x = gp[(long long)k * n4];
+                g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+            }
+        } else {  // one staged gradient per rank, all peer loads in flight before the first add, fixed rank order
+            float4 x[kMaxRanks];
+#pragma unroll
+            for (int b = 0; b < kMaxRanks; ++b)
+                if (b < nbase) x[b] = reinterpret_cast<const float4*>(src.base[b])[i];
+            g = x[0];
+#pragma unroll
+            for (int b = 1; b < kMaxRanks; ++b)
+                if (b < nbase) { g.x += x[b].x; g.y += x[b].y; g.z += x[b].z; g.w += x[b].w; }
         }
         g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
-        if (nslab > 1 || scale != 1.f) reinterpret_cast<float4*>(grads)[i] = g;
+        if (!inplace_single) reinterpret_cast<float4*>(out)[i] = g;
         acc[0] += (double)g.x * (double)g.x + (double)g.y * (double)g.y + (double)g.z * (double)g.z + (double)g.w * (double)g.w;
     }
     for (long long i = n4 * 4 + tid0; i < n; i += stride) {
-        float g = grads[i];
-        for (int k = 1; k < nslab; ++k) g += grads[(long long)k * n + i];
+        float g = src.base[0][i];
+        for (int k = 1; k < nslab; ++k) g += src.base[0][(long long)k * n + i];
+        for (int b = 1; b < nbase; ++b) g += src.base[b][i];
         g *= scale;
-        if (nslab > 1 || scale != 1.f) grads[i] = g;
+        if (!inplace_single) out[i] = g;
         acc[0] += (double)g * (double)g;
     }
     block_sum<1>(acc, s_red);
@@ -118,15 +161,6 @@ __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* _
     }
 }
 
-// Per-step scalars of the update, formed ONCE (block 0 of grad_reduce_sqnorm, overlapped with the slab sums) in double like
-// torch's python scalars -- bias corrections from beta ** step with the betas as DOUBLES (a float 0.999 is 0.99900001...:
-// 1 - beta2 ** t would be off by 1e-5 relative at early steps) -- then narrowed to f32 exactly where torch narrows them
-// (a python scalar meeting a float tensor).
-struct AdamScalars {
-    float bc2_sqrt, one_m_b1, one_m_b2, beta2, eps;
-    float step_size[RLX_ADAMW_MAX_GROUPS], decay[RLX_ADAMW_MAX_GROUPS];
-};
-
 __device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step, AdamScalars* sc) {
     const double bc1 = 1.0 - pow(a.beta1, (double)step);
     const double bc2 = 1.0 - pow(a.beta2, (double)step);
@@ -168,7 +202,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
                                                          const double* __restrict__ partials, int nparts,
                                                          const AdamScalars* __restrict__ scalars,
                                                          float* __restrict__ stats, int* __restrict__ state,
-                                                         rlx_mlp_layout lay, float* __restrict__ tiles) {
+                                                         rlx_mlp_layout lay, float* __restrict__ tiles, unsigned* __restrict__ seq_inc) {
     __shared__ double s_red[4];
     __shared__ float s_coef;
     __shared__ int s_skip;
@@ -201,6 +235,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
             stats[0] = total_norm;
             stats[1] = s_skip ? 0.f : 1.f;
             if (state != nullptr) state[1] = s_skip ? 0 : 1;
+            if (seq_inc != nullptr) *seq_inc += 1u;  // this all-reduce is consumed: the next staging launch uses the other buffer
         }
     }
     __syncthreads();
@@ -263,14 +298,75 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     }
 }
 
+__global__ void seq_inc_kernel(unsigned* seq) { *seq += 1u; }
+
+}  // namespace
+
+namespace opt {
+
 int grid_for(long long n) {  // one float4 per thread up to kMaxParts blocks, grid-stride beyond
     return (int)std::max<long long>(1, std::min<long long>((n / 4 + 255) / 256 + 1, (long long)kMaxParts));
 }
 
-}  // namespace
+int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace, size_t workspace_bytes,
+                             const PeerWait* wait, unsigned* seq_inc, hipStream_t s) {
+    RLX_REQUIRE(p != nullptr, "rlx_clip_adamw_step: NULL params struct");
+    RLX_REQUIRE(n >= 0 && (p->step >= 1 || step_state != nullptr) && p->n_groups >= 0 && p->n_groups <= RLX_ADAMW_MAX_GROUPS,
+                "rlx_clip_adamw_step: bad sizes (n=%lld step=%d groups=%d)", (long long)n, p->step, p->n_groups);
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(params && out && exp_avg && exp_avg_sq && stats && workspace, "rlx_clip_adamw_step: NULL argument");
+    if (workspace_bytes < rlx_adamw_workspace_bytes(n)) {
+        set_error("rlx_clip_adamw_step: workspace too small");
+        return RLX_ENOSPC;
+    }
+    for (int k = 0; k < p->n_groups; ++k)
+        RLX_REQUIRE(p->groups[k].begin >= 0 && p->groups[k].end <= n && p->groups[k].begin <= p->groups[k].end,
+                    "rlx_clip_adamw_step: group %d range out of bounds", k);
+    double* partials = static_cast<double*>(workspace);
+    const int nblk = grid_for(n);
+    AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + scalars_offset());
+    PeerWait w{};
+    if (wait != nullptr) w = *wait;
+    hipLaunchKernelGGL(grad_reduce_sqnorm<true>, dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
+                       step_state, *p, scalars, w);
+    RLX_LAUNCH_CHECK();
+    rlx_mlp_layout lay{};
+    float* tiles = nullptr;
+    if (p->tile_layout != nullptr && p->tiles != nullptr) {
+        lay = *p->tile_layout;
+        tiles = p->tiles;
+        RLX_REQUIRE(lay.hidden == 256 && lay.obs_dim >= 1 && lay.obs_dim <= 64 && lay.n_params == n,
+                    "rlx_clip_adamw_step: tile_layout does not describe these %lld parameters", (long long)n);
+    }
+    hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
+                       partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int launch_reduce_only(const ReduceSrc& src, float* out, int64_t n, float scale, void* workspace, size_t workspace_bytes,
+                       const PeerWait* wait, unsigned* seq_inc, hipStream_t s) {
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(out && workspace && workspace_bytes >= rlx_adamw_workspace_bytes(n), "reduce: NULL or short workspace");
+    PeerWait w{};
+    if (wait != nullptr) w = *wait;
+    rlx_adamw_params none{};
+    hipLaunchKernelGGL(grad_reduce_sqnorm<false>, dim3(grid_for(n)), dim3(256), 0, s, src, out, (long long)n, scale,
+                       static_cast<double*>(workspace), (int*)nullptr, none, (AdamScalars*)nullptr, w);
+    RLX_LAUNCH_CHECK();
+    if (seq_inc != nullptr) {
+        hipLaunchKernelGGL(seq_inc_kernel, dim3(1), dim3(1), 0, s, seq_inc);
+        RLX_LAUNCH_CHECK();
+    }
+    return RLX_OK;
+}
+
+}  // namespace opt
 }  // namespace rlx
 
 using namespace rlx;
+using namespace rlx::opt;
 
 extern "C" size_t rlx_adamw_workspace_bytes(int64_t n) {
     (void)n;
@@ -290,36 +386,11 @@ extern "C" int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* ou
 extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                    const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace,
                                    size_t workspace_bytes, rlx_stream_t stream) {
-    RLX_REQUIRE(p != nullptr, "rlx_clip_adamw_step: NULL params struct");
-    RLX_REQUIRE(n >= 0 && (p->step >= 1 || step_state != nullptr) && p->n_groups >= 0 && p->n_groups <= RLX_ADAMW_MAX_GROUPS && p->grad_partials >= 1,
-                "rlx_clip_adamw_step: bad sizes (n=%lld step=%d groups=%d slabs=%d)", (long long)n, p->step, p->n_groups,
-                p->grad_partials);
-    if (n == 0) return RLX_OK;
-    RLX_REQUIRE(params && grads && exp_avg && exp_avg_sq && stats && workspace, "rlx_clip_adamw_step: NULL argument");
-    if (workspace_bytes < rlx_adamw_workspace_bytes(n)) {
-        set_error("rlx_clip_adamw_step: workspace too small");
-        return RLX_ENOSPC;
-    }
-    for (int k = 0; k < p->n_groups; ++k)
-        RLX_REQUIRE(p->groups[k].begin >= 0 && p->groups[k].end <= n && p->groups[k].begin <= p->groups[k].end,
-                    "rlx_clip_adamw_step: group %d range out of bounds", k);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    double* partials = static_cast<double*>(workspace);
-    const int nblk = grid_for(n);
-    AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + (size_t)kMaxParts * sizeof(double));
-    hipLaunchKernelGGL(grad_reduce_sqnorm, dim3(nblk), dim3(256), 0, s, grads, (long long)n, p->grad_partials, p->grad_scale,
-                       partials, step_state, *p, scalars);
-    RLX_LAUNCH_CHECK();
-    rlx_mlp_layout lay{};
-    float* tiles = nullptr;
-    if (p->tile_layout != nullptr && p->tiles != nullptr) {
-        lay = *p->tile_layout;
-        tiles = p->tiles;
-        RLX_REQUIRE(lay.hidden == 256 && lay.obs_dim >= 1 && lay.obs_dim <= 64 && lay.n_params == n,
-                    "rlx_clip_adamw_step: tile_layout does not describe these %lld parameters", (long long)n);
-    }
-    hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblk), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, (long long)n, *p,
-                       partials, nblk, scalars, stats, step_state, lay, tiles);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
+    RLX_REQUIRE(p != nullptr && p->grad_partials >= 1, "rlx_clip_adamw_step: NULL params struct or grad_partials < 1");
+    ReduceSrc src{};
+    src.base[0] = grads;
+    src.nbase = 1;
+    src.nslab = p->grad_partials;
+    return launch_reduce_clip_adamw(params, src, grads, exp_avg, exp_avg_sq, n, p, stats, step_state, workspace, workspace_bytes,
+                                    nullptr, nullptr, static_cast<hipStream_t>(stream));
 }

@@ -922,7 +922,9 @@ class PreparedAdamw:
     """rlx_clip_adamw_step with every pointer fixed; ``stats`` is this step's (norm, applied) row."""
 
     def __init__(self, params, grads, exp_avg, exp_avg_sq, groups, *, betas, eps, weight_decay, max_grad_norm, grad_scale,
-                 stats, step_state, workspace, tile_layout=None, tiles=None):
+                 stats, step_state, workspace, tile_layout=None, tiles=None, xgmi=None, grad_flat=None):
+        """``xgmi`` (scheduler.xgmi.XgmiAllReduce) + ``grad_flat`` [n]: rlx_xgmi_clip_adamw_step instead -- ``grads`` are this
+        rank's slabs, the reduced gradient (scaled by grad_scale = 1 / world_size) lands in grad_flat, then clip + AdamW."""
         self._lib = _lib.load()
         n = params.numel()
         p = AdamwParams()
@@ -933,11 +935,18 @@ class PreparedAdamw:
             p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
         if tile_layout is not None and tiles is not None:
             p.tile_layout, p.tiles, p.tiles_bf16 = ctypes_pointer(tile_layout), tiles.data_ptr(), int(tiles.dtype == torch.bfloat16)
-        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p)
-        self._argv = (params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, byref(p), stats.data_ptr(),
-                      step_state.data_ptr(), workspace.data_ptr(), workspace.numel())
+        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat)
+        if xgmi is not None:
+            self._fn, self._name = self._lib.rlx_xgmi_clip_adamw_step, "rlx_xgmi_clip_adamw_step"
+            self._argv = (xgmi.handle, params.data_ptr(), grads.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(),
+                          exp_avg_sq.data_ptr(), n, byref(p), stats.data_ptr(), step_state.data_ptr(), workspace.data_ptr(),
+                          workspace.numel())
+        else:
+            self._fn, self._name = self._lib.rlx_clip_adamw_step, "rlx_clip_adamw_step"
+            self._argv = (params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, byref(p),
+                          stats.data_ptr(), step_state.data_ptr(), workspace.data_ptr(), workspace.numel())
 
     def __call__(self, stream: int):
-        rc = self._lib.rlx_clip_adamw_step(*self._argv, stream)
+        rc = self._fn(*self._argv, stream)
         if rc:
-            _lib.check(rc, "rlx_clip_adamw_step")
+            _lib.check(rc, self._name)

@@ -76,6 +76,13 @@ class EmbodiedFSDPActor(Worker):
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
         self.grad_flat = torch.zeros(n, device=dev)
         self._ws = {}
+        # gradient all-reduce transport (world_size > 1): hand-written xGMI peer reads, validated against torch.distributed at
+        # start-up on every rank; RCCL when that is unavailable.  Either way the update phase is graph-captured.
+        self._xgmi = None
+        if self._world_size > 1 and dev is not None and dev.type == "cuda":
+            from ...scheduler import xgmi
+            self._xgmi = xgmi.build(self.ctx, n)
+        self.grad_allreduce_backend = "none" if self._world_size == 1 else ("xgmi" if self._xgmi is not None else "rccl")
         self._build_lr_scheduler()
 
     def _build_lr_scheduler(self):
@@ -316,18 +323,20 @@ class EmbodiedFSDPActor(Worker):
             vh = [(self.model.offsets[n], self.model.offsets[n] + self.model.view(n).numel())
                   for n in self.model.shapes if "value_head" in n]
             groups = [(max(b, vb), min(e, ve), lr) for (b, e, lr) in self.groups for (vb, ve) in vh if max(b, vb) < min(e, ve)]
-        if self._world_size > 1:
+        tiles = self.model.tiles() if (self.fused_step and self.optimizer_writes_tiles) else None
+        kw = dict(betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay, max_grad_norm=o.clip_grad,
+                  stats=self.opt_stats if stats is None else stats, step_state=self.step_state, workspace=self.adamw_ws,
+                  tile_layout=self.model.layout if tiles is not None else None, tiles=tiles)
+        if self._xgmi is not None:  # stage + peer-read reduce + clip + AdamW: three launches, no host round trip
+            ops.PreparedAdamw(self.model.flat.data, grads, self.exp_avg, self.exp_avg_sq, groups, grad_scale=1.0 / self._world_size,
+                              xgmi=self._xgmi, grad_flat=self.grad_flat, **kw)(torch.cuda.current_stream(self.device).cuda_stream)
+        elif self._world_size > 1:
             ops.sum_slabs(grads, out=self.grad_flat)
             all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1)
-            g, scale = self.grad_flat, 1.0 / self._world_size
+            ops.clip_adamw_step_(self.model.flat.data, self.grad_flat, self.exp_avg, self.exp_avg_sq, groups, 0,
+                                 grad_scale=1.0 / self._world_size, **kw)
         else:
-            g, scale = grads, 1.0
-        tiles = self.model.tiles() if (self.fused_step and self.optimizer_writes_tiles) else None
-        ops.clip_adamw_step_(self.model.flat.data, g, self.exp_avg, self.exp_avg_sq, groups, 0,
-                             betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
-                             max_grad_norm=o.clip_grad, grad_scale=scale, stats=self.opt_stats if stats is None else stats,
-                             step_state=self.step_state, workspace=self.adamw_ws,
-                             tile_layout=self.model.layout if tiles is not None else None, tiles=tiles)
+            ops.clip_adamw_step_(self.model.flat.data, grads, self.exp_avg, self.exp_avg_sq, groups, 0, grad_scale=1.0, **kw)
         self.model.mark_updated(tiles_fresh=tiles is not None)
         self.optimizer_steps += 1
         # lr_list of FSDPModelManager.optimizer_step (:451-461): while the critic warms up the optimizer holds ONE group and
@@ -380,6 +389,7 @@ class EmbodiedFSDPActor(Worker):
             tiles = m.tiles() if self.optimizer_writes_tiles else None
             lp = self._loss_params(False)
             multi = self._world_size > 1
+            xg = self._xgmi
             plan, step = [], 0
             for _ in range(epochs):
                 for i in range(n_mb):
@@ -394,11 +404,11 @@ class EmbodiedFSDPActor(Worker):
                             micro_calls.append(lambda _stream, mb=mbatch, g=grads[j * ws["slabs"]:(j + 1) * ws["slabs"]],
                                                row=metrics_dev[step * accum + j]: self._entropy_bonus(mb, g, row))
                     adam = ops.PreparedAdamw(
-                        m.flat.data, self.grad_flat if multi else grads, self.exp_avg, self.exp_avg_sq, self.groups,
+                        m.flat.data, self.grad_flat if (multi and xg is None) else grads, self.exp_avg, self.exp_avg_sq, self.groups,
                         betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
                         max_grad_norm=o.clip_grad, grad_scale=1.0 / self._world_size if multi else 1.0, stats=norms_dev[step],
                         step_state=self.step_state, workspace=self.adamw_ws, tile_layout=m.layout if tiles is not None else None,
-                        tiles=tiles)
+                        tiles=tiles, xgmi=xg, grad_flat=self.grad_flat if xg is not None else None)
                     plan.append((micro_calls, adam))
                     step += 1
             self._ws["prepared_key"], self._ws["prepared_plan"] = pkey, plan
@@ -411,9 +421,9 @@ class EmbodiedFSDPActor(Worker):
             for micro_calls, adam in plan:
                 for call in micro_calls:
                     call(stream)
-                if self._world_size > 1:
+                if self._world_size > 1 and self._xgmi is None:
                     ops.sum_slabs(grads, out=self.grad_flat)
-                    all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1)
+                    all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1); capturable in a hipGraph
                 adam(stream)
         m.mark_updated(tiles_fresh=tiles_fresh)
         self.optimizer_steps += len(plan)
@@ -432,11 +442,13 @@ class EmbodiedFSDPActor(Worker):
                                  torch.zeros(n_steps, 2, device=self.device))
             metrics_dev, norms_dev = self._ws[key]
             self._lr_log = []  # (actor lr, critic lr or None) per optimizer step of this call
-            if self.enable_hip_graph and self._world_size == 1 and self.critic_warmup_steps == 0 and self.lr_scheduler.is_static:
+            if self.enable_hip_graph and self.critic_warmup_steps == 0 and self.lr_scheduler.is_static:
                 self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
             else:
                 self._run_update(flat, N, metrics_dev, norms_dev)
             out = self._collect_metrics(metrics_dev, norms_dev, accum)
+            if self._xgmi is not None:
+                self._xgmi.check_status()  # a peer that never published its gradient: raise instead of training on garbage
             self._step_lr_scheduler()
             return out
 
@@ -449,9 +461,25 @@ class EmbodiedFSDPActor(Worker):
             torch.cuda.synchronize(self.device)
             steps_before = self.optimizer_steps
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._run_update(flat, N, metrics_dev, norms_dev)
+            ok = 1
+            try:
+                with torch.cuda.graph(g):
+                    self._run_update(flat, N, metrics_dev, norms_dev)
+            except Exception as e:  # noqa: BLE001 -- e.g. an RCCL build that cannot be stream-captured
+                if self._world_size == 1:
+                    raise
+                ok = 0
+                print(f"[rlinf_amd] rank {self._rank}: capturing the update phase failed ({type(e).__name__}: {e}); running it eagerly",
+                      flush=True)
             self.optimizer_steps = steps_before  # capture records, it does not execute
+            if self._world_size > 1:  # every rank replays, or none does
+                import torch.distributed as dist
+                verdict = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                ok = int(verdict.item())
+            if not ok:
+                self.enable_hip_graph = False
+                return
             self._graph, self._graph_key = g, gkey
             return
         self._graph.replay()

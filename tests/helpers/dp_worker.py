@@ -69,16 +69,21 @@ def cpu_main(out_path):
     dist.destroy_process_group()
 
 
-def gpu_main(out_path, precision):
+def gpu_main(out_path, precision, transport="xgmi", graph="0", backend="gloo"):
+    """transport: "xgmi" (hand-written peer-read all-reduce, IPC-mapped buffers; works with both ranks on ONE GPU too) or
+    "rccl" (torch.distributed all-reduce: gloo when the ranks share a GPU -- RCCL needs a device per rank -- nccl otherwise);
+    graph "1": actor.enable_hip_graph -- with xgmi the update phase is a pure kernel chain and is captured, with gloo the
+    capture fails by construction and the worker must fall back to the eager loop on both ranks."""
     import copy
 
     from oracle import ppo_oracle as O
     from test_end_to_end import _build, make_cfg
 
     from oracle import ppo_loop as L
-    os.environ["RLX_DIST_BACKEND"] = "gloo"  # two ranks share the one GPU of the test box: RCCL needs a device per rank
+    os.environ["RLX_DIST_BACKEND"] = backend
+    os.environ["RLX_GRAD_ALLREDUCE"] = transport
     T, B, GB = 12, 64, 192
-    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=GB // 2)
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=GB // 2, hip_graph=graph == "1")
     cfg.actor.model.precision = precision
     env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
     torch.manual_seed(11)
@@ -90,6 +95,15 @@ def gpu_main(out_path, precision):
     lo, hi = ctx.rank * (B // 2), (ctx.rank + 1) * (B // 2)
     metrics = runner.run_step(eps[:, lo:hi].cuda())
     rb = runner.actor.worker.rollout_batch
+    first = dict(params=runner.actor.worker.model.flat.detach().cpu().clone(), advantages=rb["advantages"].cpu().clone(),
+                 returns=rb["returns"].cpu().clone(), actions=rb["forward_inputs"]["action"].cpu().clone(),
+                 rewards=rb["rewards"].cpu().clone())
+    iters = 1
+    if graph == "1":  # iteration 0 ran eagerly and captured; two more are replays (or the eager fallback)
+        for it in (1, 2):
+            eps_i = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
+            metrics = runner.run_step(eps_i[:, lo:hi].cuda())
+            iters += 1
     # actor -> rollout weight sync over the sparse patch format: rank 0 plays the learner, rank 1 a rollout replica that
     # holds bf16 copies; handshake and patch both travel over torch.distributed (gloo here, RCCL with a GPU per rank)
     from rlinf_amd.hybrid_engines.weight_syncer import PatchWeightSyncer
@@ -112,10 +126,12 @@ def gpu_main(out_path, precision):
         version = syncer.apply(replica, lambda: patch)
     dist.broadcast(master["w"], src=0), dist.broadcast(master["b"], src=0)
     sync_ok = ctx.rank == 0 or all(torch.equal(replica[k], master[k].to(torch.bfloat16)) for k in master)
-    torch.save(dict(rank=ctx.rank, metrics=metrics, params=runner.actor.worker.model.flat.detach().cpu(),
-                    advantages=rb["advantages"].cpu(), returns=rb["returns"].cpu(), actions=rb["forward_inputs"]["action"].cpu(),
-                    rewards=rb["rewards"].cpu(), sync_ok=bool(sync_ok), sync_version=version,
-                    patch_nnz=patch.nnz_per_tensor.tolist()), out_path)
+    w = runner.actor.worker
+    torch.save(dict(rank=ctx.rank, metrics=metrics, params=first["params"], advantages=first["advantages"], returns=first["returns"],
+                    actions=first["actions"], rewards=first["rewards"], sync_ok=bool(sync_ok), sync_version=version,
+                    patch_nnz=patch.nnz_per_tensor.tolist(), backend=w.grad_allreduce_backend, iters=iters,
+                    final_params=w.model.flat.detach().cpu(), graph_live=w._graph is not None,
+                    graph_enabled=bool(w.enable_hip_graph)), out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,4 +140,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "cpu":
         cpu_main(sys.argv[2])
     else:
-        gpu_main(sys.argv[2], sys.argv[3])
+        gpu_main(*sys.argv[2:])

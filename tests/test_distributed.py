@@ -16,11 +16,11 @@ from conftest import ROOT
 WORKER = os.path.join(ROOT, "tests", "helpers", "dp_worker.py")
 
 
-def _launch(mode, tmp_path, *extra, port=29611, timeout=300):
+def _launch(mode, tmp_path, *extra, port=29611, timeout=300, one_device=True):
     procs, outs = [], []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0" if one_device else str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out = str(tmp_path / f"rank{rank}.out")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, WORKER, mode, out, *extra], env=env, stdout=subprocess.PIPE,
@@ -53,17 +53,38 @@ def test_world_size_2_host_logic_over_gloo(tmp_path):
     assert r0["bucket_ok"] and r1["bucket_ok"]  # a weight bucket: pickled layout + one broadcast of the flat byte buffer
 
 
+def _two_gpus():
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["32"])
-def test_two_ranks_match_the_sharded_oracle(tmp_path, precision):
-    """Two processes (gloo all-reduce of CUDA tensors, one GPU) against the reference arithmetic applied shard by shard:
-    per-rank rollout on its env half, per-shard advantage normalisation, per-rank shuffle with seed + rank, per-rank
-    minibatches of global_batch / 2, gradient mean, identical clip + AdamW on every rank."""
+@pytest.mark.parametrize("transport,graph,backend", [
+    ("xgmi", "0", "gloo"),   # the hand-written peer-read all-reduce over IPC-mapped buffers, two ranks on ONE GPU
+    ("xgmi", "1", "gloo"),   # ... inside the captured hipGraph of the update phase (replayed twice)
+    ("rccl", "0", "gloo"),   # torch.distributed all-reduce (gloo stands in for RCCL: it needs a device per rank)
+    ("rccl", "1", "gloo"),   # capture cannot hold a gloo all-reduce: both ranks must agree to fall back to the eager loop
+    pytest.param("rccl", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="RCCL needs one GPU per rank")),
+    pytest.param("xgmi", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")),
+])
+def test_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph, backend, precision="32"):
+    """Two processes against the reference arithmetic applied shard by shard: per-rank rollout on its env half, per-shard
+    advantage normalisation, per-rank shuffle with seed + rank, per-rank minibatches of global_batch / 2, gradient mean
+    (FSDP NO_SHARD, rlinf/hybrid_engines/fsdp/strategy/fsdp.py:480-496), identical clip + AdamW on every rank.  The two
+    nccl cases run when the box has two GPUs (one rank per GPU, RCCL / xGMI for real)."""
     import copy
 
     from oracle import ppo_loop as L
     from oracle import ppo_oracle as O
-    outs = [torch.load(o, weights_only=False) for o in _launch("gpu", tmp_path, precision, port=29613, timeout=600)]
+    outs = [torch.load(o, weights_only=False)
+            for o in _launch("gpu", tmp_path, precision, transport, graph, backend, port=29613 + 2 * (graph == "1") + 4 * (transport == "rccl"),
+                             timeout=600, one_device=backend != "nccl")]
+    assert all(o["backend"] == transport for o in outs), [o["backend"] for o in outs]
+    if graph == "1":
+        assert all(o["iters"] == 3 for o in outs)
+        live = [o["graph_live"] for o in outs]
+        assert live[0] == live[1], "both ranks replay a graph or neither does"
+        assert live[0] == (transport == "xgmi" or backend == "nccl"), live
+        assert torch.equal(outs[0]["final_params"], outs[1]["final_params"]) and torch.isfinite(outs[0]["final_params"]).all()
     # the weight patch built by rank 0's kernels, broadcast, applied by rank 1's kernels onto its bf16 replica
     assert all(o["sync_ok"] for o in outs) and outs[1]["sync_version"] == 3
     assert outs[0]["patch_nnz"] == outs[1]["patch_nnz"] and sum(outs[0]["patch_nnz"]) > 0
