@@ -38,8 +38,9 @@ def synthetic_env_tensors(seed: int, T: int, B: int, obs_dim: int = 42, max_epis
     return dict(obs=obs, final_obs=final_obs, rewards=rewards, dones=dones)
 
 
-def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: float, auto_reset: bool = True):
-    """-> batch dict in the reference's buffer shapes ([T,...] / [T+1,...] with C = 1)."""
+def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: float, auto_reset: bool = True, autocast: bool = False):
+    """-> batch dict in the reference's buffer shapes ([T,...] / [T+1,...] with C = 1).  ``autocast``: the policy forwards run
+    under bf16 autocast (`precision: bf16`), everything else stays f32."""
     T, B = env["rewards"].shape
     A = policy.action_dim * policy.num_action_chunks
     states = torch.empty(T, B, policy.obs_dim)
@@ -50,21 +51,25 @@ def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: floa
     dones = torch.zeros(T + 1, B, 1, dtype=torch.bool)
     obs = env["obs"][0]
     for t in range(T):
-        a, lp, v = policy.act(obs, eps=eps[t], mode="train")
+        with O.amp(autocast):
+            a, lp, v = policy.act(obs, eps=eps[t], mode="train")
         states[t], action[t], logp[t], values[t] = obs, a, lp, v
         r = env["rewards"][t].clone().unsqueeze(-1)
         d = env["dones"][t + 1].unsqueeze(-1)
         if auto_reset and bool(d.any()):
-            vf = policy.value_head.mlp(env["final_obs"][t]).detach()[:, :1]
+            with O.amp(autocast):
+                vf = policy.value_head.mlp(env["final_obs"][t]).detach()[:, :1].float()
             r = O.bootstrap_rewards(r, d, vf, gamma)
         rewards[t], dones[t + 1] = r, d
         obs = env["obs"][t + 1]
-    values[T] = policy.value_head.mlp(obs).detach()
+    with O.amp(autocast):
+        values[T] = policy.value_head.mlp(obs).detach()
     return dict(rewards=rewards, dones=dones, prev_values=values, prev_logprobs=logp,
                 forward_inputs=dict(states=states, action=action))
 
 
-def rollout_epochs(policy, env: dict, eps: torch.Tensor, gamma: float, rollout_epoch: int, auto_reset: bool = True):
+def rollout_epochs(policy, env: dict, eps: torch.Tensor, gamma: float, rollout_epoch: int, auto_reset: bool = True,
+                   autocast: bool = False):
     """``rollout_epoch`` back-to-back epochs of T steps each (EnvWorker._run_interact_once's outer loop,
     env_worker.py:1074: every epoch opens with its own all-False bootstrap row and closes with its own value row),
     stacked on the time axis as the trajectory builder does and folded into the batch axis by
@@ -75,7 +80,7 @@ def rollout_epochs(policy, env: dict, eps: torch.Tensor, gamma: float, rollout_e
     for e in range(rollout_epoch):
         sl = dict(obs=env["obs"][e * T:(e + 1) * T + 1], final_obs=env["final_obs"][e * T:(e + 1) * T],
                   rewards=env["rewards"][e * T:(e + 1) * T], dones=env["dones"][e * T:(e + 1) * T + 1])
-        parts.append(rollout(policy, sl, eps[e * T:(e + 1) * T], gamma, auto_reset))
+        parts.append(rollout(policy, sl, eps[e * T:(e + 1) * T], gamma, auto_reset, autocast))
     stacked = {k: (dict((kk, torch.cat([p[k][kk] for p in parts], 0)) for kk in parts[0][k]) if isinstance(parts[0][k], dict)
                    else torch.cat([p[k] for p in parts], 0)) for k in parts[0]}
     return O.fold_rollout_epochs(stacked, rollout_epoch)
@@ -129,7 +134,8 @@ def pipeline_permutation(T: int, B: int, stage_num: int, generator: torch.Genera
 
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
            value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0,
-           perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None):
+           perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
+           autocast: bool = False):
     T, B = batch["prev_logprobs"].shape[:2]
     if perm is None:
         perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
@@ -146,7 +152,7 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
                                   loss_mask_sum=mb.get("loss_mask_sum")),
                 clip_low=clip_low, clip_high=clip_high, value_clip=value_clip, huber_delta=huber_delta,
                 clip_grad=clip_grad, action_dim=policy.action_dim, entropy_bonus=entropy_bonus, max_episode_steps=max_episode_steps,
-                critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
+                autocast=autocast, critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
             metrics.append(m)
             steps += 1
             if critic_warmup_steps > 0 and steps_done + steps == critic_warmup_steps:
@@ -210,14 +216,15 @@ def async_update(policy, opt, batch: dict, *, seed: int, global_batch: int, micr
 
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
               max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0,
-              pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None):
+              pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
+              autocast: bool = False):
     """``pipeline`` = dict(stage_num=..., generator=<the rank's stateful shuffle generator>) selects
     runner.use_training_pipeline's data path: global-statistics normalisation, per-stage shuffles, and -- every
     micro-batch being available at once here -- the epoch-major schedule PipelineEmbodiedFSDPActor.run_training reduces
     to (fsdp_actor_worker_pipeline.py:84-160: fixed global batches, epoch 1 in arrival order, then each again)."""
     t0 = time.perf_counter()
-    batch = (rollout(policy, env, eps, gamma, auto_reset) if rollout_epoch == 1
-             else rollout_epochs(policy, env, eps, gamma, rollout_epoch, auto_reset))
+    batch = (rollout(policy, env, eps, gamma, auto_reset, autocast) if rollout_epoch == 1
+             else rollout_epochs(policy, env, eps, gamma, rollout_epoch, auto_reset, autocast))
     t1 = time.perf_counter()
     perm = None
     if pipeline is None:
@@ -229,7 +236,8 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     t2 = time.perf_counter()
     metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
                      max_steps=max_update_steps, entropy_bonus=entropy_bonus, perm=perm,
-                     critic_warmup_steps=critic_warmup_steps, steps_done=steps_done, max_episode_steps=max_episode_steps)
+                     critic_warmup_steps=critic_warmup_steps, steps_done=steps_done, max_episode_steps=max_episode_steps,
+                     autocast=autocast)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))

@@ -452,14 +452,24 @@ def build_adamw(policy: nn.Module, lr=3e-4, value_lr=3e-4, betas=(0.9, 0.999), e
                              weight_decay=wd)
 
 
+def amp(enabled: bool):
+    """The learner's ``amp_context`` (fsdp_model_manager.py:122-142: torch.amp.autocast(dtype=bf16) around the model forward
+    ONLY, embodied_fsdp_actor_worker.py:624-632).  A fresh context per forward: autocast caches its bf16 weight copies per
+    context, and a copy made under no_grad (a rollout forward) would cut the training forward off from the parameters."""
+    return torch.autocast("cpu", dtype=torch.bfloat16, enabled=bool(enabled), cache_enabled=False)
+
+
 def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, value_clip=1.0,
                        huber_delta=10.0, entropy_bonus=0.0, clip_grad=0.5, action_dim=8,
-                       logprob_type="action_level", critic_warmup=False, max_episode_steps=None):
+                       logprob_type="action_level", critic_warmup=False, max_episode_steps=None, autocast=False):
     """forward -> actor_critic loss -> backward -> clip_grad_norm_ -> AdamW (skipped if norm non-finite).
     ``loss_mask_sum`` + ``max_episode_steps`` (both present when auto_reset is off) switch the aggregation to
     masked_mean_ratio, as train_micro_batch's loss_kwargs do (embodied_fsdp_actor_worker.py:641-662, losses.py:219-227)."""
     opt.zero_grad()
-    out = policy.evaluate(mb["states"], mb["action"])
+    with amp(autocast):
+        out = policy.evaluate(mb["states"], mb["action"])
+    if autocast:  # the loss asserts f32 inputs (losses.py:232-240); log-probs come out f32 by type promotion, values are cast
+        out = {k: v.float() for k, v in out.items()}
     shaped = shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type,
                                action_dim, loss_mask=mb.get("loss_mask"), loss_mask_sum=mb.get("loss_mask_sum"),
                                values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])

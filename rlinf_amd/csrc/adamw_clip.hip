@@ -84,6 +84,15 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
             const float4* gp = reinterpret_cast<const float4*>(src.base[0]) + i;
             g = gp[0];
             int k = 1;
+            // the slabs were written by other XCDs' workgroups: every batch of loads is one trip to the memory-side cache, so
+            // eight slabs (128 bytes per lane) travel together; the adds keep the ascending-slab order
+            for (; k + 7 < nslab; k += 8) {
+                float4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = gp[(long long)(k + u) * n4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
+            }
             for (; k + 3 < nslab; k += 4) {
                 const float4 x0 = gp[(long long)k * n4], x1 = gp[(long long)(k + 1) * n4], x2 = gp[(long long)(k + 2) * n4],
                              x3 = gp[(long long)(k + 3) * n4];
@@ -161,9 +170,21 @@ __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* _
     }
 }
 
+// beta ** step for an integer step by repeated squaring: <= 2 log2(step) double multiplications (each within half an ulp; the
+// result is narrowed to f32 right after) instead of libm's pow(), which costs ~3 us on the single lane that forms the scalars
+__device__ __forceinline__ double ipow(double b, int e) {
+    double r = 1.0;
+    while (e > 0) {
+        if (e & 1) r *= b;
+        b *= b;
+        e >>= 1;
+    }
+    return r;
+}
+
 __device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step, AdamScalars* sc) {
-    const double bc1 = 1.0 - pow(a.beta1, (double)step);
-    const double bc2 = 1.0 - pow(a.beta2, (double)step);
+    const double bc1 = 1.0 - ipow(a.beta1, step);
+    const double bc2 = 1.0 - ipow(a.beta2, step);
     sc->bc2_sqrt = (float)sqrt(bc2);                 // bias_correction2 ** 0.5
     sc->one_m_b1 = (float)(1.0 - a.beta1);           // lerp weight
     sc->one_m_b2 = (float)(1.0 - a.beta2);           // addcmul value

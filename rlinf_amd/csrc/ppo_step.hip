@@ -561,24 +561,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
         b -= gemm_blocks;
         if (b < a.slabs * 2) {
             // ---- head gradients: slab s takes the 32-row partials t == s (mod slabs); thread = hidden column j -------------
-            const int s = b >> 1, y = b & 1, j = tid;
-            const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
-            float* slab = a.grads + (size_t)s * lay.n_params;
-            for (int o = 0; o < n_out; ++o) {
-                float acc = 0.f;
-                for (int t = s; t < a.head_parts; t += a.slabs) acc += a.head_part[((size_t)t * 2 + y) * a.head_stride + o * HID + j];
-                slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc;
-            }
-            if (j < n_out) {
-                float sb = 0.f, sl = 0.f;
-                for (int t = s; t < a.head_parts; t += a.slabs) {
-                    const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
-                    sb += part[n_out * HID + j];
-                    sl += part[n_out * HID + n_out + j];
-                }
-                if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
-                if (y == 1) slab[lay.off_logstd + j] = sl;
-            }
+            head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
             // ---- metric row: sum the per-tile partials of both networks ---------------------------------------
             double acc[NS];

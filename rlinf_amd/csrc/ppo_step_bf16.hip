@@ -288,7 +288,21 @@ struct TileGeom {
     __host__ __device__ size_t mat() const { return (size_t)16 * nrb * 512; }  // elements per [M][256] image
 };
 
-template <int RT, int NW, int PD, int OP>
+// STAMPS: the development build of the same kernel with phase stamps (tools/phase_times.py); reading the cycle counter orders
+// the surrounding memory operations (+5 us measured), so the product instantiation carries none.
+template <bool ON>
+struct StampsT {
+    long long* buf;
+    int n;
+    __device__ __forceinline__ void mark() {
+        if constexpr (ON) {
+            if (buf != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf[n] = (long long)clock64();
+            ++n;
+        }
+    }
+};
+
+template <int RT, int NW, int PD, int OP, bool STAMPS>
 __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a, __bf16* st_tiles) {
     typedef GeoB<RT, NW> G;
     constexpr int BM = G::BM, CT = G::CT;
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     }
 
     // ---- forward -----------------------------------------------------------------------------------------------------
-    Stamps ts{a.stamps, 0};  // development: phase stamps of block (0, 0), see tools/phase_times.py
+    StampsT<STAMPS> ts{a.stamps, 0};  // development: phase stamps of block (0, 0), see tools/phase_times.py
     ts.mark();
     RowGemmB<RT, NW, PD> gemm;
     gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
@@ -524,9 +538,11 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
         if (l == 2) lds_barrier();
         ts.mark();
     }
-    if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        a.stamps[ts.n] = (long long)clock64();  // ... and the stores have drained
+    if constexpr (STAMPS) {
+        if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a.stamps[ts.n] = (long long)clock64();  // ... and the stores have drained
+        }
     }
 }
 
@@ -546,24 +562,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, cons
     if (b >= gemm_blocks) {
         b -= gemm_blocks;
         if (b < a.slabs * 2) {
-            const int s = b >> 1, y = b & 1, j = tid;
-            const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
-            float* slab = a.grads + (size_t)s * lay.n_params;
-            for (int o = 0; o < n_out; ++o) {
-                float acc = 0.f;
-                for (int t = s; t < a.head_parts; t += a.slabs) acc += a.head_part[((size_t)t * 2 + y) * a.head_stride + o * HID + j];
-                slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc;
-            }
-            if (j < n_out) {
-                float sb = 0.f, sl = 0.f;
-                for (int t = s; t < a.head_parts; t += a.slabs) {
-                    const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
-                    sb += part[n_out * HID + j];
-                    sl += part[n_out * HID + n_out + j];
-                }
-                if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
-                if (y == 1) slab[lay.off_logstd + j] = sl;
-            }
+            head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
             double acc[NS];
 #pragma unroll
@@ -693,24 +692,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, 
     if (b >= gemm_blocks) {
         b -= gemm_blocks;
         if (b < a.slabs * 2) {
-            const int s = b >> 1, y = b & 1, j = tid;
-            const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
-            float* slab = a.grads + (size_t)s * lay.n_params;
-            for (int o = 0; o < n_out; ++o) {
-                float acc = 0.f;
-                for (int t = s; t < a.head_parts; t += a.slabs) acc += a.head_part[((size_t)t * 2 + y) * a.head_stride + o * HID + j];
-                slab[lay.off_w[y][3] + (size_t)o * HID + j] = acc;
-            }
-            if (j < n_out) {
-                float sb = 0.f, sl = 0.f;
-                for (int t = s; t < a.head_parts; t += a.slabs) {
-                    const float* part = a.head_part + ((size_t)t * 2 + y) * a.head_stride;
-                    sb += part[n_out * HID + j];
-                    sl += part[n_out * HID + n_out + j];
-                }
-                if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
-                if (y == 1) slab[lay.off_logstd + j] = sl;
-            }
+            head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
             double* s_red = reinterpret_cast<double*>(dsm);
             double acc[NS];
@@ -873,12 +855,15 @@ size_t bf16_image_bytes(int64_t m) { return (size_t)16 * ((m + 31) / 32) * 512 *
 int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, hipStream_t st) {
     const size_t lds = GeoB<4, 8>::LDS_BYTES;
     __bf16* stt = static_cast<__bf16*>(st_tiles);
-    if (op8) {
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+    if (op8 && a.stamps != nullptr) {
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+    } else if (op8) {
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
     } else {
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
     }
     RLX_LAUNCH_CHECK();
     if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)

@@ -185,6 +185,65 @@ struct DwArgs {
     float* out;              // metric row (RLX_PPO_OUT_FLOATS)
 };
 
+#if defined(__HIPCC__)
+// Head-gradient block of the weight-gradient launches: slab s takes the 32-row partials t == s (mod slabs), thread = hidden
+// column j.  The sums run in ascending t like a plain loop, but the loads do not: a loop of `acc += part[t]` costs one
+// memory round trip PER PARTIAL (the partials were written by other XCDs' workgroups: ~0.4 us each from the memory-side
+// cache; 8 outputs x 11 partials = 35 us -- this tail, not the GEMM blocks, set the launch's duration), so HB partials of OB
+// outputs are requested together (clamped, unconditional loads) and only then added.
+template <int OB = 4, int HB = 12>
+__device__ __forceinline__ void head_reduce_block(const DwArgs& a, int s, int y, int j) {
+    const rlx_mlp_layout& lay = a.lay;
+    const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    float* slab = a.grads + (size_t)s * lay.n_params;
+    const int cnt = (a.head_parts - s + a.slabs - 1) / a.slabs;  // partials of this slab (>= 1: slabs <= head_parts)
+    const size_t pstride = (size_t)a.slabs * 2 * a.head_stride;  // from partial t to t + slabs
+    const float* base = a.head_part + ((size_t)s * 2 + y) * a.head_stride;
+    for (int o0 = 0; o0 < n_out; o0 += OB) {
+        float acc[OB];
+#pragma unroll
+        for (int q = 0; q < OB; ++q) acc[q] = 0.f;
+        for (int t0 = 0; t0 < cnt; t0 += HB) {
+            float x[OB][HB];
+#pragma unroll
+            for (int q = 0; q < OB; ++q)
+#pragma unroll
+                for (int u = 0; u < HB; ++u)
+                    x[q][u] = base[(size_t)min(t0 + u, cnt - 1) * pstride + (size_t)min(o0 + q, n_out - 1) * HID + j];
+#pragma unroll
+            for (int u = 0; u < HB; ++u)
+                if (t0 + u < cnt) {
+#pragma unroll
+                    for (int q = 0; q < OB; ++q) acc[q] += x[q][u];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < OB; ++q)
+            if (o0 + q < n_out) slab[lay.off_w[y][3] + (size_t)(o0 + q) * HID + j] = acc[q];
+    }
+    if (j < n_out) {
+        float sb = 0.f, sl = 0.f;
+        for (int t0 = 0; t0 < cnt; t0 += HB) {
+            float xb[HB], xl[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const float* part = base + (size_t)min(t0 + u, cnt - 1) * pstride;
+                xb[u] = part[n_out * HID + j];
+                xl[u] = part[n_out * HID + n_out + j];
+            }
+#pragma unroll
+            for (int u = 0; u < HB; ++u)
+                if (t0 + u < cnt) {
+                    sb += xb[u];
+                    sl += xl[u];
+                }
+        }
+        if (lay.off_b[y][3] >= 0) slab[lay.off_b[y][3] + j] = sb;
+        if (y == 1) slab[lay.off_logstd + j] = sl;
+    }
+}
+#endif
+
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 inline int check_layout(const rlx_mlp_layout* lay, const char* who) {

@@ -255,7 +255,7 @@ def weights_changed(model_or_state_dict) -> None:
         mark()
 
 
-def load_bucket(state: dict, bucket: dict) -> None:
+def load_bucket(state: dict, bucket: dict) -> int:
     """load_state_dict(bucket, strict=False) for the tensors of one bucket (:296-323): keys the target does not have are
     ignored, a shape mismatch raises like torch does, the copy converts to the target's dtype -- in one launch."""
     segments, errors, dev = [], [], None
@@ -274,11 +274,7 @@ def load_bucket(state: dict, bucket: dict) -> None:
     if errors:
         raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(errors))
     if not segments:
-        payload = [k for k in bucket.keys() if k not in (TOTAL_BUCKETS_KEY, SYNCER_VERSION_KEY)]
-        if payload:  # strict=False ignores unknown keys one by one; a whole bucket that lands nowhere is a wiring error
-            raise RlxError(f"weight bucket with {len(payload)} tensors (first: {payload[0]!r}) matches no key of the target "
-                           f"state dict (first target keys: {list(state)[:3]})")
-        return
+        return 0
     flat = getattr(bucket, "flat", None)
     if flat is not None and not flat.is_cuda:  # host-staged flat bucket: one host-to-device copy, then re-view
         moved = WeightBucket.from_flat(flat.to(dev), bucket.layout)
@@ -293,6 +289,7 @@ def load_bucket(state: dict, bucket: dict) -> None:
     codes = [_codes(v.dtype, t.dtype, k) for (k, _, t), v in zip(segments, srcs)]
     table["src_dtype"], table["dst_dtype"] = [c[0] for c in codes], [c[1] for c in codes]
     _launch_table(table, dev)
+    return len(segments)
 
 
 class BucketWeightSyncer:
@@ -380,15 +377,21 @@ class BucketWeightSyncer:
         bucket = recv()
         total_buckets = int(bucket.pop(self._TOTAL_BUCKETS_KEY).item())
         applied_version = int(bucket.pop(self._SYNCER_VERSION_KEY).item())
-        held = []
+        held, landed, sent_keys = [], 0, []
         for k in range(total_buckets):
             if k > 0:
                 bucket = recv()
+            sent_keys.extend(key for key in bucket.keys() if key not in (TOTAL_BUCKETS_KEY, SYNCER_VERSION_KEY))
             if self.load_instant:
-                load_bucket(state, bucket)
+                landed += load_bucket(state, bucket)
             else:
                 held.append(bucket)
         for bucket in held:
-            load_bucket(state, bucket)
+            landed += load_bucket(state, bucket)
+        if sent_keys and landed == 0:
+            # strict=False ignores unknown keys one by one; a whole sync of which NOTHING lands is a wiring error (e.g. a model
+            # whose state_dict does not carry the reference's names): the replica would silently keep its old weights
+            raise RlxError(f"weight sync delivered {len(sent_keys)} tensors (first: {sent_keys[0]!r}) but none matches a key of "
+                           f"the target state dict (first target keys: {list(state)[:3]})")
         weights_changed(model_or_state_dict)
         return applied_version

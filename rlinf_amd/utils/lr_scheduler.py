@@ -77,3 +77,11 @@ class LearnerLRScheduler:
     def step(self) -> None:
         self._opt.step()  # (keeps torch's "scheduler before optimizer" check quiet; there is nothing to update)
         self._sched.step()
+
+    def state_dict(self) -> dict:
+        return {"scheduler": self._sched.state_dict(), "lrs": [g["lr"] for g in self._opt.param_groups]}
+
+    def load_state_dict(self, state: dict) -> None:
+        self._sched.load_state_dict(state["scheduler"])
+        for g, lr in zip(self._opt.param_groups, state["lrs"]):
+            g["lr"] = lr

@@ -30,6 +30,8 @@ CRITIC_EXPLAINED_VARIANCE_KEY = "critic/explained_variance"
 
 
 class EmbodiedFSDPActor(Worker):
+    ROLE = "actor"
+
     def __init__(self, cfg, ctx=None):
         super().__init__(cfg, ctx)
         self.model = None
@@ -115,10 +117,68 @@ class EmbodiedFSDPActor(Worker):
     def state_dict(self):
         return self.model.reference_state_dict()
 
+    # ---- checkpoints ------------------------------------------------------------------------------------------
+    def save_checkpoint(self, save_path: str, step: int = 0) -> None:
+        """FSDPModelManager.save_checkpoint (fsdp_model_manager.py:360-389 -> strategy/base.py:184-268), "local_shard" form:
+        every rank writes its training state (NO_SHARD: the full model, the optimizer moments and step counter, the LR
+        schedule, the RNG streams) to ``local_shard_checkpoint/checkpoint_rank_{r}.pt``; rank 0 also writes
+        ``model_state_dict/full_weights.pt`` under the reference's parameter names -- the file the reference's own
+        MLPPolicy.load_state_dict accepts."""
+        import os
+        shard_dir = os.path.join(save_path, "local_shard_checkpoint")
+        os.makedirs(shard_dir, exist_ok=True)
+        state = {
+            "model": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+            "optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step_state": self.step_state.cpu(),
+                          "optimizer_steps": self.optimizer_steps, "critic_warmup_steps": self.critic_warmup_steps},
+            "lr_scheduler": self.lr_scheduler.state_dict(),
+            "rng": {"torch": torch.get_rng_state(),
+                    "cuda": torch.cuda.get_rng_state(self.device) if self.device is not None and self.device.type == "cuda" else None,
+                    "pipeline_shuffle": self._pipe_gen.get_state() if self.use_training_pipeline else None},
+            "version": self.version, "step": int(step), "world_size": self._world_size, "n_params": self.model.n_params,
+        }
+        torch.save(state, os.path.join(shard_dir, f"checkpoint_rank_{self._rank}.pt"))
+        if self._rank == 0:
+            sd_dir = os.path.join(save_path, "model_state_dict")
+            os.makedirs(sd_dir, exist_ok=True)
+            torch.save(state["model"], os.path.join(sd_dir, "full_weights.pt"))
+        if self._world_size > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def load_checkpoint(self, load_path: str) -> None:
+        """FSDPModelManager.load_checkpoint (:342-358): restores what save_checkpoint wrote, IN PLACE -- every device buffer
+        keeps its address, so prepared launch plans and captured hipGraphs stay valid.  A directory that only holds
+        ``model_state_dict/full_weights.pt`` (e.g. written by the reference) loads the weights alone."""
+        import os
+        shard = os.path.join(load_path, "local_shard_checkpoint", f"checkpoint_rank_{self._rank}.pt")
+        if not os.path.exists(shard):
+            full = os.path.join(load_path, "model_state_dict", "full_weights.pt")
+            assert os.path.exists(full), f"no checkpoint under {load_path}"
+            self.model.load_state_dict(torch.load(full, map_location="cpu", weights_only=False))
+            return
+        state = torch.load(shard, map_location="cpu", weights_only=False)
+        assert state["n_params"] == self.model.n_params, "checkpoint holds a different model"
+        self.model.load_state_dict(state["model"])
+        o = state["optimizer"]
+        self.exp_avg.copy_(o["exp_avg"]), self.exp_avg_sq.copy_(o["exp_avg_sq"]), self.step_state.copy_(o["step_state"])
+        self.optimizer_steps, self.critic_warmup_steps = int(o["optimizer_steps"]), int(o["critic_warmup_steps"])
+        self.lr_scheduler.load_state_dict(state["lr_scheduler"])
+        self._apply_lrs()
+        torch.set_rng_state(state["rng"]["torch"])
+        if state["rng"]["cuda"] is not None and self.device is not None and self.device.type == "cuda":
+            torch.cuda.set_rng_state(state["rng"]["cuda"], self.device)
+        if self.use_training_pipeline and state["rng"]["pipeline_shuffle"] is not None:
+            self._pipe_gen.set_state(state["rng"]["pipeline_shuffle"])
+        self.version = int(state["version"])
+
     # ---- trajectories -----------------------------------------------------------------------------------------
-    def recv_rollout_trajectories(self, trajectories: list):
+    def recv_rollout_trajectories(self, input_channel=None):
+        """``input_channel``: the reference's channel (:186-207: ``split_num`` gets) or, for this package's own callers, the
+        list of trajectory views itself."""
         send_num = self._world_size * self.cfg.rollout.get("pipeline_stage_num", 1)
         split_num = compute_split_num(send_num, self._world_size)
+        trajectories = input_channel if isinstance(input_channel, (list, tuple)) else [input_channel.get() for _ in range(split_num)]
         assert len(trajectories) == split_num, f"expected {split_num} trajectories, got {len(trajectories)}"
         self.rollout_batch = self._process_received_rollout_batch(convert_trajectories_to_batch(trajectories))
 
@@ -430,7 +490,7 @@ class EmbodiedFSDPActor(Worker):
         self._lr_log.extend([(self._lrs[0], self._lrs[1])] * len(plan))
         return len(plan)
 
-    def run_training(self) -> dict:
+    def run_training(self, input_channel=None) -> dict:
         a, alg = self.cfg.actor, self.cfg.algorithm
         with self.timer("run_training"):
             flat, N = self._flatten_and_shuffle()
@@ -442,7 +502,7 @@ class EmbodiedFSDPActor(Worker):
                                  torch.zeros(n_steps, 2, device=self.device))
             metrics_dev, norms_dev = self._ws[key]
             self._lr_log = []  # (actor lr, critic lr or None) per optimizer step of this call
-            if self.enable_hip_graph and self.critic_warmup_steps == 0 and self.lr_scheduler.is_static:
+            if self.enable_hip_graph and self.critic_warmup_steps == 0 and self.lr_scheduler.is_static and self._capturable():
                 self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
             else:
                 self._run_update(flat, N, metrics_dev, norms_dev)
@@ -451,6 +511,15 @@ class EmbodiedFSDPActor(Worker):
                 self._xgmi.check_status()  # a peer that never published its gradient: raise instead of training on garbage
             self._step_lr_scheduler()
             return out
+
+    def _capturable(self) -> bool:
+        """The update phase can live in a hipGraph when its launches are all stream operations: always on one GPU; at
+        world_size > 1 with the xGMI all-reduce (pure kernels) or with RCCL (stream-ordered, capturable) -- not with a
+        host-staged backend such as gloo."""
+        if self._world_size == 1 or self._xgmi is not None:
+            return True
+        import torch.distributed as dist
+        return dist.get_backend() == "nccl"
 
     def _replay_or_capture(self, flat, N, metrics_dev, norms_dev, n_steps):
         """hipGraph of the whole update phase (all epochs x minibatches): every buffer is persistent and the step

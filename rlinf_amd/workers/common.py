@@ -31,6 +31,8 @@ class Handle:
 class Worker:
     """Base class: rank bookkeeping + the ``timer`` metrics of rlinf/scheduler/worker/worker.py:1322-1376."""
 
+    ROLE = None  # "actor" / "rollout" / "env": the key under which the process-local peers find each other
+
     def __init__(self, cfg, ctx=None):
         from ..scheduler import DistContext
 
@@ -55,15 +57,40 @@ class Worker:
         return out
 
 
+# The workers of THIS process by role ("actor" / "rollout" / "env"): what the reference reaches through named Ray groups and
+# channels (``self.send_to(group_name=cfg.rollout.group_name, ...)``) is a direct object reference here.
+_PEERS: dict = {}
+
+
+def peer(role: str):
+    return _PEERS.get(role)
+
+
+def _role_of(cls) -> str:
+    return getattr(cls, "ROLE", None) or cls.__name__
+
+
 class _Group:
     """``Worker.create_group(cfg).launch(cluster, name=..., placement_strategy=...)`` -> the local worker, whose
-    methods return Handles."""
+    methods return Handles.  The rank context comes from ``create_group(cfg, ctx)`` (this package's own callers), from the
+    ``cluster`` (the reference's call, rlinf_amd.scheduler.Cluster) or from the torchrun environment, in that order."""
 
     def __init__(self, cls, cfg, ctx):
         self._cls, self._cfg, self._ctx = cls, cfg, ctx
 
     def launch(self, cluster=None, name: str = "", placement_strategy=None):
-        return _HandleProxy(self._cls(self._cfg, self._ctx))
+        ctx = self._ctx
+        if ctx is None and cluster is not None:
+            ctx = getattr(cluster, "ctx", None)
+        if ctx is None and placement_strategy is not None:
+            ctx = getattr(placement_strategy, "ctx", None)
+        if ctx is None:
+            from ..scheduler import init_distributed
+            ctx = init_distributed()
+        worker = self._cls(self._cfg, ctx)
+        worker.group_name = name
+        _PEERS[_role_of(self._cls)] = worker
+        return _HandleProxy(worker)
 
 
 class _HandleProxy:

@@ -15,10 +15,12 @@ from ... import ops
 from ...data import TrajectoryBuffer
 from ...envs.synthetic_env import SyntheticManiSkillEnv, generate_tensors
 from ...scheduler.placement import compute_split_num, env_shard
-from ..common import Worker
+from ..common import Worker, peer
 
 
 class EnvWorker(Worker):
+    ROLE = "env"
+
     def __init__(self, cfg, ctx=None):
         super().__init__(cfg, ctx)
         self.train_cfg = cfg.env.train
@@ -42,6 +44,8 @@ class EnvWorker(Worker):
         self.rollout = None
         self._graph = None
         self._eps = None
+        self._prefetched_train_bootstrap = None
+        self._eval_env = None
 
     def init_worker(self, env_tensors: dict | None = None):
         m = self.cfg.actor.model
@@ -70,9 +74,38 @@ class EnvWorker(Worker):
         flags = dones if self.bootstrap_type == "always" else truncations
         return ops.bootstrap_rewards_(rewards, flags, bootstrap_values, self.gamma)
 
-    def interact(self, eps: torch.Tensor | None = None, mode: str = "train"):
+    def interact(self, input_channel=None, rollout_channel=None, reward_channel=None, actor_channel=None,
+                 eps: torch.Tensor | None = None, mode: str = "train"):
         """``rollout_epoch`` epochs of T chunk steps + a closing value row each.  ``eps`` [rollout_epoch * T, B, A] injects
-        the N(0,1) draws (drawn on the device otherwise)."""
+        the N(0,1) draws (drawn on the device otherwise).
+
+        The reference's signature (env_worker.py:1058: four channels): observations and actions travel over
+        ``rollout_channel`` / ``input_channel`` there, the finished trajectories over ``actor_channel``.  In-process the
+        policy is called directly; with an ``actor_channel`` the trajectory views are put on it for
+        ``actor.recv_rollout_trajectories(input_channel=...)``.  This package's own callers pass ``eps`` as the first
+        positional argument (a tensor, or None)."""
+        if isinstance(input_channel, torch.Tensor):  # interact(eps): the package's own call style
+            eps, input_channel = input_channel, None
+        if self.rollout is None:
+            self.rollout = peer("rollout")
+        self._prefetched_train_bootstrap = None  # consumed: the first observation batch is resident (env.reset(0))
+        out = self._interact(eps, mode)
+        if actor_channel is not None:
+            for traj in self.send_rollout_trajectories():
+                actor_channel.put(traj)
+        return out
+
+    def prefetch_train_bootstrap(self, rollout_channel=None) -> None:
+        """"Prepare and send the first env batch for the next training rollout" (env_worker.py:999-1009, behind
+        runner.overlap_env_bootstrap): overlaps the simulator reset with the learner's update.  The synthetic env's
+        observations are resident tensors, so there is nothing to prepare; the call keeps the reference's contract (one
+        outstanding prefetch, consumed by interact())."""
+        if self._prefetched_train_bootstrap is not None:
+            raise RuntimeError("A prefetched train bootstrap already exists. "
+                               "Call interact() to consume it before prefetching again.")
+        self._prefetched_train_bootstrap = True
+
+    def _interact(self, eps: torch.Tensor | None = None, mode: str = "train"):
         if self._eps is None:
             self._eps = torch.empty(self.n_train_chunk_steps * self.rollout_epoch, self.num_envs, self.buffer.A,
                                     device=self.device)
@@ -122,6 +155,52 @@ class EnvWorker(Worker):
                         ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
                 ro.get_bootstrap_values(obs, out=buf.prev_values[T, cols])  # closing row of the epoch: values only
         return None
+
+    def evaluate(self, input_channel=None, rollout_channel=None) -> dict:
+        """EnvWorker.evaluate (env_worker.py:1374-1461): ``eval_rollout_epoch`` epochs of ``n_eval_chunk_steps`` on the eval
+        envs with the policy acting in eval mode (its mean, mlp_policy.py:230-236); the per-episode records of the envs that
+        finished (ManiSkill's ``final_info["episode"]``: return / episode_len / reward, maniskill_env.py:300-325) are
+        returned as tensors for compute_evaluate_metrics.  Nothing is written to the training buffer."""
+        ev = self.cfg.env.get("eval", None) or self.train_cfg
+        m = self.cfg.actor.model
+        if self.rollout is None:
+            self.rollout = peer("rollout")
+        steps = int(ev.get("max_steps_per_rollout_epoch", self.train_cfg.max_steps_per_rollout_epoch)) // m.num_action_chunks
+        epochs = int(ev.get("rollout_epoch", 1))
+        total = int(ev.get("total_num_envs", self.train_cfg.total_num_envs))
+        auto_reset = bool(ev.get("auto_reset", True))
+        if self._eval_env is None:
+            begin, end = (total // self._world_size) * self._rank, (total // self._world_size) * (self._rank + 1)
+            tensors = generate_tensors(int(ev.get("seed", 0)) + 1_000_003, steps * epochs, total, m.obs_dim,
+                                       int(ev.get("max_episode_steps", self.train_cfg.get("max_episode_steps", 50))),
+                                       mode=ev.get("synthetic_done_mode", "periodic"))
+            self._eval_env = SyntheticManiSkillEnv(tensors, self.device, m.num_action_chunks, auto_reset, slice(begin, end))
+        env, ro = self._eval_env, self.rollout
+        n = env.num_envs
+        ret = torch.zeros(n, device=self.device)
+        length = torch.zeros(n, device=self.device)
+        prev_done = torch.zeros(n, dtype=torch.bool, device=self.device)
+        records: dict = {"return": [], "episode_len": [], "reward": []}
+        for epoch in range(epochs):
+            if not auto_reset or epoch == 0:
+                obs, _ = env.reset(epoch * steps)
+                prev_done.zero_()
+            for _ in range(steps):
+                actions = ro.predict(obs, eps=None, mode="eval")
+                obs, rewards, term, trunc, _ = env.chunk_step(actions)
+                ret += rewards.sum(dim=1)
+                length += rewards.shape[1]
+                done = (term | trunc).any(dim=1)
+                newly = done if auto_reset else done & ~prev_done
+                prev_done |= done
+                if bool(newly.any()):
+                    records["return"].append(ret[newly].cpu())
+                    records["episode_len"].append(length[newly].cpu())
+                    records["reward"].append((ret[newly] / length[newly]).cpu())
+                    if auto_reset:
+                        ret[newly], length[newly] = 0.0, 0.0
+        ro.flush_bootstrap()
+        return {k: torch.cat(v, dim=0).contiguous() for k, v in records.items() if v}
 
     def send_rollout_trajectories(self, actor_world_size: int | None = None) -> list:
         """to_splited_trajectories(actor_split_num) (env_worker.py:1026,1463-1467): views, no copies."""

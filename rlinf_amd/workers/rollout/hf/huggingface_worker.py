@@ -8,10 +8,12 @@ import torch
 
 from .... import ops
 from ....models import get_model
-from ...common import Worker
+from ...common import Worker, peer
 
 
 class MultiStepRolloutWorker(Worker):
+    ROLE = "rollout"
+
     def __init__(self, cfg, ctx=None):
         super().__init__(cfg, ctx)
         self.hf_model = None
@@ -21,11 +23,18 @@ class MultiStepRolloutWorker(Worker):
 
     def init_worker(self, model=None):
         """``model``: when rollout and learner are collocated (component_placement ``env,rollout,actor: 0``) the
-        rollout worker can alias the learner's policy object -- weight sync becomes a no-op."""
+        rollout worker can alias the learner's policy object -- weight sync becomes a no-op.  Called the
+        reference's way (no argument, BEFORE the actor is initialised, embodied_runner.py:163-170) the decision is deferred to
+        the first ``sync_model_from_actor()``: alias the in-process learner's model unless ``rollout.share_actor_weights`` is
+        off (a rollout that must keep its weights frozen while the learner updates, e.g. the overlapped pipeline)."""
         if model is not None:
             self.hf_model, self._shares_actor_weights = model, True
-        else:
+        elif not (bool(self.cfg.rollout.get("share_actor_weights", True)) and peer("actor") is not None):
             self.hf_model = get_model(self.cfg.actor.model).to(self.device)
+
+    def adopt_model(self, model):
+        """Alias the collocated learner's policy object."""
+        self.hf_model, self._shares_actor_weights = model, True
 
     def set_global_step(self, step: int):
         self.version = step
@@ -34,6 +43,16 @@ class MultiStepRolloutWorker(Worker):
         """Apply the learner's weights (huggingface_worker.py:629-675).  Flat-buffer copy, or nothing when aliased; then
         rebuild the fragment-tile weight image HERE, eagerly: the rollout loop may be a replayed hipGraph, which must
         find fresh tiles in the same buffer (a lazy rebuild inside the captured region would be frozen out of it)."""
+        actor = peer("actor")
+        if self.hf_model is None:  # deferred by init_worker(): collocated -> alias the learner's policy object
+            if actor is None or actor.model is None:
+                raise RuntimeError("sync_model_from_actor: no initialised in-process actor to take the weights from")
+            if bool(self.cfg.rollout.get("share_actor_weights", True)):
+                self.adopt_model(actor.model)
+            else:
+                self.hf_model = get_model(self.cfg.actor.model).to(self.device)
+        if flat_params is None and not self._shares_actor_weights and actor is not None and actor.model is not None:
+            flat_params = actor.model.flat.data  # the reference's call carries no argument: the weights come over its channel
         if not (self._shares_actor_weights or flat_params is None):
             with torch.no_grad():
                 self.hf_model.flat.data.copy_(flat_params)
@@ -85,7 +104,12 @@ class MultiStepRolloutWorker(Worker):
         ops.mlp_rollout_step(m.flat.data, m.tiles(), m.layout, None, None, value_jobs=jobs)
         return out[:, :1]
 
-    def generate(self, *args, **kwargs):
-        """The reference runs this concurrently with EnvWorker.interact over channels; in-process the env worker
-        calls predict() directly, so there is nothing left to do here."""
+    def generate(self, input_channel=None, output_channel=None, **kwargs):
+        """The reference runs this concurrently with EnvWorker.interact over channels (huggingface_worker.py:677-800);
+        in-process the env worker calls predict() directly, so there is nothing left to do here."""
+        return None
+
+    def evaluate(self, input_channel=None, output_channel=None, **kwargs):
+        """Eval-mode counterpart of generate (huggingface_worker.py: the policy acts with its mean, mlp_policy.py:230-236):
+        EnvWorker.evaluate drives predict(mode="eval") directly."""
         return None

@@ -34,8 +34,8 @@ def _launch(mode, tmp_path, *extra, port=29611, timeout=300, one_device=True):
                 q.kill()
             raise
         logs.append(log)
-    for p, log in zip(procs, logs):
-        assert p.returncode == 0, log[-3000:]
+    if any(p.returncode != 0 for p in procs):  # the first rank to die is the one with the story; show every rank
+        raise AssertionError("\n".join(f"---- rank {r} rc={p.returncode} ----\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs))))
     return outs
 
 
@@ -62,7 +62,7 @@ def _two_gpus():
     ("xgmi", "0", "gloo"),   # the hand-written peer-read all-reduce over IPC-mapped buffers, two ranks on ONE GPU
     ("xgmi", "1", "gloo"),   # ... inside the captured hipGraph of the update phase (replayed twice)
     ("rccl", "0", "gloo"),   # torch.distributed all-reduce (gloo stands in for RCCL: it needs a device per rank)
-    ("rccl", "1", "gloo"),   # capture cannot hold a gloo all-reduce: both ranks must agree to fall back to the eager loop
+    ("rccl", "1", "gloo"),   # a gloo all-reduce cannot be stream-captured: the worker keeps the eager (prepared-launch) loop
     pytest.param("rccl", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="RCCL needs one GPU per rank")),
     pytest.param("xgmi", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")),
 ])

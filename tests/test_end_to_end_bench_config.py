@@ -95,12 +95,14 @@ def _report(name, payload):
     print(f"[{name}] {payload}")
 
 
-def test_bench_configuration_f32_matches_oracle_with_graph_replay():
-    """exact-f32 mode, hipGraph on: iteration 0 runs eagerly and captures (rollout loop and update phase), iteration 1 is
-    replayed -- both against the oracle, every tensor of the rollout batch, all 128 per-step scalars, the parameters."""
+@pytest.mark.parametrize("graph", [True, False])
+def test_bench_configuration_f32_matches_oracle(graph):
+    """exact-f32 mode.  graph=True is the benchmarked mode: iteration 0 runs eagerly and captures (rollout loop and update
+    phase), iteration 1 is replayed; graph=False launches everything eagerly -- both against the oracle: every tensor of the
+    rollout batch, all 128 per-step scalars, the parameters."""
     env = _env()
     ora, sd, opt = _oracle()
-    runner = _runner("32", True, sd)
+    runner = _runner("32", graph, sd)
     w = runner.actor.worker
     for it in range(2):
         eps = torch.randn(T, B, A, generator=torch.Generator().manual_seed(100 + it))
@@ -109,7 +111,26 @@ def test_bench_configuration_f32_matches_oracle_with_graph_replay():
         t_oracle = time.perf_counter() - t0
         metrics = runner.run_step(eps.cuda())
         rb = w.rollout_batch
-        tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=1e-2, atol=2e-3)  # iteration 1 starts from drifted weights
+        got, want = _per_step(w), _oracle_per_step(om)
+        dev = {}
+        for k in want:
+            scale = float(want[k].abs().max()) + 1e-6
+            err = (got[k] - want[k]).abs() / scale
+            dev[k] = [float(err[0]), float(err.max())]
+        diff = (w.model.flat.detach().cpu() - _flat(ora)).abs()
+        steps_taken = N_STEPS * (it + 1)
+        moved = (_flat(ora) - torch.cat([v.reshape(-1) for v in sd.values()])).abs()
+        frac_far = float((diff > 0.1 * LR * steps_taken).float().mean())
+        rollout_dev = {k: float((rb[k].cpu() - batch[k]).abs().max()) for k in ("prev_logprobs", "prev_values", "rewards", "returns", "advantages")}
+        rollout_dev["action"] = float((rb["forward_inputs"]["action"].cpu() - batch["forward_inputs"]["action"]).abs().max())
+        _report("f32_graph" if graph else "f32_eager",
+                dict(iteration=it, oracle_s=round(t_oracle, 1), rollout_max_abs_dev=rollout_dev, per_step_rel_err_first_max=dev,
+                     param_max=float(diff.max()), param_rms=float(diff.pow(2).mean().sqrt()),
+                     update_rms=float(moved.pow(2).mean().sqrt()), frac_beyond_10pct_budget=frac_far))
+        # iteration 0 starts from identical weights: f32-tight.  Iteration 1 starts from weights that differ by Adam's
+        # amplification of rounding (measured: <= 3e-6 per element), so its rollout is held to 1e-4 and its later optimizer
+        # steps to a few per cent of each scalar's scale.
+        tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=1e-3, atol=2e-4)
         torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), batch["forward_inputs"]["action"], **tol)
         torch.testing.assert_close(rb["prev_logprobs"].cpu(), batch["prev_logprobs"], **tol)
         torch.testing.assert_close(rb["prev_values"].cpu(), batch["prev_values"], **tol)
@@ -117,27 +138,13 @@ def test_bench_configuration_f32_matches_oracle_with_graph_replay():
         assert torch.equal(rb["dones"].cpu(), batch["dones"])
         torch.testing.assert_close(rb["returns"].cpu(), batch["returns"], **tol)
         torch.testing.assert_close(rb["advantages"].cpu(), batch["advantages"], rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
-        got, want = _per_step(w), _oracle_per_step(om)
-        dev = {}
-        for k in want:
-            scale = float(want[k].abs().max()) + 1e-6
-            err = (got[k] - want[k]).abs() / scale
-            dev[k] = [float(err[0]), float(err.max())]
-            if it == 0:  # the first optimizer step sees no drift at all
-                assert float(err[0]) <= (1e-4 if k != "actor/clip_fraction" else 1e-3), (k, float(got[k][0]), float(want[k][0]))
-            # every later step inherits Adam's drift; smooth scalars stay within 2 % of their scale, the clip fraction (a
-            # count of samples across a boundary) within 3 % absolute
-            assert float(err.max()) <= (0.03 if k == "actor/clip_fraction" else 0.02) * (1 + it), (k, it, float(err.max()))
+        for k, (first, worst) in dev.items():
+            # the first optimizer step of an iteration sees no drift within the iteration
+            assert first <= (1e-4 if it == 0 else 2e-3), (k, it, first)
+            assert worst <= (1e-3 if it == 0 else 0.08), (k, it, worst)
         assert metrics["train/actor/approx_kl"] == pytest.approx(float(want["actor/approx_kl"].mean()), rel=2e-2 * (1 + it), abs=2e-5)
         assert metrics["train/actor/grad_norm"] == pytest.approx(float(want["actor/grad_norm"].mean()), rel=1e-2 * (1 + it))
         assert metrics["rollout/rewards"] == pytest.approx(float(batch["rewards"].mean()), rel=1e-4)
-        diff = (w.model.flat.detach().cpu() - _flat(ora)).abs()
-        steps_taken = N_STEPS * (it + 1)
-        moved = (_flat(ora) - torch.cat([v.reshape(-1) for v in sd.values()])).abs()
-        frac_far = float((diff > 0.1 * LR * steps_taken).float().mean())
-        _report("f32_graph", dict(iteration=it, oracle_s=round(t_oracle, 1), per_step_rel_err_first_max=dev,
-                                  param_max=float(diff.max()), param_rms=float(diff.pow(2).mean().sqrt()),
-                                  update_rms=float(moved.pow(2).mean().sqrt()), frac_beyond_10pct_budget=frac_far))
         assert float(diff.max()) <= 2 * LR * steps_taken + 1e-6
         # the bulk: the RMS difference is a small fraction of the RMS distance the parameters travelled
         assert float(diff.pow(2).mean().sqrt()) <= 0.05 * float(moved.pow(2).mean().sqrt()), (it, float(diff.pow(2).mean().sqrt()))
@@ -177,10 +184,10 @@ def test_first_optimizer_step_gradient_at_bench_configuration(precision):
     def oracle_grad(autocast):
         pol = O.OracleMLPPolicy(D, A, 1)
         pol.load_state_dict(sd)
-        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
-            batch = L.advantages(L.rollout(pol, env, eps, 0.8, True), 0.8, 0.9, True)
-            fl = O.flatten_and_shuffle(batch, torch.randperm(T * B, generator=torch.Generator().manual_seed(1234)))
-            m0 = O.chunk_batch(fl, T * B // GB)[0]
+        batch = L.advantages(L.rollout(pol, env, eps, 0.8, True, autocast=autocast), 0.8, 0.9, True)
+        fl = O.flatten_and_shuffle(batch, torch.randperm(T * B, generator=torch.Generator().manual_seed(1234)))
+        m0 = O.chunk_batch(fl, T * B // GB)[0]
+        with O.amp(autocast):  # amp_context around the model forward only (embodied_fsdp_actor_worker.py:624-632)
             out = pol.evaluate(m0["forward_inputs"]["states"], m0["forward_inputs"]["action"])
         out = {k: v.float() for k, v in out.items()}
         shaped = O.shape_loss_inputs(out["logprobs"], m0["prev_logprobs"], m0["advantages"], "action_level", A,
@@ -236,8 +243,7 @@ def test_bench_configuration_bf16_matches_autocast_oracle_with_graph_replay():
         eps = torch.randn(T, B, A, generator=torch.Generator().manual_seed(100 + it))
         b32, om32 = L.iteration(ora32, opt32, env, eps, **kw)
         t0 = time.perf_counter()
-        with torch.autocast("cpu", dtype=torch.bfloat16):
-            b16, om16 = L.iteration(ora16, opt16, env, eps, **kw)
+        b16, om16 = L.iteration(ora16, opt16, env, eps, autocast=True, **kw)
         t_auto = time.perf_counter() - t0
         metrics = runner.run_step(eps.cuda())
         rb = w.rollout_batch

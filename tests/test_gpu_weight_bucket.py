@@ -252,9 +252,9 @@ def test_apply_into_mlp_policy_changes_weights_and_derived_images(syncer_kind):
     assert torch.equal(actor.flat, replica.flat)
     fresh = ops.mlp_pack_tiles(actor.flat.data, actor.layout)
     assert torch.equal(replica.tiles(), fresh) and not torch.equal(stale_tiles, fresh)
-    if syncer_kind == "bucket":  # a bucket that lands nowhere is a wiring error, not a no-op
-        from rlinf_amd.hybrid_engines.weight_syncer.bucket_syncer import WeightBucket, load_bucket
-        last = sent[-1]
-        bogus = WeightBucket.from_flat(last.flat, [("nowhere." + k, d, sh, o) for (k, d, sh, o) in last.layout])
-        with pytest.raises(RlxError, match="matches no key"):
-            load_bucket(replica.state_dict(), bogus)
+    if syncer_kind == "bucket":  # a sync of which nothing lands is a wiring error, not a no-op
+        sent_again = []
+        tx.sync(actor.state_dict(), sent_again.append, 4)
+        it = iter(sent_again)
+        with pytest.raises(RlxError, match="none matches a key"):
+            rx.apply({"some.other.module.weight": torch.zeros(4, 4, device="cuda")}, lambda: next(it))
