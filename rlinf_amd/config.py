@@ -255,6 +255,14 @@ def validate_cfg(cfg) -> DictConfig:
     """Fill defaults and assert consistency; returns the config (rlinf/config.py:1455-1566)."""
     if not isinstance(cfg, DictConfig):
         cfg = DictConfig(cfg)
+    # rlinf/config.py:1458-1464: per-worker logging defaults the entry point hands to Cluster
+    cfg.runner.per_worker_log = cfg.runner.get("per_worker_log", False)
+    cfg.runner.per_worker_log_path = None
+    if cfg.runner.per_worker_log:
+        cfg.runner.per_worker_log_path = os.path.join(cfg.runner.logger.log_path, "worker_logs")
+    if cfg.get("cluster", None) is None:  # configs built in code (tests, bench.py): the collocated single-node placement
+        cfg.cluster = DictConfig({"num_nodes": 1, "component_placement": {"env,rollout,actor": "all"}})
+    cfg.runner.save_interval = cfg.runner.get("save_interval", -1)
     task = cfg.runner.get("task_type", None)
     assert task in ("embodied",), f"task_type {task!r} is not served by this build (embodied only)"
     alg = cfg.algorithm
