@@ -191,9 +191,14 @@ __device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step
     sc->beta2 = (float)a.beta2;
     sc->eps = (float)a.eps;
     for (int k = 0; k < RLX_ADAMW_MAX_GROUPS; ++k) {
-        const double lr = k < a.n_groups ? a.groups[k].lr : 0.0;
-        sc->step_size[k] = (float)(lr / bc1);
-        sc->decay[k] = (float)(1.0 - lr * a.weight_decay);
+        if (k < a.n_groups) {  // one double division per LIVE group: this lane is the launch's critical path
+            const double lr = a.groups[k].lr;
+            sc->step_size[k] = (float)(lr / bc1);
+            sc->decay[k] = (float)(1.0 - lr * a.weight_decay);
+        } else {
+            sc->step_size[k] = 0.f;
+            sc->decay[k] = 1.f;
+        }
     }
 }
 

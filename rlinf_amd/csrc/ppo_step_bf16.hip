@@ -29,7 +29,8 @@ template <int RT, int NW>
 struct GeoB {
     static constexpr int BM = 16 * RT, NT = 64 * NW, CT = HID / (16 * NW);
     static constexpr int SLAB_FLOATS = BM * XSB / 2;  // the bf16 slab measured in floats
-    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 4 * BM * MAX_OUT;
+    // head image + bias | sHead, sLp, sG, sD | sOld, sAct, sAdv, sRet (the tile's loss inputs, staged at kernel start)
+    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 8 * BM * MAX_OUT;
     static constexpr size_t LDS_BYTES = (size_t)(SLAB_FLOATS + AUX_FLOATS) * sizeof(float) + 4096;
 };
 
@@ -123,7 +124,7 @@ struct RowGemmB {
 // The accumulator layout holds 4 consecutive rows of one column per register quad -> 8 contiguous bytes; the four
 // row-quads x sixteen columns of a wave instruction land in one contiguous 512-byte run.
 template <int RT, int NW>
-__device__ __forceinline__ void store_tiles(const bf16x4 (&v)[RT][GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
+__device__ __forceinline__ void store_tiles(const bf16x4 (*v)[GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
     constexpr int CT = GeoB<RT, NW>::CT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -146,13 +147,24 @@ __device__ __forceinline__ void load_states_b(const float* __restrict__ states, 
                                               __bf16* __restrict__ st_tiles, int nrb, int D, long long m0, long long M, __bf16* Xb) {
     typedef GeoB<RT, NW> G;
     const int kp = round_up(D, KPAD);
-    for (int i = threadIdx.x; i < G::BM * kp; i += G::NT) {
-        const int r = i / kp, c = i % kp;
-        const bool ok = c < D && m0 + r < M;
-        const size_t src = (size_t)min(m0 + r, M - 1) * D + min(c, D - 1);  // clamped, unconditional load
-        const float x = states[src];
-        if (ok && states_copy) states_copy[src] = x;
-        Xb[r * XSB + c] = (__bf16)(ok ? x : 0.f);
+    constexpr int UB = 8;  // loads in flight per lane: the whole tile (BM x 64 / NT = 8 at BM = 64) travels in ONE round trip
+    for (int i0 = threadIdx.x; i0 < G::BM * kp; i0 += G::NT * UB) {
+        float x[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = min(i0 + u * G::NT, G::BM * kp - 1);
+            const int r = i / kp, c = i % kp;
+            x[u] = states[(size_t)min(m0 + r, M - 1) * D + min(c, D - 1)];  // clamped, unconditional load
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + u * G::NT;
+            if (i >= G::BM * kp) continue;
+            const int r = i / kp, c = i % kp;
+            const bool ok = c < D && m0 + r < M;
+            if (ok && states_copy) states_copy[(size_t)(m0 + r) * D + c] = x[u];
+            Xb[r * XSB + c] = (__bf16)(ok ? x[u] : 0.f);
+        }
     }
     if (st_tiles != nullptr) {
         lds_barrier();
@@ -168,27 +180,49 @@ __device__ __forceinline__ void load_states_b(const float* __restrict__ states, 
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// tanh for two values at once, bf16 path: 1 - 2 / (exp(2x) + 1) with v_exp_f32 / v_rcp_f32 and packed f32 arithmetic
+// (v_pk_mul / v_pk_add / v_pk_fma).  ~6e-8 absolute error: far inside the 2^-9 relative rounding the result gets next.  The
+// f32 kernels keep the polynomial form (2e-7 RELATIVE near zero); here the epilogues are VALU-bound (phase stamps: three of
+// them were 18 k of the kernel's 65 k cycles at ~27 issue slots per element) and this is ~10 slots per element.
+__device__ __forceinline__ f32x2 tanh2_b(f32x2 x) {
+    const f32x2 t = x * 2.8853900817779268f;  // 2 log2(e)
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2 d = e + 1.f;
+    f32x2 q;
+    q.x = __builtin_amdgcn_rcpf(d.x);
+    q.y = __builtin_amdgcn_rcpf(d.y);
+    return __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f});
+}
+
 // forward hidden-layer epilogue: h = bf16(tanh(acc + bias)) -> slab; KEEP: 1 - h^2 of the ROUNDED value and the tile store
 template <int RT, int NW, bool KEEP>
 __device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, NW>::CT], const float* __restrict__ bias, __bf16* Xb,
-                                                f32x4 (*kept)[GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
+                                                bf16x4 (*kept)[GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
     typedef GeoB<RT, NW> G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
-    bf16x4 hv[RT][G::CT];
+    bf16x4 hloc[KEEP ? 1 : RT][G::CT];  // KEEP: the caller's `kept` holds the rounded activations (the backward sweep forms 1 - h^2 from them)
+    bf16x4 (*hv)[G::CT] = KEEP ? kept : hloc;
+    float b[G::CT];
+#pragma unroll
+    for (int ct = 0; ct < G::CT; ++ct) b[ct] = bias[wave * 16 * G::CT + ct * 16 + r16];  // both loads in flight together
 #pragma unroll
     for (int ct = 0; ct < G::CT; ++ct) {
         const int col = wave * 16 * G::CT + ct * 16 + r16;
-        const float b = bias[col];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const __bf16 hb = (__bf16)fast_tanh(acc[rt][ct][r] + b);
-                Xb[(rt * 16 + 4 * kq + r) * XSB + col] = hb;
-                hv[rt][ct][r] = hb;
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 h = tanh2_b(f32x2{acc[rt][ct][r] + b[ct], acc[rt][ct][r + 1] + b[ct]});
+                const __bf16 h0 = (__bf16)h.x, h1 = (__bf16)h.y;
+                Xb[(rt * 16 + 4 * kq + r) * XSB + col] = h0;
+                Xb[(rt * 16 + 4 * kq + r + 1) * XSB + col] = h1;
                 if constexpr (KEEP) {
-                    const float hf = (float)hb;
-                    kept[rt][ct][r] = 1.f - hf * hf;
+                    hv[rt][ct][r] = h0;
+                    hv[rt][ct][r + 1] = h1;
                 }
             }
     }
@@ -196,6 +230,13 @@ __device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, 
         if (dst != nullptr) store_tiles<RT, NW>(hv, dst, nrb, m0);
     }
     lds_barrier();
+}
+
+// tanh'(z) = 1 - h^2 from the rounded activation the forward sweep kept (two bf16 -> f32 shifts and one fma per element:
+// cheaper than carrying 96 f32 registers through the whole kernel, which pushed it into scratch)
+__device__ __forceinline__ float dtanh_b(__bf16 h) {
+    const float hf = (float)h;
+    return fmaf(-hf, hf, 1.f);
 }
 
 __device__ __forceinline__ float head_dot_b(const __bf16* xr, const float* wr, float bias, bool has_bias) {
@@ -314,6 +355,12 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     float* sLp = sHead + BM * MAX_OUT;
     float* sG = sLp + BM * MAX_OUT;
     float* sD = sG + BM * MAX_OUT;
+    // the tile's loss inputs, requested before the first GEMM so that their (memory-side) latency hides behind the forward
+    // sweeps: old log-probs and actions [BM][act_dim]; advantages [BM][npr] (actor) or prev_values [BM][n_out] (critic); returns
+    float* sOld = sD + BM * MAX_OUT;
+    float* sAct = sOld + BM * MAX_OUT;
+    float* sAdv = sAct + BM * MAX_OUT;
+    float* sRet = sAdv + BM * MAX_OUT;
     double* sRed = reinterpret_cast<double*>(smem + G::SLAB_FLOATS + G::AUX_FLOATS);
     double* sNm = sRed + 256;
 
@@ -345,14 +392,45 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     ts.mark();
     RowGemmB<RT, NW, PD> gemm;
     gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
-    load_states_b<RT, NW>(a.states, nullptr, y == 1 ? st_tiles : nullptr, tg.nrb, D, m0, M, Xb);
+    {
+        constexpr int PI = BM * MAX_OUT / G::NT;  // staging iterations per lane (2)
+        static_assert(BM * MAX_OUT % G::NT == 0, "staging assumes whole iterations");
+        float v0[PI], v1[PI], v2[PI];
+#pragma unroll
+        for (int u = 0; u < PI; ++u) {
+            const int i = tid + u * G::NT, row = i / MAX_OUT, c = i % MAX_OUT;
+            const size_t gr = (size_t)min(m0 + row, M - 1);
+            if (y == 1) {  // clamped, unconditional loads; junk columns are never read back
+                v0[u] = a.old_logprobs[gr * lay.act_dim + min(c, lay.act_dim - 1)];
+                v1[u] = a.action[gr * lay.act_dim + min(c, lay.act_dim - 1)];
+                v2[u] = a.advantages[gr * npr + min(c, npr - 1)];
+            } else {
+                v0[u] = p.has_critic ? a.prev_values[gr * n_out + min(c, n_out - 1)] : 0.f;
+                v1[u] = p.has_critic ? a.returns[gr * n_out + min(c, n_out - 1)] : 0.f;
+                v2[u] = 0.f;
+            }
+        }
+        load_states_b<RT, NW>(a.states, nullptr, y == 1 ? st_tiles : nullptr, tg.nrb, D, m0, M, Xb);
+#pragma unroll
+        for (int u = 0; u < PI; ++u) {
+            const int i = tid + u * G::NT;
+            if (y == 1) {
+                sOld[i] = v0[u];
+                sAct[i] = v1[u];
+                sAdv[i] = v2[u];
+            } else {
+                sAdv[i] = v0[u];
+                sRet[i] = v1[u];
+            }
+        }
+    }
     stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
     for (int i = tid; i < BM * MAX_OUT; i += G::NT) sHead[i] = 0.f;
     for (int i = n_out * W4S + tid; i < OP * W4S; i += G::NT) W4s[i] = 0.f;
     lds_barrier();
     ts.mark();
     f32x4 acc[RT][CT];
-    f32x4 kept[3][RT][CT];
+    bf16x4 kept[3][RT][CT];  // rounded h1, h2, h3 in the accumulator layout: the backward epilogues need exactly these lanes
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
     ts.mark();
@@ -381,9 +459,8 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
         const float s = head_dot_b(Xb + row * XSB, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
         sHead[row * MAX_OUT + o] = s;
         if (y == 1) {
-            const size_t g = (size_t)min(m0 + row, M - 1) * n_out + o;
             const float stdv = expf(a.params[lay.off_logstd + o]);
-            const float d = fsub(a.action[g], s);
+            const float d = fsub(sAct[row * MAX_OUT + o], s);
             const float var = fmul(stdv, stdv);
             const float log_scale = logf(stdv);
             sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
@@ -399,9 +476,9 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
             const bool on = has_mask ? a.loss_mask[e] != 0 : true;
             float w = 1.f;
             if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
-            const float adv = a.advantages[e];
+            const float adv = sAdv[row * MAX_OUT + c];
             lacc[S_NM] += on ? 1.0 : 0.0;
-            const float* olp = a.old_logprobs + (size_t)(m0 + row) * lay.act_dim + c * K;
+            const float* olp = sOld + row * MAX_OUT + c * K;
             for (int s = 0; s < S; ++s) {
                 float lp = 0.f, old = 0.f;
                 for (int j = 0; j < R; ++j) {
@@ -436,7 +513,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
                 float w = 1.f;
                 if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
                 gv = (a.grad_out * (float)(1.0 / den.critic)) *
-                     critic_elem(p, sHead[row * MAX_OUT + o], a.prev_values[e], a.returns[e], on, w, ratio_mode, half_delta, lacc);
+                     critic_elem(p, sHead[row * MAX_OUT + o], sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
             }
             sHead[row * MAX_OUT + o] = gv;
         }
@@ -505,7 +582,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
 #pragma unroll
                     for (int i = 0; i < 4; ++i) s = fmaf(sh[i], w4[4 * q + i], s);
                 }
-                dv[rt][ct][r] = (__bf16)(s * kept[2][rt][ct][r]);
+                dv[rt][ct][r] = (__bf16)(s * dtanh_b(kept[2][rt][ct][r]));
             }
     }
     lds_barrier();  // every read of h3 / sHead is done: the slab may be overwritten
@@ -530,7 +607,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const __bf16 z = (__bf16)(acc[rt][ct][r] * kept[l - 1][rt][ct][r]);
+                    const __bf16 z = (__bf16)(acc[rt][ct][r] * dtanh_b(kept[l - 1][rt][ct][r]));
                     dv[rt][ct][r] = z;
                     if (l == 2) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = z;
                 }

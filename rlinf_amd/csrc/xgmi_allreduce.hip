@@ -105,7 +105,7 @@ extern "C" int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_m
     n_max = (n_max + 3) / 4 * 4;
     rlx_xgmi_comm* c = new rlx_xgmi_comm();
     c->rank = rank; c->world = world; c->n_max = n_max;
-    c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 5000) * 100000ll;  // wall_clock64: 100 MHz
+    c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 120000) * 100000ll;  // wall_clock64: 100 MHz
     const size_t bytes = kFlagBytes + 2 * (size_t)n_max * sizeof(float);
     void* p = nullptr;
     hipError_t e = mem_kind == 2 ? hipMalloc(&p, bytes)
