@@ -183,7 +183,9 @@ def gae_roofline(device, iters: int = 30, with_traffic: bool = True):
         ops.gae_scan(r, v, d, None, GAMMA, LAMBDA, out=(a, q))
     c1.record()
     torch.cuda.synchronize(device)
-    out = {"bound": "hbm", "kernel": "gae_scan_c1<1,1,64,nt> (streaming scan, 65536 envs x 128 steps)",
+    out = {"bound": "hbm", "kernel": "gae_scan_c1<1,1,64,nt> (streaming scan, 65536 envs x 128 steps: the HBM-sized buffer SURVEY.md 8d "
+                                      "prescribes for the roofline; at the 1024 x 128 contract shape the loop runs gae_scan_c1<1,8,8> + "
+                                      "standardize_kernel out of L2, see contract_shape_us_per_call_incl_normalise)",
            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
            "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": round(avg_us, 2),
            "launches_timed": iters, "single_launch_event_pair_us": {"median": round(single[len(single) // 2], 2), "min": round(single[0], 2)},
@@ -327,7 +329,50 @@ def _pick_cpu_threads(pol, budget_s: float = 6.0):
     return best, avail
 
 
+def cpu_baseline_reference():
+    """kind "reference": the reference's OWN functions on the host cores (oracle/reference_loop.py: its MLPPolicy, its
+    calculate_adv_and_returns and policy_loss with their built-in callees, torch's clip_grad_norm_ + AdamW), loaded from the
+    staged copy oracle/_ref (or /root/reference).  One full rollout + advantage pass, then 3 untimed + 10 timed optimizer steps;
+    the update phase is the median step time x 128 (every minibatch step does identical work)."""
+    from oracle import ppo_loop as L
+    from oracle import reference_loader as RL
+    from oracle import reference_loop as RLoop
+    if not RL.available():
+        return None
+    ref, pol, _ = RLoop.build(OBS_DIM, ACT_DIM)
+    threads, avail = _pick_cpu_threads(pol)
+    env = L.synthetic_env_tensors(1234, HORIZON, ENVS, OBS_DIM, max_episode_steps=50)
+    t0 = time.perf_counter()
+    t = RLoop.timed_iteration(env, obs_dim=OBS_DIM, act_dim=ACT_DIM, gamma=GAMMA, gae_lambda=LAMBDA, global_batch=GLOBAL_BATCH,
+                              update_epoch=UPDATE_EPOCH, warmup_steps=3, timed_steps=10)
+    spent = time.perf_counter() - t0
+    iter_s = t["rollout_s"] + t["advantages_s"] + t["update_s_per_step"] * t["update_steps_total"]
+    return {"value": round(ENVS * HORIZON / iter_s, 1), "unit": "env-steps/s", "cores": threads, "kind": "reference",
+            "sample": f"the reference's own MLPPolicy / calculate_adv_and_returns / policy_loss + torch clip_grad_norm_ / AdamW "
+                      f"(files staged under oracle/_ref): 1 full rollout of {HORIZON}x{ENVS} + GAE, then 3 warm-up + 10 timed "
+                      f"optimizer steps of {GLOBAL_BATCH} rows, update phase = median step x {t['update_steps_total']}; "
+                      f"{spent:.1f} s of CPU work; torch threads picked by a timing probe out of {avail} schedulable cores",
+            "host_cores": avail, "updates_per_sec": round(1.0 / t["update_s_per_step"], 2), "rollout_s": round(t["rollout_s"], 3),
+            "advantages_s": round(t["advantages_s"], 4), "update_s_per_step": round(t["update_s_per_step"], 4),
+            "update_step_times_s": t["step_times_s"], "iteration_s": round(iter_s, 3)}
+
+
 def cpu_baseline(budget_s: float = 20.0):
+    """The reference's own functions when its files are reachable (kind "reference"), else the oracle port (kind "port")."""
+    try:
+        ref = cpu_baseline_reference()
+    except Exception as e:  # noqa: BLE001 -- the port below still gives a baseline; say why the reference one is missing
+        ref, why = None, f"{type(e).__name__}: {e}"[:200]
+    else:
+        why = "reference files not staged (oracle/_ref absent)"
+    if ref is not None:
+        return ref
+    out = cpu_baseline_port(budget_s)
+    out["reference_kind_unavailable"] = why
+    return out
+
+
+def cpu_baseline_port(budget_s: float = 20.0):
     """Oracle iteration on the host cores: one full rollout + GAE, then optimizer steps until ~budget_s of CPU work
     has been spent (the rest of the 128 is extrapolated linearly -- every minibatch step does identical work)."""
     from oracle import ppo_loop as L
@@ -422,6 +467,11 @@ def main():
                        "total_envs": ENVS, "horizon": HORIZON, "global_batch": GLOBAL_BATCH, "update_epoch": UPDATE_EPOCH,
                        "parallelism": f"dp{args.gpus}", "hip_graph": use_graph},
             "ppo_updates_per_sec": round(updates * args.steps / elapsed, 1),
+            # end-to-end parity AT THIS configuration (1024 x 128, 8192-row minibatches, 128 optimizer steps, hipGraph replay):
+            "parity_checked": ("tests/test_end_to_end_bench_config.py::test_bench_configuration_"
+                               + ("bf16_matches_autocast_oracle_with_graph_replay" if args.precision == "bf16" else "f32_matches_oracle[True]")
+                               + " + ::test_first_optimizer_step_gradient_at_bench_configuration (runner built by this file's "
+                                 "build_cfg / build_runner, compared with oracle.ppo_loop.iteration)"),
             "last_metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in m.items()
                              if k in ("train/actor/total_loss", "train/actor/grad_norm", "train/actor/approx_kl",
                                       "rollout/rewards")},

@@ -1,4 +1,5 @@
-"""Load the REAL reference hot-path modules from ``/root/reference`` (build container only).
+"""Load the REAL reference hot-path modules from ``/root/reference`` (build container) or from the staged copy ``oracle/_ref``
+(GPU box: the pure-torch files only, see oracle/stage_reference.py).
 
 TEST INFRASTRUCTURE.  The reference package itself is not importable here (omegaconf, ray,
 hydra, gymnasium ... are absent), but the arithmetic files on the hot path are pure torch and
@@ -15,7 +16,21 @@ import sys
 import types
 from types import SimpleNamespace
 
-REFERENCE_ROOT = os.environ.get("RLX_REFERENCE_ROOT", "/root/reference")
+_STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+
+
+def _pick_root() -> str:
+    """/root/reference in the build container; on the GPU box the staged copy of the hot-path files (oracle/_ref, written by
+    oracle/stage_reference.py, shipped by gpurun like the built .so)."""
+    env = os.environ.get("RLX_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isfile("/root/reference/rlinf/algorithms/advantages.py"):
+        return "/root/reference"
+    return _STAGED
+
+
+REFERENCE_ROOT = _pick_root()
 
 _FILES_ALGO = [
     ("rlinf.utils.metric_utils", "rlinf/utils/metric_utils.py"),
