@@ -198,6 +198,10 @@ typedef struct rlx_ppo_loss_params {
     int32_t max_episode_steps;     /* > 0 together with loss_mask and loss_mask_sum selects the
                                       masked_mean_ratio aggregation (losses.py:219-227) */
     int32_t raw_per_adv, sub_per_adv;
+    int32_t metric_unbroadcast;    /* the ratio metrics (ratio, ratio_abs, clipped, dual-clipped) divide by the UN-broadcast mask
+                                      count: the reference only expands the mask for 3-D ratios (losses.py:288-290), so a 2-D
+                                      ratio [bsz, C] against a [bsz, 1] mask -- reward_type chunk_level with logprob_type
+                                      action_level, C > 1 -- keeps the [bsz] count */
 } rlx_ppo_loss_params;
 
 size_t rlx_ppo_loss_workspace_bytes(int64_t n_adv);

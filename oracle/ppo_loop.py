@@ -135,7 +135,7 @@ def pipeline_permutation(T: int, B: int, stage_num: int, generator: torch.Genera
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
            value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0,
            perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
-           autocast: bool = False):
+           autocast: bool = False, entropy_type: str = "action_level"):
     T, B = batch["prev_logprobs"].shape[:2]
     if perm is None:
         perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
@@ -152,7 +152,7 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
                                   loss_mask_sum=mb.get("loss_mask_sum")),
                 clip_low=clip_low, clip_high=clip_high, value_clip=value_clip, huber_delta=huber_delta,
                 clip_grad=clip_grad, action_dim=policy.action_dim, entropy_bonus=entropy_bonus, max_episode_steps=max_episode_steps,
-                autocast=autocast, critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
+                autocast=autocast, entropy_type=entropy_type, critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
             metrics.append(m)
             steps += 1
             if critic_warmup_steps > 0 and steps_done + steps == critic_warmup_steps:
@@ -217,7 +217,7 @@ def async_update(policy, opt, batch: dict, *, seed: int, global_batch: int, micr
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
               max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0,
               pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
-              autocast: bool = False):
+              autocast: bool = False, entropy_type: str = "action_level"):
     """``pipeline`` = dict(stage_num=..., generator=<the rank's stateful shuffle generator>) selects
     runner.use_training_pipeline's data path: global-statistics normalisation, per-stage shuffles, and -- every
     micro-batch being available at once here -- the epoch-major schedule PipelineEmbodiedFSDPActor.run_training reduces
@@ -237,7 +237,7 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
                      max_steps=max_update_steps, entropy_bonus=entropy_bonus, perm=perm,
                      critic_warmup_steps=critic_warmup_steps, steps_done=steps_done, max_episode_steps=max_episode_steps,
-                     autocast=autocast)
+                     autocast=autocast, entropy_type=entropy_type)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))

@@ -459,9 +459,20 @@ def amp(enabled: bool):
     return torch.autocast("cpu", dtype=torch.bfloat16, enabled=bool(enabled), cache_enabled=False)
 
 
+def reshape_entropy(entropy, entropy_type: str, action_dim: int, batch_size: int):
+    """rlinf/utils/utils.py:384-408: action_level sums over action_dim ([bsz, C]), chunk_level over the whole row ([bsz]); any
+    other name (token_level) leaves the per-dimension tensor as it is."""
+    if entropy_type == "action_level":
+        return entropy.reshape(batch_size, -1, action_dim).sum(dim=-1)
+    if entropy_type == "chunk_level":
+        return entropy.sum(dim=-1)
+    return entropy
+
+
 def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, value_clip=1.0,
                        huber_delta=10.0, entropy_bonus=0.0, clip_grad=0.5, action_dim=8,
-                       logprob_type="action_level", critic_warmup=False, max_episode_steps=None, autocast=False):
+                       logprob_type="action_level", critic_warmup=False, max_episode_steps=None, autocast=False,
+                       entropy_type="action_level"):
     """forward -> actor_critic loss -> backward -> clip_grad_norm_ -> AdamW (skipped if norm non-finite).
     ``loss_mask_sum`` + ``max_episode_steps`` (both present when auto_reset is off) switch the aggregation to
     masked_mean_ratio, as train_micro_batch's loss_kwargs do (embodied_fsdp_actor_worker.py:641-662, losses.py:219-227)."""
@@ -477,7 +488,7 @@ def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, va
                                           value_clip=value_clip, huber_delta=huber_delta, max_episode_steps=max_episode_steps,
                                           **shaped)
     if entropy_bonus > 0 and not critic_warmup:  # embodied_fsdp_actor_worker.py:680
-        ent = out["entropy"].reshape(out["logprobs"].shape[0], -1, action_dim).sum(dim=-1)
+        ent = reshape_entropy(out["entropy"], entropy_type, action_dim, out["logprobs"].shape[0])
         ent_loss = masked_mean(ent, shaped["loss_mask"])
         loss = loss - entropy_bonus * ent_loss
         metrics["actor/entropy_loss"] = ent_loss.detach()

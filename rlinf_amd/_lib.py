@@ -39,7 +39,7 @@ class PpoLossParams(Structure):
         ("value_clip", c_float), ("huber_delta", c_float),
         ("use_dual_clip", c_int32), ("use_clip_log_ratio_min", c_int32), ("use_clip_log_ratio_max", c_int32),
         ("has_critic", c_int32), ("critic_warmup", c_int32), ("max_episode_steps", c_int32),
-        ("raw_per_adv", c_int32), ("sub_per_adv", c_int32),
+        ("raw_per_adv", c_int32), ("sub_per_adv", c_int32), ("metric_unbroadcast", c_int32),
     ]
 
 

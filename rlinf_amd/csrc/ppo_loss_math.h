@@ -113,7 +113,7 @@ __device__ __forceinline__ Denoms denominators(const rlx_ppo_loss_params& p, lon
     Denoms d;
     d.actor = ratio_mode ? L : (has_mask ? (nm > 0 ? nm : 1.0) : L);
     d.critic = ratio_mode ? Lc : (has_mask ? (nm > 0 ? nm : 1.0) : Lc);
-    d.metric = has_mask ? (nm > 0 ? nm * p.sub_per_adv : 1.0) : L;
+    d.metric = has_mask ? (nm > 0 ? nm * (p.metric_unbroadcast ? 1 : p.sub_per_adv) : 1.0) : L;
     d.count = has_mask ? (nm > 0 ? nm : 1.0) : L;  // loss_mask.count_nonzero() or 1
     return d;
 }

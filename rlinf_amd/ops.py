@@ -294,9 +294,9 @@ def _loss_geometry(logprobs: torch.Tensor, logprob_type: str, action_dim: int, r
     if reward_type == "chunk_level" and logprob_type == "token_level":
         return bsz, per_row, per_row
     if reward_type == "chunk_level" and logprob_type == "action_level" and chunks > 1:
-        # ratio [bsz, C] against a [bsz, 1] mask: the reference's metric denominators are the un-broadcast mask count
-        # here (no expand_as, losses.py:288-290) -- a third denominator rule no shipped config exercises
-        raise RlxError("reward_type='chunk_level' with logprob_type='action_level' is not fused")
+        # ratio [bsz, C] against [bsz, 1] advantages / mask: one advantage element per env step, C ratios under it, each the
+        # sum of action_dim raw log-probs; the ratio metrics keep the un-broadcast mask count (PpoLossParams.metric_unbroadcast)
+        return bsz, per_row, chunks
     if logprob_type == "action_level":
         return bsz * chunks, action_dim, 1
     if logprob_type == "token_level":
@@ -363,6 +363,7 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
         if t.dtype != torch.float32:
             raise RlxError(f"{name} must be float32 to keep numerical stability")
     n_adv, raw, sub = _loss_geometry(logprobs, logprob_type, action_dim, reward_type)
+    unbroadcast = reward_type == "chunk_level" and logprob_type == "action_level" and sub > 1
     if old_logprobs.numel() != logprobs.numel():
         raise RlxError("old_logprobs must have the shape of logprobs")
     if advantages.numel() != n_adv:
@@ -402,7 +403,7 @@ def ppo_loss(logprobs: torch.Tensor, old_logprobs: torch.Tensor, advantages: tor
     p.has_critic = int(has_critic)
     p.critic_warmup = int(bool(critic_warmup))
     p.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
-    p.raw_per_adv, p.sub_per_adv = raw, sub
+    p.raw_per_adv, p.sub_per_adv, p.metric_unbroadcast = raw, sub, int(unbroadcast)
     v = values.contiguous() if has_critic else None
     if decoupled is not None:
         dp, prox, versions = _decoupled_params(p, logprobs, **decoupled)
@@ -475,7 +476,8 @@ class _DecoupledLossFn(torch.autograd.Function):
 
 def make_ppo_params(*, logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low, clip_ratio_high,
                     value_clip=None, huber_delta=None, max_episode_steps=None, clip_ratio_c=None,
-                    clip_log_ratio_min=None, clip_log_ratio_max=None, critic_warmup=False, has_critic=True) -> PpoLossParams:
+                    clip_log_ratio_min=None, clip_log_ratio_max=None, critic_warmup=False, has_critic=True,
+                    reward_type=None) -> PpoLossParams:
     p = PpoLossParams()
     p.ratio_lo, p.ratio_hi = float(1.0 - clip_ratio_low), float(1.0 + clip_ratio_high)
     p.clip_ratio_c = float(clip_ratio_c) if clip_ratio_c is not None else 0.0
@@ -487,7 +489,11 @@ def make_ppo_params(*, logprob_type="action_level", action_dim=8, chunks=1, clip
     p.huber_delta = float(huber_delta) if has_critic else 0.0
     p.has_critic, p.critic_warmup = int(has_critic), int(bool(critic_warmup))
     p.max_episode_steps = int(max_episode_steps) if max_episode_steps else 0
-    if logprob_type == "action_level":
+    if reward_type == "chunk_level" and logprob_type == "token_level":  # one advantage per env step, a ratio per raw log-prob
+        p.raw_per_adv, p.sub_per_adv = action_dim * chunks, action_dim * chunks
+    elif reward_type == "chunk_level" and logprob_type == "action_level" and chunks > 1:  # ... a ratio per action chunk
+        p.raw_per_adv, p.sub_per_adv, p.metric_unbroadcast = action_dim * chunks, chunks, 1
+    elif logprob_type == "action_level":
         p.raw_per_adv, p.sub_per_adv = action_dim, 1
     elif logprob_type == "token_level":
         p.raw_per_adv, p.sub_per_adv = action_dim, action_dim

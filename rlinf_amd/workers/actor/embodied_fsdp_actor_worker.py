@@ -326,7 +326,7 @@ class EmbodiedFSDPActor(Worker):
             logprob_type=alg.logprob_type, action_dim=m.action_dim, chunks=m.num_action_chunks,
             clip_ratio_low=alg.clip_ratio_low, clip_ratio_high=alg.clip_ratio_high, value_clip=alg.get("value_clip"),
             huber_delta=alg.get("huber_delta"), max_episode_steps=self.cfg.env.train.get("max_episode_steps"),
-            critic_warmup=critic_warmup, has_critic=has_critic)
+            critic_warmup=critic_warmup, has_critic=has_critic, reward_type=alg.get("reward_type", "action_level"))
 
     def train_micro_batch(self, mbatch: dict, ws: dict, grads: torch.Tensor, out_row: torch.Tensor, grad_out: torch.Tensor,
                           lp: "ops.PpoLossParams"):
@@ -363,10 +363,18 @@ class EmbodiedFSDPActor(Worker):
         if bonus <= 0 or critic_warmup:
             return
         has_mask = mbatch.get("loss_mask") is not None
-        if has_mask and alg.get("entropy_type", "action_level") == "chunk_level":
-            # reshape_entropy (utils.py:406-407) leaves a [bsz] vector that masked_mean then multiplies with a [bsz, C] mask:
-            # an outer product for C = 1 (entropy_loss comes out bsz times larger), a shape error otherwise
-            raise NotImplementedError("entropy_type='chunk_level' together with a loss mask is not reproduced (see the comment)")
+        etype = alg.get("entropy_type", "action_level")
+        if has_mask and etype == "chunk_level":
+            # reshape_entropy (utils.py:406-407) leaves a [bsz] vector that masked_mean (utils.py:323-330) multiplies with the
+            # [bsz, C] mask.  C = 1: the product broadcasts to [bsz, bsz], so (sum_i e_i)(sum_j m_j) / sum_j m_j = the SUM of the
+            # row entropies -- bsz times the mean, whatever the mask holds (zero for an all-False mask); reproduced as written.
+            # C > 1: torch refuses to broadcast [bsz] against [bsz, C]; so do we, with its message.
+            mb, C = mbatch["loss_mask"].shape[0], int(mbatch["loss_mask"].numel() // mbatch["loss_mask"].shape[0])
+            if C != 1:
+                raise RuntimeError(f"The size of tensor a ({mb}) must match the size of tensor b ({C}) at non-singleton dimension 1")
+            ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
+                                        True, float(mb))
+            return
         per_elem = alg.get("entropy_type", "action_level") == "token_level" and not has_mask
         ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
                                     has_mask, 1.0 / self.model.layout.act_dim if per_elem else 1.0)

@@ -13,12 +13,12 @@ from oracle import ppo_oracle as O
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
              auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False,
-             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0, done_mode=None):
+             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0, done_mode=None, entropy_type="action_level"):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
         runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline),
         algorithm=dict(update_epoch=update_epoch, normalize_advantages=True, group_size=1, reward_type="action_level",
-                       logprob_type="action_level", entropy_type="action_level", adv_type="gae", loss_type="actor_critic",
+                       logprob_type="action_level", entropy_type=entropy_type, adv_type="gae", loss_type="actor_critic",
                        bootstrap_type="always", entropy_bonus=entropy_bonus, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
                        huber_delta=10.0, gamma=gamma, gae_lambda=lam),
         env=dict(train=dict(rollout_epoch=rollout_epoch, total_num_envs=total_envs, auto_reset=auto_reset, ignore_terminations=False,
@@ -94,6 +94,10 @@ def _build(cfg, env_tensors, state_dict):
                                         done_mode="bernoulli", entropy_bonus=0.02),
                                    dict(total_envs=32, steps=12, global_batch=96, auto_reset=False, done_mode="bernoulli",
                                         hip_graph=True),
+                                   # entropy_type chunk_level under a loss mask (C = 1): the reference's masked_mean broadcasts
+                                   # [bsz] x [bsz, 1] into an outer product -- the SUM of the row entropies; reproduced as written
+                                   dict(total_envs=32, steps=12, global_batch=192, micro_batch=96, auto_reset=False,
+                                        done_mode="bernoulli", entropy_bonus=0.001, entropy_type="chunk_level"),
                                    # a schedule that moves every iteration: graphs / prepared plans must follow it
                                    dict(total_envs=16, steps=10, global_batch=80, hip_graph=True, lr_scheduler="torch_cosine",
                                         total_training_steps=3)])
@@ -121,7 +125,8 @@ def test_iteration_matches_oracle(shape):
                                 global_batch=shape["global_batch"], update_epoch=2, rollout_epoch=E,
                                 entropy_bonus=shape.get("entropy_bonus", 0.0), pipeline=pipe,
                                 critic_warmup_steps=shape.get("critic_warmup_steps", 0), steps_done=steps_done,
-                                auto_reset=auto_reset, max_episode_steps=None if auto_reset else 5)
+                                auto_reset=auto_reset, max_episode_steps=None if auto_reset else 5,
+                                entropy_type=shape.get("entropy_type", "action_level"))
         steps_done += len(om)
         metrics = runner.run_step(eps.cuda())
         # lr_list is 0.0 for every step taken while the critic warms up, the ending step included (fsdp_model_manager.py:451-461)

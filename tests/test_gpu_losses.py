@@ -260,10 +260,15 @@ def test_decoupled_loss_vs_oracle(logprob_type, prox_mode, masked, thr, warmup):
 
 @pytest.mark.parametrize("loss_type", ["actor_critic", "actor", "decoupled_actor_critic"])
 @pytest.mark.parametrize("masked", [False, True])
-def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked):
+@pytest.mark.parametrize("logprob_type", ["token_level", "action_level"])
+def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked, logprob_type):
     """reward_type='chunk_level' + logprob_type='token_level' (six shipped configs, e.g. the OpenVLA GRPO ones): advantages,
     mask and values are per env-step ([bsz, 1] flattened, utils.py:296-308) while every action dimension of every chunk
-    keeps its own ratio."""
+    keeps its own ratio.  With logprob_type='action_level' and C > 1 every chunk keeps a ratio (sum over action_dim) under the
+    one advantage / mask element of its env step, and the ratio metrics divide by the UN-broadcast mask count (the reference
+    only expands the mask for 3-D ratios, losses.py:288-290)."""
+    if logprob_type == "action_level" and loss_type == "decoupled_actor_critic":
+        pytest.skip("the decoupled loss is shipped with token_level log-probs only")
     from rlinf_amd.algorithms import registry
 
     g = torch.Generator().manual_seed(23)
@@ -279,7 +284,7 @@ def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked):
     critic = dict(value_clip=0.5, huber_delta=1.0)
     lp = lp0.clone().requires_grad_(True)
     v = vals.clone().requires_grad_(True)
-    shaped = O.shape_loss_inputs(lp, old, adv, "token_level", A, loss_mask=lm, loss_mask_sum=lms, values=v, prev_values=pv,
+    shaped = O.shape_loss_inputs(lp, old, adv, logprob_type, A, loss_mask=lm, loss_mask_sum=lms, values=v, prev_values=pv,
                                  returns=ret, reward_type="chunk_level")
     if loss_type == "actor_critic":
         wloss, wm = O.ppo_actor_critic_loss(**common, **critic, **shaped)
@@ -291,7 +296,7 @@ def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked):
     wloss.backward()
     dlp = lp0.cuda().requires_grad_(True)
     dv = vals.cuda().requires_grad_(True)
-    kw = dict(task_type="embodied", loss_type=loss_type, logprob_type="token_level", reward_type="chunk_level",
+    kw = dict(task_type="embodied", loss_type=loss_type, logprob_type=logprob_type, reward_type="chunk_level",
               single_action_dim=A, logprobs=dlp, old_logprobs=_c(old), advantages=_c(adv), loss_mask=_c(lm),
               loss_mask_sum=_c(lms), **common)
     if loss_type != "actor":

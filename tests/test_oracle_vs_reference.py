@@ -144,6 +144,42 @@ def test_actor_critic_loss(ref, logprob_type, masked, variant):
         assert ev_ref[k] == float(m1[f"ev/{k}"]), k
 
 
+@pytest.mark.parametrize("logprob_type", ["action_level", "token_level"])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("ratio_agg", [False, True])
+def test_chunk_level_reward_shapes_against_the_reference(ref, logprob_type, masked, ratio_agg):
+    """reward_type='chunk_level' (utils.py:296-308: advantages / mask / values flattened to [bsz]) under a [bsz, C] (action_level)
+    or [bsz, C, A] (token_level) ratio, C = 3: the un-broadcast mask count in the action_level metrics (losses.py:288-290)."""
+    if ratio_agg and not masked:
+        pytest.skip("ratio aggregation needs a loss mask")
+    g = torch.Generator().manual_seed(5)
+    bsz, C, A = 48, 3, 4
+    lp = (torch.randn(bsz, C * A, generator=g) * 0.3).requires_grad_(True)
+    old = lp.detach() + 0.1 * torch.randn(bsz, C * A, generator=g)
+    adv, pv, ret = (torch.randn(bsz, 1, generator=g) for _ in range(3))
+    v = torch.randn(bsz, 1, generator=g).requires_grad_(True)
+    lm = (torch.rand(bsz, 1, generator=g) < 0.7) if masked else None
+    lms = torch.randint(1, 50, (bsz, 1), generator=g) if masked else None
+    mes = 50 if ratio_agg else None
+    kw = dict(loss_type="actor_critic", task_type="embodied", logprob_type=logprob_type, reward_type="chunk_level",
+              single_action_dim=A, logprobs=lp, values=v, old_logprobs=old, advantages=adv, returns=ret, prev_values=pv,
+              clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0, huber_delta=10.0, loss_mask=lm, loss_mask_sum=lms,
+              max_episode_steps=mes)
+    loss0, m0 = ref.registry.policy_loss(**kw)
+    g0 = torch.autograd.grad(loss0, [lp, v])
+    shaped = O.shape_loss_inputs(lp, old, adv, logprob_type, A, loss_mask=lm, loss_mask_sum=lms, values=v, prev_values=pv,
+                                 returns=ret, reward_type="chunk_level")
+    loss1, m1 = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0,
+                                        max_episode_steps=mes, **shaped)
+    g1 = torch.autograd.grad(loss1, [lp, v])
+    assert torch.equal(loss0.detach(), loss1.detach())
+    for a, b in zip(g0, g1):
+        _eq(a, b)
+    for k in ("actor/policy_loss", "actor/policy_loss_abs", "actor/ratio", "actor/ratio_abs", "actor/clipped_ratio",
+              "actor/approx_kl", "actor/clip_fraction", "critic/value_loss"):
+        assert m0[k] == pytest.approx(float(m1[k]), rel=0, abs=0), k
+
+
 def test_grpo_actor_loss_name(ref):
     lp, old, adv, *_ = _loss_inputs(3)
     kw = dict(loss_type="actor", task_type="embodied", logprob_type="action_level",
@@ -632,3 +668,24 @@ def test_stats_normalisation(ref):
         _eq(du.normalize_from_stats(x, s0), O.normalize_from_stats(x, s1))
     two = du.masked_stats(x[:4]) + du.masked_stats(x[4:])
     _eq(du.normalize_from_stats(x, two), O.normalize_from_stats(x, O.masked_stats(x[:4]) + O.masked_stats(x[4:])))
+
+
+@pytest.mark.parametrize("etype,C", [("action_level", 1), ("action_level", 2), ("chunk_level", 1), ("token_level", 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_entropy_bonus_shapes_against_the_reference(ref, etype, C, masked):
+    """reshape_entropy (rlinf/utils/utils.py:384-408) + masked_mean (:323-330) as train_micro_batch chains them
+    (embodied_fsdp_actor_worker.py:679-690).  chunk_level with a [bsz, 1] mask broadcasts into an outer product: the result is
+    the SUM of the row entropies; with C > 1 torch refuses the broadcast."""
+    g = torch.Generator().manual_seed(2)
+    bsz, A = 24, 4
+    ent = torch.rand(bsz, C * A, generator=g)
+    mask = (torch.rand(bsz, C, generator=g) < 0.6) if masked else None
+    want = ref.utils.masked_mean(ref.utils.reshape_entropy(ent, entropy_type=etype, action_dim=A, batch_size=bsz), mask=mask)
+    got = O.masked_mean(O.reshape_entropy(ent, etype, A, bsz), mask)
+    _eq(want, got)
+    if etype == "chunk_level" and masked:
+        assert float(want) == pytest.approx(float(ent.sum()), rel=1e-6)  # bsz times the mean, whatever the mask holds
+    if etype == "chunk_level":
+        with pytest.raises(RuntimeError, match="must match the size of tensor"):
+            ref.utils.masked_mean(ref.utils.reshape_entropy(torch.rand(bsz, 3 * A), entropy_type=etype, action_dim=A, batch_size=bsz),
+                                  mask=torch.ones(bsz, 3, dtype=torch.bool))
