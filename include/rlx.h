@@ -695,6 +695,17 @@ int rlx_copy_segments_plan(rlx_copy_segment* table_host, int32_t n_segments, int
 int rlx_copy_segments(const rlx_copy_segment* table_dev, int32_t n_segments, int64_t total_chunks, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a15  rollout_metrics  <- compute_rollout_metrics, rlinf/utils/metric_utils.py:422-506
+ *   masked mean / min / max of rewards, advantages, returns: `count` (<= 3) f32 arrays of sizes[k] elements and ONE optional
+ *   mask of mask_elems bytes (element e covers sizes[k] / mask_elems consecutive elements of array k: [.., 1] against [.., C]).
+ *   out f64[count][4] = {sum, count, -min, max} on the device: (sum, count) reduce with SUM over ranks, (-min, max) with MAX;
+ *   an empty selection leaves count 0 and -inf / -inf (the caller reports NaN like the reference, :458-460).
+ * ------------------------------------------------------------------------------------------ */
+size_t rlx_rollout_metrics_workspace_bytes(void);
+int rlx_rollout_metrics(const float* const* arrays, const int64_t* sizes, int count, const uint8_t* mask, int64_t mask_elems,
+                        double* out, void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * e  data-parallel gradient all-reduce over xGMI  <- FSDP NO_SHARD gradient synchronisation,
  *      rlinf/hybrid_engines/fsdp/strategy/fsdp.py:480-496 (sync_grad / no_sync around backward), the averaged gradient that
  *      FSDPModelManager.optimizer_step then clips and applies (fsdp_model_manager.py:429-463).

@@ -73,6 +73,76 @@ __global__ __launch_bounds__(256) void masked_normalize_kernel(const float* __re
     }
 }
 
+// a15 compute_rollout_metrics (rlinf/utils/metric_utils.py:422-506): masked sum / count / min / max of up to three arrays
+// (rewards, advantages, returns) in ONE pass over them -- the reference gathers each with a boolean index and reduces it with
+// three torch calls.  mask element e covers `per[k]` consecutive elements of array k (the loss mask is [.., 1] against
+// [.., C] rewards under reward_type chunk_level).  out[k] = {sum, count, -min, max} in f64: sums reduce with SUM over ranks,
+// (-min, max) with MAX, one collective each (scheduler/dist.py).
+constexpr int kMetricArrays = 3;
+struct MetricArgs {
+    const float* x[kMetricArrays];
+    long long n[kMetricArrays];
+    int per[kMetricArrays];
+    int count;
+};
+__global__ __launch_bounds__(256) void rollout_metrics_partial_kernel(MetricArgs a, const uint8_t* __restrict__ m,
+                                                                      double* __restrict__ partials) {
+    __shared__ double s_red[4 * 4];
+    for (int k = 0; k < a.count; ++k) {
+        double sum[2] = {0.0, 0.0};
+        float lo = INFINITY, hi = -INFINITY;
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += stride) {
+            const bool on = m ? m[i / a.per[k]] != 0 : true;
+            const float v = a.x[k][i];
+            if (on) {
+                sum[0] += (double)v;
+                sum[1] += 1.0;
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
+        }
+        block_sum<2>(sum, s_red);
+        __syncthreads();
+        // min / max: wave shuffles, then through LDS
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, off, RLX_WAVE));
+            hi = fmaxf(hi, __shfl_xor(hi, off, RLX_WAVE));
+        }
+        float* s_mm = reinterpret_cast<float*>(s_red + 8);
+        if ((threadIdx.x & 63) == 0) s_mm[(threadIdx.x >> 6) * 2] = lo, s_mm[(threadIdx.x >> 6) * 2 + 1] = hi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) lo = fminf(lo, s_mm[w * 2]), hi = fmaxf(hi, s_mm[w * 2 + 1]);
+            double* p = partials + ((size_t)blockIdx.x * kMetricArrays + k) * 4;
+            p[0] = sum[0], p[1] = sum[1], p[2] = (double)-lo, p[3] = (double)hi;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void rollout_metrics_final_kernel(const double* __restrict__ partials, int nparts, int count,
+                                                                    double* __restrict__ out) {
+    __shared__ double s_red[2 * 4];
+    __shared__ double s_mm[2 * 256];
+    for (int k = 0; k < count; ++k) {
+        double sum[2] = {0.0, 0.0};
+        double nlo = -INFINITY, hi = -INFINITY;
+        for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+            const double* p = partials + ((size_t)i * kMetricArrays + k) * 4;
+            sum[0] += p[0], sum[1] += p[1];
+            nlo = fmax(nlo, p[2]), hi = fmax(hi, p[3]);
+        }
+        block_sum<2>(sum, s_red);
+        s_mm[threadIdx.x * 2] = nlo, s_mm[threadIdx.x * 2 + 1] = hi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 1; t < 256; ++t) nlo = fmax(nlo, s_mm[t * 2]), hi = fmax(hi, s_mm[t * 2 + 1]);
+            out[k * 4 + 0] = sum[0], out[k * 4 + 1] = sum[1], out[k * 4 + 2] = nlo, out[k * 4 + 3] = hi;
+        }
+        __syncthreads();
+    }
+}
+
 int stat_grid(long long n) {
     return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, std::min<long long>(kStatBlocks, (long long)num_cu() * 4)));
 }
@@ -122,6 +192,40 @@ extern "C" int rlx_masked_normalize(const float* x, const uint8_t* mask, const d
     RLX_REQUIRE(x && out, "rlx_masked_normalize: NULL argument");
     hipLaunchKernelGGL(masked_normalize_kernel, dim3(stat_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, mask, stats,
                        eps, out, (long long)n);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" size_t rlx_rollout_metrics_workspace_bytes(void) { return (size_t)256 * kMetricArrays * 4 * sizeof(double); }
+
+extern "C" int rlx_rollout_metrics(const float* const* arrays, const int64_t* sizes, int count, const uint8_t* mask,
+                                   int64_t mask_elems, double* out, void* workspace, size_t workspace_bytes, rlx_stream_t stream) {
+    RLX_REQUIRE(arrays && sizes && out && workspace && count >= 1 && count <= kMetricArrays, "rlx_rollout_metrics: bad argument");
+    if (workspace_bytes < rlx_rollout_metrics_workspace_bytes()) {
+        set_error("rlx_rollout_metrics: workspace too small");
+        return RLX_ENOSPC;
+    }
+    MetricArgs a{};
+    a.count = count;
+    long long nmax = 0;
+    for (int k = 0; k < count; ++k) {
+        RLX_REQUIRE(sizes[k] >= 0 && (sizes[k] == 0 || arrays[k] != nullptr), "rlx_rollout_metrics: array %d is NULL", k);
+        a.x[k] = arrays[k];
+        a.n[k] = sizes[k];
+        a.per[k] = 1;
+        if (mask != nullptr) {
+            RLX_REQUIRE(mask_elems >= 1 && sizes[k] % mask_elems == 0, "rlx_rollout_metrics: array %d (%lld elements) is not a "
+                        "multiple of the mask (%lld)", k, (long long)sizes[k], (long long)mask_elems);
+            a.per[k] = (int)std::max<long long>(1, sizes[k] / mask_elems);
+        }
+        nmax = std::max<long long>(nmax, sizes[k]);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = (int)std::max<long long>(1, std::min<long long>((nmax + 1023) / 1024, 256));
+    double* partials = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(rollout_metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, a, mask, partials);
+    RLX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rollout_metrics_final_kernel, dim3(1), dim3(256), 0, s, partials, nblk, count, out);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

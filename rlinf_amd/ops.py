@@ -8,6 +8,8 @@ from __future__ import annotations
 from ctypes import byref
 from typing import Optional
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -236,6 +238,27 @@ def gaussian_entropy_bonus_(params: torch.Tensor, layout: MlpLayout, grads_slab0
                                                           float(entropy_bonus), float(grad_scale), int(bool(has_mask)),
                                                           float(elem_scale), _stream_ptr(dev)),
                    "rlx_gaussian_entropy_bonus")
+
+
+def rollout_metrics(arrays: list, loss_mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                    workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a15: masked (sum, count, -min, max) of up to three f32 arrays in one pass -> f64 [len(arrays), 4] on the device
+    (compute_rollout_metrics, metric_utils.py:422-506).  ``loss_mask`` broadcasts over trailing dimensions like the reference's
+    ``v[mask.expand_as(v)]``: every array's element count must be a multiple of the mask's."""
+    lib = _lib.load()
+    dev = _dev(*arrays, loss_mask)
+    xs = [_as_f32(a, "metric array") for a in arrays]
+    k = len(xs)
+    m8 = _as_u8(loss_mask)
+    ptrs = (ctypes.c_void_p * k)(*[x.data_ptr() for x in xs])
+    sizes = (ctypes.c_int64 * k)(*[x.numel() for x in xs])
+    out = torch.empty((k, 4), dtype=torch.float64, device=dev) if out is None else out
+    wsb = lib.rlx_rollout_metrics_workspace_bytes()
+    ws = workspace if workspace is not None and workspace.numel() >= wsb else torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.rlx_rollout_metrics(ptrs, sizes, k, _ptr(m8), 0 if m8 is None else m8.numel(), out.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), _stream_ptr(dev)), "rlx_rollout_metrics")
+    return out
 
 
 def reward_filter_mask(rewards: torch.Tensor, loss_mask: Optional[torch.Tensor], group_size: int, lower: float,

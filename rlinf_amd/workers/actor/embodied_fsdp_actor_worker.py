@@ -224,22 +224,22 @@ class EmbodiedFSDPActor(Worker):
             return self._rollout_metrics(b)
 
     def _rollout_metrics(self, b: dict) -> dict:
-        """compute_rollout_metrics (rlinf/utils/metric_utils.py:422-506): masked mean / min / max of rewards,
-        advantages, returns; reduced over ranks in ONE sum call + ONE max call, read back in one copy."""
+        """compute_rollout_metrics (rlinf/utils/metric_utils.py:422-506): masked mean / min / max of rewards, advantages,
+        returns -- ONE pass over the three arrays on the device (rlx_rollout_metrics), reduced over ranks in one SUM call + one MAX
+        call, read back in one copy.  No boolean-index gathers."""
         mask = b.get("loss_mask")
-        names, sums, maxs = [], [], []
-        for key in ("rewards", "advantages", "returns"):
-            v = b.get(key)
-            if v is None:
-                continue
-            sel = v.reshape(-1) if mask is None else v[torch.broadcast_to(mask, v.shape)]
-            n = sel.numel()
-            names.append(key)
-            sums += [sel.sum() if n else v.new_zeros(()), v.new_tensor(float(n))]
-            maxs += [-sel.min() if n else v.new_tensor(float("-inf")), sel.max() if n else v.new_tensor(float("-inf"))]
-        s, m = all_reduce_scalars(torch.stack(sums), torch.stack(maxs), self.ctx)
+        names = [k for k in ("rewards", "advantages", "returns") if b.get(k) is not None]
+        if self.device is None or self.device.type != "cuda":
+            raise ops.RlxError("rollout metrics run on the accelerator: the trajectory buffer lives there (no CPU fallback)")
+        key = ("rollout_metrics", len(names))
+        if key not in self._ws:
+            self._ws[key] = (torch.empty((len(names), 4), dtype=torch.float64, device=self.device),
+                             torch.empty(ops._lib.load().rlx_rollout_metrics_workspace_bytes(), dtype=torch.uint8, device=self.device))
+        out, ws = self._ws[key]
+        ops.rollout_metrics([b[k] for k in names], mask, out=out, workspace=ws)
+        s, m = all_reduce_scalars(out[:, :2].reshape(-1).clone(), out[:, 2:].reshape(-1).clone(), self.ctx)
         s, m = s.tolist(), m.tolist()
-        out = {}
+        res = {}
         for i, key in enumerate(names):
             cnt = s[2 * i + 1]
             if cnt > 0:
@@ -247,10 +247,10 @@ class EmbodiedFSDPActor(Worker):
             else:  # nothing selected on any rank: all three are NaN (metric_utils.py:458-460)
                 mean = vmax = vmin = float("nan")
             if key == "rewards":
-                out["rewards"] = mean
+                res["rewards"] = mean
             else:
-                out[f"{key}_mean"], out[f"{key}_max"], out[f"{key}_min"] = mean, vmax, vmin
-        return out
+                res[f"{key}_mean"], res[f"{key}_max"], res[f"{key}_min"] = mean, vmax, vmin
+        return res
 
     # ---- update -------------------------------------------------------------------------------------------------
     def _flatten_and_shuffle(self):

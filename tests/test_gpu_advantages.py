@@ -268,3 +268,29 @@ def test_global_advantage_stats(masked):
     assert empty.tolist() == [0.0, 0.0, 0.0]
     torch.testing.assert_close(ops.normalize_from_stats(parts[0].cuda(), empty).cpu(),
                                (parts[0].double() * torch.rsqrt(torch.tensor(1e-5, dtype=torch.float64))).float())
+
+
+@pytest.mark.parametrize("C,mask_kind", [(1, None), (1, "full"), (3, "full"), (3, "per_step"), (2, "empty")])
+def test_rollout_metrics_on_device(C, mask_kind):
+    """a15 compute_rollout_metrics (metric_utils.py:422-506): masked sum / count / min / max of rewards, advantages, returns in
+    one pass, against the reference's boolean-index form ``v[mask.expand_as(v)]``."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    T, B = 37, 50
+    arrs = [torch.randn(T, B, C, generator=g) * s for s in (1.0, 3.0, 0.2)]
+    mask = None
+    if mask_kind == "full":
+        mask = torch.rand(T, B, C, generator=g) < 0.6
+    elif mask_kind == "per_step":
+        mask = torch.rand(T, B, 1, generator=g) < 0.6  # chunk_level rewards: one mask element per env step
+    elif mask_kind == "empty":
+        mask = torch.zeros(T, B, C, dtype=torch.bool)
+    out = ops.rollout_metrics([a.cuda() for a in arrs], None if mask is None else mask.cuda()).cpu()
+    for k, v in enumerate(arrs):
+        sel = v.reshape(-1) if mask is None else v[mask.expand_as(v)]
+        assert float(out[k, 1]) == sel.numel()
+        if sel.numel():
+            assert float(out[k, 0]) == pytest.approx(float(sel.double().sum()), rel=1e-12, abs=1e-9)
+            assert float(-out[k, 2]) == float(sel.min()) and float(out[k, 3]) == float(sel.max())  # selections: exact
+        else:
+            assert float(out[k, 2]) == float("-inf") and float(out[k, 3]) == float("-inf")
