@@ -237,7 +237,12 @@ class EmbodiedFSDPActor(Worker):
                              torch.empty(ops._lib.load().rlx_rollout_metrics_workspace_bytes(), dtype=torch.uint8, device=self.device))
         out, ws = self._ws[key]
         ops.rollout_metrics([b[k] for k in names], mask, out=out, workspace=ws)
-        s, m = all_reduce_scalars(out[:, :2].reshape(-1).clone(), out[:, 2:].reshape(-1).clone(), self.ctx)
+        return self._metrics_from_reductions(names, out)
+
+    def _metrics_from_reductions(self, names: list, red: torch.Tensor) -> dict:
+        """red [len(names), 4] f64 = (sum, count, -min, max) of this rank's selection -> the reference's metric dict: one SUM and
+        one MAX all-reduce over ranks (metric_utils.py:451-454 does two per metric), one read-back."""
+        s, m = all_reduce_scalars(red[:, :2].reshape(-1).clone(), red[:, 2:].reshape(-1).clone(), self.ctx)
         s, m = s.tolist(), m.tolist()
         res = {}
         for i, key in enumerate(names):

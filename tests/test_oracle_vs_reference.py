@@ -499,8 +499,9 @@ def test_bootstrap_rewards(ref, bootstrap_type):
 @pytest.mark.parametrize("masked", [False, True, "empty"])
 def test_rollout_metrics(ref, masked, monkeypatch):
     """a15: compute_rollout_metrics (metric_utils.py:422-506) in a one-rank gloo group against the learner's
-    _rollout_metrics (pure torch reductions, so it runs on CPU tensors too): masked mean / min / max, NaN when nothing
-    is selected, the [T, B] mask broadcast over the trailing dim."""
+    _metrics_from_reductions over the (sum, count, -min, max) rows that rlx_rollout_metrics produces on the device (formed with
+    torch here; the kernel itself is checked against the same boolean-index form in tests/test_gpu_advantages.py): masked mean /
+    min / max, NaN when nothing is selected, the [T, B] mask broadcast over the trailing dim."""
     import math
     import sys
     import types
@@ -526,7 +527,13 @@ def test_rollout_metrics(ref, masked, monkeypatch):
         if masked:
             batch["loss_mask"] = (torch.rand(T, B, 1, generator=g) < 0.5) if masked is True else torch.zeros(T, B, 1, dtype=torch.bool)
         want = ref.metric_utils.compute_rollout_metrics(dict(batch))
-        got = EmbodiedFSDPActor(make_cfg())._rollout_metrics(dict(batch))
+        names, rows = ["rewards", "advantages", "returns"], []
+        for k in names:
+            v = batch[k]
+            sel = v.reshape(-1) if "loss_mask" not in batch else v[batch["loss_mask"].expand_as(v)]
+            rows.append([float(sel.double().sum()), float(sel.numel()), float(-sel.min()) if sel.numel() else float("-inf"),
+                         float(sel.max()) if sel.numel() else float("-inf")])
+        got = EmbodiedFSDPActor(make_cfg())._metrics_from_reductions(names, torch.tensor(rows, dtype=torch.float64))
         assert set(want) == set(got) == {"rewards", "advantages_mean", "advantages_max", "advantages_min", "returns_mean",
                                          "returns_max", "returns_min"}
         for k, v in want.items():
