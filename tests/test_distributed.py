@@ -58,13 +58,40 @@ def _two_gpus():
 
 
 @pytest.mark.gpu
+def test_xgmi_allreduce_two_ranks_on_one_gpu(tmp_path):
+    """The transport alone (csrc/xgmi_allreduce.hip through scheduler/xgmi.py), two processes sharing the ONE GPU of the test
+    box: IPC export / mapping of the fine-grained buffer, the flag hand-shake, both staging slots, slab sums, the scale, eager
+    launches and a replayed hipGraph of 20 back-to-back all-reduces -- against torch.distributed's own all-reduce.
+    (The whole learner over this transport is exercised when the box has a GPU per rank, below: two ranks time-slicing one
+    GPU's hardware queues can starve each other's spin-waits for seconds, which says nothing about xGMI.)"""
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641",
+                   RLX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", RLX_XGMI_TIMEOUT_MS="20000")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "xgmi_probe.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    out = logs[0]
+    assert "mem_kind 0: OK" in out or "mem_kind 1: OK" in out, out[-2000:]  # a coherent (fine-grained / uncached) kind works
+    assert "result ok after graph: True" in out and "result ok after graph: False" not in out, out[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("transport,graph,backend", [
-    ("xgmi", "0", "gloo"),   # the hand-written peer-read all-reduce over IPC-mapped buffers, two ranks on ONE GPU
-    ("xgmi", "1", "gloo"),   # ... inside the captured hipGraph of the update phase (replayed twice)
     ("rccl", "0", "gloo"),   # torch.distributed all-reduce (gloo stands in for RCCL: it needs a device per rank)
     ("rccl", "1", "gloo"),   # a gloo all-reduce cannot be stream-captured: the worker keeps the eager (prepared-launch) loop
+    # one rank per GPU (auto-enabled when the box has two): RCCL captured in the update graph, and the xGMI transport for real
     pytest.param("rccl", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="RCCL needs one GPU per rank")),
-    pytest.param("xgmi", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")),
+    pytest.param("xgmi", "0", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs one GPU per rank")),
+    pytest.param("xgmi", "1", "nccl", marks=pytest.mark.skipif(not _two_gpus(), reason="needs one GPU per rank")),
 ])
 def test_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph, backend, precision="32"):
     """Two processes against the reference arithmetic applied shard by shard: per-rank rollout on its env half, per-shard
@@ -77,7 +104,7 @@ def test_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph, backend,
     from oracle import ppo_oracle as O
     outs = [torch.load(o, weights_only=False)
             for o in _launch("gpu", tmp_path, precision, transport, graph, backend, port=29613 + 2 * (graph == "1") + 4 * (transport == "rccl"),
-                             timeout=600, one_device=backend != "nccl")]
+                             timeout=300, one_device=backend != "nccl")]
     assert all(o["backend"] == transport for o in outs), [o["backend"] for o in outs]
     if graph == "1":
         assert all(o["iters"] == 3 for o in outs)

@@ -28,6 +28,7 @@ def child():
         for _ in range(5):
             comm.all_reduce(x, out, 0.5)
         torch.cuda.synchronize()
+        comm.check_status()
         dist.barrier()
         t0 = time.perf_counter()
         iters = 200
@@ -62,6 +63,7 @@ def child():
 
 if __name__ == "__main__":
     if os.environ.get("RANK") is not None:
+        os.environ.setdefault("RLX_XGMI_TIMEOUT_MS", "20000")
         child()
     else:
         procs = []
