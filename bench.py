@@ -42,16 +42,21 @@ GAMMA, LAMBDA = 0.8, 0.9            # examples/embodiment/config/maniskill_ppo_m
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def build_cfg(world: int, use_graph: bool, precision: str = "32"):
+def build_cfg(world: int, use_graph: bool, precision: str = "32", pipeline: bool = False, rollout_epochs: int = 1,
+              overlap: bool = True):
+    """``pipeline`` / ``rollout_epochs`` / ``overlap``: runner.use_training_pipeline variants (NOT the headline configuration):
+    the horizon is split into ``rollout_epochs`` epochs of HORIZON / rollout_epochs steps so that the work per iteration stays
+    1024 x 128 env-steps and 128 optimizer steps."""
     from rlinf_amd.config import DictConfig
+    assert HORIZON % rollout_epochs == 0
     return DictConfig(dict(
-        runner=dict(task_type="embodied", max_epochs=1, max_steps=-1),
+        runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline, pipeline_overlap=overlap),
         algorithm=dict(update_epoch=UPDATE_EPOCH, normalize_advantages=True, group_size=1, reward_type="action_level",
                        logprob_type="action_level", entropy_type="action_level", adv_type="gae", loss_type="actor_critic",
                        bootstrap_type="always", entropy_bonus=0, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
                        huber_delta=10.0, gamma=GAMMA, gae_lambda=LAMBDA),
-        env=dict(train=dict(rollout_epoch=1, total_num_envs=ENVS, auto_reset=True, ignore_terminations=False,
-                            max_episode_steps=50, max_steps_per_rollout_epoch=HORIZON, seed=1234, group_size=1)),
+        env=dict(train=dict(rollout_epoch=rollout_epochs, total_num_envs=ENVS, auto_reset=True, ignore_terminations=False,
+                            max_episode_steps=50, max_steps_per_rollout_epoch=HORIZON // rollout_epochs, seed=1234, group_size=1)),
         rollout=dict(pipeline_stage_num=1, enable_cuda_graph=use_graph),
         actor=dict(training_backend="fsdp", micro_batch_size=GLOBAL_BATCH // world, global_batch_size=GLOBAL_BATCH,
                    seed=1234, enable_hip_graph=use_graph, optimizer_writes_tiles=bool(int(os.environ.get("RLX_BENCH_OPT_TILES", "1"))),
@@ -416,6 +421,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "32"],
                     help="operand precision of the policy's dense layers: bf16 (BASELINE.json configs[1], f32 accumulate and "
                          "master weights) or 32 (exact-f32 MFMA)")
+    ap.add_argument("--pipeline", action="store_true", help="runner.use_training_pipeline (statistics normalisation, per-stage "
+                    "shuffles; with --rollout-epochs > 1 the learner trains on epoch e while epoch e + 1 rolls out)")
+    ap.add_argument("--rollout-epochs", type=int, default=1, help="split the 128-step horizon into this many rollout epochs")
+    ap.add_argument("--no-overlap", action="store_true", help="pipeline mode on ONE stream (the comparison line for the overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-token-tier", action="store_true", help="skip the token-tier (LLM logits) roofline rows")
@@ -432,7 +441,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     dev = ctx.device
     use_graph = not args.no_graph
-    runner = build_runner(build_cfg(ctx.world_size, use_graph, args.precision), ctx)
+    runner = build_runner(build_cfg(ctx.world_size, use_graph, args.precision, pipeline=args.pipeline,
+                                    rollout_epochs=args.rollout_epochs, overlap=not args.no_overlap), ctx)
 
     def barrier():
         if ctx.world_size > 1:
@@ -465,7 +475,9 @@ def main():
                                    "(3x256 tanh actor + value head), gamma 0.8 / lambda 0.9, 8 epochs x 16 minibatches "
                                    "of 8192 (128 optimizer steps), " + ("bf16 MFMA operands / f32 accumulate, master weights, losses, GAE, AdamW" if args.precision == "bf16" else "exact-f32 MFMA") + ", synthetic env tensors resident in HBM",
                        "total_envs": ENVS, "horizon": HORIZON, "global_batch": GLOBAL_BATCH, "update_epoch": UPDATE_EPOCH,
-                       "parallelism": f"dp{args.gpus}", "hip_graph": use_graph},
+                       "parallelism": f"dp{args.gpus}", "hip_graph": use_graph,
+                       **({"pipeline": True, "rollout_epochs": args.rollout_epochs, "overlap": not args.no_overlap}
+                          if args.pipeline else {})},
             "ppo_updates_per_sec": round(updates * args.steps / elapsed, 1),
             # end-to-end parity AT THIS configuration (1024 x 128, 8192-row minibatches, 128 optimizer steps, hipGraph replay):
             "parity_checked": ("tests/test_end_to_end_bench_config.py::test_bench_configuration_"

@@ -135,13 +135,17 @@ def pipeline_permutation(T: int, B: int, stage_num: int, generator: torch.Genera
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
            value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0,
            perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
-           autocast: bool = False, entropy_type: str = "action_level"):
-    T, B = batch["prev_logprobs"].shape[:2]
-    if perm is None:
-        perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
-    flat = O.flatten_and_shuffle(batch, perm)
-    n_mb = (T * B) // global_batch
-    assert (T * B) % global_batch == 0
+           autocast: bool = False, entropy_type: str = "action_level", flat: dict | None = None):
+    """``flat``: already flattened + shuffled rows (the pipeline learner with rollout_epoch > 1 concatenates per-epoch
+    shuffles); otherwise ``batch`` is flattened with ``perm`` (default: the seeded randperm of run_training)."""
+    if flat is None:
+        T, B = batch["prev_logprobs"].shape[:2]
+        if perm is None:
+            perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(seed))
+        flat = O.flatten_and_shuffle(batch, perm)
+    n_rows = flat["prev_logprobs"].shape[0]
+    n_mb = n_rows // global_batch
+    assert n_rows % global_batch == 0
     metrics, steps = [], 0
     for _ in range(update_epoch):
         for mb in O.chunk_batch(flat, n_mb):
@@ -223,6 +227,28 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     micro-batch being available at once here -- the epoch-major schedule PipelineEmbodiedFSDPActor.run_training reduces
     to (fsdp_actor_worker_pipeline.py:84-160: fixed global batches, epoch 1 in arrival order, then each again)."""
     t0 = time.perf_counter()
+    if pipeline is not None and rollout_epoch > 1:
+        # every rollout epoch is its own learner batch (env_worker.py:1324-1330 sends per epoch): all epochs are rolled out with
+        # the iteration's FROZEN weights, each gets its own statistics normalisation and stage shuffles (the generator keeps
+        # running), the learner makes its first pass epoch by epoch and then revisits the stored global batches oldest first
+        # (fsdp_actor_worker_pipeline.py:84-160) -- one epoch-major sweep over the concatenated rows
+        T = env["rewards"].shape[0] // rollout_epoch
+        flats, batches = [], []
+        for e in range(rollout_epoch):
+            sl = dict(obs=env["obs"][e * T:(e + 1) * T + 1], final_obs=env["final_obs"][e * T:(e + 1) * T],
+                      rewards=env["rewards"][e * T:(e + 1) * T], dones=env["dones"][e * T:(e + 1) * T + 1])
+            batches.append(rollout(policy, sl, eps[e * T:(e + 1) * T], gamma, auto_reset, autocast))
+        for e in range(rollout_epoch):
+            batches[e] = pipeline_advantages(batches[e], gamma, gae_lambda, auto_reset)
+            T_, B_ = batches[e]["prev_logprobs"].shape[:2]
+            flats.append(O.flatten_and_shuffle(batches[e], pipeline_permutation(T_, B_, pipeline["stage_num"], pipeline["generator"])))
+        flat = {k: (dict((kk, torch.cat([f[k][kk] for f in flats], 0)) for kk in flats[0][k]) if isinstance(flats[0][k], dict)
+                    else torch.cat([f[k] for f in flats], 0)) for k in flats[0]}
+        metrics = update(policy, opt, None, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
+                         max_steps=max_update_steps, entropy_bonus=entropy_bonus, critic_warmup_steps=critic_warmup_steps,
+                         steps_done=steps_done, max_episode_steps=max_episode_steps, autocast=autocast, entropy_type=entropy_type,
+                         flat=flat)
+        return batches, metrics
     batch = (rollout(policy, env, eps, gamma, auto_reset, autocast) if rollout_epoch == 1
              else rollout_epochs(policy, env, eps, gamma, rollout_epoch, auto_reset, autocast))
     t1 = time.perf_counter()

@@ -137,6 +137,8 @@ class EmbodiedRunner:
         train_metrics = actor_training_handle.wait()[0]
         if env_bootstrap_handle is not None:
             env_bootstrap_handle.wait()
+        if not rollout_metrics and hasattr(self.actor.worker, "pop_rollout_metrics"):
+            rollout_metrics = self.actor.worker.pop_rollout_metrics()  # pipeline learner: produced inside run_training
         if dev is not None and dev.type == "cuda":
             torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0

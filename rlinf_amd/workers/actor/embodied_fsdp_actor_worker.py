@@ -54,10 +54,15 @@ class EmbodiedFSDPActor(Worker):
         # micro-batches.  With rollout and learner sharing the resident buffer nothing streams; what remains is the data
         # path: that normalisation, the per-stage shuffles with the rank's stateful generator, fixed global batches.
         self.use_training_pipeline = bool(cfg.runner.get("use_training_pipeline", False))
+        self.pipeline_epochs = 1
+        self.rollout_batches: list = []
+        self._deferred_rollout_metrics: dict = {}
         if self.use_training_pipeline:
             assert cfg.algorithm.adv_type == "gae", ("algorithm.adv_type only supports 'gae' now"
                                                      "when runner.use_training_pipeline is True.")  # config.py:992-996
-            assert cfg.env.train.get("rollout_epoch", 1) == 1, "the pipeline batch is prepared per rollout epoch (:1512)"
+            # rollout_epoch > 1: every epoch is its own batch (prepare_pipeline_batch, :1512; sent per epoch, :1324-1330) with
+            # its own statistics normalisation and stage shuffles; the learner trains on epoch e while epoch e + 1 rolls out
+            self.pipeline_epochs = int(cfg.env.train.get("rollout_epoch", 1))
             # _init_pipeline_params (:355-361): seed = actor.seed + actor_rank + env_rank * actor_world_size, and with one
             # env rank feeding the learner rank of the same process both ranks are this rank
             self._pipe_gen = torch.Generator().manual_seed(int(a.get("seed", 1234)) + self._rank + self._rank * self._world_size)
@@ -178,8 +183,15 @@ class EmbodiedFSDPActor(Worker):
         list of trajectory views itself."""
         send_num = self._world_size * self.cfg.rollout.get("pipeline_stage_num", 1)
         split_num = compute_split_num(send_num, self._world_size)
-        trajectories = input_channel if isinstance(input_channel, (list, tuple)) else [input_channel.get() for _ in range(split_num)]
-        assert len(trajectories) == split_num, f"expected {split_num} trajectories, got {len(trajectories)}"
+        E = self.pipeline_epochs if self.pipeline_epochs > 1 else 1
+        trajectories = (input_channel if isinstance(input_channel, (list, tuple))
+                        else [input_channel.get() for _ in range(split_num * E)])
+        assert len(trajectories) == split_num * E, f"expected {split_num * E} trajectories, got {len(trajectories)}"
+        if E > 1:  # epoch-major: one batch per rollout epoch, each trained as soon as its epoch is complete
+            self.rollout_batches = [self._process_received_rollout_batch(convert_trajectories_to_batch(
+                list(trajectories[e * split_num:(e + 1) * split_num]))) for e in range(E)]
+            self.rollout_batch = self.rollout_batches[0]
+            return
         self.rollout_batch = self._process_received_rollout_batch(convert_trajectories_to_batch(trajectories))
 
     def _process_received_rollout_batch(self, batch: dict) -> dict:
@@ -205,7 +217,19 @@ class EmbodiedFSDPActor(Worker):
         return batch
 
     def compute_advantages_and_returns(self) -> dict:
-        alg, b = self.cfg.algorithm, self.rollout_batch
+        if self.pipeline_epochs > 1:
+            # per-epoch work happens inside run_training (the reference's pipeline learner does everything there and returns
+            # {"rollout_metrics", "training_metrics"}, fsdp_actor_worker_pipeline.py:84-196): enqueueing the advantage pass of
+            # epoch e + 1 here would put its wait for that epoch's rollout IN FRONT of epoch e's training on the learner stream
+            return {}
+        return self._advantages_for(self.rollout_batch)
+
+    def pop_rollout_metrics(self) -> dict:
+        out, self._deferred_rollout_metrics = self._deferred_rollout_metrics, {}
+        return out
+
+    def _advantages_for(self, b: dict, metrics: bool = True):
+        alg = self.cfg.algorithm
         with self.timer("actor/compute_adv"):
             out = calculate_adv_and_returns(
                 task_type=self.cfg.runner.task_type, adv_type=alg.adv_type, rewards=b["rewards"], dones=b["dones"],
@@ -221,7 +245,7 @@ class EmbodiedFSDPActor(Worker):
                 stats = ops.masked_stats(adv, mask)  # this rank's stage batches together; one env rank feeds one learner
                 out["advantages"] = ops.normalize_from_stats(adv, stats)
             b.update(out)
-            return self._rollout_metrics(b)
+            return self._rollout_metrics(b) if metrics else None
 
     def _rollout_metrics(self, b: dict) -> dict:
         """compute_rollout_metrics (rlinf/utils/metric_utils.py:422-506): masked mean / min / max of rewards, advantages,
@@ -258,27 +282,34 @@ class EmbodiedFSDPActor(Worker):
         return res
 
     # ---- update -------------------------------------------------------------------------------------------------
-    def _flatten_and_shuffle(self):
+    def _pipeline_perm(self, T: int, B: int, epoch: int) -> torch.Tensor:
+        """pack_pipeline_micro_batches (env_worker.py:1519-1537): every stage's [T, B/stages] block flattened and shuffled on
+        its own, stage after stage, with a generator that is seeded ONCE -- a new order every call, written into the same
+        device buffer so that prepared launches / captured graphs keep reading the right rows."""
+        stages = int(self.cfg.rollout.get("pipeline_stage_num", 1))
+        n, N = B // stages, T * B
+        parts = []
+        for st in range(stages):
+            local = torch.randperm(T * n, generator=self._pipe_gen) if self._pipe_shuffle else torch.arange(T * n)
+            parts.append((local // n) * B + st * n + (local % n))
+        pkey = ("perm", N, epoch)
+        if pkey not in self._ws:
+            self._ws[pkey] = torch.empty(N, dtype=torch.int64, device=self.device)
+        self._ws[pkey].copy_(torch.cat(parts), non_blocking=False)
+        return self._ws[pkey]
+
+    def _flatten_and_shuffle(self, b: dict | None = None, epoch: int = 0, n_epochs: int = 1, perm_ready: bool = False):
         """process_nested_dict_for_train (rlinf/utils/nested_dict_process.py:272-285): one randperm per
-        run_training with Generator(seed = actor.seed + rank) (:511-513); one gather launch for every field."""
-        b = self.rollout_batch
+        run_training with Generator(seed = actor.seed + rank) (:511-513); one gather launch for every field.
+        ``epoch`` / ``n_epochs`` (pipeline mode, rollout_epoch > 1): batch ``b`` is rollout epoch ``epoch`` and lands in rows
+        [epoch * N, (epoch + 1) * N) of shuffled buffers that hold all epochs -> (views of that slice, N, the whole buffers)."""
+        b = self.rollout_batch if b is None else b
         T, B = b["prev_logprobs"].shape[:2]
         N = T * B
-        pkey = ("perm", N)
+        pkey = ("perm", N, epoch)
         if self.use_training_pipeline:
-            # pack_pipeline_micro_batches (env_worker.py:1519-1537): every stage's [T, B/stages] block flattened and shuffled
-            # on its own, stage after stage, with a generator that is seeded ONCE -- a new order every iteration, written
-            # into the same device buffer so that captured graphs keep reading the right rows
-            stages = int(self.cfg.rollout.get("pipeline_stage_num", 1))
-            n = B // stages
-            parts = []
-            for st in range(stages):
-                local = torch.randperm(T * n, generator=self._pipe_gen) if self._pipe_shuffle else torch.arange(T * n)
-                parts.append((local // n) * B + st * n + (local % n))
-            host_perm = torch.cat(parts)
-            if pkey not in self._ws:
-                self._ws[pkey] = torch.empty(N, dtype=torch.int64, device=self.device)
-            self._ws[pkey].copy_(host_perm, non_blocking=False)
+            if not perm_ready:
+                self._pipeline_perm(T, B, epoch)
         elif pkey not in self._ws:  # the reference re-seeds the generator on every call: the permutation never changes
             g = torch.Generator()
             g.manual_seed(int(self.cfg.actor.seed) + self._rank)
@@ -299,11 +330,14 @@ class EmbodiedFSDPActor(Worker):
         flat = [t.reshape(N, *t.shape[2:]).contiguous() for t in src]
         # the field set can change between calls with the same N (a loss mask or returns appearing): the cached output
         # buffers are keyed by every field's name, row shape and dtype, never zipped against a different list
-        key = ("shuf", N, tuple((n, tuple(t.shape[1:]), t.dtype) for n, t in zip(names, flat)))
+        key = ("shuf", N, n_epochs, tuple((n, tuple(t.shape[1:]), t.dtype) for n, t in zip(names, flat)))
         if key not in self._ws:
-            self._ws[key] = [torch.empty_like(t) for t in flat]
-        outs = ops.gather_rows(flat, perm, self._ws[key])
-        return dict(zip(names, outs)), N
+            self._ws[key] = [torch.empty((N * n_epochs, *t.shape[1:]), dtype=t.dtype, device=t.device) for t in flat]
+        big = self._ws[key]
+        outs = ops.gather_rows(flat, perm, [t[epoch * N:(epoch + 1) * N] for t in big])
+        if n_epochs == 1:
+            return dict(zip(names, outs)), N
+        return dict(zip(names, outs)), N, dict(zip(names, big))
 
     def _minibatch_workspace(self, mb: int):
         key = ("mb", mb, self.fused_step)
@@ -450,7 +484,7 @@ class EmbodiedFSDPActor(Worker):
                 step += 1
         return step
 
-    def _run_update_prepared(self, flat, N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro):
+    def _run_update_prepared(self, flat, N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro, only_build=False):
         """The same loop with every launch marshalled once: all buffers are persistent, so an optimizer step is a handful of
         ctypes calls (+ one torch.distributed all-reduce when world_size > 1) -- the eager path of multi-GPU runs is
         otherwise bound by Python argument marshalling, not by the GPU."""
@@ -486,12 +520,20 @@ class EmbodiedFSDPActor(Worker):
                     step += 1
             self._ws["prepared_key"], self._ws["prepared_plan"] = pkey, plan
         plan = self._ws["prepared_plan"]
+        if only_build:
+            return plan
+        return self._exec_plan(plan, grads)
+
+    def _exec_plan(self, plan: list, grads: torch.Tensor, lo: int = 0, hi: int | None = None) -> int:
+        """Steps [lo, hi) of a prepared plan on the current stream."""
+        m = self.model
+        steps = plan[lo:hi]
         tiles_fresh = self.optimizer_writes_tiles
         if tiles_fresh:
             m.tiles()  # make sure the image is current before the first forward (no-op when the optimizer kept it fresh)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            for micro_calls, adam in plan:
+            for micro_calls, adam in steps:
                 for call in micro_calls:
                     call(stream)
                 if self._world_size > 1 and self._xgmi is None:
@@ -499,12 +541,73 @@ class EmbodiedFSDPActor(Worker):
                     all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1); capturable in a hipGraph
                 adam(stream)
         m.mark_updated(tiles_fresh=tiles_fresh)
-        self.optimizer_steps += len(plan)
-        self._lr_log.extend([(self._lrs[0], self._lrs[1])] * len(plan))
-        return len(plan)
+        self.optimizer_steps += len(steps)
+        self._lr_log.extend([(self._lrs[0], self._lrs[1])] * len(steps))
+        return len(steps)
+
+    def _run_pipeline_epochs(self) -> dict:
+        """runner.use_training_pipeline with rollout_epoch E > 1 (fsdp_actor_worker_pipeline.py:84-160 over the per-epoch sends of
+        env_worker.py:1324-1330).  For every epoch, as soon as ITS rollout is complete (the env worker's event; the rollout of
+        the next epoch keeps running on its own stream, with its own frozen weights): un-normalised GAE, statistics
+        normalisation over the epoch's batch, per-stage stateful shuffles, first training pass over the epoch's global batches.
+        Then the stored global batches again, pass by pass, oldest first (select_global_batch).  The reference's interleaving
+        of first and later passes depends on arrival timing; this is the schedule of a rollout that delivers each epoch just as
+        the previous one's first pass ends -- the one its overlap is built for."""
+        a, alg = self.cfg.actor, self.cfg.algorithm
+        from ..common import peer
+        E = self.pipeline_epochs
+        env = peer("env")
+        events = env.epoch_events if (env is not None and env.epoch_events) else None
+        stream = torch.cuda.current_stream(self.device)
+        reds, plan, grads = [], None, None
+        T0, B0 = self.rollout_batches[0]["prev_logprobs"].shape[:2]
+        for e in range(E):  # the shuffles do not depend on the data: staged before the learner stream starts waiting on rollouts
+            self._pipeline_perm(T0, B0, e)
+        for e, b in enumerate(self.rollout_batches):
+            if events is not None:
+                stream.wait_event(events[e])
+            self._advantages_for(b, metrics=False)
+            names = [k for k in ("rewards", "advantages", "returns") if b.get(k) is not None]
+            reds.append(ops.rollout_metrics([b[k] for k in names], b.get("loss_mask")))
+            _, N_e, big = self._flatten_and_shuffle(b, epoch=e, n_epochs=E, perm_ready=True)
+            if plan is None:
+                N = N_e * E
+                n_mb, per_rank, accum = minibatch_plan(N, a.global_batch_size, a.micro_batch_size, self._world_size)
+                assert N_e % per_rank == 0, f"a rollout epoch ({N_e} rows) must hold whole global batches ({per_rank} rows per rank)"
+                n_e, epochs = N_e // per_rank, alg.get("update_epoch", 1)
+                key = ("metrics", n_mb * epochs, accum)
+                if key not in self._ws:
+                    self._ws[key] = (torch.zeros(n_mb * epochs * accum, PPO_OUT_FLOATS, device=self.device),
+                                     torch.zeros(n_mb * epochs, 2, device=self.device))
+                metrics_dev, norms_dev = self._ws[key]
+                micro = a.micro_batch_size
+                ws = self._minibatch_workspace(micro)
+                gkey = ("grads", micro, accum)
+                if gkey not in self._ws:
+                    self._ws[gkey] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
+                    self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
+                grads = self._ws[gkey]
+                self._grad_out_host = 1.0 / accum
+                assert self.fused_step and self.critic_warmup_steps == 0, "the pipeline learner runs the fused prepared step"
+                plan = self._run_update_prepared(big, N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro,
+                                                 only_build=True)
+            self._exec_plan(plan, grads, e * n_e, (e + 1) * n_e)  # first pass over THIS epoch's global batches
+        self._exec_plan(plan, grads, n_mb, None)  # passes 2 .. update_epoch over every stored global batch, oldest first
+        red = torch.stack(reds)  # [E, k, 4]: sums add, (-min, max) take the maximum
+        self._deferred_rollout_metrics = self._metrics_from_reductions(
+            names, torch.cat([red[:, :, :2].sum(dim=0), red[:, :, 2:].amax(dim=0)], dim=1))
+        out = self._collect_metrics(metrics_dev, norms_dev, accum)
+        if self._xgmi is not None:
+            self._xgmi.check_status()
+        self._step_lr_scheduler()
+        return out
 
     def run_training(self, input_channel=None) -> dict:
         a, alg = self.cfg.actor, self.cfg.algorithm
+        if self.pipeline_epochs > 1:
+            with self.timer("run_training"):
+                self._lr_log = []
+                return self._run_pipeline_epochs()
         with self.timer("run_training"):
             flat, N = self._flatten_and_shuffle()
             n_mb, _, accum = minibatch_plan(N, a.global_batch_size, a.micro_batch_size, self._world_size)

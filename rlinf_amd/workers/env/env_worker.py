@@ -18,6 +18,14 @@ from ...scheduler.placement import compute_split_num, env_shard
 from ..common import Worker, peer
 
 
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 class EnvWorker(Worker):
     ROLE = "env"
 
@@ -46,6 +54,16 @@ class EnvWorker(Worker):
         self._eps = None
         self._prefetched_train_bootstrap = None
         self._eval_env = None
+        # runner.use_training_pipeline with rollout_epoch > 1 (embodied_runner.py:565-642, env_worker.py:1074,1324-1330): the
+        # reference hands every finished rollout epoch to the learner at once and rolls the next one out while the learner
+        # trains on it.  Here: one trajectory buffer per epoch, the rollout loop on its own HIP stream with an event per epoch;
+        # the learner's stream waits on epoch e's event only (runner.pipeline_overlap: false keeps everything on one stream).
+        self.pipeline_epochs = bool(cfg.runner.get("use_training_pipeline", False)) and self.rollout_epoch > 1
+        self.overlap = self.pipeline_epochs and bool(cfg.runner.get("pipeline_overlap", True))
+        self.buffers: list = []
+        self.epoch_events: list = []
+        self._rollout_stream = None
+        self._epoch_graphs: dict = {}
 
     def init_worker(self, env_tensors: dict | None = None):
         m = self.cfg.actor.model
@@ -57,10 +75,19 @@ class EnvWorker(Worker):
                                            int(self.train_cfg.get("max_episode_steps", 50)),
                                            mode=self.train_cfg.get("synthetic_done_mode", "periodic"))
         self.env = SyntheticManiSkillEnv(env_tensors, self.device, m.num_action_chunks, self.auto_reset, slice(begin, end))
-        # rollout epochs are laid out side by side on the batch axis: the learner's fold (a8) costs nothing
-        self.buffer = TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs * self.rollout_epoch, m.obs_dim, m.action_dim,
-                                       m.num_action_chunks, device=self.device,
-                                       max_episode_length=int(self.train_cfg.get("max_episode_steps", 0)))
+        mel = int(self.train_cfg.get("max_episode_steps", 0))
+        if self.pipeline_epochs:  # one contiguous buffer per rollout epoch: each is a complete batch for the learner on its own
+            self.buffers = [TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs, m.obs_dim, m.action_dim, m.num_action_chunks,
+                                             device=self.device, max_episode_length=mel) for _ in range(self.rollout_epoch)]
+            self.buffer = self.buffers[0]
+            if self.device.type == "cuda":
+                self.epoch_events = [torch.cuda.Event() for _ in range(self.rollout_epoch)]
+                if self.overlap:
+                    self._rollout_stream = torch.cuda.Stream(self.device)
+        else:
+            # rollout epochs are laid out side by side on the batch axis: the learner's fold (a8) costs nothing
+            self.buffer = TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs * self.rollout_epoch, m.obs_dim, m.action_dim,
+                                           m.num_action_chunks, device=self.device, max_episode_length=mel)
         self._bootstrap_v = torch.zeros(self.num_envs, self.buffer.V, device=self.device)
 
     def connect(self, rollout):
@@ -115,6 +142,8 @@ class EnvWorker(Worker):
             self._eps.copy_(eps)
         # PolicyOutput.versions = full_like(prev_logprobs, version) (huggingface_worker.py:579-610): the weights do not change
         # inside a rollout, so one fill per rollout -- outside the captured step loop, the value changes every iteration
+        if self.pipeline_epochs:
+            return self._interact_pipeline_epochs(self._eps, mode)
         self.buffer.versions.fill_(float(self.rollout.version))
         if not (self.use_graph and mode == "train" and self.device.type == "cuda"):
             return self._interact_eager(self._eps, mode)
@@ -128,6 +157,55 @@ class EnvWorker(Worker):
             return None
         self._graph.replay()
         return None
+
+    def _interact_pipeline_epochs(self, eps: torch.Tensor, mode: str = "train"):
+        """Epoch after epoch into its own buffer, on the rollout stream when overlapping; event e marks "epoch e is complete"
+        (all its rows incl. the bootstrap folds and the closing value row).  With rollout.enable_cuda_graph every epoch is one
+        hipGraph (captured on the stream it replays on)."""
+        cuda = self.device.type == "cuda"
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        rs = self._rollout_stream if (self.overlap and cuda) else main
+        if cuda and rs is not main:
+            rs.wait_stream(main)  # weight sync, noise copy, the previous iteration's reads of these buffers
+        ctx = torch.cuda.stream(rs) if (cuda and rs is not main) else _null()
+        with ctx:
+            for e, buf in enumerate(self.buffers):
+                buf.versions.fill_(float(self.rollout.version))
+                if self.use_graph and mode == "train" and cuda:
+                    g = self._epoch_graphs.get(e)
+                    if g is None:
+                        self._run_epoch(e, eps, mode)  # real run; also warms every allocation
+                        torch.cuda.synchronize(self.device)
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=rs if rs is not main else None):
+                            self._run_epoch(e, eps, mode)
+                        self._epoch_graphs[e] = g
+                    else:
+                        g.replay()
+                else:
+                    self._run_epoch(e, eps, mode)
+                if cuda:
+                    self.epoch_events[e].record(rs)
+        return None
+
+    def _run_epoch(self, epoch: int, eps: torch.Tensor, mode: str = "train"):
+        """One rollout epoch of the pipeline layout into buffers[epoch] (same launches as _interact_eager's inner loop)."""
+        buf, env, ro = self.buffers[epoch], self.env, self.rollout
+        buf.reset()
+        T = self.n_train_chunk_steps
+        cols = slice(None)
+        obs, _ = env.reset(epoch * T)
+        for t in range(T):
+            chunk_actions = ro.predict(obs, out=buf.policy_rows(t, cols), eps=None if eps is None else eps[epoch * T + t],
+                                       mode=mode, states_copy=buf.states[t, cols])
+            obs, rewards, term, trunc, infos = env.chunk_step(chunk_actions)
+            r_row, d_row, te_row, tr_row = buf.env_rows(t, cols)
+            if self.auto_reset:
+                ro.queue_bootstrap(infos["final_obs"], r_row, None, self.gamma, env=(rewards, term, trunc),
+                                   rows=(d_row, te_row, tr_row), flag_is_truncation=self.bootstrap_type != "always")
+            else:
+                ops.store_env_rows_(rewards, term, trunc, r_row, d_row, te_row, tr_row)
+        ro.get_bootstrap_values(obs, out=buf.prev_values[T, cols])
 
     def _interact_eager(self, eps: torch.Tensor, mode: str = "train"):
         """ONE launch per chunk step with auto_reset: the fused policy launch also carries the value job that stores the
@@ -205,4 +283,6 @@ class EnvWorker(Worker):
     def send_rollout_trajectories(self, actor_world_size: int | None = None) -> list:
         """to_splited_trajectories(actor_split_num) (env_worker.py:1026,1463-1467): views, no copies."""
         split = compute_split_num(actor_world_size or self._world_size, self._world_size * self.stage_num)
+        if self.pipeline_epochs:  # epoch-major: the learner takes `split * stage_num` trajectories per rollout epoch
+            return [t for buf in self.buffers for t in buf.to_splited_trajectories(split * self.stage_num)]
         return self.buffer.to_splited_trajectories(split * self.stage_num)

@@ -27,10 +27,18 @@ class MultiStepRolloutWorker(Worker):
         reference's way (no argument, BEFORE the actor is initialised, embodied_runner.py:163-170) the decision is deferred to
         the first ``sync_model_from_actor()``: alias the in-process learner's model unless ``rollout.share_actor_weights`` is
         off (a rollout that must keep its weights frozen while the learner updates, e.g. the overlapped pipeline)."""
+        if self._overlapped_pipeline():  # the rollout of epoch e + 1 runs WHILE the learner updates: it needs its own frozen copy
+            self.cfg.rollout.share_actor_weights = False
+            model = None
         if model is not None:
             self.hf_model, self._shares_actor_weights = model, True
         elif not (bool(self.cfg.rollout.get("share_actor_weights", True)) and peer("actor") is not None):
             self.hf_model = get_model(self.cfg.actor.model).to(self.device)
+
+    def _overlapped_pipeline(self) -> bool:
+        r = self.cfg.runner
+        return (bool(r.get("use_training_pipeline", False)) and self.cfg.env.train.get("rollout_epoch", 1) > 1
+                and bool(r.get("pipeline_overlap", True)))
 
     def adopt_model(self, model):
         """Alias the collocated learner's policy object."""

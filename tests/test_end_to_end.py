@@ -13,10 +13,11 @@ from oracle import ppo_oracle as O
 
 def make_cfg(total_envs=8, steps=16, global_batch=32, micro_batch=None, update_epoch=2, gamma=0.8, lam=0.9,
              auto_reset=True, hip_graph=False, rollout_epoch=1, entropy_bonus=0, stage_num=1, pipeline=False,
-             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0, done_mode=None, entropy_type="action_level"):
+             critic_warmup_steps=0, lr_scheduler=None, total_training_steps=0, done_mode=None, entropy_type="action_level",
+             pipeline_overlap=True):
     from rlinf_amd.config import DictConfig
     return DictConfig(dict(
-        runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline),
+        runner=dict(task_type="embodied", max_epochs=1, max_steps=-1, use_training_pipeline=pipeline, pipeline_overlap=pipeline_overlap),
         algorithm=dict(update_epoch=update_epoch, normalize_advantages=True, group_size=1, reward_type="action_level",
                        logprob_type="action_level", entropy_type=entropy_type, adv_type="gae", loss_type="actor_critic",
                        bootstrap_type="always", entropy_bonus=entropy_bonus, clip_ratio_high=0.2, clip_ratio_low=0.2, value_clip=1.0,
@@ -170,6 +171,55 @@ def test_iteration_matches_oracle(shape):
         assert float((diff > 2e-5 * (it + 1)).float().mean()) < 0.02, float((diff > 2e-5).float().mean())
     # the device-side Adam step counter restarts when the warm-up ends (a new optimizer in the reference)
     assert int(runner.actor.worker.step_state.sum()) == runner.actor.worker.optimizer_steps - shape.get("critic_warmup_steps", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap,hip_graph,stage_num,epochs", [(True, False, 2, 2), (True, True, 1, 3), (False, False, 2, 2),
+                                                                (False, True, 2, 2)])
+def test_pipeline_rollout_epochs_overlap_matches_oracle(overlap, hip_graph, stage_num, epochs):
+    """runner.use_training_pipeline with rollout_epoch > 1 (embodied_runner.py:565-642, env_worker.py:1324-1330,
+    fsdp_actor_worker_pipeline.py:84-160): every epoch is its own learner batch -- own statistics normalisation, own stage
+    shuffles from the rank's running generator -- rolled out with the iteration's frozen weights while the learner trains on
+    the previous epoch (rollout on its own HIP stream, one event per epoch; the rollout worker holds its own weight copy).
+    Overlapped or not, graph-replayed rollouts or not: the same numbers as the oracle's sequential restatement."""
+    T, B, GB = 10, 16, 80
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=40, rollout_epoch=epochs, stage_num=stage_num, pipeline=True,
+                   hip_graph=hip_graph, pipeline_overlap=overlap)
+    env = L.synthetic_env_tensors(0, T * epochs, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    sd = copy.deepcopy(ora.state_dict())
+    opt = O.build_adamw(ora)
+    runner = _build(cfg, env, sd)
+    w = runner.actor.worker
+    assert runner.env.worker.overlap == overlap and (runner.rollout.worker.hf_model is not w.model) == overlap
+    pipe = dict(stage_num=stage_num, generator=torch.Generator().manual_seed(1234))
+    for it in range(3):
+        eps = torch.randn(T * epochs, B, 8, generator=torch.Generator().manual_seed(100 + it))
+        batches, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234, global_batch=GB, update_epoch=2,
+                                  rollout_epoch=epochs, pipeline=pipe)
+        metrics = runner.run_step(eps.cuda())
+        tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)
+        assert len(w.rollout_batches) == epochs
+        for rb, batch in zip(w.rollout_batches, batches):
+            torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), batch["forward_inputs"]["action"], **tol)
+            torch.testing.assert_close(rb["prev_values"].cpu(), batch["prev_values"], **tol)
+            torch.testing.assert_close(rb["rewards"].cpu(), batch["rewards"], **tol)
+            assert torch.equal(rb["dones"].cpu(), batch["dones"])
+            torch.testing.assert_close(rb["returns"].cpu(), batch["returns"], **tol)
+            torch.testing.assert_close(rb["advantages"].cpu(), batch["advantages"], rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+        want_gn = sum(float(m["actor/grad_norm"]) for m in om) / len(om)
+        assert metrics["train/actor/grad_norm"] == pytest.approx(want_gn, rel=2e-3)
+        want_loss = sum(float(m["actor/total_loss"]) for m in om) / len(om) / 2  # 2 micro-batches per global batch
+        assert metrics["train/actor/total_loss"] == pytest.approx(want_loss, rel=2e-3, abs=2e-4)
+        all_r = torch.cat([b["rewards"] for b in batches], dim=1)
+        assert metrics["rollout/rewards"] == pytest.approx(float(all_r.mean()), rel=1e-4)
+        assert metrics["rollout/advantages_max"] == pytest.approx(max(float(b["advantages"].max()) for b in batches), rel=1e-3)
+        diff = (w.model.flat.detach().cpu() - torch.cat([p.detach().reshape(-1) for p in ora.parameters()])).abs()
+        steps_taken = len(om) * (it + 1)
+        assert len(om) == epochs * (T * B // GB) * 2
+        assert float(diff.max()) <= 2 * 3e-4 * steps_taken + 1e-6
+        assert float((diff > 2e-5 * (it + 1)).float().mean()) < 0.02, float((diff > 2e-5).float().mean())
 
 
 @pytest.mark.gpu
