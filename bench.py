@@ -248,7 +248,9 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     adv, ret = torch.empty_like(v), torch.empty_like(v)
     lib = _lib_handle()
     st = torch.cuda.current_stream(device).cuda_stream
-    us = avg_us(lambda: lib.rlx_gae_seq(v.data_ptr(), r.data_ptr(), adv.data_ptr(), ret.data_ptr(), 4096, 8192, 1.0, 0.95, st))
+    gws = torch.empty(lib.rlx_gae_seq_workspace_bytes(4096, 8192), dtype=torch.uint8, device=device)
+    us = avg_us(lambda: lib.rlx_gae_seq(v.data_ptr(), r.data_ptr(), adv.data_ptr(), ret.data_ptr(), 4096, 8192, 1.0, 0.95,
+                                        gws.data_ptr(), gws.numel(), st))
     nb = v.numel() * 12
     rows.append({"kernel": "gae_seq", "bound": "hbm", "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1), "algorithmic_bytes": nb,

@@ -216,7 +216,9 @@ PROTOTYPES = {
     "rlx_reinpp_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_int64, c_int64, c_void_p,
                                    c_size_t, c_void_p]),
     "rlx_masked_normalize": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_int64, c_void_p]),
-    "rlx_gae_seq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p]),
+    "rlx_gae_seq_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "rlx_gae_seq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_size_t,
+                            c_void_p]),
     "rlx_grpo_seq_adv": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
     "rlx_rollout_metrics_workspace_bytes": (c_size_t, []),
     "rlx_rollout_metrics": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_int64, c_void_p, c_void_p, c_size_t,

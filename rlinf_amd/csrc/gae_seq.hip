@@ -23,9 +23,15 @@
 #define RLX_GAESEQ_NT 0  // dev switch: streaming (non-temporal) loads of the values and stores of both outputs
 #endif
 
+#include <stdlib.h>
+
 namespace rlx {
 namespace {
 
+inline int dev_variant_gaeseq() {  // development switch, read once: RLX_GAESEQ_VARIANT=1 -> the former per-sequence walk
+    static const int v = [] { const char* e = getenv("RLX_GAESEQ_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
+}
 
 __device__ __forceinline__ int pad(int i) { return i + (i >> 5); }  // chunk starts land in distinct banks
 
@@ -181,13 +187,219 @@ __global__ __launch_bounds__(ST) void gae_seq_kernel(const float* __restrict__ v
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Long sequences: ONE SEGMENT PER WORKGROUP with a decoupled look-back for the carry.
+// The kernel above walks a sequence's segments one after the other inside one workgroup of 512 lanes holding 66 KB of LDS: at
+// most two such workgroups fit a CU and each alternates load / scan / store phases, so the memory pipes idle most of the time
+// (0.57-0.63 of the HBM peak).  Here a row of `seq` tokens is cut into nseg = ceil(seq / SEG) segments and every segment is its
+// own 128-lane workgroup (17 KB of LDS: nine per CU, their phases interleave).  Segment j (counted from the END of the row, so
+// that within a row the workgroups are dispatched in the order the recurrence runs) needs g at the first token to its right:
+//   * it publishes its aggregate map (K_j, G_j): g_in -> K_j g_in + G_j, as soon as its chunk maps are composed;
+//   * it looks back over j-1, j-2, ...: a neighbour that already knows its own carry-in has published g_first (done); one that
+//     has only its aggregate contributes that map and the walk goes on (segment 0's carry-in is 0);
+//   * after its replay it publishes g_first itself.
+// A publication is ONE 64-bit agent-scope atomic store of (value, 1.0f): payload and validity travel in the same word, written
+// through to the memory side, so no fence (= no L2 write-back) is needed and a NaN payload is still a valid publication; the
+// workspace is memset to 0xFF before the launch.  Workgroups only ever wait for workgroups with a LOWER linear index, which the
+// dispatcher has already started: forward progress is guaranteed (and every wait is bounded all the same: a hang would cost
+// a GPU, a NaN row is merely wrong).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Slot {
+    unsigned long long k, g;  // the segment's aggregate map, each as (value, 1.0f)
+    unsigned long long fin;   // (g at the segment's first token, 1.0f)
+    unsigned long long pad_;
+};
+
+__device__ __forceinline__ unsigned long long publish_word(float v) {
+    return (unsigned long long)__float_as_uint(v) | ((unsigned long long)0x3F800000u << 32);
+}
+__device__ __forceinline__ bool word_valid(unsigned long long w) { return (unsigned)(w >> 32) == 0x3F800000u; }
+__device__ __forceinline__ float word_value(unsigned long long w) { return __uint_as_float((unsigned)w); }
+
+template <int ST, int SEG>
+__global__ __launch_bounds__(ST) void gae_seq_lb_kernel(const float* __restrict__ values, const float* __restrict__ rewards,
+                                                        float* __restrict__ adv, float* __restrict__ ret, int seq, int nseg,
+                                                        float gamma, float gamma_lambda, Slot* __restrict__ slots) {
+    extern __shared__ float lds[];
+    float* sv = lds;
+    float* sg = lds + pad(SEG + 1) + 1;
+    __shared__ float sK[ST / 64], sG[ST / 64], sIn[2];
+    const long long row = blockIdx.x / nseg;
+    const int j = blockIdx.x % nseg;  // segment index from the END of the row
+    const int hi = seq - j * SEG, lo = hi > SEG ? hi - SEG : 0, len = hi - lo;
+    const float* v = values + row * (long long)seq;
+    const float r = rewards[row];
+    Slot* my = slots + row * nseg + j;
+    // ---- stage (same clamped, unconditional loads as above) --------------------------------------------------------------
+    const bool vec = ((reinterpret_cast<uintptr_t>(v + lo) & 15u) == 0) && (len % 4 == 0);
+    if (vec) {
+        const int nq = len / 4;
+        const float4* v4 = reinterpret_cast<const float4*>(v + lo);
+        constexpr int QI = 4;
+        for (int q0 = 0; q0 < nq; q0 += QI * ST) {
+            float4 q[QI];
+#pragma unroll
+            for (int k = 0; k < QI; ++k) q[k] = v4[min(q0 + k * ST + (int)threadIdx.x, nq - 1)];
+#pragma unroll
+            for (int k = 0; k < QI; ++k) {
+                const int qi = q0 + k * ST + threadIdx.x;
+                if (qi < nq) {
+                    sv[pad(4 * qi)] = q[k].x, sv[pad(4 * qi + 1)] = q[k].y;
+                    sv[pad(4 * qi + 2)] = q[k].z, sv[pad(4 * qi + 3)] = q[k].w;
+                }
+            }
+        }
+    } else {
+        constexpr int SI = 8;
+        for (int i0 = 0; i0 < len; i0 += SI * ST) {
+            float x[SI];
+#pragma unroll
+            for (int k = 0; k < SI; ++k) x[k] = v[lo + min(i0 + k * ST + (int)threadIdx.x, len - 1)];
+#pragma unroll
+            for (int k = 0; k < SI; ++k) {
+                const int i = i0 + k * ST + threadIdx.x;
+                if (i < len) sv[pad(i)] = x[k];
+            }
+        }
+    }
+    if (threadIdx.x == 0) sv[pad(len)] = hi < seq ? v[hi] : 0.f;
+    __syncthreads();
+    const int per = (len + ST - 1) / ST;
+    const int chunk = ST - 1 - (int)threadIdx.x;
+    const int c0 = min(len, chunk * per), c1 = min(len, c0 + per);
+    float K = 1.f, G = 0.f;
+    {
+        float vnext = sv[pad(c1)];
+        for (int i = c1 - 1; i >= c0; --i) {
+            const int t = lo + i;
+            const float vi = sv[pad(i)];
+            const float nxt = (t == seq - 1) ? r : fmul(gamma, vnext);
+            const float delta = fsub(nxt, vi);
+            const float k = (t == seq - 1) ? 0.f : gamma_lambda;
+            G = fadd(delta, fmul(k, G));
+            K = fmul(K, k);
+            vnext = vi;
+        }
+    }
+    float iK = K, iG = G;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float oK = __shfl_up(iK, off, 64), oG = __shfl_up(iG, off, 64);
+        if (lane >= off) {
+            iG = fadd(iG, fmul(iK, oG));
+            iK = fmul(iK, oK);
+        }
+    }
+    if (lane == 63) sK[wid] = iK, sG[wid] = iG;
+    __syncthreads();
+    float bK = 1.f, bG = 0.f;
+    for (int w = 0; w < wid; ++w) {
+        bG = fadd(sG[w], fmul(sK[w], bG));
+        bK = fmul(sK[w], bK);
+    }
+    float eK = __shfl_up(iK, 1, 64), eG = __shfl_up(iG, 1, 64);
+    if (lane == 0) eK = 1.f, eG = 0.f;
+    const float tK = fmul(eK, bK), tG = fadd(eG, fmul(eK, bG));  // everything this segment visits before this chunk
+    // ---- the last lane holds the segment's aggregate: publish it, then resolve the carry by looking back ------------------
+    if (threadIdx.x == ST - 1) {
+        const float aK = fmul(iK, bK), aG = fadd(iG, fmul(iK, bG));
+        float carry = 0.f;
+        if (nseg > 1) {
+            __hip_atomic_store(&my->k, publish_word(aK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&my->g, publish_word(aG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float accK = 1.f, accG = 0.f;  // maps of the segments walked so far, nearest applied LAST: carry = accK * x + accG
+            bool done = j == 0;
+            for (int q = j - 1; !done; --q) {
+                const Slot* s = slots + row * nseg + q;
+                for (int spin = 0;; ++spin) {
+                    const unsigned long long f = __hip_atomic_load(&s->fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (word_valid(f)) {  // the neighbour knows its own carry-in: g at its first token is final
+                        carry = fadd(accG, fmul(accK, word_value(f)));
+                        done = true;
+                        break;
+                    }
+                    const unsigned long long wk = __hip_atomic_load(&s->k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long wg = __hip_atomic_load(&s->g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (word_valid(wk) && word_valid(wg)) {  // only its aggregate so far: fold it in, keep walking to the right
+                        accG = fadd(accG, fmul(accK, word_value(wg)));
+                        accK = fmul(accK, word_value(wk));
+                        if (q == 0) {  // the row's last segment starts from g = 0
+                            carry = accG;
+                            done = true;
+                        }
+                        break;
+                    }
+                    if (spin > (1 << 22)) {  // cannot happen with in-order dispatch; never hang the GPU over it
+                        carry = __uint_as_float(0x7FC00000u);
+                        done = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        sIn[0] = carry;
+        sIn[1] = fadd(aG, fmul(aK, carry));  // g at this segment's first token
+    }
+    __syncthreads();
+    const float carry = sIn[0];
+    if (threadIdx.x == ST - 1 && nseg > 1)
+        __hip_atomic_store(&my->fin, publish_word(sIn[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        float g = fadd(tG, fmul(tK, carry)), vnext = sv[pad(c1)];
+        for (int i = c1 - 1; i >= c0; --i) {
+            const int t = lo + i;
+            const float vi = sv[pad(i)];
+            const float nxt = (t == seq - 1) ? r : fmul(gamma, vnext);
+            const float delta = fsub(nxt, vi);
+            const float k = (t == seq - 1) ? 0.f : gamma_lambda;
+            g = fadd(delta, fmul(k, g));
+            sg[pad(i)] = g;
+            vnext = vi;
+        }
+    }
+    __syncthreads();
+    float* ro = ret + row * (long long)seq + lo;
+    float* ao = adv + row * (long long)seq + lo;
+    if (vec && ((reinterpret_cast<uintptr_t>(ro) | reinterpret_cast<uintptr_t>(ao)) & 15u) == 0) {
+        for (int qi = threadIdx.x; qi < len / 4; qi += ST) {
+            float rt[4], at[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float gi = sg[pad(4 * qi + jj)], vi = sv[pad(4 * qi + jj)];
+                rt[jj] = fadd(gi, vi);
+                at[jj] = fsub(rt[jj], vi);
+            }
+            reinterpret_cast<float4*>(ro)[qi] = make_float4(rt[0], rt[1], rt[2], rt[3]);
+            reinterpret_cast<float4*>(ao)[qi] = make_float4(at[0], at[1], at[2], at[3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < len; i += ST) {
+            const float gi = sg[pad(i)], vi = sv[pad(i)];
+            const float rt = fadd(gi, vi);
+            ro[i] = rt;
+            ao[i] = fsub(rt, vi);
+        }
+    }
+}
+
 }  // namespace
 }  // namespace rlx
 
 using namespace rlx;
 
+constexpr int LB_SEG = 2048, LB_ST = 128;
+
+extern "C" size_t rlx_gae_seq_workspace_bytes(int64_t bsz, int64_t seq) {
+    if (seq <= LB_SEG || bsz <= 0) return 256;
+    return (size_t)bsz * (size_t)((seq + LB_SEG - 1) / LB_SEG) * sizeof(Slot);
+}
+
 extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* advantages, float* returns, int64_t bsz,
-                           int64_t seq, float gamma, float gamma_lambda, rlx_stream_t stream) {
+                           int64_t seq, float gamma, float gamma_lambda, void* workspace, size_t workspace_bytes,
+                           rlx_stream_t stream) {
     RLX_REQUIRE(bsz >= 0 && seq >= 0 && bsz < (1ll << 31) && seq < (1ll << 31), "rlx_gae_seq: bad sizes");
     if (bsz == 0 || seq == 0) return RLX_OK;
     RLX_REQUIRE(values && rewards && advantages && returns, "rlx_gae_seq: NULL argument");
@@ -197,12 +409,11 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         return (size_t)(2 * (cap + 1 + (cap + 1) / 32) + 8) * sizeof(float);
     };
     if (seq <= 2048) {
-        // short sequences: 128 lanes each (longer chunks, fewer barriers per token), 17 KB of LDS -> nine resident per CU
+        // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token), 17 KB of LDS -> nine per CU
         hipLaunchKernelGGL((gae_seq_kernel<128, 2048>), dim3((unsigned)bsz), dim3(128), lds_for(2048), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
-    } else {
-        // long sequences: 512 lanes and 8192-token segments (66 KB): measured 0.61 of peak at 8192 tokens against 0.57 for
-        // four sequential 2048-token segments
+    } else if (dev_variant_gaeseq() == 1) {
+        // development: the former one-workgroup-per-sequence walk (512 lanes, 8192-token segments, 66 KB of LDS)
         static bool attr_set = false;
         if (!attr_set) {
             RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gae_seq_kernel<512, 8192>),
@@ -211,6 +422,20 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         }
         hipLaunchKernelGGL((gae_seq_kernel<512, 8192>), dim3((unsigned)bsz), dim3(512), lds_for(8192), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
+    } else {
+        // long sequences: one 2048-token segment per 128-lane workgroup, carries by decoupled look-back
+        const int64_t nseg = (seq + LB_SEG - 1) / LB_SEG;
+        RLX_REQUIRE(bsz * nseg < (1ll << 31), "rlx_gae_seq: too many segments for one launch");
+        const size_t need = rlx_gae_seq_workspace_bytes(bsz, seq);
+        RLX_REQUIRE(workspace != nullptr, "rlx_gae_seq: sequences longer than %d tokens need a workspace", LB_SEG);
+        if (workspace_bytes < need) {
+            set_error("rlx_gae_seq: workspace %zu < %zu bytes", workspace_bytes, need);
+            return RLX_ENOSPC;
+        }
+        RLX_HIP_CHECK(hipMemsetAsync(workspace, 0xFF, need, st));  // every slot invalid (NaN patterns)
+        hipLaunchKernelGGL((gae_seq_lb_kernel<LB_ST, LB_SEG>), dim3((unsigned)(bsz * nseg)), dim3(LB_ST),
+                           (size_t)(2 * (LB_SEG + 1 + (LB_SEG + 1) / 32) + 8) * sizeof(float), st, values, rewards, advantages,
+                           returns, (int)seq, (int)nseg, gamma, gamma_lambda, static_cast<Slot*>(workspace));
     }
     RLX_LAUNCH_CHECK();
     return RLX_OK;

@@ -281,16 +281,20 @@ def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = Non
     return tokens, logprob, actions
 
 
-def gae_seq(values: torch.Tensor, rewards: torch.Tensor, gamma: float = 1.0, gae_lambda: float = 1.0):
-    """Reasoning GAE in the [bsz, seq] layout: values [bsz, seq] f32, rewards [bsz] -> (advantages, returns), un-normalised."""
+def gae_seq(values: torch.Tensor, rewards: torch.Tensor, gamma: float = 1.0, gae_lambda: float = 1.0, out=None, workspace=None):
+    """Reasoning GAE in the [bsz, seq] layout: values [bsz, seq] f32, rewards [bsz] -> (advantages, returns), un-normalised.
+    ``out`` = (advantages, returns) and ``workspace`` (rlx_gae_seq_workspace_bytes) make the call allocation-free."""
     dev = _dev(values, rewards)
     if values.dim() != 2 or rewards.numel() != values.shape[0]:
         raise RlxError("gae_seq: values [bsz, seq], rewards [bsz]")
     v = _as_f32(values, "values")
     r = _as_f32(rewards.reshape(-1), "rewards")
     bsz, seq = v.shape
-    adv, ret = torch.empty_like(v), torch.empty_like(v)
+    adv, ret = (torch.empty_like(v), torch.empty_like(v)) if out is None else out
+    lib = _lib.load()
+    wsb = lib.rlx_gae_seq_workspace_bytes(bsz, seq)
+    ws = workspace if workspace is not None and workspace.numel() >= wsb else torch.empty(wsb, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().rlx_gae_seq(v.data_ptr(), r.data_ptr(), adv.data_ptr(), ret.data_ptr(), bsz, seq, float(gamma),
-                                           float(gamma * gae_lambda), _stream_ptr(dev)), "rlx_gae_seq")
+        _lib.check(lib.rlx_gae_seq(v.data_ptr(), r.data_ptr(), adv.data_ptr(), ret.data_ptr(), bsz, seq, float(gamma),
+                                   float(gamma * gae_lambda), ws.data_ptr(), ws.numel(), _stream_ptr(dev)), "rlx_gae_seq")
     return adv, ret

@@ -93,8 +93,8 @@ def test_argument_validation_of_the_widening_entries(lib):
                                   None) == -22
     assert b"loss_agg" in lib.rlx_last_error()
     assert lib.rlx_grpo_seq_adv(None, None, None, 10, 4, 4, 1e-6, None) == -22 and b"group_size" in lib.rlx_last_error()
-    assert lib.rlx_gae_seq(None, None, None, None, 0, 16, 1.0, 0.95, None) == 0
-    assert lib.rlx_gae_seq(None, None, None, None, 4, 16, 1.0, 0.95, None) == -22
+    assert lib.rlx_gae_seq(None, None, None, None, 0, 16, 1.0, 0.95, None, 0, None) == 0
+    assert lib.rlx_gae_seq(None, None, None, None, 4, 16, 1.0, 0.95, None, 0, None) == -22
     assert lib.rlx_patch_scan(None, 1, None, 1, 0, None, 0, None, None) == -22
     assert lib.rlx_patch_apply(None, 99, 1, 1, ptr, 0, ptr, 0, 0, ptr, 1, None, 0, None) == -22
     # copy_segments: the plan is a host function -- it validates and numbers the chunks without a GPU

@@ -97,7 +97,9 @@ def _build(cfg, env_tensors, state_dict):
                                         hip_graph=True),
                                    # entropy_type chunk_level under a loss mask (C = 1): the reference's masked_mean broadcasts
                                    # [bsz] x [bsz, 1] into an outer product -- the SUM of the row entropies; reproduced as written
-                                   dict(total_envs=32, steps=12, global_batch=192, micro_batch=96, auto_reset=False,
+                                   # (no gradient accumulation here: a SUM over the micro-batch's rows is not micro-batch
+                                   # invariant, and the oracle loop steps whole global batches)
+                                   dict(total_envs=32, steps=12, global_batch=192, auto_reset=False,
                                         done_mode="bernoulli", entropy_bonus=0.001, entropy_type="chunk_level"),
                                    # a schedule that moves every iteration: graphs / prepared plans must follow it
                                    dict(total_envs=16, steps=10, global_batch=80, hip_graph=True, lr_scheduler="torch_cosine",

@@ -70,15 +70,18 @@ def _dev(kw):
 @pytest.mark.parametrize("C", [1, 2])
 @pytest.mark.parametrize("norm", [True, False])
 @pytest.mark.parametrize("use_mask", [False, True])
-def test_real_dispatcher_gae(hooked, C, norm, use_mask):
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_real_dispatcher_gae(hooked, C, norm, use_mask, where):
+    """``where="cpu"``: the reference's trajectories are CPU tensors (embodied_types.py forces .cpu()); the registered callee
+    stages them to the accelerator and hands the result back where the inputs live."""
     ref, builtin = hooked
     r = synth_rollout(T=16, B=32, C=C, p_done=0.05)
     lm, lms = (ref.metric_utils.compute_loss_mask(r["dones"]) if use_mask else (None, None))
     kw = dict(task_type="embodied", adv_type="gae", rewards=r["rewards"], dones=r["dones"], values=r["values"], gamma=0.8,
               gae_lambda=0.9, group_size=8, reward_type="action_level", loss_mask=lm, loss_mask_sum=lms, normalize_advantages=norm)
     want = builtin.calculate_adv_and_returns(**kw)
-    got = ref.registry.calculate_adv_and_returns(**_dev(kw))
-    assert got["advantages"].is_cuda and got["advantages"].shape == want["advantages"].shape
+    got = ref.registry.calculate_adv_and_returns(**(_dev(kw) if where == "cuda" else dict(kw)))
+    assert got["advantages"].device.type == where and got["advantages"].shape == want["advantages"].shape
     torch.testing.assert_close(got["advantages"].cpu(), want["advantages"], rtol=1e-5, atol=2e-6)
     torch.testing.assert_close(got["returns"].cpu(), want["returns"], rtol=1e-5, atol=2e-6)
 
@@ -91,7 +94,11 @@ def test_real_dispatcher_grpo(hooked, G):
     kw = dict(task_type="embodied", adv_type="grpo", rewards=r["rewards"], dones=r["dones"], values=None, gamma=1.0, gae_lambda=1.0,
               group_size=G, reward_type="action_level", loss_mask=lm, loss_mask_sum=lms)
     want = builtin.calculate_adv_and_returns(**kw)
-    got = ref.registry.calculate_adv_and_returns(**_dev(kw))
+    # the reference's calculate_scores allocates its scores with torch.zeros(batch_size) on the CPU whatever the inputs' device
+    # (algorithms/utils.py:134-152): its embodied GRPO dispatcher only works on CPU trajectories, which is what
+    # the reference hands it; the registered callee stages them to the accelerator and returns CPU tensors
+    got = ref.registry.calculate_adv_and_returns(**dict(kw))
+    assert got["advantages"].device.type == "cpu"
     torch.testing.assert_close(got["advantages"].cpu(), want["advantages"], rtol=2e-5, atol=2e-5)
     assert "returns" not in got and "returns" not in want
 

@@ -432,6 +432,30 @@ def test_gae_seq_vs_oracle(seq, gl):
     assert out[0].is_contiguous() and out[1].is_contiguous()
 
 
+def test_gae_seq_lookback_many_rows_and_nan_rows():
+    """Rows longer than 2048 tokens run one segment per workgroup with a decoupled look-back for the carry: thousands of
+    workgroups in flight (every CU busy, neighbours racing), against the sequential oracle; a NaN row must come back NaN --
+    and come back (the look-back never waits on a payload's value, only on its flag)."""
+    from oracle import ppo_oracle as PO
+    bsz, seq = 1500, 6144 + 7
+    g = torch.Generator().manual_seed(9)
+    values = torch.randn(bsz, seq, generator=g)
+    values[3, 4000] = float("nan")
+    rewards = torch.randn(bsz, generator=g)
+    mask = torch.ones(bsz, seq, dtype=torch.bool)
+    pre = TO.preprocess_reasoning(rewards, mask, "gae", values=values)
+    wadv, wret = PO.gae_tb(pre["rewards"], pre["dones"], values=pre["values"], gamma=1.0, gae_lambda=0.95, normalize_advantages=False)
+    for _ in range(3):  # repeated launches reuse the workspace: the slots must be re-armed every time
+        adv, ret = token_ops.gae_seq(values.to(DEV), rewards.to(DEV), 1.0, 0.95)
+    ok = torch.ones(bsz, dtype=torch.bool)
+    ok[3] = False
+    scale = float(wret.transpose(0, 1)[ok].abs().max()) + 1.0
+    atol = (4e-6 + 2e-7 * seq ** 0.5) * scale
+    close(ret[ok.to(DEV)], wret.transpose(0, 1)[ok], atol, 1e-5, "returns")
+    close(adv[ok.to(DEV)], wadv.transpose(0, 1)[ok], atol, 1e-5, "advantages")
+    assert torch.isnan(ret[3, :4001]).all() and torch.isfinite(ret[3, 4002 + 200:]).all()  # NaN flows towards t = 0 only
+
+
 def test_empty_and_degenerate_inputs():
     """Zero tokens / sequences, a one-entry vocabulary, a one-bin categorical head, an empty tensor inside a synced state
     dict: defined results, no launches with zero-sized grids."""
