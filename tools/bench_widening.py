@@ -32,12 +32,16 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1)
     tag = os.environ.get("RLX_LIB_TAG", "") or "default"
     out = []
-    for bsz, seq in ((4096, 8192), (32768, 1024)):
+    for bsz, seq in ((4096, 8192), (16384, 2048), (32768, 1024)):
         v = torch.randn(bsz, seq, device=dev, generator=g)
         r = torch.randn(bsz, device=dev, generator=g)
-        mean, med = avg_us(lambda: token_ops.gae_seq(v, r, 1.0, 0.95))
+        # caller-owned outputs and workspace: nothing is allocated inside the timed calls (two torch.empty per call moved the
+        # round-1 numbers by 10 % from run to run)
+        outs = (torch.empty_like(v), torch.empty_like(v))
+        gws = torch.empty(_lib.load().rlx_gae_seq_workspace_bytes(bsz, seq), dtype=torch.uint8, device=dev)
+        mean, med = avg_us(lambda: token_ops.gae_seq(v, r, 1.0, 0.95, out=outs, workspace=gws))
         nb = v.numel() * 12
-        out.append(dict(lib=tag, kernel="gae_seq", shape=f"{bsz}x{seq}", us=round(mean, 1), median_us=round(med, 1),
+        out.append(dict(lib=tag, kernel="gae_seq" + ("(per-sequence walk)" if os.environ.get("RLX_GAESEQ_VARIANT") == "1" else ""), shape=f"{bsz}x{seq}", us=round(mean, 1), median_us=round(med, 1),
                         frac=round(nb / mean / 1e3 / 8000, 4)))
         lp = -torch.rand(bsz, seq, device=dev, generator=g) * 3
         rlp = lp + 0.3 * torch.randn(bsz, seq, device=dev, generator=g)
@@ -46,7 +50,7 @@ def main():
         nb = v.numel() * 21
         out.append(dict(lib=tag, kernel="reinpp_seq_adv", shape=f"{bsz}x{seq}", us=round(mean, 1), median_us=round(med, 1),
                         frac=round(nb / mean / 1e3 / 8000, 4)))
-        del v, lp, rlp, msk
+        del v, lp, rlp, msk, outs, gws
     masters = [(f"w{i}", torch.randn(4096, 8192, device=dev, generator=g), torch.bfloat16) for i in range(16)]
     packer = BucketPacker(masters)
     mean, med = avg_us(lambda: packer.pack(masters, dev, None, persistent=True))
