@@ -390,7 +390,8 @@ __global__ __launch_bounds__(ST) void gae_seq_lb_kernel(const float* __restrict_
 
 using namespace rlx;
 
-constexpr int LB_SEG = 2048, LB_ST = 128;
+constexpr int LB_SEG = 1024, LB_ST = 128;  // 8.5 KB of LDS per workgroup: sixteen 128-lane workgroups per CU (measured: one-segment rows of
+                                           // 1024 tokens run at 0.72 of the HBM peak, of 2048 tokens at 0.64)
 
 extern "C" size_t rlx_gae_seq_workspace_bytes(int64_t bsz, int64_t seq) {
     if (seq <= LB_SEG || bsz <= 0) return 256;
@@ -408,8 +409,8 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         const int cap = (int)(seq < seg ? seq : seg);
         return (size_t)(2 * (cap + 1 + (cap + 1) / 32) + 8) * sizeof(float);
     };
-    if (seq <= 2048) {
-        // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token), 17 KB of LDS -> nine per CU
+    if (seq <= LB_SEG || (seq <= 2048 && dev_variant_gaeseq() == 1)) {
+        // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token)
         hipLaunchKernelGGL((gae_seq_kernel<128, 2048>), dim3((unsigned)bsz), dim3(128), lds_for(2048), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
     } else if (dev_variant_gaeseq() == 1) {
@@ -423,7 +424,7 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         hipLaunchKernelGGL((gae_seq_kernel<512, 8192>), dim3((unsigned)bsz), dim3(512), lds_for(8192), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
     } else {
-        // long sequences: one 2048-token segment per 128-lane workgroup, carries by decoupled look-back
+        // longer rows: one LB_SEG-token segment per 128-lane workgroup, carries by decoupled look-back
         const int64_t nseg = (seq + LB_SEG - 1) / LB_SEG;
         RLX_REQUIRE(bsz * nseg < (1ll << 31), "rlx_gae_seq: too many segments for one launch");
         const size_t need = rlx_gae_seq_workspace_bytes(bsz, seq);

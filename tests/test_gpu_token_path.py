@@ -400,7 +400,7 @@ def test_categorical_sample_follows_the_distribution():
     assert lg.grad is not None and float(lg.grad[..., :32064 - 64 - 256].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("seq", [1, 5, 300, 8192, 8193, 20000])
+@pytest.mark.parametrize("seq", [1, 5, 300, 1024, 1500, 2048, 8192, 8193, 20000])
 @pytest.mark.parametrize("gl", [(1.0, 0.95), (0.99, 0.9), (1.0, 1.0)])
 def test_gae_seq_vs_oracle(seq, gl):
     """Reasoning GAE along the contiguous axis against the reference's shaping + its sequential loop (the oracle's
@@ -507,7 +507,7 @@ def test_reinpp_matches_reference_fixture():
         _reinpp_close(adv, case["advantages"], p["seq"], str(p))
 
 
-@pytest.mark.parametrize("seq", [1, 3, 64, 1023, 1024, 1025, 4100])
+@pytest.mark.parametrize("seq", [1, 3, 64, 512, 1023, 1024, 1025, 1028, 2048, 4100])
 @pytest.mark.parametrize("kl,beta", [("", 0.0), ("kl", 0.02), ("abs", 0.1), ("mse", 0.1), ("low_var_kl", 0.001)])
 @pytest.mark.parametrize("masks", ["prefix", "ragged"])
 def test_reinpp_vs_oracle(seq, kl, beta, masks):
