@@ -28,9 +28,9 @@
 namespace rlx {
 namespace {
 
-inline int dev_variant_gaeseq() {  // development switch, read once: RLX_GAESEQ_VARIANT=1 -> the former per-sequence walk
-    static const int v = [] { const char* e = getenv("RLX_GAESEQ_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
+inline int dev_variant_gaeseq() {  // RLX_GAESEQ_VARIANT=2 -> one segment per workgroup with decoupled look-back (measured slower)
+    const char* e = getenv("RLX_GAESEQ_VARIANT");
+    return e ? atoi(e) : 0;
 }
 
 __device__ __forceinline__ int pad(int i) { return i + (i >> 5); }  // chunk starts land in distinct banks
@@ -390,8 +390,7 @@ __global__ __launch_bounds__(ST) void gae_seq_lb_kernel(const float* __restrict_
 
 using namespace rlx;
 
-constexpr int LB_SEG = 1024, LB_ST = 128;  // 8.5 KB of LDS per workgroup: sixteen 128-lane workgroups per CU (measured: one-segment rows of
-                                           // 1024 tokens run at 0.72 of the HBM peak, of 2048 tokens at 0.64)
+constexpr int LB_SEG = 2048, LB_ST = 128;
 
 extern "C" size_t rlx_gae_seq_workspace_bytes(int64_t bsz, int64_t seq) {
     if (seq <= LB_SEG || bsz <= 0) return 256;
@@ -409,12 +408,15 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         const int cap = (int)(seq < seg ? seq : seg);
         return (size_t)(2 * (cap + 1 + (cap + 1) / 32) + 8) * sizeof(float);
     };
-    if (seq <= LB_SEG || (seq <= 2048 && dev_variant_gaeseq() == 1)) {
-        // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token)
+    if (seq <= 2048) {
+        // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token), 17 KB of LDS -> nine per CU
         hipLaunchKernelGGL((gae_seq_kernel<128, 2048>), dim3((unsigned)bsz), dim3(128), lds_for(2048), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
-    } else if (dev_variant_gaeseq() == 1) {
-        // development: the former one-workgroup-per-sequence walk (512 lanes, 8192-token segments, 66 KB of LDS)
+    } else if (dev_variant_gaeseq() != 2) {
+        // long sequences: one 512-lane workgroup walks the row in 8192-token segments (66 KB of LDS): 0.62 of the HBM peak at
+        // 4096 x 8192.  The variant below -- one 2048- or 1024-token segment per 128-lane workgroup, carries by decoupled
+        // look-back -- was built to lift the occupancy and measured SLOWER (0.59 with 2048-token segments, 0.50 with 1024):
+        // the chain of publish / poll round trips through the memory side costs more than the idle phases it removes.
         static bool attr_set = false;
         if (!attr_set) {
             RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gae_seq_kernel<512, 8192>),
@@ -424,11 +426,11 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         hipLaunchKernelGGL((gae_seq_kernel<512, 8192>), dim3((unsigned)bsz), dim3(512), lds_for(8192), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
     } else {
-        // longer rows: one LB_SEG-token segment per 128-lane workgroup, carries by decoupled look-back
+        // RLX_GAESEQ_VARIANT=2 (kept tested): one LB_SEG-token segment per 128-lane workgroup, carries by decoupled look-back
         const int64_t nseg = (seq + LB_SEG - 1) / LB_SEG;
         RLX_REQUIRE(bsz * nseg < (1ll << 31), "rlx_gae_seq: too many segments for one launch");
         const size_t need = rlx_gae_seq_workspace_bytes(bsz, seq);
-        RLX_REQUIRE(workspace != nullptr, "rlx_gae_seq: sequences longer than %d tokens need a workspace", LB_SEG);
+        RLX_REQUIRE(workspace != nullptr, "rlx_gae_seq: the look-back variant needs a workspace for rows longer than %d tokens", LB_SEG);
         if (workspace_bytes < need) {
             set_error("rlx_gae_seq: workspace %zu < %zu bytes", workspace_bytes, need);
             return RLX_ENOSPC;

@@ -69,9 +69,10 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
     float* out = ret + b * S;
     const bool vec_ok = aligned && (S % 4 == 0);  // every row then starts 16-byte aligned
     const long long n_tiles = (S + TILE - 1) / TILE;
-    // A tile's operands travel in registers one tile AHEAD of the arithmetic: the loads of the first (rightmost) tile are
-    // issued before the mirrored-mask scan below, every later tile's before the current one is scanned -- a workgroup then
-    // pays one memory round trip per tile instead of two dependent ones (short sequences: 0.47 -> of peak at 32768 x 1024).
+    // Short rows (one or two tiles): the tile's operands travel in registers one tile AHEAD of the arithmetic -- the loads of
+    // the rightmost tile are issued before the mirrored-mask scan below, so a workgroup pays one memory round trip instead of
+    // two dependent ones (32768 x 1024: 0.47 -> 0.51 of the HBM peak).  Longer rows load inside the loop: holding the next
+    // tile across the scan cost 5 % there (4096 x 8192: 0.69 -> 0.65), the block's other waves already cover the latency.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     struct Tile {
         f32x4 a, c;
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
         t.mw = vec_ok ? *reinterpret_cast<const uint32_t*>(m + qc) : 0u;
         return t;
     };
-    Tile nxt = fetch(n_tiles - 1);
+    const bool ahead = n_tiles <= 2;
+    Tile nxt = fetch(ahead ? n_tiles - 1 : 0);
     // ---- reward position (see the header): first True of the mirrored sequence's mask; none -> argmax's 0
     if (tid == 0) s_first = S;
     __syncthreads();
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
     double cnt = 0.0, sum = 0.0, sq = 0.0;
     for (long long tile = n_tiles - 1; tile >= 0; --tile) {
         const long long t0 = tile * TILE + (long long)tid * 4;
-        const Tile cur = nxt;
-        if (tile > 0) nxt = fetch(tile - 1);
+        const Tile cur = ahead ? nxt : fetch(tile);
+        if (ahead && tile > 0) nxt = fetch(tile - 1);
         float r[4];
         uint8_t mk[4];
         if (vec_ok && t0 + 4 <= S) {
@@ -188,90 +190,6 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
         for (int w = 0; w < RT / RLX_WAVE; ++w) t += s_red[tid][w];
         partials[b * 3 + tid] = t;
     }
-}
-
-// Short rows (S <= 64 * TPL, 16-byte aligned, S % 4 == 0): ONE WAVE PER ROW, four rows per workgroup, no LDS and no barrier --
-// every lane owns TPL consecutive tokens, all of a row's loads (log-probs, reference log-probs, mask words, the mirrored row's
-// mask) are in flight together, the suffix sums are a lane-serial pass plus one wave scan.  The block kernel above pays five
-// barriers and two dependent memory round trips per 13 KB row at S = 1024 (0.47-0.51 of the HBM peak at 32768 x 1024).
-template <int TPL>
-__global__ __launch_bounds__(RT) void reinpp_returns_wave_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ mask,
-                                                                 const float* __restrict__ logprob, const float* __restrict__ ref,
-                                                                 int kl_kind, float kl_beta, float* __restrict__ ret,
-                                                                 double* __restrict__ partials, long long B, long long S) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int Q = TPL / 4;  // 16-byte groups per lane
-    const int lane = threadIdx.x & (RLX_WAVE - 1);
-    const long long b = (long long)blockIdx.x * (RT / RLX_WAVE) + threadIdx.x / RLX_WAVE;
-    if (b >= B) return;  // whole waves leave: no barrier below
-    const bool has_kl = kl_beta > 0.f;
-    const float* lp = logprob + b * S;
-    const float* rf = ref + b * S;
-    const uint8_t* m = mask + b * S;
-    const uint8_t* mm = mask + (B - 1 - b) * S;  // the mirrored row decides where the reward lands (see the header)
-    const long long t0 = (long long)lane * TPL;
-    f32x4 a[Q], c[Q];
-    uint32_t mw[Q], mmw[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const long long t = t0 + 4 * q;
-        const long long tc = t + 4 <= S ? t : 0;  // clamped, unconditional
-        if (has_kl) {
-            a[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(lp + tc));
-            c[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rf + tc));
-        }
-        mw[q] = *reinterpret_cast<const uint32_t*>(m + tc);
-        mmw[q] = *reinterpret_cast<const uint32_t*>(mm + tc);
-    }
-    // first True of the mirrored row: lowest token index over the wave (bool bytes are 0 / 1)
-    long long first = S;
-#pragma unroll
-    for (int q = Q - 1; q >= 0; --q) {
-        const long long t = t0 + 4 * q;
-        if (t + 4 <= S && mmw[q]) first = t + (__ffs((int)mmw[q]) - 1) / 8;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long o = __shfl_xor(first, off, RLX_WAVE);
-        first = o < first ? o : first;
-    }
-    const long long eos = S - 1 - (first == S ? 0 : first);
-    const float reward = rewards[b];
-    float r[TPL];
-#pragma unroll
-    for (int q = 0; q < Q; ++q)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long t = t0 + 4 * q + k;
-            float x = 0.f;
-            if (has_kl && t < S) x = -fmul(kl_beta, kl_value(kl_kind, a[q][k], c[q][k]));
-            if (t == eos) x = has_kl ? fadd(reward, x) : reward;
-            r[4 * q + k] = t < S ? x : 0.f;
-        }
-    // suffix sums in f64: inside the lane from the right, then over the lanes to the right
-    double suf[TPL];
-    double run = 0.0;
-#pragma unroll
-    for (int i = TPL - 1; i >= 0; --i) {
-        run += (double)r[i];
-        suf[i] = run;
-    }
-    const double right = wave_incl_scan_from_right(run, lane) - run;
-    double cnt = 0.0, sum = 0.0, sq = 0.0;
-    float* out = ret + b * S;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const long long t = t0 + 4 * q;
-        if (t + 4 > S) continue;
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = (float)(right + suf[4 * q + k]);
-            if ((mw[q] >> (8 * k)) & 0xffu) cnt += 1.0, sum += (double)v[k], sq += (double)v[k] * (double)v[k];
-        }
-        *reinterpret_cast<f32x4*>(out + t) = v;
-    }
-    cnt = wave_sum(cnt), sum = wave_sum(sum), sq = wave_sum(sq);
-    if (lane == 0) partials[b * 3] = cnt, partials[b * 3 + 1] = sum, partials[b * 3 + 2] = sq;
 }
 
 // partials [B][3] -> groups [G][3]: block g sums sequences g, g + G, ... (one single workgroup walking 3 B doubles was
@@ -363,18 +281,10 @@ extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask
     double* groups = partials + (size_t)bsz * 3;
     const uintptr_t bits = reinterpret_cast<uintptr_t>(loss_mask) | reinterpret_cast<uintptr_t>(advantages) |
                            (kl_beta > 0.f ? (reinterpret_cast<uintptr_t>(logprob) | reinterpret_cast<uintptr_t>(ref_logprob)) : 0);
-    const bool aligned = (bits & 15) == 0;
-    const unsigned wave_blocks = (unsigned)((bsz + RT / RLX_WAVE - 1) / (RT / RLX_WAVE));
-    if (aligned && seq % 4 == 0 && seq <= 64 * 16) {
-        hipLaunchKernelGGL(reinpp_returns_wave_kernel<16>, dim3(wave_blocks), dim3(RT), 0, st, rewards, loss_mask, logprob,
-                           ref_logprob, kl_type, kl_beta, advantages, partials, (long long)bsz, (long long)seq);
-    } else if (aligned && seq % 4 == 0 && seq <= 64 * 32) {
-        hipLaunchKernelGGL(reinpp_returns_wave_kernel<32>, dim3(wave_blocks), dim3(RT), 0, st, rewards, loss_mask, logprob,
-                           ref_logprob, kl_type, kl_beta, advantages, partials, (long long)bsz, (long long)seq);
-    } else {
-        hipLaunchKernelGGL(reinpp_returns_kernel, dim3((unsigned)bsz), dim3(RT), 0, st, rewards, loss_mask, logprob, ref_logprob,
-                           kl_type, kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)aligned);
-    }
+    // (A one-wave-per-row variant for rows of <= 2048 tokens -- no LDS, no barrier, 16 / 32 tokens per lane in registers -- was
+    //  measured and dropped: 0.41 / 0.23 of the HBM peak at 32768 x 1024 / 16384 x 2048 against 0.51 / 0.57 for this kernel.)
+    hipLaunchKernelGGL(reinpp_returns_kernel, dim3((unsigned)bsz), dim3(RT), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
+                       kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
     RLX_LAUNCH_CHECK();
     const int n_groups = (int)std::min<long long>(MAX_GROUPS, (bsz + RT - 1) / RT);
     hipLaunchKernelGGL(reinpp_reduce_kernel, dim3(n_groups), dim3(RT), 0, st, partials, (long long)bsz, groups);

@@ -432,11 +432,13 @@ def test_gae_seq_vs_oracle(seq, gl):
     assert out[0].is_contiguous() and out[1].is_contiguous()
 
 
-def test_gae_seq_lookback_many_rows_and_nan_rows():
-    """Rows longer than 2048 tokens run one segment per workgroup with a decoupled look-back for the carry: thousands of
-    workgroups in flight (every CU busy, neighbours racing), against the sequential oracle; a NaN row must come back NaN --
-    and come back (the look-back never waits on a payload's value, only on its flag)."""
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_gae_seq_lookback_many_rows_and_nan_rows(variant, monkeypatch):
+    """Long rows, both kernels: the default walk (one workgroup per row) and RLX_GAESEQ_VARIANT=2, one segment per workgroup with
+    a decoupled look-back for the carry (thousands of workgroups in flight, neighbours racing) -- against the sequential
+    oracle; a NaN row must come back NaN, and come back (the look-back never waits on a payload's value, only on its flag)."""
     from oracle import ppo_oracle as PO
+    monkeypatch.setenv("RLX_GAESEQ_VARIANT", variant)
     bsz, seq = 1500, 6144 + 7
     g = torch.Generator().manual_seed(9)
     values = torch.randn(bsz, seq, generator=g)
