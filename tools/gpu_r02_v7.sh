@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round 2, GPU visit 7: measurement pass -- kernel traces (bf16 / f32), two full bench lines, widening sweep, token tests.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() { name=$1; shift; timeout "$1" "${@:2}" > gpurun_out/$name.log 2>&1; echo "$name rc=$?"; tail -3 gpurun_out/$name.log | cut -c1-250; }
+run v7_t_token 600 python -m pytest tests/test_gpu_token_path.py -q -m gpu -k "gae_seq or reinpp"
+for prec in bf16 32; do
+rm -rf gpurun_out/prof_bench_$prec
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench_$prec -o bench -- python bench.py --precision $prec --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > gpurun_out/v7_bench_prof_$prec.log 2>&1
+echo "prof $prec rc=$?"; tail -1 gpurun_out/v7_bench_prof_$prec.log | cut -c1-160
+DB=$(ls gpurun_out/prof_bench_$prec/*.db gpurun_out/prof_bench_$prec/*/*.db 2>/dev/null | head -1)
+if [ -n "$DB" ]; then python tools/rocpd_stats.py "$DB" > gpurun_out/v7_bench_kernels_$prec.txt 2>&1; head -12 gpurun_out/v7_bench_kernels_$prec.txt; fi
+done
+run v7_bench_a 900 python bench.py
+run v7_bench_b 600 python bench.py --no-cpu-baseline --no-roofline
+run v7_bench_f32 600 python bench.py --precision 32 --no-cpu-baseline --no-roofline
+run v7_bench_nograph 600 python bench.py --no-graph --no-cpu-baseline --no-roofline
+run v7_widening 300 python tools/bench_widening.py; grep kernel gpurun_out/v7_widening.log
