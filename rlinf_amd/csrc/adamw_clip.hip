@@ -264,8 +264,11 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
     __syncthreads();
     const float coef = s_coef;
     const bool skip = s_skip != 0;
-    for (long long i = i0; i < n4; i += stride) {
-        if (i != i0) {
+    const int lane = threadIdx.x & 63;
+    for (long long iw = i0 - lane; iw < n4; iw += stride) {  // wave-uniform trip count: the tile scatter below shuffles across lanes
+        const long long i = iw + lane;
+        const bool live = i < n4;
+        if (live && i != i0) {
             p4 = reinterpret_cast<const float4*>(p)[i];
             g4 = reinterpret_cast<const float4*>(g)[i];
             m4 = reinterpret_cast<const float4*>(m)[i];
@@ -273,26 +276,40 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         }
         float pe[4] = {p4.x, p4.y, p4.z, p4.w}, ge[4] = {g4.x, g4.y, g4.z, g4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w},
               ve[4] = {v4.x, v4.y, v4.z, v4.w};
-        int grp[4];
-        const int g_first = group_of(a, 4 * i), g_last = group_of(a, 4 * i + 3);
+        int grp[4] = {-1, -1, -1, -1};
+        if (live) {
+            const int g_first = group_of(a, 4 * i), g_last = group_of(a, 4 * i + 3);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            grp[e] = (e == 0) ? g_first : (e == 3 ? g_last : (g_first == g_last ? g_first : group_of(a, 4 * i + e)));
-            adamw_elem(pe[e], ge[e], me[e], ve[e], coef, grp[e], skip, s_sc);
+            for (int e = 0; e < 4; ++e) {
+                grp[e] = (e == 0) ? g_first : (e == 3 ? g_last : (g_first == g_last ? g_first : group_of(a, 4 * i + e)));
+                adamw_elem(pe[e], ge[e], me[e], ve[e], coef, grp[e], skip, s_sc);
+            }
+            reinterpret_cast<float4*>(g)[i] = float4{ge[0], ge[1], ge[2], ge[3]};
+            if (!skip && (grp[0] >= 0 || grp[1] >= 0 || grp[2] >= 0 || grp[3] >= 0)) {
+                reinterpret_cast<float4*>(p)[i] = float4{pe[0], pe[1], pe[2], pe[3]};
+                reinterpret_cast<float4*>(m)[i] = float4{me[0], me[1], me[2], me[3]};
+                reinterpret_cast<float4*>(v)[i] = float4{ve[0], ve[1], ve[2], ve[3]};
+            }
         }
-        reinterpret_cast<float4*>(g)[i] = float4{ge[0], ge[1], ge[2], ge[3]};
-        if (skip) continue;
-        if (g_first >= 0 || g_last >= 0 || grp[1] >= 0 || grp[2] >= 0) {
-            reinterpret_cast<float4*>(p)[i] = float4{pe[0], pe[1], pe[2], pe[3]};
-            reinterpret_cast<float4*>(m)[i] = float4{me[0], me[1], me[2], me[3]};
-            reinterpret_cast<float4*>(v)[i] = float4{ve[0], ve[1], ve[2], ve[3]};
-            if (tiles != nullptr) {
+        if (tiles != nullptr) {
+            // The scatter wants CONSECUTIVE parameters in consecutive lanes (a weight row's 64 neighbours land in a handful of
+            // full tile lines); a lane that scatters its own four values writes 4 bytes of every 16 per instruction instead --
+            // measured on the f32 image: AdamW 12 -> 16.5 us and the next fused launch 102 -> 120 us behind the partial-line
+            // writes.  So the wave transposes: instruction e covers elements 4 * iw + 64 e .. + 63, lane L takes component L % 4
+            // of lane 16 e + L / 4.
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (grp[e] < 0) continue;
-                    if (a.tiles_bf16) tile_scatter<true>(lay, tiles, 4 * i + e, pe[e]);
-                    else tile_scatter<false>(lay, tiles, 4 * i + e, pe[e]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int srcl = 16 * e + (lane >> 2), c = lane & 3;
+                const float v0 = __shfl(pe[0], srcl, 64), v1 = __shfl(pe[1], srcl, 64), v2 = __shfl(pe[2], srcl, 64),
+                            v3 = __shfl(pe[3], srcl, 64);
+                const int q0 = __shfl(grp[0], srcl, 64), q1 = __shfl(grp[1], srcl, 64), q2 = __shfl(grp[2], srcl, 64),
+                          q3 = __shfl(grp[3], srcl, 64);
+                const float val = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
+                const int gq = c == 0 ? q0 : (c == 1 ? q1 : (c == 2 ? q2 : q3));
+                if (skip || gq < 0) continue;
+                const long long idx = 4 * iw + 64 * e + lane;
+                if (a.tiles_bf16) tile_scatter<true>(lay, tiles, idx, val);
+                else tile_scatter<false>(lay, tiles, idx, val);
             }
         }
     }
