@@ -30,8 +30,14 @@ struct GeoB {
     static constexpr int BM = 16 * RT, NT = 64 * NW, CT = HID / (16 * NW);
     static constexpr int SLAB_FLOATS = BM * XSB / 2;  // the bf16 slab measured in floats
     // head image + bias | sHead, sLp, sG, sD | sOld, sAct, sAdv, sRet (the tile's loss inputs, staged at kernel start)
-    static constexpr int AUX_FLOATS = MAX_OUT * W4S + MAX_OUT + 8 * BM * MAX_OUT;
+    // | the three hidden layers' biases [3][HID] | std, var, log(std) of the policy [3][MAX_OUT] (+ pad)
+    static constexpr int BIAS_OFF = MAX_OUT * W4S + MAX_OUT + 8 * BM * MAX_OUT;  // floats past the slab
+    static constexpr int AUX_FLOATS = BIAS_OFF + 3 * HID + 4 * MAX_OUT;
     static constexpr size_t LDS_BYTES = (size_t)(SLAB_FLOATS + AUX_FLOATS) * sizeof(float) + 4096;
+    // fused step only: the rounded activations h1, h2 in the accumulator layout, one 8-byte word per lane and 16x16 tile
+    // (lane-linear: conflict-free b64 accesses), read back by the backward epilogues -- 32 VGPRs that no longer pin the kernel
+    // at the register limit (the spills they caused were reloaded with vmcnt(0) waits, i.e. behind the weight prefetch)
+    static constexpr size_t KEEP_BYTES = (size_t)2 * BM * HID * sizeof(__bf16);
 };
 
 // bf16 weight tiles: same matrix list and element offsets as struct Tiles, tile = 16 (n) x 32 (k):
@@ -142,23 +148,29 @@ __device__ __forceinline__ void store_tiles(const bf16x4 (*v)[GeoB<RT, NW>::CT],
 
 // obs-preprocess into the bf16 slab (k tail and rows past M zero); states_copy: f32 copy (trajectory buffer row);
 // st_tiles: k-tiled transposed bf16 image of the states (B operand of the first layers' weight gradients), 4 column blocks.
+// Split into issue / commit: a wave's loads retire in order (vmcnt), so WAITING for a load also waits for every load issued
+// before it.  The kernels therefore request the tile's states FIRST, then every other global input of the launch, and only
+// then commit the states to LDS -- one memory round trip for everything instead of one per input.
 template <int RT, int NW>
-__device__ __forceinline__ void load_states_b(const float* __restrict__ states, float* __restrict__ states_copy,
-                                              __bf16* __restrict__ st_tiles, int nrb, int D, long long m0, long long M, __bf16* Xb) {
+struct StatesB {
     typedef GeoB<RT, NW> G;
-    const int kp = round_up(D, KPAD);
-    constexpr int UB = 8;  // loads in flight per lane: the whole tile (BM x 64 / NT = 8 at BM = 64) travels in ONE round trip
-    for (int i0 = threadIdx.x; i0 < G::BM * kp; i0 += G::NT * UB) {
-        float x[UB];
+    static_assert(Tiles::K1P == 64, "one pass per lane assumes a 64-wide padded first layer");
+    static constexpr int UB = G::BM * Tiles::K1P / G::NT;  // loads per lane: the whole tile travels in ONE round trip
+    float x[UB];
+    __device__ __forceinline__ void issue(const float* __restrict__ states, int D, long long m0, long long M) {
+        const int kp = round_up(D, KPAD);
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int i = min(i0 + u * G::NT, G::BM * kp - 1);
+            const int i = min((int)threadIdx.x + u * G::NT, G::BM * kp - 1);
             const int r = i / kp, c = i % kp;
             x[u] = states[(size_t)min(m0 + r, M - 1) * D + min(c, D - 1)];  // clamped, unconditional load
         }
+    }
+    __device__ __forceinline__ void commit(float* __restrict__ states_copy, int D, long long m0, long long M, __bf16* Xb) const {
+        const int kp = round_up(D, KPAD);
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int i = i0 + u * G::NT;
+            const int i = (int)threadIdx.x + u * G::NT;
             if (i >= G::BM * kp) continue;
             const int r = i / kp, c = i % kp;
             const bool ok = c < D && m0 + r < M;
@@ -166,8 +178,9 @@ __device__ __forceinline__ void load_states_b(const float* __restrict__ states, 
             Xb[r * XSB + c] = (__bf16)(ok ? x[u] : 0.f);
         }
     }
-    if (st_tiles != nullptr) {
-        lds_barrier();
+    // after an LDS barrier behind commit()
+    __device__ __forceinline__ static void tiles(__bf16* __restrict__ st_tiles, int nrb, int D, long long m0, const __bf16* Xb) {
+        const int kp = round_up(D, KPAD);
         for (int u = threadIdx.x; u < 4 * (G::BM / 8) * 16; u += G::NT) {
             const int cb = u / ((G::BM / 8) * 16), ko = (u / 16) % (G::BM / 8), c16 = u & 15;
             const int rb = (int)(m0 >> 5) + (ko >> 2);
@@ -178,7 +191,59 @@ __device__ __forceinline__ void load_states_b(const float* __restrict__ states, 
             *reinterpret_cast<bf16x8*>(st_tiles + ((size_t)(cb * nrb + rb) * 64 + (ko & 3) * 16 + c16) * 8) = v;
         }
     }
-}
+};
+
+// The small parameter inputs of a tile: the three hidden layers' biases, the f32 head image + bias, the policy's log-std.
+// issue() requests them into registers (clamped, unconditional), commit() writes them to LDS: sBias [3][HID], W4s / b4s, and
+// sStd = std | var | log(std) per output (the same expf / fmul / logf the per-element code used to repeat).
+template <int NT>
+struct SmallInputsB {
+    static constexpr int NB = (3 * HID + NT - 1) / NT, NH = (MAX_OUT * 64 + NT - 1) / NT;
+    float bv[NB];
+    f32x4 hw[NH];
+    float b4v, lsv;
+    __device__ __forceinline__ void issue(const float* __restrict__ params, const rlx_mlp_layout& lay, int y, int n_out) {
+        const int tid = threadIdx.x;
+        // (lay lives in the kernel arguments: indexing it with a per-lane value would turn into a VECTOR load of the argument
+        //  block and a dependent round trip -- the three offsets are read as scalars and selected per lane.)
+        const long long ob0 = lay.off_b[y][0], ob1 = lay.off_b[y][1], ob2 = lay.off_b[y][2];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = min(tid + u * NT, 3 * HID - 1), l = i / HID;
+            bv[u] = params[(l == 0 ? ob0 : l == 1 ? ob1 : ob2) + i % HID];
+        }
+        const float* W4 = params + lay.off_w[y][3];
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            const int f = min(tid + u * NT, n_out * 64 - 1), o = f >> 6, c4 = (f & 63) * 4;
+            hw[u] = *reinterpret_cast<const f32x4*>(W4 + (size_t)o * HID + c4);
+        }
+        // unconditional, clamped loads (a load under a branch gets its wait under the branch too)
+        const int oc = min(tid, n_out - 1);
+        const long long ob3 = lay.off_b[y][3];
+        b4v = params[(ob3 >= 0 ? ob3 : 0) + oc];
+        if (ob3 < 0) b4v = 0.f;
+        lsv = params[y == 1 ? lay.off_logstd + oc : 0];
+    }
+    __device__ __forceinline__ void commit(int n_out, float* sBias, float* W4s, float* b4s, float* sStd) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (tid + u * NT < 3 * HID) sBias[tid + u * NT] = bv[u];
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            const int f = tid + u * NT;
+            if (f < n_out * 64) *reinterpret_cast<f32x4*>(W4s + (f >> 6) * W4S + (f & 63) * 4) = hw[u];
+        }
+        if (tid < n_out) {  // (the value network's lanes compute the std terms of a junk word: never read)
+            b4s[tid] = b4v;
+            const float stdv = expf(lsv);
+            sStd[tid] = stdv;
+            sStd[MAX_OUT + tid] = fmul(stdv, stdv);
+            sStd[2 * MAX_OUT + tid] = logf(stdv);
+        }
+    }
+};
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -198,17 +263,18 @@ __device__ __forceinline__ f32x2 tanh2_b(f32x2 x) {
     return __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f});
 }
 
-// forward hidden-layer epilogue: h = bf16(tanh(acc + bias)) -> slab; KEEP: 1 - h^2 of the ROUNDED value and the tile store
+// forward hidden-layer epilogue: h = bf16(tanh(acc + bias)) -> slab; KEEP: the rounded value also goes to `kept` (registers) or
+// `keep_lds` (lane-linear LDS words) for the backward sweep's 1 - h^2, and to the k-tiled image `dst`.  `bias` is an LDS image.
 template <int RT, int NW, bool KEEP>
-__device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, NW>::CT], const float* __restrict__ bias, __bf16* Xb,
-                                                bf16x4 (*kept)[GeoB<RT, NW>::CT], __bf16* __restrict__ dst, int nrb, long long m0) {
+__device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, NW>::CT], const float* bias, __bf16* Xb,
+                                                bf16x4 (*kept)[GeoB<RT, NW>::CT], bf16x4* keep_lds, __bf16* __restrict__ dst, int nrb,
+                                                long long m0) {
     typedef GeoB<RT, NW> G;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
-    bf16x4 hloc[KEEP ? 1 : RT][G::CT];  // KEEP: the caller's `kept` holds the rounded activations (the backward sweep forms 1 - h^2 from them)
-    bf16x4 (*hv)[G::CT] = KEEP ? kept : hloc;
+    bf16x4 hloc[KEEP ? RT : 1][G::CT];
     float b[G::CT];
 #pragma unroll
-    for (int ct = 0; ct < G::CT; ++ct) b[ct] = bias[wave * 16 * G::CT + ct * 16 + r16];  // both loads in flight together
+    for (int ct = 0; ct < G::CT; ++ct) b[ct] = bias[wave * 16 * G::CT + ct * 16 + r16];
 #pragma unroll
     for (int ct = 0; ct < G::CT; ++ct) {
         const int col = wave * 16 * G::CT + ct * 16 + r16;
@@ -221,13 +287,20 @@ __device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, 
                 Xb[(rt * 16 + 4 * kq + r) * XSB + col] = h0;
                 Xb[(rt * 16 + 4 * kq + r + 1) * XSB + col] = h1;
                 if constexpr (KEEP) {
-                    hv[rt][ct][r] = h0;
-                    hv[rt][ct][r + 1] = h1;
+                    hloc[rt][ct][r] = h0;
+                    hloc[rt][ct][r + 1] = h1;
                 }
             }
     }
     if constexpr (KEEP) {
-        if (dst != nullptr) store_tiles<RT, NW>(hv, dst, nrb, m0);
+        if (dst != nullptr) store_tiles<RT, NW>(hloc, dst, nrb, m0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < G::CT; ++ct) {
+                if (keep_lds != nullptr) keep_lds[(rt * G::CT + ct) * G::NT + threadIdx.x] = hloc[rt][ct];
+                if (kept != nullptr) kept[rt][ct] = hloc[rt][ct];
+            }
     }
     lds_barrier();
 }
@@ -239,19 +312,61 @@ __device__ __forceinline__ float dtanh_b(__bf16 h) {
     return fmaf(-hf, hf, 1.f);
 }
 
-__device__ __forceinline__ float head_dot_b(const __bf16* xr, const float* wr, float bias, bool has_bias) {
-    float s = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < HID; j += 8) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(xr + j);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + j), w1 = *reinterpret_cast<const f32x4*>(wr + j + 4);
+// ---- the f32 heads on the matrix pipe ----------------------------------------------------------------------------------
+// The heads keep f32 weights and f32 outputs (file header).  An f32 number is exactly the sum of three bf16 numbers
+// (hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid): 3 x 8 significand bits, the differences are exact in f32), and a
+// product of two bf16 numbers is exact in f32 -- so  x . w  with x in bf16 is three bf16 MFMAs with f32 accumulation: the same
+// real-number sum as the f32 dot product, only the order of the f32 additions differs.  As VALU dot products the head phases
+// were LDS-bound (every (row, output) pair re-read its 1 KiB weight row: ~6 k cycles of b128 reads per tile).
+struct Split3 {
+    bf16x8 hi, mid, lo;
+};
+__device__ __forceinline__ Split3 split3(const float (&w)[8]) {
+    Split3 q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s = fmaf((float)x[i], w0[i], s);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s = fmaf((float)x[4 + i], w1[i], s);
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)w[j];
+        const float r1 = fsub(w[j], (float)h);
+        const __bf16 m = (__bf16)r1;
+        const float r2 = fsub(r1, (float)m);
+        q.hi[j] = h;
+        q.mid[j] = m;
+        q.lo[j] = (__bf16)r2;
     }
-    if (has_bias) s += bias;
-    return s;
+    return q;
+}
+__device__ __forceinline__ f32x4 mfma3(bf16x8 a, const Split3& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.mid, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.lo, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma3(const Split3& a, bf16x8 b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b, acc, 0, 0, 0);
+}
+
+// head forward: out[row][o] = h3[row][:] . W4[o][:], written as TWO k-half partials P0 / P1 [BM][MAX_OUT] (the caller adds them
+// and the bias: P0 + P1 + b).  Wave w < 2 RT takes row tile w % RT and k half w / RT -- the rollout launch (RT = 1) and the
+// training launch (RT = 4) therefore add every row's products in the same order: the log-prob a sample gets at rollout time
+// and the one the first training epoch recomputes are bit-identical, as with the reference.  Rows of W4s past n_out are zero.
+template <int RT>
+__device__ __forceinline__ void head_forward_mfma(const __bf16* Xb, const float* W4s, float* P0, float* P1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
+    if (wave >= 2 * RT) return;
+    const int rt = wave % RT, kh = wave / RT;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < HID / 64; ++q) {
+        const int k0 = (kh * (HID / 64) + q) * 32 + 8 * kq;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xb + (rt * 16 + r16) * XSB + k0);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(W4s + r16 * W4S + k0), w1 = *reinterpret_cast<const f32x4*>(W4s + r16 * W4S + k0 + 4);
+        const float w[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        acc = mfma3(a, split3(w), acc);
+    }
+    float* P = kh == 0 ? P0 : P1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[(rt * 16 + 4 * kq + r) * MAX_OUT + r16] = acc[r];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -283,39 +398,61 @@ __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
         y = 0; m0 = (long long)b * G::BM; M = a.vj[job - 1].m; states = a.vj[job - 1].states;
     }
     const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
-    RowGemmB<RT, NW, PD> gemm;
-    gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
-    load_states_b<RT, NW>(states, states_copy, nullptr, 0, D, m0, M, Xb);
-    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    float* sBias = smem + G::SLAB_FLOATS + G::BIAS_OFF;
+    float* sStd = sBias + 3 * HID;
+
+    // Every global input of the tile is requested before anything waits: states, biases / head / log-std, the noise of this
+    // lane's output element, and ALL three layers' weight fragments (16 rows per workgroup leave the registers for it:
+    // 16 + 64 + 64 VGPRs).  The launch then costs one memory round trip plus the compute chain, instead of one round trip per
+    // layer (each layer's first fragment loads used to be waited for by the previous epilogue's bias load).
+    StatesB<RT, NW> st;
+    st.issue(states, D, m0, M);
+    SmallInputsB<G::NT> si;
+    si.issue(a.params, lay, y, n_out);
+    const int orow = tid / n_out, oo = tid % n_out;
+    const bool olive = tid < G::BM * n_out && m0 + orow < M;
+    const size_t og = (size_t)min(m0 + orow, M - 1) * n_out + oo;
+    const float epsv = (a.eps != nullptr ? a.eps : a.params)[(job == 0 && y == 1 && a.eps != nullptr && tid < G::BM * n_out) ? og : 0];
+    const ValuePre vp = value_job_prefetch(a.vj[max(job - 1, 0)], job != 0, (size_t)min(m0 + orow, M - 1), a.params);
+    __builtin_amdgcn_sched_barrier(0);
+    RowGemmB<RT, NW, Tiles::K1P / 32> gemm1;
+    RowGemmB<RT, NW, HID / 32> gemm2, gemm3;
+    gemm1.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
+    gemm2.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
+    gemm3.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
+    st.commit(states_copy, D, m0, M, Xb);
+    si.commit(n_out, sBias, W4s, b4s, sStd);
+    for (int i = n_out * W4S + tid; i < MAX_OUT * W4S; i += G::NT) W4s[i] = 0.f;
     lds_barrier();
     f32x4 acc[RT][G::CT];
-    gemm.run(Xb, acc);
-    gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
-    epilogue_tanh_b<RT, NW, false>(acc, a.params + lay.off_b[y][0], Xb, nullptr, nullptr, 0, m0);
-    gemm.run(Xb, acc);
-    gemm.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
-    epilogue_tanh_b<RT, NW, false>(acc, a.params + lay.off_b[y][1], Xb, nullptr, nullptr, 0, m0);
-    gemm.run(Xb, acc);
-    epilogue_tanh_b<RT, NW, false>(acc, a.params + lay.off_b[y][2], Xb, nullptr, nullptr, 0, m0);
+    gemm1.run(Xb, acc);
+    epilogue_tanh_b<RT, NW, false>(acc, sBias, Xb, nullptr, nullptr, nullptr, 0, m0);
+    gemm2.run(Xb, acc);
+    epilogue_tanh_b<RT, NW, false>(acc, sBias + HID, Xb, nullptr, nullptr, nullptr, 0, m0);
+    gemm3.run(Xb, acc);
+    epilogue_tanh_b<RT, NW, false>(acc, sBias + 2 * HID, Xb, nullptr, nullptr, nullptr, 0, m0);
 
-    for (int idx = tid; idx < G::BM * n_out; idx += G::NT) {
-        const int row = idx / n_out, o = idx % n_out;
-        const float s = head_dot_b(Xb + row * XSB, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
-        if (m0 + row >= M) continue;
-        const size_t g = (size_t)(m0 + row) * n_out + o;
+    static_assert(G::BM * MAX_OUT <= G::NT, "one head output per lane");
+    float* sP0 = b4s + MAX_OUT, *sP1 = sP0 + G::BM * MAX_OUT;
+    head_forward_mfma<RT>(Xb, W4s, sP0, sP1);
+    lds_barrier();
+    if (tid < G::BM * n_out) {
+        float s = fadd(sP0[orow * MAX_OUT + oo], sP1[orow * MAX_OUT + oo]);
+        if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[oo]);
+        if (!olive) return;
         if (job == 0 && y == 0) {
-            a.value[g] = s;
+            a.value[og] = s;
         } else if (job == 0) {
             const float mean = s;
-            const float stdv = expf(a.params[lay.off_logstd + o]);
-            const float act = a.eps ? fadd(fmul(a.eps[g], stdv), mean) : mean;
+            const float stdv = sStd[oo];
+            const float act = a.eps ? fadd(fmul(epsv, stdv), mean) : mean;
             const float d = fsub(act, mean);
-            const float var = fmul(stdv, stdv);
-            const float log_scale = logf(stdv);
-            a.logprob[g] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
-            a.action[g] = act;
+            const float var = sStd[MAX_OUT + oo];
+            const float log_scale = sStd[2 * MAX_OUT + oo];
+            a.logprob[og] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            a.action[og] = act;
         } else {
-            value_job_output(a.vj[job - 1], g, (size_t)(m0 + row), o, s);
+            value_job_output(a.vj[job - 1], og, (size_t)(m0 + orow), oo, s, &vp);
         }
     }
 }
@@ -337,7 +474,7 @@ struct StampsT {
     int n;
     __device__ __forceinline__ void mark() {
         if constexpr (ON) {
-            if (buf != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf[n] = (long long)clock64();
+            if (buf != nullptr && blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) buf[n] = (long long)clock64();  // the policy network's tile 0
             ++n;
         }
     }
@@ -363,6 +500,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     float* sRet = sAdv + BM * MAX_OUT;
     double* sRed = reinterpret_cast<double*>(smem + G::SLAB_FLOATS + G::AUX_FLOATS);
     double* sNm = sRed + 256;
+    bf16x4* sKeep = reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(smem) + G::LDS_BYTES);  // [2][RT * CT][NT] words
 
     const rlx_mlp_layout& lay = a.lay;
     const rlx_ppo_loss_params& p = a.p;
@@ -390,60 +528,71 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     // ---- forward -----------------------------------------------------------------------------------------------------
     StampsT<STAMPS> ts{a.stamps, 0};  // development: phase stamps of block (0, 0), see tools/phase_times.py
     ts.mark();
-    RowGemmB<RT, NW, PD> gemm;
-    gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
-    {
-        constexpr int PI = BM * MAX_OUT / G::NT;  // staging iterations per lane (2)
-        static_assert(BM * MAX_OUT % G::NT == 0, "staging assumes whole iterations");
-        float v0[PI], v1[PI], v2[PI];
+    float* sBias = smem + G::SLAB_FLOATS + G::BIAS_OFF;
+    float* sStd = sBias + 3 * HID;
+    // Request order = wait order (a wave's loads retire in order): the tile's states first, then the loss inputs, the biases /
+    // head image / log-std, then the first layer's weight fragments.  Nothing below the commits touches global memory except the
+    // weight stream, so no epilogue waits behind a weight prefetch any more (the per-layer bias load used to: it was issued
+    // after the next layer's first fragment loads and its wait covered their whole first-touch latency).
+    StatesB<RT, NW> st;
+    st.issue(a.states, D, m0, M);
+    constexpr int PI = BM * MAX_OUT / G::NT;  // staging iterations per lane (2)
+    static_assert(BM * MAX_OUT % G::NT == 0, "staging assumes whole iterations");
+    float v0[PI], v1[PI], v2[PI];
 #pragma unroll
-        for (int u = 0; u < PI; ++u) {
-            const int i = tid + u * G::NT, row = i / MAX_OUT, c = i % MAX_OUT;
-            const size_t gr = (size_t)min(m0 + row, M - 1);
-            if (y == 1) {  // clamped, unconditional loads; junk columns are never read back
-                v0[u] = a.old_logprobs[gr * lay.act_dim + min(c, lay.act_dim - 1)];
-                v1[u] = a.action[gr * lay.act_dim + min(c, lay.act_dim - 1)];
-                v2[u] = a.advantages[gr * npr + min(c, npr - 1)];
-            } else {
-                v0[u] = p.has_critic ? a.prev_values[gr * n_out + min(c, n_out - 1)] : 0.f;
-                v1[u] = p.has_critic ? a.returns[gr * n_out + min(c, n_out - 1)] : 0.f;
-                v2[u] = 0.f;
-            }
-        }
-        load_states_b<RT, NW>(a.states, nullptr, y == 1 ? st_tiles : nullptr, tg.nrb, D, m0, M, Xb);
-#pragma unroll
-        for (int u = 0; u < PI; ++u) {
-            const int i = tid + u * G::NT;
-            if (y == 1) {
-                sOld[i] = v0[u];
-                sAct[i] = v1[u];
-                sAdv[i] = v2[u];
-            } else {
-                sAdv[i] = v0[u];
-                sRet[i] = v1[u];
-            }
+    for (int u = 0; u < PI; ++u) {
+        const int i = tid + u * G::NT, row = i / MAX_OUT, c = i % MAX_OUT;
+        const size_t gr = (size_t)min(m0 + row, M - 1);
+        if (y == 1) {  // clamped, unconditional loads; junk columns are never read back
+            v0[u] = a.old_logprobs[gr * lay.act_dim + min(c, lay.act_dim - 1)];
+            v1[u] = a.action[gr * lay.act_dim + min(c, lay.act_dim - 1)];
+            v2[u] = a.advantages[gr * npr + min(c, npr - 1)];
+        } else {
+            v0[u] = p.has_critic ? a.prev_values[gr * n_out + min(c, n_out - 1)] : 0.f;
+            v1[u] = p.has_critic ? a.returns[gr * n_out + min(c, n_out - 1)] : 0.f;
+            v2[u] = 0.f;
         }
     }
-    stage_head(a.params + lay.off_w[y][3], lay.off_b[y][3] >= 0 ? a.params + lay.off_b[y][3] : nullptr, n_out, W4s, b4s, G::NT);
+    SmallInputsB<G::NT> si;
+    si.issue(a.params, lay, y, n_out);
+    __builtin_amdgcn_sched_barrier(0);
+    RowGemmB<RT, NW, PD> gemm;
+    gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
+    st.commit(nullptr, D, m0, M, Xb);
+    ts.mark();
+#pragma unroll
+    for (int u = 0; u < PI; ++u) {
+        const int i = tid + u * G::NT;
+        if (y == 1) {
+            sOld[i] = v0[u];
+            sAct[i] = v1[u];
+            sAdv[i] = v2[u];
+        } else {
+            sAdv[i] = v0[u];
+            sRet[i] = v1[u];
+        }
+    }
+    si.commit(n_out, sBias, W4s, b4s, sStd);
     for (int i = tid; i < BM * MAX_OUT; i += G::NT) sHead[i] = 0.f;
-    for (int i = n_out * W4S + tid; i < OP * W4S; i += G::NT) W4s[i] = 0.f;
+    for (int i = n_out * W4S + tid; i < MAX_OUT * W4S; i += G::NT) W4s[i] = 0.f;
     lds_barrier();
+    if (y == 1) StatesB<RT, NW>::tiles(st_tiles, tg.nrb, D, m0, Xb);
     ts.mark();
     f32x4 acc[RT][CT];
-    bf16x4 kept[3][RT][CT];  // rounded h1, h2, h3 in the accumulator layout: the backward epilogues need exactly these lanes
+    bf16x4 kept3[RT][CT];  // rounded h3 in the accumulator layout (h1, h2: sKeep): the backward epilogues need exactly these lanes
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
     ts.mark();
-    epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][0], Xb, kept[0], hy, tg.nrb, m0);
+    epilogue_tanh_b<RT, NW, true>(acc, sBias, Xb, nullptr, sKeep, hy, tg.nrb, m0);
     ts.mark();
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
     ts.mark();
-    epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][1], Xb, kept[1], hy + tg.mat(), tg.nrb, m0);
+    epilogue_tanh_b<RT, NW, true>(acc, sBias + HID, Xb, nullptr, sKeep + RT * CT * G::NT, hy + tg.mat(), tg.nrb, m0);
     ts.mark();
     gemm.run(Xb, acc);
     ts.mark();
-    epilogue_tanh_b<RT, NW, true>(acc, a.params + lay.off_b[y][2], Xb, kept[2], nullptr, tg.nrb, m0);
+    epilogue_tanh_b<RT, NW, true>(acc, sBias + 2 * HID, Xb, kept3, nullptr, nullptr, tg.nrb, m0);
     ts.mark();
 
     // ---- head + loss element math (f32, identical to ppo_step.hip) ------------------------------------------------------
@@ -454,20 +603,29 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
 #pragma unroll
     for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
 
+    head_forward_mfma<RT>(Xb, W4s, sG, sLp);  // the two k-half partials land in sG / sLp (both free until the passes below)
+    lds_barrier();
+    ts.mark();
     for (int idx = tid; idx < BM * n_out; idx += G::NT) {
         const int row = idx / n_out, o = idx % n_out;
-        const float s = head_dot_b(Xb + row * XSB, W4s + o * W4S, b4s[o], lay.off_b[y][3] >= 0);
+        float s = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
+        if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[o]);
         sHead[row * MAX_OUT + o] = s;
         if (y == 1) {
-            const float stdv = expf(a.params[lay.off_logstd + o]);
             const float d = fsub(sAct[row * MAX_OUT + o], s);
-            const float var = fmul(stdv, stdv);
-            const float log_scale = logf(stdv);
+            const float var = sStd[MAX_OUT + o];
+            const float log_scale = sStd[2 * MAX_OUT + o];
             sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
             sD[row * MAX_OUT + o] = d;
         }
     }
     lds_barrier();
+    ts.mark();
+    // wave 0 walks the tile's loss elements (a fixed lane <-> element assignment keeps the f64 metric sums reproducible) and
+    // parks its 16 per-lane partial sums in the slab (h3 is dead: the head gradients and dZ3 work from registers and sHead);
+    // behind the barrier every wave butterfly-sums two of the 16 slots while all lanes run the dOut pass -- the same 64-lane
+    // butterfly wave 0 used to run 16 times in a row (~7 k cycles with the other seven waves parked at the barrier).
+    double* sLacc = reinterpret_cast<double*>(Xb);  // [NS][64]
     if (y == 1) {
         for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {
             const int row = idx / npr, c = idx % npr;
@@ -489,20 +647,6 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
                 sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
             }
         }
-        lds_barrier();
-        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
-            const int row = idx / n_out, o = idx % n_out;
-            float dmu = 0.f, dls = 0.f;
-            if (m0 + row < M) {
-                const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
-                const float stdv = expf(a.params[lay.off_logstd + o]);
-                const float var = stdv * stdv, d = sD[row * MAX_OUT + o];
-                dmu = dlp * d / var;
-                dls = dlp * (d * d / var - 1.f);
-            }
-            sHead[row * MAX_OUT + o] = dmu;
-            sLp[row * MAX_OUT + o] = dls;
-        }
     } else {
         for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {
             const int row = idx / n_out, o = idx % n_out;
@@ -519,71 +663,106 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
         }
     }
     if (wave == 0) {
-        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const double v = wave_sum(lacc[k]);
+        for (int k = 0; k < NS; ++k) sLacc[k * 64 + lane] = lacc[k];
+    }
+    lds_barrier();
+    ts.mark();
+    if (y == 1) {
+        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+            const int row = idx / n_out, o = idx % n_out;
+            float dmu = 0.f, dls = 0.f;
+            if (m0 + row < M) {
+                const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
+                const float var = sStd[MAX_OUT + o], d = sD[row * MAX_OUT + o];
+                dmu = dlp * d / var;
+                dls = dlp * (d * d / var - 1.f);
+            }
+            sHead[row * MAX_OUT + o] = dmu;
+            sLp[row * MAX_OUT + o] = dls;
+        }
+    }
+    {
+        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
+        for (int k = wave; k < NS; k += NW) {
+            const double v = wave_sum(sLacc[k * 64 + lane]);
             if (lane == 0) lp[k] = v;
         }
     }
     lds_barrier();
     ts.mark();
 
-    // ---- head parameter gradients per 32-row half tile (f32 accumulation over the bf16 h3 in the slab) -----------------
-    for (int u = tid; u < (BM / 32) * HID; u += G::NT) {
-        const int sub = u / HID, j = u % HID, r0 = sub * 32;
-        float* part = a.head_part + ((size_t)(tile * (BM / 32) + sub) * 2 + y) * a.head_stride;
-        float s[OP];
+    // ---- head parameter gradients per 32-row half tile: dW4[o][j] = sum_rows dOut[row][o] h3[row][j] on the matrix pipe -------
+    // M = o, N = j (this wave's 2 x 16 columns), K = the half's 32 rows.  K is only a summation index, so the k slots are
+    // mapped to rows the way the accumulator layout already holds h3: lane (r16, kq) slot jj <-> row (jj >> 2) * 16 + 4 kq +
+    // (jj & 3) of the half -- the B fragment is then kept3[2 sub][ct] | kept3[2 sub + 1][ct] straight from registers, and the
+    // A fragment (dOut, f32 in sHead) is split into three bf16 planes (exact, see split3).
+    {
+        const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 ones;
 #pragma unroll
-        for (int o = 0; o < OP; ++o) s[o] = 0.f;
-#pragma unroll 4
-        for (int row = r0; row < r0 + 32; ++row) {
-            const float hv = (float)Xb[row * XSB + j];
+        for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.f;
 #pragma unroll
-            for (int q = 0; q < OP / 4; ++q) {
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(sHead + row * MAX_OUT + 4 * q);
+        for (int sub = 0; sub < BM / 32; ++sub) {
+            float* part = a.head_part + ((size_t)(tile * (BM / 32) + sub) * 2 + y) * a.head_stride;
+            float av[8], lv[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[4 * q + i] = fmaf(sh[i], hv, s[4 * q + i]);
+            for (int jj = 0; jj < 8; ++jj) {
+                const int row = sub * 32 + (jj >> 2) * 16 + 4 * kq + (jj & 3);
+                av[jj] = sHead[row * MAX_OUT + r16];
+                lv[jj] = sLp[row * MAX_OUT + r16];
             }
-        }
+            const Split3 A = split3(av);
 #pragma unroll
-        for (int o = 0; o < OP; ++o)
-            if (o < n_out) part[o * HID + j] = s[o];
-        if (j < n_out) {
-            float sb = 0.f, sl = 0.f;
-            for (int row = r0; row < r0 + 32; ++row) {
-                sb += sHead[row * MAX_OUT + j];
-                sl += sLp[row * MAX_OUT + j];
+            for (int ct = 0; ct < CT; ++ct) {
+                bf16x8 B;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) B[jj] = kept3[2 * sub + (jj >> 2)][ct][jj & 3];
+                const f32x4 g = mfma3(A, B, zero4);
+                const int j = wave * 16 * CT + ct * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kq + r < n_out) part[(4 * kq + r) * HID + j] = g[r];
             }
-            part[n_out * HID + j] = sb;
-            part[n_out * HID + n_out + j] = y == 1 ? sl : 0.f;
+            if (wave == 0) {  // bias / log-std gradients: row sums, i.e. the same product against a fragment of ones
+                const f32x4 gb = mfma3(A, ones, zero4);
+                const f32x4 gl = y == 1 ? mfma3(split3(lv), ones, zero4) : zero4;
+                if (r16 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * kq + r < n_out) {
+                            part[n_out * HID + 4 * kq + r] = gb[r];
+                            part[n_out * HID + n_out + 4 * kq + r] = gl[r];
+                        }
+                }
+            }
         }
     }
 
     ts.mark();
-    // ---- dZ3 = (dOut . W4) * (1 - h3^2) -> bf16 slab + tiles ---------------------------------------------------------------
+    // ---- dZ3 = (dOut . W4) * (1 - h3^2) -> bf16 slab + tiles: K = n_out is tiny, f32 operands -> v_mfma_f32_16x16x4_f32 ------
     gemm.prefetch(tiles + Tiles::mat(y, 4), HID / 32);  // W3^T
     bf16x4 dv[RT][CT];
+    {
+        f32x4 dz[RT][CT];
+        zero_acc(dz);
+        for (int ks = 0; ks < (n_out + 3) / 4; ++ks) {
+            float av[RT], bv[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int col = wave * 16 * CT + ct * 16 + r16;
-        float w4[OP];
+            for (int rt = 0; rt < RT; ++rt) av[rt] = sHead[(rt * 16 + r16) * MAX_OUT + 4 * ks + kq];
 #pragma unroll
-        for (int o = 0; o < OP; ++o) w4[o] = W4s[o * W4S + col];
+            for (int ct = 0; ct < CT; ++ct) bv[ct] = W4s[(4 * ks + kq) * W4S + wave * 16 * CT + ct * 16 + r16];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) dz[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[ct], dz[rt][ct], 0, 0, 0);
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rt * 16 + 4 * kq + r;
-                float s = 0.f;
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                for (int q = 0; q < OP / 4; ++q) {
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(sHead + row * MAX_OUT + 4 * q);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s = fmaf(sh[i], w4[4 * q + i], s);
-                }
-                dv[rt][ct][r] = (__bf16)(s * dtanh_b(kept[2][rt][ct][r]));
-            }
+                for (int r = 0; r < 4; ++r) dv[rt][ct][r] = (__bf16)(dz[rt][ct][r] * dtanh_b(kept3[rt][ct][r]));
     }
     lds_barrier();  // every read of h3 / sHead is done: the slab may be overwritten
 #pragma unroll
@@ -604,19 +783,21 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x4 hk = sKeep[((l - 1) * RT * CT + rt * CT + ct) * G::NT + tid];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const __bf16 z = (__bf16)(acc[rt][ct][r] * dtanh_b(kept[l - 1][rt][ct][r]));
+                    const __bf16 z = (__bf16)(acc[rt][ct][r] * dtanh_b(hk[r]));
                     dv[rt][ct][r] = z;
                     if (l == 2) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = z;
                 }
+            }
         store_tiles<RT, NW>(dv, dzy + (size_t)(l - 1) * tg.mat(), tg.nrb, m0);
         if (l == 2) lds_barrier();
         ts.mark();
     }
     if constexpr (STAMPS) {
-        if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             a.stamps[ts.n] = (long long)clock64();  // ... and the stores have drained
         }
@@ -930,11 +1111,17 @@ int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
 size_t bf16_image_bytes(int64_t m) { return (size_t)16 * ((m + 31) / 32) * 512 * sizeof(__bf16); }
 
 int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, hipStream_t st) {
-    const size_t lds = GeoB<4, 8>::LDS_BYTES;
+    const size_t lds = GeoB<4, 8>::LDS_BYTES + GeoB<4, 8>::KEEP_BYTES;
     __bf16* stt = static_cast<__bf16*>(st_tiles);
     if (op8 && a.stamps != nullptr) {
         if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>, lds)) return rc;
         hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+    } else if (op8 && dev_variant("RLX_FUSED_PD", 4) == 8) {  // development: deeper weight-fragment rings
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+    } else if (op8 && dev_variant("RLX_FUSED_PD", 4) == 6) {
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 6, 8, false>, lds)) return rc;
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 6, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
     } else if (op8) {
         if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>, lds)) return rc;
         hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);

@@ -105,24 +105,47 @@ struct ValueJob {
 };
 
 // value-only job epilogue for output o of row `row` (global row index): value store, bootstrap fold, env-row store
-__device__ __forceinline__ void value_job_output(const ValueJob& v, size_t g, size_t row, int o, float s) {
+// The env-row inputs of a value job's row, requested at kernel start (chunk == 1, the embodied case) so that the job's tail does
+// not add two dependent memory round trips behind the head.
+struct ValuePre {
+    float r;
+    unsigned b0, b1;  // env path: termination / truncation byte; flags path: b0 = the flag
+};
+// Straight-line, unconditional loads (pointer selects, no branches): a load under a branch -- or a merge with a constant -- gets
+// its wait placed right behind it.  `safe` is any readable address for the lanes / jobs that have nothing to fetch.
+__device__ __forceinline__ ValuePre value_job_prefetch(const ValueJob& v, bool live, size_t row, const float* safe) {
+    const bool on = live && v.rewards != nullptr, env = on && v.env_rewards != nullptr;
+    const size_t i = on ? row * v.chunk + (v.chunk - 1) : 0;
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(safe);
+    ValuePre q;
+    q.b0 = (env ? v.env_term : on ? v.flags : sb)[i];
+    q.b1 = (env ? v.env_trunc : sb)[i];
+    q.r = (env ? v.env_rewards : on ? (const float*)v.rewards : safe)[i];
+    return q;
+}
+__device__ __forceinline__ void value_job_output(const ValueJob& v, size_t g, size_t row, int o, float s, const ValuePre* pre = nullptr) {
     if (v.values) v.values[g] = s;
     if (o != 0 || v.rewards == nullptr) return;
     if (v.env_rewards != nullptr) {
         for (int c = 0; c < v.chunk; ++c) {
             const size_t i = row * v.chunk + c;
-            const uint8_t te = v.env_term[i] != 0, tr = v.env_trunc[i] != 0;
+            const bool last = c == v.chunk - 1, have = pre != nullptr && last;
+            const uint8_t te = have ? pre->b0 != 0 : v.env_term[i] != 0, tr = have ? pre->b1 != 0 : v.env_trunc[i] != 0;
             v.term_row[i] = te;
             v.trunc_row[i] = tr;
             v.done_row[i] = te | tr;  // dones = terminations | truncations (maniskill_env.py:343-350)
-            float r = v.env_rewards[i];
+            float r = have ? pre->r : v.env_rewards[i];
             const bool flag = v.flag_is_trunc ? tr != 0 : (te | tr) != 0;
-            if (c == v.chunk - 1 && flag) r = fadd(r, fmul(v.gamma, s));  // env_worker.py:744-758
+            if (last && flag) r = fadd(r, fmul(v.gamma, s));  // env_worker.py:744-758
             v.rewards[i] = r;
         }
     } else {  // r[:, -1] += gamma * V(final_obs)[:, 0] where flags[:, -1]
         const size_t i = row * v.chunk + (v.chunk - 1);
-        if (v.flags[i]) v.rewards[i] = fadd(v.rewards[i], fmul(v.gamma, s));
+        if (pre != nullptr) {
+            if (pre->b0) v.rewards[i] = fadd(pre->r, fmul(v.gamma, s));
+        } else if (v.flags[i]) {
+            v.rewards[i] = fadd(v.rewards[i], fmul(v.gamma, s));
+        }
     }
 }
 struct RolloutArgs {

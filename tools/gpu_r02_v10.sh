@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 2, GPU visit 11: front-loaded inputs (rollout + fused bf16), kept activations in LDS: parity tests, kernel trace, bench.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+run() { name=$1; shift; timeout "$1" "${@:2}" > gpurun_out/$name.log 2>&1; echo "$name rc=$?"; tail -3 gpurun_out/$name.log | cut -c1-250; }
+run v11_t_step 900 python -m pytest tests -q -m gpu -x -k "fused_step or end_to_end or rollout or smoke or mlp"
+rm -rf gpurun_out/prof_bench_bf16
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench_bf16 -o bench -- python bench.py --precision bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/v11_bench_prof_bf16.log 2>&1
+DB=$(ls gpurun_out/prof_bench_bf16/*.db gpurun_out/prof_bench_bf16/*/*.db 2>/dev/null | head -1)
+if [ -n "$DB" ]; then python tools/rocpd_stats.py "$DB" > gpurun_out/v11_bench_kernels_bf16.txt 2>&1; head -8 gpurun_out/v11_bench_kernels_bf16.txt; fi
+run v11_bench_b 600 python bench.py --no-cpu-baseline --no-roofline
+run v11_phase 300 python tools/phase_times.py 8192
+cat gpurun_out/v11_phase.log | cut -c1-400
