@@ -77,28 +77,24 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
         float4 g;
         if (nbase == 1) {
             const float4* gp = reinterpret_cast<const float4*>(src.base[0]) + i;
+            // The slabs were written by other XCDs' workgroups: every dependent batch of loads is one more trip to the
+            // memory-side cache (~1 us).  So ALL slabs of this float4 (up to 1 + SB) are requested before the first add --
+            // clamped, unconditional loads; the adds keep the ascending-slab order and skip the slots past nslab.  (Round 2:
+            // batches of 8 / 4 / 1 made 24 slabs seven dependent trips.)
+            constexpr int SB = 24;
+            float4 x[SB];
             g = gp[0];
-            int k = 1;
-            // the slabs were written by other XCDs' workgroups: every batch of loads is one trip to the memory-side cache, so
-            // eight slabs (128 bytes per lane) travel together; the adds keep the ascending-slab order
-            for (; k + 7 < nslab; k += 8) {
-                float4 x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = gp[(long long)(k + u) * n4];
+            for (int u = 0; u < SB; ++u) x[u] = gp[(long long)min(1 + u, nslab - 1) * n4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
-            }
-            for (; k + 3 < nslab; k += 4) {
-                const float4 x0 = gp[(long long)k * n4], x1 = gp[(long long)(k + 1) * n4], x2 = gp[(long long)(k + 2) * n4],
-                             x3 = gp[(long long)(k + 3) * n4];
-                g.x = (((g.x + x0.x) + x1.x) + x2.x) + x3.x;
-                g.y = (((g.y + x0.y) + x1.y) + x2.y) + x3.y;
-                g.z = (((g.z + x0.z) + x1.z) + x2.z) + x3.z;
-                g.w = (((g.w + x0.w) + x1.w) + x2.w) + x3.w;
-            }
-            for (; k < nslab; ++k) {
-                const float4 x = gp[(long long)k * n4];
-                g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+            for (int u = 0; u < SB; ++u)
+                if (1 + u < nslab) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
+            for (int k = 1 + SB; k < nslab; k += SB) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) x[u] = gp[(long long)min(k + u, nslab - 1) * n4];
+#pragma unroll
+                for (int u = 0; u < SB; ++u)
+                    if (k + u < nslab) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
             }
         } else {  // one staged gradient per rank, all peer loads in flight before the first add, fixed rank order
             float4 x[kMaxRanks];
@@ -241,8 +237,16 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         m4 = reinterpret_cast<const float4*>(m)[i0];
         v4 = reinterpret_cast<const float4*>(v)[i0];
     }
+    // the norm partials (<= kMaxParts = 4 x 256): all of a lane's loads in flight together, added in ascending order
     double acc[1] = {0.0};
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc[0] += partials[i];
+    {
+        double pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pv[u] = partials[min((int)threadIdx.x + u * 256, nparts - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((int)threadIdx.x + u * 256 < nparts) acc[0] += pv[u];
+    }
     // the step's scalars: one lane per block forms them (in parallel across blocks, hidden behind the partial-norm reduction;
     // formed once in the reduce launch they sat on ITS critical path: +2.7 us measured)
     if (threadIdx.x == 64) form_scalars(a, state != nullptr ? state[0] + 1 : a.step, &s_sc);  // state[0] is stable for the whole launch

@@ -37,7 +37,7 @@ struct GeoB {
     // fused step only: the rounded activations h1, h2 in the accumulator layout, one 8-byte word per lane and 16x16 tile
     // (lane-linear: conflict-free b64 accesses), read back by the backward epilogues -- 32 VGPRs that no longer pin the kernel
     // at the register limit (the spills they caused were reloaded with vmcnt(0) waits, i.e. behind the weight prefetch)
-    static constexpr size_t KEEP_BYTES = (size_t)2 * BM * HID * sizeof(__bf16);
+    static constexpr size_t KEEP_BYTES = RT == 4 ? (size_t)2 * BM * HID * sizeof(__bf16) : 0;  // RT == 2: registers (16 VGPRs)
 };
 
 // bf16 weight tiles: same matrix list and element offsets as struct Tiles, tile = 16 (n) x 32 (k):
@@ -481,7 +481,7 @@ struct StampsT {
 };
 
 template <int RT, int NW, int PD, int OP, bool STAMPS>
-__global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a, __bf16* st_tiles) {
+__global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_kernel(StepArgs a, __bf16* st_tiles) {
     typedef GeoB<RT, NW> G;
     constexpr int BM = G::BM, CT = G::CT;
     extern __shared__ __align__(16) float smem[];
@@ -580,15 +580,18 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
     ts.mark();
     f32x4 acc[RT][CT];
     bf16x4 kept3[RT][CT];  // rounded h3 in the accumulator layout (h1, h2: sKeep): the backward epilogues need exactly these lanes
+    constexpr bool KEEP_LDS = RT == 4;
+    bf16x4 kept12[KEEP_LDS ? 1 : 2][RT][CT];  // the 32-row variant has the registers for h1, h2 as well
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
     ts.mark();
-    epilogue_tanh_b<RT, NW, true>(acc, sBias, Xb, nullptr, sKeep, hy, tg.nrb, m0);
+    epilogue_tanh_b<RT, NW, true>(acc, sBias, Xb, KEEP_LDS ? nullptr : kept12[0], KEEP_LDS ? sKeep : nullptr, hy, tg.nrb, m0);
     ts.mark();
     gemm.run(Xb, acc);
     gemm.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
     ts.mark();
-    epilogue_tanh_b<RT, NW, true>(acc, sBias + HID, Xb, nullptr, sKeep + RT * CT * G::NT, hy + tg.mat(), tg.nrb, m0);
+    epilogue_tanh_b<RT, NW, true>(acc, sBias + HID, Xb, KEEP_LDS ? nullptr : kept12[KEEP_LDS ? 0 : 1], KEEP_LDS ? sKeep + RT * CT * G::NT : nullptr,
+                                  hy + tg.mat(), tg.nrb, m0);
     ts.mark();
     gemm.run(Xb, acc);
     ts.mark();
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_bf16_kernel(StepArgs a
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const bf16x4 hk = sKeep[((l - 1) * RT * CT + rt * CT + ct) * G::NT + tid];
+                const bf16x4 hk = KEEP_LDS ? sKeep[((l - 1) * RT * CT + rt * CT + ct) * G::NT + tid] : kept12[KEEP_LDS ? 0 : l - 1][rt][ct];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const __bf16 z = (__bf16)(acc[rt][ct][r] * dtanh_b(hk[r]));
@@ -1110,24 +1113,36 @@ int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
 // workspace carve (bytes) of the bf16 step: tiled activation images instead of the f32 row-major ones
 size_t bf16_image_bytes(int64_t m) { return (size_t)16 * ((m + 31) / 32) * 512 * sizeof(__bf16); }
 
-int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, hipStream_t st) {
+int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles, int dw_blocks, bool op8, hipStream_t st) {
     const size_t lds = GeoB<4, 8>::LDS_BYTES + GeoB<4, 8>::KEEP_BYTES;
     __bf16* stt = static_cast<__bf16*>(st_tiles);
-    if (op8 && a.stamps != nullptr) {
+    if (fused_bm_bf16() == 32) {  // `tiles` counts 32-row tiles (plan_step)
+        const size_t lds2 = GeoB<2, 8>::LDS_BYTES;
+        if (a.stamps != nullptr) {
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, true>, lds2)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, true>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
+        } else if (dev_variant("RLX_FUSED_PD", 4) == 2) {
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 2, 8, false>, lds2)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 2, 8, false>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
+        } else if (dev_variant("RLX_FUSED_PD", 4) == 3) {
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 3, 8, false>, lds2)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 3, 8, false>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
+        } else {
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, false>, lds2)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, false>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
+        }
+    } else if (op8 && a.stamps != nullptr) {
         if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
     } else if (op8 && dev_variant("RLX_FUSED_PD", 4) == 8) {  // development: deeper weight-fragment rings
         if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
-    } else if (op8 && dev_variant("RLX_FUSED_PD", 4) == 6) {
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 6, 8, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 6, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
     } else if (op8) {
         if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
     } else {
         if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>), dim3(tiles64, 2), dim3(512), lds, st, a, stt);
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
     }
     RLX_LAUNCH_CHECK();
     if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)

@@ -315,12 +315,19 @@ struct StepPlan {
     size_t off_h, off_dz, off_head, off_loss, off_tiles, off_st, bytes;
 };
 constexpr int STEP_BM = 64;
+// rows per workgroup of the bf16 fused launch: 32 (default: two workgroups per CU at 8192 rows -- their phases, matrix pipe /
+// VALU epilogues / barrier and memory latency, overlap; 58 KB of LDS and 128 VGPRs each) or 64 (RLX_FUSED_RT=4: one per CU,
+// half the weight-fragment traffic, 157 KB of LDS).  Measured (profiles/r02_fused_rows_per_workgroup.txt): 25.6 against 27.7 us.
+inline int fused_bm_bf16() { return dev_variant("RLX_FUSED_RT", 2) == 4 ? 64 : 32; }
 inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = false) {
     StepPlan pl{};
-    pl.tiles = ceil_div(m, STEP_BM);
-    pl.head_parts = pl.tiles * (STEP_BM / 32);
-    // 20 GEMM items per slab; fill 2 workgroups per CU once (no second, half-empty round)
-    int want = 2 * num_cu() / 20;
+    const int bm = bf16 ? fused_bm_bf16() : STEP_BM;
+    pl.tiles = ceil_div(m, bm);
+    pl.head_parts = pl.tiles * (bm / 32);
+    // 20 GEMM items per slab.  Every slab is 1.15 MB written here and read back by the slab reduce through the memory side:
+    // measured (round 2, after the head-reduce tail fix) 16 slabs = 1.25 workgroups per CU is the best trade -- weight-gradient
+    // launch 16.2 us + slab reduce 9.1 us, against 15.8 + 10.4 us with 24 slabs (2 per CU, no second round)
+    int want = 5 * num_cu() / (4 * 20);
     if (const char* e = getenv("RLX_DW_SLABS")) want = std::max(1, atoi(e));  // development: tools/bench_step.py sweeps it
     int slabs = std::max(1, std::min(want, ceil_div(m, 32)));
     pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);

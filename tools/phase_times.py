@@ -48,7 +48,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     t = buf.cpu().tolist()
     n = len(names16)
-    print(f"ppo_step_fused_bf16 M={M} block (0,1): total {t[n-1]-t[0]} ticks")
+    print(f"ppo_step_fused_bf16 (32 rows per workgroup) M={M} block (0,1): total {t[n-1]-t[0]} ticks")
     print("   " + "  ".join(f"{names16[i]}: {t[i]-t[i-1]}" for i in range(1, n)))
     t = t[32:48]
     print(f"dw bf16 (item 0): prologue->first barrier {t[1]-t[0]}  per k-block {[t[i+1]-t[i] for i in range(1, 11)]}  loop end {t[14]-t[0]}  stores drained {t[15]-t[14]}")
