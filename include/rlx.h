@@ -448,7 +448,10 @@ typedef struct rlx_ppo_step_args {
                            kept fresh by rlx_clip_adamw_step); NULL = rlx_ppo_step packs one into its workspace first */
     int32_t bf16;       /* 1: bf16 MFMA operands; activations / gradients travel to the weight-gradient kernel as bf16 */
 } rlx_ppo_step_args;
-int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);
+int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);                   /* bf16 == 0 */
+/* the split-K slab count depends on the operand precision (the f32 launch is bound by the matrix pipe and wants two
+   workgroups per CU, the bf16 one by slab bytes and wants fewer, larger slabs): grads must hold exactly this many */
+int rlx_ppo_step_slabs_for(const rlx_mlp_layout* layout, int64_t m, int32_t bf16);
 size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* layout, int64_t m);
 int rlx_ppo_step(const rlx_ppo_step_args* args, rlx_stream_t stream);
 

@@ -188,6 +188,7 @@ PROTOTYPES = {
     "rlx_mlp_pack_tiles_bf16": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
     "rlx_mlp_rollout_step": (c_int, [POINTER(RolloutStep), c_void_p]),
     "rlx_ppo_step_slabs": (c_int, [POINTER(MlpLayout), c_int64]),
+    "rlx_ppo_step_slabs_for": (c_int, [POINTER(MlpLayout), c_int64, c_int32]),
     "rlx_ppo_step_workspace_bytes": (c_size_t, [POINTER(MlpLayout), c_int64]),
     "rlx_ppo_step": (c_int, [POINTER(PpoStepArgs), c_void_p]),
     "rlx_decoupled_loss_workspace_bytes": (c_size_t, [c_int64]),

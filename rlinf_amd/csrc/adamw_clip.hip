@@ -76,26 +76,7 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
     for (long long i = tid0; i < n4; i += stride) {
         float4 g;
         if (nbase == 1) {
-            const float4* gp = reinterpret_cast<const float4*>(src.base[0]) + i;
-            // The slabs were written by other XCDs' workgroups: every dependent batch of loads is one more trip to the
-            // memory-side cache (~1 us).  So ALL slabs of this float4 (up to 1 + SB) are requested before the first add --
-            // clamped, unconditional loads; the adds keep the ascending-slab order and skip the slots past nslab.  (Round 2:
-            // batches of 8 / 4 / 1 made 24 slabs seven dependent trips.)
-            constexpr int SB = 24;
-            float4 x[SB];
-            g = gp[0];
-#pragma unroll
-            for (int u = 0; u < SB; ++u) x[u] = gp[(long long)min(1 + u, nslab - 1) * n4];
-#pragma unroll
-            for (int u = 0; u < SB; ++u)
-                if (1 + u < nslab) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
-            for (int k = 1 + SB; k < nslab; k += SB) {
-#pragma unroll
-                for (int u = 0; u < SB; ++u) x[u] = gp[(long long)min(k + u, nslab - 1) * n4];
-#pragma unroll
-                for (int u = 0; u < SB; ++u)
-                    if (k + u < nslab) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
-            }
+            g = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + i, n4, nslab);  // opt_common.h
         } else {  // one staged gradient per rank, all peer loads in flight before the first add, fixed rank order
             float4 x[kMaxRanks];
 #pragma unroll

@@ -22,6 +22,31 @@ struct ReduceSrc {
     const unsigned* seq;
 };
 
+// One float4 of the sum of `nslab` slabs (slab k at gp + k * n4).  The slabs were written by other XCDs' workgroups: every
+// dependent batch of loads is one more trip to the memory-side cache (~1 us), so ALL slabs of this float4 (up to 1 + SB) are
+// requested before the first add -- clamped, unconditional loads; the adds keep the ascending-slab order and skip the slots
+// past nslab.  (Batches of 8 / 4 / 1 made 24 slabs seven dependent trips.)
+#ifdef __HIPCC__
+__device__ __forceinline__ float4 sum_slabs_f4(const float4* __restrict__ gp, long long n4, int nslab) {
+    constexpr int SB = 24;
+    float4 x[SB];
+    float4 g = gp[0];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) x[u] = gp[(long long)min(1 + u, nslab - 1) * n4];
+#pragma unroll
+    for (int u = 0; u < SB; ++u)
+        if (1 + u < nslab) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
+    for (int k = 1 + SB; k < nslab; k += SB) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) x[u] = gp[(long long)min(k + u, nslab - 1) * n4];
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+            if (k + u < nslab) { g.x += x[u].x; g.y += x[u].y; g.z += x[u].z; g.w += x[u].w; }
+    }
+    return g;
+}
+#endif
+
 // Cross-GPU hand-shake in front of a peer read (xgmi_allreduce.hip): publish "my staged gradient number s is complete" to
 // every peer's flag array, then wait until every peer has published s.  world == 0: single GPU, nothing to wait for.
 struct PeerWait {

@@ -712,7 +712,8 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
     a.stamps = g_timing_buffer;
     a.params = r->params; a.tiles = r->tiles; a.lay = *r->layout; a.states = r->states; a.eps = r->eps; a.M = r->m;
     a.action = r->action; a.logprob = r->logprob; a.value = r->value; a.states_copy = r->states_copy;
-    a.tiles_policy = ceil_div(r->m, 16);
+    const int bm = r->bf16 ? rollout_bm_bf16() : 16;  // rows per workgroup
+    a.tiles_policy = ceil_div(r->m, bm);
     int tv[2] = {0, 0};
     for (int k = 0; k < r->n_value_jobs; ++k) {
         const rlx_value_job& j = r->value_jobs[k];
@@ -724,7 +725,7 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
                     "rlx_mlp_rollout_step: value job %d stores env rows but a pointer is NULL", k);
         a.vj[k] = ValueJob{j.states, j.m, j.values, j.rewards, j.flags, j.chunk, j.gamma, j.env_rewards, j.env_terminations,
                            j.env_truncations, j.done_row, j.termination_row, j.truncation_row, j.flag_is_truncation};
-        tv[k] = ceil_div(j.m, 16);
+        tv[k] = ceil_div(j.m, bm);
     }
     a.tiles_vj0 = tv[0]; a.tiles_vj1 = tv[1];
     const int blocks = 2 * a.tiles_policy + tv[0] + tv[1];
@@ -772,6 +773,11 @@ extern "C" int rlx_mlp_pack_tiles_bf16(const float* params, const rlx_mlp_layout
 extern "C" int rlx_ppo_step_slabs(const rlx_mlp_layout* lay, int64_t m) {
     if (!lay || m <= 0) return 1;
     return plan_step(lay, m).slabs;
+}
+
+extern "C" int rlx_ppo_step_slabs_for(const rlx_mlp_layout* lay, int64_t m, int32_t bf16) {
+    if (!lay || m <= 0) return 1;
+    return plan_step(lay, m, bf16 != 0).slabs;
 }
 
 extern "C" size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* lay, int64_t m) {

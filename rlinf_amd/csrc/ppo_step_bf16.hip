@@ -372,9 +372,9 @@ __device__ __forceinline__ void head_forward_mfma(const __bf16* Xb, const float*
 // ---------------------------------------------------------------------------------------------------------------
 // rollout step (RT = 1, NW = 8)
 // ---------------------------------------------------------------------------------------------------------------
-template <int PD>
+template <int RT>  // 16 RT rows per workgroup
 __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
-    constexpr int RT = 1, NW = 8;
+    constexpr int NW = 8;
     typedef GeoB<RT, NW> G;
     extern __shared__ __align__(16) float smem[];
     __bf16* Xb = reinterpret_cast<__bf16*>(smem);
@@ -940,8 +940,27 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, cons
 // how fast a CU can pull data that the previous launch produced (~11 B/clk), so halving the bytes is what counts.
 // Ring of 3 LDS buffers, counted vmcnt waits, raw s_barrier (a __syncthreads() would drain the DMAs).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int DW_NBUF = 3, DW_BUF_BYTES = 16 * 1024;
+constexpr int DW_BUF_BYTES = 16 * 1024;
 
+// s_waitcnt takes an immediate: wait until at most 4 * ahead of this wave's copies (the k-blocks behind the current one) are
+// still in flight
+template <int N>
+__device__ __forceinline__ void wait_copies_ahead(int ahead) {
+    if constexpr (N > 0) {
+        if (ahead >= N) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * N) : "memory");
+            return;
+        }
+        wait_copies_ahead<N - 1>(ahead);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// DW_NBUF LDS buffers = DW_NBUF - 1 k-blocks in flight per workgroup.  The loop is bound by the LATENCY of the copies (the
+// operands were written by the previous launch from every XCD: memory-side trips of ~2.4 k cycles): with 2 k-blocks in flight a
+// workgroup moved 16 KB per ~1.2 k cycles (13.7 B/clk) against 256 cycles of MFMA work per k-block.
+template <int DW_NBUF>
 __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, const __bf16* __restrict__ st_tiles) {
     extern __shared__ __align__(16) char dsm[];
     const rlx_mlp_layout& lay = a.lay;
@@ -1017,16 +1036,17 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, 
     // stamps by the workgroup that owns GEMM item 0
     long long* stp = (a.stamps != nullptr && item == 0 && tid == 0) ? a.stamps : nullptr;
     if (stp) stp[0] = clock64();
-    if (nkb > 0) dma(0, 0);
-    if (nkb > 1) dma(1, 1);
+    constexpr int AHEAD = DW_NBUF - 1;  // k-blocks in flight
+#pragma unroll
+    for (int d = 0; d < AHEAD; ++d)
+        if (d < nkb) dma(d, d);
     for (int kb = 0; kb < nkb; ++kb) {
-        // this wave's copies of k-block kb have landed once at most the 4 of k-block kb+1 are still in flight
-        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's copies of k-block kb have landed once only those of the k-blocks behind it are still in flight
+        wait_copies_ahead<AHEAD - 1>(min(AHEAD - 1, nkb - 1 - kb));
         __builtin_amdgcn_s_barrier();  // everybody's copies of kb landed; everybody finished reading kb - 1
         asm volatile("" ::: "memory");
         if (stp && kb < 12) stp[1 + kb] = clock64();
-        if (kb + 2 < nkb) dma(kb + 2, (kb + 2) % DW_NBUF);  // into the buffer k-block kb - 1 just vacated
+        if (kb + AHEAD < nkb) dma(kb + AHEAD, (kb + AHEAD) % DW_NBUF);  // into the buffer k-block kb - 1 just vacated
         const char* buf = dsm + (kb % DW_NBUF) * DW_BUF_BYTES + lane * 16;
         bf16x8 fa[4], fb[4];
 #pragma unroll
@@ -1103,9 +1123,15 @@ int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles,
 }
 
 int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
-    const size_t lds = GeoB<1, 8>::LDS_BYTES;
-    if (int rc = set_lds_b(rollout_step_bf16_kernel<4>, lds)) return rc;
-    hipLaunchKernelGGL(rollout_step_bf16_kernel<4>, dim3(blocks), dim3(512), lds, st, a);
+    if (rollout_bm_bf16() == 32) {
+        const size_t lds = GeoB<2, 8>::LDS_BYTES;
+        if (int rc = set_lds_b(rollout_step_bf16_kernel<2>, lds)) return rc;
+        hipLaunchKernelGGL(rollout_step_bf16_kernel<2>, dim3(blocks), dim3(512), lds, st, a);
+    } else {
+        const size_t lds = GeoB<1, 8>::LDS_BYTES;
+        if (int rc = set_lds_b(rollout_step_bf16_kernel<1>, lds)) return rc;
+        hipLaunchKernelGGL(rollout_step_bf16_kernel<1>, dim3(blocks), dim3(512), lds, st, a);
+    }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -1117,7 +1143,7 @@ int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int til
     const size_t lds = GeoB<4, 8>::LDS_BYTES + GeoB<4, 8>::KEEP_BYTES;
     __bf16* stt = static_cast<__bf16*>(st_tiles);
     if (fused_bm_bf16() == 32) {  // `tiles` counts 32-row tiles (plan_step)
-        const size_t lds2 = GeoB<2, 8>::LDS_BYTES;
+        const size_t lds2 = GeoB<2, 8>::LDS_BYTES + (size_t)dev_variant("RLX_FUSED_LDS_PAD", 0);  // development: LDS-size sensitivity
         if (a.stamps != nullptr) {
             if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, true>, lds2)) return rc;
             hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, true>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
@@ -1148,9 +1174,21 @@ int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int til
     if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)
         hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
     } else {
-        const size_t dlds = (size_t)DW_NBUF * DW_BUF_BYTES;
-        if (int rc = set_lds_b(ppo_step_dw_bf16_lds_kernel, dlds)) return rc;
-        hipLaunchKernelGGL(ppo_step_dw_bf16_lds_kernel, dim3(dw_blocks), dim3(256), dlds, st, d, static_cast<const __bf16*>(stt));
+#define RLX_DW_LAUNCH(NB)                                                                                                       \
+    {                                                                                                                           \
+        const size_t dlds = (size_t)(NB) * DW_BUF_BYTES;                                                                          \
+        if (int rc = set_lds_b(ppo_step_dw_bf16_lds_kernel<NB>, dlds)) return rc;                                               \
+        hipLaunchKernelGGL(ppo_step_dw_bf16_lds_kernel<NB>, dim3(dw_blocks), dim3(256), dlds, st, d, static_cast<const __bf16*>(stt)); \
+    }
+        switch (dw_nbuf()) {
+            case 2: RLX_DW_LAUNCH(2) break;
+            case 3: RLX_DW_LAUNCH(3) break;
+            case 4: RLX_DW_LAUNCH(4) break;
+            case 6: RLX_DW_LAUNCH(6) break;
+            case 9: RLX_DW_LAUNCH(9) break;
+            default: RLX_DW_LAUNCH(5) break;
+        }
+#undef RLX_DW_LAUNCH
     }
     RLX_LAUNCH_CHECK();
     return RLX_OK;

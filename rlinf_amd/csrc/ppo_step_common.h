@@ -318,6 +318,9 @@ constexpr int STEP_BM = 64;
 // rows per workgroup of the bf16 fused launch: 32 (default: two workgroups per CU at 8192 rows -- their phases, matrix pipe /
 // VALU epilogues / barrier and memory latency, overlap; 58 KB of LDS and 128 VGPRs each) or 64 (RLX_FUSED_RT=4: one per CU,
 // half the weight-fragment traffic, 157 KB of LDS).  Measured (profiles/r02_fused_rows_per_workgroup.txt): 25.6 against 27.7 us.
+// rows per workgroup of the bf16 rollout launch (every workgroup pulls its network's whole 0.29 MB tile image through the L2)
+inline int rollout_bm_bf16() { return dev_variant("RLX_ROLLOUT_RT", 1) == 2 ? 32 : 16; }
+inline int dw_nbuf() { return dev_variant("RLX_DW_NBUF", 3); }  // LDS ring depth of the bf16 weight-gradient launch (3, 4, 5, 6, 9)
 inline int fused_bm_bf16() { return dev_variant("RLX_FUSED_RT", 2) == 4 ? 64 : 32; }
 inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = false) {
     StepPlan pl{};
@@ -327,9 +330,12 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     // 20 GEMM items per slab.  Every slab is 1.15 MB written here and read back by the slab reduce through the memory side:
     // measured (round 2, after the head-reduce tail fix) 16 slabs = 1.25 workgroups per CU is the best trade -- weight-gradient
     // launch 16.2 us + slab reduce 9.1 us, against 15.8 + 10.4 us with 24 slabs (2 per CU, no second round)
-    int want = 5 * num_cu() / (4 * 20);
+    // (the exact-f32 launch is bound by the f32 matrix pipe, not by slab bytes: it keeps 2 workgroups per CU in one round --
+    //  measured 71 us with 24 slabs against 97 us with 16)
+    int want = bf16 ? 5 * num_cu() / (4 * 20) : 2 * num_cu() / 20;
     if (const char* e = getenv("RLX_DW_SLABS")) want = std::max(1, atoi(e));  // development: tools/bench_step.py sweeps it
-    int slabs = std::max(1, std::min(want, ceil_div(m, 32)));
+    // ... and at least 256 rows (8 k-blocks) per slab: a data-parallel rank's small minibatch should not pay 16 slabs of traffic
+    int slabs = std::max(1, std::min(want, ceil_div(m, 256)));
     pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
     pl.slabs = ceil_div(m, pl.rows_per_slab);
     pl.head_stride = head_stride_of(lay);

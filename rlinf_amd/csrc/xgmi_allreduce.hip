@@ -48,21 +48,7 @@ __global__ __launch_bounds__(256) void xgmi_stage_kernel(const float* __restrict
     const bool vec = (n % 4 == 0) && (n_max % 4 == 0) && (reinterpret_cast<uintptr_t>(g) % 16 == 0);
     const long long n4 = vec ? n / 4 : 0;
     for (long long i = tid0; i < n4; i += stride) {
-        const float4* gp = reinterpret_cast<const float4*>(g) + i;
-        float4 s = gp[0];
-        int k = 1;
-        for (; k + 3 < nslab; k += 4) {
-            const float4 x0 = gp[(long long)k * n4], x1 = gp[(long long)(k + 1) * n4], x2 = gp[(long long)(k + 2) * n4],
-                         x3 = gp[(long long)(k + 3) * n4];
-            s.x = (((s.x + x0.x) + x1.x) + x2.x) + x3.x;
-            s.y = (((s.y + x0.y) + x1.y) + x2.y) + x3.y;
-            s.z = (((s.z + x0.z) + x1.z) + x2.z) + x3.z;
-            s.w = (((s.w + x0.w) + x1.w) + x2.w) + x3.w;
-        }
-        for (; k < nslab; ++k) {
-            const float4 x = gp[(long long)k * n4];
-            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
-        }
+        const float4 s = sum_slabs_f4(reinterpret_cast<const float4*>(g) + i, n4, nslab);  // all slabs in flight, ascending adds
         reinterpret_cast<float4*>(dst)[i] = s;
     }
     for (long long i = n4 * 4 + tid0; i < n; i += stride) {

@@ -876,8 +876,9 @@ def ctypes_pointer(layout: MlpLayout):
     return ctypes.pointer(layout)
 
 
-def ppo_step_slabs(layout: MlpLayout, m: int) -> int:
-    return _lib.load().rlx_ppo_step_slabs(byref(layout), int(m))
+def ppo_step_slabs(layout: MlpLayout, m: int, bf16: bool = False) -> int:
+    """Split-K slabs `grads` must hold for a minibatch of m rows at the given operand precision."""
+    return _lib.load().rlx_ppo_step_slabs_for(byref(layout), int(m), 1 if bf16 else 0)
 
 
 def ppo_step_workspace_bytes(layout: MlpLayout, m: int) -> int:

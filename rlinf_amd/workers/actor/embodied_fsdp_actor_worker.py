@@ -346,7 +346,7 @@ class EmbodiedFSDPActor(Worker):
         if key not in self._ws:
             lay, dev = self.model.layout, self.device
             if self.fused_step:
-                self._ws[key] = dict(slabs=ops.ppo_step_slabs(lay, mb),
+                self._ws[key] = dict(slabs=ops.ppo_step_slabs(lay, mb, self.model.compute_dtype == torch.bfloat16),
                                      step_ws=torch.empty(ops.ppo_step_workspace_bytes(lay, mb), dtype=torch.uint8, device=dev))
                 return self._ws[key]
             f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731

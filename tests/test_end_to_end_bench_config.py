@@ -174,7 +174,7 @@ def test_first_optimizer_step_gradient_at_bench_configuration(precision):
     assert N == T * B
     mb = {k: v[:GB] for k, v in flat.items()}
     lay = w.model.layout
-    grads = torch.full((ops.ppo_step_slabs(lay, GB), lay.n_params), float("nan"), device="cuda")
+    grads = torch.full((ops.ppo_step_slabs(lay, GB, bf16=bf16), lay.n_params), float("nan"), device="cuda")
     ws = torch.empty(ops.ppo_step_workspace_bytes(lay, GB), dtype=torch.uint8, device="cuda")
     row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
     ops.ppo_step(w.model.flat.data, lay, w._loss_params(False), mb, grads, row, ws, grad_out=1.0, bf16=bf16)

@@ -252,7 +252,7 @@ def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask, rows_per_workg
     lay = pol.layout
     lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
                              value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
-    grads = torch.full((ops.ppo_step_slabs(lay, M), lay.n_params), float("nan"), device="cuda")  # every element must be written
+    grads = torch.full((ops.ppo_step_slabs(lay, M, bf16=True), lay.n_params), float("nan"), device="cuda")  # every element must be written
     ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
     row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
     dev_mb = {k: v.cuda().contiguous() for k, v in mb.items()}

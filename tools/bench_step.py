@@ -38,7 +38,7 @@ def main():
     for prec in ("bf16", "f32"):
         for slabs in (24, 16, 12, 8):
             os.environ["RLX_DW_SLABS"] = str(slabs)
-            grads = torch.empty((ops.ppo_step_slabs(lay, M), lay.n_params), device="cuda")
+            grads = torch.empty((ops.ppo_step_slabs(lay, M, bf16=prec == "bf16"), lay.n_params), device="cuda")
             ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
             m_, v_ = torch.zeros(lay.n_params, device="cuda"), torch.zeros(lay.n_params, device="cuda")
             p2 = pol.flat.data.clone()

@@ -39,12 +39,13 @@ for rep in range(3):
     print("   " + "  ".join(f"{names[i]}: {t[i]-t[i-1]}" for i in range(1, n)))
 # bf16 fused kernel (block (0,0)) and weight-gradient kernel (LDS-DMA variant): stamps of the workgroup owning GEMM item 0 land at buf[32:]
 pol16 = MLPPolicy(42, 8, 1, True, False, compute_dtype=torch.bfloat16).to("cuda")
+grads16 = torch.empty((ops.ppo_step_slabs(lay, M, bf16=True), lay.n_params), device="cuda")
 names16 = ["start", "states arrived", "inputs staged", "gemm L1", "epi1+tiles", "gemm L2", "epi2+tiles", "gemm L3", "epi3", "head (mfma)",
            "element pass", "loss pass (wave 0)", "dOut pass + metric sums", "head grads", "dz3+tiles", "bwd gemm W3 + epi + tiles",
            "bwd gemm W2 + epi + tiles", "stores drained"]  # ("loss pass" is stamped by the policy network's workgroup only)
 for rep in range(3):
     buf.zero_()
-    ops.ppo_step(pol16.flat.data, lay, lp, mb, grads, row, ws, grad_out=1.0, bf16=True)
+    ops.ppo_step(pol16.flat.data, lay, lp, mb, grads16, row, ws, grad_out=1.0, bf16=True)
     torch.cuda.synchronize()
     t = buf.cpu().tolist()
     n = len(names16)

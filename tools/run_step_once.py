@@ -18,7 +18,7 @@ mb = dict(states=torch.randn(M, 42, generator=g), action=torch.randn(M, 8, gener
 mb = {k: v.cuda() for k, v in mb.items()}
 lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
                          value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
-grads = torch.empty((ops.ppo_step_slabs(lay, M), lay.n_params), device="cuda")
+grads = torch.empty((ops.ppo_step_slabs(lay, M, bf16=BF16), lay.n_params), device="cuda")
 ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
 row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
 m_, v_ = torch.zeros(lay.n_params, device="cuda"), torch.zeros(lay.n_params, device="cuda")
