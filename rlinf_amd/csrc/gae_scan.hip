@@ -91,12 +91,13 @@ struct Moments {
     }
 };
 
-__device__ __forceinline__ void flush_moments(const Moments& mo, double* partials, double* scratch) {
+__device__ __forceinline__ void flush_moments(const Moments& mo, double* partials, double* scratch, long long slot = -1) {
     double v[5] = {mo.n, mo.sa, mo.qa, mo.sr, mo.qr};
     block_sum<5>(v, scratch);
     if (threadIdx.x == 0) {
+        const size_t at = slot >= 0 ? (size_t)slot : (size_t)blockIdx.x;  // the env group's slot: the final sum keeps its order
 #pragma unroll
-        for (int k = 0; k < 5; ++k) partials[(size_t)blockIdx.x * 5 + k] = v[k];
+        for (int k = 0; k < 5; ++k) partials[at * 5 + k] = v[k];
     }
 }
 
@@ -130,7 +131,12 @@ struct Batch {
     uint32_t dn[UU], mk[UU];
 };
 
-template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK>
+// PAIR (streaming variant, one wave per workgroup): a wave's `done` row is 64 bytes -- half a 128-byte line, and the
+// neighbouring wave's half is fetched AGAIN when that wave runs on another XCD (workgroup i goes to XCD i % 8): measured
+// reads 1.117 x algorithmic (profiles/r01_*pmc*).  With PAIR the env groups 2k and 2k + 1 are given to workgroups b and
+// b + 8 -- the same XCD, dispatched together -- and the `done` loads go through the caches normally, so the second half
+// of the line is an L2 hit.
+template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK, bool PAIR = false>
 __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
     // CRITIC / MASK are compile-time: a runtime "load or constant" select makes hipcc branch around
     // every load and drain vmcnt(0) per element (measured 27 us -> see DESIGN.md).
@@ -141,7 +147,12 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
     constexpr int W = 64 * VEC;  // envs per block
     const int lane = threadIdx.x & 63;
     const int seg = NSEG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long e0 = ((long long)blockIdx.x * 64 + lane) * VEC;
+    long long grp = blockIdx.x;  // env group (64 * VEC envs) of this workgroup
+    if constexpr (PAIR) {
+        const unsigned b = blockIdx.x, paired = gridDim.x & ~15u;
+        if (b < paired) grp = (long long)(((b >> 4) * 8 + (b & 7)) * 2 + ((b >> 3) & 1));
+    }
+    const long long e0 = (grp * 64 + lane) * VEC;
     const bool active = e0 < a.B;
     constexpr bool critic = CRITIC;
     const int T = a.T;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
                 const size_t t = (size_t)(t_top - 1 - u);
                 ld<VEC, NT>(a.r + t * B + e0, bt.r[u]);
                 if constexpr (critic) ld<VEC, NT>(a.v + t * B + e0, bt.v[u]);
-                bt.dn[u] = ldb<VEC, NT>(a.d + (t + 1) * B + e0);
+                bt.dn[u] = ldb<VEC, NT && !PAIR>(a.d + (t + 1) * B + e0);
                 if constexpr (MASK) bt.mk[u] = ldb<VEC, NT>(a.m + t * B + e0);
                 else bt.mk[u] = 0x01010101u;
             }
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
             }
         }
     }
-    flush_moments(mo, a.partials, s_red);
+    flush_moments(mo, a.partials, s_red, grp);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -517,10 +528,10 @@ inline size_t lds_bytes(int vec, int nseg, int T) {
     return (size_t)T * W * 4 * 2 + (size_t)nseg * W * 4 * 2 + 5 * nseg * sizeof(double);
 }
 
-template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK>
+template <int VEC, int NSEG, int U, bool NT, bool CRITIC, bool MASK, bool PAIR = false>
 int launch_c1(const GaeArgs& a, hipStream_t s, int nblk) {
     const size_t lds = lds_bytes(VEC, NSEG, a.T);
-    auto kern = gae_scan_c1<VEC, NSEG, U, NT, CRITIC, MASK>;
+    auto kern = gae_scan_c1<VEC, NSEG, U, NT, CRITIC, MASK, PAIR>;
     if (lds > 48 * 1024) {
         RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -540,7 +551,11 @@ int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk, int rows = 8, bool nt
         if (critic && !mask) {
             if (rows == 16) return nt ? launch_c1<1, 1, 16, true, true, false>(a, s, nblk) : launch_c1<1, 1, 16, false, true, false>(a, s, nblk);
             if (rows == 32) return nt ? launch_c1<1, 1, 32, true, true, false>(a, s, nblk) : launch_c1<1, 1, 32, false, true, false>(a, s, nblk);
-            if (rows == 64) return nt ? launch_c1<1, 1, 64, true, true, false>(a, s, nblk) : launch_c1<1, 1, 64, false, true, false>(a, s, nblk);
+            if (rows == 64 && nt) {
+                static const bool pair = getenv("RLX_GAE_PAIR") == nullptr || atoi(getenv("RLX_GAE_PAIR")) != 0;  // development: A / B
+                return pair ? launch_c1<1, 1, 64, true, true, false, true>(a, s, nblk) : launch_c1<1, 1, 64, true, true, false>(a, s, nblk);
+            }
+            if (rows == 64) return launch_c1<1, 1, 64, false, true, false>(a, s, nblk);
             if (rows == 128) return nt ? launch_c1<1, 1, 128, true, true, false>(a, s, nblk) : launch_c1<1, 1, 128, false, true, false>(a, s, nblk);
             if (nt) return launch_c1<1, 1, 8, true, true, false>(a, s, nblk);
         }
