@@ -609,80 +609,148 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     head_forward_mfma<RT>(Xb, W4s, sG, sLp);  // the two k-half partials land in sG / sLp (both free until the passes below)
     lds_barrier();
     ts.mark();
-    for (int idx = tid; idx < BM * n_out; idx += G::NT) {
-        const int row = idx / n_out, o = idx % n_out;
-        float s = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
-        if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[o]);
-        sHead[row * MAX_OUT + o] = s;
+    // Fast path (the embodied shapes: one loss element per row -- action_level log-probs, one sub-group --, or a value head of
+    // at most 64 / BM outputs): element math, loss element and dOut in ONE pass with no barrier in between.  A row's n_out lanes
+    // are neighbours (idx = row * n_out + o), so the row leader (o == 0) collects the per-dimension log-probs with n_out - 1
+    // lane shifts and adds them in the reference's order (j ascending, starting from 0.f), evaluates the loss element and hands
+    // d(loss)/d(logprob) back to its lanes.  Slot r of the metric partials is row r's element, exactly what wave 0's lane r
+    // held in the general path: the butterfly sums -- and so the metrics -- are bit-identical between the two paths.
+    double* sLacc = reinterpret_cast<double*>(Xb);  // [NS][64]; h3's slab is dead: the head gradients / dZ3 use registers + sHead
+    const bool fast = BM * n_out <= G::NT && (y == 0 ? BM * n_out <= 64 : (npr == 1 && S == 1 && 64 % n_out == 0));
+    if (fast) {
+        for (int i = tid; i < NS * 64; i += G::NT)
+            if ((i & 63) >= (y == 0 ? BM * n_out : BM)) sLacc[i] = 0.0;  // the slots no element owns
+        const bool mine = tid < BM * n_out;
+        const int row = mine ? tid / n_out : 0, o = mine ? tid % n_out : 0;
+        const bool valid = mine && m0 + row < M;
+        float sv = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
+        if (lay.off_b[y][3] >= 0) sv = fadd(sv, b4s[o]);
         if (y == 1) {
-            const float d = fsub(sAct[row * MAX_OUT + o], s);
-            const float var = sStd[MAX_OUT + o];
-            const float log_scale = sStd[2 * MAX_OUT + o];
-            sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
-            sD[row * MAX_OUT + o] = d;
-        }
-    }
-    lds_barrier();
-    ts.mark();
-    // wave 0 walks the tile's loss elements (a fixed lane <-> element assignment keeps the f64 metric sums reproducible) and
-    // parks its 16 per-lane partial sums in the slab (h3 is dead: the head gradients and dZ3 work from registers and sHead);
-    // behind the barrier every wave butterfly-sums two of the 16 slots while all lanes run the dOut pass -- the same 64-lane
-    // butterfly wave 0 used to run 16 times in a row (~7 k cycles with the other seven waves parked at the barrier).
-    double* sLacc = reinterpret_cast<double*>(Xb);  // [NS][64]
-    if (y == 1) {
-        for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {
-            const int row = idx / npr, c = idx % npr;
-            if (m0 + row >= M) continue;
-            const long long e = (m0 + row) * npr + c;
-            const bool on = has_mask ? a.loss_mask[e] != 0 : true;
-            float w = 1.f;
-            if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
-            const float adv = sAdv[row * MAX_OUT + c];
-            lacc[S_NM] += on ? 1.0 : 0.0;
-            const float* olp = sOld + row * MAX_OUT + c * K;
-            for (int s = 0; s < S; ++s) {
-                float lp = 0.f, old = 0.f;
-                for (int j = 0; j < R; ++j) {
-                    lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
-                    old = fadd(old, olp[s * R + j]);
-                }
-                const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
-                sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+            const float d = fsub(sAct[row * MAX_OUT + o], sv);
+            const float var = sStd[MAX_OUT + o], log_scale = sStd[2 * MAX_OUT + o];
+            const float lpe = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            const float olde = sOld[row * MAX_OUT + o];
+            float lp = fadd(0.f, lpe), old = fadd(0.f, olde);
+            for (int j = 1; j < n_out; ++j) {  // wave-uniform trip count; only the leaders' sums are used
+                lp = fadd(lp, __shfl_down(lpe, j, 64));
+                old = fadd(old, __shfl_down(olde, j, 64));
             }
-        }
-    } else {
-        for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {
-            const int row = idx / n_out, o = idx % n_out;
+            float gs = 0.f;
+            if (valid && o == 0) {
+                const long long e = m0 + row;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                lacc[S_NM] += on ? 1.0 : 0.0;
+                const float g = actor_elem(p, lp, old, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc);
+                gs = (a.grad_out * (float)(1.0 / den.actor)) * g;
+            }
+            gs = __shfl(gs, (lane - o) & 63, 64);  // from the row leader
+            float dmu = 0.f, dls = 0.f;
+            if (valid) {
+                dmu = gs * d / var;
+                dls = gs * (d * d / var - 1.f);
+            }
+            if (mine) {
+                sHead[row * MAX_OUT + o] = dmu;
+                sLp[row * MAX_OUT + o] = dls;
+                if (o == 0) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) sLacc[k * 64 + row] = lacc[k];
+                }
+            }
+        } else if (mine) {
             float gv = 0.f;
-            if (m0 + row < M && p.has_critic) {
+            if (valid && p.has_critic) {
                 const long long e = (m0 + row) * n_out + o;
                 const bool on = has_mask ? a.loss_mask[e] != 0 : true;
                 float w = 1.f;
                 if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
                 gv = (a.grad_out * (float)(1.0 / den.critic)) *
-                     critic_elem(p, sHead[row * MAX_OUT + o], sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
+                     critic_elem(p, sv, sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
             }
             sHead[row * MAX_OUT + o] = gv;
-        }
-    }
-    if (wave == 0) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) sLacc[k * 64 + lane] = lacc[k];
-    }
-    lds_barrier();
-    ts.mark();
-    if (y == 1) {
+            for (int k = 0; k < NS; ++k) sLacc[k * 64 + tid] = lacc[k];
+        }
+        lds_barrier();
+        ts.mark();
+        ts.mark();  // (the general path's two intermediate stamps)
+    } else {
         for (int idx = tid; idx < BM * n_out; idx += G::NT) {
             const int row = idx / n_out, o = idx % n_out;
-            float dmu = 0.f, dls = 0.f;
-            if (m0 + row < M) {
-                const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
-                const float var = sStd[MAX_OUT + o], d = sD[row * MAX_OUT + o];
-                dmu = dlp * d / var;
-                dls = dlp * (d * d / var - 1.f);
+            float s = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
+            if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[o]);
+            sHead[row * MAX_OUT + o] = s;
+            if (y == 1) {
+                const float d = fsub(sAct[row * MAX_OUT + o], s);
+                const float var = sStd[MAX_OUT + o];
+                const float log_scale = sStd[2 * MAX_OUT + o];
+                sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+                sD[row * MAX_OUT + o] = d;
             }
-            sHead[row * MAX_OUT + o] = dmu;
-            sLp[row * MAX_OUT + o] = dls;
+        }
+        lds_barrier();
+        ts.mark();
+        // wave 0 walks the tile's loss elements (a fixed lane <-> element assignment keeps the f64 metric sums reproducible) and
+        // parks its 16 per-lane partial sums in the slab (h3 is dead: the head gradients and dZ3 work from registers and sHead);
+        // behind the barrier every wave butterfly-sums two of the 16 slots while all lanes run the dOut pass -- the same 64-lane
+        // butterfly wave 0 used to run 16 times in a row (~7 k cycles with the other seven waves parked at the barrier).
+        if (y == 1) {
+            for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {
+                const int row = idx / npr, c = idx % npr;
+                if (m0 + row >= M) continue;
+                const long long e = (m0 + row) * npr + c;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                const float adv = sAdv[row * MAX_OUT + c];
+                lacc[S_NM] += on ? 1.0 : 0.0;
+                const float* olp = sOld + row * MAX_OUT + c * K;
+                for (int s = 0; s < S; ++s) {
+                    float lp = 0.f, old = 0.f;
+                    for (int j = 0; j < R; ++j) {
+                        lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
+                        old = fadd(old, olp[s * R + j]);
+                    }
+                    const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
+                    sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                }
+            }
+        } else {
+            for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {
+                const int row = idx / n_out, o = idx % n_out;
+                float gv = 0.f;
+                if (m0 + row < M && p.has_critic) {
+                    const long long e = (m0 + row) * n_out + o;
+                    const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                    float w = 1.f;
+                    if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                    gv = (a.grad_out * (float)(1.0 / den.critic)) *
+                         critic_elem(p, sHead[row * MAX_OUT + o], sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
+                }
+                sHead[row * MAX_OUT + o] = gv;
+            }
+        }
+        if (wave == 0) {
+    #pragma unroll
+            for (int k = 0; k < NS; ++k) sLacc[k * 64 + lane] = lacc[k];
+        }
+        lds_barrier();
+        ts.mark();
+        if (y == 1) {
+            for (int idx = tid; idx < BM * n_out; idx += G::NT) {
+                const int row = idx / n_out, o = idx % n_out;
+                float dmu = 0.f, dls = 0.f;
+                if (m0 + row < M) {
+                    const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
+                    const float var = sStd[MAX_OUT + o], d = sD[row * MAX_OUT + o];
+                    dmu = dlp * d / var;
+                    dls = dlp * (d * d / var - 1.f);
+                }
+                sHead[row * MAX_OUT + o] = dmu;
+                sLp[row * MAX_OUT + o] = dls;
+            }
         }
     }
     {
