@@ -413,18 +413,25 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         hipLaunchKernelGGL((gae_seq_kernel<128, 2048>), dim3((unsigned)bsz), dim3(128), lds_for(2048), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
     } else if (dev_variant_gaeseq() != 2) {
-        // long sequences: one 512-lane workgroup walks the row in 8192-token segments (66 KB of LDS): 0.62 of the HBM peak at
-        // 4096 x 8192.  The variant below -- one 2048- or 1024-token segment per 128-lane workgroup, carries by decoupled
-        // look-back -- was built to lift the occupancy and measured SLOWER (0.59 with 2048-token segments, 0.50 with 1024):
-        // the chain of publish / poll round trips through the memory side costs more than the idle phases it removes.
-        static bool attr_set = false;
-        if (!attr_set) {
-            RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gae_seq_kernel<512, 8192>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_for(8192)));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((gae_seq_kernel<512, 8192>), dim3((unsigned)bsz), dim3(512), lds_for(8192), st, values, rewards,
-                           advantages, returns, (int)seq, gamma, gamma_lambda);
+        // long sequences: one workgroup walks the row in LDS segments from the end, 16 tokens per lane.  Measured at 4096 x 8192
+        // (profiles/r02_gae_seq_segment_sweep.txt): 256 lanes x 4096-token segments (34 KB of LDS: four workgroups per CU, two
+        // passes per row) 0.65 of the HBM peak; 512 x 8192 (66 KB, two per CU, one pass: the round-1 shape) 0.61;
+        // 128 x 2048 0.58; 8 or 32 tokens per lane 0.43-0.51.  The look-back variant below -- one segment per workgroup, carries
+        // through the memory side -- 0.50-0.59: the publish / poll round trips cost more than the idle phases they remove.
+#define RLX_GAESEQ_LAUNCH(STV, SEGV)                                                                                         \
+    {                                                                                                                        \
+        static bool attr_set = false;                                                                                        \
+        if (!attr_set) {                                                                                                     \
+            RLX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gae_seq_kernel<STV, SEGV>),                      \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_for(SEGV)));              \
+            attr_set = true;                                                                                                 \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((gae_seq_kernel<STV, SEGV>), dim3((unsigned)bsz), dim3(STV), lds_for(SEGV), st, values, rewards,   \
+                           advantages, returns, (int)seq, gamma, gamma_lambda);                                              \
+    }
+        if (dev_variant_gaeseq() == 1) RLX_GAESEQ_LAUNCH(512, 8192)  // the round-1 shape, kept tested
+        else RLX_GAESEQ_LAUNCH(256, 4096)
+#undef RLX_GAESEQ_LAUNCH
     } else {
         // RLX_GAESEQ_VARIANT=2 (kept tested): one LB_SEG-token segment per 128-lane workgroup, carries by decoupled look-back
         const int64_t nseg = (seq + LB_SEG - 1) / LB_SEG;

@@ -432,9 +432,10 @@ def test_gae_seq_vs_oracle(seq, gl):
     assert out[0].is_contiguous() and out[1].is_contiguous()
 
 
-@pytest.mark.parametrize("variant", ["0", "2"])
+@pytest.mark.parametrize("variant", ["0", "1", "2"])
 def test_gae_seq_lookback_many_rows_and_nan_rows(variant, monkeypatch):
-    """Long rows, both kernels: the default walk (one workgroup per row) and RLX_GAESEQ_VARIANT=2, one segment per workgroup with
+    """Long rows, all kernels: the default walk (one 256-lane workgroup per row, 4096-token segments), the round-1 shape of it
+    (RLX_GAESEQ_VARIANT=1: 512 lanes, 8192-token segments) and RLX_GAESEQ_VARIANT=2, one segment per workgroup with
     a decoupled look-back for the carry (thousands of workgroups in flight, neighbours racing) -- against the sequential
     oracle; a NaN row must come back NaN, and come back (the look-back never waits on a payload's value, only on its flag)."""
     from oracle import ppo_oracle as PO
