@@ -410,6 +410,17 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
     };
     if (seq <= 2048) {
         // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token), 17 KB of LDS -> nine per CU
+        const int v = dev_variant_gaeseq();  // development: 20 = 256 lanes, 21 = 64 lanes, 22 = 1024-token segments
+        if (v == 20)
+            hipLaunchKernelGGL((gae_seq_kernel<256, 2048>), dim3((unsigned)bsz), dim3(256), lds_for(2048), st, values, rewards,
+                               advantages, returns, (int)seq, gamma, gamma_lambda);
+        else if (v == 21)
+            hipLaunchKernelGGL((gae_seq_kernel<64, 2048>), dim3((unsigned)bsz), dim3(64), lds_for(2048), st, values, rewards,
+                               advantages, returns, (int)seq, gamma, gamma_lambda);
+        else if (v == 22)
+            hipLaunchKernelGGL((gae_seq_kernel<128, 1024>), dim3((unsigned)bsz), dim3(128), lds_for(1024), st, values, rewards,
+                               advantages, returns, (int)seq, gamma, gamma_lambda);
+        else
         hipLaunchKernelGGL((gae_seq_kernel<128, 2048>), dim3((unsigned)bsz), dim3(128), lds_for(2048), st, values, rewards,
                            advantages, returns, (int)seq, gamma, gamma_lambda);
     } else if (dev_variant_gaeseq() != 2) {

@@ -28,7 +28,6 @@ namespace rlx {
 namespace {
 
 constexpr int RT = 256;
-constexpr int TILE = RT * 4;
 
 __device__ __forceinline__ float kl_value(int kind, float lp, float ref) {  // kl_penalty(logprob, ref_logprob), utils.py:26-64
     const float diff = fsub(lp, ref);
@@ -53,10 +52,12 @@ __device__ __forceinline__ double wave_incl_scan_from_right(double v, int lane) 
     return v;
 }
 
-__global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ mask,
+template <int RTV>  // lanes per sequence; a tile is 4 RTV tokens
+__global__ __launch_bounds__(RTV) void reinpp_returns_kernel(const float* __restrict__ rewards, const uint8_t* __restrict__ mask,
                                                             const float* __restrict__ logprob, const float* __restrict__ ref,
                                                             int kl_kind, float kl_beta, float* __restrict__ ret,
                                                             double* __restrict__ partials, long long B, long long S, int aligned) {
+    constexpr int RT = RTV, TILE = RTV * 4;
     __shared__ long long s_first;
     __shared__ double s_wave[RT / RLX_WAVE];
     __shared__ double s_red[3][RT / RLX_WAVE];
@@ -99,10 +100,12 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
     };
     const bool ahead = n_tiles <= 2;
     Tile nxt = fetch(ahead ? n_tiles - 1 : 0);
+    const float reward = rewards[b];                       // requested with the tile: not one more round trip further down
+    const uint8_t mirror_first = mask[(B - 1 - b) * S];    // response masks start with True: then eos = S - 1, no search
     // ---- reward position (see the header): first True of the mirrored sequence's mask; none -> argmax's 0
-    if (tid == 0) s_first = S;
+    if (tid == 0) s_first = mirror_first ? 0 : S;
     __syncthreads();
-    {
+    if (!mirror_first) {  // (block-uniform)
         const uint8_t* mm = mask + (B - 1 - b) * S;
         long long first = S;
         if (aligned && S % 4 == 0) {  // four mask bytes per lane and load (bool bytes are 0 / 1: the lowest set bit names the byte)
@@ -121,10 +124,9 @@ __global__ __launch_bounds__(RT) void reinpp_returns_kernel(const float* __restr
             first = o < first ? o : first;
         }
         if (lane == 0 && first < S) atomicMin(&s_first, first);
+        __syncthreads();
     }
-    __syncthreads();
     const long long eos = S - 1 - (s_first == S ? 0 : s_first);
-    const float reward = rewards[b];
     double carry = 0.0;                // sum of r over everything to the right of the current tile
     double cnt = 0.0, sum = 0.0, sq = 0.0;
     for (long long tile = n_tiles - 1; tile >= 0; --tile) {
@@ -283,8 +285,21 @@ extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask
                            (kl_beta > 0.f ? (reinterpret_cast<uintptr_t>(logprob) | reinterpret_cast<uintptr_t>(ref_logprob)) : 0);
     // (A one-wave-per-row variant for rows of <= 2048 tokens -- no LDS, no barrier, 16 / 32 tokens per lane in registers -- was
     //  measured and dropped: 0.41 / 0.23 of the HBM peak at 32768 x 1024 / 16384 x 2048 against 0.51 / 0.57 for this kernel.)
-    hipLaunchKernelGGL(reinpp_returns_kernel, dim3((unsigned)bsz), dim3(RT), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
+    {
+        // lanes per sequence (a tile is 4 x lanes tokens), measured on three shapes (profiles/r02_reinpp_lanes_sweep.txt):
+        // rows of <= 2048 tokens want 64 lanes (0.65-0.66 of the HBM peak against 0.58-0.62 with 256: a row is 4-8 short tiles
+        // of one wave each, no cross-wave hand-off, and many rows share a CU), rows of >= 4096 tokens 256 lanes (0.69 against 0.63)
+        static const int forced = getenv("RLX_REINPP_RT") ? atoi(getenv("RLX_REINPP_RT")) : 0;  // development override
+        const int rtv = forced ? forced : (seq <= 2048 ? 64 : (seq < 4096 ? 128 : 256));
+        if (rtv == 64) hipLaunchKernelGGL(reinpp_returns_kernel<64>, dim3((unsigned)bsz), dim3(64), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
                        kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
+        else if (rtv == 128) hipLaunchKernelGGL(reinpp_returns_kernel<128>, dim3((unsigned)bsz), dim3(128), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
+                       kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
+        else if (rtv == 512) hipLaunchKernelGGL(reinpp_returns_kernel<512>, dim3((unsigned)bsz), dim3(512), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
+                       kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
+        else hipLaunchKernelGGL(reinpp_returns_kernel<256>, dim3((unsigned)bsz), dim3(256), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
+                       kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));
+    }
     RLX_LAUNCH_CHECK();
     const int n_groups = (int)std::min<long long>(MAX_GROUPS, (bsz + RT - 1) / RT);
     hipLaunchKernelGGL(reinpp_reduce_kernel, dim3(n_groups), dim3(RT), 0, st, partials, (long long)bsz, groups);

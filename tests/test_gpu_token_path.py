@@ -510,7 +510,7 @@ def test_reinpp_matches_reference_fixture():
         _reinpp_close(adv, case["advantages"], p["seq"], str(p))
 
 
-@pytest.mark.parametrize("seq", [1, 3, 64, 512, 1023, 1024, 1025, 1028, 2048, 4100])
+@pytest.mark.parametrize("seq", [1, 3, 64, 512, 1023, 1024, 1025, 1028, 2048, 3000, 4100])
 @pytest.mark.parametrize("kl,beta", [("", 0.0), ("kl", 0.02), ("abs", 0.1), ("mse", 0.1), ("low_var_kl", 0.001)])
 @pytest.mark.parametrize("masks", ["prefix", "ragged"])
 def test_reinpp_vs_oracle(seq, kl, beta, masks):
