@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     // d(loss)/d(logprob) back to its lanes.  Slot r of the metric partials is row r's element, exactly what wave 0's lane r
     // held in the general path: the butterfly sums -- and so the metrics -- are bit-identical between the two paths.
     double* sLacc = reinterpret_cast<double*>(Xb);  // [NS][64]; h3's slab is dead: the head gradients / dZ3 use registers + sHead
-    const bool fast = BM * n_out <= G::NT && (y == 0 ? BM * n_out <= 64 : (npr == 1 && S == 1 && 64 % n_out == 0));
+    const bool fast = a.merged_loss_pass && BM * n_out <= G::NT && (y == 0 ? BM * n_out <= 64 : (npr == 1 && S == 1 && 64 % n_out == 0));
     if (fast) {
         for (int i = tid; i < NS * 64; i += G::NT)
             if ((i & 63) >= (y == 0 ? BM * n_out : BM)) sLacc[i] = 0.0;  // the slots no element owns
