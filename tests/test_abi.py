@@ -116,3 +116,20 @@ def test_argument_validation_of_the_widening_entries(lib):
     assert b"proximal_mode" in lib.rlx_last_error()
     assert lib.rlx_reward_filter_mask(None, None, None, 4, 10, 1, 4, 0.0, 1.0, None) == -22
     assert lib.rlx_patch_workspace_bytes(1 << 20) > (1 << 20) // 8
+
+
+def test_split_k_slab_plan_by_precision(lib):
+    """rlx_ppo_step_slabs_for: the slab count `grads` must hold depends on the operand precision (f32: two workgroups per CU
+    in one round; bf16: fewer, larger slabs -- the launch is bound by slab bytes), never leaves a slab with fewer than 256
+    rows (a data-parallel rank's small minibatch), and the legacy entry is the f32 plan.  Pure host arithmetic: no GPU."""
+    from ctypes import byref
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    lay = MLPPolicy(42, 8, 1, True, False).layout
+    for m in (1, 5, 100, 256, 257, 1024, 2048, 4096, 8192, 65536):
+        f32, bf16 = lib.rlx_ppo_step_slabs_for(byref(lay), m, 0), lib.rlx_ppo_step_slabs_for(byref(lay), m, 1)
+        assert lib.rlx_ppo_step_slabs(byref(lay), m) == f32
+        assert 1 <= bf16 <= f32 <= max(1, -(-m // 256)), (m, f32, bf16)
+        rows = -(-m // f32)
+        rows = -(-rows // 32) * 32          # rows per slab are whole 32-row k-blocks ...
+        assert -(-m // rows) == f32, (m, f32)  # ... and every slab is non-empty: the launch writes each one
+    assert lib.rlx_ppo_step_slabs_for(byref(lay), 0, 1) == 1 and lib.rlx_ppo_step_slabs_for(None, 8192, 1) == 1
