@@ -16,7 +16,8 @@ Extra objects on that line:
                 launch stream at the scaled shape 65536 envs x 128 steps (the 1024 x 128 buffer is 2.2 MB and lives in
                 L2); algorithmic bytes = 17 B per env-step.
   roofline_widening  (N = 1) the kernels of the widening rows: token_logprob fwd / bwd at 4096 tokens x
-                151936 vocab (bf16 logits), gae_seq at 4096 x 8192, patch_scan over a 622 M-element bf16 tensor; same
+                151936 vocab (bf16 logits), gae_seq at 4096 x 8192, patch_scan over a 622 M-element bf16 tensor, reinpp at
+                4096 x 8192 and 32768 x 1024; same
                 HIP-event method.
   cpu_baseline  the CPU oracle (a port of the reference's torch-CPU path, oracle/ppo_loop.py) on this box's host
                 cores, on a bounded sample, N = 1 only.
@@ -274,6 +275,17 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     rows.append({"kernel": "reinpp_seq_adv (returns + reduce + normalize)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
                  "algorithmic_bytes": nb, "shape": "4096 sequences x 8192 tokens, k3 KL penalty"})
+    # the same bytes as short rows (one 64-lane workgroup per sequence, four tiles each): the shape round 1 was furthest off at
+    try:
+        r2 = torch.randn(32768, device=device, generator=g)
+        lp2, rlp2, msk2 = lp.view(32768, 1024), rlp.view(32768, 1024), msk.view(32768, 1024)
+        us = avg_us(lambda: _t.reinpp_seq_adv(r2, msk2, lp2, rlp2, 0.001, "low_var_kl"))
+        rows.append({"kernel": "reinpp_seq_adv (returns + reduce + normalize)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4),
+                     "avg_launch_us": round(us, 1), "algorithmic_bytes": nb, "shape": "32768 sequences x 1024 tokens, k3 KL penalty"})
+        del lp2, rlp2, msk2
+    except Exception as e:  # noqa: BLE001 -- an extra row must never cost the others
+        rows.append({"kernel": "reinpp_seq_adv", "shape": "32768 sequences x 1024 tokens", "error": f"{type(e).__name__}: {e}"[:200]})
     del lp, rlp, msk
     # bucket weight sync: 16 f32 masters of 4096 x 8192 -> one flat bf16 transport buffer (6 B per element, one launch)
     from rlinf_amd.hybrid_engines.weight_syncer.bucket_syncer import BucketPacker
