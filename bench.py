@@ -19,8 +19,8 @@ Extra objects on that line:
                 151936 vocab (bf16 logits), gae_seq at 4096 x 8192, patch_scan over a 622 M-element bf16 tensor, reinpp at
                 4096 x 8192 and 32768 x 1024; same
                 HIP-event method.
-  cpu_baseline  the CPU oracle (a port of the reference's torch-CPU path, oracle/ppo_loop.py) on this box's host
-                cores, on a bounded sample, N = 1 only.
+  cpu_baseline  the reference's own functions (staged under oracle/_ref; kind "reference") -- or, where those files are
+                absent, the CPU oracle (kind "port") -- on this box's host cores, on a bounded sample, N = 1 only.
 """
 
 from __future__ import annotations
