@@ -27,9 +27,11 @@ class XgmiAllReduce:
     def __init__(self, ctx, n_max: int, timeout_ms: Optional[int] = None, mem_kind: int = 0):
         # The wait bound is a safety net against a peer that died, not a performance knob: ranks reach their first all-reduce
         # seconds apart (lazy code-object loading on a fresh box -- measured: > 5 s between two ranks sharing one GPU), so the
-        # default is generous; a wait that does expire sets the status word and run_training raises.
+        # default is generous -- but bounded so that a node where the peers' flags never become visible costs the start-up
+        # validation (two memory kinds) about a minute before it falls back to RCCL, not several; a wait that does expire sets
+        # the status word and run_training raises.
         if timeout_ms is None:
-            timeout_ms = int(os.environ.get("RLX_XGMI_TIMEOUT_MS", "120000"))
+            timeout_ms = int(os.environ.get("RLX_XGMI_TIMEOUT_MS", "30000"))
         if ctx.world_size > XGMI_MAX_RANKS:
             raise RlxError(f"xGMI all-reduce is for one node (<= {XGMI_MAX_RANKS} ranks), world_size={ctx.world_size}")
         if ctx.device is None or ctx.device.type != "cuda":
