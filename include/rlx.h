@@ -715,15 +715,26 @@ int rlx_rollout_metrics(const float* const* arrays, const int64_t* sizes, int co
  * e  data-parallel gradient all-reduce over xGMI  <- FSDP NO_SHARD gradient synchronisation,
  *      rlinf/hybrid_engines/fsdp/strategy/fsdp.py:480-496 (sync_grad / no_sync around backward), the averaged gradient that
  *      FSDPModelManager.optimizer_step then clips and applies (fsdp_model_manager.py:429-463).
- * One process per GPU.  Every rank owns a fine-grained device buffer (two staging slots of n_max floats + a flag per rank),
- * exported with hipIpcGetMemHandle and mapped by every peer.  An all-reduce is two launches, no host involvement, no
- * RCCL call -- so the whole optimizer step stays one hipGraph-capturable kernel chain:
- *   stage   sum this rank's split-K gradient slabs into its staging slot (seq + 1) & 1
- *   reduce  publish "slot complete" to every peer's flag array, wait for every peer's flag, then read all W staged
- *           gradients over xGMI and add them IN RANK ORDER (every rank forms bit-identical sums), scale by grad_scale,
- *           write the reduced gradient locally with the squared-norm partials the AdamW launch needs.
+ * One process per GPU.  Every rank owns a fine-grained device buffer (two staging slots of n_max floats, two reduced-shard areas,
+ * norm partials and two flag sets), exported with hipIpcGetMemHandle and mapped by every peer.  An all-reduce is a short chain of
+ * launches with no host involvement and no RCCL call -- so the whole optimizer step stays one hipGraph-capturable kernel chain.
+ * Two forms (rlx_xgmi_configure `algo`; the default is direct for world <= 3, rs + ag from 4 ranks on):
+ *   direct   stage    sum this rank's split-K gradient slabs into its staging slot (seq + 1) & 1
+ *            reduce   publish "slot complete" to every peer's flag array, wait for every peer's flag, then read all W staged
+ *                     gradients over xGMI and add them IN RANK ORDER (every rank forms bit-identical sums), scale by grad_scale,
+ *                     write the reduced gradient locally with the squared-norm partials the AdamW launch needs
+ *            clip + AdamW                                                        [n floats per link, one hand-shake]
+ *   rs + ag  stage    as above
+ *            reduce-scatter   hand-shake 0, then rank r reads shard r of every rank's staged gradient, adds in rank order,
+ *                     scales, writes the shard + its norm partials into its own exported shard area
+ *            gather + clip + AdamW   hand-shake 1, then every rank reads shard q and its norm partials from rank q inside the
+ *                     AdamW launch (same reduction tree on every rank -> the same norm and bit-identical parameters)
+ *                                                                                [2 n / W floats per link, two hand-shakes]
+ * The hand-shake runs inside the consuming launch (wait_mode 0: every block polls) or as a one-wave launch of its own in front
+ * of it (wait_mode 1: ranks that share a device must not hold it with a device-wide spin).
  * The sequence number lives on the device and is advanced by the launch that consumes the result (graph replay needs no
- * host bookkeeping).  A wait that exceeds timeout_ms sets the status word (rlx_xgmi_status) instead of hanging the GPU.
+ * host bookkeeping).  A wait that exceeds timeout_ms sets the status word (rlx_xgmi_status) instead of hanging the GPU, and the
+ * AdamW launch of such an all-reduce SKIPS its update (stats[1] = 0): garbage sums are never applied.
  * 1.15 MB x 7 peers at ~50 GB/s per xGMI link is ~25 us of wire time; RCCL's ring needs 2 (W - 1) latency-bound steps.
  * ------------------------------------------------------------------------------------------ */
 #define RLX_XGMI_MAX_RANKS 8
@@ -734,6 +745,12 @@ typedef struct rlx_xgmi_comm rlx_xgmi_comm;
  * (world x RLX_XGMI_HANDLE_BYTES, own slot ignored).  mem_kind: 0 fine-grained (default), 1 uncached, 2 plain hipMalloc. */
 int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_ms, int mem_kind, rlx_xgmi_comm** comm, void* handle_out);
 int rlx_xgmi_connect(rlx_xgmi_comm* comm, const void* all_handles);
+/* Same-process emulation of a W-rank group (tests: every "rank" on its own stream of ONE device, no IPC): wires W
+ * communicators created with rank 0 .. W-1 to each other's buffers directly. */
+int rlx_xgmi_connect_local(rlx_xgmi_comm* const* comms, int world);
+/* algo: 0 direct, 1 reduce-scatter + all-gather; wait_mode: 0 inline, 1 own launch; timeout_ms > 0: new bound of every peer
+ * wait.  -1 (0 for the timeout) keeps the current value.  Every rank of a group must configure the same algo. */
+int rlx_xgmi_configure(rlx_xgmi_comm* comm, int algo, int wait_mode, int timeout_ms);
 int rlx_xgmi_destroy(rlx_xgmi_comm* comm);
 /* 0 = ok, 1 = a peer wait timed out since the last call (cleared by the call; synchronises the stream's device first). */
 int rlx_xgmi_status(rlx_xgmi_comm* comm);

@@ -39,29 +39,37 @@ def synthetic_env_tensors(seed: int, T: int, B: int, obs_dim: int = 42, max_epis
 
 
 def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: float, auto_reset: bool = True, autocast: bool = False):
-    """-> batch dict in the reference's buffer shapes ([T,...] / [T+1,...] with C = 1).  ``autocast``: the policy forwards run
-    under bf16 autocast (`precision: bf16`), everything else stays f32."""
-    T, B = env["rewards"].shape
-    A = policy.action_dim * policy.num_action_chunks
+    """-> batch dict in the reference's buffer shapes ([n, B, ...] / [n + 1, B, ...], n chunk steps of C = num_action_chunks env
+    steps each).  ``env`` is indexed by ENV step; a chunk step (ManiSkill's chunk_step, maniskill_env.py:327-372) plays C of
+    them: rewards side by side [B, C], the done flag of every env that finished anywhere inside the chunk raised in the LAST
+    column, auto-reset -- and therefore the bootstrap value of the true final observation (env_worker.py:718-758: first value
+    column, added to the last reward column) -- at the chunk's end only.  ``autocast``: the policy forwards run under bf16
+    autocast (`precision: bf16`), everything else stays f32."""
+    C = policy.num_action_chunks
+    T_env, B = env["rewards"].shape
+    assert T_env % C == 0
+    T = T_env // C
+    A = policy.action_dim * C
     states = torch.empty(T, B, policy.obs_dim)
     action = torch.empty(T, B, A)
     logp = torch.empty(T, B, A)
-    values = torch.empty(T + 1, B, 1)
-    rewards = torch.empty(T, B, 1)
-    dones = torch.zeros(T + 1, B, 1, dtype=torch.bool)
+    values = torch.empty(T + 1, B, C)
+    rewards = torch.empty(T, B, C)
+    dones = torch.zeros(T + 1, B, C, dtype=torch.bool)
     obs = env["obs"][0]
     for t in range(T):
         with O.amp(autocast):
             a, lp, v = policy.act(obs, eps=eps[t], mode="train")
         states[t], action[t], logp[t], values[t] = obs, a, lp, v
-        r = env["rewards"][t].clone().unsqueeze(-1)
-        d = env["dones"][t + 1].unsqueeze(-1)
+        r = env["rewards"][t * C:(t + 1) * C].transpose(0, 1).clone()           # [B, C]
+        d = torch.zeros(B, C, dtype=torch.bool)
+        d[:, -1] = env["dones"][t * C + 1:(t + 1) * C + 1].any(dim=0)
         if auto_reset and bool(d.any()):
             with O.amp(autocast):
-                vf = policy.value_head.mlp(env["final_obs"][t]).detach()[:, :1].float()
+                vf = policy.value_head.mlp(env["final_obs"][(t + 1) * C - 1]).detach()[:, :1].float()
             r = O.bootstrap_rewards(r, d, vf, gamma)
         rewards[t], dones[t + 1] = r, d
-        obs = env["obs"][t + 1]
+        obs = env["obs"][(t + 1) * C]
     with O.amp(autocast):
         values[T] = policy.value_head.mlp(obs).detach()
     return dict(rewards=rewards, dones=dones, prev_values=values, prev_logprobs=logp,
@@ -86,15 +94,20 @@ def rollout_epochs(policy, env: dict, eps: torch.Tensor, gamma: float, rollout_e
     return O.fold_rollout_epochs(stacked, rollout_epoch)
 
 
-def advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = True):
+def advantages(batch: dict, gamma: float, gae_lambda: float, auto_reset: bool = True, adv_type: str = "gae",
+               reward_type: str = "action_level", group_size: int = 1):
     lm = lms = None
     if not auto_reset:  # embodied_fsdp_actor_worker.py:219-233
         lm, lms = O.loss_mask_from_dones(batch["dones"])
-    out = O.embodied_adv_and_returns(adv_type="gae", rewards=batch["rewards"], dones=batch["dones"],
-                                     values=batch["prev_values"], gamma=gamma, gae_lambda=gae_lambda, loss_mask=lm,
-                                     loss_mask_sum=lms)
+        if reward_type == "chunk_level":  # :228-230
+            lm, lms = lm.any(dim=-1, keepdim=True), lms[..., -1:]
+    out = O.embodied_adv_and_returns(adv_type=adv_type, rewards=batch["rewards"], dones=batch["dones"],
+                                     values=batch["prev_values"] if adv_type == "gae" else None, gamma=gamma, gae_lambda=gae_lambda,
+                                     loss_mask=lm, loss_mask_sum=lms, reward_type=reward_type, group_size=group_size)
     batch = dict(batch)
-    batch.update(advantages=out["advantages"].contiguous(), returns=out["returns"].contiguous())
+    batch.update(advantages=out["advantages"].contiguous())
+    if "returns" in out:
+        batch.update(returns=out["returns"].contiguous())
     if lm is not None:
         batch.update(loss_mask=lm.contiguous(), loss_mask_sum=lms.contiguous())
     return batch
@@ -135,7 +148,8 @@ def pipeline_permutation(T: int, B: int, stage_num: int, generator: torch.Genera
 def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epoch: int, clip_low=0.2, clip_high=0.2,
            value_clip=1.0, huber_delta=10.0, clip_grad=0.5, max_steps: int | None = None, entropy_bonus: float = 0.0,
            perm: torch.Tensor | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
-           autocast: bool = False, entropy_type: str = "action_level", flat: dict | None = None):
+           autocast: bool = False, entropy_type: str = "action_level", flat: dict | None = None,
+           logprob_type: str = "action_level", reward_type: str = "action_level", loss_type: str = "actor_critic"):
     """``flat``: already flattened + shuffled rows (the pipeline learner with rollout_epoch > 1 concatenates per-epoch
     shuffles); otherwise ``batch`` is flattened with ``perm`` (default: the seeded randperm of run_training)."""
     if flat is None:
@@ -152,11 +166,12 @@ def update(policy, opt, batch: dict, *, seed: int, global_batch: int, update_epo
             m = O.ppo_minibatch_step(
                 policy, opt, dict(states=mb["forward_inputs"]["states"], action=mb["forward_inputs"]["action"],
                                   prev_logprobs=mb["prev_logprobs"], advantages=mb["advantages"],
-                                  prev_values=mb["prev_values"], returns=mb["returns"], loss_mask=mb.get("loss_mask"),
+                                  prev_values=mb["prev_values"], returns=mb.get("returns"), loss_mask=mb.get("loss_mask"),
                                   loss_mask_sum=mb.get("loss_mask_sum")),
                 clip_low=clip_low, clip_high=clip_high, value_clip=value_clip, huber_delta=huber_delta,
                 clip_grad=clip_grad, action_dim=policy.action_dim, entropy_bonus=entropy_bonus, max_episode_steps=max_episode_steps,
-                autocast=autocast, entropy_type=entropy_type, critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
+                autocast=autocast, entropy_type=entropy_type, logprob_type=logprob_type, reward_type=reward_type, loss_type=loss_type,
+                critic_warmup=(steps_done + steps) < critic_warmup_steps)  # optimizer_steps < critic_warmup_steps (:664)
             metrics.append(m)
             steps += 1
             if critic_warmup_steps > 0 and steps_done + steps == critic_warmup_steps:
@@ -221,7 +236,8 @@ def async_update(policy, opt, batch: dict, *, seed: int, global_batch: int, micr
 def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, update_epoch, auto_reset=True,
               max_update_steps=None, timings=None, rollout_epoch: int = 1, entropy_bonus: float = 0.0,
               pipeline: dict | None = None, critic_warmup_steps: int = 0, steps_done: int = 0, max_episode_steps=None,
-              autocast: bool = False, entropy_type: str = "action_level"):
+              autocast: bool = False, entropy_type: str = "action_level", adv_type: str = "gae", loss_type: str = "actor_critic",
+              reward_type: str = "action_level", logprob_type: str = "action_level", group_size: int = 1):
     """``pipeline`` = dict(stage_num=..., generator=<the rank's stateful shuffle generator>) selects
     runner.use_training_pipeline's data path: global-statistics normalisation, per-stage shuffles, and -- every
     micro-batch being available at once here -- the epoch-major schedule PipelineEmbodiedFSDPActor.run_training reduces
@@ -254,7 +270,7 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     t1 = time.perf_counter()
     perm = None
     if pipeline is None:
-        batch = advantages(batch, gamma, gae_lambda, auto_reset)
+        batch = advantages(batch, gamma, gae_lambda, auto_reset, adv_type=adv_type, reward_type=reward_type, group_size=group_size)
     else:
         batch = pipeline_advantages(batch, gamma, gae_lambda, auto_reset)
         T_, B_ = batch["prev_logprobs"].shape[:2]
@@ -263,7 +279,8 @@ def iteration(policy, opt, env, eps, *, gamma, gae_lambda, seed, global_batch, u
     metrics = update(policy, opt, batch, seed=seed, global_batch=global_batch, update_epoch=update_epoch,
                      max_steps=max_update_steps, entropy_bonus=entropy_bonus, perm=perm,
                      critic_warmup_steps=critic_warmup_steps, steps_done=steps_done, max_episode_steps=max_episode_steps,
-                     autocast=autocast, entropy_type=entropy_type)
+                     autocast=autocast, entropy_type=entropy_type, logprob_type=logprob_type, reward_type=reward_type,
+                     loss_type=loss_type)
     t3 = time.perf_counter()
     if timings is not None:
         timings.update(rollout=t1 - t0, advantages=t2 - t1, update=t3 - t2, update_steps=len(metrics))

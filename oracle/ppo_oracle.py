@@ -472,8 +472,9 @@ def reshape_entropy(entropy, entropy_type: str, action_dim: int, batch_size: int
 def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, value_clip=1.0,
                        huber_delta=10.0, entropy_bonus=0.0, clip_grad=0.5, action_dim=8,
                        logprob_type="action_level", critic_warmup=False, max_episode_steps=None, autocast=False,
-                       entropy_type="action_level"):
-    """forward -> actor_critic loss -> backward -> clip_grad_norm_ -> AdamW (skipped if norm non-finite).
+                       entropy_type="action_level", reward_type="action_level", loss_type="actor_critic"):
+    """forward -> actor_critic (or, loss_type "actor": value-free PPO / GRPO) loss -> backward -> clip_grad_norm_ -> AdamW
+    (skipped if norm non-finite).
     ``loss_mask_sum`` + ``max_episode_steps`` (both present when auto_reset is off) switch the aggregation to
     masked_mean_ratio, as train_micro_batch's loss_kwargs do (embodied_fsdp_actor_worker.py:641-662, losses.py:219-227)."""
     opt.zero_grad()
@@ -481,12 +482,19 @@ def ppo_minibatch_step(policy, opt, mb: dict, *, clip_low=0.2, clip_high=0.2, va
         out = policy.evaluate(mb["states"], mb["action"])
     if autocast:  # the loss asserts f32 inputs (losses.py:232-240); log-probs come out f32 by type promotion, values are cast
         out = {k: v.float() for k, v in out.items()}
+    critic = loss_type == "actor_critic"
     shaped = shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type,
                                action_dim, loss_mask=mb.get("loss_mask"), loss_mask_sum=mb.get("loss_mask_sum"),
-                               values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
-    loss, metrics = ppo_actor_critic_loss(clip_ratio_low=clip_low, clip_ratio_high=clip_high, critic_warmup=critic_warmup,
-                                          value_clip=value_clip, huber_delta=huber_delta, max_episode_steps=max_episode_steps,
-                                          **shaped)
+                               values=out["values"] if critic else None, prev_values=mb["prev_values"] if critic else None,
+                               returns=mb.get("returns") if critic else None, reward_type=reward_type)
+    if critic:
+        loss, metrics = ppo_actor_critic_loss(clip_ratio_low=clip_low, clip_ratio_high=clip_high, critic_warmup=critic_warmup,
+                                              value_clip=value_clip, huber_delta=huber_delta, max_episode_steps=max_episode_steps,
+                                              **shaped)
+    else:  # registry name "actor" (losses.py:170-312 alone): the value head gets no gradient, i.e. no update (grad None)
+        loss, metrics = ppo_actor_loss(shaped["logprobs"], shaped["old_logprobs"], shaped["advantages"], clip_low, clip_high,
+                                       loss_mask=shaped["loss_mask"], max_episode_steps=max_episode_steps,
+                                       loss_mask_sum=shaped["loss_mask_sum"])
     if entropy_bonus > 0 and not critic_warmup:  # embodied_fsdp_actor_worker.py:680
         ent = reshape_entropy(out["entropy"], entropy_type, action_dim, out["logprobs"].shape[0])
         ent_loss = masked_mean(ent, shaped["loss_mask"])

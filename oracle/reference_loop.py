@@ -91,9 +91,10 @@ def optimizer_step(ref, pol, opt, mb: dict, clip_grad: float = 0.5):
 
 
 def timed_iteration(env: dict, *, obs_dim: int, act_dim: int, gamma: float, gae_lambda: float, global_batch: int,
-                    update_epoch: int, warmup_steps: int = 3, timed_steps: int = 10):
-    """-> phase timings of one iteration: the rollout and the advantage pass in full, the update phase as the MEDIAN of
-    ``timed_steps`` optimizer steps after ``warmup_steps`` untimed ones (every minibatch step does identical work)."""
+                    update_epoch: int, warmup_steps: int = 3, timed_steps: int | None = 10, update_budget_s: float = 15.0):
+    """-> phase timings of one iteration: the rollout and the advantage pass in full, then ``warmup_steps`` untimed optimizer
+    steps and ``timed_steps`` timed ones (None: every step of the update phase -- n_mb x update_epoch -- as long as the running
+    total stays under ``update_budget_s``; every minibatch step does identical work, so a truncated run extrapolates)."""
     ref, pol, opt = build(obs_dim, act_dim)
     t0 = time.perf_counter()
     batch = rollout(ref, pol, env, gamma)
@@ -103,14 +104,22 @@ def timed_iteration(env: dict, *, obs_dim: int, act_dim: int, gamma: float, gae_
     flat = flatten_and_shuffle(batch, 1234)
     n = flat["states"].shape[0]
     n_mb = n // global_batch
-    steps = []
-    for k in range(warmup_steps + timed_steps):
+    total = n_mb * update_epoch
+    want = total if timed_steps is None else timed_steps
+    steps, spent = [], 0.0
+    for k in range(warmup_steps + want):
         lo = (k % n_mb) * global_batch
         mb = {key: v[lo:lo + global_batch] for key, v in flat.items()}
         s0 = time.perf_counter()
         optimizer_step(ref, pol, opt, mb)
-        steps.append(time.perf_counter() - s0)
-    timed = sorted(steps[warmup_steps:])
-    median = timed[len(timed) // 2]
-    return dict(rollout_s=t1 - t0, advantages_s=t2 - t1, update_s_per_step=median, update_steps_total=n_mb * update_epoch,
-                warmup_steps=warmup_steps, timed_steps=timed_steps, step_times_s=[round(x, 4) for x in steps])
+        dt = time.perf_counter() - s0
+        steps.append(dt)
+        if k >= warmup_steps:
+            spent += dt
+            if timed_steps is None and spent > update_budget_s and k + 1 - warmup_steps >= 10:
+                break
+    timed = steps[warmup_steps:]
+    median = sorted(timed)[len(timed) // 2]
+    return dict(rollout_s=t1 - t0, advantages_s=t2 - t1, update_s_per_step=median, update_steps_total=total,
+                warmup_steps=warmup_steps, timed_steps=len(timed), step_times_s=[round(x, 4) for x in steps],
+                timed_step_times_s=timed)

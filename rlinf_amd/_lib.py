@@ -226,6 +226,8 @@ PROTOTYPES = {
                                     c_void_p]),
     "rlx_xgmi_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, POINTER(c_void_p), c_void_p]),
     "rlx_xgmi_connect": (c_int, [c_void_p, c_void_p]),
+    "rlx_xgmi_connect_local": (c_int, [POINTER(c_void_p), c_int]),
+    "rlx_xgmi_configure": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rlx_xgmi_destroy": (c_int, [c_void_p]),
     "rlx_xgmi_status": (c_int, [c_void_p]),
     "rlx_xgmi_allreduce_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_void_p]),

@@ -248,7 +248,34 @@ def validate_embodied_cfg(cfg):
         "env.train.max_steps_per_rollout_epoch must be divisible by actor.model.num_action_chunks")
     cfg.runner.weight_sync_interval = cfg.runner.get("weight_sync_interval", 1)
     assert cfg.runner.weight_sync_interval > 0, "weight_sync_interval must be greater than 0"
+    validate_mlp_kernel_shapes(model_cfg)
     return cfg
+
+
+# Shape limits of the HIP kernels behind ``mlp_policy`` (this build's own check -- the reference's torch modules take any
+# width): the rollout launch and the fused optimizer step keep a row tile's activations in ONE LDS slab of 256 columns and the
+# first layer's weight tiles zero-padded to 64 inputs (csrc/ppo_step_common.h: HID = 256, Tiles::K1P = 64), and the head's
+# outputs in 16 accumulator columns (MAX_OUT = 16).  All of the reference's MLP configurations fit (obs_dim <= 42, act 8).
+MLP_KERNEL_LIMITS = {"hidden_dim": 256, "obs_dim_max": 64, "action_outputs_max": 16}
+
+
+def validate_mlp_kernel_shapes(model_cfg) -> None:
+    """Reject, with the limit named, a policy shape the kernels cannot take -- at configuration time instead of as an error
+    string from the first launch."""
+    lim = MLP_KERNEL_LIMITS
+    hidden = model_cfg.get("hidden_dim", lim["hidden_dim"])
+    assert int(hidden) == lim["hidden_dim"], (
+        f"actor.model.hidden_dim={hidden}: the MI355X kernels of mlp_policy are built for the reference's hidden width "
+        f"{lim['hidden_dim']} (3 x 256 tanh layers); other widths are not served by this build")
+    obs = int(model_cfg.obs_dim)
+    assert 1 <= obs <= lim["obs_dim_max"], (
+        f"actor.model.obs_dim={obs}: the fused rollout / optimizer-step kernels take 1 <= obs_dim <= {lim['obs_dim_max']} "
+        f"(first-layer weight tiles are padded to {lim['obs_dim_max']} inputs)")
+    chunks = int(model_cfg.get("num_action_chunks", 1))
+    outs = int(model_cfg.action_dim) * chunks
+    assert 1 <= outs <= lim["action_outputs_max"], (
+        f"actor.model.action_dim * num_action_chunks = {model_cfg.action_dim} * {chunks} = {outs}: the fused kernels take at most "
+        f"{lim['action_outputs_max']} head outputs per policy step")
 
 
 def validate_cfg(cfg) -> DictConfig:

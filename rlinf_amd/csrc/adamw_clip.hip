@@ -26,24 +26,45 @@ using namespace opt;
 __device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step, AdamScalars* sc);
 
 // publish + wait (see opt_common.h, PeerWait).  Called by every block: thread r < world handles rank r.
+__device__ __forceinline__ void peer_poll(const PeerWait& w, int r, unsigned s, int sleep) {
+    const unsigned* flag = w.flags_mine + w.phase * kMaxRanks + r;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - s) < 0) {
+        if (wall_clock64() - t0 > w.timeout_ticks) {
+            *w.status = 1;
+            break;
+        }
+        if (sleep > 64) __builtin_amdgcn_s_sleep(127);
+        else __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 __device__ __forceinline__ void peer_handshake(const PeerWait& w) {
-    if (w.world <= 1) return;
+    if (w.world <= 1) {
+        if (w.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // the wait was the previous launch; this is its acquire
+        return;
+    }
     const unsigned s = *w.seq + 1u;
     if ((int)threadIdx.x < w.world) {
         const int r = threadIdx.x;
-        if (blockIdx.x == 0)  // this rank's staged gradient s is complete (the staging launch ended before this one began)
-            __hip_atomic_store(w.flags_peer[r] + w.rank, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(w.flags_mine + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - s) < 0) {
-            if (wall_clock64() - t0 > w.timeout_ticks) {
-                *w.status = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
+        if (blockIdx.x == 0)  // this rank's buffer s is complete (the launch that wrote it ended before this one began)
+            __hip_atomic_store(w.flags_peer[r] + w.phase * kMaxRanks + w.rank, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        peer_poll(w, r, s, 8);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: nothing of the peers' buffers may be served from a stale line
+}
+
+// The same hand-shake as a launch of its own: one wave, thread r handles rank r, ~5 us between polls.  The launch behind it
+// starts when every peer has published; nothing else of this rank occupies the device while it waits -- which is what lets
+// ranks that SHARE a device (the one-GPU test set-up, an oversubscribed node) make progress instead of starving each other.
+__global__ __launch_bounds__(64) void peer_wait_kernel(PeerWait w) {
+    const unsigned s = *w.seq + 1u;
+    if ((int)threadIdx.x < w.world) {
+        const int r = threadIdx.x;
+        __hip_atomic_store(w.flags_peer[r] + w.phase * kMaxRanks + w.rank, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        peer_poll(w, r, s, 127);
+    }
 }
 
 template <bool ADAM>
@@ -101,6 +122,60 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
     }
     block_sum<1>(acc, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// Reduce-scatter half of the RS + AG all-reduce: this rank sums ITS shard (float4 elements [lo4, lo4 + n4)) of every rank's
+// staged gradient -- W peer reads of n / W floats each instead of n -- scales it, writes it to its own fine-grained shard area
+// (read by every peer in the gather) and leaves one squared-norm partial per block next to it.
+__global__ __launch_bounds__(256) void reduce_scatter_kernel(ReduceSrc src, float* __restrict__ shard0, long long shard_stride,
+                                                             double* __restrict__ parts0, int nparts, long long lo4, long long n4,
+                                                             float scale, int* __restrict__ state, PeerWait wait) {
+    __shared__ double s_red[4];
+    if (state != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && state[1] != 0) {
+        state[0] += 1;  // the previous optimizer call applied its step: folded in strictly before this call's AdamW launch
+        state[1] = 0;
+    }
+    peer_handshake(wait);
+    const unsigned slot = (*src.seq + 1u) & 1u;
+    const size_t off = (size_t)slot * (size_t)src.slot_stride;
+    float* __restrict__ shard_out = shard0 + (size_t)slot * (size_t)shard_stride;
+    double* __restrict__ parts_out = parts0 + (size_t)slot * (size_t)nparts;
+    const int nbase = src.nbase;
+    double acc[1] = {0.0};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 x[kMaxRanks];
+#pragma unroll
+        for (int b = 0; b < kMaxRanks; ++b)
+            if (b < nbase) x[b] = reinterpret_cast<const float4*>(src.base[b] + off)[lo4 + i];
+        float4 g = x[0];
+#pragma unroll
+        for (int b = 1; b < kMaxRanks; ++b)
+            if (b < nbase) { g.x += x[b].x; g.y += x[b].y; g.z += x[b].z; g.w += x[b].w; }
+        g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
+        reinterpret_cast<float4*>(shard_out)[i] = g;
+        acc[0] += (double)g.x * (double)g.x + (double)g.y * (double)g.y + (double)g.z * (double)g.z + (double)g.w * (double)g.w;
+    }
+    block_sum<1>(acc, s_red);
+    if (threadIdx.x == 0) parts_out[blockIdx.x] = acc[0];
+}
+
+__device__ __forceinline__ float4 gather_f4(const GatherSrc& src, size_t off, long long i) {
+    const int owner = (int)(i / src.shard4);
+    const float* base = src.shard[0];
+#pragma unroll
+    for (int r = 1; r < kMaxRanks; ++r)
+        if (r == owner) base = src.shard[r];  // scalar selects: an indexed read of the argument block would be a vector load
+    return reinterpret_cast<const float4*>(base + off)[i - (long long)owner * src.shard4];
+}
+
+// All-gather half on its own (validation / the plain all-reduce entry point): out = every rank's reduced shard, in place order.
+__global__ __launch_bounds__(256) void gather_kernel(GatherSrc src, float* __restrict__ out, long long n4, PeerWait wait) {
+    peer_handshake(wait);
+    const size_t off = (size_t)((*src.seq + 1u) & 1u) * (size_t)src.slot_stride;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4*>(out)[i] = gather_f4(src, off, i);
 }
 
 // Fragment-tile weight image (ppo_step.hip, struct Tiles) kept in step with the flat parameters: the optimizer writes
@@ -195,16 +270,25 @@ __device__ __forceinline__ void adamw_elem(float& pi, float& gi, float& mi, floa
 
 // One float4 of parameters per thread (p, g, m, v: four 16-byte loads in flight per lane); the (<= 1024) norm partials are
 // re-reduced by every block (a device-wide "last block" finalisation would serialise one memory-side atomic per block).
+// GATHER (the RS + AG all-reduce): the reduced gradient and its norm partials are read from every rank's shard area (peer reads
+// over xGMI behind the phase-1 hand-shake) instead of from `g` / `partials`; `g` still receives the clipped gradient.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, rlx_adamw_params a,
                                                          const double* __restrict__ partials, int nparts,
                                                          const AdamScalars* __restrict__ scalars,
                                                          float* __restrict__ stats, int* __restrict__ state,
-                                                         rlx_mlp_layout lay, float* __restrict__ tiles, unsigned* __restrict__ seq_inc) {
+                                                         rlx_mlp_layout lay, float* __restrict__ tiles, unsigned* __restrict__ seq_inc,
+                                                         const int* __restrict__ status, GatherSrc gsrc, PeerWait wait) {
     __shared__ double s_red[4];
     __shared__ float s_coef;
     __shared__ int s_skip;
     __shared__ AdamScalars s_sc;
+    size_t goff = 0;
+    if constexpr (GATHER) {
+        peer_handshake(wait);
+        goff = (size_t)((*gsrc.seq + 1u) & 1u) * (size_t)gsrc.slot_stride;
+    }
     // issue this thread's loads before the norm is known: they do not depend on it
     const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                                        reinterpret_cast<uintptr_t>(v)) % 16 == 0);
@@ -214,13 +298,30 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
     float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
     if (i0 < n4) {
         p4 = reinterpret_cast<const float4*>(p)[i0];
-        g4 = reinterpret_cast<const float4*>(g)[i0];
+        if constexpr (GATHER) g4 = gather_f4(gsrc, goff, i0);
+        else g4 = reinterpret_cast<const float4*>(g)[i0];
         m4 = reinterpret_cast<const float4*>(m)[i0];
         v4 = reinterpret_cast<const float4*>(v)[i0];
     }
     // the norm partials (<= kMaxParts = 4 x 256): all of a lane's loads in flight together, added in ascending order
     double acc[1] = {0.0};
-    {
+    if constexpr (GATHER) {  // world x nparts partials, rank-major: the same tree on every rank -> the same norm on every rank
+        const int total = gsrc.world * gsrc.nparts;
+        const size_t poff = (size_t)((*gsrc.seq + 1u) & 1u) * (size_t)gsrc.nparts;
+        double pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = min((int)threadIdx.x + u * 256, total - 1), owner = idx / gsrc.nparts;
+            const double* base = gsrc.parts[0];
+#pragma unroll
+            for (int r = 1; r < kMaxRanks; ++r)
+                if (r == owner) base = gsrc.parts[r];
+            pv[u] = base[poff + (idx - owner * gsrc.nparts)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((int)threadIdx.x + u * 256 < total) acc[0] += pv[u];
+    } else {
         double pv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) pv[u] = partials[min((int)threadIdx.x + u * 256, nparts - 1)];
@@ -238,7 +339,8 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         float coef = 1.f;
         if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
         s_coef = coef;
-        s_skip = !isfinite(total_norm);
+        // a peer wait of this step's all-reduce timed out: the sums are garbage -- never apply them (the host raises)
+        s_skip = !isfinite(total_norm) || (status != nullptr && *status != 0);
         if (blockIdx.x == 0) {
             stats[0] = total_norm;
             stats[1] = s_skip ? 0.f : 1.f;
@@ -255,7 +357,8 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         const bool live = i < n4;
         if (live && i != i0) {
             p4 = reinterpret_cast<const float4*>(p)[i];
-            g4 = reinterpret_cast<const float4*>(g)[i];
+            if constexpr (GATHER) g4 = gather_f4(gsrc, goff, i);
+            else g4 = reinterpret_cast<const float4*>(g)[i];
             m4 = reinterpret_cast<const float4*>(m)[i];
             v4 = reinterpret_cast<const float4*>(v)[i];
         }
@@ -333,21 +436,39 @@ int grid_for(long long n) {  // one float4 per thread up to kMaxParts blocks, gr
     return (int)std::max<long long>(1, std::min<long long>((n / 4 + 255) / 256 + 1, (long long)kMaxParts));
 }
 
-int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
-                             const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace, size_t workspace_bytes,
-                             const PeerWait* wait, unsigned* seq_inc, hipStream_t s) {
+namespace {
+int check_adamw_args(float* params, float* out, float* exp_avg, float* exp_avg_sq, int64_t n, const rlx_adamw_params* p, float* stats,
+                     int32_t* step_state, rlx_mlp_layout& lay, float*& tiles) {
     RLX_REQUIRE(p != nullptr, "rlx_clip_adamw_step: NULL params struct");
     RLX_REQUIRE(n >= 0 && (p->step >= 1 || step_state != nullptr) && p->n_groups >= 0 && p->n_groups <= RLX_ADAMW_MAX_GROUPS,
                 "rlx_clip_adamw_step: bad sizes (n=%lld step=%d groups=%d)", (long long)n, p->step, p->n_groups);
+    RLX_REQUIRE(params && out && exp_avg && exp_avg_sq && stats, "rlx_clip_adamw_step: NULL argument");
+    for (int k = 0; k < p->n_groups; ++k)
+        RLX_REQUIRE(p->groups[k].begin >= 0 && p->groups[k].end <= n && p->groups[k].begin <= p->groups[k].end,
+                    "rlx_clip_adamw_step: group %d range out of bounds", k);
+    tiles = nullptr;
+    if (p->tile_layout != nullptr && p->tiles != nullptr) {
+        lay = *p->tile_layout;
+        tiles = p->tiles;
+        RLX_REQUIRE(lay.hidden == 256 && lay.obs_dim >= 1 && lay.obs_dim <= 64 && lay.n_params == n,
+                    "rlx_clip_adamw_step: tile_layout does not describe these %lld parameters", (long long)n);
+    }
+    return RLX_OK;
+}
+}  // namespace
+
+int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace, size_t workspace_bytes,
+                             const PeerWait* wait, unsigned* seq_inc, const int* status, hipStream_t s) {
     if (n == 0) return RLX_OK;
-    RLX_REQUIRE(params && out && exp_avg && exp_avg_sq && stats && workspace, "rlx_clip_adamw_step: NULL argument");
+    rlx_mlp_layout lay{};
+    float* tiles = nullptr;
+    if (int rc = check_adamw_args(params, out, exp_avg, exp_avg_sq, n, p, stats, step_state, lay, tiles)) return rc;
+    RLX_REQUIRE(workspace != nullptr, "rlx_clip_adamw_step: NULL workspace");
     if (workspace_bytes < rlx_adamw_workspace_bytes(n)) {
         set_error("rlx_clip_adamw_step: workspace too small");
         return RLX_ENOSPC;
     }
-    for (int k = 0; k < p->n_groups; ++k)
-        RLX_REQUIRE(p->groups[k].begin >= 0 && p->groups[k].end <= n && p->groups[k].begin <= p->groups[k].end,
-                    "rlx_clip_adamw_step: group %d range out of bounds", k);
     double* partials = static_cast<double*>(workspace);
     const int nblk = grid_for(n);
     AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + scalars_offset());
@@ -356,17 +477,61 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
     hipLaunchKernelGGL(grad_reduce_sqnorm<true>, dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
                        step_state, *p, scalars, w);
     RLX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
+                       partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc, status, GatherSrc{}, PeerWait{});
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int launch_peer_wait(const PeerWait& wait, hipStream_t s) {
+    hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, s, wait);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int rsag_parts(long long shard_n4) {
+    return (int)std::max<long long>(1, std::min<long long>((shard_n4 + 255) / 256, (long long)(kMaxParts / kMaxRanks)));
+}
+
+int launch_reduce_scatter(const ReduceSrc& src, float* shard0, long long shard_stride, double* parts0, long long shard_lo4,
+                          long long shard_n4, int nparts, float scale, int32_t* step_state, const PeerWait* wait, hipStream_t s) {
+    PeerWait w{};
+    if (wait != nullptr) w = *wait;
+    hipLaunchKernelGGL(reduce_scatter_kernel, dim3(nparts), dim3(256), 0, s, src, shard0, shard_stride, parts0, nparts, shard_lo4,
+                       shard_n4, scale, step_state, w);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int launch_gather_clip_adamw(float* params, const GatherSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             const rlx_adamw_params* p, float* stats, int32_t* step_state, const PeerWait* wait, unsigned* seq_inc,
+                             const int* status, hipStream_t s) {
+    if (n == 0) return RLX_OK;
     rlx_mlp_layout lay{};
     float* tiles = nullptr;
-    if (p->tile_layout != nullptr && p->tiles != nullptr) {
-        lay = *p->tile_layout;
-        tiles = p->tiles;
-        RLX_REQUIRE(lay.hidden == 256 && lay.obs_dim >= 1 && lay.obs_dim <= 64 && lay.n_params == n,
-                    "rlx_clip_adamw_step: tile_layout does not describe these %lld parameters", (long long)n);
-    }
-    hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
-                       partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc);
+    if (int rc = check_adamw_args(params, out, exp_avg, exp_avg_sq, n, p, stats, step_state, lay, tiles)) return rc;
+    RLX_REQUIRE(n % 4 == 0 && src.world >= 2 && src.world * src.nparts <= kMaxParts, "gather clip_adamw: n %% 4 != 0 or bad shard plan");
+    RLX_REQUIRE((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(exp_avg) |
+                 reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 == 0, "gather clip_adamw: buffers must be 16-byte aligned");
+    PeerWait w{};
+    if (wait != nullptr) w = *wait;
+    hipLaunchKernelGGL(clip_adamw_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
+                       (const double*)nullptr, 0, (const AdamScalars*)nullptr, stats, step_state, lay, tiles, seq_inc, status, src, w);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+int launch_gather_only(const GatherSrc& src, float* out, int64_t n, const PeerWait* wait, unsigned* seq_inc, hipStream_t s) {
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(out != nullptr && n % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0, "gather: NULL / unaligned output");
+    PeerWait w{};
+    if (wait != nullptr) w = *wait;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, out, (long long)(n / 4), w);
+    RLX_LAUNCH_CHECK();
+    if (seq_inc != nullptr) {
+        hipLaunchKernelGGL(seq_inc_kernel, dim3(1), dim3(1), 0, s, seq_inc);
+        RLX_LAUNCH_CHECK();
+    }
     return RLX_OK;
 }
 
@@ -417,5 +582,5 @@ extern "C" int rlx_clip_adamw_step(float* params, float* grads, float* exp_avg, 
     src.nbase = 1;
     src.nslab = p->grad_partials;
     return launch_reduce_clip_adamw(params, src, grads, exp_avg, exp_avg_sq, n, p, stats, step_state, workspace, workspace_bytes,
-                                    nullptr, nullptr, static_cast<hipStream_t>(stream));
+                                    nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }

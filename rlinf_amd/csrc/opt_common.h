@@ -47,15 +47,32 @@ __device__ __forceinline__ float4 sum_slabs_f4(const float4* __restrict__ gp, lo
 }
 #endif
 
-// Cross-GPU hand-shake in front of a peer read (xgmi_allreduce.hip): publish "my staged gradient number s is complete" to
-// every peer's flag array, then wait until every peer has published s.  world == 0: single GPU, nothing to wait for.
+// Cross-GPU hand-shake in front of a peer read (xgmi_allreduce.hip): publish "my buffer number s of phase p is complete" to
+// every peer's flag array, then wait until every peer has published s.  world == 0: nothing to wait for (single GPU, or the
+// wait ran as its own one-wave launch in front of this one: `fence` then asks for the acquire that goes with it).
+// Flag layout of a rank's buffer: flags[phase][kMaxRanks] u32; phase 0 = "staged gradient complete", phase 1 = "reduced shard
+// complete" (the reduce-scatter + all-gather form).
 struct PeerWait {
-    unsigned* flags_mine;             // [world], fine-grained LOCAL memory, slot r written remotely by rank r
+    unsigned* flags_mine;             // [phases][kMaxRanks], fine-grained LOCAL memory, slot r written remotely by rank r
     unsigned* flags_peer[kMaxRanks];  // peer r's flag array (mapped over IPC); this rank writes slot [rank]
     const unsigned* seq;              // local: number of all-reduces completed so far (this one is seq + 1)
-    int* status;                      // local: set to 1 when a wait timed out (results are then garbage; the host raises)
+    int* status;                      // local: set to 1 when a wait timed out (the AdamW launch then skips; the host raises)
     long long timeout_ticks;          // wall_clock64 ticks (100 MHz)
     int rank, world;
+    int phase;                        // which flag set
+    int fence;                        // world == 0 only: system-scope acquire at kernel start (the wait was a launch of its own)
+};
+
+// Reduce-scatter + all-gather form: where the AdamW launch finds the reduced gradient -- shard r (float4 elements
+// [r * shard4, (r + 1) * shard4)) lives in rank r's buffer, next to the squared-norm partials of that shard.
+struct GatherSrc {
+    const float* shard[kMaxRanks];    // rank r's reduced-shard area, slot 0
+    const double* parts[kMaxRanks];   // rank r's norm partials, slot 0 (nparts doubles per slot)
+    long long shard4;                 // float4 elements per shard
+    long long slot_stride;            // floats between slot 0 and slot 1 of the shard area
+    int nparts;                       // partials per rank
+    int world;                        // 0: not used (the gradient is local)
+    const unsigned* seq;
 };
 
 // Per-step scalars of the update, formed ONCE per step in double like torch's python scalars -- bias corrections from
@@ -71,13 +88,30 @@ inline size_t scalars_offset() { return (size_t)kMaxParts * sizeof(double); }
 int grid_for(long long n);
 
 // grad_reduce_sqnorm + clip_adamw on `stream`.  out: reduced (scaled) gradient; wait: peer hand-shake or nullptr;
-// seq_inc: device word incremented by the AdamW launch (the all-reduce sequence number), or nullptr.
+// seq_inc: device word incremented by the AdamW launch (the all-reduce sequence number), or nullptr; status: device word that
+// makes the AdamW launch skip its update when set (a peer wait timed out: the sums are garbage), or nullptr.
 int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
                              const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace, size_t workspace_bytes,
-                             const PeerWait* wait, unsigned* seq_inc, hipStream_t stream);
+                             const PeerWait* wait, unsigned* seq_inc, const int* status, hipStream_t stream);
 // the reduce alone (validation / plain all-reduce): out = scale * sum; no optimizer state touched
 int launch_reduce_only(const ReduceSrc& src, float* out, int64_t n, float scale, void* workspace, size_t workspace_bytes,
                        const PeerWait* wait, unsigned* seq_inc, hipStream_t stream);
+// publish + wait as a launch of its own: ONE wave, long sleeps between polls (ranks that share a device, or any set-up where a
+// device-wide spin must not hold the GPU)
+int launch_peer_wait(const PeerWait& wait, hipStream_t stream);
+// reduce-scatter: this rank's shard of the sum of every rank's staged gradient -> its shard area + norm partials
+// (shard0 / parts0: slot 0 of the areas; the kernel picks the slot from the device-side sequence number)
+int launch_reduce_scatter(const ReduceSrc& src, float* shard0, long long shard_stride, double* parts0, long long shard_lo4,
+                          long long shard_n4, int nparts, float scale, int32_t* step_state, const PeerWait* wait,
+                          hipStream_t stream);
+// clip + AdamW with the reduced gradient gathered from every rank's shard area (all-gather fused into the update); `out`
+// receives the clipped gradient like the local form
+int launch_gather_clip_adamw(float* params, const GatherSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             const rlx_adamw_params* p, float* stats, int32_t* step_state, const PeerWait* wait, unsigned* seq_inc,
+                             const int* status, hipStream_t stream);
+// plain gather (validation / plain all-reduce): out = the reduced gradient, no optimizer state touched
+int launch_gather_only(const GatherSrc& src, float* out, int64_t n, const PeerWait* wait, unsigned* seq_inc, hipStream_t stream);
+int rsag_parts(long long shard_n4);  // blocks (= norm partials) of the reduce-scatter launch for a shard of this many float4
 
 }  // namespace opt
 }  // namespace rlx

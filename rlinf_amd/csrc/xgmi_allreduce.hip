@@ -12,8 +12,18 @@
 // stale L2 line; the flags are system-scope atomics.  Layout of a rank's buffer: [flags: kMaxRanks x u32, padded to 4 KiB]
 // [slot 0: n_max f32][slot 1: n_max f32].  Two slots suffice: a rank can only reach the staging launch of all-reduce s + 2
 // after every peer has published s + 1, i.e. after every peer finished reading slot s.
+//
+// Two forms of the exchange (rlx_xgmi_configure, `algo`):
+//   direct  every rank reads all W staged gradients in full (n floats per link, ONE hand-shake)        -- W = 2, 3
+//   rs + ag reduce-scatter: rank r sums shard r of every rank's staged gradient into its shard area;
+//           all-gather fused into the AdamW launch, which reads shard q from rank q
+//           (2 n / W floats per link, TWO hand-shakes; the norm partials travel with the shards)        -- W >= 4
+// and two forms of the hand-shake (`wait_mode`): inline in the consuming launch (every block polls: lowest latency, one GPU per
+// rank) or as a one-wave launch of its own in front of it (ranks sharing a device: a device-wide spin would starve the peer).
 
 #include <string.h>
+
+#include <algorithm>
 
 #include "opt_common.h"
 
@@ -21,11 +31,13 @@ struct rlx_xgmi_comm {
     int rank, world;
     int64_t n_max;
     long long timeout_ticks;
+    int algo;                              // 0 direct, 1 reduce-scatter + all-gather
+    int wait_mode;                         // 0 inline, 1 own launch
     char* base_local;                      // own buffer
     char* base_peer[RLX_XGMI_MAX_RANKS];   // mapped peers (own slot = base_local)
     unsigned* seq;                         // device word (plain memory): all-reduces completed
     int* status;                           // device word: timeout flag
-    bool connected;
+    bool connected, local_peers;           // local_peers: same-process emulation, nothing to unmap
 };
 
 namespace rlx {
@@ -33,10 +45,17 @@ namespace {
 
 using namespace opt;
 
-constexpr size_t kFlagBytes = 4096;
+constexpr size_t kFlagBytes = 4096;                      // flags[2 phases][kMaxRanks] u32, padded
+constexpr int kPartsPerRank = kMaxParts / kMaxRanks;     // norm partials a rank publishes with its shard
 
+// [flags][slot 0][slot 1][shard 0][shard 1][parts 0][parts 1]
+inline size_t buffer_bytes(int64_t n_max) { return kFlagBytes + 4 * (size_t)n_max * sizeof(float) + 2 * kPartsPerRank * sizeof(double); }
 inline float* slot_ptr(char* base, int64_t n_max, int slot) {
     return reinterpret_cast<float*>(base + kFlagBytes) + (size_t)slot * (size_t)n_max;
+}
+inline float* shard_ptr(char* base, int64_t n_max) { return reinterpret_cast<float*>(base + kFlagBytes) + 2 * (size_t)n_max; }
+inline double* parts_ptr(char* base, int64_t n_max) {
+    return reinterpret_cast<double*>(base + kFlagBytes + 4 * (size_t)n_max * sizeof(float));
 }
 
 // stage: dst = sum of this rank's slabs, into slot (seq + 1) & 1 of the local buffer
@@ -65,7 +84,7 @@ int check(const rlx_xgmi_comm* c, int64_t n, const char* who) {
     return RLX_OK;
 }
 
-void fill_wait(const rlx_xgmi_comm* c, PeerWait& w) {
+void fill_wait(const rlx_xgmi_comm* c, PeerWait& w, int phase) {
     w.flags_mine = reinterpret_cast<unsigned*>(c->base_local);
     for (int r = 0; r < c->world; ++r) w.flags_peer[r] = reinterpret_cast<unsigned*>(c->base_peer[r]);
     w.seq = c->seq;
@@ -73,6 +92,73 @@ void fill_wait(const rlx_xgmi_comm* c, PeerWait& w) {
     w.timeout_ticks = c->timeout_ticks;
     w.rank = c->rank;
     w.world = c->world;
+    w.phase = phase;
+    w.fence = 0;
+}
+
+// The hand-shake of `phase` in front of the next launch: inline (returns the PeerWait that launch executes itself) or as its own
+// one-wave launch (the next launch then only fences).
+int handshake(const rlx_xgmi_comm* c, int phase, PeerWait& for_next, hipStream_t st) {
+    fill_wait(c, for_next, phase);
+    if (c->world <= 1) { for_next.world = 0; return RLX_OK; }
+    if (c->wait_mode == 1) {
+        if (int rc = launch_peer_wait(for_next, st)) return rc;
+        for_next.world = 0;
+        for_next.fence = 1;
+    }
+    return RLX_OK;
+}
+
+void fill_reduce_src(const rlx_xgmi_comm* c, ReduceSrc& src) {
+    src.nbase = c->world;
+    src.nslab = 1;
+    for (int r = 0; r < c->world; ++r) src.base[r] = slot_ptr(c->base_peer[r], c->n_max, 0);
+    src.slot_stride = c->n_max;
+    src.seq = c->seq;
+}
+
+struct ShardPlan { long long shard4, lo4, cnt4; int nparts; };
+
+// rs + ag needs whole float4 and at least one float4 per rank; the plan depends on (n, world) only, so every rank agrees
+bool use_rsag(const rlx_xgmi_comm* c, int64_t n) { return c->algo == 1 && c->world >= 2 && n % 4 == 0 && n / 4 >= c->world; }
+
+ShardPlan plan_shards(const rlx_xgmi_comm* c, int64_t n) {
+    ShardPlan p{};
+    const long long n4 = n / 4;
+    p.shard4 = (n4 + c->world - 1) / c->world;
+    p.lo4 = (long long)c->rank * p.shard4;
+    p.cnt4 = std::max<long long>(0, std::min<long long>(p.shard4, n4 - p.lo4));
+    p.nparts = rsag_parts(p.shard4);
+    return p;
+}
+
+void fill_gather_src(const rlx_xgmi_comm* c, const ShardPlan& p, GatherSrc& g) {
+    for (int r = 0; r < c->world; ++r) {
+        g.shard[r] = shard_ptr(c->base_peer[r], c->n_max);
+        g.parts[r] = parts_ptr(c->base_peer[r], c->n_max);
+    }
+    g.shard4 = p.shard4;
+    g.slot_stride = c->n_max;
+    g.nparts = p.nparts;
+    g.world = c->world;
+    g.seq = c->seq;
+}
+
+int stage(const rlx_xgmi_comm* c, const float* in, int slabs, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(xgmi_stage_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, (long long)n, slabs,
+                       slot_ptr(c->base_local, c->n_max, 0), (long long)c->n_max, c->seq);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+void release(rlx_xgmi_comm* c) {
+    if (c == nullptr) return;
+    if (!c->local_peers)
+        for (int r = 0; r < c->world; ++r)
+            if (r != c->rank && c->base_peer[r] != nullptr) (void)hipIpcCloseMemHandle(c->base_peer[r]);
+    if (c->base_local) (void)hipFree(c->base_local);
+    if (c->seq) (void)hipFree(c->seq);
+    delete c;
 }
 
 }  // namespace
@@ -89,34 +175,35 @@ extern "C" int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_m
     RLX_REQUIRE(n_max >= 1, "rlx_xgmi_create: n_max=%lld", (long long)n_max);
     static_assert(sizeof(hipIpcMemHandle_t) == RLX_XGMI_HANDLE_BYTES, "handle size");
     n_max = (n_max + 3) / 4 * 4;
-    rlx_xgmi_comm* c = new rlx_xgmi_comm();
+    rlx_xgmi_comm* c = new rlx_xgmi_comm();  // value-initialised: every pointer NULL, so release() is safe at any point below
     c->rank = rank; c->world = world; c->n_max = n_max;
-    c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 120000) * 100000ll;  // wall_clock64: 100 MHz
-    const size_t bytes = kFlagBytes + 2 * (size_t)n_max * sizeof(float);
-    void* p = nullptr;
+    c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 300000) * 100000ll;  // wall_clock64: 100 MHz
+    c->algo = world >= 4 ? 1 : 0;
+    const size_t bytes = buffer_bytes(n_max);
+    void *p = nullptr, *words = nullptr;
     hipError_t e = mem_kind == 2 ? hipMalloc(&p, bytes)
                                  : hipExtMallocWithFlags(&p, bytes, mem_kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
-    if (e != hipSuccess) {
-        set_error("rlx_xgmi_create: allocating %zu bytes (mem_kind %d) failed: %s", bytes, mem_kind, hipGetErrorString(e));
-        delete c;
-        return RLX_EHIP;
+    const char* what = "allocating the exchange buffer";
+    if (e == hipSuccess) {
+        c->base_local = static_cast<char*>(p);
+        c->base_peer[rank] = c->base_local;
+        what = "hipMemset";
+        e = hipMemset(p, 0, bytes);
     }
-    c->base_local = static_cast<char*>(p);
-    c->base_peer[rank] = c->base_local;
-    RLX_HIP_CHECK(hipMemset(p, 0, bytes));
-    void* words = nullptr;
-    RLX_HIP_CHECK(hipMalloc(&words, 256));
-    RLX_HIP_CHECK(hipMemset(words, 0, 256));
-    c->seq = static_cast<unsigned*>(words);
-    c->status = reinterpret_cast<int*>(static_cast<char*>(words) + 128);
-    RLX_HIP_CHECK(hipDeviceSynchronize());
+    if (e == hipSuccess) { what = "hipMalloc (sequence / status words)"; e = hipMalloc(&words, 256); }
+    if (e == hipSuccess) {
+        c->seq = static_cast<unsigned*>(words);
+        c->status = reinterpret_cast<int*>(static_cast<char*>(words) + 128);
+        what = "hipMemset";
+        e = hipMemset(words, 0, 256);
+    }
+    if (e == hipSuccess) { what = "hipDeviceSynchronize"; e = hipDeviceSynchronize(); }
     hipIpcMemHandle_t h;
-    e = hipIpcGetMemHandle(&h, p);
-    if (e != hipSuccess) {
-        set_error("rlx_xgmi_create: hipIpcGetMemHandle failed (mem_kind %d): %s", mem_kind, hipGetErrorString(e));
-        (void)hipFree(p);
-        (void)hipFree(words);
-        delete c;
+    memset(&h, 0, sizeof(h));
+    if (e == hipSuccess && world > 1) { what = "hipIpcGetMemHandle"; e = hipIpcGetMemHandle(&h, p); }
+    if (e != hipSuccess) {  // one cleanup path for every failure above
+        set_error("rlx_xgmi_create: %s failed (%zu bytes, mem_kind %d): %s", what, bytes, mem_kind, hipGetErrorString(e));
+        release(c);
         return RLX_EHIP;
     }
     memcpy(handle_out, &h, sizeof(h));
@@ -127,6 +214,7 @@ extern "C" int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_m
 
 extern "C" int rlx_xgmi_connect(rlx_xgmi_comm* c, const void* all_handles) {
     RLX_REQUIRE(c != nullptr && all_handles != nullptr, "rlx_xgmi_connect: NULL argument");
+    RLX_REQUIRE(!c->connected || c->world == 1, "rlx_xgmi_connect: already connected");
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank) continue;
         hipIpcMemHandle_t h;
@@ -135,6 +223,11 @@ extern "C" int rlx_xgmi_connect(rlx_xgmi_comm* c, const void* all_handles) {
         hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
             set_error("rlx_xgmi_connect: hipIpcOpenMemHandle(rank %d) failed: %s", r, hipGetErrorString(e));
+            for (int q = 0; q < r; ++q)  // unmap what was mapped so far: a failed connect leaves nothing behind
+                if (q != c->rank && c->base_peer[q] != nullptr) {
+                    (void)hipIpcCloseMemHandle(c->base_peer[q]);
+                    c->base_peer[q] = nullptr;
+                }
             return RLX_EHIP;
         }
         c->base_peer[r] = static_cast<char*>(p);
@@ -143,14 +236,32 @@ extern "C" int rlx_xgmi_connect(rlx_xgmi_comm* c, const void* all_handles) {
     return RLX_OK;
 }
 
+extern "C" int rlx_xgmi_connect_local(rlx_xgmi_comm* const* comms, int world) {
+    RLX_REQUIRE(comms != nullptr && world >= 1 && world <= RLX_XGMI_MAX_RANKS, "rlx_xgmi_connect_local: bad arguments");
+    for (int r = 0; r < world; ++r)
+        RLX_REQUIRE(comms[r] != nullptr && comms[r]->world == world && comms[r]->rank == r && comms[r]->n_max == comms[0]->n_max,
+                    "rlx_xgmi_connect_local: communicator %d does not belong to this group", r);
+    for (int r = 0; r < world; ++r) {
+        for (int q = 0; q < world; ++q) comms[r]->base_peer[q] = comms[q]->base_local;
+        comms[r]->connected = true;
+        comms[r]->local_peers = true;
+    }
+    return RLX_OK;
+}
+
+extern "C" int rlx_xgmi_configure(rlx_xgmi_comm* c, int algo, int wait_mode, int timeout_ms) {
+    RLX_REQUIRE(c != nullptr, "rlx_xgmi_configure: NULL communicator");
+    RLX_REQUIRE(algo >= -1 && algo <= 1 && wait_mode >= -1 && wait_mode <= 1, "rlx_xgmi_configure: algo %d / wait_mode %d", algo, wait_mode);
+    if (algo >= 0) c->algo = algo;
+    if (wait_mode >= 0) c->wait_mode = wait_mode;
+    if (timeout_ms > 0) c->timeout_ticks = (long long)timeout_ms * 100000ll;
+    return RLX_OK;
+}
+
 extern "C" int rlx_xgmi_destroy(rlx_xgmi_comm* c) {
     if (c == nullptr) return RLX_OK;
     (void)hipDeviceSynchronize();
-    for (int r = 0; r < c->world; ++r)
-        if (r != c->rank && c->base_peer[r] != nullptr) (void)hipIpcCloseMemHandle(c->base_peer[r]);
-    if (c->base_local) (void)hipFree(c->base_local);
-    if (c->seq) (void)hipFree(c->seq);
-    delete c;
+    release(c);
     return RLX_OK;
 }
 
@@ -168,18 +279,21 @@ extern "C" int rlx_xgmi_allreduce_f32(rlx_xgmi_comm* c, const float* in, int sla
     if (n == 0) return RLX_OK;
     RLX_REQUIRE(in && out && slabs >= 1, "rlx_xgmi_allreduce_f32: NULL argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(xgmi_stage_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, (long long)n, slabs,
-                       slot_ptr(c->base_local, c->n_max, 0), (long long)c->n_max, c->seq);
-    RLX_LAUNCH_CHECK();
+    if (int rc = stage(c, in, slabs, n, st)) return rc;
     ReduceSrc src{};
-    src.nbase = c->world;
-    src.nslab = 1;
-    for (int r = 0; r < c->world; ++r) src.base[r] = slot_ptr(c->base_peer[r], c->n_max, 0);
-    src.slot_stride = c->n_max;
-    src.seq = c->seq;
+    fill_reduce_src(c, src);
     PeerWait w{};
-    fill_wait(c, w);
-    return launch_reduce_only(src, out, n, scale, workspace, workspace_bytes, &w, c->seq, st);
+    if (int rc = handshake(c, 0, w, st)) return rc;
+    if (!use_rsag(c, n)) return launch_reduce_only(src, out, n, scale, workspace, workspace_bytes, &w, c->seq, st);
+    const ShardPlan p = plan_shards(c, n);
+    if (int rc = launch_reduce_scatter(src, shard_ptr(c->base_local, c->n_max), c->n_max, parts_ptr(c->base_local, c->n_max), p.lo4,
+                                       p.cnt4, p.nparts, scale, nullptr, &w, st))
+        return rc;
+    GatherSrc g{};
+    fill_gather_src(c, p, g);
+    PeerWait w1{};
+    if (int rc = handshake(c, 1, w1, st)) return rc;
+    return launch_gather_only(g, out, n, &w1, c->seq, st);
 }
 
 extern "C" int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* c, float* params, const float* grads, float* grad_flat, float* exp_avg,
@@ -189,17 +303,21 @@ extern "C" int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* c, float* params, const f
     RLX_REQUIRE(p != nullptr && p->grad_partials >= 1 && grads && grad_flat, "rlx_xgmi_clip_adamw_step: NULL argument");
     if (n == 0) return RLX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(xgmi_stage_kernel, dim3(grid_for(n)), dim3(256), 0, st, grads, (long long)n, p->grad_partials,
-                       slot_ptr(c->base_local, c->n_max, 0), (long long)c->n_max, c->seq);
-    RLX_LAUNCH_CHECK();
+    if (int rc = stage(c, grads, p->grad_partials, n, st)) return rc;
     ReduceSrc src{};
-    src.nbase = c->world;
-    src.nslab = 1;
-    for (int r = 0; r < c->world; ++r) src.base[r] = slot_ptr(c->base_peer[r], c->n_max, 0);
-    src.slot_stride = c->n_max;
-    src.seq = c->seq;
+    fill_reduce_src(c, src);
     PeerWait w{};
-    fill_wait(c, w);
-    return launch_reduce_clip_adamw(params, src, grad_flat, exp_avg, exp_avg_sq, n, p, stats, step_state, workspace, workspace_bytes,
-                                    &w, c->seq, st);
+    if (int rc = handshake(c, 0, w, st)) return rc;
+    if (!use_rsag(c, n))
+        return launch_reduce_clip_adamw(params, src, grad_flat, exp_avg, exp_avg_sq, n, p, stats, step_state, workspace, workspace_bytes,
+                                        &w, c->seq, c->status, st);
+    const ShardPlan sp = plan_shards(c, n);
+    if (int rc = launch_reduce_scatter(src, shard_ptr(c->base_local, c->n_max), c->n_max, parts_ptr(c->base_local, c->n_max), sp.lo4,
+                                       sp.cnt4, sp.nparts, p->grad_scale, step_state, &w, st))
+        return rc;
+    GatherSrc g{};
+    fill_gather_src(c, sp, g);
+    PeerWait w1{};
+    if (int rc = handshake(c, 1, w1, st)) return rc;
+    return launch_gather_clip_adamw(params, g, grad_flat, exp_avg, exp_avg_sq, n, p, stats, step_state, &w1, c->seq, c->status, st);
 }

@@ -34,25 +34,36 @@ def generate_tensors(seed: int, num_steps: int, num_envs: int, obs_dim: int = 42
 
 
 class SyntheticManiSkillEnv:
+    """``tensors`` are indexed by ENV step; a chunk step consumes ``num_action_chunks`` of them (maniskill_env.py:327-372): the
+    rewards of its C sub-steps side by side, terminations / truncations raised in the LAST column for every env that finished
+    anywhere inside the chunk, the observation after the chunk, and -- with auto_reset -- the true observation the chunk ended
+    on as ``final_obs``.  The per-chunk views are laid out once at construction, so a chunk step is pure indexing."""
+
     def __init__(self, tensors: dict, device, num_action_chunks: int = 1, auto_reset: bool = True,
                  env_slice: Optional[slice] = None, done_is_truncation: bool = True):
         sl = env_slice if env_slice is not None else slice(None)
-        self.obs = tensors["obs"][:, sl].to(device).contiguous()
-        self.final_obs = tensors["final_obs"][:, sl].to(device).contiguous()
-        self.rewards = tensors["rewards"][:, sl].to(device).contiguous()
-        self.dones = tensors["dones"][:, sl].to(device).contiguous()
-        self.C = int(num_action_chunks)
-        assert self.C == 1, "the synthetic env steps one action per chunk step"
+        C = self.C = int(num_action_chunks)
+        obs, final_obs = tensors["obs"][:, sl], tensors["final_obs"][:, sl]
+        rewards, dones = tensors["rewards"][:, sl], tensors["dones"][:, sl]
+        n_env_steps = rewards.shape[0]
+        assert n_env_steps % C == 0, "the pre-generated horizon must hold whole action chunks"
+        Tc, B = n_env_steps // C, rewards.shape[1]
+        self.obs = obs[::C].to(device).contiguous()                         # [Tc + 1, B, D]: before chunk t / after chunk t - 1
+        self.final_obs = final_obs[C - 1::C].to(device).contiguous()       # [Tc, B, D]
+        self.rewards = rewards.reshape(Tc, C, B).transpose(1, 2).to(device).contiguous()     # [Tc, B, C]
+        flags = torch.zeros(Tc, B, C, dtype=torch.bool)
+        flags[:, :, -1] = dones[1:].reshape(Tc, C, B).any(dim=1)            # past_dones -> last column (:359-371)
+        self.flags = flags.to(device).contiguous()
         self.auto_reset = auto_reset
         self.done_is_truncation = done_is_truncation
-        self.num_steps = self.rewards.shape[0]
-        self.num_envs = self.obs.shape[1]
+        self.num_steps = Tc
+        self.num_envs = B
         self.t = 0
-        self._false = torch.zeros(self.num_envs, 1, dtype=torch.bool, device=device)
+        self._false = torch.zeros(B, C, dtype=torch.bool, device=device)
 
     def reset(self, start_step: int = 0):
-        """``start_step``: where in the pre-generated horizon this episode batch begins (rollout epoch e of T steps
-        starts at e * T, so that every epoch sees fresh transitions)."""
+        """``start_step`` (in CHUNK steps): where in the pre-generated horizon this episode batch begins (rollout epoch e of T
+        chunk steps starts at e * T, so that every epoch sees fresh transitions)."""
         self.t = int(start_step)
         return {"states": self.obs[self.t]}, {}
 
@@ -60,8 +71,8 @@ class SyntheticManiSkillEnv:
         """-> (obs dict, rewards [B,C], terminations [B,C], truncations [B,C], infos)."""
         t = self.t
         assert t < self.num_steps, "rollout longer than the pre-generated horizon"
-        done = self.dones[t + 1].unsqueeze(-1)
+        done = self.flags[t]
         trunc, term = (done, self._false) if self.done_is_truncation else (self._false, done)
         infos = {"final_obs": {"states": self.final_obs[t]}} if self.auto_reset else {}
         self.t += 1
-        return {"states": self.obs[t + 1]}, self.rewards[t].unsqueeze(-1), term, trunc, infos
+        return {"states": self.obs[t + 1]}, self.rewards[t], term, trunc, infos

@@ -78,6 +78,20 @@ class EmbodiedRunner:
         self.actor.load_checkpoint(actor_checkpoint_path).wait()
         self.global_step = int(resume_dir.split("global_step_")[-1])
 
+    def close(self):
+        """Tear the runner down: its workers leave the process-local peer registry (a later runner must not adopt them) and
+        the actor's xGMI communicator is destroyed (its exported buffers are unmapped by the peers' own close)."""
+        from ..workers.common import clear_peers
+        clear_peers(self.actor, self.rollout, self.env)
+        w = getattr(self.actor, "worker", self.actor)
+        xg = getattr(w, "_xgmi", None)
+        if xg is not None:
+            if getattr(w, "device", None) is not None and w.device.type == "cuda":
+                torch.cuda.synchronize(w.device)
+            w._graph = None
+            xg.close()
+            w._xgmi = None
+
     def update_rollout_weights(self):
         rollout_handle = self.rollout.sync_model_from_actor()
         actor_handle = self.actor.sync_model_to_rollout()

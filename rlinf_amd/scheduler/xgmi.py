@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import socket
 from typing import Optional
 
 import torch
@@ -24,31 +25,77 @@ from ..ops import _stream_ptr
 
 
 class XgmiAllReduce:
+    """One rank's end of the exchange.  Construction is COLLECTIVE-SAFE: whatever fails locally (allocation, IPC export, a bad
+    device), every rank still takes part in the one all_gather_object of the handles and derives the same verdict from the
+    gathered list -- a rank never sits in a collective its peers have skipped."""
+
     def __init__(self, ctx, n_max: int, timeout_ms: Optional[int] = None, mem_kind: int = 0):
-        # The wait bound is a safety net against a peer that died, not a performance knob: ranks reach their first all-reduce
-        # seconds apart (lazy code-object loading on a fresh box -- measured: > 5 s between two ranks sharing one GPU), so the
-        # default is generous -- but bounded so that a node where the peers' flags never become visible costs the start-up
-        # validation (two memory kinds) about a minute before it falls back to RCCL, not several; a wait that does expire sets
-        # the status word and run_training raises.
+        # The wait bound is a safety net against a peer that died, not a performance knob: ranks reach an all-reduce seconds
+        # apart (lazy code-object loading on a fresh box, a slow checkpoint write on one rank), so the default is minutes, like
+        # a collective library's.  An expired wait sets the status word; the AdamW launch of that all-reduce skips its update
+        # and run_training raises.  (Start-up validation runs with its own short bound, see _attempt.)
         if timeout_ms is None:
-            timeout_ms = int(os.environ.get("RLX_XGMI_TIMEOUT_MS", "30000"))
-        if ctx.world_size > XGMI_MAX_RANKS:
-            raise RlxError(f"xGMI all-reduce is for one node (<= {XGMI_MAX_RANKS} ranks), world_size={ctx.world_size}")
-        if ctx.device is None or ctx.device.type != "cuda":
-            raise RlxError("xGMI all-reduce needs device tensors")
+            timeout_ms = int(os.environ.get("RLX_XGMI_TIMEOUT_MS", "300000"))
         self.ctx, self.n_max = ctx, int(n_max)
         self._lib = _lib.load()
         self._comm = ctypes.c_void_p()
+        self.algo = "direct"
+        self.wait_mode = "inline"
         handle = (ctypes.c_char * XGMI_HANDLE_BYTES)()
-        with torch.cuda.device(ctx.device):
-            _lib.check(self._lib.rlx_xgmi_create(ctx.rank, ctx.world_size, self.n_max, int(timeout_ms), int(mem_kind),
-                                                 ctypes.byref(self._comm), handle), "rlx_xgmi_create")
-            if ctx.world_size > 1:
-                handles = [None] * ctx.world_size
-                dist.all_gather_object(handles, bytes(handle))
-                blob = b"".join(handles)
-                _lib.check(self._lib.rlx_xgmi_connect(self._comm, blob), "rlx_xgmi_connect")
+        err = None
+        try:  # local part: may fail on some ranks only
+            if ctx.world_size > XGMI_MAX_RANKS:
+                raise RlxError(f"xGMI all-reduce is for one node (<= {XGMI_MAX_RANKS} ranks), world_size={ctx.world_size}")
+            if ctx.device is None or ctx.device.type != "cuda":
+                raise RlxError("xGMI all-reduce needs device tensors")
+            with torch.cuda.device(ctx.device):
+                _lib.check(self._lib.rlx_xgmi_create(ctx.rank, ctx.world_size, self.n_max, int(timeout_ms), int(mem_kind),
+                                                     ctypes.byref(self._comm), handle), "rlx_xgmi_create")
+        except Exception as e:  # noqa: BLE001 -- reported through the gather below, raised on every rank alike
+            err = f"{type(e).__name__}: {e}"
+        if ctx.world_size > 1:
+            # collective part: ALWAYS entered.  (handle or None, device identity) per rank
+            dev_id = None
+            if err is None:
+                try:
+                    dev_id = (socket.gethostname(), str(torch.cuda.get_device_properties(ctx.device).uuid)
+                              if hasattr(torch.cuda.get_device_properties(ctx.device), "uuid") else int(ctx.device.index or 0))
+                except Exception:  # noqa: BLE001
+                    dev_id = (socket.gethostname(), int(ctx.device.index or 0))
+            gathered = [None] * ctx.world_size
+            dist.all_gather_object(gathered, (None if err is not None else bytes(handle), dev_id, err))
+            bad = [(r, g[2]) for r, g in enumerate(gathered) if g[0] is None]
+            if bad:  # the same list on every rank -> every rank raises here
+                self.close()
+                raise RlxError("xGMI communicator could not be created on rank(s) " + ", ".join(f"{r} ({why})" for r, why in bad))
+            # ranks that share a device (the one-GPU test set-up) must not hold it with a device-wide spin: the hand-shake then
+            # runs as a one-wave launch of its own.  Derived from the gathered list, so every rank picks the same mode.
+            ids = [g[1] for g in gathered]
+            self.shared_device = len(set(ids)) < len(ids)
+            with torch.cuda.device(ctx.device):
+                _lib.check(self._lib.rlx_xgmi_connect(self._comm, b"".join(g[0] for g in gathered)), "rlx_xgmi_connect")
+        elif err is not None:
+            raise RlxError(err)
+        else:
+            self.shared_device = False
         self._ws = torch.empty(self._lib.rlx_adamw_workspace_bytes(self.n_max), dtype=torch.uint8, device=ctx.device)
+        algo = os.environ.get("RLX_XGMI_ALGO", "auto").lower()
+        wait = os.environ.get("RLX_XGMI_WAIT", "auto").lower()
+        self.configure(algo=None if algo == "auto" else algo,
+                       wait_mode=("kernel" if self.shared_device else "inline") if wait == "auto" else wait)
+
+    _ALGOS = {"direct": 0, "rsag": 1}
+    _WAITS = {"inline": 0, "kernel": 1}
+
+    def configure(self, algo: Optional[str] = None, wait_mode: Optional[str] = None, timeout_ms: int = 0):
+        """algo "direct" / "rsag" (None: the library's default -- direct below four ranks, reduce-scatter + all-gather from four
+        on); wait_mode "inline" / "kernel"; timeout_ms > 0: a new bound for every peer wait.  Same call on every rank."""
+        a = -1 if algo is None else self._ALGOS[algo]
+        w = -1 if wait_mode is None else self._WAITS[wait_mode]
+        _lib.check(self._lib.rlx_xgmi_configure(self._comm, a, w, int(timeout_ms)), "rlx_xgmi_configure")
+        self.algo = algo if algo is not None else ("rsag" if self.ctx.world_size >= 4 else "direct")
+        if wait_mode is not None:
+            self.wait_mode = wait_mode
 
     @property
     def handle(self):
@@ -67,11 +114,16 @@ class XgmiAllReduce:
                        "rlx_xgmi_allreduce_f32")
         return out
 
+    def status_ok(self) -> bool:
+        """False when a peer wait timed out since the last call (clears the word)."""
+        with torch.cuda.device(self.ctx.device):
+            return self._lib.rlx_xgmi_status(self._comm) == 0
+
     def check_status(self):
         """Raises when a peer wait timed out since the last call (a rank died or never reached the all-reduce)."""
-        with torch.cuda.device(self.ctx.device):
-            if self._lib.rlx_xgmi_status(self._comm) != 0:
-                raise RlxError("xGMI all-reduce: a peer did not publish its gradient within the timeout; results are invalid")
+        if not self.status_ok():
+            raise RlxError("xGMI all-reduce: a peer did not publish its gradient within the timeout; results are invalid "
+                           "(the optimizer skipped the affected steps)")
 
     def close(self):
         if self._comm:
@@ -85,36 +137,62 @@ class XgmiAllReduce:
             pass
 
 
-def _attempt(ctx, n_max: int, mem_kind: int, rounds: int):
-    """-> (communicator or None, reason); the verdict is collective: every rank gets the same answer."""
+def _agree(ok: int, ctx) -> bool:
+    verdict = torch.tensor([int(ok)], dtype=torch.int32, device=ctx.device)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+    return int(verdict.item()) == 1
+
+
+def _attempt(ctx, n_max: int, mem_kind: int, rounds: int, validate_timeout_ms: int = 20000):
+    """-> (communicator or None, reason); the verdict is collective: every rank gets the same answer.
+
+    Every rank executes THE SAME sequence of torch.distributed calls whatever happens locally: the constructor's one gather, one
+    MIN, then per round one SUM of `want`, then one MIN -- a rank that sees a mismatch or a time-out records it and keeps going
+    (it only stops issuing xGMI launches), so the collectives never get out of step (with RCCL a size / op mismatch is undefined
+    behaviour, exactly when the transport misbehaves on a subset of ranks)."""
     comm, ok, why = None, 1, ""
     try:
         comm = XgmiAllReduce(ctx, n_max, mem_kind=mem_kind)
     except Exception as e:  # noqa: BLE001 -- every failure mode takes the same collective decision below
         ok, why = 0, f"{type(e).__name__}: {e}"
-    verdict = torch.tensor([ok], dtype=torch.int32, device=ctx.device)
-    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-    if int(verdict.item()) == 1:
-        try:
-            g = torch.Generator(device=ctx.device).manual_seed(1234 + ctx.rank)
-            for k in range(rounds):  # both staging slots, a two-slab input, the scale
-                x = torch.randn(2, n_max, device=ctx.device, generator=g)
-                want = x.sum(0)
-                dist.all_reduce(want)
-                got = comm.all_reduce(x, scale=1.0 / ctx.world_size)
-                torch.cuda.synchronize(ctx.device)
-                comm.check_status()
-                if not torch.allclose(got * ctx.world_size, want, rtol=1e-5, atol=1e-5):
-                    ok, why = 0, f"round {k}: max |diff| {float((got * ctx.world_size - want).abs().max()):.3e}"
-                    break
-        except Exception as e:  # noqa: BLE001
-            ok, why = 0, f"{type(e).__name__}: {e}"
-        verdict = torch.tensor([ok], dtype=torch.int32, device=ctx.device)
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
-    if int(verdict.item()) != 1:
+    if not _agree(ok, ctx):
         if comm is not None:
             comm.close()
-        return None, why or "a peer failed"
+        return None, why or "a peer failed to create / connect its communicator"
+    product_timeout = int(os.environ.get("RLX_XGMI_TIMEOUT_MS", "300000"))
+    algos = ["direct", "rsag"] if ctx.world_size >= 2 and n_max % 4 == 0 else ["direct"]
+    preferred = comm.algo
+    g = torch.Generator(device=ctx.device).manual_seed(1234 + ctx.rank)
+    try:
+        comm.configure(timeout_ms=min(validate_timeout_ms, product_timeout))  # a dead transport costs one short wait, not minutes
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    for algo in algos:  # both forms are validated: the preferred one runs the product, the other is what RLX_XGMI_ALGO selects
+        for k in range(rounds):  # both staging slots, a two-slab input, the scale
+            x = torch.randn(2, n_max, device=ctx.device, generator=g)
+            want = x.sum(0)
+            dist.all_reduce(want)  # unconditional: the ranks stay in step
+            if not ok:
+                continue
+            try:
+                comm.configure(algo=algo)
+                got = comm.all_reduce(x, scale=1.0 / ctx.world_size)
+                torch.cuda.synchronize(ctx.device)
+                if not comm.status_ok():
+                    ok, why = 0, f"{algo} round {k}: a peer wait timed out"
+                elif not torch.allclose(got * ctx.world_size, want, rtol=1e-5, atol=1e-5):
+                    ok, why = 0, f"{algo} round {k}: max |diff| {float((got * ctx.world_size - want).abs().max()):.3e}"
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, f"{type(e).__name__}: {e}"
+    if ok:
+        try:
+            comm.configure(algo=preferred, timeout_ms=product_timeout)
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, f"{type(e).__name__}: {e}"
+    if not _agree(ok, ctx):
+        if comm is not None:
+            comm.close()
+        return None, why or "a peer failed the validation"
     return comm, ""
 
 
@@ -134,3 +212,53 @@ def build(ctx, n_max: int, rounds: int = 4) -> Optional[XgmiAllReduce]:
         reasons.append(f"mem_kind {kind}: {why}")
     print(f"[rlinf_amd] rank {ctx.rank}: xGMI gradient all-reduce unavailable ({'; '.join(reasons)}); using RCCL", flush=True)
     return None
+
+
+class LocalXgmiGroup:
+    """W communicators of ONE process wired to each other directly (rlx_xgmi_connect_local): every "rank" launches on its own
+    stream of the same device.  Test / bring-up tool for the exchange protocol at W = 2 .. 8 on a one-GPU box (no IPC, no
+    torch.distributed); the hand-shake runs as its own one-wave launch so that W spinning grids never fill the device."""
+
+    def __init__(self, world: int, n_max: int, device, algo: str = "direct", timeout_ms: int = 20000, mem_kind: int = 0):
+        self._lib = _lib.load()
+        self.world, self.n_max, self.device = int(world), int(n_max), torch.device(device)
+        self.comms = []
+        handle = (ctypes.c_char * XGMI_HANDLE_BYTES)()
+        with torch.cuda.device(self.device):
+            for r in range(world):
+                c = ctypes.c_void_p()
+                _lib.check(self._lib.rlx_xgmi_create(r, 1 if world == 1 else world, self.n_max, timeout_ms, mem_kind, ctypes.byref(c),
+                                                     handle), "rlx_xgmi_create")
+                self.comms.append(c)
+            arr = (ctypes.c_void_p * world)(*[c.value for c in self.comms])
+            _lib.check(self._lib.rlx_xgmi_connect_local(arr, world), "rlx_xgmi_connect_local")
+            for c in self.comms:
+                _lib.check(self._lib.rlx_xgmi_configure(c, XgmiAllReduce._ALGOS[algo], 1, 0), "rlx_xgmi_configure")
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(world)]
+        self._ws = [torch.empty(self._lib.rlx_adamw_workspace_bytes(self.n_max), dtype=torch.uint8, device=self.device)
+                    for _ in range(world)]
+
+    def all_reduce(self, inputs, outs, scale: float = 1.0):
+        """inputs[r] ([slabs, n] f32) -> outs[r] ([n]) for every rank, each on its own stream; returns after enqueueing."""
+        cur = torch.cuda.current_stream(self.device)
+        for r in range(self.world):
+            self.streams[r].wait_stream(cur)
+        for r in range(self.world):
+            x = inputs[r]
+            n = x.shape[-1]
+            with torch.cuda.stream(self.streams[r]):
+                _lib.check(self._lib.rlx_xgmi_allreduce_f32(self.comms[r], x.data_ptr(), x.numel() // n, outs[r].data_ptr(), n,
+                                                            float(scale), self._ws[r].data_ptr(), self._ws[r].numel(),
+                                                            self.streams[r].cuda_stream), "rlx_xgmi_allreduce_f32")
+        for r in range(self.world):
+            cur.wait_stream(self.streams[r])
+
+    def status_ok(self) -> bool:
+        with torch.cuda.device(self.device):
+            return all(self._lib.rlx_xgmi_status(c) == 0 for c in self.comms)
+
+    def close(self):
+        for c in self.comms:
+            if c:
+                self._lib.rlx_xgmi_destroy(c)
+        self.comms = []

@@ -558,7 +558,7 @@ class EmbodiedFSDPActor(Worker):
         a, alg = self.cfg.actor, self.cfg.algorithm
         from ..common import peer
         E = self.pipeline_epochs
-        env = peer("env")
+        env = peer("env", self.cfg)
         events = env.epoch_events if (env is not None and env.epoch_events) else None
         stream = torch.cuda.current_stream(self.device)
         reds, plan, grads = [], None, None

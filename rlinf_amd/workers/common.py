@@ -62,8 +62,24 @@ class Worker:
 _PEERS: dict = {}
 
 
-def peer(role: str):
-    return _PEERS.get(role)
+def peer(role: str, cfg=None):
+    """The worker of ``role`` launched in this process, or None.  ``cfg``: the asking worker's own configuration -- a worker that
+    was launched with a DIFFERENT configuration (an earlier runner of the same process, a tool that built one worker on its own)
+    is not a peer: its model / buffers must never be adopted silently."""
+    w = _PEERS.get(role)
+    if w is not None and cfg is not None and not (w.cfg is cfg or w.cfg == cfg):
+        return None
+    return w
+
+
+def clear_peers(*workers) -> None:
+    """Forget the given workers (all of them without arguments): a runner that is torn down must not leave its workers behind
+    for the next one to adopt."""
+    if not workers:
+        _PEERS.clear()
+        return
+    for role in [r for r, w in _PEERS.items() if any(w is x or w is getattr(x, "worker", None) for x in workers)]:
+        del _PEERS[role]
 
 
 def _role_of(cls) -> str:

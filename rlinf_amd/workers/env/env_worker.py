@@ -70,7 +70,9 @@ class EnvWorker(Worker):
         begin, _ = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank, 0)
         _, end = env_shard(self.train_cfg.total_num_envs, self._world_size, self.stage_num, self._rank, self.stage_num - 1)
         if env_tensors is None:
-            env_tensors = generate_tensors(int(self.train_cfg.get("seed", 0)), self.n_train_chunk_steps * self.rollout_epoch,
+            # the synthetic horizon is counted in ENV steps: num_action_chunks of them per chunk step
+            env_tensors = generate_tensors(int(self.train_cfg.get("seed", 0)),
+                                           self.n_train_chunk_steps * self.rollout_epoch * int(m.num_action_chunks),
                                            self.train_cfg.total_num_envs, m.obs_dim,
                                            int(self.train_cfg.get("max_episode_steps", 50)),
                                            mode=self.train_cfg.get("synthetic_done_mode", "periodic"))
@@ -114,7 +116,7 @@ class EnvWorker(Worker):
         if isinstance(input_channel, torch.Tensor):  # interact(eps): the package's own call style
             eps, input_channel = input_channel, None
         if self.rollout is None:
-            self.rollout = peer("rollout")
+            self.rollout = peer("rollout", self.cfg)
         self._prefetched_train_bootstrap = None  # consumed: the first observation batch is resident (env.reset(0))
         out = self._interact(eps, mode)
         if actor_channel is not None:
@@ -242,14 +244,14 @@ class EnvWorker(Worker):
         ev = self.cfg.env.get("eval", None) or self.train_cfg
         m = self.cfg.actor.model
         if self.rollout is None:
-            self.rollout = peer("rollout")
+            self.rollout = peer("rollout", self.cfg)
         steps = int(ev.get("max_steps_per_rollout_epoch", self.train_cfg.max_steps_per_rollout_epoch)) // m.num_action_chunks
         epochs = int(ev.get("rollout_epoch", 1))
         total = int(ev.get("total_num_envs", self.train_cfg.total_num_envs))
         auto_reset = bool(ev.get("auto_reset", True))
         if self._eval_env is None:
             begin, end = (total // self._world_size) * self._rank, (total // self._world_size) * (self._rank + 1)
-            tensors = generate_tensors(int(ev.get("seed", 0)) + 1_000_003, steps * epochs, total, m.obs_dim,
+            tensors = generate_tensors(int(ev.get("seed", 0)) + 1_000_003, steps * epochs * int(m.num_action_chunks), total, m.obs_dim,
                                        int(ev.get("max_episode_steps", self.train_cfg.get("max_episode_steps", 50))),
                                        mode=ev.get("synthetic_done_mode", "periodic"))
             self._eval_env = SyntheticManiSkillEnv(tensors, self.device, m.num_action_chunks, auto_reset, slice(begin, end))

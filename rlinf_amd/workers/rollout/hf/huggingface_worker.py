@@ -32,7 +32,7 @@ class MultiStepRolloutWorker(Worker):
             model = None
         if model is not None:
             self.hf_model, self._shares_actor_weights = model, True
-        elif not (bool(self.cfg.rollout.get("share_actor_weights", True)) and peer("actor") is not None):
+        elif not (bool(self.cfg.rollout.get("share_actor_weights", True)) and peer("actor", self.cfg) is not None):
             self.hf_model = get_model(self.cfg.actor.model).to(self.device)
 
     def _overlapped_pipeline(self) -> bool:
@@ -51,7 +51,7 @@ class MultiStepRolloutWorker(Worker):
         """Apply the learner's weights (huggingface_worker.py:629-675).  Flat-buffer copy, or nothing when aliased; then
         rebuild the fragment-tile weight image HERE, eagerly: the rollout loop may be a replayed hipGraph, which must
         find fresh tiles in the same buffer (a lazy rebuild inside the captured region would be frozen out of it)."""
-        actor = peer("actor")
+        actor = peer("actor", self.cfg)
         if self.hf_model is None:  # deferred by init_worker(): collocated -> alias the learner's policy object
             if actor is None or actor.model is None:
                 raise RuntimeError("sync_model_from_actor: no initialised in-process actor to take the weights from")

@@ -57,6 +57,73 @@ def test_config_validation_rules():
         validate_cfg(bad)
 
 
+def test_config_rejects_shapes_the_kernels_cannot_take():
+    """validate_cfg names the limit instead of leaving it to the first launch's errno string (csrc/ppo_step_common.h: HID = 256,
+    Tiles::K1P = 64, MAX_OUT = 16)."""
+    from rlinf_amd.config import MLP_KERNEL_LIMITS, validate_cfg
+    assert MLP_KERNEL_LIMITS == {"hidden_dim": 256, "obs_dim_max": 64, "action_outputs_max": 16}
+    ok = make_cfg()
+    ok.actor.model.num_action_chunks, ok.actor.model.obs_dim = 2, 64
+    validate_cfg(ok)  # 2 x 8 = 16 head outputs and 64 inputs are the edges that still fit
+    bad = make_cfg()
+    bad.actor.model.obs_dim = 65
+    with pytest.raises(AssertionError, match="obs_dim=65.*<= 64"):
+        validate_cfg(bad)
+    bad = make_cfg(steps=18)
+    bad.actor.model.num_action_chunks = 3
+    with pytest.raises(AssertionError, match=r"8 \* 3 = 24.*at most 16"):
+        validate_cfg(bad)
+    bad = make_cfg()
+    bad.actor.model.hidden_dim = 512
+    with pytest.raises(AssertionError, match="hidden_dim=512"):
+        validate_cfg(bad)
+
+
+def test_synthetic_env_chunk_steps_match_the_oracle_rollouts_indexing():
+    """The product's synthetic env and the oracle loop cut the same ENV-step tensors into the same chunk steps (C = 1, 2, 4):
+    rewards side by side, done flags raised in the last column for any sub-step, obs after / final obs of the chunk."""
+    from rlinf_amd.envs.synthetic_env import SyntheticManiSkillEnv, generate_tensors
+    for C in (1, 2, 4):
+        T_env, B = 24, 6
+        t = generate_tensors(3, T_env, B, 5, 50, mode="bernoulli", p_done=0.2)
+        env = SyntheticManiSkillEnv(t, "cpu", C, auto_reset=True)
+        obs, _ = env.reset(0)
+        assert torch.equal(obs["states"], t["obs"][0])
+        for k in range(T_env // C):
+            obs, r, term, trunc, infos = env.chunk_step(None)
+            assert torch.equal(r, t["rewards"][k * C:(k + 1) * C].transpose(0, 1)) and r.is_contiguous()
+            want = torch.zeros(B, C, dtype=torch.bool)
+            want[:, -1] = t["dones"][k * C + 1:(k + 1) * C + 1].any(dim=0)
+            assert torch.equal(trunc, want) and not term.any()
+            assert torch.equal(obs["states"], t["obs"][(k + 1) * C])
+            assert torch.equal(infos["final_obs"]["states"], t["final_obs"][(k + 1) * C - 1])
+
+
+def test_worker_peers_are_scoped_to_their_configuration():
+    """A worker launched by another runner / tool with a different configuration is not a peer (its model must never be adopted
+    silently), and a runner that is closed leaves nothing behind."""
+    from rlinf_amd.workers import common
+    from rlinf_amd.workers.common import Worker, clear_peers, peer
+
+    class A(Worker):
+        ROLE = "actor"
+
+    class R(Worker):
+        ROLE = "rollout"
+
+    cfg1, cfg2 = make_cfg(), make_cfg(total_envs=16)
+    clear_peers()
+    a1 = A.create_group(cfg1).launch(None).worker
+    assert peer("actor") is a1 and peer("actor", cfg1) is a1 and peer("actor", make_cfg()) is a1  # equal configurations are one job
+    assert peer("actor", cfg2) is None
+    r2 = R.create_group(cfg2).launch(None).worker
+    assert peer("rollout", cfg1) is None and peer("rollout", cfg2) is r2
+    clear_peers(a1)
+    assert peer("actor") is None and peer("rollout") is r2
+    clear_peers()
+    assert common._PEERS == {}
+
+
 def _build(cfg, env_tensors, state_dict):
     from rlinf_amd.config import validate_cfg
     from rlinf_amd.runners import EmbodiedRunner
@@ -173,6 +240,94 @@ def test_iteration_matches_oracle(shape):
         assert float((diff > 2e-5 * (it + 1)).float().mean()) < 0.02, float((diff > 2e-5).float().mean())
     # the device-side Adam step counter restarts when the warm-up ends (a new optimizer in the reference)
     assert int(runner.actor.worker.step_state.sum()) == runner.actor.worker.optimizer_steps - shape.get("critic_warmup_steps", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # adv, loss, reward_type, logprob_type, auto_reset, hip_graph, precision
+    dict(adv="gae", loss="actor_critic", reward="action_level", logprob="action_level", auto_reset=True, hip_graph=False),
+    dict(adv="gae", loss="actor_critic", reward="action_level", logprob="action_level", auto_reset=True, hip_graph=True),
+    dict(adv="gae", loss="actor_critic", reward="action_level", logprob="token_level", auto_reset=True, hip_graph=False),
+    dict(adv="gae", loss="actor_critic", reward="action_level", logprob="action_level", auto_reset=False, hip_graph=False),
+    dict(adv="gae", loss="actor_critic", reward="action_level", logprob="action_level", auto_reset=False, hip_graph=True),
+    # value-free GRPO on chunk-level rewards (the only reward_type = chunk_level combination the reference's own shapes allow
+    # with its MLP policy: its value head always has num_action_chunks outputs, so GAE cannot take a chunk-summed reward)
+    dict(adv="grpo", loss="actor", reward="chunk_level", logprob="chunk_level", auto_reset=False, hip_graph=False),
+    dict(adv="grpo", loss="actor", reward="chunk_level", logprob="chunk_level", auto_reset=False, hip_graph=True),
+    dict(adv="grpo", loss="actor", reward="chunk_level", logprob="action_level", auto_reset=False, hip_graph=False),
+    dict(adv="gae", loss="actor_critic", reward="action_level", logprob="action_level", auto_reset=True, hip_graph=True, precision="bf16"),
+], ids=lambda c: "-".join(str(v) for v in c.values()))
+def test_action_chunks_whole_loop_matches_oracle(case):
+    """num_action_chunks = 2 through the WHOLE loop (SURVEY.md 8c "C > 1"): the env's chunk steps ([B, 2] rewards, done flags in
+    the last column, bootstrap at the chunk's end), 16 head outputs and 2 value columns per policy step, the [n, B, C] <-> [T, B]
+    time-chunk layout inside GAE / the loss mask, loss shaping per logprob_type, the fused optimizer step and AdamW -- eager and
+    as replayed hipGraphs -- against oracle.ppo_loop.iteration on identical seeds, weights, injected noise and shuffle order."""
+    C, A, B, GB = 2, 8, 32, 96
+    steps_env, group = 24, 4                      # 12 chunk steps of 2 env steps
+    n = steps_env // C
+    bf16 = case.get("precision") == "bf16"
+    cfg = make_cfg(total_envs=B, steps=steps_env, global_batch=GB, auto_reset=case["auto_reset"], hip_graph=case["hip_graph"],
+                   done_mode=None if case["auto_reset"] else "bernoulli")
+    cfg.actor.model.num_action_chunks = C
+    cfg.actor.model.precision = case.get("precision", "32")
+    alg = cfg.algorithm
+    alg.adv_type, alg.loss_type, alg.reward_type, alg.logprob_type = case["adv"], case["loss"], case["reward"], case["logprob"]
+    if case["adv"] == "grpo":
+        alg.group_size = cfg.env.train.group_size = group
+    env = L.synthetic_env_tensors(0, steps_env, B, 42, max_episode_steps=5, mode="periodic" if case["auto_reset"] else "bernoulli",
+                                  p_done=0.05)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, A, C)
+    sd = copy.deepcopy(ora.state_dict())
+    opt = O.build_adamw(ora)
+    runner = _build(cfg, env, sd)
+    w = runner.actor.worker
+    assert w.model.layout.act_dim == C * A and w.model.layout.val_dim == C
+    init = w.model.flat.detach().cpu().clone()
+    for it in range(3 if case["hip_graph"] else 2):
+        eps = torch.randn(n, B, C * A, generator=torch.Generator().manual_seed(100 + it))
+        batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234, global_batch=GB, update_epoch=2,
+                                auto_reset=case["auto_reset"], max_episode_steps=None if case["auto_reset"] else 5,
+                                adv_type=case["adv"], loss_type=case["loss"], reward_type=case["reward"],
+                                logprob_type=case["logprob"], group_size=group if case["adv"] == "grpo" else 1, autocast=bf16)
+        metrics = runner.run_step(eps.cuda())
+        rb = w.rollout_batch
+        if bf16:
+            tol = dict(rtol=3e-2, atol=3e-2)
+        else:
+            tol = dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4)
+        torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), batch["forward_inputs"]["action"], **tol)
+        torch.testing.assert_close(rb["prev_logprobs"].cpu(), batch["prev_logprobs"], **(tol if not bf16 else dict(rtol=5e-2, atol=5e-2)))
+        torch.testing.assert_close(rb["prev_values"].cpu(), batch["prev_values"], **tol)
+        torch.testing.assert_close(rb["rewards"].cpu(), batch["rewards"], **tol)
+        assert torch.equal(rb["dones"].cpu(), batch["dones"])
+        assert rb["rewards"].shape == (n, B, C) and rb["dones"].shape == (n + 1, B, C) and rb["prev_values"].shape == (n + 1, B, C)
+        if "returns" in batch:
+            torch.testing.assert_close(rb["returns"].cpu(), batch["returns"], **tol)
+        if not bf16:
+            torch.testing.assert_close(rb["advantages"].cpu(), batch["advantages"], rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+        if not case["auto_reset"]:  # integer work: bit-exact (chunk_level: reduced with any / last column, :228-230)
+            assert torch.equal(rb["loss_mask"].cpu(), batch["loss_mask"]) and torch.equal(rb["loss_mask_sum"].cpu(), batch["loss_mask_sum"])
+        if not bf16:
+            want_loss = sum(float(m["actor/total_loss"]) for m in om) / len(om)
+            assert metrics["train/actor/total_loss"] == pytest.approx(want_loss, rel=2e-3, abs=2e-4)
+            want_gn = sum(float(m["actor/grad_norm"]) for m in om) / len(om)
+            assert metrics["train/actor/grad_norm"] == pytest.approx(want_gn, rel=2e-3)
+            for k in ("actor/policy_loss", "actor/approx_kl", "actor/clip_fraction") + (("critic/value_loss",) if case["loss"] == "actor_critic" else ()):
+                want_k = sum(float(m[k]) for m in om) / len(om)
+                assert metrics["train/" + k] == pytest.approx(want_k, rel=5e-3, abs=5e-5), k
+        got = w.model.flat.detach().cpu()
+        want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+        diff = (got - want).abs()
+        steps_taken = len(om) * (it + 1)
+        assert float(diff.max()) <= 2 * 3e-4 * steps_taken + 1e-6
+        if not bf16:
+            assert float((diff > 2e-5 * (it + 1)).float().mean()) < 0.02, float((diff > 2e-5).float().mean())
+        if case["loss"] == "actor":  # no critic: the value head is never touched (grad None in the reference: no decay either)
+            for nm in w.model.shapes:
+                if "value_head" in nm:
+                    b, e = w.model.offsets[nm], w.model.offsets[nm] + w.model.view(nm).numel()
+                    assert torch.equal(got[b:e], init[b:e]), nm
 
 
 @pytest.mark.gpu

@@ -278,3 +278,103 @@ def test_bench_configuration_bf16_matches_autocast_oracle_with_graph_replay():
         assert float(d_ours.abs().max()) <= 2 * LR * steps_taken + 1e-6
         assert metrics["train/actor/grad_norm"] == pytest.approx(float(w32["actor/grad_norm"].mean()), rel=5e-2)
         assert metrics["train/actor/approx_kl"] == pytest.approx(float(w32["actor/approx_kl"].mean()), rel=0.1, abs=5e-4)
+
+
+@pytest.mark.parametrize("precision", ["32", "bf16"])
+def test_ten_iterations_reseeded_oracle_at_bench_configuration(precision):
+    """TEN iterations of the benchmarked loop (hipGraph replay from iteration 1 on), drift-free by construction: at the start of
+    every iteration the oracle is RE-SEEDED with the product's current weights, so iteration k's rollout tensors, returns,
+    advantages and FIRST optimizer step (scalars from the replayed graph's own metric rows, and the gradient vector recomputed
+    by the fused step at the iteration-start weights on the iteration's own shuffled minibatch 0) are compared as tightly as
+    iteration 0's -- a slow bias (stale weight tiles after graph replay, a mis-stepped device-side Adam counter, a stale
+    behaviour-policy row) surfaces as a growing distance, which two iterations cannot show.  Also checked every iteration: the
+    device step counter, and that the replayed update actually moved the weights by a plausible AdamW amount.
+    Bounds: f32 rel-L2 of the gradient <= 2e-4; bf16 no farther from the f32 gradient than twice the autocast oracle."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
+    env = _env()
+    _, sd, _ = _oracle()
+    bf16 = precision == "bf16"
+    runner = _runner(precision, True, sd)
+    w = runner.actor.worker
+    lay = w.model.layout
+    grads = torch.empty((ops.ppo_step_slabs(lay, GB, bf16=bf16), lay.n_params), device="cuda")
+    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, GB), dtype=torch.uint8, device="cuda")
+    row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+    perm = torch.randperm(T * B, generator=torch.Generator().manual_seed(1234))
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    probe = MLPPolicy(D, A, 1, True, False, compute_dtype=torch.bfloat16 if bf16 else torch.float32).to("cuda")
+
+    def oracle_first_step(state_dict, eps, autocast):
+        pol = O.OracleMLPPolicy(D, A, 1)
+        pol.load_state_dict(state_dict)
+        batch = L.advantages(L.rollout(pol, env, eps, 0.8, True, autocast=autocast), 0.8, 0.9, True)
+        m0 = O.chunk_batch(O.flatten_and_shuffle(batch, perm), T * B // GB)[0]
+        with O.amp(autocast):
+            out = pol.evaluate(m0["forward_inputs"]["states"], m0["forward_inputs"]["action"])
+        out = {k: v.float() for k, v in out.items()}
+        shaped = O.shape_loss_inputs(out["logprobs"], m0["prev_logprobs"], m0["advantages"], "action_level", A,
+                                     values=out["values"], prev_values=m0["prev_values"], returns=m0["returns"])
+        loss, metrics = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+        loss.backward()
+        gn = float(_flat_grad(pol).norm())
+        return batch, _flat_grad(pol), float(loss), {k: float(v) for k, v in metrics.items()}, gn
+
+    worst = {}
+    for it in range(10):
+        start = {k: v.detach().cpu().clone() for k, v in w.model.reference_state_dict().items()}
+        start_flat = w.model.flat.detach().clone()
+        eps = torch.randn(T, B, A, generator=torch.Generator().manual_seed(100 + it))
+        b32, g32, loss32, m32, gn32 = oracle_first_step(start, eps, False)
+        metrics = runner.run_step(eps.cuda())
+        assert (w._graph is not None) and (it == 0 or runner.env.worker._graph is not None), "the benchmarked mode replays hipGraphs"
+        rb = w.rollout_batch
+        ps = _per_step(w)
+        # (1) this iteration's rollout tensors against the oracle re-seeded with this iteration's start weights
+        if bf16:
+            b16, g16, loss16, _, _ = oracle_first_step(start, eps, True)
+            tol = dict(rtol=2e-2, atol=2e-2)
+            torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), b16["forward_inputs"]["action"], **tol)
+            torch.testing.assert_close(rb["prev_values"].cpu(), b16["prev_values"], **tol)
+            torch.testing.assert_close(rb["returns"].cpu(), b16["returns"], rtol=2e-2, atol=4e-2)
+            torch.testing.assert_close(rb["advantages"].cpu(), b16["advantages"], rtol=2e-2, atol=6e-2)
+            torch.testing.assert_close(rb["prev_logprobs"].cpu(), b32["prev_logprobs"], rtol=1e-4, atol=1e-4)
+        else:
+            tol = dict(rtol=2e-4, atol=2e-5)
+            torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), b32["forward_inputs"]["action"], **tol)
+            torch.testing.assert_close(rb["prev_logprobs"].cpu(), b32["prev_logprobs"], **tol)
+            torch.testing.assert_close(rb["prev_values"].cpu(), b32["prev_values"], **tol)
+            torch.testing.assert_close(rb["rewards"].cpu(), b32["rewards"], **tol)
+            torch.testing.assert_close(rb["returns"].cpu(), b32["returns"], **tol)
+            torch.testing.assert_close(rb["advantages"].cpu(), b32["advantages"], rtol=1e-3, atol=1e-4)
+        assert torch.equal(rb["dones"].cpu(), b32["dones"])
+        # (2) the first optimizer step's scalars, as the (replayed) update graph itself wrote them
+        first = {"loss": float(ps["actor/total_loss"][0]), "grad_norm": float(ps["actor/grad_norm"][0]),
+                 **{k: float(ps[k][0]) for k in KEYS}}
+        rel_s = 2e-2 if bf16 else 2e-4
+        assert first["loss"] == pytest.approx(loss32, rel=rel_s, abs=rel_s * 0.1), (it, first["loss"], loss32)
+        assert first["grad_norm"] == pytest.approx(gn32, rel=5e-2 if bf16 else 5e-4), (it, first["grad_norm"], gn32)
+        for k in KEYS:
+            assert first[k] == pytest.approx(m32[k], rel=rel_s, abs=(2e-3 if bf16 else 2e-6)), (it, k, first[k], m32[k])
+        # (3) the gradient vector at the iteration-start weights on this iteration's shuffled minibatch 0
+        flat = {k: v for k, v in zip(("states", "action", "prev_logprobs", "advantages", "prev_values", "returns"),
+                                     w._ws[[k for k in w._ws if isinstance(k, tuple) and k[0] == "shuf"][0]])}
+        mb = {k: v[:GB] for k, v in flat.items()}
+        probe.flat.data.copy_(start_flat)
+        probe.mark_updated()
+        ops.ppo_step(probe.flat.data, lay, w._loss_params(False), mb, grads, row, ws, grad_out=1.0, bf16=bf16)
+        got = grads.sum(dim=0).cpu()
+        rel = float((got - g32).norm() / g32.norm())
+        if bf16:
+            rel_auto = float((g16 - g32).norm() / g32.norm())
+            assert rel <= 2.0 * rel_auto + 1e-3, (it, rel, rel_auto)
+            worst[it] = [rel, rel_auto]
+        else:
+            assert rel <= 2e-4, (it, rel)
+            worst[it] = rel
+        # (4) bookkeeping that graph replay must keep right
+        assert int(w.step_state.sum()) == w.optimizer_steps == N_STEPS * (it + 1)
+        moved = (w.model.flat.detach() - start_flat).abs()
+        assert 0 < float(moved.max()) <= 2 * LR * N_STEPS + 1e-6 and float(moved.mean()) > 0.05 * LR
+        assert metrics["train/actor/grad_norm"] > 0 and metrics["rollout/rewards"] == pytest.approx(float(b32["rewards"].mean()), rel=2e-2 if bf16 else 1e-4)
+    _report(f"ten_iterations_{'bf16' if bf16 else 'f32'}", dict(first_step_gradient_rel_l2_by_iteration=worst))

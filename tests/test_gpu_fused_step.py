@@ -123,6 +123,87 @@ def test_ppo_step_gradients_and_metrics_vs_oracle(M, with_mask):
         assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(float(metrics[key]), rel=5e-4, abs=5e-5), key
 
 
+@pytest.mark.parametrize("M,case,bf16", [
+    (2048, ("action_level", "action_level", True, False), False),   # [M, C] ratios under [M, C] advantages, C values per row
+    (700, ("action_level", "action_level", True, True), False),     # ... under a [M, C] loss mask
+    (333, ("action_level", "token_level", True, True), False),      # [M, C, A] ratios, advantages / mask unsqueezed
+    (512, ("chunk_level", "chunk_level", False, True), False),      # value-free (GRPO): one ratio per row
+    (512, ("chunk_level", "action_level", False, True), False),     # [M, C] ratios under [M, 1] advantages
+    (2048, ("action_level", "action_level", True, False), True),    # bf16 operands
+])
+def test_ppo_step_two_action_chunks(M, case, bf16):
+    """num_action_chunks = 2 (act_dim = 16 head outputs, 2 value columns) through the FUSED step: every loss shaping of SURVEY.md
+    8c that exists for C > 1, gradients of every parameter and the metric row against the oracle."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    reward_type, logprob_type, critic, with_mask = case
+    C, A = 2, 8
+    torch.manual_seed(21)
+    ora = O.OracleMLPPolicy(42, A, C)
+    with torch.no_grad():
+        for p in ora.parameters():
+            p.add_(torch.randn_like(p) * 0.02)
+    pol = MLPPolicy(42, A, C, True, False, compute_dtype=torch.bfloat16 if bf16 else torch.float32)
+    pol.load_reference_state_dict(ora.state_dict())
+    pol = pol.to("cuda")
+    g = torch.Generator().manual_seed(8)
+    nadv = 1 if reward_type == "chunk_level" else C
+    mb = dict(states=torch.randn(M, 42, generator=g), action=torch.randn(M, C * A, generator=g) * 0.6,
+              advantages=torch.randn(M, nadv, generator=g), prev_values=torch.randn(M, C, generator=g),
+              returns=torch.randn(M, C, generator=g))
+    if with_mask:
+        mb["loss_mask"] = torch.rand(M, nadv, generator=g) < 0.7
+    with torch.no_grad():
+        cur = ora.evaluate(mb["states"], mb["action"])["logprobs"]
+    mb["prev_logprobs"] = cur + torch.randn(M, C * A, generator=g) * 0.05
+    out = ora.evaluate(mb["states"], mb["action"])
+    shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type, A,
+                                 loss_mask=mb.get("loss_mask"), values=out["values"] if critic else None,
+                                 prev_values=mb["prev_values"] if critic else None, returns=mb["returns"] if critic else None,
+                                 reward_type=reward_type)
+    if critic:
+        loss, metrics = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+    else:
+        loss, metrics = O.ppo_actor_loss(shaped["logprobs"], shaped["old_logprobs"], shaped["advantages"], 0.2, 0.2,
+                                         loss_mask=shaped["loss_mask"])
+    loss.backward()
+    lay = pol.layout
+    lp = ops.make_ppo_params(logprob_type=logprob_type, action_dim=A, chunks=C, clip_ratio_low=0.2, clip_ratio_high=0.2,
+                             value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=critic, reward_type=reward_type)
+    grads = torch.full((ops.ppo_step_slabs(lay, M, bf16=bf16), lay.n_params), float("nan"), device="cuda")
+    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+    row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+    dev_mb = {k: v.cuda().contiguous() for k, v in mb.items()}
+    if not critic:
+        dev_mb.pop("returns")
+    if with_mask:
+        dev_mb["loss_mask"] = dev_mb["loss_mask"].view(torch.uint8)
+    ops.ppo_step(pol.flat.data, lay, lp, dev_mb, grads, row, ws, grad_out=1.0, bf16=bf16)
+    got = grads.sum(dim=0).cpu()
+    assert torch.isfinite(got).all()
+    want = torch.zeros_like(got)
+    for name, p in ora.named_parameters():
+        if p.grad is not None:
+            want[pol.offsets[name]:pol.offsets[name] + p.numel()] = p.grad.reshape(-1)
+    if bf16:  # operand rounding: bounded like the C = 1 bf16 gradient (tests/test_end_to_end_bench_config.py), relative L2
+        assert float((got - want).norm() / want.norm()) < 0.05
+    else:
+        scale = float(want.abs().max())
+        for name, p in ora.named_parameters():
+            o = pol.offsets[name]
+            w = want[o:o + p.numel()]
+            tol = 3e-4 * max(float(w.abs().max()), 1e-3 * scale) + 1e-7
+            err = float((got[o:o + p.numel()] - w).abs().max())
+            assert err <= tol, (name, err, tol)
+    host = row.cpu()
+    tol = dict(rel=2e-2, abs=2e-3) if bf16 else dict(rel=5e-4, abs=5e-5)
+    assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(float(loss.detach()), **tol)
+    for key in ("actor/policy_loss", "actor/ratio", "actor/clipped_ratio", "actor/approx_kl", "actor/clip_fraction") + (
+            ("critic/value_loss",) if critic else ()):
+        assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(float(metrics[key]), **tol), key
+
+
 def test_ppo_step_matches_unfused_chain():
     """Same micro-batch through the stage-by-stage entry points (train_fwd -> ppo_loss -> train_bwd)."""
     from rlinf_amd import ops

@@ -27,38 +27,43 @@ def child():
             print(f"mem_kind {kind}: {'OK' if comm is not None else 'FAILED: ' + why}", flush=True)
         if comm is None:
             continue
+        if ctx.rank == 0:
+            print(f"   shared device: {comm.shared_device}; wait_mode {comm.wait_mode}", flush=True)
         x = torch.randn(24, n, device=ctx.device)
         out = torch.empty(n, device=ctx.device)
-        for _ in range(5):
-            comm.all_reduce(x, out, 0.5)
-        torch.cuda.synchronize()
-        comm.check_status()
-        dist.barrier()
-        t0 = time.perf_counter()
-        iters = n_eager
-        for _ in range(iters):
-            comm.all_reduce(x, out, 0.5)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / iters * 1e6
-        comm.check_status()
-        # the same inside a captured graph
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(n_graph):
+        for algo in ("direct", "rsag"):
+            comm.configure(algo=algo)
+            for _ in range(5):
                 comm.all_reduce(x, out, 0.5)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(n_replay):
-            g.replay()
-        torch.cuda.synchronize()
-        dg = (time.perf_counter() - t0) / (n_graph * n_replay) * 1e6
-        comm.check_status()
-        want = x.sum(0)
-        dist.all_reduce(want)
-        ok = torch.allclose(out * 2, want, rtol=1e-5, atol=1e-5)
-        if ctx.rank == 0:
-            print(f"   stage + reduce (+ seq launch): {dt:.1f} us eager, {dg:.1f} us in a replayed graph; result ok after graph: {ok}", flush=True)
+            torch.cuda.synchronize()
+            comm.check_status()
+            dist.barrier()
+            t0 = time.perf_counter()
+            iters = n_eager
+            for _ in range(iters):
+                comm.all_reduce(x, out, 0.5)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / iters * 1e6
+            comm.check_status()
+            # the same inside a captured graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(n_graph):
+                    comm.all_reduce(x, out, 0.5)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_replay):
+                g.replay()
+            torch.cuda.synchronize()
+            dg = (time.perf_counter() - t0) / (n_graph * n_replay) * 1e6
+            comm.check_status()
+            want = x.sum(0)
+            dist.all_reduce(want)
+            ok = torch.allclose(out * 2, want, rtol=1e-5, atol=1e-5)
+            if ctx.rank == 0:
+                print(f"   {algo}: all-reduce {dt:.1f} us eager, {dg:.1f} us in a replayed graph; {algo}: result ok after graph: {ok}", flush=True)
+            del g
         comm.close()
         if light:
             break
