@@ -701,6 +701,26 @@ int rlx_copy_segments_plan(rlx_copy_segment* table_host, int32_t n_segments, int
 int rlx_copy_segments(const rlx_copy_segment* table_dev, int32_t n_segments, int64_t total_chunks, rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * f3  patch-stream codec  <- NVCompCompressor._compress_tensor / _decompress_tensor,
+ *      rlinf/hybrid_engines/weight_syncer/compressor.py:148-199 (the rows / cols / value-byte fields of a WeightPatch travel as
+ *      compressed byte tensors inside a CompressedWeightPatch, patch_syncer.py:205-250).
+ * nvCOMP is NVIDIA-only and its container is not public: the payload is this build's own "RLXZ" v1 format (csrc/zplane_codec.hip:
+ * byte planes of 4096-element blocks, each stored as nothing / two-level zero masks + the nonzero bytes / raw, whichever is
+ * smallest -- what delta-encoded COO indices and the exponent bytes of changed weights actually consist of).  Lossless, byte-exact.
+ *   bound_bytes      worst-case size of a compressed stream (allocate `out` that large)
+ *   compress         in: n_elems elements of elem_size (1, 2, 4, 8) bytes, 16-byte aligned; *out_bytes (device u64) = stream length
+ *   parse_header     the first 24 bytes of a stream (HOST copy) -> n_elems, elem_size, total stream length
+ *   decompress       *status (device int, zeroed by the caller) != 0: the stream is corrupt / truncated (nothing out of bounds
+ *                    is ever read or written)
+ * ------------------------------------------------------------------------------------------ */
+size_t rlx_zplane_bound_bytes(int64_t n_elems, int elem_size);
+size_t rlx_zplane_workspace_bytes(int64_t n_elems, int elem_size);
+int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_size, void* out, size_t out_capacity, uint64_t* out_bytes,
+                        void* workspace, size_t workspace_bytes, rlx_stream_t stream);
+int rlx_zplane_parse_header(const void* header_host, int64_t* n_elems, int* elem_size, uint64_t* total_bytes);
+int rlx_zplane_decompress(const void* in, size_t in_bytes, void* out, int64_t n_elems, int elem_size, int* status, rlx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a15  rollout_metrics  <- compute_rollout_metrics, rlinf/utils/metric_utils.py:422-506
  *   masked mean / min / max of rewards, advantages, returns: `count` (<= 3) f32 arrays of sizes[k] elements and ONE optional
  *   mask of mask_elems bytes (element e covers sizes[k] / mask_elems consecutive elements of array k: [.., 1] against [.., C]).

@@ -211,6 +211,11 @@ PROTOTYPES = {
     "rlx_patch_apply_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_patch_apply": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64,
                                 c_void_p, c_size_t, c_void_p]),
+    "rlx_zplane_bound_bytes": (c_size_t, [c_int64, c_int]),
+    "rlx_zplane_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "rlx_zplane_compress": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rlx_zplane_parse_header": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int), POINTER(ctypes.c_uint64)]),
+    "rlx_zplane_decompress": (c_int, [c_void_p, c_size_t, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rlx_copy_segments_plan": (c_int, [POINTER(CopySegment), c_int32, POINTER(c_int64)]),
     "rlx_copy_segments": (c_int, [c_void_p, c_int32, c_int64, c_void_p]),
     "rlx_reinpp_workspace_bytes": (c_size_t, [c_int64]),

@@ -6,7 +6,10 @@ from .bucket_syncer import (  # noqa: F401
     load_bucket,
     plan_buckets,
 )
+from .compressor import IdentityCompressor, PatchCompressor, ZPlaneCompressor  # noqa: F401
 from .patch_syncer import (  # noqa: F401
+    CompressedWeightPatch,
+    CPUSnapshotPatchBuilder,
     EmptyWeightPatch,
     PatchBuilder,
     PatchWeightSyncer,

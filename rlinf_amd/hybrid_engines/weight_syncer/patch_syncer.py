@@ -5,8 +5,10 @@
     sender   scan (one read of tensor + snapshot) -> [host reads nnz, as the reference does after nonzero()] -> emit
     receiver decode + scatter in one pass
 
-What is mirrored is the same-device ("GPU snapshot") builder with ``compression: none`` -- nvCOMP, the reference's only
-compressor, is NVIDIA-only -- and the init handshake (receiver announces key order, shapes and
+Mirrored: both patch builders -- the same-device ("GPU snapshot") one and the host-snapshot one (``CPUSnapshotPatchBuilder``
+:416-640: the snapshot lives in pinned host memory and is staged tensor by tensor on a copy stream, one tensor ahead of the
+scan) --, the compression stage (``PatchCompressor.create`` / ``CompressedWeightPatch``: compressor.py, with a gfx950 codec in place
+of nvCOMP's, which is NVIDIA-only) and the init handshake (receiver announces key order, shapes and
 dtypes; the sender snapshots in the RECEIVER's dtypes, :950-1010).  Transport is any pair of send / recv callables, as in
 the reference; ``rlinf_amd.scheduler.dist.broadcast_weight_patch`` is the RCCL broadcast of a patch from the
 actor rank to the rollout ranks.  A patch built here is applied by the
@@ -93,6 +95,28 @@ class WeightPatch:
 
     def tensors(self) -> list:
         return [self.version, self.ordinals, self.nnz_per_tensor, self.rows, self.cols, self.values]
+
+
+@dataclass
+class CompressedWeightPatch:
+    """patch_syncer.py:205-250: the WeightPatch with rows / cols / value bytes as compressed byte tensors + the dtype codes the
+    receiver needs to rebuild them (compressor.py:35-46)."""
+    version: torch.Tensor
+    ordinals: torch.Tensor
+    nnz_per_tensor: torch.Tensor
+    rows_compressed: torch.Tensor
+    cols_compressed: torch.Tensor
+    values_compressed: torch.Tensor
+    rows_dtype_code: torch.Tensor
+    cols_dtype_code: torch.Tensor
+    values_dtype_code: torch.Tensor
+
+    def to(self, device, non_blocking: bool = False) -> "CompressedWeightPatch":
+        return CompressedWeightPatch(*[t.to(device=device, non_blocking=non_blocking) for t in self.tensors()])
+
+    def tensors(self) -> list:
+        return [self.version, self.ordinals, self.nnz_per_tensor, self.rows_compressed, self.cols_compressed,
+                self.values_compressed, self.rows_dtype_code, self.cols_dtype_code, self.values_dtype_code]
 
 
 class PatchBuilder:
@@ -216,6 +240,135 @@ class PatchBuilder:
             values=torch.cat(vals_l).to(tdev))
 
 
+class CPUSnapshotPatchBuilder(PatchBuilder):
+    """The snapshot lives on the HOST (patch_syncer.py:416-640, `snapshot_device: cpu`: a sender whose accelerator cannot spare a
+    second copy of the weights).  Per tensor: the pinned host snapshot is staged to the accelerator on a copy stream -- one tensor
+    AHEAD of the scan, like the reference's _prefetch_snapshot -- scanned / emitted by the same kernels as the same-device builder
+    (which also bring the staged copy up to date), and, only when something changed, written back to the host snapshot as ONE
+    sequential copy on the copy stream.  (The reference scatters the changed values into the host tensor with index_put: a
+    random-access pass over host memory per tensor; a sequential PCIe write of the tensor is cheaper from the first few per cent
+    of changed elements on, and nothing at all is written back for an unchanged tensor.)"""
+
+    def __init__(self, snapshot, ordered_keys, param_names_need_sync, original_shapes, transport_device, delta_encoding):
+        super().__init__(snapshot, ordered_keys, param_names_need_sync, original_shapes, transport_device, delta_encoding)
+        self._copy_streams: dict = {}
+        if snapshot is not None:
+            for key, t in snapshot.items():
+                if t.device.type != "cpu":
+                    raise ValueError(f"CPUSnapshotPatchBuilder requires snapshots to be on CPU. Got key={key}, device={t.device}.")
+
+    def _copy_stream(self, dev):
+        st = self._copy_streams.get(dev)
+        if st is None:
+            st = self._copy_streams[dev] = torch.cuda.Stream(dev)
+        return st
+
+    def _prefetch(self, state_dict: dict, i: int):
+        name = self.param_names_need_sync[i]
+        value = state_dict[name]
+        if value.shape != self.original_shapes[name]:
+            raise ValueError(f"Shape mismatch for key {name}: expected {self.original_shapes[name]}, got {value.shape}")
+        value2d, _ = as_coo_2d_view(value.detach())
+        if not value2d.is_cuda:
+            raise ValueError(f"CPUSnapshotPatchBuilder requires sender state_dict tensors to be on accelerator. Got key={name}, "
+                             f"device={value2d.device}.")
+        host = self.snapshot[name]
+        dev = value2d.device
+        cs = self._copy_stream(dev)
+        cs.wait_stream(torch.cuda.current_stream(dev))  # the staging buffer's previous user
+        with torch.cuda.stream(cs):
+            staged = host.to(device=dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(cs)
+        return name, value2d.contiguous(), host, staged, done
+
+    @torch.no_grad()
+    def create_patch(self, state_dict: dict, version):
+        if set(state_dict.keys()) != set(self.ordered_keys):
+            raise ValueError("State dict keys do not match snapshot keys")
+        if self.snapshot is None:
+            return EmptyWeightPatch(torch.as_tensor(version, dtype=torch.int64, device=self.transport_device))
+        lib = _lib.load()
+        staged_l, dev = [], None
+        nxt = self._prefetch(state_dict, 0)
+        for i in range(len(self.param_names_need_sync)):
+            name, value2d, host, snap, done = nxt
+            nxt = self._prefetch(state_dict, i + 1) if i + 1 < len(self.param_names_need_sync) else None
+            if dev is None:
+                dev = value2d.device
+            elif dev != value2d.device:
+                raise ValueError("CPUSnapshotPatchBuilder requires all sender state_dict tensors to be on the same accelerator. "
+                                 f"Expected {dev}, got {value2d.device} for key={name}.")
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(done)
+            snap.record_stream(cur)
+            try:
+                vcode, scode = _dtype_code(value2d.dtype), _dtype_code(snap.dtype)
+                supported = vcode == scode or (vcode == _lib.DTYPE_F32 and scode in (_lib.DTYPE_BF16, _lib.DTYPE_F16))
+            except (RlxError, KeyError):
+                supported = False
+            if not supported:
+                value2d = value2d.to(snap.dtype)
+                vcode = scode = _dtype_code(snap.dtype)
+            n = value2d.numel()
+            if n == 0:
+                continue
+            nbytes = lib.rlx_patch_workspace_bytes(n)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rlx_patch_scan(value2d.data_ptr(), vcode, snap.data_ptr(), scode, n, ws.data_ptr(), nbytes,
+                                              nnz.data_ptr(), _stream_ptr(dev)), "rlx_patch_scan")
+            staged_l.append((self.param_names_need_sync_ordinals[name], snap, value2d, vcode, scode, nnz, ws, host))
+        if dev is None:
+            raise RuntimeError("Snapshot contains no tensors")
+        counts = torch.cat([s[5] for s in staged_l]).tolist() if staged_l else []  # ONE readback for the whole state dict
+        ords, nnzs, rows_l, cols_l, vals_l = [], [], [], [], []
+        maxima = torch.zeros(2, dtype=torch.int64, device=dev)
+        cs = self._copy_stream(dev)
+        for (ordinal, snap, value2d, vcode, scode, _, ws, host), nnz in zip(staged_l, counts):
+            if nnz == 0:
+                continue  # unchanged tensor: the host snapshot is already right, nothing travels back
+            rows = torch.empty(nnz, dtype=torch.int64, device=dev)
+            cols = torch.empty(nnz, dtype=torch.int64, device=dev)
+            vals = torch.empty(nnz, dtype=snap.dtype, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.rlx_patch_emit(value2d.data_ptr(), vcode, snap.data_ptr(), scode, value2d.numel(),
+                                              snap.shape[1], int(self.delta_encoding), ws.data_ptr(), nnz, rows.data_ptr(),
+                                              cols.data_ptr(), vals.data_ptr(), maxima.data_ptr(), _stream_ptr(dev)),
+                           "rlx_patch_emit")
+            # the emit launch brought the staged copy up to date: it IS the new snapshot -> one sequential write-back
+            cs.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(cs):
+                host.copy_(snap, non_blocking=True)
+            snap.record_stream(cs)
+            ords.append(ordinal), nnzs.append(nnz), rows_l.append(rows), cols_l.append(cols)
+            vals_l.append(vals.view(torch.uint8))
+        cs.synchronize()  # the host snapshot is complete when create_patch returns (the next call may start right away)
+        tdev = self.transport_device or dev
+        if not rows_l:
+            return EmptyWeightPatch(torch.tensor(version, dtype=torch.int64, device=tdev))
+        max_r, max_c = maxima.tolist()
+        return WeightPatch(
+            version=torch.tensor(version, dtype=torch.int64, device=tdev),
+            ordinals=torch.tensor(ords, dtype=torch.int32, device=tdev),
+            nnz_per_tensor=torch.tensor(nnzs, dtype=torch.int32, device=tdev),
+            rows=torch.cat(rows_l).to(_index_dtype_for(max_r)).to(tdev),
+            cols=torch.cat(cols_l).to(_index_dtype_for(max_c)).to(tdev),
+            values=torch.cat(vals_l).to(tdev))
+
+
+def create_patch_builder(snapshot, ordered_keys, param_names_need_sync, original_shapes, snapshot_device, transport_device,
+                         delta_encoding):
+    """PatchBuilder.create (patch_syncer.py:372-404): host snapshot -> CPUSnapshotPatchBuilder, accelerator -> the same-device one."""
+    snapshot_device = torch.device(snapshot_device)
+    if snapshot_device.type == "cpu":
+        return CPUSnapshotPatchBuilder(snapshot, ordered_keys, param_names_need_sync, original_shapes, transport_device, delta_encoding)
+    if snapshot_device.type == "cuda":
+        return PatchBuilder(snapshot, ordered_keys, param_names_need_sync, original_shapes, transport_device, delta_encoding)
+    raise ValueError(f"Unsupported snapshot device: {snapshot_device}")
+
+
 class PatchWeightSyncer:
     """init_receiver / init_sender / sync / apply with the reference's semantics; send / recv are plain callables (or
     awaitables are not needed here: workers of one rank share a process and cross-rank transport is a collective)."""
@@ -223,10 +376,14 @@ class PatchWeightSyncer:
     def __init__(self, snapshot_device="cuda", transport_device=None, delta_encoding: bool = True,
                  compression_algorithm: str = "none", init_sync_enabled: bool = False, init_sync_prefixes=None,
                  init_sync_bucket_size: int = 128 * 1024 * 1024):
-        if compression_algorithm != "none":
-            raise NotImplementedError("only compression_algorithm='none' exists on MI355X (nvCOMP is NVIDIA-only)")
-        if torch.device(snapshot_device).type != "cuda":
-            raise NotImplementedError("the HIP patch builder keeps its snapshot on the accelerator (snapshot_device='cuda')")
+        from .compressor import PatchCompressor
+        self.snapshot_device = torch.device(snapshot_device)
+        if self.snapshot_device.type not in ("cuda", "cpu"):
+            raise ValueError(f"Unsupported snapshot device: {snapshot_device}")
+        self.compression_algorithm = compression_algorithm
+        # patch_syncer.py:806-809; the compressed transport needs accelerator tensors (like the reference's nvCOMP one)
+        self.compressor = PatchCompressor.create(compression_algorithm=compression_algorithm,
+                                                 transport_device=transport_device if transport_device is not None else "cuda")
         self.snapshot = None
         self.ordered_keys: Optional[list] = None
         self.original_shapes: Optional[dict] = None
@@ -331,10 +488,15 @@ class PatchWeightSyncer:
             if shape != self.original_shapes[key]:
                 raise ValueError(f"Shape mismatch for key {key}: expected {self.original_shapes[key]}, got {shape}")
             if is_sender:
-                snapshot[key] = view.to(dtype=dtypes[key], copy=True).contiguous()
+                snap = view.to(dtype=dtypes[key], copy=True).contiguous()
+                if self.snapshot_device.type == "cpu":  # pinned: the per-tensor staging copies are asynchronous
+                    host = torch.empty(snap.shape, dtype=snap.dtype, device="cpu", pin_memory=torch.cuda.is_available())
+                    host.copy_(snap)
+                    snap = host
+                snapshot[key] = snap
         self.snapshot = snapshot if is_sender else None
-        self.patch_builder = PatchBuilder(self.snapshot, self.ordered_keys, list(param_names_need_sync),
-                                          self.original_shapes, self.transport_device, self.delta_encoding)
+        self.patch_builder = create_patch_builder(self.snapshot, self.ordered_keys, list(param_names_need_sync), self.original_shapes,
+                                                  self.snapshot_device, self.transport_device, self.delta_encoding)
         self._sender_initialized = True
 
     def create_patch(self, state_dict: dict, version):
@@ -343,7 +505,9 @@ class PatchWeightSyncer:
         return self.patch_builder.create_patch(state_dict, version)
 
     def sync(self, state_dict: dict, send: Callable, version) -> None:
-        send(self.create_patch(state_dict, version))
+        """patch_syncer.py:1018-1041: build the patch, compress it (an EmptyWeightPatch travels as it is), send."""
+        patch = self.create_patch(state_dict, version)
+        send(patch if isinstance(patch, EmptyWeightPatch) else self.compressor.compress(patch))
 
     @torch.no_grad()
     def apply(self, model_or_state_dict, recv: Callable) -> int:
@@ -351,6 +515,7 @@ class PatchWeightSyncer:
         payload = recv()
         if isinstance(payload, EmptyWeightPatch):
             return int(payload.version.item())
+        payload = self.compressor.decompress(payload)  # :1060 (identity for compression "none")
         from .bucket_syncer import target_state, weights_changed
         state = target_state(model_or_state_dict)
         nnzs = payload.nnz_per_tensor.tolist()

@@ -219,7 +219,10 @@ class LocalXgmiGroup:
     stream of the same device.  Test / bring-up tool for the exchange protocol at W = 2 .. 8 on a one-GPU box (no IPC, no
     torch.distributed); the hand-shake runs as its own one-wave launch so that W spinning grids never fill the device."""
 
-    def __init__(self, world: int, n_max: int, device, algo: str = "direct", timeout_ms: int = 20000, mem_kind: int = 0):
+    def __init__(self, world: int, n_max: int, device, algo: str = "direct", timeout_ms: int = 20000, mem_kind: int = 0,
+                 streams=None):
+        """``streams``: reuse these (one per rank) instead of creating new ones -- every "rank" needs a hardware queue of its own
+        (GPU_MAX_HW_QUEUES >= world), and a process that keeps creating streams eventually shares queues between them."""
         self._lib = _lib.load()
         self.world, self.n_max, self.device = int(world), int(n_max), torch.device(device)
         self.comms = []
@@ -234,7 +237,8 @@ class LocalXgmiGroup:
             _lib.check(self._lib.rlx_xgmi_connect_local(arr, world), "rlx_xgmi_connect_local")
             for c in self.comms:
                 _lib.check(self._lib.rlx_xgmi_configure(c, XgmiAllReduce._ALGOS[algo], 1, 0), "rlx_xgmi_configure")
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(world)]
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream(self.device) for _ in range(world)]
+        assert len(self.streams) == world
         self._ws = [torch.empty(self._lib.rlx_adamw_workspace_bytes(self.n_max), dtype=torch.uint8, device=self.device)
                     for _ in range(world)]
 

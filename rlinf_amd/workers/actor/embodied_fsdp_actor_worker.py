@@ -29,6 +29,22 @@ from ..common import Worker
 CRITIC_EXPLAINED_VARIANCE_KEY = "critic/explained_variance"
 
 
+def _host_randperm(n: int, generator: torch.Generator) -> torch.Tensor:
+    """torch.randperm on the host with the caller's generator -- the reference's own call (nested_dict_process.py:272-285,
+    env_worker.py:1519-1537), so the order is ITS order -- on ONE thread: the permutation itself is a serial Fisher-Yates walk of
+    the mt19937 stream (randperm_cpu), but torch first fills the arange through at::parallel_for, and above its 32768-element
+    grain that wakes the whole intra-op pool: measured 57-65 ms per call for 131072 elements against 0.9 ms single-threaded,
+    identical result (tests/test_end_to_end.py::test_single_thread_randperm_is_torchs_randperm)."""
+    old = torch.get_num_threads()
+    if old == 1:
+        return torch.randperm(n, generator=generator)
+    torch.set_num_threads(1)
+    try:
+        return torch.randperm(n, generator=generator)
+    finally:
+        torch.set_num_threads(old)
+
+
 class EmbodiedFSDPActor(Worker):
     ROLE = "actor"
 
@@ -292,7 +308,7 @@ class EmbodiedFSDPActor(Worker):
         for st in range(stages):
             # index arithmetic in numpy: torch's element-wise CPU ops fan out over every core of the host above 32768 elements
             # (measured on the 256-core box: 30 ms per iteration for three int64 ops on 131072 elements)
-            local = (torch.randperm(T * n, generator=self._pipe_gen) if self._pipe_shuffle else torch.arange(T * n)).numpy()
+            local = (_host_randperm(T * n, self._pipe_gen) if self._pipe_shuffle else torch.arange(T * n)).numpy()
             parts.append((local // n) * B + st * n + (local % n))
         pkey = ("perm", N, epoch)
         if pkey not in self._ws:
@@ -315,7 +331,7 @@ class EmbodiedFSDPActor(Worker):
         elif pkey not in self._ws:  # the reference re-seeds the generator on every call: the permutation never changes
             g = torch.Generator()
             g.manual_seed(int(self.cfg.actor.seed) + self._rank)
-            self._ws[pkey] = torch.randperm(N, generator=g).to(self.device)
+            self._ws[pkey] = _host_randperm(N, g).to(self.device)
         perm = self._ws[pkey]
         names = ["states", "action", "prev_logprobs", "advantages", "prev_values"]
         src = [b["forward_inputs"]["states"], b["forward_inputs"]["action"], b["prev_logprobs"], b["advantages"],

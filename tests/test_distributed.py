@@ -104,8 +104,9 @@ from rlinf_amd.scheduler.xgmi import LocalXgmiGroup
 W, algo = {world}, {algo!r}
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(7)
+streams = [torch.cuda.Stream(dev) for _ in range(W)]   # ONE hardware queue per "rank", reused by every group below
 for n in (287504, 4 * W + 4, 1030, 4 * 257 * W + 4):
-    grp = LocalXgmiGroup(W, n, dev, algo=algo, timeout_ms=15000)
+    grp = LocalXgmiGroup(W, n, dev, algo=algo, timeout_ms=15000, streams=streams)
     for it in range(5):
         xs = [torch.randn(1 + (r + it) % 3, n, device=dev, generator=g) for r in range(W)]
         outs = [torch.full((n,), float("nan"), device=dev) for _ in range(W)]

@@ -99,6 +99,20 @@ def test_synthetic_env_chunk_steps_match_the_oracle_rollouts_indexing():
             assert torch.equal(infos["final_obs"]["states"], t["final_obs"][(k + 1) * C - 1])
 
 
+def test_single_thread_randperm_is_torchs_randperm():
+    """The learner's shuffles come from torch.randperm with the reference's generators; run on one thread (the multi-threaded
+    arange fill in front of the serial shuffle costs ~60 ms per call above 32768 elements) they are the same permutations, from
+    the same generator state, and leave the generator where torch leaves it."""
+    from rlinf_amd.workers.actor.embodied_fsdp_actor_worker import _host_randperm
+    for n in (10, 32768, 32769, 131072):
+        g1, g2 = torch.Generator().manual_seed(1234), torch.Generator().manual_seed(1234)
+        threads = torch.get_num_threads()
+        a, a2 = _host_randperm(n, g1), _host_randperm(n, g1)
+        b, b2 = torch.randperm(n, generator=g2), torch.randperm(n, generator=g2)
+        assert torch.equal(a, b) and torch.equal(a2, b2) and torch.equal(g1.get_state(), g2.get_state())
+        assert torch.get_num_threads() == threads
+
+
 def test_worker_peers_are_scoped_to_their_configuration():
     """A worker launched by another runner / tool with a different configuration is not a peer (its model must never be adopted
     silently), and a runner that is closed leaves nothing behind."""

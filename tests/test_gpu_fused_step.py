@@ -186,8 +186,20 @@ def test_ppo_step_two_action_chunks(M, case, bf16):
     for name, p in ora.named_parameters():
         if p.grad is not None:
             want[pol.offsets[name]:pol.offsets[name] + p.numel()] = p.grad.reshape(-1)
-    if bf16:  # operand rounding: bounded like the C = 1 bf16 gradient (tests/test_end_to_end_bench_config.py), relative L2
-        assert float((got - want).norm() / want.norm()) < 0.05
+    if bf16:  # DERIVED bound, as for C = 1: no farther from the f32 gradient than twice the reference arithmetic under bf16 autocast
+        for p in ora.parameters():
+            p.grad = None
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out16 = ora.evaluate(mb["states"], mb["action"])
+        out16 = {k: v.float() for k, v in out16.items()}
+        sh16 = O.shape_loss_inputs(out16["logprobs"], mb["prev_logprobs"], mb["advantages"], logprob_type, A, loss_mask=mb.get("loss_mask"),
+                                   values=out16["values"], prev_values=mb["prev_values"], returns=mb["returns"], reward_type=reward_type)
+        O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **sh16)[0].backward()
+        auto = torch.zeros_like(got)
+        for name, p in ora.named_parameters():
+            auto[pol.offsets[name]:pol.offsets[name] + p.numel()] = p.grad.reshape(-1)
+        rel, rel_auto = float((got - want).norm() / want.norm()), float((auto - want).norm() / want.norm())
+        assert rel <= 2.0 * rel_auto + 1e-3, (rel, rel_auto)
     else:
         scale = float(want.abs().max())
         for name, p in ora.named_parameters():

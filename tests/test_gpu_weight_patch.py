@@ -166,3 +166,135 @@ def test_unaligned_views_and_wide_sender():
     down.send(patch)
     rx.apply(recv_state, down.recv)
     assert _same_bits(recv_state["w"], w2) and _same_bits(recv_state["m"], m2.to(torch.bfloat16))
+
+
+# ---- f3: the compression stage (csrc/zplane_codec.hip behind PatchCompressor) and the host-snapshot builder ------------------
+def _zplane(t: torch.Tensor):
+    from rlinf_amd.hybrid_engines.weight_syncer import ZPlaneCompressor
+    c = ZPlaneCompressor("rlx_zplane", "cuda")
+    out, length, keep = c._launch_compress(t)
+    return c, out[:int(length.item())].clone()
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.int16, torch.int32, torch.int64, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n", [0, 1, 63, 4095, 4096, 4097, 70000])
+def test_zplane_codec_streams_are_byte_identical_to_the_numpy_restatement(dtype, n):
+    """HIP encoder == numpy encoder byte for byte (all four plane modes occur: zeros, sparse -> masks, constant runs -> XOR-filtered
+    masks, noise -> raw), HIP decoder reads the numpy stream, numpy decoder reads the HIP stream, and both restore the input."""
+    import numpy as np
+
+    from oracle import zplane_oracle as Z
+    g = torch.Generator().manual_seed(n + 17)
+    es = torch.empty((), dtype=dtype).element_size()
+    raw = torch.randint(0, 256, (n * es,), generator=g, dtype=torch.uint8)
+    quarter = max(n * es // 4, 1)
+    raw[quarter:2 * quarter] = 0                                                          # all-zero planes
+    raw[2 * quarter:3 * quarter] *= (torch.rand(len(raw[2 * quarter:3 * quarter]), generator=g) < 0.04).to(torch.uint8)   # sparse
+    raw[3 * quarter:] = 5                                                                 # a constant run
+    host = raw.clone().view(dtype) if n else torch.empty(0, dtype=dtype)
+    c, stream = _zplane(host.to(DEV))
+    want = Z.compress(raw.numpy(), es)
+    assert stream.numel() == want.size and np.array_equal(stream.cpu().numpy(), want), (dtype, n, stream.numel(), want.size)
+    code = torch.tensor({torch.uint8: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3, torch.bfloat16: 5, torch.float32: 6}[dtype],
+                        dtype=torch.int8)
+    c._pending_status = []
+    back = c._decompress_tensor(torch.from_numpy(want).to(DEV), code)      # numpy stream -> HIP decoder
+    assert back.dtype == dtype and _same_bits(back.cpu(), host)
+    assert not c._pending_status or int(torch.cat(c._pending_status).max()) == 0
+    back_np, es2 = Z.decompress(stream.cpu().numpy())                      # HIP stream -> numpy decoder
+    assert es2 == es and np.array_equal(back_np, raw.numpy())
+
+
+def test_zplane_decoder_rejects_truncated_and_foreign_streams():
+    from rlinf_amd._lib import RlxError
+    c, stream = _zplane(torch.arange(20000, dtype=torch.int32, device=DEV) % 300)
+    code = torch.tensor(2, dtype=torch.int8)
+    c._pending_status = []
+    with pytest.raises(RlxError, match="does not match"):
+        c._decompress_tensor(stream[:-8].clone(), code)            # shorter than its header says
+    with pytest.raises(RlxError, match="does not match"):
+        c._decompress_tensor(stream, torch.tensor(3, dtype=torch.int8))   # dtype code of another width
+    bad = stream.clone()
+    bad[0] = 0
+    with pytest.raises(RlxError, match="not an RLXZ v1 stream"):
+        c._decompress_tensor(bad, code)
+    # a directory entry pointing past the end: the kernel reads nothing out of bounds and raises the status word
+    bad = stream.clone()
+    bad[24:32] = torch.tensor([0xF0, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x7F], dtype=torch.uint8, device=DEV)  # mode 1, offset 2^62 - 16
+    c._pending_status = []
+    c._decompress_tensor(bad, code)
+    assert int(torch.cat(c._pending_status).max()) != 0
+
+
+@pytest.mark.parametrize("algorithm", ["rlx_zplane", "nvcomp_lz4"])
+@pytest.mark.parametrize("density,delta", [(1e-3, True), (0.3, True), (1.0, True), (0.05, False)])
+def test_compressed_patch_transport_round_trip(algorithm, density, delta):
+    """PatchWeightSyncer with a compression algorithm: sync() sends a CompressedWeightPatch (the reference's fields and dtype
+    codes), apply() restores the receiver bit for bit; the decompressed patch equals the uncompressed builder's patch field by
+    field; sparse and DENSE updates (column deltas all 1 -> the XOR-filtered mode) really shrink the index streams."""
+    from rlinf_amd.hybrid_engines.weight_syncer import CompressedWeightPatch
+    g = torch.Generator(device=DEV).manual_seed(4)
+    base = torch.randn(1031, 4099, device=DEV, generator=g).bfloat16()
+    new = torch.where(torch.rand(base.shape, device=DEV, generator=g) < density, base * 2 + 1, base)
+    state, recv_state = {"w": base.clone(), "b": torch.zeros(5, device=DEV)}, {"w": base.clone(), "b": torch.zeros(5, device=DEV)}
+    up, down = Pipe(), Pipe()
+    rx = PatchWeightSyncer(delta_encoding=delta, compression_algorithm=algorithm)
+    tx = PatchWeightSyncer(delta_encoding=delta, compression_algorithm=algorithm)
+    plain = PatchWeightSyncer(delta_encoding=delta)
+    rx.init_receiver(recv_state, down.recv, up.send)
+    meta = up.q[0]
+    tx.init_sender(state, ["w", "b"], down.send, up.recv)
+    plain.init_sender({k: v.clone() for k, v in state.items()}, ["w", "b"], None, lambda: meta)
+    want = plain.create_patch({"w": new, "b": state["b"]}, 3)
+    tx.sync({"w": new, "b": state["b"]}, down.send, 3)
+    payload = down.q[0]
+    assert isinstance(payload, CompressedWeightPatch)
+    assert payload.rows_dtype_code.dtype == torch.int8 and int(payload.values_dtype_code) == 0     # value bytes travel as uint8
+    assert int(payload.rows_dtype_code) == {torch.uint8: 0, torch.int32: 2, torch.int64: 3}[want.rows.dtype]
+    got = rx.compressor.decompress(payload)
+    for f in FIELDS:
+        assert getattr(got, f).dtype == getattr(want, f).dtype and torch.equal(getattr(got, f), getattr(want, f)), f
+    index_bytes = want.rows.numel() * want.rows.element_size() + want.cols.numel() * want.cols.element_size()
+    packed = payload.rows_compressed.numel() + payload.cols_compressed.numel()
+    if delta:
+        assert packed < 0.5 * index_bytes, (density, packed, index_bytes)
+    assert payload.values_compressed.numel() <= want.values.numel() + 24 + 16 * (want.values.numel() // 4096 + 1)
+    assert rx.apply(recv_state, down.recv) == 3
+    assert _same_bits(recv_state["w"], new)
+    # an unchanged state: the EmptyWeightPatch travels uncompressed (patch_syncer.py:1036-1041)
+    tx.sync({"w": new, "b": state["b"]}, down.send, 4)
+    assert isinstance(down.q[0], EmptyWeightPatch) and rx.apply(recv_state, down.recv) == 4
+
+
+@pytest.mark.parametrize("delta", [True, False])
+def test_cpu_snapshot_builder_matches_the_same_device_builder(delta):
+    """snapshot_device="cpu" (CPUSnapshotPatchBuilder, patch_syncer.py:416-640): the snapshot sits in pinned host memory, is staged
+    one tensor ahead and written back only for tensors that changed -- the patches equal the same-device builder's byte for
+    byte over three syncs (changes, no changes, changes again), and the host snapshot ends up equal to the sender's weights."""
+    before, after = patch_states(5)
+    names = list(before)
+    recv_state = {k: v.clone().to(DEV) for k, v in before.items()}
+    up, down = Pipe(), Pipe()
+    rx = PatchWeightSyncer(delta_encoding=delta)
+    rx.init_receiver(recv_state, down.recv, up.send)
+    meta = up.q[0]
+    dev_tx, cpu_tx = PatchWeightSyncer(delta_encoding=delta), PatchWeightSyncer(delta_encoding=delta, snapshot_device="cpu")
+    dev_tx.init_sender({k: v.to(DEV) for k, v in before.items()}, names, None, lambda: meta)
+    cpu_tx.init_sender({k: v.to(DEV) for k, v in before.items()}, names, None, lambda: meta)
+    assert all(t.device.type == "cpu" and t.is_pinned() for t in cpu_tx.snapshot.values())
+    after2 = {k: v.clone() for k, v in after.items()}
+    after2["backbone.weight"][3, 7] = 1.0          # replaces the NaN (torch.ne reports a NaN as changed on every sync)
+    after3 = {k: (v + 1 if v.is_floating_point() and v.numel() > 8 else v.clone()) for k, v in after2.items()}
+    for version, st in ((1, after), (2, after2), (3, after2), (4, after3)):
+        dev_state = {k: v.to(DEV) for k, v in st.items()}
+        a, b = dev_tx.create_patch(dev_state, version), cpu_tx.create_patch(dev_state, version)
+        assert type(a) is type(b), version
+        if isinstance(a, WeightPatch):
+            for f in FIELDS:
+                assert getattr(a, f).dtype == getattr(b, f).dtype and _same_bits(getattr(a, f), getattr(b, f)), (version, f)
+        else:
+            assert version == 3 and int(b.version) == 3
+    for k, v in after3.items():
+        assert _same_bits(cpu_tx.snapshot[k], dev_tx.snapshot[k].cpu()), k
+    down.send(cpu_tx.create_patch({k: v.to(DEV) for k, v in before.items()}, 5))     # and back again, applied by the kernels
+    assert rx.apply(recv_state, down.recv) == 5

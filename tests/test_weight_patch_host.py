@@ -98,10 +98,24 @@ def test_known_answers_of_the_reference_unit_tests():
 
 
 def test_syncer_argument_checks():
-    with pytest.raises(NotImplementedError, match="nvCOMP"):
-        PatchWeightSyncer(compression_algorithm="nvcomp_lz4")
-    with pytest.raises(NotImplementedError, match="accelerator"):
-        PatchWeightSyncer(snapshot_device="cpu")
+    from rlinf_amd.hybrid_engines.weight_syncer import CPUSnapshotPatchBuilder, IdentityCompressor, PatchCompressor, ZPlaneCompressor
+    from rlinf_amd.hybrid_engines.weight_syncer.patch_syncer import create_patch_builder
+    # PatchCompressor.create (compressor.py:70-98): "none", the GPU codec under its own name and under the reference's name for
+    # "the GPU codec", an unknown name ignored with a warning
+    assert isinstance(PatchWeightSyncer(compression_algorithm="none").compressor, IdentityCompressor)
+    for name in ("rlx_zplane", "nvcomp_lz4"):
+        assert isinstance(PatchWeightSyncer(compression_algorithm=name).compressor, ZPlaneCompressor)
+    with pytest.warns(UserWarning, match="is ignored for now"):
+        assert isinstance(PatchCompressor.create("zstd", "cuda"), IdentityCompressor)
+    with pytest.raises(ValueError, match="requires transport_device to be the accelerator"):
+        PatchCompressor.create("rlx_zplane", "cpu")
+    # PatchBuilder.create (:372-404)
+    assert isinstance(create_patch_builder(None, ["a"], ["a"], {}, "cpu", None, True), CPUSnapshotPatchBuilder)
+    assert type(create_patch_builder(None, ["a"], ["a"], {}, "cuda", None, True)) is PatchBuilder
+    with pytest.raises(ValueError, match="Unsupported snapshot device"):
+        PatchWeightSyncer(snapshot_device="meta")
+    with pytest.raises(ValueError, match="requires snapshots to be on CPU"):
+        CPUSnapshotPatchBuilder({"a": torch.zeros(1, 1, device="meta")}, ["a"], ["a"], {}, None, True)
     with pytest.raises(ValueError, match="must not be empty"):
         PatchBuilder({}, ["a"], [], {}, None, True)
     s = PatchWeightSyncer()
@@ -182,3 +196,49 @@ def test_full_protocol_reference_sender_to_reference_receiver_vs_oracle(delta, m
         want = target[rename[k]]
         same = (have == want) | ((have != have) & (want != want)) if want.is_floating_point() else have == want
         assert have.dtype == want.dtype and bool(same.all()), k
+
+
+def test_compressed_transport_contract_matches_the_reference_tables():
+    """The dtype-code table and the CompressedWeightPatch field list ARE the wire contract (compressor.py:35-46,
+    patch_syncer.py:205-250): checked against the reference's own module where it is present."""
+    import dataclasses
+
+    from rlinf_amd.hybrid_engines.weight_syncer import CompressedWeightPatch
+    from rlinf_amd.hybrid_engines.weight_syncer.compressor import CODE_TO_DTYPE, DTYPE_TO_CODE
+    assert DTYPE_TO_CODE == {torch.uint8: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3, torch.float16: 4, torch.bfloat16: 5,
+                             torch.float32: 6, torch.float64: 7} and CODE_TO_DTYPE[5] is torch.bfloat16
+    names = [f.name for f in dataclasses.fields(CompressedWeightPatch)]
+    assert names == ["version", "ordinals", "nnz_per_tensor", "rows_compressed", "cols_compressed", "values_compressed",
+                     "rows_dtype_code", "cols_dtype_code", "values_dtype_code"]
+    from oracle import reference_loader
+    if reference_loader.available() and reference_loader.REFERENCE_ROOT == "/root/reference":
+        m = reference_loader.load_weight_syncer()
+        import sys
+        comp = sys.modules["rlinf.hybrid_engines.weight_syncer.compressor"]
+        assert comp._NVCOMP_DTYPE_TO_CODE == DTYPE_TO_CODE
+        assert [f.name for f in dataclasses.fields(m.CompressedWeightPatch)] == names
+
+
+def test_zplane_oracle_round_trip_and_known_sizes():
+    """The numpy restatement of the RLXZ format on its own (CPU): decode(encode(x)) == x over element sizes, ragged lengths and
+    the four kinds of plane (noise, zeros, sparse, constant run), and the sizes the format promises: all-zero planes cost only
+    their directory entry, a constant run is caught by the XOR filter, noise falls back to raw + 8 bytes per plane-block."""
+    import numpy as np
+
+    from oracle import zplane_oracle as Z
+    rng = np.random.default_rng(0)
+    for es in (1, 2, 4, 8):
+        for n in (0, 1, 63, 4095, 4096, 4097, 9000):
+            kinds = (rng.integers(0, 256, n * es, dtype=np.uint8), np.zeros(n * es, np.uint8),
+                     ((rng.random(n * es) < 0.05) * rng.integers(1, 255, n * es)).astype(np.uint8), np.full(n * es, 7, np.uint8))
+            for k, d in enumerate(kinds):
+                s = Z.compress(d, es)
+                back, es2 = Z.decompress(s)
+                assert es2 == es and np.array_equal(back, d), (es, n, k)
+                nb = (n + 4095) // 4096
+                if k == 1:
+                    assert s.size == 24 + 8 * nb * es
+                if k == 3 and n >= 4096:
+                    assert s.size < d.size / 20
+                if k == 0 and n >= 4096:
+                    assert s.size <= 24 + 8 * nb * es + nb * es * 4096
