@@ -263,6 +263,29 @@ __device__ __forceinline__ f32x2 tanh2_b(f32x2 x) {
     return __builtin_elementwise_fma(q, f32x2{-2.f, -2.f}, f32x2{1.f, 1.f});
 }
 
+// A wave's tile values in the accumulator layout (lane (r16, kq) holds rows 4 kq .. 4 kq + 3 of column c = col0 + r16) -> the
+// row-major bf16 slab, as 32-BIT words.  As four ds_write_b16 per tile this was the kernel's main source of LDS bank conflicts
+// (round-2 counters: SQ_LDS_BANK_CONFLICT 30 % of the LDS-active cycles): stores bank on (a / 4) mod 32 within 32-lane groups,
+// the 136-dword row stride puts rows r and r + 4 (lanes kq and kq + 1 of one group) on the same banks, and two lanes share every
+// dword.  Instead neighbouring lanes swap halves (one DPP quad_perm [1, 0, 3, 2]): the even lane then holds columns (c, c + 1) of
+// rows 4 kq, 4 kq + 1 and its odd neighbour the same columns of rows 4 kq + 2, 4 kq + 3 -- two ds_write_b32 per tile.  Which of its
+// two rows a lane stores FIRST alternates with kq: one instruction's 32-lane group then covers rows {0, 2, 5, 7} (mod 8), i.e. row
+// offsets {0, 16, 8, 24} (mod 32 dwords) x 8 dwords each = all 32 banks once.  Same values, same addresses: bit-identical slab.
+__device__ __forceinline__ void store_slab_quad(__bf16* Xb, int row_base /* rt * 16 */, int col0 /* multiple of 16 */, bf16x4 v) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4, odd = lane & 1;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 p = __builtin_bit_cast(u32x2, v);                     // p.x = rows 0, 1 of this column; p.y = rows 2, 3
+    const unsigned keep = odd ? p.y : p.x, send = odd ? p.x : p.y;
+    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    const unsigned lo = odd ? recv : keep, hi = odd ? keep : recv;   // lo: the even column's two rows, hi: the odd column's
+    const unsigned w0 = __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // first row of the pair:  (lo.low16, hi.low16)
+    const unsigned w1 = __builtin_amdgcn_perm(hi, lo, 0x07060302u);  // second row of the pair: (lo.high16, hi.high16)
+    const int row = row_base + 4 * kq + 2 * odd, flip = kq & 1;
+    unsigned* base = reinterpret_cast<unsigned*>(Xb + col0 + (r16 & ~1));
+    base[(row + flip) * (XSB / 2)] = flip ? w1 : w0;
+    base[(row + 1 - flip) * (XSB / 2)] = flip ? w0 : w1;
+}
+
 // forward hidden-layer epilogue: h = bf16(tanh(acc + bias)) -> slab; KEEP: the rounded value also goes to `kept` (registers) or
 // `keep_lds` (lane-linear LDS words) for the backward sweep's 1 - h^2, and to the k-tiled image `dst`.  `bias` is an LDS image.
 template <int RT, int NW, bool KEEP>
@@ -270,27 +293,25 @@ __device__ __forceinline__ void epilogue_tanh_b(const f32x4 (&acc)[RT][GeoB<RT, 
                                                 bf16x4 (*kept)[GeoB<RT, NW>::CT], bf16x4* keep_lds, __bf16* __restrict__ dst, int nrb,
                                                 long long m0) {
     typedef GeoB<RT, NW> G;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, kq = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15;
     bf16x4 hloc[KEEP ? RT : 1][G::CT];
     float b[G::CT];
 #pragma unroll
     for (int ct = 0; ct < G::CT; ++ct) b[ct] = bias[wave * 16 * G::CT + ct * 16 + r16];
 #pragma unroll
     for (int ct = 0; ct < G::CT; ++ct) {
-        const int col = wave * 16 * G::CT + ct * 16 + r16;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+            bf16x4 hv;
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
                 const f32x2 h = tanh2_b(f32x2{acc[rt][ct][r] + b[ct], acc[rt][ct][r + 1] + b[ct]});
-                const __bf16 h0 = (__bf16)h.x, h1 = (__bf16)h.y;
-                Xb[(rt * 16 + 4 * kq + r) * XSB + col] = h0;
-                Xb[(rt * 16 + 4 * kq + r + 1) * XSB + col] = h1;
-                if constexpr (KEEP) {
-                    hloc[rt][ct][r] = h0;
-                    hloc[rt][ct][r + 1] = h1;
-                }
+                hv[r] = (__bf16)h.x;
+                hv[r + 1] = (__bf16)h.y;
             }
+            store_slab_quad(Xb, rt * 16, wave * 16 * G::CT + ct * 16, hv);
+            if constexpr (KEEP) hloc[rt][ct] = hv;
+        }
     }
     if constexpr (KEEP) {
         if (dst != nullptr) store_tiles<RT, NW>(hloc, dst, nrb, m0);
@@ -840,8 +861,7 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = dv[rt][ct][r];
+            store_slab_quad(Xb, rt * 16, wave * 16 * CT + ct * 16, dv[rt][ct]);
     store_tiles<RT, NW>(dv, dzy + 2 * tg.mat(), tg.nrb, m0);
     lds_barrier();
     ts.mark();
@@ -857,11 +877,8 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
             for (int rt = 0; rt < RT; ++rt) {
                 const bf16x4 hk = KEEP_LDS ? sKeep[((l - 1) * RT * CT + rt * CT + ct) * G::NT + tid] : kept12[KEEP_LDS ? 0 : l - 1][rt][ct];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const __bf16 z = (__bf16)(acc[rt][ct][r] * dtanh_b(hk[r]));
-                    dv[rt][ct][r] = z;
-                    if (l == 2) Xb[(rt * 16 + 4 * kq + r) * XSB + wave * 16 * CT + ct * 16 + r16] = z;
-                }
+                for (int r = 0; r < 4; ++r) dv[rt][ct][r] = (__bf16)(acc[rt][ct][r] * dtanh_b(hk[r]));
+                if (l == 2) store_slab_quad(Xb, rt * 16, wave * 16 * CT + ct * 16, dv[rt][ct]);
             }
         store_tiles<RT, NW>(dv, dzy + (size_t)(l - 1) * tg.mat(), tg.nrb, m0);
         if (l == 2) lds_barrier();

@@ -83,6 +83,8 @@ class EmbodiedFSDPActor(Worker):
             # env rank feeding the learner rank of the same process both ranks are this rank
             self._pipe_gen = torch.Generator().manual_seed(int(a.get("seed", 1234)) + self._rank + self._rank * self._world_size)
             self._pipe_shuffle = bool(cfg.algorithm.get("shuffle_rollout", True))
+        self._perm_prefetch: dict = {}
+        self._perm_prefetch_state = None
 
     # ---- set-up ---------------------------------------------------------------------------------------------
     def init_worker(self):
@@ -155,7 +157,8 @@ class EmbodiedFSDPActor(Worker):
             "lr_scheduler": self.lr_scheduler.state_dict(),
             "rng": {"torch": torch.get_rng_state(),
                     "cuda": torch.cuda.get_rng_state(self.device) if self.device is not None and self.device.type == "cuda" else None,
-                    "pipeline_shuffle": self._pipe_gen.get_state() if self.use_training_pipeline else None},
+                    "pipeline_shuffle": ((self._perm_prefetch_state if self._perm_prefetch else self._pipe_gen.get_state())
+                                         if self.use_training_pipeline else None)},
             "version": self.version, "step": int(step), "world_size": self._world_size, "n_params": self.model.n_params,
         }
         torch.save(state, os.path.join(shard_dir, f"checkpoint_rank_{self._rank}.pt"))
@@ -191,6 +194,7 @@ class EmbodiedFSDPActor(Worker):
             torch.cuda.set_rng_state(state["rng"]["cuda"], self.device)
         if self.use_training_pipeline and state["rng"]["pipeline_shuffle"] is not None:
             self._pipe_gen.set_state(state["rng"]["pipeline_shuffle"])
+            self._perm_prefetch.clear()  # orders drawn ahead belong to the run that was replaced
         self.version = int(state["version"])
 
     # ---- trajectories -----------------------------------------------------------------------------------------
@@ -298,23 +302,46 @@ class EmbodiedFSDPActor(Worker):
         return res
 
     # ---- update -------------------------------------------------------------------------------------------------
-    def _pipeline_perm(self, T: int, B: int, epoch: int) -> torch.Tensor:
-        """pack_pipeline_micro_batches (env_worker.py:1519-1537): every stage's [T, B/stages] block flattened and shuffled on
-        its own, stage after stage, with a generator that is seeded ONCE -- a new order every call, written into the same
-        device buffer so that prepared launches / captured graphs keep reading the right rows."""
+    def _pipeline_perm_host(self, T: int, B: int) -> np.ndarray:
         stages = int(self.cfg.rollout.get("pipeline_stage_num", 1))
-        n, N = B // stages, T * B
+        n = B // stages
         parts = []
         for st in range(stages):
             # index arithmetic in numpy: torch's element-wise CPU ops fan out over every core of the host above 32768 elements
             # (measured on the 256-core box: 30 ms per iteration for three int64 ops on 131072 elements)
             local = (_host_randperm(T * n, self._pipe_gen) if self._pipe_shuffle else torch.arange(T * n)).numpy()
             parts.append((local // n) * B + st * n + (local % n))
+        return np.concatenate(parts)
+
+    def _pipeline_perm(self, T: int, B: int, epoch: int) -> torch.Tensor:
+        """pack_pipeline_micro_batches (env_worker.py:1519-1537): every stage's [T, B/stages] block flattened and shuffled on
+        its own, stage after stage, with a generator that is seeded ONCE -- a new order every call, written into the same
+        device buffer so that prepared launches / captured graphs keep reading the right rows.  The host side of it (a serial
+        Fisher-Yates walk, ~1 ms per 131072 rows) is normally already done: _prefetch_pipeline_perms drew this iteration's
+        orders while the GPU was still busy with the previous iteration."""
+        N = T * B
+        host = self._perm_prefetch.pop((T, B, epoch), None)
+        if host is None:
+            if self._perm_prefetch:  # a shape change: orders drawn ahead for another shape are void -> rewind the generator
+                self._pipe_gen.set_state(self._perm_prefetch_state)
+                self._perm_prefetch.clear()
+            host = torch.from_numpy(self._pipeline_perm_host(T, B))
         pkey = ("perm", N, epoch)
         if pkey not in self._ws:
             self._ws[pkey] = torch.empty(N, dtype=torch.int64, device=self.device)
-        self._ws[pkey].copy_(torch.from_numpy(np.concatenate(parts)), non_blocking=False)
+        self._ws[pkey].copy_(host, non_blocking=False)
         return self._ws[pkey]
+
+    def _prefetch_pipeline_perms(self, T: int, B: int, n_epochs: int) -> None:
+        """Draw the NEXT iteration's shuffles now -- the GPU work of this iteration is enqueued and the host would otherwise sit
+        in the metric read-back -- in the order the next iteration would draw them (epoch 0 .. E - 1, stages inside): the
+        generator stream is consumed exactly as without the prefetch.  A checkpoint written in between saves the generator's
+        state from BEFORE the draw (``_perm_prefetch_state``), and loading one drops the prefetched orders."""
+        if not (self.use_training_pipeline and self._pipe_shuffle) or self._perm_prefetch:
+            return
+        self._perm_prefetch_state = self._pipe_gen.get_state()
+        for e in range(n_epochs):
+            self._perm_prefetch[(T, B, e)] = torch.from_numpy(self._pipeline_perm_host(T, B))
 
     def _flatten_and_shuffle(self, b: dict | None = None, epoch: int = 0, n_epochs: int = 1, perm_ready: bool = False):
         """process_nested_dict_for_train (rlinf/utils/nested_dict_process.py:272-285): one randperm per
@@ -563,54 +590,90 @@ class EmbodiedFSDPActor(Worker):
         self._lr_log.extend([(self._lrs[0], self._lrs[1])] * len(steps))
         return len(steps)
 
+    def _pipeline_schedule(self, E: int, n_e: int, passes: int) -> list:
+        """Order in which the learner trains the (pass, global batch) pairs of one iteration in pipeline mode with E rollout epochs
+        of n_e global batches each: [(k, g)], pass k in [0, passes), global batch g in [0, E * n_e) -- g // n_e is its epoch.
+        This base class: every epoch's first pass as the epochs complete, then every stored global batch again, pass by pass,
+        oldest first.  PipelineEmbodiedFSDPActor derives the order from the reference's own queue logic instead."""
+        return [(0, g) for g in range(E * n_e)] + [(k, g) for k in range(1, passes) for g in range(E * n_e)]
+
     def _run_pipeline_epochs(self) -> dict:
         """runner.use_training_pipeline with rollout_epoch E > 1 (fsdp_actor_worker_pipeline.py:84-160 over the per-epoch sends of
-        env_worker.py:1324-1330).  For every epoch, as soon as ITS rollout is complete (the env worker's event; the rollout of
-        the next epoch keeps running on its own stream, with its own frozen weights): un-normalised GAE, statistics
-        normalisation over the epoch's batch, per-stage stateful shuffles, first training pass over the epoch's global batches.
-        Then the stored global batches again, pass by pass, oldest first (select_global_batch).  The reference's interleaving
-        of first and later passes depends on arrival timing; this is the schedule of a rollout that delivers each epoch just as
-        the previous one's first pass ends -- the one its overlap is built for."""
+        env_worker.py:1324-1330).  For every epoch, when the schedule first touches it and as soon as ITS rollout is complete (the
+        env worker's event; the rollout of the next epoch keeps running on its own stream, with its own frozen weights):
+        un-normalised GAE, statistics normalisation over the epoch's batch, per-stage stateful shuffles; then the global batches
+        in the order _pipeline_schedule gives -- by default every epoch's first pass on arrival and the stored global batches
+        again, pass by pass, oldest first (select_global_batch).  The reference's interleaving of first and later passes depends
+        on arrival timing; the default is the schedule of a rollout that delivers each epoch just as the previous one's first
+        pass ends -- the one its overlap is built for."""
         a, alg = self.cfg.actor, self.cfg.algorithm
         from ..common import peer
         E = self.pipeline_epochs
         env = peer("env", self.cfg)
         events = env.epoch_events if (env is not None and env.epoch_events) else None
         stream = torch.cuda.current_stream(self.device)
-        reds, plan, grads = [], None, None
         T0, B0 = self.rollout_batches[0]["prev_logprobs"].shape[:2]
         for e in range(E):  # the shuffles do not depend on the data: staged before the learner stream starts waiting on rollouts
             self._pipeline_perm(T0, B0, e)
-        for e, b in enumerate(self.rollout_batches):
+        reds, bigs, names_box = [None] * E, [None], [None]
+
+        def prepare(e: int):
+            b = self.rollout_batches[e]
             if events is not None:
                 stream.wait_event(events[e])
             self._advantages_for(b, metrics=False)
-            names = [k for k in ("rewards", "advantages", "returns") if b.get(k) is not None]
-            reds.append(ops.rollout_metrics([b[k] for k in names], b.get("loss_mask")))
+            names_box[0] = [k for k in ("rewards", "advantages", "returns") if b.get(k) is not None]
+            reds[e] = ops.rollout_metrics([b[k] for k in names_box[0]], b.get("loss_mask"))
             _, N_e, big = self._flatten_and_shuffle(b, epoch=e, n_epochs=E, perm_ready=True)
-            if plan is None:
-                N = N_e * E
-                n_mb, per_rank, accum = minibatch_plan(N, a.global_batch_size, a.micro_batch_size, self._world_size)
-                assert N_e % per_rank == 0, f"a rollout epoch ({N_e} rows) must hold whole global batches ({per_rank} rows per rank)"
-                n_e, epochs = N_e // per_rank, alg.get("update_epoch", 1)
-                key = ("metrics", n_mb * epochs, accum)
-                if key not in self._ws:
-                    self._ws[key] = (torch.zeros(n_mb * epochs * accum, PPO_OUT_FLOATS, device=self.device),
-                                     torch.zeros(n_mb * epochs, 2, device=self.device))
-                metrics_dev, norms_dev = self._ws[key]
-                micro = a.micro_batch_size
-                ws = self._minibatch_workspace(micro)
-                gkey = ("grads", micro, accum)
-                if gkey not in self._ws:
-                    self._ws[gkey] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
-                    self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
-                grads = self._ws[gkey]
-                self._grad_out_host = 1.0 / accum
-                assert self.fused_step and self.critic_warmup_steps == 0, "the pipeline learner runs the fused prepared step"
-                plan = self._run_update_prepared(big, N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro,
-                                                 only_build=True)
-            self._exec_plan(plan, grads, e * n_e, (e + 1) * n_e)  # first pass over THIS epoch's global batches
-        self._exec_plan(plan, grads, n_mb, None)  # passes 2 .. update_epoch over every stored global batch, oldest first
+            bigs[0] = big
+            return N_e
+
+        N_e = prepare(0)
+        N = N_e * E
+        n_mb, per_rank, accum = minibatch_plan(N, a.global_batch_size, a.micro_batch_size, self._world_size)
+        assert N_e % per_rank == 0, f"a rollout epoch ({N_e} rows) must hold whole global batches ({per_rank} rows per rank)"
+        n_e, epochs = N_e // per_rank, alg.get("update_epoch", 1)
+        key = ("metrics", n_mb * epochs, accum)
+        if key not in self._ws:
+            self._ws[key] = (torch.zeros(n_mb * epochs * accum, PPO_OUT_FLOATS, device=self.device),
+                             torch.zeros(n_mb * epochs, 2, device=self.device))
+        metrics_dev, norms_dev = self._ws[key]
+        micro = a.micro_batch_size
+        ws = self._minibatch_workspace(micro)
+        gkey = ("grads", micro, accum)
+        if gkey not in self._ws:
+            self._ws[gkey] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
+            self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
+        grads = self._ws[gkey]
+        self._grad_out_host = 1.0 / accum
+        assert self.fused_step and self.critic_warmup_steps == 0, "the pipeline learner runs the fused prepared step"
+        # the plan is laid out pass-major: entry k * n_mb + g trains global batch g for the (k + 1)-th time
+        plan = self._run_update_prepared(bigs[0], N, metrics_dev, norms_dev, grads, ws, n_mb, per_rank, accum, micro, only_build=True)
+        order = self._pipeline_schedule(E, n_e, epochs)
+        assert sorted(order) == [(k, g) for k in range(epochs) for g in range(n_mb)], "every (pass, global batch) exactly once"
+        prepared, seen, run = {0}, set(), []
+
+        def flush():
+            if run:
+                self._exec_plan(plan, grads, run[0], run[-1] + 1)
+                run.clear()
+
+        for k, g in order:
+            e = g // n_e
+            assert k == 0 or (k - 1, g) in seen, "a global batch is revisited only after its previous pass"
+            if e not in prepared:  # first touch of a later epoch: its advantage pass and shuffle go in front of its first batch
+                assert k == 0
+                flush()
+                prepare(e)
+                prepared.add(e)
+            idx = k * n_mb + g
+            if run and idx != run[-1] + 1:
+                flush()
+            run.append(idx)
+            seen.add((k, g))
+        flush()
+        self._prefetch_pipeline_perms(T0, B0, E)  # host work for the NEXT iteration, behind this iteration's enqueued launches
+        names = names_box[0]
         red = torch.stack(reds)  # [E, k, 4]: sums add, (-min, max) take the maximum
         self._deferred_rollout_metrics = self._metrics_from_reductions(
             names, torch.cat([red[:, :, :2].sum(dim=0), red[:, :, 2:].amax(dim=0)], dim=1))
@@ -640,6 +703,9 @@ class EmbodiedFSDPActor(Worker):
                 self._replay_or_capture(flat, N, metrics_dev, norms_dev, n_steps)
             else:
                 self._run_update(flat, N, metrics_dev, norms_dev)
+            if self.use_training_pipeline:
+                Tb, Bb = self.rollout_batch["prev_logprobs"].shape[:2]
+                self._prefetch_pipeline_perms(Tb, Bb, 1)  # host work for the NEXT iteration, behind the enqueued update phase
             out = self._collect_metrics(metrics_dev, norms_dev, accum)
             if self._xgmi is not None:
                 self._xgmi.check_status()  # a peer that never published its gradient: raise instead of training on garbage
