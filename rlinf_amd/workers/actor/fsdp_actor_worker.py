@@ -162,3 +162,307 @@ class TokenLearnerStep:
         if not use_kl:
             metrics.update({"actor/kl_loss": 0.0})
         return loss / gradient_accumulation, metrics
+
+
+# =================================================================================================================
+# FSDPActor: the loop AROUND the token step (rlinf/workers/actor/fsdp_actor_worker.py:434-1000), NO_SHARD data parallel
+# =================================================================================================================
+def seqlen_balanced_partitions(seqlen_list: list, k_partitions: int, equal_size: bool = True) -> list:
+    """get_seqlen_balanced_partitions (rlinf/utils/data_iter_utils.py:301-444): Karmarkar-Karp largest differencing -- the
+    partial partitions with the largest spread are merged first, largest set against smallest -- with the reference's tie rules
+    (sum, then size, then the (index, length) lists), so that every rank derives the SAME partitions from the gathered lengths.
+    Returns k sorted index lists."""
+    import heapq
+
+    assert len(seqlen_list) >= k_partitions, f"number of items:[{len(seqlen_list)}] < k_partitions:[{k_partitions}]"
+
+    class _Set:
+        __slots__ = ("sum", "items")
+
+        def __init__(self):
+            self.sum, self.items = 0, []
+
+        def key(self):
+            return (self.sum, len(self.items), self.items)
+
+    class _State:
+        def __init__(self, items):
+            self.sets = [_Set() for _ in range(k_partitions)]
+            for i, (idx, val) in enumerate(items):
+                self.sets[i].items.append((idx, val))
+                self.sets[i].sum += val
+            self.sets.sort(key=_Set.key, reverse=True)
+
+        def merge(self, other):
+            for i in range(k_partitions):
+                o = other.sets[k_partitions - 1 - i]
+                self.sets[i].items.extend(o.items)
+                self.sets[i].sum += o.sum
+            self.sets.sort(key=_Set.key, reverse=True)
+
+        def __lt__(self, other):  # a min-heap that pops the largest spread first, then the largest leading set
+            a, b = self.sets[0].sum - self.sets[-1].sum, other.sets[0].sum - other.sets[-1].sum
+            if a != b:
+                return a > b
+            return self.sets[0].key() > other.sets[0].key()
+
+    order = sorted((int(v), i) for i, v in enumerate(seqlen_list))
+    heap = []
+    if equal_size:
+        assert len(seqlen_list) % k_partitions == 0, f"{len(seqlen_list)} % {k_partitions} != 0"
+        for off in range(0, len(order), k_partitions):
+            heapq.heappush(heap, _State([(idx, v) for v, idx in order[off:off + k_partitions]]))
+    else:
+        for v, idx in order:
+            heapq.heappush(heap, _State([(idx, v)]))
+    while len(heap) > 1:
+        s0, s1 = heapq.heappop(heap), heapq.heappop(heap)
+        s0.merge(s1)
+        heapq.heappush(heap, s0)
+    parts = [sorted(idx for idx, _ in s.items) for s in heap[0].sets]
+    assert all(parts) and sorted(sum(parts, [])) == list(range(len(seqlen_list)))
+    return parts
+
+
+class FSDPActor:
+    """The reasoning learner around ``TokenLearnerStep``, with the reference's method names and call order
+    (fsdp_actor_worker.py): ``run_training`` (:860-939: collect the rank's rollout batch, advantages, optional sequence-length
+    balancing over the data-parallel group, masked normalisation, seeded shuffle into ``n_minibatches`` global batches, one
+    ``training_step`` each), ``training_step`` (:659-813: micro-batches, forward -> log-prob / entropy -> loss -> backward with
+    1 / gradient_accumulation, then clip + AdamW), ``inference_step`` / ``run_inference`` (:509-558: recomputed and reference-policy
+    log-probs, micro-batch by micro-batch without a graph), ``compute_advantages_and_returns`` (:941-978), ``_dp_load_balance``
+    (:846-858).
+
+    What runs where: the transformer is the caller's (any module returning ``.logits`` [bsz, seq, vocab]: model backends are out
+    of scope); everything from the logits on is this package's kernels -- one read of the logits forward, one read +
+    one write backward (token_ops.hip), the fused token loss, the advantage kernels, the data-parallel gradient mean and
+    clip + AdamW on ONE flat f32 parameter buffer (the module's parameters are re-pointed at views of it, its gradients at views of
+    a flat gradient buffer: adamw_clip.hip needs no per-tensor launches and the all-reduce is one call).  Sequence packing
+    (``enable_dynamic_batch_size`` / ``variable_seq_lengths``) belongs to the model backend and is refused."""
+
+    ROLE = "actor"
+
+    def __init__(self, cfg, ctx=None, model: Optional[torch.nn.Module] = None):
+        from ...scheduler import DistContext
+        self.cfg, self.ctx = cfg, ctx or DistContext()
+        self._rank, self._world_size, self.device = self.ctx.rank, self.ctx.world_size, self.ctx.device
+        algo, actor, data = _get(cfg, "algorithm"), _get(cfg, "actor"), _get(cfg, "data")
+        if _get(actor, "enable_dynamic_batch_size", False) or _get(actor, "variable_seq_lengths", False):
+            raise NotImplementedError("sequence packing (enable_dynamic_batch_size / variable_seq_lengths) is a model-backend "
+                                      "feature; this learner takes fixed [bsz, seq] batches")
+        self.step = TokenLearnerStep.from_cfg(cfg)
+        self.response_len = self.step.response_len
+        self.micro_batch_size = int(_get(actor, "micro_batch_size"))
+        self.n_mini_batches = int(_get(algo, "n_minibatches", 1))
+        self.total_batch_size_per_dp = (int(_get(data, "rollout_batch_size")) * int(_get(algo, "group_size", 1))) // self._world_size
+        assert int(_get(actor, "global_batch_size")) % (self.micro_batch_size * self._world_size) == 0  # :915-919
+        self.enable_dp_load_balance = bool(_get(actor, "enable_dp_load_balance", False))
+        self.logprob_forward_micro_batch_size = int(_get(algo, "logprob_forward_micro_batch_size", self.micro_batch_size))
+        self.shuffle_rollout = bool(_get(algo, "shuffle_rollout", True))
+        self.seed = int(_get(actor, "seed", 1234))
+        self.max_prompt_length = int(_get(data, "max_prompt_length"))
+        self.gradient_accumulation = 1
+        self.model = None
+        self.ref_policy_flat: Optional[torch.Tensor] = None
+        self.optimizer_steps = 0
+        if model is not None:
+            self.init_worker(model)
+
+    # ---- set-up: one flat parameter / gradient buffer under the module -------------------------------------------------------
+    def init_worker(self, model: torch.nn.Module, keep_reference_policy: Optional[bool] = None):
+        o = _get(_get(self.cfg, "actor"), "optim")
+        self.model = model.to(self.device)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.grad_flat = torch.zeros(n, dtype=torch.float32, device=self.device)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1).float())
+                p.data = self.flat[off:off + k].view_as(p)
+                p.grad = self.grad_flat[off:off + k].view_as(p)
+                off += k
+        self._params = params
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.opt_stats = torch.zeros(2, device=self.device)
+        self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=self.device)
+        self._optim = dict(betas=(float(_get(o, "adam_beta1", 0.9)), float(_get(o, "adam_beta2", 0.999))), eps=float(_get(o, "adam_eps", 1e-8)),
+                           weight_decay=float(_get(o, "weight_decay", 1e-2)), max_grad_norm=float(_get(o, "clip_grad", 1.0)))
+        self.lr = float(_get(o, "lr", 1e-6))
+        need_ref = (self.step.kl_beta > 0 or self.step.reinpp_kl_beta > 0) if keep_reference_policy is None else keep_reference_policy
+        if need_ref:  # ref_policy_state_dict (:262-273): the weights the run starts from
+            self.ref_policy_flat = self.flat.clone()
+
+    # ---- forward (fixed-length branch of forward_batch, :434-505) ----------------------------------------------------------
+    def forward_batch(self, m_batch: Mapping, calculate_entropy: bool = False):
+        outputs = self.model(input_ids=m_batch["input_ids"], attention_mask=m_batch["attention_mask"],
+                             position_ids=m_batch["position_ids"], use_cache=False)
+        step = self.step
+        if calculate_entropy and not step.calculate_entropy:
+            step = TokenLearnerStep(**{**step.__dict__, "calculate_entropy": True})
+        logprobs, entropy = step.logprobs_and_entropy(outputs.logits, m_batch["input_ids"])  # temperature fused (:478)
+        return (logprobs, entropy) if calculate_entropy else logprobs
+
+    def _split_to_micro_batch(self, batch: Mapping, split_num: int):
+        """get_iterator_k_split without shuffle (:391-414, data_iter_utils.py:199-243): ``split_num`` equal row ranges, views."""
+        bsz = next(v for v in batch.values() if isinstance(v, torch.Tensor)).shape[0]
+        assert bsz % split_num == 0, "Issue with batch size configuration!"
+        per = bsz // split_num
+        return [{k: (v[i * per:(i + 1) * per] if isinstance(v, (torch.Tensor, list)) else v) for k, v in batch.items()
+                 if isinstance(v, (torch.Tensor, list))} for i in range(split_num)], split_num
+
+    @torch.no_grad()
+    def inference_step(self, batch: Mapping, num_sequences: int, compute_ref_logprobs: bool):
+        """:509-558 -> (recomputed_logprobs, ref_logprobs | None), both [num_sequences, response_len] on the accelerator (the
+        reference moves them to the host for its channel; here the next consumer is a kernel on the same device)."""
+        micro_batches, _ = self._split_to_micro_batch(batch, num_sequences // self.logprob_forward_micro_batch_size)
+        recomputed = torch.cat([self.forward_batch(mb) for mb in micro_batches])
+        ref = None
+        if compute_ref_logprobs:
+            assert self.ref_policy_flat is not None, "Reference policy state dict is None but compute_ref_logprobs is True"
+            live = self.flat.clone()  # cpu_weight_swap (:544-548): run the same module on the reference weights, then restore
+            self.flat.copy_(self.ref_policy_flat)
+            try:
+                ref = torch.cat([self.forward_batch(mb) for mb in micro_batches])
+            finally:
+                self.flat.copy_(live)
+        return recomputed, ref
+
+    def run_inference(self, batch: dict, compute_ref_logprobs: bool) -> dict:
+        """run_inference (:560-657) for a batch that is already on this rank: fills ``recomputed_logprobs`` (and
+        ``ref_logprobs``) in place of putting RolloutResults on an output channel."""
+        self.model.eval()
+        n = batch["input_ids"].shape[0]
+        batch["recomputed_logprobs"], ref = self.inference_step(batch, n, compute_ref_logprobs)
+        if compute_ref_logprobs:
+            batch["ref_logprobs"] = ref
+        return batch
+
+    # ---- advantages (:941-978) and the data-parallel balancing (:846-858) ------------------------------------------------------
+    def compute_advantages_and_returns(self, batch: dict) -> dict:
+        return self.step.compute_advantages_and_returns(batch)
+
+    def _dp_load_balance(self, batch: dict) -> dict:
+        """RolloutDataBalance.from_rollout_batches (rlinf/utils/distributed.py:309-470): the ranks' samples are re-dealt so that
+        every rank trains the same number of sequences with about the same number of TOKENS (attention_mask sums), by
+        Karmarkar-Karp partitions computed identically on every rank from the gathered lengths.  One all_gather of the (small,
+        [bsz, seq]-shaped) per-sequence tensors; world_size 1: the identity."""
+        bsz = batch["input_ids"].shape[0]
+        assert bsz == self.total_batch_size_per_dp, (
+            f"DP Load balance is only available when a single batch contains all data, e.g., in collocated mode. But got "
+            f"batch_size={bsz} and self.total_batch_size_per_dp={self.total_batch_size_per_dp}.")
+        if self._world_size == 1:
+            return batch
+        import torch.distributed as dist
+        keys = sorted(k for k, v in batch.items() if isinstance(v, torch.Tensor) and v.shape[:1] == (bsz,))
+        gathered = {}
+        for k in keys:
+            parts = [torch.empty_like(batch[k]) for _ in range(self._world_size)]
+            dist.all_gather(parts, batch[k].contiguous())
+            gathered[k] = torch.cat(parts)
+        lengths = gathered["attention_mask"].sum(dim=1).tolist()
+        mine = seqlen_balanced_partitions(lengths, self._world_size, equal_size=True)[self._rank]
+        idx = torch.tensor(mine, dtype=torch.int64, device=gathered[keys[0]].device)
+        out = dict(batch)
+        out.update({k: gathered[k][idx] for k in keys})
+        return out
+
+    # ---- one optimizer step (:659-813) -------------------------------------------------------------------------------------------
+    def optimizer_step(self):
+        """FSDPModelManager.optimizer_step (fsdp_model_manager.py:429-463) on the flat buffers: data-parallel mean of the
+        gradient, global-norm clip, AdamW (skipped when the norm is not finite) -- two launches (+ one all-reduce)."""
+        from ...scheduler import all_reduce_flat_
+        if self._world_size > 1:
+            all_reduce_flat_(self.grad_flat, self.ctx)
+        ops.clip_adamw_step_(self.flat, self.grad_flat, self.exp_avg, self.exp_avg_sq, [(0, self.flat.numel(), self.lr)], 0,
+                             grad_scale=1.0 / self._world_size, stats=self.opt_stats, step_state=self.step_state,
+                             workspace=self.adamw_ws, **self._optim)
+        self.optimizer_steps += 1
+        return self.opt_stats[0], [self.lr]
+
+    def training_step(self, batch: Mapping) -> dict:
+        global_batch_size = batch["input_ids"].shape[0]
+        assert global_batch_size % self.micro_batch_size == 0, (
+            f"global batch size {global_batch_size} can not divide micro_batch_size {self.micro_batch_size}")
+        micro_batches, cnt = self._split_to_micro_batch(batch, global_batch_size // self.micro_batch_size)
+        self.gradient_accumulation = cnt
+        self.grad_flat.zero_()  # optimizer.zero_grad(): the parameters' .grad are views of this buffer
+        rows = []
+        for m_batch in micro_batches:
+            outputs = self.model(input_ids=m_batch["input_ids"], attention_mask=m_batch["attention_mask"],
+                                 position_ids=m_batch["position_ids"], use_cache=False)
+            loss, metrics = self.step(outputs.logits, m_batch, cnt)
+            loss.backward()
+            rows.append(metrics)
+        grad_norm, lr_list = self.optimizer_step()
+        keys = [k for k in rows[0] if all(k in r for r in rows)]
+        stacked = torch.stack([torch.stack([torch.as_tensor(r[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys])
+                               for r in rows]).mean(dim=0)  # mean over micro-batches (:783-791)
+        if self._world_size > 1:
+            from ...scheduler import all_reduce_flat_
+            all_reduce_flat_(stacked, self.ctx, average=True)
+        host = torch.cat([stacked, grad_norm.reshape(1)]).tolist()  # ONE read-back per optimizer step
+        out = dict(zip(keys, host[:-1]))
+        out["actor/grad_norm"], out["actor/lr"] = host[-1], lr_list[0]
+        return out
+
+    # ---- the iteration (:860-939) ----------------------------------------------------------------------------------------------
+    def get_batch(self, input_channel):
+        """-> (batch dict, number of sequences): the channel hands out dicts of [n, ...] tensors (already on the accelerator)."""
+        batch = input_channel.get() if hasattr(input_channel, "get") else input_channel.pop(0)
+        return batch, batch["input_ids"].shape[0]
+
+    def run_training(self, input_channel):
+        batches, got = [], 0
+        while got < self.total_batch_size_per_dp:
+            batch, n = self.get_batch(input_channel)
+            batches.append(batch)
+            got += n
+        assert got == self.total_batch_size_per_dp, f"Expected {self.total_batch_size_per_dp} sequences from channel, but got {got}"
+        global_batch = batches[0] if len(batches) == 1 else {k: torch.cat([b[k] for b in batches]) for k in batches[0]
+                                                             if isinstance(batches[0][k], torch.Tensor)}
+        assert "recomputed_logprobs" in global_batch or "rollout_logprobs" in global_batch
+        global_batch = self.compute_advantages_and_returns(global_batch)
+        if self.enable_dp_load_balance:
+            global_batch = self._dp_load_balance(global_batch)
+        global_batch = self.step.normalize_batch_advantages(global_batch, self.ctx if self._world_size > 1 else None)
+        # get_iterator_k_split(shuffle=True, shuffle_seed=actor.seed) (data_iter_utils.py:148-181): ONE seeded permutation of the
+        # rows, re-drawn identically every call (the generator is re-seeded) -- every tensor gathered by the same index
+        tensors = {k: v for k, v in global_batch.items() if isinstance(v, torch.Tensor)}
+        bsz = tensors["input_ids"].shape[0]
+        if self.shuffle_rollout:
+            perm = torch.randperm(bsz, generator=torch.Generator().manual_seed(self.seed)).to(self.device)
+            tensors = {k: (v[perm] if v.shape[:1] == (bsz,) else v) for k, v in tensors.items()}
+        global_batch = {**global_batch, **tensors}
+        mini_batches, _ = self._split_to_micro_batch(tensors, self.n_mini_batches)
+        self.model.train()
+        training_metrics_list = [self.training_step(mb) for mb in mini_batches]
+        return self.rollout_metrics(global_batch), training_metrics_list
+
+    def rollout_metrics(self, batch: Mapping) -> dict:
+        """compute_math_rollout_metrics (rlinf/utils/distributed.py:186-306): lengths, rewards, end fraction and masked advantage
+        statistics of the iteration's batch; sums in one all-reduce, the (-min, max) pair in another, one read-back."""
+        import torch.distributed as dist
+        mask = batch["response_mask"][:, -self.response_len:]
+        adv = batch["advantages"]
+        valid = adv[mask]
+        plen, rlen = batch["prompt_lengths"].float(), batch["response_lengths"].float()
+        sums = torch.stack([plen.sum(), rlen.sum(), batch["rewards"].float().sum(), batch["is_end"].float().sum(),
+                            valid.double().sum().float(), torch.tensor(float(plen.numel()), device=adv.device),
+                            mask.sum().float(), (rlen * rlen).sum()])
+        ext = torch.stack([-valid.min(), valid.max(), -rlen.min(), rlen.max()]) if valid.numel() else torch.zeros(4, device=adv.device)
+        if self._world_size > 1:
+            dist.all_reduce(sums)
+            dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+        s_pl, s_rl, s_rw, s_end, s_adv, n_seq, n_tok, s_rl2 = sums.tolist()
+        e = ext.tolist()
+        mean_rl = s_rl / n_seq
+        var_rl = (s_rl2 - n_seq * mean_rl * mean_rl) / (n_seq - 1) if n_seq > 1 else float("nan")  # torch.var: unbiased
+        return {"total_num_sequence": n_seq, "prompt_length": s_pl / n_seq, "response_length": s_rl / n_seq,
+                "average_response_length": mean_rl, "variance_of_response_length": var_rl, "max_of_response_length": e[3],
+                "min_of_response_length": -e[2], "total_length": (s_pl + s_rl) / n_seq, "reward_scores": s_rw / n_seq,
+                "fraction_of_samples_properly_ended": s_end / n_seq, "advantages_mean": s_adv / n_tok if n_tok else float("nan"),
+                "advantages_max": e[1], "advantages_min": -e[0]}

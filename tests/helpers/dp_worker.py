@@ -64,6 +64,22 @@ def cpu_main(out_path):
     res["bucket_ok"] = (list(got_b) == ["total_buckets", "syncer_version", "w", "steps", "flags"] and int(got_b["syncer_version"]) == 9
                         and got_b["w"].dtype == torch.bfloat16 and got_b["w"].float().flatten().tolist() == list(range(15))
                         and int(got_b["steps"]) == -4 and got_b["flags"].tolist() == [True, False] * 3 + [True])
+    # reasoning learner: sequence-length balancing over the data-parallel group (FSDPActor._dp_load_balance): every rank ends up
+    # with the same number of sequences and about the same number of tokens, from partitions all ranks compute alike
+    from rlinf_amd.workers.actor.fsdp_actor_worker import FSDPActor
+    rcfg = dict(runner=dict(task_type="reasoning"), algorithm=dict(group_size=2, n_minibatches=1),
+                actor=dict(micro_batch_size=2, global_batch_size=8, enable_dp_load_balance=True, model=dict(encoder_seq_length=12), optim={}),
+                data=dict(rollout_batch_size=4, max_prompt_length=4))
+    learner = FSDPActor(rcfg, ctx)
+    g = torch.Generator().manual_seed(50 + ctx.rank)
+    lens = torch.randint(1, 13, (4,), generator=g) if ctx.rank == 0 else torch.randint(8, 13, (4,), generator=g)  # rank 1 drew long ones
+    batch = {"input_ids": torch.arange(4).unsqueeze(1).expand(4, 12).clone() + 100 * ctx.rank,
+             "attention_mask": torch.arange(12).unsqueeze(0) < lens.unsqueeze(1), "rewards": torch.arange(4.0) + 10 * ctx.rank}
+    bal = learner._dp_load_balance(batch)
+    res["balance_lens_in"] = lens.tolist()
+    res["balance_ids"] = bal["input_ids"][:, 0].tolist()
+    res["balance_tokens"] = int(bal["attention_mask"].sum())
+    res["balance_rewards"] = bal["rewards"].tolist()
     json.dump(res, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()

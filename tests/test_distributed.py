@@ -51,6 +51,17 @@ def test_world_size_2_host_logic_over_gloo(tmp_path):
     # the weight patch the actor rank broadcasts arrives byte for byte (header + one broadcast per field)
     assert r0["patch_ok"] and r1["patch_ok"] and r0["empty_ok"] and r1["empty_ok"]
     assert r0["bucket_ok"] and r1["bucket_ok"]  # a weight bucket: pickled layout + one broadcast of the flat byte buffer
+    # FSDPActor._dp_load_balance: the 8 sequences re-dealt 4 + 4 by the Karmarkar-Karp partitions of the GATHERED lengths
+    from rlinf_amd.workers.actor.fsdp_actor_worker import seqlen_balanced_partitions
+    lens = r0["balance_lens_in"] + r1["balance_lens_in"]
+    parts = seqlen_balanced_partitions(lens, 2, True)
+    ids = [0, 1, 2, 3, 100, 101, 102, 103]
+    rew = [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0, 13.0]
+    for r, part in zip((r0, r1), parts):
+        assert r["balance_ids"] == [ids[i] for i in part] and r["balance_rewards"] == [rew[i] for i in part]
+        assert r["balance_tokens"] == sum(lens[i] for i in part)
+    assert abs(r0["balance_tokens"] - r1["balance_tokens"]) <= max(lens)           # balanced by tokens, not just by count
+    assert abs(sum(r0["balance_lens_in"]) - sum(r1["balance_lens_in"])) >= abs(r0["balance_tokens"] - r1["balance_tokens"])
 
 
 def _two_gpus():

@@ -1,0 +1,111 @@
+"""The reasoning learner AROUND the token kernels (BASELINE.json configs[2]'s driver loop):
+rlinf_amd.workers.actor.fsdp_actor_worker.FSDPActor -- run_inference / run_training / training_step over a tiny stand-in
+transformer on the GPU -- against oracle.token_loop.iteration, which tests/test_reference_reasoning_loop.py pins bit for bit to the
+reference's own FSDPActor.run_training / training_step / forward_batch compiled from source."""
+
+import copy
+
+import pytest
+import torch
+
+from oracle import token_loop as TL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cfg(*, resp, prompt, micro, n_mini, total, group_size, case):
+    return dict(
+        runner=dict(task_type="reasoning"),
+        algorithm=dict(adv_type=case.get("adv_type", "grpo"), group_size=group_size, n_minibatches=n_mini,
+                       normalize_advantages=case.get("normalize", True), shuffle_rollout=True, loss_type="actor",
+                       loss_agg_func=case.get("loss_agg", "token-mean"), ratio_clip_eps=0.2, clip_ratio_high=0.28,
+                       sampling_params=dict(temperature=case.get("temperature", 1.0)), calculate_entropy=case.get("entropy_bonus", 0) > 0,
+                       entropy_bonus=case.get("entropy_bonus", 0.0), kl_beta=case.get("kl_beta", 0.0),
+                       kl_penalty_type=case.get("kl", "low_var_kl"), logprob_forward_micro_batch_size=micro),
+        actor=dict(seed=1234, micro_batch_size=micro, global_batch_size=total // n_mini,
+                   model=dict(encoder_seq_length=prompt + resp),
+                   optim=dict(lr=1e-3, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, weight_decay=0.01, clip_grad=1.0)),
+        data=dict(rollout_batch_size=total // group_size, max_prompt_length=prompt))
+
+
+@pytest.mark.parametrize("case", [
+    dict(),
+    dict(loss_agg="seq-mean-token-sum", temperature=0.7, entropy_bonus=0.01),
+    dict(loss_agg="seq-mean-token-mean", temperature=1.3, kl_beta=0.05, kl="low_var_kl"),
+    dict(adv_type="reinpp", normalize=False),
+    dict(normalize=False, group_size=2),
+], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()) or "default")
+def test_run_training_matches_the_oracle_loop(case):
+    from rlinf_amd.scheduler import init_distributed
+    from rlinf_amd.workers.actor.fsdp_actor_worker import FSDPActor
+    resp, prompt, vocab, dim = 12, 6, 211, 32
+    total, micro, n_mini, group = 32, 8, 2, case.get("group_size", 4)
+    torch.manual_seed(5)
+    base = TL.TinyCausalLM(vocab, dim, prompt + resp)
+    batch = TL.synthetic_rollout_batch(7, total, prompt, resp, vocab)
+    temp = case.get("temperature", 1.0)
+    ctx = init_distributed()
+    actor = FSDPActor(_cfg(resp=resp, prompt=prompt, micro=micro, n_mini=n_mini, total=total, group_size=group, case=case), ctx,
+                      model=copy.deepcopy(base))
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    oracle_batch = {k: v.clone() for k, v in batch.items()}
+    if case.get("kl_beta", 0) > 0:
+        # run_inference: recomputed + reference-policy log-probs from the learner's own forward (the weights the run starts from)
+        assert actor.ref_policy_flat is not None
+        actor.run_inference(dev_batch, compute_ref_logprobs=True)
+        with torch.no_grad():
+            want = TL.forward_logprobs(base, batch, resp, temp)
+        torch.testing.assert_close(dev_batch["recomputed_logprobs"].cpu(), want, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(dev_batch["ref_logprobs"].cpu(), want, rtol=2e-4, atol=2e-5)
+        assert torch.equal(actor.flat, actor.ref_policy_flat)  # the weight swap restored the live weights
+        # (the reference prefers recomputed over rollout log-probs as the behaviour policy, :697-700)
+        oracle_batch["recomputed_logprobs"], oracle_batch["ref_logprobs"] = want.clone(), want.clone()
+    ora = copy.deepcopy(base)
+    opt = torch.optim.AdamW(ora.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    shuffled, want_metrics = TL.iteration(
+        ora, opt, oracle_batch, response_len=resp, micro_batch=micro, n_minibatches=n_mini, seed=1234,
+        adv_type=case.get("adv_type", "grpo"), group_size=group, normalize_advantages=case.get("normalize", True), temperature=temp,
+        loss_agg=case.get("loss_agg", "token-mean"), clip_ratio_low=0.2, clip_ratio_high=0.28,
+        calculate_entropy=case.get("entropy_bonus", 0) > 0, entropy_bonus=case.get("entropy_bonus", 0.0),
+        kl_beta=case.get("kl_beta", 0.0), kl_penalty_type=case.get("kl", "low_var_kl"), clip_grad=1.0)
+    rollout_metrics, got_metrics = actor.run_training([dev_batch])
+    assert len(got_metrics) == n_mini == len(want_metrics)
+    for w, g in zip(want_metrics, got_metrics):
+        for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "actor/entropy_loss", "actor/kl_loss",
+                  "actor/grad_norm"):
+            assert g[k] == pytest.approx(w[k], rel=2e-3, abs=2e-5), (k, g[k], w[k])
+    # parameters after two clipped AdamW steps through the flat buffers: the module's tensors ARE views of actor.flat
+    want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+    got = torch.cat([p.detach().reshape(-1) for p in actor.model.parameters()]).cpu()
+    assert torch.equal(got, actor.flat.cpu())
+    diff = (got - want).abs()
+    assert float(diff.max()) <= 2 * 1e-3 * n_mini + 1e-6 and float((diff > 5e-5).float().mean()) < 0.02, (float(diff.max()),)
+    assert actor.optimizer_steps == n_mini and int(actor.step_state.sum()) == n_mini
+    # rollout metrics of the iteration (compute_math_rollout_metrics)
+    mask = shuffled["response_mask"][:, -resp:]
+    assert rollout_metrics["total_num_sequence"] == total
+    assert rollout_metrics["reward_scores"] == pytest.approx(float(batch["rewards"].mean()), rel=1e-5)
+    assert rollout_metrics["response_length"] == pytest.approx(float(batch["response_lengths"].float().mean()), rel=1e-6)
+    assert rollout_metrics["variance_of_response_length"] == pytest.approx(float(batch["response_lengths"].float().var()), rel=1e-4)
+    assert rollout_metrics["advantages_max"] == pytest.approx(float(shuffled["advantages"][mask].max()), rel=1e-4, abs=1e-5)
+    assert rollout_metrics["advantages_mean"] == pytest.approx(float(shuffled["advantages"][mask].double().mean()), rel=1e-3, abs=1e-5)
+
+
+def test_dp_load_balance_partitions_and_refusals():
+    from rlinf_amd.scheduler import init_distributed
+    from rlinf_amd.workers.actor.fsdp_actor_worker import FSDPActor, seqlen_balanced_partitions
+    parts = seqlen_balanced_partitions([9, 1, 8, 2, 7, 3, 6, 4], 2, True)
+    assert sorted(sum(parts, [])) == list(range(8)) and len(parts[0]) == len(parts[1]) == 4
+    assert abs(sum([9, 1, 8, 2, 7, 3, 6, 4][i] for i in parts[0]) - 20) <= 1
+    cfg = _cfg(resp=4, prompt=2, micro=2, n_mini=1, total=4, group_size=2, case={})
+    cfg["actor"]["enable_dynamic_batch_size"] = True
+    with pytest.raises(NotImplementedError, match="sequence packing"):
+        FSDPActor(cfg, init_distributed())
+    cfg["actor"]["enable_dynamic_batch_size"] = False
+    cfg["actor"]["enable_dp_load_balance"] = True
+    actor = FSDPActor(cfg, init_distributed(), model=TL.TinyCausalLM(17, 8, 6))
+    batch = {k: v.to(DEV) for k, v in TL.synthetic_rollout_batch(1, 4, 2, 4, 17).items()}
+    assert actor._dp_load_balance(batch) is batch  # one rank: the identity
+    with pytest.raises(AssertionError, match="DP Load balance is only available"):
+        actor._dp_load_balance({k: v[:2] for k, v in batch.items()})

@@ -1,0 +1,149 @@
+"""oracle.token_loop.iteration against the REFERENCE's own reasoning learner loop, executed on CPU: FSDPActor.run_training,
+training_step, forward_batch, compute_advantages_and_returns (rlinf/workers/actor/fsdp_actor_worker.py:434-505, 659-813, 860-978)
+and get_iterator_k_split (rlinf/utils/data_iter_utils.py:129-262) are compiled from their source where they lie and run as plain
+functions over a stand-in ``self`` (a tiny real torch model, torch's AdamW, clip_grad_norm_ as the NO_SHARD branch of
+FSDPModelManager.optimizer_step): everything that computes -- advantages through its registry, masked_normalization, the seeded
+shuffle, mini / micro-batching, policy_loss, entropy bonus, KL penalty, accumulation -- is the reference's code.  The oracle loop
+must land on the same parameters bit for bit; the HIP learner is compared with the oracle loop on the GPU
+(tests/test_gpu_reasoning_loop.py)."""
+
+import contextlib
+import copy
+import logging
+from collections import UserDict
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import token_loop as TL
+
+pytestmark = pytest.mark.reference
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+    def get(self, k, d=None):
+        return self[k] if k in self and self[k] is not None else d
+
+
+@pytest.fixture(scope="module")
+def one_rank_group():
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29637", rank=0, world_size=1)
+    yield
+    if started:
+        dist.destroy_process_group()
+
+
+def reference_learner(ref, model, *, resp, prompt, micro, n_mini, total, case):
+    from oracle import reference_loader as R
+    du = R.load_distributed_utils()
+    py = "rlinf/workers/actor/fsdp_actor_worker.py"
+    it_py = "rlinf/utils/data_iter_utils.py"
+    worker_stub = SimpleNamespace(torch_device_type="cpu", timer=lambda *_a, **_k: (lambda f: f),
+                                  torch_platform=SimpleNamespace(current_device=lambda: torch.device("cpu")))
+    split_list = R.load_function(it_py, "split_list")
+    import itertools
+    k_split = R.load_function(it_py, "get_iterator_k_split", torch=torch, UserDict=UserDict, logging=logging, split_list=split_list, itertools=itertools,
+                              Union=None, Optional=None, Iterator=None)
+    mu = ref.metric_utils
+
+    def masked_normalization_cpu(x, mask):  # the reference's own function moves its inputs to .cuda(): same arithmetic, on the host
+        src = R.load_function("rlinf/utils/distributed.py", "masked_normalization", torch=torch, np=__import__("numpy"))
+        orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            return src(x, mask)
+        finally:
+            torch.Tensor.cuda = orig
+
+    bonus, beta = case.get("entropy_bonus", 0.0), case.get("kl_beta", 0.0)
+    alg = Cfg(sampling_params=Cfg(temperature=case.get("temperature", 1.0)), ratio_clip_eps=0.2, clip_ratio_high=0.28, loss_type="actor",
+              entropy_bonus=bonus, adv_type=case.get("adv_type", "grpo"), group_size=case.get("group_size", 4),
+              normalize_advantages=case.get("normalize", True), n_minibatches=n_mini, shuffle_rollout=True)
+    cfg = Cfg(algorithm=alg, actor=Cfg(seed=1234, global_batch_size=total // n_mini, micro_batch_size=micro), data=Cfg(max_prompt_length=prompt))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    me = SimpleNamespace(
+        cfg=cfg, model=model, response_len=resp, enable_dynamic_batch_size=False, variable_seq_lengths=False, max_tokens_per_mbs=None,
+        amp_context=contextlib.nullcontext(), before_micro_batch=lambda *_a, **_k: contextlib.nullcontext(), task_type="reasoning",
+        loss_agg_func=ref.utils.get_loss_agg_func(case.get("loss_agg", "token-mean")), calculate_entropy=bonus > 0,
+        calculate_entropy_loss=bonus > 0, kl_beta=beta, kl_penalty_type=case.get("kl", "low_var_kl"), entropy_op_type="torch",
+        micro_batch_size=micro, total_batch_size_per_dp=total, n_mini_batches=n_mini, gradient_accumulation=None,
+        lr_sched_sync_with_optim=False, optimizer=opt, grad_scaler=SimpleNamespace(scale=lambda loss: loss), is_pipeline=False,
+        enable_dp_load_balance=False, _world_size=1, reinpp_kl_beta=case.get("reinpp_kl_beta", 0.0),
+        lr_scheduler=SimpleNamespace(step=lambda: None), worker_timer=lambda *_a: contextlib.nullcontext(),
+        _load_weight_and_optimizer=lambda: None)
+
+    def optimizer_step():  # FSDPModelManager.optimizer_step, NO_SHARD: torch's clip_grad_norm_, step unless the norm is not finite
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        if torch.isfinite(gn):
+            opt.step()
+        return float(gn), [1e-3]
+
+    me.optimizer_step = optimizer_step
+    me.compute_logprobs = lambda logits, target: ref.utils.compute_logprobs_from_logits(logits, target, op_type="torch")
+    forward_batch = R.load_function(py, "FSDPActor.forward_batch", torch=torch, Worker=worker_stub,
+                                    compute_entropy_from_logits=ref.utils.compute_entropy_from_logits)
+    me.forward_batch = lambda m_batch, calculate_entropy=False: forward_batch(me, m_batch, calculate_entropy)
+    split = R.load_function(py, "FSDPActor._split_to_micro_batch", get_iterator_k_split=k_split, Optional=None)
+    me._split_to_micro_batch = lambda *a, **k: split(*a, **k)
+    training_step = R.load_function(
+        py, "FSDPActor.training_step", torch=torch, Worker=worker_stub, policy_loss=ref.registry.policy_loss,
+        kl_penalty=ref.algo_utils.kl_penalty, append_to_dict=mu.append_to_dict, compute_rollout_train_kl=lambda *_a: None,
+        pop_critic_explained_variance_stats=mu.pop_critic_explained_variance_stats, all_reduce_dict=lambda d, op=None: d,
+        compute_critic_explained_variance_from_stats=mu.compute_critic_explained_variance_from_stats,
+        CRITIC_EXPLAINED_VARIANCE_KEY=mu.CRITIC_EXPLAINED_VARIANCE_KEY, BatchResizingIterator=type("BatchResizingIterator", (), {}))
+    me.training_step = lambda batch: training_step(me, batch)
+    cadv = R.load_function(py, "FSDPActor.compute_advantages_and_returns", Worker=worker_stub,
+                           calculate_adv_and_returns=ref.registry.calculate_adv_and_returns)
+    me.compute_advantages_and_returns = lambda batch: cadv(me, batch)
+    rollout_result = SimpleNamespace(merge_batches=staticmethod(lambda batches: batches[0]))
+    run_training = R.load_function(py, "FSDPActor.run_training", torch=torch, RolloutResult=rollout_result,
+                                   masked_normalization=masked_normalization_cpu, get_iterator_k_split=k_split,
+                                   compute_math_rollout_metrics=lambda *a, **k: ({"n": 1}, None, None), Channel=None)
+    me.run_training = lambda channel: run_training(me, channel)
+    return me
+
+
+@pytest.mark.parametrize("case", [
+    dict(),
+    dict(loss_agg="seq-mean-token-sum", temperature=0.7, entropy_bonus=0.01),
+    dict(loss_agg="seq-mean-token-mean", temperature=1.3, kl_beta=0.05, kl="low_var_kl"),
+    dict(adv_type="reinpp", normalize=False, reinpp_kl_beta=0.0),
+    dict(normalize=False, group_size=2),
+], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()) or "default")
+def test_oracle_iteration_matches_the_reference_run_training(ref, one_rank_group, case):
+    resp, prompt, vocab, dim = 6, 4, 53, 16
+    total, micro, n_mini = 16, 4, 2
+    torch.manual_seed(5)
+    base = TL.TinyCausalLM(vocab, dim, prompt + resp)
+    batch = TL.synthetic_rollout_batch(7, total, prompt, resp, vocab)
+    if case.get("kl_beta", 0) > 0:
+        with torch.no_grad():
+            batch["ref_logprobs"] = TL.forward_logprobs(base, batch, resp, case.get("temperature", 1.0)) + 0.05 * torch.randn(total, resp)
+    m_ref, m_ora = copy.deepcopy(base), copy.deepcopy(base)
+    me = reference_learner(ref, m_ref, resp=resp, prompt=prompt, micro=micro, n_mini=n_mini, total=total, case=case)
+    feed = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}]
+    me.get_batch = lambda _ch: (feed.pop(0), SimpleNamespace(num_sequence=total))
+    _, want_metrics = me.run_training(None)
+    opt = torch.optim.AdamW(m_ora.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    _, got_metrics = TL.iteration(
+        m_ora, opt, {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}, response_len=resp,
+        micro_batch=micro, n_minibatches=n_mini, seed=1234, adv_type=case.get("adv_type", "grpo"), group_size=case.get("group_size", 4),
+        normalize_advantages=case.get("normalize", True), temperature=case.get("temperature", 1.0),
+        loss_agg=case.get("loss_agg", "token-mean"), clip_ratio_low=0.2, clip_ratio_high=0.28,
+        calculate_entropy=case.get("entropy_bonus", 0) > 0, entropy_bonus=case.get("entropy_bonus", 0.0),
+        kl_beta=case.get("kl_beta", 0.0), kl_penalty_type=case.get("kl", "low_var_kl"), clip_grad=1.0,
+        reinpp_kl_beta=case.get("reinpp_kl_beta", 0.0))
+    for (n, a), (_, b) in zip(m_ref.named_parameters(), m_ora.named_parameters()):
+        assert torch.equal(a, b), n
+    assert not torch.equal(next(m_ref.parameters()), next(base.parameters()))  # it did train
+    assert len(want_metrics) == len(got_metrics) == n_mini
+    for w, g in zip(want_metrics, got_metrics):
+        for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "actor/entropy_loss",
+                  "actor/kl_loss", "actor/grad_norm"):
+            assert float(w[k]) == pytest.approx(g[k], rel=1e-6, abs=1e-9), k
