@@ -596,6 +596,8 @@ def main():
     ap.add_argument("--no-token-tier", action="store_true", help="skip the token-tier (LLM logits) roofline rows")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 job: kill it after this many seconds")
+    ap.add_argument("--pair-timeout", type=float, default=240.0, help="N > 1: seconds one (regime, transport) measurement may take "
+                    "before the watchdog prints the line assembled so far and ends the job")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -616,32 +618,17 @@ def main():
 
     # ---- the timed regions ------------------------------------------------------------------------------------------------
     runs, errors = {}, {}
-    if args.gpus == 1:
-        runs[("strong", None)] = measure(ctx, scaling="strong", **common)
-    else:
-        forced = os.environ.get("RLX_GRAD_ALLREDUCE")
-        names = [forced] if forced else (["xgmi", "rccl"] if args.transports == "auto" else args.transports.split(","))
-        for regime in ("strong", "weak"):
-            for tr in names:
-                try:
-                    runs[(regime, tr)] = measure(ctx, scaling=regime, transport=tr, **common)
-                except Exception as e:  # noqa: BLE001 -- reported in the line; collectively consistent only if it failed everywhere
-                    errors[f"{regime}/{tr}"] = f"{type(e).__name__}: {e}"[:300]
-        # a transport failing on ONE rank only would leave the ranks in different collectives: agree on what exists
-        have = torch.tensor([1 if (rg, tr) in runs else 0 for rg in ("strong", "weak") for tr in names], device=dev, dtype=torch.int32)
-        dist.all_reduce(have, op=dist.ReduceOp.MIN)
-        keep = [(rg, tr) for (rg, tr), ok in zip([(rg, tr) for rg in ("strong", "weak") for tr in names], have.tolist()) if ok]
-        runs = {k: v for k, v in runs.items() if k in keep}
-        if not any(rg == args.scaling for rg, _ in runs):
-            raise SystemExit(f"no transport completed the {args.scaling}-scaling run: {errors}")
 
     def best(regime):
         c = [(v["env_steps_per_sec"], tr, v) for (rg, tr), v in runs.items() if rg == regime]
         return max(c, key=lambda x: x[0]) if c else None
 
-    line = None
-    if ctx.rank == 0:
-        _, head_tr, head = best(args.scaling)
+    def assemble():
+        """The JSON line from whatever has been measured so far (None before the first headline-regime run exists)."""
+        top = best(args.scaling)
+        if top is None:
+            return None
+        _, _, head = top
         line = {
             "metric": "env_steps_per_sec", "value": head["env_steps_per_sec"], "unit": "env-steps/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -673,7 +660,52 @@ def main():
             line["transports"] = {f"{rg}/{tr}": {k: v[k] for k in ("env_steps_per_sec", "ms_per_step", "grad_allreduce", "update_graph_replayed")}
                                   for (rg, tr), v in runs.items()}
             if errors:
-                line["transport_errors"] = errors
+                line["transport_errors"] = dict(errors)
+        return line
+
+    if args.gpus == 1:
+        runs[("strong", None)] = measure(ctx, scaling="strong", **common)
+    else:
+        # Every (regime, transport) pair is its own runner and its own timed region.  Order: the headline regime first, and inside
+        # it the transport most likely to give a number.  A watchdog guards the rest: the N > 1 paths meet real multi-GPU hardware
+        # for the first time under the driver -- if a later pair hangs (an RCCL capture that never returns, a dead link), every
+        # rank's timer fires, rank 0 prints the line assembled from what WAS measured (the hang named in transport_errors) and the
+        # job exits instead of taking the measured headline down with it.
+        import threading
+        forced = os.environ.get("RLX_GRAD_ALLREDUCE")
+        names = [forced] if forced else (["xgmi", "rccl"] if args.transports == "auto" else args.transports.split(","))
+        os.environ.setdefault("RLX_XGMI_TIMEOUT_MS", "30000")  # a dead exchange costs the bench one bounded wait, then raises
+        pairs = [(rg, tr) for rg in (args.scaling, "weak" if args.scaling == "strong" else "strong") for tr in names]
+        current = {"pair": None}
+
+        def emergency():
+            if ctx.rank == 0:
+                errors[f"{current['pair']}"] = f"no progress within --pair-timeout {args.pair_timeout:.0f} s: abandoned (watchdog)"
+                line = assemble()
+                if line is not None:
+                    print(json.dumps(line), flush=True)
+            os._exit(0 if (ctx.rank != 0 or best(args.scaling) is not None) else 3)
+
+        for rg, tr in pairs:
+            current["pair"] = f"{rg}/{tr}"
+            dog = threading.Timer(args.pair_timeout, emergency)
+            dog.daemon = True
+            dog.start()
+            try:
+                runs[(rg, tr)] = measure(ctx, scaling=rg, transport=tr, **common)
+            except Exception as e:  # noqa: BLE001 -- reported in the line; collectively consistent only if it failed everywhere
+                errors[f"{rg}/{tr}"] = f"{type(e).__name__}: {e}"[:300]
+            # a transport failing on ONE rank only would leave the ranks in different collectives: agree on what exists
+            have = torch.tensor([1 if (rg, tr) in runs else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            dog.cancel()
+            if not int(have.item()):
+                runs.pop((rg, tr), None)
+                errors.setdefault(f"{rg}/{tr}", "failed on another rank")
+        if best(args.scaling) is None:
+            raise SystemExit(f"no transport completed the {args.scaling}-scaling run: {errors}")
+
+    line = assemble() if ctx.rank == 0 else None
 
     # ---- N = 1: the variant lines (own runners, same timing method), then the probes ---------------------------------------
     if args.gpus == 1:

@@ -28,6 +28,9 @@ __device__ __forceinline__ void form_scalars(const rlx_adamw_params& a, int step
 // publish + wait (see opt_common.h, PeerWait).  Called by every block: thread r < world handles rank r.
 __device__ __forceinline__ void peer_poll(const PeerWait& w, int r, unsigned s, int sleep) {
     const unsigned* flag = w.flags_mine + w.phase * kMaxRanks + r;
+    // an earlier wait of this run already expired (the status word stays set until the host reads it): the exchange is dead,
+    // every further wait would cost its full bound again -- fall through, the AdamW launches skip, the host raises
+    if (__hip_atomic_load(w.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - s) < 0) {
         if (wall_clock64() - t0 > w.timeout_ticks) {

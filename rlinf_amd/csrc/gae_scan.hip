@@ -433,6 +433,90 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_regseg(GaeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Register-resident segments with an EARLY hand-off (C == 1, one env per lane).  grid = ceil(B / 64), block = 64 * NSEG threads.
+//   Why: a wave can have at most 64 vector-memory operations outstanding (vmcnt is 6 bits), so the one-wave-per-env-group
+//   streaming scan caps the bytes in flight at B x 256 B whatever its register batches hold -- 16.8 MB at 65536 envs, about what
+//   5.3 TB/s x 3 us needs and no more.  More waves per env group is the only way to put more requests in flight.
+//   How: wave s owns the time segment [s * SEG, (s + 1) * SEG) and requests ALL its rows up front (r, V, done: 3 * SEG loads).
+//   The recurrence needs the accumulator g from the later segment; gae_scan_regseg passes it down a serial chain in which
+//   every wave computes AND stores before the next one starts.  Here the chain carries ONLY the recurrence -- SEG fused
+//   multiply-add-class steps from registers, no stores -- then every wave runs its full pass (recurrence again, moments, stores)
+//   CONCURRENTLY with its true incoming g.  Same operations in the same order as the sequential loop: bit-identical results.
+// ------------------------------------------------------------------------------------------
+template <int NSEG, int SEG, bool NT, bool CRITIC, bool MASK>
+__global__ __launch_bounds__(64 * NSEG) void gae_scan_handoff(GaeArgs a) {
+    __shared__ float s_gin[NSEG][64];
+    __shared__ double s_red[5 * NSEG];
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned e0 = (unsigned)blockIdx.x * 64u + (unsigned)lane;
+    const bool active = e0 < (unsigned)a.B;
+    const int T = a.T;
+    const unsigned B = (unsigned)a.B;
+    const int t_lo = seg * SEG;
+    const int t_hi = min(T, t_lo + SEG);
+    const unsigned nf = (unsigned)T * B * 4u, nf1 = (unsigned)(T + 1) * B * 4u;  // < 2^31 (host-checked)
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.r), 0, (int)nf, 0x00020000);
+    const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v), 0, CRITIC ? (int)nf1 : 0, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.d), 0, (int)(nf1 / 4), 0x00020000);
+    const auto rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.m), 0, MASK ? (int)(nf / 4) : 0, 0x00020000);
+    const auto rs_adv = __builtin_amdgcn_make_buffer_rsrc(a.adv, 0, (int)nf, 0x00020000);
+    const auto rs_ret = __builtin_amdgcn_make_buffer_rsrc(a.ret, 0, (int)nf, 0x00020000);
+    const unsigned vo4 = active ? e0 * 4u : 0x7fffffffu, vo1 = active ? e0 : 0x7fffffffu;
+
+    float r[SEG][1], v[SEG][1], vtop[1] = {0.f};
+    uint32_t dn[SEG], mk[SEG];
+#pragma unroll
+    for (int u = SEG - 1; u >= 0; --u) {  // latest row first: the order the recurrence consumes them
+        const unsigned t = (unsigned)min(t_lo + u, T - 1);
+        bld<1, NT>(rs_r, vo4, t * B * 4u, r[u]);
+        if constexpr (CRITIC) bld<1, NT>(rs_v, vo4, t * B * 4u, v[u]);
+        dn[u] = bldb<1, NT>(rs_d, vo1, (t + 1) * B);
+        if constexpr (MASK) mk[u] = bldb<1, NT>(rs_m, vo1, t * B);
+        else mk[u] = 1u;
+    }
+    if constexpr (CRITIC) bld<1, false>(rs_v, vo4, (unsigned)min(t_hi, T) * B * 4u, vtop);
+
+    // ---- the chain: recurrence only, latest segment first; s_gin[s] = the accumulator segment s hands to segment s - 1 ----
+    for (int s = NSEG - 1; s >= 1; --s) {
+        if (s == seg) {
+            float g = (s == NSEG - 1 || t_hi >= T) ? 0.f : s_gin[s + 1 < NSEG ? s + 1 : s][lane];
+            float vnext = CRITIC ? vtop[0] : 0.f, adv, ret;
+#pragma unroll
+            for (int u = SEG - 1; u >= 0; --u) {
+                if (t_lo + u < t_hi) {
+                    const float vk = CRITIC ? v[u][0] : 0.f;
+                    gae_step(r[u][0], vk, vnext, (dn[u] & 0xffu) ? 0.f : 1.f, CRITIC, a.gamma, a.gl, g, adv, ret);
+                    vnext = vk;
+                }
+            }
+            s_gin[s][lane] = g;
+        }
+        __syncthreads();
+    }
+    // ---- the full pass, all segments at once -------------------------------------------------------------------------------
+    Moments mo;
+    if (active && t_hi > t_lo) {
+        float g = (seg == NSEG - 1 || t_hi >= T) ? 0.f : s_gin[seg + 1 < NSEG ? seg + 1 : seg][lane];
+        float vnext = CRITIC ? vtop[0] : 0.f;
+#pragma unroll
+        for (int u = SEG - 1; u >= 0; --u) {
+            if (t_lo + u < t_hi) {  // wave-uniform
+                float adv[1], ret[1];
+                const float vk = CRITIC ? v[u][0] : 0.f;
+                gae_step(r[u][0], vk, vnext, (dn[u] & 0xffu) ? 0.f : 1.f, CRITIC, a.gamma, a.gl, g, adv[0], ret[0]);
+                mo.add(adv[0], ret[0], (mk[u] & 0xffu) != 0);
+                vnext = vk;
+                const unsigned row = (unsigned)(t_lo + u) * B * 4u;
+                bst<1, NT>(rs_adv, vo4, row, adv);
+                bst<1, NT>(rs_ret, vo4, row, ret);
+            }
+        }
+    }
+    flush_moments(mo, a.partials, s_red);
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic time-chunk layout (C > 1): one lane per env, sequential, strided addressing.
 //   time step t = k*C + c  ->  element ((k*B + b)*C + c); dones use flat rows shifted by C-1
 //   (the reference keeps the LAST T+1 rows of the (n+1)*C flattened done rows, utils.py:111-114),
@@ -673,7 +757,31 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
             nt_sel = true;
         }
         const bool regseg = (p->variant >> 26) & 1;  // register-resident 32-step segments, serial carry chain
-        if (regseg) {
+        const bool handoff = (p->variant >> 28) & 1;  // register-resident segments, early hand-off (gae_scan_handoff)
+        if (handoff) {
+            RLX_REQUIRE((unsigned long long)(a.T + 1) * (unsigned long long)batch * 4ull < (1ull << 31),
+                        "rlx_gae_scan: the hand-off variant addresses rows through 32-bit buffer offsets: (T+1)*B*4 must stay below 2 GiB");
+            const int seg = 16 << ((p->variant >> 29) & 3);  // 16, 32, 64
+            RLX_REQUIRE(seg <= 64, "rlx_gae_scan: hand-off segment of %d steps", seg);
+            const int ns = ceil_div(a.T, seg);
+            RLX_REQUIRE(ns >= 1 && ns <= 8, "rlx_gae_scan: hand-off variant with %d-step segments needs T <= %d (T=%d)", seg, 8 * seg, a.T);
+            const bool critic = a.v != nullptr, mask = a.m != nullptr;
+            nblk = ceil_div(batch, 64);
+#define RLX_HANDOFF(NS, SG)                                                                                                        \
+            do {                                                                                                                       \
+                if (critic && !mask) { if (nt) hipLaunchKernelGGL((gae_scan_handoff<NS, SG, true, true, false>), dim3(nblk), dim3(64 * NS), 0, s, a);   \
+                                       else hipLaunchKernelGGL((gae_scan_handoff<NS, SG, false, true, false>), dim3(nblk), dim3(64 * NS), 0, s, a); }    \
+                else if (critic) hipLaunchKernelGGL((gae_scan_handoff<NS, SG, false, true, true>), dim3(nblk), dim3(64 * NS), 0, s, a);                \
+                else if (mask) hipLaunchKernelGGL((gae_scan_handoff<NS, SG, false, false, true>), dim3(nblk), dim3(64 * NS), 0, s, a);                 \
+                else hipLaunchKernelGGL((gae_scan_handoff<NS, SG, false, false, false>), dim3(nblk), dim3(64 * NS), 0, s, a);                          \
+            } while (0)
+            const int nsp = ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 4 ? 4 : 8;
+            if (seg == 64) { if (nsp == 1) RLX_HANDOFF(1, 64); else if (nsp == 2) RLX_HANDOFF(2, 64); else if (nsp == 4) RLX_HANDOFF(4, 64); else RLX_HANDOFF(8, 64); }
+            else if (seg == 32) { if (nsp == 1) RLX_HANDOFF(1, 32); else if (nsp == 2) RLX_HANDOFF(2, 32); else if (nsp == 4) RLX_HANDOFF(4, 32); else RLX_HANDOFF(8, 32); }
+            else { if (nsp == 1) RLX_HANDOFF(1, 16); else if (nsp == 2) RLX_HANDOFF(2, 16); else if (nsp == 4) RLX_HANDOFF(4, 16); else RLX_HANDOFF(8, 16); }
+#undef RLX_HANDOFF
+            RLX_LAUNCH_CHECK();
+        } else if (regseg) {
             RLX_REQUIRE(vec == 1 || vec == 2 || vec == 4, "rlx_gae_scan: regseg vec=%d", vec);
             RLX_REQUIRE(batch % vec == 0, "rlx_gae_scan: regseg vec=%d needs batch %% vec == 0 (batch=%d)", vec, batch);
             RLX_REQUIRE((unsigned long long)(a.T + 1) * (unsigned long long)batch * 4ull < (1ull << 31),

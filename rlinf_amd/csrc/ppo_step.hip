@@ -547,6 +547,44 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_kernel(StepArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int frag_row32(int r, int khalf) { return (r & 3) + 8 * (r >> 2) + 4 * khalf; }
 
+// ---- f32 products on the bf16 matrix pipe ("3 x bf16 split") ------------------------------------------------------------
+// An f32 number is EXACTLY hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (3 x 8 significand bits,
+// the differences are exact in f32: tests/test_bf16_split_exact.py), and a product of two bf16 numbers is exact in f32.  So
+// a . b = sum over the nine partial products; the six kept here -- hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid -- leave out terms
+// below 2^-24 of |a||b| (mid.lo, lo.mid, lo.lo), i.e. below the rounding of the f32 accumulation itself.  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each for K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each for K = 2): 2.7 x less
+// matrix-pipe time for the same f32-level accuracy -- the f32 MFMA rate of this part is 1/16 of its bf16 rate.  The operand
+// split runs on the VALU (packed converts), next to the matrix pipe.
+typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
+struct DwSplit3 {
+    dw_bf16x8 hi, mid, lo;
+};
+__device__ __forceinline__ DwSplit3 dw_split3(const float (&w)[8]) {
+    DwSplit3 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)w[j];
+        const float r1 = fsub(w[j], (float)h);
+        const __bf16 m = (__bf16)r1;
+        const float r2 = fsub(r1, (float)m);
+        q.hi[j] = h;
+        q.mid[j] = m;
+        q.lo[j] = (__bf16)r2;
+    }
+    return q;
+}
+__device__ __forceinline__ f32x16 dw_mfma6(const DwSplit3& a, const DwSplit3& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);   // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
+// SPLIT: the products run as 3 x bf16 splits on v_mfma_f32_32x32x16_bf16 (default); false: exact f32 products on
+// v_mfma_f32_32x32x2_f32 (RLX_F32_EXACT_MFMA=1).
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
     __shared__ __align__(16) float As[2][32][128];
     __shared__ __align__(16) float Bs[2][32][128];
@@ -646,17 +684,44 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
         if (c + 1 < nchunks) gload(c + 1);
+        if constexpr (SPLIT) {
+            // two 16-k blocks per 32-row chunk; lane (column lrow, k group khalf) holds k = 16 kb + 8 khalf + j, j = 0 .. 7 of its
+            // column for A and for B alike (K is only the summation index: the slots just have to pair up)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float af[2][8], bf[2][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * kb + 8 * khalf + j;
+                    af[0][j] = As[cur][k][wi * 64 + lrow];
+                    af[1][j] = As[cur][k][wi * 64 + 32 + lrow];
+                    bf[0][j] = Bs[cur][k][wj * 64 + lrow];
+                    bf[1][j] = Bs[cur][k][wj * 64 + 32 + lrow];
+                }
+                const DwSplit3 A0 = dw_split3(af[0]), A1 = dw_split3(af[1]), B0 = dw_split3(bf[0]), B1 = dw_split3(bf[1]);
+                acc[0][0] = dw_mfma6(A0, B0, acc[0][0]);
+                acc[0][1] = dw_mfma6(A0, B1, acc[0][1]);
+                acc[1][0] = dw_mfma6(A1, B0, acc[1][0]);
+                acc[1][1] = dw_mfma6(A1, B1, acc[1][1]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bsum[0] += af[0][j];
+                    bsum[1] += af[1][j];
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int kp = 0; kp < 16; ++kp) {
-            const int k = 2 * kp + khalf;
-            const float a0 = As[cur][k][wi * 64 + lrow], a1 = As[cur][k][wi * 64 + 32 + lrow];
-            const float b0 = Bs[cur][k][wj * 64 + lrow], b1 = Bs[cur][k][wj * 64 + 32 + lrow];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            bsum[0] += a0;
-            bsum[1] += a1;
+            for (int kp = 0; kp < 16; ++kp) {
+                const int k = 2 * kp + khalf;
+                const float a0 = As[cur][k][wi * 64 + lrow], a1 = As[cur][k][wi * 64 + 32 + lrow];
+                const float b0 = Bs[cur][k][wj * 64 + lrow], b1 = Bs[cur][k][wj * 64 + 32 + lrow];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                bsum[0] += a0;
+                bsum[1] += a1;
+            }
         }
         if (c + 1 < nchunks) swrite(cur ^ 1);
         __syncthreads();
@@ -872,7 +937,11 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
 #undef RLX_LAUNCH_FUSED
     RLX_LAUNCH_CHECK();
     const int blocks = dw_blocks;
-    hipLaunchKernelGGL(ppo_step_dw_kernel, dim3(blocks), dim3(256), 0, st, d);
+    // exact-f32 MFMA on request (RLX_F32_EXACT_MFMA=1); default: the same f32-accurate products as 3 x bf16 splits, 2.7 x less
+    // matrix-pipe time (see dw_mfma6)
+    static const bool exact = getenv("RLX_F32_EXACT_MFMA") != nullptr && atoi(getenv("RLX_F32_EXACT_MFMA")) != 0;
+    if (exact) hipLaunchKernelGGL(ppo_step_dw_kernel<false>, dim3(blocks), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(ppo_step_dw_kernel<true>, dim3(blocks), dim3(256), 0, st, d);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

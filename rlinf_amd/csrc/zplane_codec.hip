@@ -51,27 +51,104 @@ static_assert(sizeof(Header) == kHeaderBytes, "header layout");
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 __host__ __device__ inline size_t pad8(size_t x) { return (x + 7) & ~(size_t)7; }
 
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {lo (0..3), hi (4..7)}
+__device__ __forceinline__ uint32_t bperm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 4 x 4 byte transpose: elements w[0..3] (one dword each) -> p[j] = (w0.bj, w1.bj, w2.bj, w3.bj)
+__device__ __forceinline__ void transpose4(const uint32_t (&w)[4], uint32_t (&p)[4]) {
+    const uint32_t a = bperm(w[1], w[0], 0x05010400u), b = bperm(w[1], w[0], 0x07030602u);  // (w0.b0 w1.b0 w0.b1 w1.b1), (.. b2 .. b3)
+    const uint32_t c = bperm(w[3], w[2], 0x05010400u), d = bperm(w[3], w[2], 0x07030602u);
+    p[0] = bperm(c, a, 0x05040100u);
+    p[1] = bperm(c, a, 0x07060302u);
+    p[2] = bperm(d, b, 0x05040100u);
+    p[3] = bperm(d, b, 0x07060302u);
+}
+
 // Load one block (up to 4096 elements of ES bytes) and split it into byte planes in LDS; bytes past n_bytes read as zero.
+// Coalesced 16-byte global loads; the byte de-interleave runs in registers (v_perm_b32), so a lane's LDS stores are whole words:
+// ES = 1 one b128, ES = 2 two b64, ES = 4 four b32, ES = 8 eight b32 per 32 input bytes (byte stores made this the codec's
+// slowest phase by far).
 template <int ES>
 __device__ __forceinline__ void load_planes(const uint8_t* __restrict__ in, size_t block_byte0, size_t n_bytes_total, uint8_t* planes) {
-    constexpr int BYTES = kBlock * ES;
+    constexpr int BYTES = kBlock * ES, STEP = ES == 8 ? 32 : 16;  // input bytes per lane and trip
     const uint8_t* src = in + block_byte0;
     const size_t avail = n_bytes_total > block_byte0 ? n_bytes_total - block_byte0 : 0;
-    // 16-byte chunks (the input pointer is 16-byte aligned and block_byte0 is a multiple of 4096): coalesced dwordx4 loads
-    for (int c = threadIdx.x; c < BYTES / 16; c += kThreads) {
-        const size_t b0 = (size_t)c * 16;
-        union { uint4 v; uint8_t b[16]; } u;
-        uint8_t* tmp = u.b;
-        if (b0 + 16 <= avail) {
-            u.v = *reinterpret_cast<const uint4*>(src + b0);
+    for (int c = threadIdx.x; c < BYTES / STEP; c += kThreads) {
+        const size_t b0 = (size_t)c * STEP;
+        union { uint4 v[STEP / 16]; uint32_t w[STEP / 4]; uint8_t b[STEP]; } u;
+        if (b0 + STEP <= avail) {
+#pragma unroll
+            for (int q = 0; q < STEP / 16; ++q) u.v[q] = *reinterpret_cast<const uint4*>(src + b0 + 16 * q);
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) tmp[k] = (b0 + k < avail) ? src[b0 + k] : (uint8_t)0;
+            for (int k = 0; k < STEP; ++k) u.b[k] = (b0 + k < avail) ? src[b0 + k] : (uint8_t)0;
         }
+        const int e0 = (int)(b0 / ES);  // first element of this chunk
+        if constexpr (ES == 1) {
+            *reinterpret_cast<uint4*>(planes + e0) = u.v[0];
+        } else if constexpr (ES == 2) {  // 8 elements: even bytes -> plane 0, odd bytes -> plane 1
+            uint2 p0, p1;
+            p0.x = bperm(u.w[1], u.w[0], 0x06040200u); p1.x = bperm(u.w[1], u.w[0], 0x07050301u);
+            p0.y = bperm(u.w[3], u.w[2], 0x06040200u); p1.y = bperm(u.w[3], u.w[2], 0x07050301u);
+            *reinterpret_cast<uint2*>(planes + e0) = p0;
+            *reinterpret_cast<uint2*>(planes + kBlock + e0) = p1;
+        } else if constexpr (ES == 4) {  // 4 elements
+            uint32_t w[4] = {u.w[0], u.w[1], u.w[2], u.w[3]}, p[4];
+            transpose4(w, p);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int byte = (int)b0 + k;
-            planes[(byte % ES) * kBlock + byte / ES] = tmp[k];
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t*>(planes + j * kBlock + e0) = p[j];
+        } else {  // ES == 8: 4 elements = 8 dwords; low dwords feed planes 0..3, high dwords planes 4..7
+            uint32_t lo[4] = {u.w[0], u.w[2], u.w[4], u.w[6]}, hi[4] = {u.w[1], u.w[3], u.w[5], u.w[7]}, p[4], q[4];
+            transpose4(lo, p);
+            transpose4(hi, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint32_t*>(planes + j * kBlock + e0) = p[j];
+                *reinterpret_cast<uint32_t*>(planes + (4 + j) * kBlock + e0) = q[j];
+            }
+        }
+    }
+}
+
+// inverse of load_planes: the block's planes -> interleaved elements, 16 (ES = 8: 32) output bytes per lane and trip
+template <int ES>
+__device__ __forceinline__ void store_planes(const uint8_t* planes, uint8_t* __restrict__ dst, size_t valid) {
+    constexpr int BYTES = kBlock * ES, STEP = ES == 8 ? 32 : 16;
+    for (int c = threadIdx.x; c < BYTES / STEP; c += kThreads) {
+        const size_t b0 = (size_t)c * STEP;
+        if (b0 >= valid) break;
+        union { uint4 v[STEP / 16]; uint32_t w[STEP / 4]; uint8_t b[STEP]; } u;
+        const int e0 = (int)(b0 / ES);
+        if constexpr (ES == 1) {
+            u.v[0] = *reinterpret_cast<const uint4*>(planes + e0);
+        } else if constexpr (ES == 2) {
+            const uint2 p0 = *reinterpret_cast<const uint2*>(planes + e0), p1 = *reinterpret_cast<const uint2*>(planes + kBlock + e0);
+            u.w[0] = bperm(p1.x, p0.x, 0x05010400u); u.w[1] = bperm(p1.x, p0.x, 0x07030602u);  // (p0.b0 p1.b0 p0.b1 p1.b1), (.. b2 .. b3)
+            u.w[2] = bperm(p1.y, p0.y, 0x05010400u); u.w[3] = bperm(p1.y, p0.y, 0x07030602u);
+        } else if constexpr (ES == 4) {  // the 4 x 4 byte transpose is its own inverse
+            uint32_t p[4], w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = *reinterpret_cast<const uint32_t*>(planes + j * kBlock + e0);
+            transpose4(p, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u.w[j] = w[j];
+        } else {
+            uint32_t p[4], q[4], lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[j] = *reinterpret_cast<const uint32_t*>(planes + j * kBlock + e0);
+                q[j] = *reinterpret_cast<const uint32_t*>(planes + (4 + j) * kBlock + e0);
+            }
+            transpose4(p, lo);
+            transpose4(q, hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { u.w[2 * j] = lo[j]; u.w[2 * j + 1] = hi[j]; }
+        }
+        if (b0 + STEP <= valid) {
+#pragma unroll
+            for (int q = 0; q < STEP / 16; ++q) *reinterpret_cast<uint4*>(dst + b0 + 16 * q) = u.v[q];
+        } else {
+            for (int k = 0; k < STEP && b0 + k < valid; ++k) dst[b0 + k] = u.b[k];
         }
     }
 }
@@ -80,18 +157,49 @@ __device__ __forceinline__ void load_planes(const uint8_t* __restrict__ in, size
 // group's last byte
 __device__ __forceinline__ uint8_t xor_prev(const uint8_t* plane, int i) { return plane[i] ^ (i > 0 ? plane[i - 1] : (uint8_t)0); }
 
-// mask bookkeeping of one plane-block, one wave: nz = nonzero bytes, ng = nonzero groups, plain and under the XOR filter
+// 4-bit "byte is nonzero" mask of a dword (bit j = byte j): the classic has-zero-byte carry trick, then a multiply that gathers
+// bits 0, 8, 16, 24 into one nibble (all partial products land on distinct bit positions: no carries)
+__device__ __forceinline__ uint32_t nz4(uint32_t w) {
+    const uint32_t t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+    return ((t >> 7) * 0x01020408u) >> 24;
+}
+__device__ __forceinline__ uint32_t nz16(const uint4& v) { return nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12); }
+
+// mask bookkeeping of one plane-block, one wave: nz = nonzero bytes, ng = nonzero 64-byte groups, plain and under the XOR filter.
+// A lane reads 16 consecutive bytes (one b128) of a 1024-byte span -- four lanes make a group -- and works on them in registers;
+// the byte in front of a lane's first one comes from its neighbour (or the previous span's last lane).
 __device__ __forceinline__ void plane_stats(const uint8_t* plane, int& nz, int& ng, int& nzx, int& ngx) {
     const int lane = threadIdx.x & 63;
-    nz = ng = nzx = ngx = 0;
-    for (int g = 0; g < kGroups; ++g) {
-        const uint64_t m = __ballot(plane[g * 64 + lane] != 0);
-        const uint64_t mx = __ballot(xor_prev(plane, g * 64 + lane) != 0);
-        nz += __popcll(m);
-        ng += m != 0;
-        nzx += __popcll(mx);
-        ngx += mx != 0;
+    int cnt = 0, cntx = 0;
+    ng = ngx = 0;
+    uint32_t carry = 0;  // last byte of the previous span (in the low byte)
+#pragma unroll
+    for (int sp = 0; sp < kBlock / 1024; ++sp) {
+        const uint4 v = *reinterpret_cast<const uint4*>(plane + sp * 1024 + lane * 16);
+        uint32_t prev = (uint32_t)__shfl_up((int)(v.w >> 24), 1, 64);
+        if (lane == 0) prev = carry;
+        carry = (uint32_t)__shfl((int)(v.w >> 24), 63, 64);
+        uint4 x;  // v XOR (v shifted up by one byte, with the predecessor byte coming in at the bottom)
+        x.x = v.x ^ ((v.x << 8) | prev);
+        x.y = v.y ^ ((v.y << 8) | (v.x >> 24));
+        x.z = v.z ^ ((v.z << 8) | (v.y >> 24));
+        x.w = v.w ^ ((v.w << 8) | (v.z >> 24));
+        const uint32_t m = nz16(v), mx = nz16(x);
+        cnt += __popc(m);
+        cntx += __popc(mx);
+        // a group is nonzero iff any of its four lanes holds a nonzero byte: OR over the quad, counted once per quad
+        const uint64_t any = __ballot(m != 0), anyx = __ballot(mx != 0);
+        uint64_t q = any | (any >> 1) | (any >> 2) | (any >> 3), qx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
+        ng += __popcll(q & 0x1111111111111111ull);
+        ngx += __popcll(qx & 0x1111111111111111ull);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        cntx += __shfl_xor(cntx, off, 64);
+    }
+    nz = cnt;
+    nzx = cntx;
 }
 
 template <int ES>
@@ -260,25 +368,8 @@ __global__ __launch_bounds__(kThreads) void zplane_unpack(const uint8_t* __restr
         }
     }
     __syncthreads();
-    // interleave the planes back into elements: 16 output bytes per thread and trip, coalesced
-    uint8_t* dst = out + (size_t)blk * kBlock * ES;
-    const size_t valid = (size_t)in_block * ES;
-    for (int c = threadIdx.x; c < kBlock * ES / 16; c += kThreads) {
-        const size_t b0 = (size_t)c * 16;
-        if (b0 >= valid) break;
-        union { uint4 v; uint8_t b[16]; } u;
-        uint8_t* tmp = u.b;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int byte = (int)b0 + k;
-            tmp[k] = planes[(byte % ES) * kBlock + byte / ES];
-        }
-        if (b0 + 16 <= valid) {
-            *reinterpret_cast<uint4*>(dst + b0) = u.v;
-        } else {
-            for (int k = 0; k < 16 && b0 + k < valid; ++k) dst[b0 + k] = tmp[k];
-        }
-    }
+    // interleave the planes back into elements (coalesced 16-byte stores)
+    store_planes<ES>(planes, out + (size_t)blk * kBlock * ES, (size_t)in_block * ES);
 }
 
 inline long long blocks_of(int64_t n) { return (n + kBlock - 1) / kBlock; }

@@ -215,6 +215,34 @@ def test_scaled_buffer_streaming_vs_segmented_agree():
             torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("T,B", [(128, 65536), (128, 1024), (100, 700), (130, 129), (40, 64), (512, 256)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_gae_handoff_variant_is_bit_identical(T, B, masked):
+    """gae_scan_handoff (register-resident time segments, the recurrence handed down a chain BEFORE any store, then every segment's
+    full pass at once: variant bit 28, segment length in bits 29-30): the sequential loop's own operations in its own order, so
+    bit-identical to the streaming scan and to the CPU loop -- ragged last segments, more / fewer envs than a wave, with and
+    without a loss mask and the normalisation behind it.  (Built to test whether the 64-deep vmcnt window bounds the streaming
+    scan at the roofline shape; it does not -- profiles/r03_gae_handoff_sweep_*.txt -- the variant stays as a tested alternative.)"""
+    ops = _ops()
+    r = synth_rollout(seed=7, T=T, B=B, p_done=0.03)
+    lm = None
+    if masked:
+        lm, _ = O.loss_mask_from_dones(r["dones"])
+    rc, vc, dc = r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda()
+    lmc = None if lm is None else lm.cuda()
+    base = ops.gae_scan(rc, vc, dc, lmc, 0.99, 0.95, normalize_advantages=False, variant=1)
+    base_n = ops.gae_scan(rc, vc, dc, lmc, 0.99, 0.95, normalize_advantages=True, variant=1)
+    for seg_code, seg in ((2, 64), (1, 32), (0, 16)):
+        if (T + seg - 1) // seg > 8:
+            continue
+        for nt in (0, 1):
+            variant = 1 | (1 << 8) | (nt << 25) | (1 << 28) | (seg_code << 29)
+            adv, ret = ops.gae_scan(rc, vc, dc, lmc, 0.99, 0.95, normalize_advantages=False, variant=variant)
+            assert torch.equal(adv, base[0]) and torch.equal(ret, base[1]), (seg, nt)
+            adv_n, _ = ops.gae_scan(rc, vc, dc, lmc, 0.99, 0.95, normalize_advantages=True, variant=variant)
+            torch.testing.assert_close(adv_n, base_n[0], rtol=RTOL, atol=ATOL)  # the moment partials sum in another order
+
+
 @pytest.mark.parametrize("C", [1, 3])
 @pytest.mark.parametrize("masked", [False, True])
 def test_reward_filter_mask(C, masked):

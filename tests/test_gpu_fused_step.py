@@ -216,6 +216,67 @@ def test_ppo_step_two_action_chunks(M, case, bf16):
         assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(float(metrics[key]), **tol), key
 
 
+def test_f32_weight_gradients_split_vs_exact_mfma():
+    """The f32 weight-gradient launch runs its products as 3 x bf16 splits on the bf16 matrix pipe (six of the nine partial
+    products: what is dropped lies below 2^-24 of |a||b|); RLX_F32_EXACT_MFMA=1 selects the exact f32 MFMA.  Same minibatch through
+    both, in two processes (the switch is read once per process): each within the f32 tolerance of the oracle's autograd, and
+    within 2e-6 relative L2 of each other -- the split is f32-accurate, not bf16-accurate."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    from conftest import ROOT
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from oracle import ppo_oracle as O
+from rlinf_amd import ops
+from rlinf_amd._lib import PPO_OUT_FLOATS
+from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+torch.manual_seed(11)
+ora = O.OracleMLPPolicy(42, 8, 1)
+pol = MLPPolicy(42, 8, 1, True, False)
+pol.load_reference_state_dict(ora.state_dict())
+pol = pol.to("cuda")
+g = torch.Generator().manual_seed(5)
+M = 8192
+mb = dict(states=torch.randn(M, 42, generator=g), action=torch.randn(M, 8, generator=g) * 0.6, advantages=torch.randn(M, 1, generator=g),
+          prev_values=torch.randn(M, 1, generator=g), returns=torch.randn(M, 1, generator=g))
+with torch.no_grad():
+    mb["prev_logprobs"] = ora.evaluate(mb["states"], mb["action"])["logprobs"] + torch.randn(M, 8, generator=g) * 0.08
+out = ora.evaluate(mb["states"], mb["action"])
+shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8, values=out["values"],
+                             prev_values=mb["prev_values"], returns=mb["returns"])
+loss, _ = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+loss.backward()
+want = torch.cat([p.grad.reshape(-1) for p in ora.parameters()])
+lay = pol.layout
+lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0,
+                         huber_delta=10.0, max_episode_steps=50, has_critic=True)
+grads = torch.full((ops.ppo_step_slabs(lay, M), lay.n_params), float("nan"), device="cuda")
+ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+ops.ppo_step(pol.flat.data, lay, lp, {k: v.cuda().contiguous() for k, v in mb.items()}, grads, row, ws, grad_out=1.0)
+got = grads.sum(dim=0).cpu()
+torch.save(dict(got=got, want=want), sys.argv[1])
+""" % ROOT
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, flag in (("split", "0"), ("exact", "1")):
+            out = os.path.join(d, name + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, RLX_F32_EXACT_MFMA=flag), capture_output=True,
+                               text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[name] = torch.load(out)
+    want = res["split"]["want"]
+    for name in ("split", "exact"):
+        rel = float((res[name]["got"] - want).norm() / want.norm())
+        assert rel <= 2e-5, (name, rel)
+    between = float((res["split"]["got"] - res["exact"]["got"]).norm() / want.norm())
+    assert 0 < between <= 2e-6, between   # different arithmetic (not the same kernel twice), f32-level agreement
+
+
 def test_ppo_step_matches_unfused_chain():
     """Same micro-batch through the stage-by-stage entry points (train_fwd -> ppo_loss -> train_bwd)."""
     from rlinf_amd import ops

@@ -7,8 +7,12 @@ from rlinf_amd import ops
 from rlinf_amd._lib import RlxError
 
 
-def V(vec, nseg, rows=0, nt=0, regseg=0, seg16=0):
-    return vec | (nseg << 8) | (rows << 16) | (nt << 25) | (regseg << 26) | (seg16 << 27)
+def V(vec, nseg, rows=0, nt=0, regseg=0, seg16=0, handoff_seg=0):
+    """handoff_seg: 16 / 32 / 64 selects gae_scan_handoff (register-resident segments, early hand-off) with that segment length"""
+    v = vec | (nseg << 8) | (rows << 16) | (nt << 25) | (regseg << 26) | (seg16 << 27)
+    if handoff_seg:
+        v |= (1 << 28) | ({16: 0, 32: 1, 64: 2}[handoff_seg] << 29)
+    return v
 
 
 def main():
@@ -24,7 +28,8 @@ def main():
         bufs.append((r, v, d, torch.empty_like(r), torch.empty_like(r)))
     combos = [(V(1, 1, rows, nt), f"stream rows={rows} nt={nt}") for rows in (8, 64) for nt in (0, 1)]
     combos += [(V(vec, 1, 0, nt, 1, s16), f"regseg vec={vec} seg={16 if s16 else 32} nt={nt}")
-               for vec, s16 in ((1, 0), (1, 1), (2, 0), (2, 1), (4, 1)) for nt in (0, 1)]
+               for vec, s16 in ((1, 0), (1, 1)) for nt in (0, 1)]
+    combos += [(V(1, 1, 0, nt, handoff_seg=seg), f"handoff seg={seg} nt={nt}") for seg in (64, 32, 16) for nt in (0, 1)]
     # correctness: every variant must reproduce the streaming scan bit for bit
     r, v, d, a0, q0 = bufs[0]
     ops.gae_scan(r, v, d, None, 0.99, 0.95, normalize_advantages=False, variant=V(1, 1), out=(a0, q0))
