@@ -231,7 +231,8 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2 and line["value"] > 0
     assert line["config"]["total_envs"] == 1024 and line["config"]["global_batch"] == 8192 and line["config"]["parallelism"] == "dp2"
     assert line["weak_scaling"]["total_envs"] == 2048 and line["weak_scaling"]["global_batch"] == 16384
-    assert set(line["transports"]) == {"strong/xgmi", "strong/rccl", "weak/xgmi", "weak/rccl"}, line.get("transport_errors")
+    assert set(line["transports"]) == {"strong/rccl-eager", "strong/xgmi", "strong/rccl", "weak/xgmi", "weak/rccl"}, line.get("transport_errors")
+    assert line["transports"]["strong/rccl-eager"]["update_graph_replayed"] is False
     assert line["transports"]["strong/xgmi"]["grad_allreduce"].startswith("xgmi (direct, kernel hand-shake)")
     assert line["transports"]["strong/xgmi"]["update_graph_replayed"] is True    # a pure kernel chain: captured at any world size
     assert line["transports"]["strong/rccl"]["update_graph_replayed"] is False   # gloo cannot be captured: eager fallback, both ranks
