@@ -194,6 +194,25 @@ def load_function(rel_path: str, name: str, **globs):
     return ns[name]
 
 
+def load_class(rel_path: str, name: str, **globs):
+    """One top-level class of a reference file whose module cannot be imported here, compiled on its own from its source where it
+    lies (signature annotations dropped, decorators of its methods kept).  ``globs`` supplies the names its bodies refer to."""
+    import ast
+
+    path = os.path.join(REFERENCE_ROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == name)
+    node.decorator_list = []
+    for fn in ast.walk(node):
+        if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)):
+            fn.returns = None
+            for a in fn.args.args + fn.args.kwonlyargs:
+                a.annotation = None
+    ns = dict(globs)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
 _tb_cache = None
 
 

@@ -9,6 +9,7 @@ Restates the control flow of FSDPActor.run_training / training_step / forward_ba
   micro-batch     model(...).logits / temperature -> response window -> log-prob / entropy -> PPO token loss (+ entropy bonus,
                   + KL to the reference policy) / gradient_accumulation -> backward
   optimizer step  clip_grad_norm_ + AdamW, skipped when the norm is not finite (fsdp_model_manager.py:429-463)
+  pipeline mode   pipeline_iteration: run_training_pipeline :816-854 over BatchResizingIterator (reasoning_results.py:1424-1600)
 tests/test_reference_reasoning_loop.py pins it bit for bit against the reference's own run_training / training_step /
 forward_batch compiled from source around the same tiny model; the HIP learner (rlinf_amd.workers.actor.fsdp_actor_worker.
 FSDPActor) is compared with THIS loop on the GPU (tests/test_gpu_reasoning_loop.py).  Nothing in rlinf_amd/ imports it."""
@@ -103,27 +104,100 @@ def iteration(model, opt, batch: dict, *, response_len: int, micro_batch: int, n
     for i in range(n_minibatches):
         mini = {k: v[i * per:(i + 1) * per] for k, v in batch.items() if isinstance(v, torch.Tensor)}
         accum = per // micro_batch
-        opt.zero_grad()
-        rows = []
-        for j in range(accum):
-            mb = {k: v[j * micro_batch:(j + 1) * micro_batch] for k, v in mini.items()}
-            logits = model(input_ids=mb["input_ids"], attention_mask=mb["attention_mask"], position_ids=mb["position_ids"],
-                           use_cache=False).logits
-            old = mb.get("recomputed_logprobs")
-            if old is None:
-                old = mb["rollout_logprobs"]
-            loss, metrics, _, _ = TO.reasoning_micro_batch_loss(
-                logits[:, -response_len - 1:-1, :], mb["input_ids"][:, -response_len:], old, mb["advantages"],
-                mb["response_mask"][:, -response_len:], temperature=temperature, loss_agg=loss_agg, clip_ratio_low=clip_ratio_low,
-                clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c, calculate_entropy=calculate_entropy,
-                entropy_bonus=entropy_bonus, ref_logprobs=mb.get("ref_logprobs"), kl_beta=kl_beta, kl_penalty_type=kl_penalty_type,
-                gradient_accumulation=accum)
-            loss.backward()
-            rows.append(metrics)
-        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad)
-        if torch.isfinite(gn):
-            opt.step()
-        m = {k: float(torch.mean(torch.stack([torch.as_tensor(r[k], dtype=torch.float32) for r in rows]))) for k in rows[0]}
-        m["actor/grad_norm"] = float(gn)
-        out.append(m)
+        micro = [{k: v[j * micro_batch:(j + 1) * micro_batch] for k, v in mini.items()} for j in range(accum)]
+        out.append(optimizer_step(model, opt, micro, response_len=response_len, temperature=temperature, loss_agg=loss_agg,
+                                  clip_ratio_low=clip_ratio_low, clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c,
+                                  calculate_entropy=calculate_entropy, entropy_bonus=entropy_bonus, kl_beta=kl_beta,
+                                  kl_penalty_type=kl_penalty_type, clip_grad=clip_grad))
     return batch, out
+
+
+def optimizer_step(model, opt, micro_batches: list, *, response_len: int, temperature: float, loss_agg: str, clip_ratio_low: float,
+                   clip_ratio_high: float, clip_ratio_c: float, calculate_entropy: bool, entropy_bonus: float, kl_beta: float,
+                   kl_penalty_type: str, clip_grad: float) -> dict:
+    """training_step (:659-813) over the micro-batches of one global batch -> its metric dict."""
+    accum = len(micro_batches)
+    opt.zero_grad()
+    rows = []
+    for mb in micro_batches:
+        logits = model(input_ids=mb["input_ids"], attention_mask=mb["attention_mask"], position_ids=mb["position_ids"],
+                       use_cache=False).logits
+        old = mb.get("recomputed_logprobs")
+        if old is None:
+            old = mb["rollout_logprobs"]
+        loss, metrics, _, _ = TO.reasoning_micro_batch_loss(
+            logits[:, -response_len - 1:-1, :], mb["input_ids"][:, -response_len:], old, mb["advantages"],
+            mb["response_mask"][:, -response_len:], temperature=temperature, loss_agg=loss_agg, clip_ratio_low=clip_ratio_low,
+            clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c, calculate_entropy=calculate_entropy,
+            entropy_bonus=entropy_bonus, ref_logprobs=mb.get("ref_logprobs"), kl_beta=kl_beta, kl_penalty_type=kl_penalty_type,
+            gradient_accumulation=accum)
+        loss.backward()
+        rows.append(metrics)
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad)
+    if torch.isfinite(gn):
+        opt.step()
+    m = {k: float(torch.mean(torch.stack([torch.as_tensor(r[k], dtype=torch.float32) for r in rows]))) for k in rows[0]}
+    m["actor/grad_norm"] = float(gn)
+    return m
+
+
+def _shuffled_split(batch: dict, num_splits: int, shuffle: bool, seed: int):
+    """get_iterator_k_split (rlinf/utils/data_iter_utils.py:129-262): one permutation from a generator seeded HERE (equal sizes ->
+    equal permutations), then equal row ranges."""
+    tensors = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    n = next(iter(tensors.values())).shape[0]
+    assert n % num_splits == 0
+    if shuffle:
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(seed))
+        tensors = {k: v[perm] for k, v in tensors.items()}
+    per = n // num_splits
+    return [{k: v[i * per:(i + 1) * per] for k, v in tensors.items()} for i in range(num_splits)]
+
+
+def pipeline_iteration(model, opt, received: list, *, total: int, response_len: int, micro_batch: int, n_minibatches: int, seed: int,
+                       adv_type: str = "grpo", group_size: int = 1, normalize_advantages: bool = True, shuffle: bool = True,
+                       temperature: float = 1.0, loss_agg: str = "token-mean", clip_ratio_low: float = 0.2, clip_ratio_high: float = 0.2,
+                       clip_ratio_c: float = 3.0, calculate_entropy: bool = False, entropy_bonus: float = 0.0, kl_beta: float = 0.0,
+                       kl_penalty_type: str = "low_var_kl", clip_grad: float = 1.0, reinpp_kl_beta: float = 0.0):
+    """FSDPActor.run_training_pipeline (:816-854) around BatchResizingIterator (rlinf/data/schema/reasoning_results.py:1424-1600):
+    ``received`` = the rank's rollout pieces in arrival order.  Every piece gets its advantages when it arrives; a piece smaller than
+    a global batch (total / n_minibatches sequences) is topped up with the following pieces when advantages are normalised (the
+    normalisation needs whole global batches), otherwise handed on as it is; pieces are shuffled and cut into global batches,
+    each global batch is normalised ON ITS OWN, shuffled again (same seed) and cut into micro-batches; every optimizer step takes
+    global / micro of them.  -> (everything trained on, in consumption order; per-step metric dicts)."""
+    gbs = total // n_minibatches
+    feed = list(received)
+
+    def receive():
+        return advantages(dict(feed.pop(0)), response_len=response_len, adv_type=adv_type, group_size=group_size,
+                          reinpp_kl_beta=reinpp_kl_beta, kl_penalty_type=kl_penalty_type)
+
+    def cat(a, b):
+        return {k: torch.cat([a[k], b[k]]) for k in a if isinstance(a[k], torch.Tensor)}
+
+    def micro_batches():
+        while feed:
+            piece = receive()
+            n = piece["input_ids"].shape[0]
+            if n % gbs != 0 and not normalize_advantages:
+                globals_ = [piece]
+            else:
+                while n < gbs and n % gbs != 0:
+                    piece = cat(piece, receive())
+                    n = piece["input_ids"].shape[0]
+                globals_ = _shuffled_split(piece, n // gbs, shuffle, seed)
+            for g in globals_:
+                if normalize_advantages:
+                    g = dict(g)
+                    g["advantages"] = O.masked_normalization(g["advantages"], g["response_mask"][:, -response_len:]).float()
+                yield from _shuffled_split(g, g["input_ids"].shape[0] // micro_batch, shuffle, seed)
+
+    stream, seen, out = micro_batches(), [], []
+    for _ in range(n_minibatches):
+        micro = [next(stream) for _ in range(gbs // micro_batch)]
+        seen.extend(micro)
+        out.append(optimizer_step(model, opt, micro, response_len=response_len, temperature=temperature, loss_agg=loss_agg,
+                                  clip_ratio_low=clip_ratio_low, clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c,
+                                  calculate_entropy=calculate_entropy, entropy_bonus=entropy_bonus, kl_beta=kl_beta,
+                                  kl_penalty_type=kl_penalty_type, clip_grad=clip_grad))
+    return {k: torch.cat([m[k] for m in seen]) for k in seen[0]}, out

@@ -231,7 +231,8 @@ class FSDPActor:
     ``training_step`` each), ``training_step`` (:659-813: micro-batches, forward -> log-prob / entropy -> loss -> backward with
     1 / gradient_accumulation, then clip + AdamW), ``inference_step`` / ``run_inference`` (:509-558: recomputed and reference-policy
     log-probs, micro-batch by micro-batch without a graph), ``compute_advantages_and_returns`` (:941-978), ``_dp_load_balance``
-    (:846-858).
+    (:846-858), ``run_training_pipeline`` (:816-854: pipeline mode, micro-batches streamed out of a ``BatchResizingIterator``
+    while pieces of the rollout are still arriving).
 
     What runs where: the transformer is the caller's (any module returning ``.logits`` [bsz, seq, vocab]: model backends are out
     of scope); everything from the logits on is this package's kernels -- one read of the logits forward, one read +
@@ -257,6 +258,10 @@ class FSDPActor:
         self.total_batch_size_per_dp = (int(_get(data, "rollout_batch_size")) * int(_get(algo, "group_size", 1))) // self._world_size
         assert int(_get(actor, "global_batch_size")) % (self.micro_batch_size * self._world_size) == 0  # :915-919
         self.enable_dp_load_balance = bool(_get(actor, "enable_dp_load_balance", False))
+        # the reference reads this off the placement (``is_disaggregated``, :135); here: ``actor.pipeline`` / ``cluster.pipeline``
+        self.is_pipeline = bool(_get(actor, "pipeline", _get(_get(cfg, "cluster") or {}, "pipeline", False)))
+        if self.is_pipeline:
+            assert not self.enable_dp_load_balance, "DP load balance is not supported in pipeline mode."  # :160-163
         self.logprob_forward_micro_batch_size = int(_get(algo, "logprob_forward_micro_batch_size", self.micro_batch_size))
         self.shuffle_rollout = bool(_get(algo, "shuffle_rollout", True))
         self.seed = int(_get(actor, "seed", 1234))
@@ -383,11 +388,17 @@ class FSDPActor:
         self.optimizer_steps += 1
         return self.opt_stats[0], [self.lr]
 
-    def training_step(self, batch: Mapping) -> dict:
-        global_batch_size = batch["input_ids"].shape[0]
-        assert global_batch_size % self.micro_batch_size == 0, (
-            f"global batch size {global_batch_size} can not divide micro_batch_size {self.micro_batch_size}")
-        micro_batches, cnt = self._split_to_micro_batch(batch, global_batch_size // self.micro_batch_size)
+    def training_step(self, batch) -> dict:
+        """``batch``: one global batch (a dict, cut into micro-batches here) or, in pipeline mode, the ``BatchResizingIterator``
+        the step pulls its ``global_batch / micro_batch`` micro-batches from (:662-683)."""
+        if isinstance(batch, Mapping):
+            global_batch_size = batch["input_ids"].shape[0]
+            assert global_batch_size % self.micro_batch_size == 0, (
+                f"global batch size {global_batch_size} can not divide micro_batch_size {self.micro_batch_size}")
+            micro_batches, cnt = self._split_to_micro_batch(batch, global_batch_size // self.micro_batch_size)
+        else:
+            cnt = (self.total_batch_size_per_dp // self.n_mini_batches) // self.micro_batch_size
+            micro_batches = (next(batch) for _ in range(cnt))
         self.gradient_accumulation = cnt
         self.grad_flat.zero_()  # optimizer.zero_grad(): the parameters' .grad are views of this buffer
         rows = []
@@ -415,7 +426,27 @@ class FSDPActor:
         batch = input_channel.get() if hasattr(input_channel, "get") else input_channel.pop(0)
         return batch, batch["input_ids"].shape[0]
 
+    def run_training_pipeline(self, input_channel):
+        """:816-854 -- the rollout side is still producing: every received piece gets its advantages at once, pieces are topped up
+        / cut to global batches, each global batch is normalised on its own, and ``n_minibatches`` optimizer steps pull their
+        micro-batches from the stream; the rollout metrics are taken over everything that was trained on."""
+        from functools import partial
+
+        from ...data.batch_iterator import BatchResizingIterator
+        self.model.train()
+        it = BatchResizingIterator(cfg=self.cfg, get_batch_fn=partial(self.get_batch, input_channel), micro_batch_size=self.micro_batch_size,
+                                   total_batch_size=self.total_batch_size_per_dp, num_global_batches=self.n_mini_batches,
+                                   forward_only=False)
+        it.register_get_batch_handler(self.compute_advantages_and_returns)
+        if self.step.normalize_advantages:
+            it.register_global_batch_handler(
+                lambda b: self.step.normalize_batch_advantages(b, self.ctx if self._world_size > 1 else None))
+        training_metrics_list = [self.training_step(it) for _ in range(self.n_mini_batches)]
+        return self.rollout_metrics(it.get_all_batches()), training_metrics_list
+
     def run_training(self, input_channel):
+        if self.is_pipeline:
+            return self.run_training_pipeline(input_channel)
         batches, got = [], 0
         while got < self.total_batch_size_per_dp:
             batch, n = self.get_batch(input_channel)

@@ -92,6 +92,60 @@ def test_run_training_matches_the_oracle_loop(case):
     assert rollout_metrics["advantages_mean"] == pytest.approx(float(shuffled["advantages"][mask].double().mean()), rel=1e-3, abs=1e-5)
 
 
+@pytest.mark.parametrize("case", [
+    dict(sizes=(32,)),
+    dict(sizes=(16, 16), loss_agg="seq-mean-token-sum", temperature=0.7, entropy_bonus=0.01),
+    dict(sizes=(8, 8, 16), normalize=True),
+    dict(sizes=(8, 8, 8, 8), normalize=False, group_size=2),
+    dict(sizes=(16, 8, 8), adv_type="reinpp", normalize=False),
+], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()))
+def test_run_training_pipeline_matches_the_oracle_loop(case):
+    """Pipeline mode (``actor.pipeline``): the rollout arrives in pieces; FSDPActor.run_training -> run_training_pipeline over
+    rlinf_amd.data.batch_iterator.BatchResizingIterator against oracle.token_loop.pipeline_iteration, which
+    tests/test_reference_reasoning_loop.py pins bit for bit to the reference's run_training_pipeline + its own iterator class."""
+    from rlinf_amd.scheduler import init_distributed
+    from rlinf_amd.workers.actor.fsdp_actor_worker import FSDPActor
+    resp, prompt, vocab, dim = 12, 6, 211, 32
+    total, micro, n_mini, group = 32, 8, 2, case.get("group_size", 4)
+    torch.manual_seed(5)
+    base = TL.TinyCausalLM(vocab, dim, prompt + resp)
+    batch = {k: v for k, v in TL.synthetic_rollout_batch(7, total, prompt, resp, vocab).items() if isinstance(v, torch.Tensor)}
+    cfg = _cfg(resp=resp, prompt=prompt, micro=micro, n_mini=n_mini, total=total, group_size=group, case=case)
+    cfg["actor"]["pipeline"] = True
+    actor = FSDPActor(cfg, init_distributed(), model=copy.deepcopy(base))
+    assert actor.is_pipeline
+
+    def pieces(to_dev):
+        out, lo = [], 0
+        for n in case["sizes"]:
+            out.append({k: (v[lo:lo + n].to(DEV) if to_dev else v[lo:lo + n].clone()) for k, v in batch.items()})
+            lo += n
+        return out
+
+    ora = copy.deepcopy(base)
+    opt = torch.optim.AdamW(ora.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    trained_on, want_metrics = TL.pipeline_iteration(
+        ora, opt, pieces(False), total=total, response_len=resp, micro_batch=micro, n_minibatches=n_mini, seed=1234,
+        adv_type=case.get("adv_type", "grpo"), group_size=group, normalize_advantages=case.get("normalize", True),
+        temperature=case.get("temperature", 1.0), loss_agg=case.get("loss_agg", "token-mean"), clip_ratio_low=0.2, clip_ratio_high=0.28,
+        calculate_entropy=case.get("entropy_bonus", 0) > 0, entropy_bonus=case.get("entropy_bonus", 0.0), clip_grad=1.0)
+    feed = pieces(True)
+    rollout_metrics, got_metrics = actor.run_training(feed)
+    assert not feed and len(got_metrics) == n_mini == len(want_metrics)
+    for w, g in zip(want_metrics, got_metrics):
+        for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "actor/entropy_loss", "actor/grad_norm"):
+            assert g[k] == pytest.approx(w[k], rel=2e-3, abs=2e-5), (k, g[k], w[k])
+    want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+    diff = (actor.flat.cpu() - want).abs()
+    assert float(diff.max()) <= 2 * 1e-3 * n_mini + 1e-6 and float((diff > 5e-5).float().mean()) < 0.02, (float(diff.max()),)
+    assert actor.optimizer_steps == n_mini
+    mask = trained_on["response_mask"][:, -resp:]
+    assert rollout_metrics["total_num_sequence"] == total
+    assert rollout_metrics["reward_scores"] == pytest.approx(float(batch["rewards"].mean()), rel=1e-5)
+    assert rollout_metrics["advantages_max"] == pytest.approx(float(trained_on["advantages"][mask].max()), rel=1e-4, abs=1e-5)
+    assert rollout_metrics["advantages_mean"] == pytest.approx(float(trained_on["advantages"][mask].double().mean()), rel=1e-3, abs=1e-5)
+
+
 def test_dp_load_balance_partitions_and_refusals():
     from rlinf_amd.scheduler import init_distributed
     from rlinf_amd.workers.actor.fsdp_actor_worker import FSDPActor, seqlen_balanced_partitions

@@ -147,3 +147,143 @@ def test_oracle_iteration_matches_the_reference_run_training(ref, one_rank_group
         for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "actor/entropy_loss",
                   "actor/kl_loss", "actor/grad_norm"):
             assert float(w[k]) == pytest.approx(g[k], rel=1e-6, abs=1e-9), k
+
+
+# ---- pipeline mode: run_training_pipeline over the reference's own BatchResizingIterator ---------------------------------------
+def _reference_batch_iterator_class(ref):
+    from typing import Callable, Optional
+
+    from oracle import reference_loader as R
+    it_py = "rlinf/utils/data_iter_utils.py"
+    import itertools
+    split_list = R.load_function(it_py, "split_list")
+    k_split = R.load_function(it_py, "get_iterator_k_split", torch=torch, UserDict=UserDict, logging=logging, split_list=split_list,
+                              itertools=itertools, Union=None, Optional=None, Iterator=None)
+    merge = R.load_function("rlinf/data/schema/reasoning_results.py", "RolloutResult.merge_batches", torch=torch)
+    rollout_result = SimpleNamespace(merge_batches=staticmethod(merge))
+    cls = R.load_class("rlinf/data/schema/reasoning_results.py", "BatchResizingIterator", torch=torch, Optional=Optional, Callable=Callable,
+                       RolloutResult=rollout_result, get_iterator_k_split=k_split,
+                       get_batch_size=lambda batch, key="input_ids": batch[key].size(0))
+    return cls, rollout_result
+
+
+def _pieces(batch, sizes):
+    out, lo = [], 0
+    for n in sizes:
+        out.append({k: (v[lo:lo + n].clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
+        lo += n
+    return out
+
+
+@pytest.mark.parametrize("sizes,handler", [((16,), True), ((8, 8), True), ((4, 4, 8), True), ((4, 4, 4, 4), False), ((8, 8), False),
+                                           ((16,), False), ((2, 2, 4, 8), True)], ids=str)
+def test_batch_resizing_iterator_hands_out_what_the_reference_class_does(ref, sizes, handler):
+    """rlinf_amd.data.batch_iterator.BatchResizingIterator against the reference class compiled from its source: the same
+    micro-batches in the same order, the same bookkeeping, for pieces larger than / equal to / smaller than a global batch, with
+    and without a global-batch handler."""
+    from rlinf_amd.data.batch_iterator import BatchResizingIterator
+    ref_cls, _ = _reference_batch_iterator_class(ref)
+    total, micro, n_mini = 16, 2, 2
+    batch = {k: v for k, v in TL.synthetic_rollout_batch(3, total, 4, 6, 53).items() if isinstance(v, torch.Tensor)}
+    cfg = Cfg(algorithm=Cfg(shuffle_rollout=True), actor=Cfg(seed=1234))
+    streams = []
+    for cls in (ref_cls, BatchResizingIterator):
+        feed = _pieces(batch, sizes)
+
+        def get_batch(feed=feed):
+            piece = feed.pop(0)
+            return piece, SimpleNamespace(num_sequence=piece["input_ids"].shape[0])
+
+        it = cls(cfg=cfg, get_batch_fn=get_batch, micro_batch_size=micro, total_batch_size=total, num_global_batches=n_mini,
+                 forward_only=False)
+        it.register_get_batch_handler(lambda b: {**b, "tag": b["rewards"] * 2})
+        if handler:
+            it.register_global_batch_handler(lambda b: {**b, "norm": b["rewards"] - b["rewards"].mean()})
+        got, done = [], []
+        peek = it.prefetch_one_batch()
+        for i in range(total // micro):
+            mb = next(it)
+            if i == 0:
+                assert mb is peek
+            got.append(mb)
+            done.append(it.global_batch_done)
+        it.check_finished_global_batch()
+        streams.append((got, done, it.get_all_batches()))
+    (want, want_done, want_all), (got, got_done, got_all) = streams
+    assert want_done == got_done
+    for w, g in zip(want, got):
+        assert w.keys() == g.keys()
+        for k in w:
+            assert torch.equal(w[k], g[k]), k
+    for k in want_all:
+        assert torch.equal(want_all[k], got_all[k]), k
+
+
+@pytest.mark.parametrize("case", [
+    dict(sizes=(16,)),
+    dict(sizes=(8, 8), loss_agg="seq-mean-token-sum", temperature=0.7, entropy_bonus=0.01),
+    dict(sizes=(4, 4, 8), kl_beta=0.05),
+    dict(sizes=(4, 4, 4, 4), normalize=False, group_size=2),
+    dict(sizes=(8, 4, 4), adv_type="reinpp", normalize=False),
+], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()))
+def test_oracle_pipeline_iteration_matches_the_reference_run_training_pipeline(ref, one_rank_group, case):
+    from functools import partial
+
+    from oracle import reference_loader as R
+    resp, prompt, vocab, dim = 6, 4, 53, 16
+    total, micro, n_mini = 16, 4, 2
+    torch.manual_seed(5)
+    base = TL.TinyCausalLM(vocab, dim, prompt + resp)
+    batch = TL.synthetic_rollout_batch(7, total, prompt, resp, vocab)
+    if case.get("kl_beta", 0) > 0:
+        with torch.no_grad():
+            batch["ref_logprobs"] = TL.forward_logprobs(base, batch, resp, case.get("temperature", 1.0)) + 0.05 * torch.randn(total, resp)
+    batch = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    m_ref, m_ora = copy.deepcopy(base), copy.deepcopy(base)
+    me = reference_learner(ref, m_ref, resp=resp, prompt=prompt, micro=micro, n_mini=n_mini, total=total, case=case)
+    it_cls, rollout_result = _reference_batch_iterator_class(ref)
+    # training_step tells a dict from the iterator by isinstance(batch, dict): recompile it next to the real class
+    py = "rlinf/workers/actor/fsdp_actor_worker.py"
+    mu = ref.metric_utils
+    worker_stub = SimpleNamespace(torch_device_type="cpu", torch_platform=SimpleNamespace(current_device=lambda: torch.device("cpu")))
+    du = R.load_distributed_utils()
+
+    def masked_normalization_cpu(x, mask):
+        src = R.load_function("rlinf/utils/distributed.py", "masked_normalization", torch=torch, np=__import__("numpy"))
+        orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            return src(x, mask)
+        finally:
+            torch.Tensor.cuda = orig
+
+    seen = {}
+
+    def metrics_probe(b, *_a, **_k):
+        seen["batch"] = b
+        return {"n": b["input_ids"].shape[0]}, None, None
+
+    pipeline = R.load_function(py, "FSDPActor.run_training_pipeline", torch=torch, BatchResizingIterator=it_cls, partial=partial,
+                               masked_normalization=masked_normalization_cpu, compute_math_rollout_metrics=metrics_probe, Channel=None)
+    feed = _pieces(batch, case["sizes"])
+    me.get_batch = lambda _ch: (lambda p: (p, SimpleNamespace(num_sequence=p["input_ids"].shape[0])))(feed.pop(0))
+    me.is_pipeline = True
+    rollout_metrics, want_metrics = pipeline(me, None)
+    assert rollout_metrics == {"n": total} and not feed
+    opt = torch.optim.AdamW(m_ora.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    trained_on, got_metrics = TL.pipeline_iteration(
+        m_ora, opt, _pieces(batch, case["sizes"]), total=total, response_len=resp, micro_batch=micro, n_minibatches=n_mini, seed=1234,
+        adv_type=case.get("adv_type", "grpo"), group_size=case.get("group_size", 4), normalize_advantages=case.get("normalize", True),
+        temperature=case.get("temperature", 1.0), loss_agg=case.get("loss_agg", "token-mean"), clip_ratio_low=0.2, clip_ratio_high=0.28,
+        calculate_entropy=case.get("entropy_bonus", 0) > 0, entropy_bonus=case.get("entropy_bonus", 0.0),
+        kl_beta=case.get("kl_beta", 0.0), kl_penalty_type=case.get("kl", "low_var_kl"), clip_grad=1.0,
+        reinpp_kl_beta=case.get("reinpp_kl_beta", 0.0))
+    for (n, a), (_, b) in zip(m_ref.named_parameters(), m_ora.named_parameters()):
+        assert torch.equal(a, b), n
+    assert not torch.equal(next(m_ref.parameters()), next(base.parameters()))
+    for k in ("input_ids", "advantages", "rewards"):
+        assert torch.equal(seen["batch"][k], trained_on[k]), k
+    assert len(want_metrics) == len(got_metrics) == n_mini
+    for w, g in zip(want_metrics, got_metrics):
+        for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "actor/grad_norm"):
+            assert float(w[k]) == pytest.approx(g[k], rel=1e-6, abs=1e-9), k
