@@ -304,6 +304,40 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     rows.append({"kernel": "copy_segments (bucket pack f32 -> bf16)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
                  "algorithmic_bytes": nb, "shape": "16 tensors x 4096 x 8192 f32 into one bf16 bucket"})
+    del masters, packer
+    # compressed patch transport (csrc/zplane_codec.hip): the two index streams of a sparse weight patch, 100 MB each.
+    # Algorithmic bytes: compress reads the stream twice (measure, pack) and writes the compressed form; decompress reads the
+    # compressed form and writes the stream.
+    try:
+        from rlinf_amd import _lib
+        from rlinf_amd.ops import _stream_ptr
+        lib = _lib.load()
+        n = 100_000_000
+        streams = (("rows: uint8 deltas, 1 in 800 nonzero", (torch.rand(n, device=device, generator=g) < 1 / 800).to(torch.uint8)),
+                   ("cols: int32 gaps, mean 800", torch.randint(1, 1600, (n // 4,), device=device, generator=g, dtype=torch.int32)))
+        for label, t in streams:
+            es, ne = t.element_size(), t.numel()
+            out = torch.empty(lib.rlx_zplane_bound_bytes(ne, es), dtype=torch.uint8, device=device)
+            ws = torch.empty(lib.rlx_zplane_workspace_bytes(ne, es), dtype=torch.uint8, device=device)
+            length = torch.zeros(1, dtype=torch.int64, device=device)
+            back, status = torch.empty_like(t), torch.zeros(1, dtype=torch.int32, device=device)
+            st = _stream_ptr(dev_t)
+            comp = lambda: _lib.check(lib.rlx_zplane_compress(t.data_ptr(), ne, es, out.data_ptr(), out.numel(), length.data_ptr(),  # noqa: E731
+                                                              ws.data_ptr(), ws.numel(), st), "rlx_zplane_compress")
+            t_c = avg_us(comp)
+            clen = int(length.item())
+            dec = lambda: _lib.check(lib.rlx_zplane_decompress(out.data_ptr(), clen, back.data_ptr(), ne, es, status.data_ptr(), st),  # noqa: E731
+                                     "rlx_zplane_decompress")
+            t_d = avg_us(dec)
+            ok = bool(torch.equal(back, t)) and int(status.item()) == 0
+            raw = ne * es
+            for kname, us, nb in (("zplane compress (measure + scan + pack)", t_c, 2 * raw + clen), ("zplane decompress", t_d, raw + clen)):
+                rows.append({"kernel": kname, "bound": "hbm", "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1), "algorithmic_bytes": nb,
+                             "shape": f"{label}; {raw} -> {clen} bytes ({raw / clen:.1f} x), round trip {'ok' if ok else 'MISMATCH'}"})
+            del out, ws, back
+    except Exception as e:  # noqa: BLE001
+        rows.append({"kernel": "zplane codec", "error": f"{type(e).__name__}: {e}"[:200]})
     return rows
 
 

@@ -22,8 +22,11 @@
 //                become zeros -- the dense-update case, where the column deltas are all 1 and the row deltas all 0
 //
 // compress = measure (sizes per entry) -> scan (offsets, one workgroup) -> pack; decompress = one launch.  A workgroup owns one
-// block: it loads the block's elements with coalesced 16-byte loads, splits them into byte planes in LDS, and every wave walks
-// planes with one ballot per 64-byte group.  HBM-bound: the input is read twice (measure, pack), the output written once.
+// block: it loads the block's elements with coalesced 16-byte loads and splits them into byte planes in LDS (byte streams skip
+// this: a lane's 16 bytes come straight from global memory); each of its four waves then owns one 1024-byte span of every plane,
+// 16 bytes per lane in registers (see "cells" below): masks from register arithmetic, offsets from one wave scan per cell, the
+// nonzero bytes compacted through LDS and moved to / from global memory in whole 8-byte words.  HBM-bound: the input is read
+// twice (measure, pack), the output written once.
 // Integer / byte work: bit-exact round trip (tests/test_gpu_weight_patch.py, against a numpy restatement of the format).
 
 #include <string.h>
@@ -153,10 +156,6 @@ __device__ __forceinline__ void store_planes(const uint8_t* planes, uint8_t* __r
     }
 }
 
-// byte i of the plane under the XOR filter (b[i] ^ b[i-1], b[-1] = 0): the predecessor of a group's first byte is the previous
-// group's last byte
-__device__ __forceinline__ uint8_t xor_prev(const uint8_t* plane, int i) { return plane[i] ^ (i > 0 ? plane[i - 1] : (uint8_t)0); }
-
 // 4-bit "byte is nonzero" mask of a dword (bit j = byte j): the classic has-zero-byte carry trick, then a multiply that gathers
 // bits 0, 8, 16, 24 into one nibble (all partial products land on distinct bit positions: no carries)
 __device__ __forceinline__ uint32_t nz4(uint32_t w) {
@@ -165,55 +164,159 @@ __device__ __forceinline__ uint32_t nz4(uint32_t w) {
 }
 __device__ __forceinline__ uint32_t nz16(const uint4& v) { return nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12); }
 
-// mask bookkeeping of one plane-block, one wave: nz = nonzero bytes, ng = nonzero 64-byte groups, plain and under the XOR filter.
-// A lane reads 16 consecutive bytes (one b128) of a 1024-byte span -- four lanes make a group -- and works on them in registers;
-// the byte in front of a lane's first one comes from its neighbour (or the previous span's last lane).
-__device__ __forceinline__ void plane_stats(const uint8_t* plane, int& nz, int& ng, int& nzx, int& ngx) {
+// ---- cells ----------------------------------------------------------------------------------------------------------------------
+// The unit of wave work is a CELL: one 1024-byte span of one plane-block.  Lane L holds bytes [16 L, 16 L + 16) of the span in a
+// uint4 (four lanes make a 64-byte group, so a lane's 16-bit nonzero mask is a quarter of the group's 64-bit mask, and 64 of them
+// laid out as u16 in lane order ARE the span's 16 group masks in memory order).  Wave w of the workgroup owns span w of EVERY plane
+// of the block: all four waves are busy for every element size (one wave per plane left three idle on byte streams), and every
+// cross-lane step -- counts, offsets, the XOR filter's running value -- is one wave scan per cell instead of one per group.
+constexpr int kSpan = 1024, kSpans = kBlock / kSpan;
+static_assert(kSpans == kThreads / 64, "one wave per span");
+
+// the lane's 16 bytes under the XOR filter (b[i] ^ b[i-1]); `before` = the byte in front of the span (0 for the plane's first)
+__device__ __forceinline__ uint4 xor_filter(const uint4& v, uint32_t before) {
     const int lane = threadIdx.x & 63;
-    int cnt = 0, cntx = 0;
-    ng = ngx = 0;
-    uint32_t carry = 0;  // last byte of the previous span (in the low byte)
-#pragma unroll
-    for (int sp = 0; sp < kBlock / 1024; ++sp) {
-        const uint4 v = *reinterpret_cast<const uint4*>(plane + sp * 1024 + lane * 16);
-        uint32_t prev = (uint32_t)__shfl_up((int)(v.w >> 24), 1, 64);
-        if (lane == 0) prev = carry;
-        carry = (uint32_t)__shfl((int)(v.w >> 24), 63, 64);
-        uint4 x;  // v XOR (v shifted up by one byte, with the predecessor byte coming in at the bottom)
-        x.x = v.x ^ ((v.x << 8) | prev);
-        x.y = v.y ^ ((v.y << 8) | (v.x >> 24));
-        x.z = v.z ^ ((v.z << 8) | (v.y >> 24));
-        x.w = v.w ^ ((v.w << 8) | (v.z >> 24));
-        const uint32_t m = nz16(v), mx = nz16(x);
-        cnt += __popc(m);
-        cntx += __popc(mx);
-        // a group is nonzero iff any of its four lanes holds a nonzero byte: OR over the quad, counted once per quad
-        const uint64_t any = __ballot(m != 0), anyx = __ballot(mx != 0);
-        uint64_t q = any | (any >> 1) | (any >> 2) | (any >> 3), qx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
-        ng += __popcll(q & 0x1111111111111111ull);
-        ngx += __popcll(qx & 0x1111111111111111ull);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        cnt += __shfl_xor(cnt, off, 64);
-        cntx += __shfl_xor(cntx, off, 64);
-    }
-    nz = cnt;
-    nzx = cntx;
+    uint32_t prev = (uint32_t)__shfl_up((int)(v.w >> 24), 1, 64);
+    if (lane == 0) prev = before;
+    uint4 x;
+    x.x = v.x ^ ((v.x << 8) | prev);
+    x.y = v.y ^ ((v.y << 8) | (v.x >> 24));
+    x.z = v.z ^ ((v.z << 8) | (v.y >> 24));
+    x.w = v.w ^ ((v.w << 8) | (v.z >> 24));
+    return x;
 }
 
+// inverse within the lane: byte j <- XOR of bytes 0..j; returns the lane's total (its last byte) for the scan across lanes
+__device__ __forceinline__ uint32_t xor_prefix16(uint4& v) {
+    v.x ^= v.x << 8; v.x ^= v.x << 16;
+    v.y ^= v.y << 8; v.y ^= v.y << 16; v.y ^= (v.x >> 24) * 0x01010101u;
+    v.z ^= v.z << 8; v.z ^= v.z << 16; v.z ^= (v.y >> 24) * 0x01010101u;
+    v.w ^= v.w << 8; v.w ^= v.w << 16; v.w ^= (v.z >> 24) * 0x01010101u;
+    return v.w >> 24;
+}
+
+__device__ __forceinline__ int wave_incl_sum(int x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(x, d, 64);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_xor(uint32_t x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
+        if (lane >= d) x ^= t;
+    }
+    return x;
+}
+
+// the lane's 16 bytes of cell (plane 0, span `span`) of a BYTE stream straight from global memory (no plane split to do);
+// bytes past `avail` read as zero
+__device__ __forceinline__ uint4 load_cell_bytes(const uint8_t* __restrict__ src, size_t avail, int span) {
+    const size_t b0 = (size_t)span * kSpan + (threadIdx.x & 63) * 16;
+    if (b0 + 16 <= avail) return *reinterpret_cast<const uint4*>(src + b0);
+    union { uint4 v; uint8_t b[16]; } u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u.b[k] = (b0 + k < avail) ? src[b0 + k] : (uint8_t)0;
+    return u.v;
+}
+
+// byte k (0..15, compile time) of a uint4
+template <int K>
+__device__ __forceinline__ uint32_t byte_of(const uint4& v) {
+    const uint32_t w = K < 4 ? v.x : (K < 8 ? v.y : (K < 12 ? v.z : v.w));
+    return (w >> ((K & 3) * 8)) & 0xffu;
+}
+template <int K>
+__device__ __forceinline__ void or_byte(uint4& v, uint32_t b) {
+    const uint32_t s = b << ((K & 3) * 8);
+    if (K < 4) v.x |= s; else if (K < 8) v.y |= s; else if (K < 12) v.z |= s; else v.w |= s;
+}
+
+// the lane's nonzero bytes (mask m) -> stage[off ...], in byte order
+template <int K = 0>
+__device__ __forceinline__ void compact16(const uint4& v, uint32_t m, uint8_t* stage, int off) {
+    if constexpr (K < 16) {
+        if ((m >> K) & 1u) stage[off++] = (uint8_t)byte_of<K>(v);
+        compact16<K + 1>(v, m, stage, off);
+    }
+}
+// inverse: stage[off ...] -> the byte positions set in m
+template <int K = 0>
+__device__ __forceinline__ void expand16(uint4& v, uint32_t m, const uint8_t* stage, int off) {
+    if constexpr (K < 16) {
+        if ((m >> K) & 1u) or_byte<K>(v, stage[off++]);
+        expand16<K + 1>(v, m, stage, off);
+    }
+}
+
+// A workgroup works on Q "virtual planes": the ES planes of one block, or -- byte streams, whose blocks are only 4 KiB --
+// plane 0 of kBytesBlocks consecutive blocks (more bytes in flight per workgroup, fewer workgroup launches).
+constexpr int kBytesBlocks = 4;
 template <int ES>
-__global__ __launch_bounds__(kThreads) void zplane_measure(const uint8_t* __restrict__ in, long long n_elems, uint64_t* __restrict__ sizes) {
-    __shared__ __attribute__((aligned(16))) uint8_t planes[ES * kBlock];
-    const long long blk = blockIdx.x;
-    load_planes<ES>(in, (size_t)blk * kBlock * ES, (size_t)n_elems * ES, planes);
+struct Geo {
+    static constexpr int BPW = ES == 1 ? kBytesBlocks : 1;  // blocks per workgroup
+    static constexpr int Q = BPW * ES;                      // virtual planes per workgroup: q -> (block q / ES, plane q % ES)
+};
+
+template <int ES>
+__global__ __launch_bounds__(kThreads) void zplane_measure(const uint8_t* __restrict__ in, long long n_elems, long long n_blocks,
+                                                           uint64_t* __restrict__ sizes) {
+    constexpr int BPW = Geo<ES>::BPW, Q = Geo<ES>::Q;
+    __shared__ __attribute__((aligned(16))) uint8_t planes[ES == 1 ? 16 : ES * kBlock];
+    __shared__ int cnt[Q][4];  // nz, ng, nzx, ngx of each plane, summed over its four cells
+    const long long blk0 = (long long)blockIdx.x * BPW;
+    const int span = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t total = (size_t)n_elems * ES;
+    if (threadIdx.x < Q * 4) (&cnt[0][0])[threadIdx.x] = 0;
+    if constexpr (ES > 1) load_planes<ES>(in, (size_t)blk0 * kBlock * ES, total, planes);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
-    for (int p = wave; p < ES; p += kThreads / 64) {
-        int nz, ng, nzx, ngx;
-        plane_stats(planes + p * kBlock, nz, ng, nzx, ngx);
+    uint4 v[Q];
+    uint32_t before[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {  // all of the workgroup's loads in flight before the first use
+        before[q] = 0;
+        if constexpr (ES == 1) {
+            const size_t byte0 = (size_t)(blk0 + q) * kBlock, avail = total > byte0 ? total - byte0 : 0;
+            v[q] = load_cell_bytes(in + byte0, avail, span);
+            if (span > 0 && (size_t)span * kSpan - 1 < avail) before[q] = in[byte0 + (size_t)span * kSpan - 1];
+        } else {
+            v[q] = *reinterpret_cast<const uint4*>(planes + q * kBlock + span * kSpan + lane * 16);
+            if (span > 0) before[q] = planes[q * kBlock + span * kSpan - 1];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const uint4 x = xor_filter(v[q], before[q]);
+        const uint32_t m = nz16(v[q]), mx = nz16(x);
+        int c = __popc(m), cx = __popc(mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            c += __shfl_xor(c, off, 64);
+            cx += __shfl_xor(cx, off, 64);
+        }
+        // a group is nonzero iff any of its four lanes holds a nonzero byte: OR over the quad, counted once per quad
+        const uint64_t any = __ballot(m != 0), anyx = __ballot(mx != 0);
+        const uint64_t g = any | (any >> 1) | (any >> 2) | (any >> 3), gx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
         if (lane == 0) {
+            atomicAdd(&cnt[q][0], c);
+            atomicAdd(&cnt[q][1], __popcll(g & 0x1111111111111111ull));
+            atomicAdd(&cnt[q][2], cx);
+            atomicAdd(&cnt[q][3], __popcll(gx & 0x1111111111111111ull));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        const int q = threadIdx.x;
+        const long long blk = blk0 + q / ES;
+        if (blk < n_blocks) {
+            const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
+            const int nz = cnt[q][0], ng = cnt[q][1], nzx = cnt[q][2], ngx = cnt[q][3];
             const size_t masked = 8 + 8 * (size_t)ng + pad8((size_t)nz), xored = 8 + 8 * (size_t)ngx + pad8((size_t)nzx),
                          raw = pad8((size_t)in_block);
             uint64_t mode, size;
@@ -221,155 +324,317 @@ __global__ __launch_bounds__(kThreads) void zplane_measure(const uint8_t* __rest
             else if (masked <= xored && masked < raw) { mode = 1; size = masked; }
             else if (xored < raw) { mode = 3; size = xored; }
             else { mode = 2; size = raw; }
-            sizes[blk * ES + p] = (mode << 62) | size;
+            sizes[blk * ES + q % ES] = (mode << 62) | size;
         }
     }
 }
 
-// exclusive scan of the entry sizes -> directory entries (mode | offset) + the header; ONE workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void zplane_scan(const uint64_t* __restrict__ sizes, long long n_entries, uint64_t* __restrict__ directory,
-                                                    Header* __restrict__ header, long long n_elems, int elem_size,
-                                                    uint64_t* __restrict__ out_bytes) {
-    __shared__ uint64_t s_part[1024];
-    const long long chunk = (n_entries + 1023) / 1024;
-    const long long lo = min(n_entries, (long long)threadIdx.x * chunk), hi = min(n_entries, lo + chunk);
-    uint64_t sum = 0;
-    for (long long i = lo; i < hi; ++i) sum += sizes[i] & ((1ull << 62) - 1);
-    s_part[threadIdx.x] = sum;
+// Offsets: exclusive scan of the entry sizes in two levels.  (One workgroup walking all entries was the slowest launch of the
+// codec: ~90 us for 49 k entries, every one of its 48 dependent trips a full memory latency.)
+//   scan_tiles   one workgroup per tile of 4096 entries: directory[i] = mode | offset WITHIN the tile, tile_total[t]
+//   scan_bases   one workgroup: tile_total -> tile_base (exclusive), the header, the stream length
+// The pack launch adds tile_base to its own entries and stores the final directory words.
+constexpr int kScanTile = 4096;
+constexpr uint64_t kSizeMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ uint64_t block_excl_scan_1024(uint64_t x, uint64_t* s_wave, uint64_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = (uint64_t)__shfl_up((long long)incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan over the 1024 partial sums
-        const uint64_t v = threadIdx.x >= (unsigned)off ? s_part[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint64_t t = s_wave[w];
+        if (w < wave) base += t;
+        tot += t;
     }
-    uint64_t run = threadIdx.x == 0 ? 0 : s_part[threadIdx.x - 1];
-    for (long long i = lo; i < hi; ++i) {
-        const uint64_t e = sizes[i];
-        directory[i] = (e & (3ull << 62)) | run;
-        run += e & ((1ull << 62) - 1);
+    __syncthreads();  // s_wave may be reused by the caller's next round
+    total = tot;
+    return base + incl - x;
+}
+
+__global__ __launch_bounds__(1024) void zplane_scan_tiles(const uint64_t* __restrict__ sizes, long long n_entries, uint64_t* __restrict__ directory,
+                                                          uint64_t* __restrict__ tile_total) {
+    __shared__ uint64_t s_wave[16];
+    const long long i0 = (long long)blockIdx.x * kScanTile + threadIdx.x * 4;
+    uint64_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = i0 + k < n_entries ? sizes[i0 + k] : 0ull;
+    const uint64_t mine = (e[0] & kSizeMask) + (e[1] & kSizeMask) + (e[2] & kSizeMask) + (e[3] & kSizeMask);
+    uint64_t total;
+    uint64_t run = block_excl_scan_1024(mine, s_wave, total);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < n_entries) directory[i0 + k] = (e[k] & ~kSizeMask) | run;
+        run += e[k] & kSizeMask;
     }
-    if (threadIdx.x == 1023) {
-        const uint64_t payload = s_part[1023];
+    if (threadIdx.x == 0) tile_total[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void zplane_scan_bases(uint64_t* __restrict__ tile_total, long long n_tiles, long long n_entries,
+                                                          Header* __restrict__ header, long long n_elems, int elem_size,
+                                                          uint64_t* __restrict__ out_bytes) {
+    __shared__ uint64_t s_wave[16];
+    uint64_t carry = 0;
+    for (long long t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const long long t = t0 + threadIdx.x;
+        const uint64_t x = t < n_tiles ? tile_total[t] : 0ull;
+        uint64_t total;
+        const uint64_t excl = block_excl_scan_1024(x, s_wave, total);
+        if (t < n_tiles) tile_total[t] = carry + excl;  // in place: tile_total becomes tile_base
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
         header->magic = kMagic;
         header->version = 1;
         header->elem_size = (uint8_t)elem_size;
         header->block_log2 = kBlockLog2;
         header->n_elems = (uint64_t)n_elems;
-        header->payload_bytes = payload;
-        *out_bytes = kHeaderBytes + 8ull * (uint64_t)n_entries + payload;
+        header->payload_bytes = carry;
+        *out_bytes = kHeaderBytes + 8ull * (uint64_t)n_entries + carry;
     }
 }
 
+// pack: every cell's bytes are taken into registers first (so the plane area of LDS can be reused as the staging buffer), the
+// nonzero ones are compacted into LDS at their final order, and the workgroup then copies masks and bytes out in whole 8-byte words.
 template <int ES>
-__global__ __launch_bounds__(kThreads) void zplane_pack(const uint8_t* __restrict__ in, long long n_elems, const uint64_t* __restrict__ directory,
+__global__ __launch_bounds__(kThreads) void zplane_pack(const uint8_t* __restrict__ in, long long n_elems, long long n_blocks,
+                                                        uint64_t* __restrict__ directory, const uint64_t* __restrict__ tile_base,
                                                         uint8_t* __restrict__ payload) {
-    __shared__ __attribute__((aligned(16))) uint8_t planes[ES * kBlock];
-    const long long blk = blockIdx.x;
-    load_planes<ES>(in, (size_t)blk * kBlock * ES, (size_t)n_elems * ES, planes);
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
-    for (int p = wave; p < ES; p += kThreads / 64) {
-        const uint64_t e = directory[blk * ES + p];
-        const int mode = (int)(e >> 62);
-        uint8_t* dst = payload + (e & ((1ull << 62) - 1));
-        const uint8_t* plane = planes + p * kBlock;
-        if (mode == 0) continue;
-        if (mode == 2) {
-            const int n8 = (int)pad8((size_t)in_block);  // the pad bytes were loaded as zero
-            for (int i = lane * 8; i < n8; i += 64 * 8) *reinterpret_cast<uint2*>(dst + i) = *reinterpret_cast<const uint2*>(plane + i);
+    constexpr int BPW = Geo<ES>::BPW, Q = Geo<ES>::Q;
+    __shared__ __attribute__((aligned(16))) uint8_t planes[Q * kBlock];
+    __shared__ __attribute__((aligned(8))) uint16_t masks[Q][kThreads];  // = u64 group mask [Q][64]
+    __shared__ int span_cnt[Q][kSpans];
+    __shared__ int s_ng[Q];
+    const long long blk0 = (long long)blockIdx.x * BPW;
+    const int span = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t total = (size_t)n_elems * ES;
+    if constexpr (ES > 1) {
+        load_planes<ES>(in, (size_t)blk0 * kBlock * ES, total, planes);
+        __syncthreads();
+    }
+    uint4 v[Q];
+    uint32_t m[Q];
+    int incl[Q], mode[Q], n8_raw[Q];
+    uint8_t* dst[Q];
+    uint64_t word[Q];  // the final directory words: mode | offset in the payload
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const long long blk = blk0 + q / ES, entry = blk * ES + q % ES;
+        m[q] = 0;
+        incl[q] = 0;
+        mode[q] = 0;
+        n8_raw[q] = 0;
+        dst[q] = payload;
+        word[q] = 0;
+        if (blk >= n_blocks) continue;
+        const uint64_t e = directory[entry];  // mode | offset within its scan tile
+        const uint64_t off = (e & kSizeMask) + tile_base[entry / kScanTile];
+        word[q] = (e & ~kSizeMask) | off;
+        mode[q] = (int)(e >> 62);
+        dst[q] = payload + off;
+        n8_raw[q] = (int)pad8((size_t)min((long long)kBlock, n_elems - blk * kBlock));
+    }
+    __syncthreads();  // every thread of the workgroup (the entries' only reader) has its copy: now they may be overwritten
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (threadIdx.x == q && blk0 + q / ES < n_blocks) directory[(blk0 + q / ES) * ES + q % ES] = word[q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (mode[q] == 0) continue;
+        uint32_t before = 0;
+        if constexpr (ES == 1) {
+            const size_t byte0 = (size_t)(blk0 + q) * kBlock, avail = total > byte0 ? total - byte0 : 0;
+            v[q] = load_cell_bytes(in + byte0, avail, span);
+            if (mode[q] == 3 && span > 0 && (size_t)span * kSpan - 1 < avail) before = in[byte0 + (size_t)span * kSpan - 1];
+        } else {
+            v[q] = *reinterpret_cast<const uint4*>(planes + q * kBlock + span * kSpan + lane * 16);
+            if (mode[q] == 3 && span > 0) before = planes[q * kBlock + span * kSpan - 1];
+        }
+        if (mode[q] == 2) continue;
+        if (mode[q] == 3) v[q] = xor_filter(v[q], before);
+        m[q] = nz16(v[q]);
+        masks[q][threadIdx.x] = (uint16_t)m[q];
+        incl[q] = wave_incl_sum(__popc(m[q]));
+        if (lane == 63) span_cnt[q][span] = incl[q];
+    }
+    __syncthreads();  // every cell is in registers: planes[] is free; masks and span counts are complete
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (mode[q] == 2) {
+            if constexpr (ES == 1) {  // byte stream, raw: the lane's 16 bytes go straight out (the plane was never staged)
+                const int b0 = span * kSpan + lane * 16;
+                if (b0 + 8 <= n8_raw[q]) *reinterpret_cast<uint2*>(dst[q] + b0) = uint2{v[q].x, v[q].y};
+                if (b0 + 16 <= n8_raw[q]) *reinterpret_cast<uint2*>(dst[q] + b0 + 8) = uint2{v[q].z, v[q].w};
+            }
             continue;
         }
-        // mode 1 / 3: [top][group masks][nonzero bytes] of the plane (3: under the XOR filter).  First the masks (so that the byte
-        // area's start is known), then the bytes.
-        const bool filt = mode == 3;
-        uint64_t top = 0;
-        int ng = 0;
-        for (int g = 0; g < kGroups; ++g) {
-            const uint8_t b = filt ? xor_prev(plane, g * 64 + lane) : plane[g * 64 + lane];
-            const uint64_t m = __ballot(b != 0);
-            if (m != 0) {
-                top |= 1ull << g;
-                if (lane == 0) reinterpret_cast<uint64_t*>(dst)[1 + ng] = m;
-                ++ng;
+        if (mode[q] == 0) continue;
+        int base = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < kSpans; ++s2)
+            if (s2 < span) base += span_cnt[q][s2];
+        compact16(v[q], m[q], planes + q * kBlock, base + incl[q] - __popc(m[q]));
+        if (span == (q & (kSpans - 1))) {  // one wave writes the plane's [top][group masks] and pads the byte area
+            const uint64_t gm = reinterpret_cast<const uint64_t*>(&masks[q][0])[lane];
+            const uint64_t top = __ballot(gm != 0);
+            uint64_t* d64 = reinterpret_cast<uint64_t*>(dst[q]);
+            if (gm != 0) d64[1 + __popcll(top & lanes_below(lane))] = gm;
+            if (lane == 0) {
+                d64[0] = top;
+                s_ng[q] = __popcll(top);
             }
+            const int nz = span_cnt[q][0] + span_cnt[q][1] + span_cnt[q][2] + span_cnt[q][3];
+            if (lane < (int)(pad8((size_t)nz) - nz)) planes[q * kBlock + nz + lane] = 0;  // deterministic pad bytes (nobody compacts past nz)
         }
-        if (lane == 0) reinterpret_cast<uint64_t*>(dst)[0] = top;
-        uint8_t* bytes = dst + 8 + 8 * (size_t)ng;
-        int run = 0;
-        for (int g = 0; g < kGroups; ++g) {
-            const uint8_t b = filt ? xor_prev(plane, g * 64 + lane) : plane[g * 64 + lane];
-            const uint64_t m = __ballot(b != 0);
-            if (b != 0) bytes[run + __popcll(m & lanes_below(lane))] = b;
-            run += __popcll(m);
+    }
+    __syncthreads();  // the staged bytes are complete
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (mode[q] == 0) continue;
+        if (mode[q] == 2) {
+            if constexpr (ES > 1)
+                for (int i = threadIdx.x * 8; i < n8_raw[q]; i += kThreads * 8)
+                    *reinterpret_cast<uint2*>(dst[q] + i) = *reinterpret_cast<const uint2*>(planes + q * kBlock + i);
+            continue;
         }
-        if (lane < (int)(pad8((size_t)run) - run)) bytes[run + lane] = 0;  // deterministic pad bytes
+        const int nz = span_cnt[q][0] + span_cnt[q][1] + span_cnt[q][2] + span_cnt[q][3];
+        uint8_t* bytes = dst[q] + 8 + 8 * (size_t)s_ng[q];
+        for (int i = threadIdx.x * 8; i < (int)pad8((size_t)nz); i += kThreads * 8)
+            *reinterpret_cast<uint2*>(bytes + i) = *reinterpret_cast<const uint2*>(planes + q * kBlock + i);
     }
 }
 
+// unpack: the headers (one wave per plane: group masks expanded to LDS, per-span byte counts), then the workgroup copies every
+// plane's byte area (or raw plane) into LDS in whole words, then the cells pull their bytes out of that staging area into
+// registers, undo the XOR filter with one scan per cell, and write the planes (byte streams: straight to global memory).
 template <int ES>
 __global__ __launch_bounds__(kThreads) void zplane_unpack(const uint8_t* __restrict__ in, size_t in_bytes, long long n_elems,
                                                           uint8_t* __restrict__ out, int* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t planes[ES * kBlock];
-    const long long blk = blockIdx.x;
+    constexpr int BPW = Geo<ES>::BPW, Q = Geo<ES>::Q;
+    __shared__ __attribute__((aligned(16))) uint8_t planes[Q * kBlock];
+    __shared__ uint64_t gmask[Q][kGroups];
+    __shared__ int span_cnt[Q][kSpans];
+    __shared__ uint32_t span_xor[Q][kSpans];
+    __shared__ int s_mode[Q];                  // 0 / 1 / 2 / 3, or 0 with the status word set when the entry does not fit the stream
+    __shared__ unsigned long long s_src64[Q];  // offset of the plane's byte area (mode 1 / 3) or raw plane (mode 2) in the stream
+    __shared__ int s_copy[Q];                  // bytes to stage (multiple of 8)
+    const long long blk0 = (long long)blockIdx.x * BPW;
     const long long n_blocks = (n_elems + kBlock - 1) / kBlock;
     const uint64_t* directory = reinterpret_cast<const uint64_t*>(in + kHeaderBytes);
     const size_t payload0 = kHeaderBytes + 8 * (size_t)n_blocks * ES;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
-    for (int p = wave; p < ES; p += kThreads / 64) {
-        const uint64_t e = directory[blk * ES + p];
-        const int mode = (int)(e >> 62);
-        const size_t off = payload0 + (size_t)(e & ((1ull << 62) - 1));
-        uint8_t* plane = planes + p * kBlock;
-        if (mode == 0) {
-            for (int i = lane * 8; i < kBlock; i += 64 * 8) *reinterpret_cast<uint2*>(plane + i) = uint2{0, 0};
-            continue;
+    for (int q = wave; q < Q; q += kThreads / 64) {
+        const long long blk = blk0 + q / ES;
+        int mode = 0, copy = 0;
+        size_t off = 0;
+        if (blk < n_blocks) {
+            const uint64_t e = directory[blk * ES + q % ES];
+            mode = (int)(e >> 62);
+            off = payload0 + (size_t)(e & kSizeMask);
         }
         if (mode == 2) {
-            const int n8 = (int)pad8((size_t)in_block);
-            if (off + n8 > in_bytes) { if (lane == 0) *status = 2; continue; }
-            for (int i = lane * 8; i < n8; i += 64 * 8) *reinterpret_cast<uint2*>(plane + i) = *reinterpret_cast<const uint2*>(in + off + i);
-            continue;
-        }
-        if (off + 8 > in_bytes) { if (lane == 0) *status = 3; continue; }
-        const uint64_t top = *reinterpret_cast<const uint64_t*>(in + off);
-        const int ng = __popcll(top);
-        if (off + 8 + 8 * (size_t)ng > in_bytes) { if (lane == 0) *status = 4; continue; }
-        // lane g owns group g's mask and the offset of its bytes (wave-wide exclusive scan of the popcounts)
-        const bool has = (top >> lane) & 1;
-        const uint64_t gm = has ? reinterpret_cast<const uint64_t*>(in + off + 8)[__popcll(top & lanes_below(lane))] : 0ull;
-        int incl = __popcll(gm);
+            copy = (int)pad8((size_t)min((long long)kBlock, n_elems - blk * kBlock));
+            if (off + copy > in_bytes) { if (lane == 0) *status = 2; mode = 0; }
+        } else if (mode != 0) {
+            uint64_t top = 0;
+            if (off + 8 > in_bytes) { if (lane == 0) *status = 3; mode = 0; }
+            else top = *reinterpret_cast<const uint64_t*>(in + off);
+            const int ng = __popcll(top);
+            if (mode != 0 && off + 8 + 8 * (size_t)ng > in_bytes) { if (lane == 0) *status = 4; mode = 0; top = 0; }
+            // lane g owns group g's mask
+            const bool has = (top >> lane) & 1;
+            const uint64_t gm = has ? reinterpret_cast<const uint64_t*>(in + off + 8)[__popcll(top & lanes_below(lane))] : 0ull;
+            gmask[q][lane] = gm;
+            int c = __popcll(gm);  // bytes of this group; summed over the 16 groups of each span
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += v;
+            for (int d = 1; d < 16; d <<= 1) c += __shfl_xor(c, d, 64);
+            if ((lane & 15) == 0) span_cnt[q][lane >> 4] = c;
+            const int total = __shfl(c, 0, 64) + __shfl(c, 16, 64) + __shfl(c, 32, 64) + __shfl(c, 48, 64);
+            off += 8 + 8 * (size_t)ng;
+            copy = (int)pad8((size_t)total);
+            if (mode != 0 && off + (size_t)copy > in_bytes) { if (lane == 0) *status = 5; mode = 0; }  // byte area incl. its pad
         }
-        const int excl = incl - __popcll(gm);
-        const int total = __shfl(incl, 63, 64);
-        const uint8_t* bytes = in + off + 8 + 8 * (size_t)ng;
-        if (off + 8 + 8 * (size_t)ng + (size_t)total > in_bytes) { if (lane == 0) *status = 5; continue; }
-        unsigned carry = 0;  // mode 3: the running XOR up to the previous group's last byte
-        for (int g = 0; g < kGroups; ++g) {
-            const uint64_t mg = __shfl(gm, g, 64);
-            const int og = __shfl(excl, g, 64);
-            unsigned b = ((mg >> lane) & 1) ? bytes[og + __popcll(mg & lanes_below(lane))] : 0u;
-            if (mode == 3) {  // undo b[i] ^ b[i-1]: inclusive XOR scan over the lanes, then the carry of the groups before
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const unsigned v = __shfl_up(b, d, 64);
-                    if (lane >= d) b ^= v;
-                }
-                b ^= carry;
-                carry = __shfl(b, 63, 64);
-            }
-            plane[g * 64 + lane] = (uint8_t)b;
+        if (lane == 0) {
+            s_mode[q] = mode;
+            s_src64[q] = off;
+            s_copy[q] = mode == 0 ? 0 : copy;
         }
     }
     __syncthreads();
-    // interleave the planes back into elements (coalesced 16-byte stores)
-    store_planes<ES>(planes, out + (size_t)blk * kBlock * ES, (size_t)in_block * ES);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const uint8_t* src = in + s_src64[q];
+        for (int i = threadIdx.x * 8; i < s_copy[q]; i += kThreads * 8)
+            *reinterpret_cast<uint2*>(planes + q * kBlock + i) = *reinterpret_cast<const uint2*>(src + i);
+    }
+    __syncthreads();
+    const int span = wave;
+    uint4 v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int mode = s_mode[q];
+        v[q] = uint4{0, 0, 0, 0};
+        if (mode == 0) continue;
+        if (mode == 2) {
+            v[q] = *reinterpret_cast<const uint4*>(planes + q * kBlock + span * kSpan + lane * 16);
+            continue;
+        }
+        const uint32_t m = reinterpret_cast<const uint16_t*>(&gmask[q][0])[threadIdx.x];
+        const int incl = wave_incl_sum(__popc(m));
+        int base = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < kSpans; ++s2)
+            if (s2 < span) base += span_cnt[q][s2];
+        expand16(v[q], m, planes + q * kBlock, base + incl - __popc(m));
+        if (mode == 3) {  // undo b[i] ^ b[i-1]: prefix XOR inside the lane, one scan over the lanes, the spans before via LDS
+            const uint32_t tot = xor_prefix16(v[q]);
+            const uint32_t incl_x = wave_incl_xor(tot);
+            const uint32_t k = (incl_x ^ tot) * 0x01010101u;
+            v[q].x ^= k; v[q].y ^= k; v[q].z ^= k; v[q].w ^= k;
+            if (lane == 63) span_xor[q][span] = incl_x;
+        }
+    }
+    __syncthreads();  // every cell is in registers: the staging area may be overwritten by the planes; span_xor is complete
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (s_mode[q] == 3) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < kSpans; ++s2)
+                if (s2 < span) carry ^= span_xor[q][s2];
+            const uint32_t k = (carry & 0xffu) * 0x01010101u;
+            v[q].x ^= k; v[q].y ^= k; v[q].z ^= k; v[q].w ^= k;
+        }
+        if constexpr (ES == 1) {
+            const long long blk = blk0 + q;
+            if (blk < n_blocks) {
+                const size_t valid = (size_t)min((long long)kBlock, n_elems - blk * kBlock);
+                uint8_t* dst = out + (size_t)blk * kBlock;
+                const size_t b0 = (size_t)span * kSpan + lane * 16;
+                if (b0 + 16 <= valid) {
+                    *reinterpret_cast<uint4*>(dst + b0) = v[q];
+                } else {
+                    union { uint4 w; uint8_t b[16]; } u;
+                    u.w = v[q];
+                    for (int k = 0; k < 16 && b0 + k < valid; ++k) dst[b0 + k] = u.b[k];
+                }
+            }
+        } else {
+            *reinterpret_cast<uint4*>(planes + q * kBlock + span * kSpan + lane * 16) = v[q];
+        }
+    }
+    if constexpr (ES > 1) {
+        __syncthreads();
+        const size_t valid = (size_t)min((long long)kBlock, n_elems - blk0 * kBlock) * ES;
+        store_planes<ES>(planes, out + (size_t)blk0 * kBlock * ES, valid);  // interleave the planes back into elements (coalesced 16-byte stores)
+    }
 }
 
 inline long long blocks_of(int64_t n) { return (n + kBlock - 1) / kBlock; }
@@ -388,7 +653,8 @@ extern "C" size_t rlx_zplane_bound_bytes(int64_t n_elems, int elem_size) {
 
 extern "C" size_t rlx_zplane_workspace_bytes(int64_t n_elems, int elem_size) {
     if (n_elems < 0 || !es_ok(elem_size)) return 0;
-    return 8 * (size_t)blocks_of(n_elems) * elem_size + 64;  // entry sizes
+    const size_t n_entries = (size_t)blocks_of(n_elems) * elem_size;
+    return 8 * n_entries + 8 * ((n_entries + kScanTile - 1) / kScanTile) + 64;  // entry sizes | scan tile totals
 }
 
 extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_size, void* out, size_t out_capacity, uint64_t* out_bytes,
@@ -404,28 +670,32 @@ extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_siz
         return RLX_ENOSPC;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const long long nb = blocks_of(n_elems), n_entries = nb * elem_size;
+    const long long nb = blocks_of(n_elems), n_entries = nb * elem_size, n_tiles = (n_entries + kScanTile - 1) / kScanTile;
     uint64_t* sizes = static_cast<uint64_t*>(workspace);
+    uint64_t* tile_total = sizes + n_entries;
     uint8_t* o = static_cast<uint8_t*>(out);
     uint64_t* directory = reinterpret_cast<uint64_t*>(o + kHeaderBytes);
     uint8_t* payload = o + kHeaderBytes + 8 * (size_t)n_entries;
     const uint8_t* src = static_cast<const uint8_t*>(in);
+    const unsigned grid1 = (unsigned)((nb + kBytesBlocks - 1) / kBytesBlocks);  // byte streams: several blocks per workgroup
 #define RLX_ZP_DISPATCH(KERNEL, ...)                                                                              \
     switch (elem_size) {                                                                                          \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;    \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid1), dim3(kThreads), 0, st, __VA_ARGS__); break;           \
         case 2: hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;    \
         case 4: hipLaunchKernelGGL(KERNEL<4>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;    \
         default: hipLaunchKernelGGL(KERNEL<8>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;   \
     }
     if (nb > 0) {
-        RLX_ZP_DISPATCH(zplane_measure, src, (long long)n_elems, sizes);
+        RLX_ZP_DISPATCH(zplane_measure, src, (long long)n_elems, nb, sizes);
+        RLX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(zplane_scan_tiles, dim3((unsigned)n_tiles), dim3(1024), 0, st, sizes, n_entries, directory, tile_total);
         RLX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(zplane_scan, dim3(1), dim3(1024), 0, st, sizes, n_entries, directory, reinterpret_cast<Header*>(o), (long long)n_elems,
-                       elem_size, out_bytes);
+    hipLaunchKernelGGL(zplane_scan_bases, dim3(1), dim3(1024), 0, st, tile_total, n_tiles, n_entries, reinterpret_cast<Header*>(o),
+                       (long long)n_elems, elem_size, out_bytes);
     RLX_LAUNCH_CHECK();
     if (nb > 0) {
-        RLX_ZP_DISPATCH(zplane_pack, src, (long long)n_elems, directory, payload);
+        RLX_ZP_DISPATCH(zplane_pack, src, (long long)n_elems, nb, directory, (const uint64_t*)tile_total, payload);
         RLX_LAUNCH_CHECK();
     }
     return RLX_OK;
@@ -455,6 +725,7 @@ extern "C" int rlx_zplane_decompress(const void* in, size_t in_bytes, void* out,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint8_t* src = static_cast<const uint8_t*>(in);
     uint8_t* dst = static_cast<uint8_t*>(out);
+    const unsigned grid1 = (unsigned)((nb + kBytesBlocks - 1) / kBytesBlocks);
     RLX_ZP_DISPATCH(zplane_unpack, src, in_bytes, (long long)n_elems, dst, status);
     RLX_LAUNCH_CHECK();
 #undef RLX_ZP_DISPATCH

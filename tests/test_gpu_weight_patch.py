@@ -205,6 +205,30 @@ def test_zplane_codec_streams_are_byte_identical_to_the_numpy_restatement(dtype,
     assert es2 == es and np.array_equal(back_np, raw.numpy())
 
 
+@pytest.mark.parametrize("dtype,n", [(torch.int64, 4096 * 520 + 77), (torch.uint8, 4096 * 4101 + 5), (torch.uint8, 4096 * 6 + 1000)],
+                         ids=["int64-two-scan-tiles", "uint8-two-scan-tiles", "uint8-partial-workgroup"])
+def test_zplane_codec_large_streams(dtype, n):
+    """More directory entries than one scan tile (4096) holds -- the offsets come out of the two-level scan -- and byte streams
+    whose block count is not a multiple of the blocks a workgroup takes: byte-identical to the numpy restatement, both decoders."""
+    import numpy as np
+
+    from oracle import zplane_oracle as Z
+    g = torch.Generator().manual_seed(n)
+    es = torch.empty((), dtype=dtype).element_size()
+    raw = torch.randint(0, 256, (n * es,), generator=g, dtype=torch.uint8)
+    quarter = n * es // 4
+    raw[quarter:2 * quarter] = 0
+    raw[2 * quarter:3 * quarter] *= (torch.rand(quarter, generator=g) < 0.04).to(torch.uint8)
+    raw[3 * quarter:] = 5
+    c, stream = _zplane(raw.clone().view(dtype).to(DEV))
+    want = Z.compress(raw.numpy(), es)
+    assert stream.numel() == want.size and np.array_equal(stream.cpu().numpy(), want)
+    c._pending_status = []
+    code = torch.tensor({torch.uint8: 0, torch.int64: 3}[dtype], dtype=torch.int8)
+    back = c._decompress_tensor(stream, code)
+    assert _same_bits(back.cpu(), raw.view(dtype)) and int(torch.cat(c._pending_status).max()) == 0
+
+
 def test_zplane_decoder_rejects_truncated_and_foreign_streams():
     from rlinf_amd._lib import RlxError
     c, stream = _zplane(torch.arange(20000, dtype=torch.int32, device=DEV) % 300)
