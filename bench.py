@@ -552,8 +552,7 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
             pipeline: bool = False, rollout_epochs: int = 1, overlap: bool = True, transport: str | None = None) -> dict:
     """One timed region: W untimed iterations, then exactly ``steps`` iterations between barrier + synchronize on both sides,
     MAX over ranks.  ``scaling``: strong = 1024 envs / 8192-row global batch in total, weak = that much PER GPU.  Also returns
-    the spread of the iteration time over 10-step windows (run_step ends with a device synchronisation, so host time stamps
-    taken between iterations are exact)."""
+    the spread of the iteration time over 10-step windows (host time stamps taken when a window's last step has landed on the host)."""
     import torch.distributed as dist
     world, dev = ctx.world_size, ctx.device
     envs = ENVS * (world if scaling == "weak" else 1)
@@ -578,12 +577,31 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
         barrier()
         t0 = time.perf_counter()
         stamps = [t0]
-        for i in range(steps):
-            m = runner.run_step()
-            if (i + 1) % 10 == 0:
+        # the runner's own loop (EmbodiedRunner.run with runner.defer_metrics, its default): iteration i + 1 is queued on the
+        # device before iteration i's metrics are read on the host, so the device never waits for the host between iterations.
+        # Every iteration's metrics ARE read, inside the timed region; a 10-step window closes when its last step has landed.
+        pending, box = None, {"m": {}, "landed": 0}
+
+        def land(step):
+            box["m"] = step.result() if DEFER_METRICS else step
+            box["landed"] += 1
+            if box["landed"] % 10 == 0:
                 stamps.append(time.perf_counter())
+
+        for i in range(steps):
+            step = runner.run_step(defer=DEFER_METRICS)
+            if pending is not None:
+                land(pending)
+            if DEFER_METRICS:
+                pending = step
+            else:
+                land(step)
+        if pending is not None:
+            land(pending)
         barrier()
         elapsed = time.perf_counter() - t0
+        m = box["m"]
+        assert box["landed"] == steps and len(runner.metrics_history) >= steps
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -597,6 +615,7 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
                 "ppo_updates_per_sec": round(updates * steps / elapsed, 1), "steps": steps, "total_envs": envs, "global_batch": gb,
                 "grad_allreduce": w.grad_allreduce_backend + (f" ({w._xgmi.algo}, {w._xgmi.wait_mode} hand-shake)" if w._xgmi is not None else ""),
                 "update_graph_replayed": w._graph is not None, "elapsed_s": round(elapsed, 4),
+                "metrics_read": "every iteration, one iteration late (runner.defer_metrics)" if DEFER_METRICS else "every iteration, before the next is queued",
                 "last_metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in m.items()
                                  if k in ("train/actor/total_loss", "train/actor/grad_norm", "train/actor/approx_kl", "rollout/rewards")}}
     finally:
@@ -604,6 +623,8 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
         del runner
         torch.cuda.empty_cache()
 
+
+DEFER_METRICS = os.environ.get("RLX_BENCH_DEFER_METRICS", "1") != "0"  # 0: read every step's metrics before queueing the next
 
 WORKLOAD = ("ManiSkill PickCube-shaped PPO: 1024 envs x 128 steps, obs 42, act 8, MLP policy (3x256 tanh actor + value head), "
             "gamma 0.8 / lambda 0.9, 8 epochs x 16 minibatches of 8192 (128 optimizer steps), {prec}, synthetic env tensors "

@@ -51,8 +51,8 @@ def main(cfg) -> None:
     rank = cluster.ctx.rank
     keep = ("rollout/rewards", "train/actor/total_loss", "train/actor/approx_kl", "train/critic/value_loss",
             "train/actor/grad_norm", "perf/env_steps_per_sec", "time/step", "eval/return", "eval/num_trajectories")
-    for step in range(runner.global_step, runner.max_steps):  # runner.run(), one printed line per iteration
-        m = runner.run_step()
+    first = runner.global_step
+    for step, m in enumerate(runner.iter_steps(), start=first):  # runner.run(), one printed line per iteration (read one iteration late)
         if rank == 0:
             print(json.dumps({"step": step, **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in m.items() if k in keep}}),
                   flush=True)

@@ -24,7 +24,21 @@ import time
 import torch
 
 from ..scheduler import Channel
+from ..utils.pending import resolve
 from ..utils.runner_utils import check_progress
+
+
+class PendingStep:
+    """One queued iteration: ``result()`` waits for ITS metric copies (not for the device) and returns the step's metric dict."""
+
+    def __init__(self, finish):
+        self._finish, self._value = finish, None
+
+    def result(self) -> dict:
+        if self._value is None:
+            self._value = self._finish()
+            self._finish = None
+        return self._value
 
 
 class EmbodiedRunner:
@@ -42,6 +56,7 @@ class EmbodiedRunner:
         self.set_max_steps()
         self.metrics_history: list = []
         self.eval_history: list = []
+        self._last_landed = None  # host time at which the previous deferred step's metrics landed
 
     def set_max_steps(self):
         r = self.cfg.runner
@@ -129,10 +144,17 @@ class EmbodiedRunner:
         return eval_metrics
 
     # ---- one iteration ------------------------------------------------------------------------------------------------
-    def run_step(self, eps=None) -> dict:
+    def run_step(self, eps=None, defer: bool = False):
+        """One iteration with the reference's call sequence.  ``defer`` (this package's own): queue the whole iteration on the
+        device and return a ``PendingStep`` instead of its metric dict -- the numbers are copied to pinned host memory behind the
+        kernels that produce them and read when ``.result()`` is called.  ``run()`` calls it one iteration late, so the host
+        never waits with an empty device queue (no idle between the rollout, the update phase and the next rollout)."""
         dev = self.actor.worker.device
         step = self.global_step
         t0 = time.perf_counter()
+        worker = getattr(self.actor, "worker", self.actor)
+        if hasattr(worker, "defer_host_reads"):
+            worker.defer_host_reads = bool(defer)
         self.actor.set_global_step(self.global_step).wait()
         self.rollout.set_global_step(self.global_step).wait()
         if step % self.weight_sync_interval == 0:
@@ -153,31 +175,62 @@ class EmbodiedRunner:
             env_bootstrap_handle.wait()
         if not rollout_metrics and hasattr(self.actor.worker, "pop_rollout_metrics"):
             rollout_metrics = self.actor.worker.pop_rollout_metrics()  # pipeline learner: produced inside run_training
-        if dev is not None and dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
         self.global_step += 1
-        eval_metrics = self._maybe_eval_and_checkpoint(step)
         tr = self.cfg.env.train
         env_steps = tr.total_num_envs * tr.max_steps_per_rollout_epoch * tr.get("rollout_epoch", 1)
-        metrics = {f"rollout/{k}": v for k, v in rollout_metrics.items()}
-        metrics.update({f"train/{k}": v for k, v in train_metrics.items()})
-        metrics.update(eval_metrics)
-        metrics.update({"time/step": dt, "perf/env_steps_per_sec": env_steps / dt})
-        self.metrics_history.append(metrics)
-        return metrics
+
+        def finish() -> dict:
+            rm, tm = resolve(rollout_metrics), resolve(train_metrics)  # waits for this step's copies only
+            now = time.perf_counter()
+            # deferred: the iteration time is the time between two consecutive steps landing (the steady-state rate)
+            dt = (now - self._last_landed) if (defer and self._last_landed is not None) else now - t0
+            self._last_landed = now
+            metrics = {f"rollout/{k}": v for k, v in rm.items()}
+            metrics.update({f"train/{k}": v for k, v in tm.items()})
+            metrics.update(eval_metrics)
+            metrics.update({"time/step": dt, "perf/env_steps_per_sec": env_steps / dt})
+            self.metrics_history.append(metrics)
+            return metrics
+
+        if not defer:
+            if dev is not None and dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            eval_metrics = self._maybe_eval_and_checkpoint(step)
+            return finish()
+        eval_metrics = self._maybe_eval_and_checkpoint(step)  # (evaluation / checkpoints read the device: they wait by themselves)
+        return PendingStep(finish)
 
     def run(self, eps_fn=None):
+        """``runner.defer_metrics`` (default true): iterations are queued one ahead of the metrics being read (see run_step)."""
         if self.cfg.runner.get("use_training_pipeline", False):
             return self.run_pipeline(eps_fn)
+        return self._run_ahead(eps_fn)
+
+    def iter_steps(self, eps_fn=None):
+        """The loop as a generator: yields every iteration's metric dict, in order.  With ``runner.defer_metrics`` (default true)
+        iteration i + 1 is queued on the device before iteration i's dict is yielded: the numbers are read one iteration late and
+        the device never waits for the host (measured at the benchmark shape, one process, alternating: 9.27-9.33 ms per
+        iteration reading each step's numbers first, 8.89-8.92 ms this way; profiles/r03_run_ahead_loop_ab_same_process.txt)."""
+        defer = bool(self.cfg.runner.get("defer_metrics", True))
+        pending = None
         for _ in range(self.global_step, self.max_steps):
-            self.run_step(None if eps_fn is None else eps_fn(self.global_step))
+            step = self.run_step(None if eps_fn is None else eps_fn(self.global_step), defer=defer)
+            if not defer:
+                yield step
+                continue
+            if pending is not None:
+                yield pending.result()
+            pending = step
+        if pending is not None:
+            yield pending.result()
+
+    def _run_ahead(self, eps_fn=None):
+        for _ in self.iter_steps(eps_fn):
+            pass
         return self.metrics_history
 
     def run_pipeline(self, eps_fn=None):
         """runner.use_training_pipeline (:565-642): the learner consumes the rollout while it is produced.  The data path
         (statistics normalisation, per-stage shuffles, global-batch composition) lives in the actor worker; one iteration is
         the same call sequence."""
-        for _ in range(self.global_step, self.max_steps):
-            self.run_step(None if eps_fn is None else eps_fn(self.global_step))
-        return self.metrics_history
+        return self._run_ahead(eps_fn)

@@ -24,6 +24,7 @@ from ...models import get_model
 from ...scheduler.dist import all_reduce_flat_, all_reduce_scalars
 from ...scheduler.placement import compute_split_num, minibatch_plan
 from ...utils.lr_scheduler import LearnerLRScheduler
+from ...utils.pending import PendingMetrics
 from ..common import Worker
 
 CRITIC_EXPLAINED_VARIANCE_KEY = "critic/explained_variance"
@@ -73,6 +74,8 @@ class EmbodiedFSDPActor(Worker):
         self.pipeline_epochs = 1
         self.rollout_batches: list = []
         self._deferred_rollout_metrics: dict = {}
+        # True (set by the runner's run-ahead loop): metric dicts come back as PendingMetrics, read one iteration late
+        self.defer_host_reads = False
         if self.use_training_pipeline:
             assert cfg.algorithm.adv_type == "gae", ("algorithm.adv_type only supports 'gae' now"
                                                      "when runner.use_training_pipeline is True.")  # config.py:992-996
@@ -287,19 +290,26 @@ class EmbodiedFSDPActor(Worker):
         """red [len(names), 4] f64 = (sum, count, -min, max) of this rank's selection -> the reference's metric dict: one SUM and
         one MAX all-reduce over ranks (metric_utils.py:451-454 does two per metric), one read-back."""
         s, m = all_reduce_scalars(red[:, :2].reshape(-1).clone(), red[:, 2:].reshape(-1).clone(), self.ctx)
-        s, m = s.tolist(), m.tolist()
-        res = {}
-        for i, key in enumerate(names):
-            cnt = s[2 * i + 1]
-            if cnt > 0:
-                mean, vmax, vmin = s[2 * i] / cnt, m[2 * i + 1], -m[2 * i]
-            else:  # nothing selected on any rank: all three are NaN (metric_utils.py:458-460)
-                mean = vmax = vmin = float("nan")
-            if key == "rewards":
-                res["rewards"] = mean
-            else:
-                res[f"{key}_mean"], res[f"{key}_max"], res[f"{key}_min"] = mean, vmax, vmin
-        return res
+        ns = s.numel()
+
+        def finish(host: list) -> dict:
+            s, m = host[:ns], host[ns:]
+            res = {}
+            for i, key in enumerate(names):
+                cnt = s[2 * i + 1]
+                if cnt > 0:
+                    mean, vmax, vmin = s[2 * i] / cnt, m[2 * i + 1], -m[2 * i]
+                else:  # nothing selected on any rank: all three are NaN (metric_utils.py:458-460)
+                    mean = vmax = vmin = float("nan")
+                if key == "rewards":
+                    res["rewards"] = mean
+                else:
+                    res[f"{key}_mean"], res[f"{key}_max"], res[f"{key}_min"] = mean, vmax, vmin
+            return res
+
+        if self.defer_host_reads:  # the runner reads one iteration late (utils/pending.py)
+            return PendingMetrics(torch.cat([s, m]), finish)
+        return finish(s.tolist() + m.tolist())
 
     # ---- update -------------------------------------------------------------------------------------------------
     def _pipeline_perm_host(self, T: int, B: int) -> np.ndarray:
@@ -678,7 +688,7 @@ class EmbodiedFSDPActor(Worker):
         self._deferred_rollout_metrics = self._metrics_from_reductions(
             names, torch.cat([red[:, :, :2].sum(dim=0), red[:, :, 2:].amax(dim=0)], dim=1))
         out = self._collect_metrics(metrics_dev, norms_dev, accum)
-        if self._xgmi is not None:
+        if self._xgmi is not None and not self.defer_host_reads:
             self._xgmi.check_status()
         self._step_lr_scheduler()
         return out
@@ -707,7 +717,7 @@ class EmbodiedFSDPActor(Worker):
                 Tb, Bb = self.rollout_batch["prev_logprobs"].shape[:2]
                 self._prefetch_pipeline_perms(Tb, Bb, 1)  # host work for the NEXT iteration, behind the enqueued update phase
             out = self._collect_metrics(metrics_dev, norms_dev, accum)
-            if self._xgmi is not None:
+            if self._xgmi is not None and not self.defer_host_reads:
                 self._xgmi.check_status()  # a peer that never published its gradient: raise instead of training on garbage
             self._step_lr_scheduler()
             return out
@@ -770,20 +780,28 @@ class EmbodiedFSDPActor(Worker):
             all_reduce_flat_(avg, self.ctx, average=True)
             all_reduce_flat_(ev, self.ctx)
             vec = torch.cat([avg[:-1], ev, avg[-1:]])
-        host = vec.tolist()
-        out = {k: host[PPO_OUT_NAMES[k]] for k in _ACTOR_KEYS}
-        if has_critic:
-            out.update({k: host[PPO_OUT_NAMES[k]] for k in _CRITIC_KEYS})
-            stats = {name: host[PPO_OUT_FLOATS + i] for i, name in enumerate(_EV_MAP.values())}
-            out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(stats)
-        out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
-        out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
-        out["actor/grad_norm"] = host[-1]
         # averaged per optimizer step like every other entry of the reference's metric lists (append_to_dict + np.mean);
         # a replayed graph ran every step at the current rates and logs nothing per step
-        log = self._lr_log or [(self._lrs[0], self._lrs[1])]
-        out["actor/lr"] = float(np.mean([a for a, _ in log]))
-        critic = [c for _, c in log if c is not None]
-        if critic:
-            out["critic/lr"] = float(np.mean(critic))
-        return out
+        log = list(self._lr_log) or [(self._lrs[0], self._lrs[1])]
+        xgmi = self._xgmi
+
+        def finish(host: list) -> dict:
+            out = {k: host[PPO_OUT_NAMES[k]] for k in _ACTOR_KEYS}
+            if has_critic:
+                out.update({k: host[PPO_OUT_NAMES[k]] for k in _CRITIC_KEYS})
+                stats = {name: host[PPO_OUT_FLOATS + i] for i, name in enumerate(_EV_MAP.values())}
+                out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(stats)
+            out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
+            out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
+            out["actor/grad_norm"] = host[-1]
+            out["actor/lr"] = float(np.mean([a for a, _ in log]))
+            critic = [c for _, c in log if c is not None]
+            if critic:
+                out["critic/lr"] = float(np.mean(critic))
+            if xgmi is not None and self.defer_host_reads:
+                xgmi.check_status()  # a peer that never published its gradient: raise instead of reporting garbage
+            return out
+
+        if self.defer_host_reads:  # the runner reads one iteration late (utils/pending.py)
+            return PendingMetrics(vec, finish)
+        return finish(vec.tolist())

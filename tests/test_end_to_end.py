@@ -471,6 +471,40 @@ def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [dict(hip_graph=True), dict(hip_graph=False), dict(hip_graph=True, pipeline=True, rollout_epoch=2)],
+                         ids=["graph", "eager", "pipeline-e2"])
+def test_run_ahead_loop_reads_the_same_metrics_one_iteration_late(shape):
+    """EmbodiedRunner.run() queues iteration i + 1 before it reads iteration i's metrics (runner.defer_metrics, the default): every
+    iteration's metric dict and the final weights are identical, bit for bit, to the loop that reads each step's numbers before it
+    queues the next (defer_metrics false), and every iteration is logged exactly once, in order."""
+    E = shape.get("rollout_epoch", 1)
+    T, B, n_iter = 16 * E, 64, 5
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    sd = copy.deepcopy(O.OracleMLPPolicy(42, 8, 1).state_dict())
+    outs = []
+    for defer in (False, True):
+        cfg = make_cfg(total_envs=B, steps=16, global_batch=256, **shape)
+        cfg.runner.max_epochs = n_iter
+        cfg.runner.defer_metrics = defer
+        runner = _build(cfg, env, sd)
+        runner.set_max_steps()
+        eps = [torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it)).cuda() for it in range(n_iter)]
+        hist = runner.run(eps_fn=lambda step: eps[step])
+        assert len(hist) == n_iter and runner.global_step == n_iter
+        outs.append(([{k: v for k, v in m.items() if not k.startswith(("time/", "perf/"))} for m in hist],
+                     runner.actor.worker.model.flat.detach().cpu().clone()))
+        runner.close()
+    (want, w_want), (got, w_got) = outs
+    assert torch.equal(w_want, w_got)
+    for a, b in zip(want, got):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), k
+    assert len({m["train/actor/total_loss"] for m in got}) == n_iter  # (the iterations really differ: nothing was logged twice)
+
+
+@pytest.mark.gpu
 def test_non_auto_reset_builds_loss_mask_and_trains():
     """auto_reset=False -> loss mask + mask_sum ratio aggregation (embodied_fsdp_actor_worker.py:219-233, losses.py:219-227)."""
     cfg = make_cfg(total_envs=16, steps=12, global_batch=64, auto_reset=False)
