@@ -876,6 +876,7 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     StepArgs a{};
     a.stamps = g_timing_buffer;
     a.merged_loss_pass = dev_variant("RLX_FUSED_MERGED", 1);
+    a.xcd_rows = dev_variant("RLX_FUSED_XCD_ROWS", 0);  // measured: no effect (see the kernel), identity kept
     a.params = s->params; a.lay = lay; a.states = s->states; a.action = s->action; a.old_logprobs = s->old_logprobs;
     a.advantages = s->advantages; a.prev_values = s->prev_values; a.returns = s->returns; a.loss_mask = s->loss_mask;
     a.loss_mask_sum = s->loss_mask_sum; a.M = s->m; a.p = p; a.grad_out = s->grad_out;

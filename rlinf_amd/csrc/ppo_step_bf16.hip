@@ -525,7 +525,15 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
 
     const rlx_mlp_layout& lay = a.lay;
     const rlx_ppo_loss_params& p = a.p;
-    const int y = blockIdx.y, tile = blockIdx.x, D = lay.obs_dim, tid = threadIdx.x;
+    // Workgroups go to the 8 XCDs round-robin (linear id % 8 = blockIdx.x % 8: gridDim.x is a multiple of 8 whenever the remap is
+    // used).  The weight-gradient launch behind this one gives XCD x the split-K slabs over rows [x M / 8, (x + 1) M / 8); with the
+    // identity map those rows were written by ALL XCDs and every operand fetch of that launch is a memory-side trip.  Remapped
+    // (development: RLX_FUSED_XCD_ROWS=1), XCD x writes exactly the rows it reads back next -- measured, same box, 3200 launches
+    // each: weight-gradient launch 15.88 -> 15.64 us, this launch 25.16 -> 25.44 us (profiles/r03_xcd_row_map_*.txt).  A launch
+    // boundary writes back AND invalidates the XCD's L2, so which XCD produced a line does not matter to the next launch; only
+    // producer and consumer inside ONE launch could share an L2.  The identity map stays.
+    const int nt = gridDim.x, bx = blockIdx.x;
+    const int y = blockIdx.y, tile = (a.xcd_rows && (nt & 7) == 0) ? (bx & 7) * (nt >> 3) + (bx >> 3) : bx, D = lay.obs_dim, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
     const long long m0 = (long long)tile * BM, M = a.M;
     const int n_out = y == 1 ? lay.act_dim : lay.val_dim;

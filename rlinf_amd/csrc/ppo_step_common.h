@@ -181,6 +181,7 @@ struct StepArgs {
     rlx_ppo_loss_params p;
     float grad_out;             // d(total)/d(loss) of this micro-batch (1 / gradient_accumulation)
     int merged_loss_pass;       // bf16 launch: element math + loss element + dOut in one pass where the shapes allow (development: RLX_FUSED_MERGED=0)
+    int xcd_rows;               // bf16 launch: workgroup -> row-tile map that gives every XCD one CONTIGUOUS eighth of the rows (see the kernel)
     float* h;                   // [2 nets][2][M][256]  hidden activations 1, 2   (B operands of the weight gradients)
     float* dz;                  // [2 nets][3][M][256]  pre-activation gradients  (A operands)
     float* head_part;           // [head_parts][2][head_stride]  per-32-row head gradients: dW4 [n_out][256], db4, dlogstd [n_out]
