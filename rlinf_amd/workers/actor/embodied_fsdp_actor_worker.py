@@ -339,7 +339,25 @@ class EmbodiedFSDPActor(Worker):
         pkey = ("perm", N, epoch)
         if pkey not in self._ws:
             self._ws[pkey] = torch.empty(N, dtype=torch.int64, device=self.device)
-        self._ws[pkey].copy_(host, non_blocking=False)
+        if self.device.type != "cuda":
+            self._ws[pkey].copy_(host)
+            return self._ws[pkey]
+        # Upload without stalling the host (a copy from pageable memory waits for everything queued before it -- that alone kept
+        # the host in lock-step with the device in pipeline mode): a small ring of pinned staging buffers per order, each reused
+        # only after the upload that last read it has finished (two iterations ago: the event is long set).
+        skey = ("perm_stage", N, epoch)
+        ring = self._ws.setdefault(skey, {"bufs": [], "events": [], "next": 0})
+        if len(ring["bufs"]) < 3:
+            ring["bufs"].append(torch.empty(N, dtype=torch.int64, pin_memory=True))
+            ring["events"].append(torch.cuda.Event())
+            i = len(ring["bufs"]) - 1
+        else:
+            i = ring["next"] % 3
+            ring["events"][i].synchronize()
+        ring["next"] = i + 1
+        np.copyto(ring["bufs"][i].numpy(), host.numpy())  # (torch's CPU copy_ wakes the whole intra-op pool above 32768 elements)
+        self._ws[pkey].copy_(ring["bufs"][i], non_blocking=True)
+        ring["events"][i].record(torch.cuda.current_stream(self.device))
         return self._ws[pkey]
 
     def _prefetch_pipeline_perms(self, T: int, B: int, n_epochs: int) -> None:

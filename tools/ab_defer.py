@@ -16,10 +16,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--pipeline-epochs", type=int, default=0, help="> 0: pipeline mode with this many rollout epochs")
     args = ap.parse_args()
     from rlinf_amd.scheduler import init_distributed
     ctx = init_distributed()
-    runner = bench.build_runner(bench.build_cfg(1, True, "bf16", total_envs=bench.ENVS, global_batch=bench.GLOBAL_BATCH), ctx)
+    pipe = args.pipeline_epochs > 0
+    runner = bench.build_runner(bench.build_cfg(1, True, "bf16", pipeline=pipe, rollout_epochs=max(args.pipeline_epochs, 1),
+                                                total_envs=bench.ENVS, global_batch=bench.GLOBAL_BATCH), ctx)
     for _ in range(5):
         runner.run_step()
     dev = ctx.device
