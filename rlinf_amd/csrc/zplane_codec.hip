@@ -29,6 +29,7 @@
 // twice (measure, pack), the output written once.
 // Integer / byte work: bit-exact round trip (tests/test_gpu_weight_patch.py, against a numpy restatement of the format).
 
+#include <stdlib.h>
 #include <string.h>
 
 #include "rlx_common.h"
@@ -511,6 +512,221 @@ __global__ __launch_bounds__(kThreads) void zplane_pack(const uint8_t* __restric
     }
 }
 
+// ---- single-pass encoder ---------------------------------------------------------------------------------------------------------
+// measure + offsets + pack in ONE launch: the input is read once.  A workgroup takes its cells into registers, sizes its planes
+// (as zplane_measure), and needs the payload offset of its first plane = the sum of the sizes of everything before it.  That sum
+// comes from a decoupled look-back: every workgroup publishes (flag, value) words -- first its own total ("aggregate"), later the
+// total of everything up to and including itself ("prefix") -- and one of its waves walks the words of its predecessors, 64 at a
+// time, adding aggregates until it meets a prefix.  While that wave looks back, the other three compact their cells into LDS (the
+// compaction does not need the offset; only the copy-out does).  The stream comes out byte-identical to the multi-launch encoder
+// and to the numpy restatement: offsets follow block order, whatever order the workgroups ran in.
+// Forward progress: the block a workgroup encodes is its TICKET (an atomic counter taken at start), not blockIdx.x, so everything a
+// workgroup waits for has already started; a bounded wait (2 s) turns a lost predecessor into a length-0 result instead of a hang.
+// MEASURED (profiles/r03_zplane_single_pass_*.{jsonl,txt}; 200 MB streams): 205-239 us against 124-129 us for measure + two scan
+// launches + pack.  A workgroup's work is short (one 4-16 KiB block, ~3 us), ~2000 of them are resident at once and they publish
+// their aggregates together, so a look-back has to walk back over most of the resident set before it meets a prefix: dozens of
+// dependent device-scope reads per workgroup, more than the second read of the input costs.  The multi-launch encoder stays the
+// default; this one is kept selectable (RLX_ZPLANE_SINGLE_PASS=1) and tested for byte identity.
+constexpr uint64_t kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62;
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += (uint64_t)__shfl_xor((long long)x, d, 64);
+    return x;
+}
+
+// wave-wide: exclusive prefix of workgroup `wg` (its own total `mine` already known); publishes aggregate then prefix
+__device__ __forceinline__ uint64_t lookback_exclusive(unsigned long long* states, long long wg, uint64_t mine, unsigned long long* fail) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long* my = states + wg;
+    if (wg == 0) {
+        if (lane == 0) __hip_atomic_store(my, kFlagPrefix | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(my, kFlagAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    long long pos = wg - 1;
+    const long long t0 = wall_clock64();
+    while (true) {
+        const long long idx = pos - lane;
+        const uint64_t w = idx >= 0 ? __hip_atomic_load(states + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;  // nothing before block 0
+        const int flag = (int)(w >> 62);
+        const uint64_t pmask = __ballot(flag == 2), emask = __ballot(flag == 0);
+        const int first_p = pmask ? __builtin_ctzll(pmask) : 64;
+        const uint64_t needed = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1);  // lanes 0 .. first_p
+        if (emask & needed) {  // a predecessor in the window has not published yet
+            if (wall_clock64() - t0 > 200000000ll) {  // 2 s at 100 MHz
+                if (lane == 0) atomicExch(fail, 1ull);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        excl += wave_sum_u64(lane <= first_p ? (w & kSizeMask) : 0ull);
+        if (first_p < 64) break;
+        pos -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(my, kFlagPrefix | ((excl + mine) & kSizeMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <int ES>
+__global__ __launch_bounds__(kThreads) void zplane_encode(const uint8_t* __restrict__ in, long long n_elems, long long n_blocks,
+                                                          uint64_t* __restrict__ directory, uint8_t* __restrict__ payload,
+                                                          unsigned long long* __restrict__ sync_words,  // [0] ticket, [1] fail, [2 ...] states
+                                                          Header* __restrict__ header, uint64_t* __restrict__ out_bytes) {
+    constexpr int BPW = Geo<ES>::BPW, Q = Geo<ES>::Q;
+    __shared__ __attribute__((aligned(16))) uint8_t planes[Q * kBlock];
+    __shared__ __attribute__((aligned(8))) uint16_t masks[Q][kThreads];
+    __shared__ int span_cnt[Q][kSpans];
+    __shared__ int cnt[Q][4];
+    __shared__ int s_ng[Q], s_mode[Q];
+    __shared__ unsigned long long s_size[Q], s_excl, s_wg;
+    const int span = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_wg = atomicAdd(sync_words, 1ull);
+    if (threadIdx.x < Q * 4) (&cnt[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    const long long wg = (long long)s_wg, blk0 = wg * BPW, n_wg = (n_blocks + BPW - 1) / BPW;
+    const size_t total = (size_t)n_elems * ES;
+    if constexpr (ES > 1) {
+        load_planes<ES>(in, (size_t)blk0 * kBlock * ES, total, planes);
+        __syncthreads();
+    }
+    uint4 v[Q];
+    uint32_t before[Q], m[Q], mx[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        before[q] = 0;
+        if constexpr (ES == 1) {
+            const size_t byte0 = (size_t)(blk0 + q) * kBlock, avail = total > byte0 ? total - byte0 : 0;
+            v[q] = load_cell_bytes(in + byte0, avail, span);
+            if (span > 0 && (size_t)span * kSpan - 1 < avail) before[q] = in[byte0 + (size_t)span * kSpan - 1];
+        } else {
+            v[q] = *reinterpret_cast<const uint4*>(planes + q * kBlock + span * kSpan + lane * 16);
+            if (span > 0) before[q] = planes[q * kBlock + span * kSpan - 1];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {  // the statistics of zplane_measure
+        const uint4 x = xor_filter(v[q], before[q]);
+        m[q] = nz16(v[q]);
+        mx[q] = nz16(x);
+        int c = __popc(m[q]), cx = __popc(mx[q]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            c += __shfl_xor(c, off, 64);
+            cx += __shfl_xor(cx, off, 64);
+        }
+        const uint64_t any = __ballot(m[q] != 0), anyx = __ballot(mx[q] != 0);
+        const uint64_t g = any | (any >> 1) | (any >> 2) | (any >> 3), gx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
+        if (lane == 0) {
+            atomicAdd(&cnt[q][0], c);
+            atomicAdd(&cnt[q][1], __popcll(g & 0x1111111111111111ull));
+            atomicAdd(&cnt[q][2], cx);
+            atomicAdd(&cnt[q][3], __popcll(gx & 0x1111111111111111ull));
+        }
+    }
+    __syncthreads();  // plane statistics complete; every cell is in registers (planes[] is free from here on)
+    if (threadIdx.x < Q) {
+        const int q = threadIdx.x;
+        const long long blk = blk0 + q / ES;
+        uint64_t mode = 0, size = 0;
+        if (blk < n_blocks) {
+            const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
+            const int nz = cnt[q][0], ng = cnt[q][1], nzx = cnt[q][2], ngx = cnt[q][3];
+            const size_t masked = 8 + 8 * (size_t)ng + pad8((size_t)nz), xored = 8 + 8 * (size_t)ngx + pad8((size_t)nzx),
+                         raw = pad8((size_t)in_block);
+            if (nz == 0) { mode = 0; size = 0; }
+            else if (masked <= xored && masked < raw) { mode = 1; size = masked; }
+            else if (xored < raw) { mode = 3; size = xored; }
+            else { mode = 2; size = raw; }
+        }
+        s_mode[q] = (int)mode;
+        s_size[q] = size;
+    }
+    __syncthreads();
+    int mode[Q];
+    uint64_t local_off[Q], mine = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        mode[q] = s_mode[q];
+        local_off[q] = mine;
+        mine += s_size[q];
+    }
+    int incl[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {  // masks + per-span counts of the chosen form
+        incl[q] = 0;
+        if (mode[q] != 1 && mode[q] != 3) continue;
+        if (mode[q] == 3) {
+            v[q] = xor_filter(v[q], before[q]);
+            m[q] = mx[q];
+        }
+        masks[q][threadIdx.x] = (uint16_t)m[q];
+        incl[q] = wave_incl_sum(__popc(m[q]));
+        if (lane == 63) span_cnt[q][span] = incl[q];
+    }
+    __syncthreads();
+    if (span == kSpans - 1) {  // this wave looks back while the others already compact; it compacts its own cells afterwards
+        const uint64_t excl = lookback_exclusive(sync_words + 2, wg, mine, sync_words + 1);
+        if (lane == 0) s_excl = excl;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (mode[q] != 1 && mode[q] != 3) continue;
+        int base = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < kSpans; ++s2)
+            if (s2 < span) base += span_cnt[q][s2];
+        compact16(v[q], m[q], planes + q * kBlock, base + incl[q] - __popc(m[q]));
+        if (span == (q & (kSpans - 1))) {
+            const int nz = span_cnt[q][0] + span_cnt[q][1] + span_cnt[q][2] + span_cnt[q][3];
+            if (lane < (int)(pad8((size_t)nz) - nz)) planes[q * kBlock + nz + lane] = 0;
+            const uint64_t top = __ballot(reinterpret_cast<const uint64_t*>(&masks[q][0])[lane] != 0);
+            if (lane == 0) s_ng[q] = __popcll(top);
+        }
+    }
+    __syncthreads();  // the staged bytes are complete and the payload offset is known
+    const uint64_t excl = s_excl;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const long long blk = blk0 + q / ES;
+        if (blk >= n_blocks) continue;
+        uint8_t* dst = payload + excl + local_off[q];
+        if (threadIdx.x == q) directory[blk * ES + q % ES] = ((uint64_t)mode[q] << 62) | (excl + local_off[q]);
+        if (mode[q] == 0) continue;
+        if (mode[q] == 2) {
+            const int n8_raw = (int)pad8((size_t)min((long long)kBlock, n_elems - blk * kBlock));
+            const int b0 = span * kSpan + lane * 16;  // the raw plane: every lane's 16 bytes of its cell, straight from the registers
+            if (b0 + 8 <= n8_raw) *reinterpret_cast<uint2*>(dst + b0) = uint2{v[q].x, v[q].y};
+            if (b0 + 16 <= n8_raw) *reinterpret_cast<uint2*>(dst + b0 + 8) = uint2{v[q].z, v[q].w};
+            continue;
+        }
+        if (span == (q & (kSpans - 1))) {  // [top][group masks]
+            const uint64_t gm = reinterpret_cast<const uint64_t*>(&masks[q][0])[lane];
+            const uint64_t top = __ballot(gm != 0);
+            uint64_t* d64 = reinterpret_cast<uint64_t*>(dst);
+            if (gm != 0) d64[1 + __popcll(top & lanes_below(lane))] = gm;
+            if (lane == 0) d64[0] = top;
+        }
+        const int nz = span_cnt[q][0] + span_cnt[q][1] + span_cnt[q][2] + span_cnt[q][3];
+        uint8_t* bytes = dst + 8 + 8 * (size_t)s_ng[q];
+        for (int i = threadIdx.x * 8; i < (int)pad8((size_t)nz); i += kThreads * 8)
+            *reinterpret_cast<uint2*>(bytes + i) = *reinterpret_cast<const uint2*>(planes + q * kBlock + i);
+    }
+    if (wg == n_wg - 1 && threadIdx.x == 0) {  // the last block in stream order closes the stream
+        const uint64_t payload_bytes = excl + mine;
+        const bool failed = __hip_atomic_load(sync_words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        header->magic = kMagic;
+        header->version = 1;
+        header->elem_size = (uint8_t)ES;
+        header->block_log2 = kBlockLog2;
+        header->n_elems = (uint64_t)n_elems;
+        header->payload_bytes = payload_bytes;
+        *out_bytes = failed ? 0ull : kHeaderBytes + 8ull * (uint64_t)n_blocks * ES + payload_bytes;
+    }
+}
+
 // unpack: the headers (one wave per plane: group masks expanded to LDS, per-span byte counts), then the workgroup copies every
 // plane's byte area (or raw plane) into LDS in whole words, then the cells pull their bytes out of that staging area into
 // registers, undo the XOR filter with one scan per cell, and write the planes (byte streams: straight to global memory).
@@ -654,7 +870,8 @@ extern "C" size_t rlx_zplane_bound_bytes(int64_t n_elems, int elem_size) {
 extern "C" size_t rlx_zplane_workspace_bytes(int64_t n_elems, int elem_size) {
     if (n_elems < 0 || !es_ok(elem_size)) return 0;
     const size_t n_entries = (size_t)blocks_of(n_elems) * elem_size;
-    return 8 * n_entries + 8 * ((n_entries + kScanTile - 1) / kScanTile) + 64;  // entry sizes | scan tile totals
+    // multi-launch encoder: entry sizes | scan tile totals; single-pass encoder: ticket | fail | one look-back word per workgroup
+    return 8 * n_entries + 8 * ((n_entries + kScanTile - 1) / kScanTile) + 8 * ((size_t)blocks_of(n_elems) + 2) + 64;
 }
 
 extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_size, void* out, size_t out_capacity, uint64_t* out_bytes,
@@ -684,6 +901,18 @@ extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_siz
         case 2: hipLaunchKernelGGL(KERNEL<2>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;    \
         case 4: hipLaunchKernelGGL(KERNEL<4>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;    \
         default: hipLaunchKernelGGL(KERNEL<8>, dim3((unsigned)nb), dim3(kThreads), 0, st, __VA_ARGS__); break;   \
+    }
+    // development: RLX_ZPLANE_SINGLE_PASS=1 selects the one-launch encoder (same bytes; measured SLOWER, see its comment); read per
+    // call so that the tests can switch it
+    const char* sp_env = getenv("RLX_ZPLANE_SINGLE_PASS");
+    const bool single_pass = sp_env != nullptr && atoi(sp_env) != 0;
+    if (single_pass && nb > 0) {
+        unsigned long long* sync_words = reinterpret_cast<unsigned long long*>(tile_total + n_tiles);
+        const long long n_wg = elem_size == 1 ? (long long)grid1 : nb;
+        RLX_HIP_CHECK(hipMemsetAsync(sync_words, 0, 8 * (size_t)(n_wg + 2), st));
+        RLX_ZP_DISPATCH(zplane_encode, src, (long long)n_elems, nb, directory, payload, sync_words, reinterpret_cast<Header*>(o), out_bytes);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
     }
     if (nb > 0) {
         RLX_ZP_DISPATCH(zplane_measure, src, (long long)n_elems, nb, sizes);

@@ -125,6 +125,9 @@ class ZPlaneCompressor(PatchCompressor):
         fields = (patch.rows, patch.cols, patch.values)
         launched = [self._launch_compress(t) if t.numel() else None for t in fields]
         lengths = torch.cat([l[1] for l in launched if l is not None]).tolist() if any(launched) else []  # ONE read-back
+        if any(n < 24 for n in lengths):  # the encoder's bounded wait expired (a workgroup never published its offset): no stream
+            raise RlxError("rlx_zplane_compress produced no stream (its look-back wait expired); set RLX_ZPLANE_SINGLE_PASS=0 for "
+                           "the multi-launch encoder")
         outs, it = [], iter(lengths)
         for t, l in zip(fields, launched):
             outs.append(torch.empty(0, dtype=torch.uint8, device=dev) if l is None else l[0][:next(it)].clone())

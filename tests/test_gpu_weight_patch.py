@@ -207,12 +207,14 @@ def test_zplane_codec_streams_are_byte_identical_to_the_numpy_restatement(dtype,
 
 @pytest.mark.parametrize("dtype,n", [(torch.int64, 4096 * 520 + 77), (torch.uint8, 4096 * 4101 + 5), (torch.uint8, 4096 * 6 + 1000)],
                          ids=["int64-two-scan-tiles", "uint8-two-scan-tiles", "uint8-partial-workgroup"])
-def test_zplane_codec_large_streams(dtype, n):
+@pytest.mark.parametrize("single_pass", ["0", "1"], ids=["multi-launch", "single-pass"])
+def test_zplane_codec_large_streams(dtype, n, single_pass, monkeypatch):
     """More directory entries than one scan tile (4096) holds -- the offsets come out of the two-level scan -- and byte streams
     whose block count is not a multiple of the blocks a workgroup takes: byte-identical to the numpy restatement, both decoders."""
     import numpy as np
 
     from oracle import zplane_oracle as Z
+    monkeypatch.setenv("RLX_ZPLANE_SINGLE_PASS", single_pass)  # "1": the one-launch encoder with the decoupled look-back (kept selectable)
     g = torch.Generator().manual_seed(n)
     es = torch.empty((), dtype=dtype).element_size()
     raw = torch.randint(0, 256, (n * es,), generator=g, dtype=torch.uint8)
