@@ -30,6 +30,8 @@
 // Integer / byte work: bit-exact round trip (tests/test_gpu_weight_patch.py, against a numpy restatement of the format).
 
 #include <stdlib.h>
+
+#include <algorithm>
 #include <string.h>
 
 #include "rlx_common.h"
@@ -177,7 +179,8 @@ static_assert(kSpans == kThreads / 64, "one wave per span");
 // the lane's 16 bytes under the XOR filter (b[i] ^ b[i-1]); `before` = the byte in front of the span (0 for the plane's first)
 __device__ __forceinline__ uint4 xor_filter(const uint4& v, uint32_t before) {
     const int lane = threadIdx.x & 63;
-    uint32_t prev = (uint32_t)__shfl_up((int)(v.w >> 24), 1, 64);
+    // the last byte of the lane below: wave_shr:1 (a DPP move on the VALU; __shfl_up would be a ds_bpermute through the LDS pipe)
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v.w >> 24), 0x138, 0xf, 0xf, false);
     if (lane == 0) prev = before;
     uint4 x;
     x.x = v.x ^ ((v.x << 8) | prev);
@@ -196,24 +199,38 @@ __device__ __forceinline__ uint32_t xor_prefix16(uint4& v) {
     return v.w >> 24;
 }
 
-__device__ __forceinline__ int wave_incl_sum(int x) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(x, d, 64);
-        if (lane >= d) x += t;
-    }
-    return x;
+// Cross-lane sums of SMALL values without the LDS pipe: one ballot per bit of the value; v_mbcnt counts the set bits below a
+// lane (a prefix), s_bcnt1 all of them (a total).  A 6-step __shfl_up / __shfl_xor ladder is six ds_bpermute trips through the
+// CU's one LDS pipe per value, shared by all four SIMDs -- it was what the codec's launches were bound by.
+__device__ __forceinline__ int lane_prefix_count(uint64_t mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__device__ __forceinline__ uint32_t wave_incl_xor(uint32_t x) {
-    const int lane = threadIdx.x & 63;
+// inclusive prefix sum over the lanes of x in [0, 31]
+__device__ __forceinline__ int wave_incl_sum(int x) {
+    int excl = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)x, d, 64);
-        if (lane >= d) x ^= t;
+    for (int b2 = 0; b2 < 5; ++b2) excl += lane_prefix_count(__ballot((x >> b2) & 1)) << b2;
+    return excl + x;
+}
+
+// sum over the lanes of x in [0, 31] (wave-uniform)
+__device__ __forceinline__ int wave_total(int x) {
+    int t = 0;
+#pragma unroll
+    for (int b2 = 0; b2 < 5; ++b2) t += __popcll(__ballot((x >> b2) & 1)) << b2;
+    return t;
+}
+
+// inclusive prefix XOR over the lanes of an 8-bit value
+__device__ __forceinline__ uint32_t wave_incl_xor(uint32_t x) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int b2 = 0; b2 < 8; ++b2) {
+        const uint32_t bit = (x >> b2) & 1u;
+        r |= (((uint32_t)lane_prefix_count(__ballot(bit != 0)) + bit) & 1u) << b2;
     }
-    return x;
+    return r;
 }
 
 // the lane's 16 bytes of cell (plane 0, span `span`) of a BYTE stream straight from global memory (no plane split to do);
@@ -270,62 +287,65 @@ __global__ __launch_bounds__(kThreads) void zplane_measure(const uint8_t* __rest
                                                            uint64_t* __restrict__ sizes) {
     constexpr int BPW = Geo<ES>::BPW, Q = Geo<ES>::Q;
     __shared__ __attribute__((aligned(16))) uint8_t planes[ES == 1 ? 16 : ES * kBlock];
-    __shared__ int cnt[Q][4];  // nz, ng, nzx, ngx of each plane, summed over its four cells
-    const long long blk0 = (long long)blockIdx.x * BPW;
+    __shared__ int cnt[2][kSpans][Q][4];  // nz, ng, nzx, ngx of each cell (plain stores, summed by the deciding thread); two sets, alternating between trips
     const int span = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t total = (size_t)n_elems * ES;
-    if (threadIdx.x < Q * 4) (&cnt[0][0])[threadIdx.x] = 0;
-    if constexpr (ES > 1) load_planes<ES>(in, (size_t)blk0 * kBlock * ES, total, planes);
-    __syncthreads();
-    uint4 v[Q];
-    uint32_t before[Q];
+    const long long n_wg = (n_blocks + BPW - 1) / BPW;
+    // grid-stride over the workgroup-sized pieces (the host caps the grid for byte streams, see rlx_zplane_compress)
+    int par = 0;
+    for (long long wg = blockIdx.x; wg < n_wg; wg += gridDim.x, par ^= 1) {
+        const long long blk0 = wg * BPW;
+        if constexpr (ES > 1) load_planes<ES>(in, (size_t)blk0 * kBlock * ES, total, planes);
+        __syncthreads();  // planes staged (and the previous trip's decisions have read their counters: this trip writes the other set)
+        uint4 v[Q];
+        uint32_t before[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {  // all of the workgroup's loads in flight before the first use
-        before[q] = 0;
-        if constexpr (ES == 1) {
-            const size_t byte0 = (size_t)(blk0 + q) * kBlock, avail = total > byte0 ? total - byte0 : 0;
-            v[q] = load_cell_bytes(in + byte0, avail, span);
-            if (span > 0 && (size_t)span * kSpan - 1 < avail) before[q] = in[byte0 + (size_t)span * kSpan - 1];
-        } else {
-            v[q] = *reinterpret_cast<const uint4*>(planes + q * kBlock + span * kSpan + lane * 16);
-            if (span > 0) before[q] = planes[q * kBlock + span * kSpan - 1];
+        for (int q = 0; q < Q; ++q) {  // all of the workgroup's loads in flight before the first use
+            before[q] = 0;
+            if constexpr (ES == 1) {
+                const size_t byte0 = (size_t)(blk0 + q) * kBlock, avail = total > byte0 ? total - byte0 : 0;
+                v[q] = load_cell_bytes(in + byte0, avail, span);
+                if (span > 0 && (size_t)span * kSpan - 1 < avail) before[q] = in[byte0 + (size_t)span * kSpan - 1];
+            } else {
+                v[q] = *reinterpret_cast<const uint4*>(planes + q * kBlock + span * kSpan + lane * 16);
+                if (span > 0) before[q] = planes[q * kBlock + span * kSpan - 1];
+            }
         }
-    }
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const uint4 x = xor_filter(v[q], before[q]);
-        const uint32_t m = nz16(v[q]), mx = nz16(x);
-        int c = __popc(m), cx = __popc(mx);
+        for (int q = 0; q < Q; ++q) {
+            const uint4 x = xor_filter(v[q], before[q]);
+            const uint32_t m = nz16(v[q]), mx = nz16(x);
+            const int c = wave_total(__popc(m)), cx = wave_total(__popc(mx));
+            // a group is nonzero iff any of its four lanes holds a nonzero byte: OR over the quad, counted once per quad
+            const uint64_t any = __ballot(m != 0), anyx = __ballot(mx != 0);
+            const uint64_t g = any | (any >> 1) | (any >> 2) | (any >> 3), gx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
+            if (lane == 0) {
+                cnt[par][span][q][0] = c;
+                cnt[par][span][q][1] = __popcll(g & 0x1111111111111111ull);
+                cnt[par][span][q][2] = cx;
+                cnt[par][span][q][3] = __popcll(gx & 0x1111111111111111ull);
+            }
+        }
+        __syncthreads();  // this trip's counters are complete; nobody reads planes[] any more
+        if (threadIdx.x < Q) {
+            const int q = threadIdx.x;
+            const long long blk = blk0 + q / ES;
+            int nz = 0, ng = 0, nzx = 0, ngx = 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            c += __shfl_xor(c, off, 64);
-            cx += __shfl_xor(cx, off, 64);
-        }
-        // a group is nonzero iff any of its four lanes holds a nonzero byte: OR over the quad, counted once per quad
-        const uint64_t any = __ballot(m != 0), anyx = __ballot(mx != 0);
-        const uint64_t g = any | (any >> 1) | (any >> 2) | (any >> 3), gx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
-        if (lane == 0) {
-            atomicAdd(&cnt[q][0], c);
-            atomicAdd(&cnt[q][1], __popcll(g & 0x1111111111111111ull));
-            atomicAdd(&cnt[q][2], cx);
-            atomicAdd(&cnt[q][3], __popcll(gx & 0x1111111111111111ull));
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < Q) {
-        const int q = threadIdx.x;
-        const long long blk = blk0 + q / ES;
-        if (blk < n_blocks) {
-            const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
-            const int nz = cnt[q][0], ng = cnt[q][1], nzx = cnt[q][2], ngx = cnt[q][3];
-            const size_t masked = 8 + 8 * (size_t)ng + pad8((size_t)nz), xored = 8 + 8 * (size_t)ngx + pad8((size_t)nzx),
-                         raw = pad8((size_t)in_block);
-            uint64_t mode, size;
-            if (nz == 0) { mode = 0; size = 0; }
-            else if (masked <= xored && masked < raw) { mode = 1; size = masked; }
-            else if (xored < raw) { mode = 3; size = xored; }
-            else { mode = 2; size = raw; }
-            sizes[blk * ES + q % ES] = (mode << 62) | size;
+            for (int s2 = 0; s2 < kSpans; ++s2) {
+                nz += cnt[par][s2][q][0]; ng += cnt[par][s2][q][1]; nzx += cnt[par][s2][q][2]; ngx += cnt[par][s2][q][3];
+            }
+            if (blk < n_blocks) {
+                const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
+                const size_t masked = 8 + 8 * (size_t)ng + pad8((size_t)nz), xored = 8 + 8 * (size_t)ngx + pad8((size_t)nzx),
+                             raw = pad8((size_t)in_block);
+                uint64_t mode, size;
+                if (nz == 0) { mode = 0; size = 0; }
+                else if (masked <= xored && masked < raw) { mode = 1; size = masked; }
+                else if (xored < raw) { mode = 3; size = xored; }
+                else { mode = 2; size = raw; }
+                sizes[blk * ES + q % ES] = (mode << 62) | size;
+            }
         }
     }
 }
@@ -579,12 +599,11 @@ __global__ __launch_bounds__(kThreads) void zplane_encode(const uint8_t* __restr
     __shared__ __attribute__((aligned(16))) uint8_t planes[Q * kBlock];
     __shared__ __attribute__((aligned(8))) uint16_t masks[Q][kThreads];
     __shared__ int span_cnt[Q][kSpans];
-    __shared__ int cnt[Q][4];
+    __shared__ int cnt[kSpans][Q][4];
     __shared__ int s_ng[Q], s_mode[Q];
     __shared__ unsigned long long s_size[Q], s_excl, s_wg;
     const int span = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_wg = atomicAdd(sync_words, 1ull);
-    if (threadIdx.x < Q * 4) (&cnt[0][0])[threadIdx.x] = 0;
     __syncthreads();
     const long long wg = (long long)s_wg, blk0 = wg * BPW, n_wg = (n_blocks + BPW - 1) / BPW;
     const size_t total = (size_t)n_elems * ES;
@@ -611,19 +630,14 @@ __global__ __launch_bounds__(kThreads) void zplane_encode(const uint8_t* __restr
         const uint4 x = xor_filter(v[q], before[q]);
         m[q] = nz16(v[q]);
         mx[q] = nz16(x);
-        int c = __popc(m[q]), cx = __popc(mx[q]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            c += __shfl_xor(c, off, 64);
-            cx += __shfl_xor(cx, off, 64);
-        }
+        const int c = wave_total(__popc(m[q])), cx = wave_total(__popc(mx[q]));
         const uint64_t any = __ballot(m[q] != 0), anyx = __ballot(mx[q] != 0);
         const uint64_t g = any | (any >> 1) | (any >> 2) | (any >> 3), gx = anyx | (anyx >> 1) | (anyx >> 2) | (anyx >> 3);
         if (lane == 0) {
-            atomicAdd(&cnt[q][0], c);
-            atomicAdd(&cnt[q][1], __popcll(g & 0x1111111111111111ull));
-            atomicAdd(&cnt[q][2], cx);
-            atomicAdd(&cnt[q][3], __popcll(gx & 0x1111111111111111ull));
+            cnt[span][q][0] = c;
+            cnt[span][q][1] = __popcll(g & 0x1111111111111111ull);
+            cnt[span][q][2] = cx;
+            cnt[span][q][3] = __popcll(gx & 0x1111111111111111ull);
         }
     }
     __syncthreads();  // plane statistics complete; every cell is in registers (planes[] is free from here on)
@@ -633,7 +647,11 @@ __global__ __launch_bounds__(kThreads) void zplane_encode(const uint8_t* __restr
         uint64_t mode = 0, size = 0;
         if (blk < n_blocks) {
             const long long in_block = min((long long)kBlock, n_elems - blk * kBlock);
-            const int nz = cnt[q][0], ng = cnt[q][1], nzx = cnt[q][2], ngx = cnt[q][3];
+            int nz = 0, ng = 0, nzx = 0, ngx = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < kSpans; ++s2) {
+                nz += cnt[s2][q][0]; ng += cnt[s2][q][1]; nzx += cnt[s2][q][2]; ngx += cnt[s2][q][3];
+            }
             const size_t masked = 8 + 8 * (size_t)ng + pad8((size_t)nz), xored = 8 + 8 * (size_t)ngx + pad8((size_t)nzx),
                          raw = pad8((size_t)in_block);
             if (nz == 0) { mode = 0; size = 0; }
@@ -915,7 +933,19 @@ extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_siz
         return RLX_OK;
     }
     if (nb > 0) {
-        RLX_ZP_DISPATCH(zplane_measure, src, (long long)n_elems, nb, sizes);
+        {  // measure can walk its pieces grid-stride with at most `cap` workgroups (development: RLX_ZPLANE_MEASURE_GRID; 0 = one
+           // workgroup per piece).  Measured (profiles/r03_zplane_codec_v4_kernels.txt): byte streams 52.6 -> 48.4 us with 2048,
+           // 4-byte elements 57.1 -> 59.0 us -- the launch is NOT bound by the workgroup start rate; byte streams keep the walk.
+            const char* ge = getenv("RLX_ZPLANE_MEASURE_GRID");
+            const long long cap = ge != nullptr ? atoll(ge) : (elem_size == 1 ? 2048 : 0), pieces = elem_size == 1 ? (long long)grid1 : nb;
+            const unsigned gm = (unsigned)(cap > 0 ? std::min(cap, pieces) : pieces);
+            switch (elem_size) {
+                case 1: hipLaunchKernelGGL(zplane_measure<1>, dim3(gm), dim3(kThreads), 0, st, src, (long long)n_elems, nb, sizes); break;
+                case 2: hipLaunchKernelGGL(zplane_measure<2>, dim3(gm), dim3(kThreads), 0, st, src, (long long)n_elems, nb, sizes); break;
+                case 4: hipLaunchKernelGGL(zplane_measure<4>, dim3(gm), dim3(kThreads), 0, st, src, (long long)n_elems, nb, sizes); break;
+                default: hipLaunchKernelGGL(zplane_measure<8>, dim3(gm), dim3(kThreads), 0, st, src, (long long)n_elems, nb, sizes); break;
+            }
+        }
         RLX_LAUNCH_CHECK();
         hipLaunchKernelGGL(zplane_scan_tiles, dim3((unsigned)n_tiles), dim3(1024), 0, st, sizes, n_entries, directory, tile_total);
         RLX_LAUNCH_CHECK();
