@@ -1130,6 +1130,8 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, 
     long long* stp = (a.stamps != nullptr && item == 0 && tid == 0) ? a.stamps : nullptr;
     if (stp) stp[0] = clock64();
     constexpr int AHEAD = DW_NBUF - 1;  // k-blocks in flight
+    for (int rep = 0; rep < a.repeat; ++rep) {  // (1 pass; development: a second, L2-warm pass for timing)
+    if (rep > 0) __builtin_amdgcn_s_barrier();  // everybody finished reading the last k-blocks before the ring is refilled
 #pragma unroll
     for (int d = 0; d < AHEAD; ++d)
         if (d < nkb) dma(d, d);
@@ -1160,6 +1162,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragment reads are done before this wave arrives at the next barrier
+    }
     }
     if (stp) stp[14] = clock64();
     if (!live) return;

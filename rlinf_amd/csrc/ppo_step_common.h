@@ -204,6 +204,8 @@ struct DwArgs {
     int head_parts;          // 32-row head-gradient partial slots per network
     int head_stride;
     int gemm_items;          // slabs * 20, the grid holds round_up(gemm_items, 8) GEMM blocks
+    int repeat;              // 1; development (RLX_DW_REPEAT = 2, TIMING ONLY -- the sums come out doubled): the bf16 LDS-DMA kernel walks
+                             // its k-blocks twice, the second time with its operands warm in its XCD's L2
     float* grads;            // [slabs][n_params]
     rlx_ppo_loss_params p;
     int has_mask, has_msum;
