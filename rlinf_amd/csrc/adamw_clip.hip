@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherSrc src, float* __res
 __device__ __forceinline__ size_t tile_slot(size_t mat_off, int nit, int n, int k) {  // f32 tiles: 16 (n) x 16 (k), two per 32 k
     return mat_off + ((((size_t)(n >> 4) * nit + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3);
 }
-__device__ __forceinline__ size_t tile_slot_bf16(size_t mat_off, int nit, int n, int k) {  // bf16 tiles: 16 (n) x 32 (k)
-    return mat_off + (((size_t)(n >> 4) * nit + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
+__device__ __forceinline__ size_t tile_slot_bf16(size_t mat_off, int nit, int n, int k) {  // bf16 tiles: 16 (n) x 32 (k), k-step major
+    (void)nit;
+    return mat_off + (((size_t)(k >> 5) * 16 + (n >> 4)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
 }
 template <bool BF16>
 __device__ __forceinline__ void tile_store(float* __restrict__ tiles, size_t mat_off, int nit, int n, int k, float val) {

@@ -847,7 +847,7 @@ extern "C" int rlx_ppo_step_slabs_for(const rlx_mlp_layout* lay, int64_t m, int3
 
 extern "C" size_t rlx_ppo_step_workspace_bytes(const rlx_mlp_layout* lay, int64_t m) {
     if (!lay || m <= 0) return 256;
-    return std::max(plan_step(lay, m, false).bytes, plan_step(lay, m, true).bytes);  // either precision fits
+    return std::max({plan_step(lay, m, false).bytes, plan_step(lay, m, true).bytes, plan_step(lay, m, true, true).bytes});  // any launch fits
 }
 
 extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
@@ -865,7 +865,8 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
                 "rlx_ppo_step: NULL argument");
     RLX_REQUIRE(!p.has_critic || (s->prev_values && s->returns), "rlx_ppo_step: has_critic set but a critic tensor is NULL");
     const bool bf16 = s->bf16 != 0;
-    const StepPlan pl = plan_step(&lay, s->m, bf16);
+    const bool rows = bf16 && fused_rows_bf16() && fused_rows_eligible(lay, p);
+    const StepPlan pl = plan_step(&lay, s->m, bf16, rows);
     RLX_REQUIRE(s->slabs == pl.slabs, "rlx_ppo_step: grads holds %d slabs, rlx_ppo_step_slabs() says %d", s->slabs, pl.slabs);
     if (s->workspace_bytes < pl.bytes) {
         set_error("rlx_ppo_step: workspace %zu < %zu bytes", s->workspace_bytes, pl.bytes);
@@ -886,7 +887,7 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     DwArgs d{};
     d.stamps = g_timing_buffer ? g_timing_buffer + 32 : nullptr;
     d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
-    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.tiles; d.head_parts = pl.head_parts;
+    d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.loss_slots; d.head_parts = pl.head_parts;
     d.head_stride = pl.head_stride;
     d.gemm_items = pl.slabs * 20; d.grads = s->grads; d.p = p; d.has_mask = s->loss_mask != nullptr;
     d.repeat = std::max(1, dev_variant("RLX_DW_REPEAT", 1));
@@ -900,7 +901,7 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
             a.tiles = static_cast<const float*>(tiles);
             if (int rc = pack_tiles_bf16(s->params, lay, tiles, st)) return rc;
         }
-        return launch_step_bf16(a, d, ws + pl.off_st, pl.tiles, dw_blocks, lay.act_dim <= 8 && lay.val_dim <= 8, st);
+        return launch_step_bf16(a, d, ws + pl.off_st, pl.tiles, dw_blocks, lay.act_dim <= 8 && lay.val_dim <= 8, rows, st);
     }
     if (s->tiles != nullptr) {
         a.tiles = s->tiles;

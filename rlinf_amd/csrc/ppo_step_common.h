@@ -200,8 +200,8 @@ struct DwArgs {
     long long M;
     int rows_per_slab;       // multiple of 32
     int slabs;
-    int tiles;               // 64-row tiles of the fused kernel (loss partial slots per network)
-    int head_parts;          // 32-row head-gradient partial slots per network
+    int tiles;               // loss partial slots per network (StepPlan.loss_slots)
+    int head_parts;          // head-gradient partial slots per network
     int head_stride;
     int gemm_items;          // slabs * 20, the grid holds round_up(gemm_items, 8) GEMM blocks
     int repeat;              // 1; development (RLX_DW_REPEAT = 2, TIMING ONLY -- the sums come out doubled): the bf16 LDS-DMA kernel walks
@@ -313,8 +313,9 @@ inline int head_stride_of(const rlx_mlp_layout* lay) {
 }
 
 struct StepPlan {
-    int tiles;        // 64-row tiles of the fused kernel (= loss partial slots per network)
-    int head_parts;   // 32-row head-gradient partial slots per network
+    int tiles;        // row tiles of the fused kernel (its grid)
+    int loss_slots;   // metric partial slots per network (one per tile; the row-split bf16 launch: one per 16-row wave)
+    int head_parts;   // head-gradient partial slots per network (one per 32 rows; the row-split bf16 launch: one per 64-row tile)
     int slabs, rows_per_slab, head_stride;
     size_t off_h, off_dz, off_head, off_loss, off_tiles, off_st, bytes;
 };
@@ -326,11 +327,16 @@ constexpr int STEP_BM = 64;
 inline int rollout_bm_bf16() { return dev_variant("RLX_ROLLOUT_RT", 1) == 2 ? 32 : 16; }
 inline int dw_nbuf() { return dev_variant("RLX_DW_NBUF", 3); }  // LDS ring depth of the bf16 weight-gradient launch (3, 4, 5, 6, 9)
 inline int fused_bm_bf16() { return dev_variant("RLX_FUSED_RT", 2) == 4 ? 64 : 32; }
-inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = false) {
+// The row-split bf16 launch (ppo_step_bf16_rows.hip: 64 rows per workgroup, one wave per 16 rows, weights through an LDS ring) for
+// the shapes it covers (fused_rows_eligible), behind RLX_FUSED_ROWS=1 while it is being tuned.
+inline bool fused_rows_bf16() { return dev_variant("RLX_FUSED_ROWS", 0) != 0; }
+bool fused_rows_eligible(const rlx_mlp_layout& lay, const rlx_ppo_loss_params& p);
+inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = false, bool rows = false) {
     StepPlan pl{};
-    const int bm = bf16 ? fused_bm_bf16() : STEP_BM;
+    const int bm = (bf16 && rows) ? 64 : bf16 ? fused_bm_bf16() : STEP_BM;
     pl.tiles = ceil_div(m, bm);
-    pl.head_parts = pl.tiles * (bm / 32);
+    pl.head_parts = (bf16 && rows) ? pl.tiles : pl.tiles * (bm / 32);
+    pl.loss_slots = (bf16 && rows) ? pl.tiles * 4 : pl.tiles;
     // 20 GEMM items per slab.  Every slab is 1.15 MB written here and read back by the slab reduce through the memory side:
     // measured (round 2, after the head-reduce tail fix) 16 slabs = 1.25 workgroups per CU is the best trade -- weight-gradient
     // launch 16.2 us + slab reduce 9.1 us, against 15.8 + 10.4 us with 24 slabs (2 per CU, no second round)
@@ -358,7 +364,7 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
         pl.off_tiles = take(2 * Tiles::per_net() * sizeof(float));
     }
     pl.off_head = take((size_t)pl.head_parts * 2 * pl.head_stride * sizeof(float));
-    pl.off_loss = take((size_t)pl.tiles * 2 * NS * sizeof(double));
+    pl.off_loss = take((size_t)pl.loss_slots * 2 * NS * sizeof(double));
     pl.bytes = off;
     return pl;
 }
@@ -368,7 +374,8 @@ extern long long* g_timing_buffer;  // development: phase stamps (rlx_dev_set_ti
 // bf16 launches (ppo_step_bf16.hip)
 int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles, hipStream_t st);
 int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st);
-int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, hipStream_t st);
+int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, bool rows, hipStream_t st);
+int launch_fused_rows_bf16(const StepArgs& a, void* st_tiles, int tiles64, hipStream_t st);  // ppo_step_bf16_rows.hip
 
 }  // namespace step
 }  // namespace rlx

@@ -370,10 +370,11 @@ def test_rollout_step_bf16_vs_autocast_oracle(M):
     torch.testing.assert_close(lp.cpu(), f32_lp, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("rows_per_workgroup", [32, 64])
-@pytest.mark.parametrize("M,with_mask", [(8192, False), (700, True), (704, False), (5, False)])
-def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask, rows_per_workgroup, monkeypatch):
-    """Both tilings of the fused launch (32 rows per workgroup, the default: two workgroups per CU; 64: RLX_FUSED_RT=4).
+@pytest.mark.parametrize("launch", ["rows", "cols32", "cols64"])
+@pytest.mark.parametrize("M,with_mask", [(8192, False), (700, True), (704, False), (5, False), (1000, True)])
+def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask, launch, monkeypatch):
+    """Every form of the fused bf16 launch: the row-split one (the default where its shapes allow: a wave per 16 rows, weights through
+    an LDS ring) and both tilings of the column-split one (RLX_FUSED_ROWS=0; 32 rows per workgroup, or 64: RLX_FUSED_RT=4).
 
     bf16 operands perturb the log-probs by ~1e-2, which moves samples across PPO's clip boundary: the actor gradient of
     ANY bf16 implementation differs from the f32 one by a few percent (norm-wise), discontinuously.  The yardstick is
@@ -381,7 +382,8 @@ def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask, rows_per_workg
     twice its distance; the critic (smooth Huber loss) is held to a tight bound, tensor by tensor."""
     from rlinf_amd import ops
     from rlinf_amd._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
-    monkeypatch.setenv("RLX_FUSED_RT", "4" if rows_per_workgroup == 64 else "2")  # read at every plan / launch
+    monkeypatch.setenv("RLX_FUSED_ROWS", "1" if launch == "rows" else "0")  # read at every plan / launch
+    monkeypatch.setenv("RLX_FUSED_RT", "4" if launch == "cols64" else "2")
     ora, pol = _bf16_policy(seed=11)
     g = torch.Generator().manual_seed(5)
     mb = _minibatch(M, g, with_mask)

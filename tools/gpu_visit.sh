@@ -1,0 +1,50 @@
+#!/bin/bash
+# One GPU-box visit (gpurun): named steps, each under its own timeout, logs under gpurun_out/<tag>_*.
+#   tools/gpu_visit.sh <tag> <step> [<step> ...]
+# steps: fused_tests | all_tests | smoke | rows_probe | rows_probe_prof | share_prof | bench | bench_prof | step_prof
+set -u
+TAG=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+prof_db() { ls $1/*.db $1/*/*.db 2>/dev/null | head -1; }
+for STEP in "$@"; do
+  echo "=== $STEP"
+  case $STEP in
+    fused_tests)
+      timeout 600 python -m pytest tests/test_gpu_fused_step.py tests/test_end_to_end_bench_config.py -x -q > gpurun_out/${TAG}_fused_tests.log 2>&1
+      echo "rc=$?"; tail -5 gpurun_out/${TAG}_fused_tests.log ;;
+    rows_tests)
+      timeout 300 python -m pytest tests/test_gpu_fused_step.py -x -q -k "(bf16_gradients and (rows or cols32)) or tile_image or rollout_step_bf16" > gpurun_out/${TAG}_rows_tests.log 2>&1
+      echo "rc=$?"; tail -3 gpurun_out/${TAG}_rows_tests.log ;;
+    all_tests)
+      timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+      echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest_gpu.log ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    rows_probe)
+      timeout 300 python tools/fused_rows_probe.py > gpurun_out/${TAG}_rows_probe.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_probe.txt ;;
+    rows_probe_prof)
+      rm -rf gpurun_out/prof_rows
+      timeout 400 rocprofv3 --kernel-trace -d gpurun_out/prof_rows -o rows -- python tools/fused_rows_probe.py --iters 100 > gpurun_out/${TAG}_rows_probe_prof.log 2>&1
+      echo "rc=$?"; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_rows)" rlx --by-grid > gpurun_out/${TAG}_rows_probe_kernels.txt 2>&1
+      cat gpurun_out/${TAG}_rows_probe_kernels.txt; rm -rf gpurun_out/prof_rows ;;
+    share_prof)
+      for ROWS in 1 0; do for SH in 1 8; do
+        rm -rf gpurun_out/prof_share
+        RLX_FUSED_ROWS=$ROWS timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_share -o share -- python tools/per_rank_share.py --share $SH --steps 20 > gpurun_out/${TAG}_share${SH}_rows${ROWS}.log 2>&1
+        echo "rows=$ROWS share=$SH rc=$?"; grep "ms / iteration" gpurun_out/${TAG}_share${SH}_rows${ROWS}.log
+        python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_share)" rlx > gpurun_out/${TAG}_share${SH}_rows${ROWS}_kernels.txt 2>&1
+        head -9 gpurun_out/${TAG}_share${SH}_rows${ROWS}_kernels.txt; rm -rf gpurun_out/prof_share
+        RLX_FUSED_ROWS=$ROWS timeout 120 python tools/per_rank_share.py --share $SH --steps 50 2>/dev/null | grep "ms / iteration" | sed "s/^/untraced rows=$ROWS: /" | tee -a gpurun_out/${TAG}_share${SH}_rows${ROWS}.log
+      done; done ;;
+    bench)
+      timeout 600 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench.log | cut -c1-600 ;;
+    bench_quick)
+      timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_bench_quick.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_quick.log | cut -c1-400 ;;
+    bench_prof)
+      rm -rf gpurun_out/prof_bench
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-traffic --no-variants > gpurun_out/${TAG}_bench_prof.log 2>&1
+      echo "rc=$?"; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_bench)" > gpurun_out/${TAG}_bench_kernels.txt 2>&1; head -14 gpurun_out/${TAG}_bench_kernels.txt; rm -rf gpurun_out/prof_bench ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+done
