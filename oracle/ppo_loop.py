@@ -64,14 +64,14 @@ def rollout(policy: O.OracleMLPPolicy, env: dict, eps: torch.Tensor, gamma: floa
         r = env["rewards"][t * C:(t + 1) * C].transpose(0, 1).clone()           # [B, C]
         d = torch.zeros(B, C, dtype=torch.bool)
         d[:, -1] = env["dones"][t * C + 1:(t + 1) * C + 1].any(dim=0)
-        if auto_reset and bool(d.any()):
+        if auto_reset and bool(d.any()) and policy.add_value_head:  # value-free policy: get_bootstrap_values is None (huggingface_worker.py:617-620)
             with O.amp(autocast):
                 vf = policy.value_head.mlp(env["final_obs"][(t + 1) * C - 1]).detach()[:, :1].float()
             r = O.bootstrap_rewards(r, d, vf, gamma)
         rewards[t], dones[t + 1] = r, d
         obs = env["obs"][(t + 1) * C]
     with O.amp(autocast):
-        values[T] = policy.value_head.mlp(obs).detach()
+        values[T] = policy.value_head.mlp(obs).detach() if policy.add_value_head else 0.0  # (zeros: mlp_policy.py:283-286)
     return dict(rewards=rewards, dones=dones, prev_values=values, prev_logprobs=logp,
                 forward_inputs=dict(states=states, action=action))
 

@@ -349,9 +349,10 @@ class OracleMLPPolicy(nn.Module):
     """Same parameter names/shapes as the reference MLPPolicy (PPO configuration: state-independent
     log-std, no tanh squashing, value head 3x256 tanh with bias-free last layer)."""
 
-    def __init__(self, obs_dim=42, action_dim=8, num_action_chunks=1, hidden=256):
+    def __init__(self, obs_dim=42, action_dim=8, num_action_chunks=1, hidden=256, add_value_head=True):
         super().__init__()
         self.obs_dim, self.action_dim, self.num_action_chunks = obs_dim, action_dim, num_action_chunks
+        self.add_value_head = add_value_head  # False: mlp_policy.py:56-62 builds no value head (value-free PPO / GRPO)
 
         def ortho(layer, gain):
             nn.init.orthogonal_(layer.weight, gain)
@@ -360,18 +361,19 @@ class OracleMLPPolicy(nn.Module):
 
         # construction order == the reference's (value head first, mlp_policy.py:56-105), so
         # named_parameters() order and a shared torch seed line up tensor by tensor.
-        vh = nn.Module()
-        vh.mlp = nn.Sequential(
-            nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
-            nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, num_action_chunks, bias=False))
-        for m in vh.mlp:
-            if isinstance(m, nn.Linear):
-                if m is vh.mlp[-1]:
-                    nn.init.normal_(m.weight, mean=0.0, std=0.02)
-                else:
-                    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="tanh")
-                    nn.init.zeros_(m.bias)
-        self.value_head = vh
+        if add_value_head:
+            vh = nn.Module()
+            vh.mlp = nn.Sequential(
+                nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, num_action_chunks, bias=False))
+            for m in vh.mlp:
+                if isinstance(m, nn.Linear):
+                    if m is vh.mlp[-1]:
+                        nn.init.normal_(m.weight, mean=0.0, std=0.02)
+                    else:
+                        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="tanh")
+                        nn.init.zeros_(m.bias)
+            self.value_head = vh
         g = math.sqrt(2.0)
         self.backbone = nn.Sequential(
             ortho(nn.Linear(obs_dim, hidden), g), nn.Tanh(),
@@ -393,7 +395,7 @@ class OracleMLPPolicy(nn.Module):
         action = mean.clone() if mode == "eval" else eps * std + mean
         # torch.distributions.Normal.log_prob: -(x-mu)^2/(2 var) - log(scale) - log(sqrt(2 pi))
         logp = -((action - mean) ** 2) / (2 * std ** 2) - std.log() - LOG_SQRT_2PI
-        value = self.value_head.mlp(states)
+        value = self.value_head.mlp(states) if self.add_value_head else torch.zeros_like(logp[..., :1])  # mlp_policy.py:283-286
         return action, logp, value
 
     def evaluate(self, states, action):
@@ -402,6 +404,8 @@ class OracleMLPPolicy(nn.Module):
         std = torch.exp(logstd)
         logp = -((action - mean) ** 2) / (2 * std ** 2) - std.log() - LOG_SQRT_2PI
         ent = 0.5 + HALF_LOG_2PI + torch.log(std)
+        if not self.add_value_head:  # (the reference raises when asked for values, :230-235; its actor-only callers do not ask)
+            return dict(logprobs=logp, entropy=ent)
         return dict(logprobs=logp, entropy=ent, values=self.value_head.mlp(states))
 
 

@@ -132,12 +132,17 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
 // (read by every peer in the gather) and leaves one squared-norm partial per block next to it.
 __global__ __launch_bounds__(256) void reduce_scatter_kernel(ReduceSrc src, float* __restrict__ shard0, long long shard_stride,
                                                              double* __restrict__ parts0, int nparts, long long lo4, long long n4,
-                                                             float scale, int* __restrict__ state, PeerWait wait) {
+                                                             float scale, int* __restrict__ state, unsigned* __restrict__ seq_snapshot,
+                                                             PeerWait wait) {
     __shared__ double s_red[4];
     if (state != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && state[1] != 0) {
         state[0] += 1;  // the previous optimizer call applied its step: folded in strictly before this call's AdamW launch
         state[1] = 0;
     }
+    // The gather + AdamW launch behind this one INCREMENTS the sequence word at its end, so its own blocks must not read it (a
+    // block that runs late would see seq + 1: the other slot, a flag value nobody publishes).  They read this copy instead, which
+    // nothing writes while that launch runs.
+    if (seq_snapshot != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *seq_snapshot = *src.seq;
     peer_handshake(wait);
     const unsigned slot = (*src.seq + 1u) & 1u;
     const size_t off = (size_t)slot * (size_t)src.slot_stride;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
                                                          const AdamScalars* __restrict__ scalars,
                                                          float* __restrict__ stats, int* __restrict__ state,
                                                          rlx_mlp_layout lay, float* __restrict__ tiles, unsigned* __restrict__ seq_inc,
-                                                         const int* __restrict__ status, GatherSrc gsrc, PeerWait wait) {
+                                                         const int* status, GatherSrc gsrc, PeerWait wait) {
     __shared__ double s_red[4];
     __shared__ float s_coef;
     __shared__ int s_skip;
@@ -344,7 +349,8 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
         s_coef = coef;
         // a peer wait of this step's all-reduce timed out: the sums are garbage -- never apply them (the host raises)
-        s_skip = !isfinite(total_norm) || (status != nullptr && *status != 0);
+        // (`status` is the word peer_poll sets on a timeout, possibly in THIS launch: no restrict / readonly promise, a fresh load)
+        s_skip = !isfinite(total_norm) || (status != nullptr && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
         if (blockIdx.x == 0) {
             stats[0] = total_norm;
             stats[1] = s_skip ? 0.f : 1.f;
@@ -498,11 +504,12 @@ int rsag_parts(long long shard_n4) {
 }
 
 int launch_reduce_scatter(const ReduceSrc& src, float* shard0, long long shard_stride, double* parts0, long long shard_lo4,
-                          long long shard_n4, int nparts, float scale, int32_t* step_state, const PeerWait* wait, hipStream_t s) {
+                          long long shard_n4, int nparts, float scale, int32_t* step_state, unsigned* seq_snapshot, const PeerWait* wait,
+                          hipStream_t s) {
     PeerWait w{};
     if (wait != nullptr) w = *wait;
     hipLaunchKernelGGL(reduce_scatter_kernel, dim3(nparts), dim3(256), 0, s, src, shard0, shard_stride, parts0, nparts, shard_lo4,
-                       shard_n4, scale, step_state, w);
+                       shard_n4, scale, step_state, seq_snapshot, w);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -102,10 +102,11 @@ int launch_peer_wait(const PeerWait& wait, hipStream_t stream);
 // reduce-scatter: this rank's shard of the sum of every rank's staged gradient -> its shard area + norm partials
 // (shard0 / parts0: slot 0 of the areas; the kernel picks the slot from the device-side sequence number)
 int launch_reduce_scatter(const ReduceSrc& src, float* shard0, long long shard_stride, double* parts0, long long shard_lo4,
-                          long long shard_n4, int nparts, float scale, int32_t* step_state, const PeerWait* wait,
-                          hipStream_t stream);
+                          long long shard_n4, int nparts, float scale, int32_t* step_state, unsigned* seq_snapshot,
+                          const PeerWait* wait, hipStream_t stream);  // seq_snapshot: device word that receives *src.seq (see the kernel), or nullptr
 // clip + AdamW with the reduced gradient gathered from every rank's shard area (all-gather fused into the update); `out`
-// receives the clipped gradient like the local form
+// receives the clipped gradient like the local form.  The launch increments *seq_inc, so src.seq / wait->seq must NOT point at that
+// word: pass the snapshot the reduce-scatter launch left.
 int launch_gather_clip_adamw(float* params, const GatherSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
                              const rlx_adamw_params* p, float* stats, int32_t* step_state, const PeerWait* wait, unsigned* seq_inc,
                              const int* status, hipStream_t stream);

@@ -314,7 +314,7 @@ inline int head_stride_of(const rlx_mlp_layout* lay) {
 
 struct StepPlan {
     int tiles;        // row tiles of the fused kernel (its grid)
-    int loss_slots;   // metric partial slots per network (one per tile; the row-split bf16 launch: one per 16-row wave)
+    int loss_slots;   // metric partial slots per network (one per tile)
     int head_parts;   // head-gradient partial slots per network (one per 32 rows; the row-split bf16 launch: one per 64-row tile)
     int slabs, rows_per_slab, head_stride;
     size_t off_h, off_dz, off_head, off_loss, off_tiles, off_st, bytes;
@@ -336,7 +336,7 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     const int bm = (bf16 && rows) ? 64 : bf16 ? fused_bm_bf16() : STEP_BM;
     pl.tiles = ceil_div(m, bm);
     pl.head_parts = (bf16 && rows) ? pl.tiles : pl.tiles * (bm / 32);
-    pl.loss_slots = (bf16 && rows) ? pl.tiles * 4 : pl.tiles;
+    pl.loss_slots = pl.tiles;
     // 20 GEMM items per slab.  Every slab is 1.15 MB written here and read back by the slab reduce through the memory side:
     // measured (round 2, after the head-reduce tail fix) 16 slabs = 1.25 workgroups per CU is the best trade -- weight-gradient
     // launch 16.2 us + slab reduce 9.1 us, against 15.8 + 10.4 us with 24 slabs (2 per CU, no second round)

@@ -36,6 +36,7 @@ struct rlx_xgmi_comm {
     char* base_local;                      // own buffer
     char* base_peer[RLX_XGMI_MAX_RANKS];   // mapped peers (own slot = base_local)
     unsigned* seq;                         // device word (plain memory): all-reduces completed
+    unsigned* seq_snapshot;                // device word: copy of *seq taken by the reduce-scatter launch for the gather + AdamW launch
     int* status;                           // device word: timeout flag
     bool connected, local_peers;           // local_peers: same-process emulation, nothing to unmap
 };
@@ -194,6 +195,7 @@ extern "C" int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_m
     if (e == hipSuccess) {
         c->seq = static_cast<unsigned*>(words);
         c->status = reinterpret_cast<int*>(static_cast<char*>(words) + 128);
+        c->seq_snapshot = reinterpret_cast<unsigned*>(static_cast<char*>(words) + 64);
         what = "hipMemset";
         e = hipMemset(words, 0, 256);
     }
@@ -287,7 +289,7 @@ extern "C" int rlx_xgmi_allreduce_f32(rlx_xgmi_comm* c, const float* in, int sla
     if (!use_rsag(c, n)) return launch_reduce_only(src, out, n, scale, workspace, workspace_bytes, &w, c->seq, st);
     const ShardPlan p = plan_shards(c, n);
     if (int rc = launch_reduce_scatter(src, shard_ptr(c->base_local, c->n_max), c->n_max, parts_ptr(c->base_local, c->n_max), p.lo4,
-                                       p.cnt4, p.nparts, scale, nullptr, &w, st))
+                                       p.cnt4, p.nparts, scale, nullptr, nullptr, &w, st))
         return rc;
     GatherSrc g{};
     fill_gather_src(c, p, g);
@@ -313,11 +315,14 @@ extern "C" int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* c, float* params, const f
                                         &w, c->seq, c->status, st);
     const ShardPlan sp = plan_shards(c, n);
     if (int rc = launch_reduce_scatter(src, shard_ptr(c->base_local, c->n_max), c->n_max, parts_ptr(c->base_local, c->n_max), sp.lo4,
-                                       sp.cnt4, sp.nparts, p->grad_scale, step_state, &w, st))
+                                       sp.cnt4, sp.nparts, p->grad_scale, step_state, c->seq_snapshot, &w, st))
         return rc;
     GatherSrc g{};
     fill_gather_src(c, sp, g);
     PeerWait w1{};
     if (int rc = handshake(c, 1, w1, st)) return rc;
+    // the gather + AdamW launch increments c->seq itself: its blocks read the reduce-scatter launch's snapshot instead
+    g.seq = c->seq_snapshot;
+    w1.seq = c->seq_snapshot;
     return launch_gather_clip_adamw(params, g, grad_flat, exp_avg, exp_avg_sq, n, p, stats, step_state, &w1, c->seq, c->status, st);
 }

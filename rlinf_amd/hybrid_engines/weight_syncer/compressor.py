@@ -5,9 +5,12 @@ rlinf/hybrid_engines/weight_syncer/compressor.py: ``PatchCompressor.create`` :70
 Same surface -- ``create(compression_algorithm, transport_device)``, ``compress(WeightPatch) -> transport payload``,
 ``decompress(payload) -> WeightPatch``, the same CompressedWeightPatch fields and the same dtype-code table -- with the codec
 itself written for gfx950: ``ZPlaneCompressor`` (csrc/zplane_codec.hip, byte planes + two-level zero masks by wavefront ballot).
-nvCOMP, the reference's only codec, is NVIDIA-only and its container is not a public format, so the payload BYTES differ from
-an nvCOMP stream; sender and receiver of a deployment both run this package, and the reference's algorithm name
-(``nvcomp_lz4``) is accepted as an alias so that a configuration written for the reference keeps working unchanged.
+nvCOMP, the reference's only codec, is NVIDIA-only and its container is not a public format: the payload BYTES of
+``rlx_zplane`` differ from an nvCOMP stream and a reference peer cannot decode them.  The codec therefore answers to its OWN
+name only.  The reference's name ``nvcomp_lz4`` is REFUSED with an error that says so (round 3 accepted it as a silent alias,
+which hid the incompatible wire format): a deployment whose sender and receiver both run this package chooses ``rlx_zplane``
+explicitly -- or sets ``RLX_NVCOMP_LZ4_AS_ZPLANE=1`` to keep a reference configuration file unchanged, with a loud warning --
+and a deployment that shares patches with reference peers uses ``none``, the only byte-compatible transport.
 """
 
 from __future__ import annotations
@@ -25,8 +28,8 @@ from ...ops import _stream_ptr
 DTYPE_TO_CODE = {torch.uint8: 0, torch.int16: 1, torch.int32: 2, torch.int64: 3, torch.float16: 4, torch.bfloat16: 5,
                  torch.float32: 6, torch.float64: 7}
 CODE_TO_DTYPE = {code: dtype for dtype, code in DTYPE_TO_CODE.items()}
-# algorithm names served by the gfx950 codec: its own name, and the reference's name for "the GPU codec"
-ZPLANE_ALGORITHMS = ("rlx_zplane", "nvcomp_lz4")
+ZPLANE_ALGORITHMS = ("rlx_zplane",)   # the gfx950 codec answers to its own name only
+NVCOMP_ALGORITHMS = ("nvcomp_lz4",)    # rlinf/hybrid_engines/weight_syncer/compressor.py:30-32: a wire format this build cannot produce
 
 
 class PatchCompressor(ABC):
@@ -45,6 +48,18 @@ class PatchCompressor(ABC):
             return IdentityCompressor(transport_device=transport_device)
         if compression_algorithm in ZPLANE_ALGORITHMS:
             return ZPlaneCompressor(compression_algorithm=compression_algorithm, transport_device=transport_device)
+        if compression_algorithm in NVCOMP_ALGORITHMS:
+            import os
+            import warnings
+            if os.environ.get("RLX_NVCOMP_LZ4_AS_ZPLANE", "0") not in ("", "0"):
+                warnings.warn(f"compression_algorithm={compression_algorithm}: nvCOMP is NVIDIA-only; sending 'rlx_zplane' streams instead "
+                              "(RLX_NVCOMP_LZ4_AS_ZPLANE=1).  A reference (nvCOMP) peer CANNOT decode them: both ends must run rlinf_amd.",
+                              stacklevel=2)
+                return ZPlaneCompressor(compression_algorithm="rlx_zplane", transport_device=transport_device)
+            raise ValueError(f"compression_algorithm={compression_algorithm!r} names the reference's nvCOMP LZ4 container, which this "
+                             "gfx950 build cannot produce or read.  Use 'rlx_zplane' when sender and receiver both run rlinf_amd (its own "
+                             "wire format), or 'none' for patches shared with reference peers; RLX_NVCOMP_LZ4_AS_ZPLANE=1 maps the name "
+                             "to 'rlx_zplane' for configuration files that must stay unchanged.")
         # compressor.py:92-98: an unknown name is ignored with a warning, the flat tensors travel as they are
         import warnings
         warnings.warn("PatchWeightSyncer uses flat tensor transport; "
@@ -72,6 +87,7 @@ class ZPlaneCompressor(PatchCompressor):
         if self.transport_device is not None and self.transport_device.type != "cuda":
             raise ValueError(f"{compression_algorithm} compression requires transport_device to be the accelerator")
         self._lib = _lib.load()
+        self._pending_status = []  # device status words of the decompress launches of the current payload
 
     # ---- one stream ---------------------------------------------------------------------------------------------------
     def _launch_compress(self, tensor: torch.Tensor):
@@ -96,6 +112,8 @@ class ZPlaneCompressor(PatchCompressor):
             return torch.empty(0, dtype=dtype, device=stream.device)
         if not stream.is_cuda:
             raise RlxError("patch decompression runs on the accelerator (no CPU fallback)")
+        if stream.numel() < 24:  # shorter than the "RLXZ" header: the C side would read 24 bytes out of a shorter buffer
+            raise RlxError(f"compressed patch field is truncated: {stream.numel()} bytes, the stream header alone is 24")
         stream = stream.contiguous()
         if stream.data_ptr() % 8:
             stream = stream.clone()

@@ -1,5 +1,5 @@
 """MLPPolicy on HIP kernels -- same constructor, method names and return structures as the reference's
-rlinf/models/embodiment/mlp_policy/mlp_policy.py (PPO configuration: value head, no Q head).
+rlinf/models/embodiment/mlp_policy/mlp_policy.py (the PPO / GRPO configurations: with or without a value head, no Q head).
 
 All parameters live in ONE flat f32 buffer (``self.flat``) laid out in the reference's
 ``named_parameters()`` order, so (a) ``state_dict`` round-trips with the reference's names and shapes,
@@ -70,17 +70,32 @@ class MLPPolicy(nn.Module):
         if compute_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"compute_dtype must be float32 or bfloat16, got {compute_dtype}")
         self.compute_dtype = compute_dtype
-        if add_q_head or not add_value_head:
-            raise NotImplementedError("only the PPO configuration (value head, no Q head) is on the hot path")
+        if add_q_head:
+            raise NotImplementedError("the Q-head (SAC) variant of the MLP policy is outside the PPO / GRPO hot path")
+        # add_value_head False (mlp_policy.py:42-66: the value-free policy of actor-only PPO / GRPO configurations): the reference
+        # builds no value head, predict_action_batch returns zeros as prev_values (:283-286) and default_forward(compute_values=True)
+        # raises (:230-235).  The fused launches are built around the (value net, policy net) pair, so the flat buffer keeps a
+        # PHANTOM value net behind the real parameters: all zeros (its outputs are exactly 0: tanh(0) = 0 through every layer),
+        # absent from shapes / state_dict / named_views / the optimizer's groups, never trained (an actor-only loss gives it zero
+        # gradients and AdamW holds no range over it).
+        self.has_value_head = bool(add_value_head)
         self.obs_dim, self.action_dim, self.num_action_chunks = int(obs_dim), int(action_dim), int(num_action_chunks)
         self.value_granularity = value_granularity
         self.value_dim = 1 if value_granularity == "chunk_level" else self.num_action_chunks
         self.independent_std, self.final_tanh, self.action_scale = True, False, None
-        self.shapes = _reference_shapes(self.obs_dim, self.action_dim, self.num_action_chunks, self.value_dim)
+        full = _reference_shapes(self.obs_dim, self.action_dim, self.num_action_chunks, self.value_dim)
+        self.shapes = OrderedDict((k, v) for k, v in full.items() if self.has_value_head or not k.startswith("value_head."))
         self.offsets, off = OrderedDict(), 0
         for name, shp in self.shapes.items():
             self.offsets[name] = off
             off += math.prod(shp)
+        self.n_exposed = off  # elements the reference's named_parameters() would hold
+        self._phantom_offsets = OrderedDict()
+        for name, shp in full.items():
+            if name not in self.shapes:
+                off = (off + 3) // 4 * 4  # (the kernels want 16-byte aligned weight matrices)
+                self._phantom_offsets[name] = off
+                off += math.prod(shp)
         self.n_params = off
         self.flat = nn.Parameter(torch.empty(self.n_params, dtype=torch.float32))
         self.layout = self._make_layout()
@@ -96,10 +111,11 @@ class MLPPolicy(nn.Module):
         lay.off_logstd = self.offsets["actor_logstd"]
         nets = (("value_head.mlp.0", "value_head.mlp.2", "value_head.mlp.4", "value_head.mlp.6"),
                 ("backbone.0", "backbone.2", "backbone.4", "actor_mean"))
+        where = {**self.offsets, **self._phantom_offsets}
         for y, names in enumerate(nets):
             for l, nm in enumerate(names):
-                lay.off_w[y][l] = self.offsets[nm + ".weight"]
-                lay.off_b[y][l] = self.offsets.get(nm + ".bias", -1)
+                lay.off_w[y][l] = where[nm + ".weight"]
+                lay.off_b[y][l] = where.get(nm + ".bias", -1)
         return lay
 
     def view(self, name: str) -> torch.Tensor:
@@ -131,8 +147,9 @@ class MLPPolicy(nn.Module):
         ValueHead kaiming-normal(fan_out, tanh)/N(0, 0.02) (value_head.py:52-64), orthogonal(sqrt 2) backbone,
         orthogonal(0.01 sqrt 2) actor_mean, logstd = -0.5 (mlp_policy.py:91-105, modules/utils.py:20-23)."""
         D, act = self.obs_dim, self.num_action_chunks * self.action_dim
+        self.flat.data.zero_()  # (the phantom value net of a value-free policy stays zero)
         vh = [nn.Linear(D, HIDDEN), nn.Linear(HIDDEN, HIDDEN), nn.Linear(HIDDEN, HIDDEN),
-              nn.Linear(HIDDEN, self.value_dim, bias=False)]
+              nn.Linear(HIDDEN, self.value_dim, bias=False)] if self.has_value_head else []  # (not built: no RNG draws either)
         for i, m in enumerate(vh):
             if i == 3:
                 nn.init.normal_(m.weight, mean=0.0, std=0.02)
@@ -191,7 +208,10 @@ class MLPPolicy(nn.Module):
         """Accepts the reference's key set (or the single-key {'flat': ...} form older checkpoints of this package used)."""
         if set(state_dict.keys()) == {"flat"}:
             with torch.no_grad():
-                self.flat.data.copy_(state_dict["flat"].to(self.flat.device, torch.float32).reshape(-1))
+                src = state_dict["flat"].to(self.flat.device, torch.float32).reshape(-1)
+                if src.numel() not in (self.n_params, self.n_exposed):
+                    raise RuntimeError(f"size mismatch for flat: {src.numel()} elements, this policy holds {self.n_exposed}")
+                self.flat.data[:src.numel()].copy_(src)
             self.mark_updated()
             return torch.nn.modules.module._IncompatibleKeys([], [])
         if not strict:
@@ -236,6 +256,8 @@ class MLPPolicy(nn.Module):
         states = forward_inputs["states"].to(self.flat.device, torch.float32).contiguous()
         action = forward_inputs["action"].to(self.flat.device, torch.float32).contiguous()
         action = action.reshape(states.shape[0], -1)
+        if compute_values and not self.has_value_head:
+            raise NotImplementedError  # mlp_policy.py:230-235
         logprob, entropy, value = _MlpTrainFn.apply(self.flat, self, states, action)
         out = {}
         if compute_logprobs:
@@ -261,8 +283,8 @@ class MLPPolicy(nn.Module):
         else:
             raise NotImplementedError(f"{mode=}")
         action, logprob, value = ops.mlp_rollout_step(self.flat.data, self.tiles(), self.layout, states, eps)
-        if not calculate_values:
-            value = torch.zeros_like(logprob[..., :1])
+        if not calculate_values or not self.has_value_head:
+            value = torch.zeros_like(logprob[..., :1])  # mlp_policy.py:283-286
         chunk_actions = action.reshape(-1, self.num_action_chunks, self.action_dim)
         forward_inputs = {"action": action, "model_action": action}
         if return_obs:

@@ -257,6 +257,35 @@ class LocalXgmiGroup:
         for r in range(self.world):
             cur.wait_stream(self.streams[r])
 
+    def clip_adamw_step(self, params, grads, grad_flat, exp_avg, exp_avg_sq, groups, stats, step_state, *, betas=(0.9, 0.999),
+                        eps: float = 1e-8, weight_decay: float = 0.01, max_grad_norm: float = 0.5):
+        """rlx_xgmi_clip_adamw_step on every "rank" (rank r: params[r], its slabs grads[r] [slabs, n], ...), each on its own
+        stream: stage + exchange (the group's form: direct, or reduce-scatter + the gather fused into the AdamW launch) + clip +
+        AdamW with the gradient mean.  Returns after enqueueing."""
+        from ..ops import AdamwGroup, AdamwParams  # (ops imports nothing from here)
+        cur = torch.cuda.current_stream(self.device)
+        for r in range(self.world):
+            self.streams[r].wait_stream(cur)
+        keep = []
+        for r in range(self.world):
+            n = params[r].numel()
+            p = AdamwParams()
+            p.beta1, p.beta2, p.eps, p.weight_decay = float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+            p.max_grad_norm, p.step, p.n_groups = float(max_grad_norm), 0, len(groups)
+            p.grad_partials, p.grad_scale = grads[r].numel() // n, 1.0 / self.world
+            for k, (b, e, lr) in enumerate(groups):
+                p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
+            keep.append(p)
+            with torch.cuda.stream(self.streams[r]):
+                _lib.check(self._lib.rlx_xgmi_clip_adamw_step(self.comms[r], params[r].data_ptr(), grads[r].data_ptr(),
+                                                              grad_flat[r].data_ptr(), exp_avg[r].data_ptr(), exp_avg_sq[r].data_ptr(),
+                                                              n, ctypes.byref(p), stats[r].data_ptr(), step_state[r].data_ptr(),
+                                                              self._ws[r].data_ptr(), self._ws[r].numel(),
+                                                              self.streams[r].cuda_stream), "rlx_xgmi_clip_adamw_step")
+        for r in range(self.world):
+            cur.wait_stream(self.streams[r])
+        return keep
+
     def status_ok(self) -> bool:
         with torch.cuda.device(self.device):
             return all(self._lib.rlx_xgmi_status(c) == 0 for c in self.comms)

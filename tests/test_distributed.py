@@ -138,6 +138,56 @@ print("OK")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,algo", [(2, "direct"), (4, "rsag"), (8, "rsag")])
+def test_xgmi_clip_adamw_step_in_process_group(world, algo):
+    """The optimizer entry point over the exchange, W "ranks" of one process on one device, several steps in a row: the
+    reduce-scatter + all-gather form runs the gather INSIDE the AdamW launch, which also advances the exchange's sequence word --
+    its blocks must read the snapshot the reduce-scatter launch left, never the word being incremented (a late block would read the
+    other staging slot or wait for a flag nobody publishes).  Every rank must end every step with bit-identical parameters and
+    moments, equal to plain clip + AdamW on the gradient mean."""
+    code = f"""
+import sys, torch
+sys.path.insert(0, {ROOT!r})
+from rlinf_amd import ops
+from rlinf_amd.scheduler.xgmi import LocalXgmiGroup
+W, algo = {world}, {algo!r}
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(11)
+n = 287504
+groups = [(0, n // 2, 3e-4), (n // 2, n, 1e-3)]
+streams = [torch.cuda.Stream(dev) for _ in range(W)]
+grp = LocalXgmiGroup(W, n, dev, algo=algo, timeout_ms=15000, streams=streams)
+p0 = torch.randn(n, device=dev, generator=g) * 0.1
+params = [p0.clone() for _ in range(W)]
+m = [torch.zeros(n, device=dev) for _ in range(W)]
+v = [torch.zeros(n, device=dev) for _ in range(W)]
+flat = [torch.empty(n, device=dev) for _ in range(W)]
+stats = [torch.zeros(2, device=dev) for _ in range(W)]
+state = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(W)]
+ref_p, ref_m, ref_v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+for it in range(6):
+    slabs = [torch.randn(1 + (r + it) % 3, n, device=dev, generator=g) * (5.0 if it % 2 else 0.01) for r in range(W)]
+    keep = grp.clip_adamw_step(params, slabs, flat, m, v, groups, stats, state)
+    torch.cuda.synchronize()
+    assert grp.status_ok(), f"it={{it}}: a peer wait timed out"
+    for r in range(1, W):
+        assert torch.equal(params[r], params[0]) and torch.equal(m[r], m[0]) and torch.equal(v[r], v[0]), f"it={{it}}: rank {{r}} diverged"
+        assert torch.equal(flat[r], flat[0]) and torch.equal(stats[r], stats[0])
+    mean = (sum(x.double().sum(0) for x in slabs) / W).float()
+    ops.clip_adamw_step_(ref_p, mean.clone(), ref_m, ref_v, groups, it + 1, max_grad_norm=0.5)
+    # (the reference adds the ranks' slabs in another order: AdamW's m / sqrt(v) amplifies the last-bit differences of tiny gradients)
+    torch.testing.assert_close(params[0], ref_p, rtol=2e-3, atol=2e-5)
+    assert float(stats[0][1]) == 1.0
+    assert all(int(s[0]) + int(s[1]) == it + 1 for s in state)
+grp.close()
+print("OK")
+"""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("transport,graph,backend", [
     ("rccl", "0", "gloo"),   # torch.distributed all-reduce (gloo stands in for RCCL: it needs a device per rank)
     ("rccl", "1", "gloo"),   # a gloo all-reduce cannot be stream-captured: the worker keeps the eager (prepared-launch) loop

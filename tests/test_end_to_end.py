@@ -542,6 +542,56 @@ def test_example_entry_point_runs_the_shipped_config(precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hip_graph,precision", [(False, "32"), (True, "32"), (True, "bf16")])
+def test_value_free_grpo_whole_loop_matches_oracle(hip_graph, precision):
+    """actor.model.add_value_head False (mlp_policy.py:42-66: the value-free MLP policy of the reference's GRPO / actor-only PPO
+    configurations): the policy exposes the reference's parameter set without a value head, prev_values are zeros, nothing is
+    bootstrapped, and rollout -> GRPO advantages -> actor loss -> clip + AdamW match oracle.ppo_loop.iteration run on the
+    reference-shaped value-free oracle policy (pinned to the reference's own MLPPolicy(add_value_head=False) in
+    test_oracle_vs_reference.py) on identical seeds, weights, injected noise and shuffle order."""
+    B, T, GB, group = 32, 12, 96, 4
+    bf16 = precision == "bf16"
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, auto_reset=False, hip_graph=hip_graph, done_mode="bernoulli")
+    cfg.actor.model.add_value_head = False
+    cfg.actor.model.precision = precision
+    alg = cfg.algorithm
+    alg.adv_type, alg.loss_type, alg.group_size = "grpo", "actor", group
+    cfg.env.train.group_size = group
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5, mode="bernoulli", p_done=0.05)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, 8, 1, add_value_head=False)
+    sd = copy.deepcopy(ora.state_dict())
+    opt = O.build_adamw(ora)
+    runner = _build(cfg, env, sd)
+    w = runner.actor.worker
+    assert not w.model.has_value_head and list(w.model.state_dict()) == list(sd)
+    for it in range(3 if hip_graph else 2):
+        eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
+        batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234, global_batch=GB, update_epoch=2,
+                                auto_reset=False, max_episode_steps=5, adv_type="grpo", loss_type="actor", group_size=group, autocast=bf16)
+        metrics = runner.run_step(eps.cuda())
+        rb = w.rollout_batch
+        tol = dict(rtol=3e-2, atol=3e-2) if bf16 else (dict(rtol=2e-4, atol=2e-5) if it == 0 else dict(rtol=5e-3, atol=5e-4))
+        torch.testing.assert_close(rb["forward_inputs"]["action"].cpu(), batch["forward_inputs"]["action"], **tol)
+        torch.testing.assert_close(rb["prev_logprobs"].cpu(), batch["prev_logprobs"], **(tol if not bf16 else dict(rtol=5e-2, atol=5e-2)))
+        assert not rb["prev_values"].any() and not batch["prev_values"].any()        # zeros on both sides
+        assert torch.equal(rb["rewards"].cpu(), batch["rewards"])                       # nothing bootstrapped
+        assert torch.equal(rb["loss_mask"].cpu(), batch["loss_mask"])
+        if not bf16:
+            torch.testing.assert_close(rb["advantages"].cpu(), batch["advantages"], rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+            for k in ("actor/total_loss", "actor/grad_norm", "actor/policy_loss", "actor/approx_kl"):
+                want_k = sum(float(m[k]) for m in om) / len(om)
+                assert metrics["train/" + k] == pytest.approx(want_k, rel=5e-3, abs=5e-5), k
+        assert "train/critic/value_loss" not in metrics
+        got = w.model.flat.detach().cpu()
+        want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+        diff = (got[:w.model.n_exposed] - want).abs()
+        assert float(diff.max()) <= 2 * 3e-4 * len(om) * (it + 1) + 1e-6
+        assert not got[w.model.n_exposed:].any()                                        # the phantom value net stays zero
+    runner.close() if hasattr(runner, "close") else None
+
+
+@pytest.mark.gpu
 def test_embodied_grpo_iteration():
     """adv_type grpo + loss_type actor on the MLP policy (the reference's libero_spatial_0_grpo_mlp.yaml pairing): the
     advantages match the oracle's GRPO on the rollout the runner produced, the actor trains, and the value head -- whose

@@ -215,6 +215,30 @@ def test_policy_param_names_and_init_distribution(ref):
         _eq(p.detach(), q.detach())
 
 
+def test_value_free_policy_matches_the_reference(ref):
+    """add_value_head False (mlp_policy.py:56-62, :283-286): no value-head parameters, the same init stream for the rest, zeros as
+    prev_values."""
+    torch.manual_seed(5)
+    theirs = ref.mlp_policy.MLPPolicy(42, 8, 1, False, False)
+    torch.manual_seed(5)
+    ours = O.OracleMLPPolicy(42, 8, 1, add_value_head=False)
+    assert [n for n, _ in theirs.named_parameters()] == [n for n, _ in ours.named_parameters()]
+    assert not any("value_head" in n for n, _ in ours.named_parameters())
+    for (n, p), (m, q) in zip(theirs.named_parameters(), ours.named_parameters()):
+        _eq(p.detach(), q.detach())
+    states = torch.randn(16, 42, generator=torch.Generator().manual_seed(3))
+    torch.manual_seed(7)
+    acts0, res0 = theirs.predict_action_batch({"states": states}, mode="train")
+    torch.manual_seed(7)
+    a1, lp1, v1 = ours.act(states, eps=torch.randn(16, 8), mode="train")
+    _eq(acts0.reshape(16, 8), a1)
+    _eq(res0["prev_logprobs"], lp1)
+    _eq(res0["prev_values"], v1)
+    assert v1.shape == (16, 1) and not v1.any()
+    with pytest.raises(NotImplementedError):
+        theirs.default_forward({"states": states, "action": a1})
+
+
 def test_policy_rollout_with_injected_noise(ref):
     theirs, ours = _paired_policies(ref)
     g = torch.Generator().manual_seed(11)

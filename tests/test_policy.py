@@ -40,6 +40,29 @@ def test_init_stream_names_and_layout_match_reference():
         pol.load_reference_state_dict({k: v for k, v in sd.items() if k != "actor_mean.bias"})
 
 
+def test_value_free_policy_exposes_the_reference_parameter_set():
+    """add_value_head False: the reference's names / shapes / init stream without the value head (pinned to the reference itself in
+    test_oracle_vs_reference.py), a phantom all-zero value net behind them for the kernels, untouched by the optimizer's groups."""
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(5)
+    ora = O.OracleMLPPolicy(42, 8, 1, add_value_head=False)
+    torch.manual_seed(5)
+    pol = MLPPolicy(42, 8, 1, False, False)
+    assert list(pol.shapes) == [n for n, _ in ora.named_parameters()] and list(pol.state_dict()) == list(pol.shapes)
+    for n, p in ora.named_parameters():
+        assert torch.equal(pol.view(n), p.detach()), n
+    assert pol.n_exposed == sum(p.numel() for p in ora.parameters()) == 144656 and pol.n_params > pol.n_exposed
+    assert not pol.flat.detach()[pol.n_exposed:].any()                      # the phantom value net is all zeros
+    lay = pol.layout
+    assert all(lay.off_w[0][l] >= pol.n_exposed and lay.off_w[0][l] % 4 == 0 for l in range(4)) and lay.off_b[0][3] == -1
+    assert pol.group_ranges(3e-4, 1e-3, train_value_head=False) == [(0, pol.n_exposed, 3e-4)]
+    pol.load_state_dict(ora.state_dict())                                      # the reference's key set round-trips
+    with pytest.raises(NotImplementedError):
+        pol.default_forward({"states": torch.zeros(2, 42), "action": torch.zeros(2, 8)})
+    with pytest.raises(NotImplementedError):
+        MLPPolicy(42, 8, 1, False, True)                                       # the Q head (SAC) stays out of scope
+
+
 def test_model_registry_boundary():
     from rlinf_amd import models
     m = models.get_model(dict(model_type="mlp_policy", obs_dim=42, action_dim=8, num_action_chunks=1,

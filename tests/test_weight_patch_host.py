@@ -97,14 +97,20 @@ def test_known_answers_of_the_reference_unit_tests():
     assert downscale_nonnegative_indices(torch.tensor([0, torch.iinfo(torch.int32).max + 1])).dtype == torch.int64
 
 
-def test_syncer_argument_checks():
+def test_syncer_argument_checks(monkeypatch):
     from rlinf_amd.hybrid_engines.weight_syncer import CPUSnapshotPatchBuilder, IdentityCompressor, PatchCompressor, ZPlaneCompressor
     from rlinf_amd.hybrid_engines.weight_syncer.patch_syncer import create_patch_builder
-    # PatchCompressor.create (compressor.py:70-98): "none", the GPU codec under its own name and under the reference's name for
-    # "the GPU codec", an unknown name ignored with a warning
+    # PatchCompressor.create (compressor.py:70-98): "none", the GPU codec under its OWN name, an unknown name ignored with a warning;
+    # the reference's nvCOMP name is refused (its container is a wire format this build cannot produce) unless the caller opts in
     assert isinstance(PatchWeightSyncer(compression_algorithm="none").compressor, IdentityCompressor)
-    for name in ("rlx_zplane", "nvcomp_lz4"):
-        assert isinstance(PatchWeightSyncer(compression_algorithm=name).compressor, ZPlaneCompressor)
+    assert isinstance(PatchWeightSyncer(compression_algorithm="rlx_zplane").compressor, ZPlaneCompressor)
+    with pytest.raises(ValueError, match="nvCOMP LZ4 container"):
+        PatchWeightSyncer(compression_algorithm="nvcomp_lz4")
+    monkeypatch.setenv("RLX_NVCOMP_LZ4_AS_ZPLANE", "1")
+    with pytest.warns(UserWarning, match="CANNOT decode"):
+        c = PatchCompressor.create("nvcomp_lz4", "cuda")
+    assert isinstance(c, ZPlaneCompressor) and c.compression_algorithm == "rlx_zplane"
+    monkeypatch.delenv("RLX_NVCOMP_LZ4_AS_ZPLANE")
     with pytest.warns(UserWarning, match="is ignored for now"):
         assert isinstance(PatchCompressor.create("zstd", "cuda"), IdentityCompressor)
     with pytest.raises(ValueError, match="requires transport_device to be the accelerator"):

@@ -16,6 +16,12 @@ for STEP in "$@"; do
     rows_tests)
       timeout 300 python -m pytest tests/test_gpu_fused_step.py -x -q -k "(bf16_gradients and (rows or cols32)) or tile_image or rollout_step_bf16" > gpurun_out/${TAG}_rows_tests.log 2>&1
       echo "rc=$?"; tail -3 gpurun_out/${TAG}_rows_tests.log ;;
+    xgmi_tests)
+      timeout 600 python -m pytest tests/test_distributed.py -x -q -m gpu -k "in_process_group" > gpurun_out/${TAG}_xgmi_tests.log 2>&1
+      echo "rc=$?"; tail -4 gpurun_out/${TAG}_xgmi_tests.log ;;
+    valuefree_tests)
+      timeout 600 python -m pytest tests/test_end_to_end.py -x -q -m gpu -k "value_free or embodied_grpo" > gpurun_out/${TAG}_valuefree_tests.log 2>&1
+      echo "rc=$?"; tail -15 gpurun_out/${TAG}_valuefree_tests.log | cut -c1-300 ;;
     all_tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1
       echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest_gpu.log ;;
@@ -41,6 +47,11 @@ for STEP in "$@"; do
       timeout 600 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench.log | cut -c1-600 ;;
     bench_quick)
       timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_bench_quick.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_quick.log | cut -c1-400 ;;
+    bench_ab)
+      for ROWS in 0 1 0 1; do
+        RLX_FUSED_ROWS=$ROWS timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_bench_rows${ROWS}.log 2>&1
+        echo "rows=$ROWS rc=$? $(tail -1 gpurun_out/${TAG}_bench_rows${ROWS}.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"
+      done ;;
     bench_prof)
       rm -rf gpurun_out/prof_bench
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-traffic --no-variants > gpurun_out/${TAG}_bench_prof.log 2>&1
