@@ -263,6 +263,7 @@ __device__ __forceinline__ void head_forward_mfma(const __bf16* Xb, const float*
 template <int RT>  // 16 RT rows per workgroup
 __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
     constexpr int NW = 8;
+    touch_kernargs<(int)sizeof(RolloutArgs)>();
     typedef GeoB<RT, NW> G;
     extern __shared__ __align__(16) float smem[];
     __bf16* Xb = reinterpret_cast<__bf16*>(smem);
@@ -1045,6 +1046,230 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradients, RING variant (round 4): the same items, tiles and arithmetic as ppo_step_dw_bf16_lds_kernel -- every MFMA sees
+// the same operands in the same order: bit-identical slabs -- restructured around three things measured this round:
+//   * A compute wave that issues its own LDS-DMAs stalls ~100-185 cycles per instruction while the LDS serves fragment reads
+//     (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): with four copies per wave and k-block that WAS the ~1.2 k cycles per
+//     k-block of the kernel above (256 cycles of MFMA work).  Two LOADER waves (one per operand: the 8 dZ^T tiles, the 8 H^T
+//     tiles of every k-block) do nothing but copy, DW_NBUF - 1 k-blocks ahead; their memory queues hold only copies, so their
+//     counted vmcnt waits are exact; the four compute waves never wait on vmcnt.
+//   * MFMAs on BOTH sides of the hand-off: 8 MFMAs of k-block kb | barrier | the 8 fragment reads of k-block kb + 1 | the other 8
+//     MFMAs of kb -- their operands were read one k-block earlier, so the matrix pipe restarts the moment the barrier releases.
+//   * The 64 x 64 f32 result of a wave left as 64 four-byte stores per lane, 16 rows x 64 B each (7 k cycles of store issue);
+//     now it goes through the (idle) ring as two 32-row halves and leaves as 16-byte stores, four full 256-byte rows per instruction.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DWR_THREADS = 384;  // 4 compute waves (2 x 2, 64 x 64 each) + 2 loader waves
+template <int N>
+__device__ __forceinline__ void dwr_wait_behind(int behind) {  // vmcnt(8 x behind)
+    if constexpr (N > 0) {
+        if (behind >= N) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * N) : "memory");
+            return;
+        }
+        dwr_wait_behind<N - 1>(behind);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+__device__ __forceinline__ void dwr_barrier() {  // lgkmcnt(0) as the builtin: hipcc then knows the fragment reads have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int DW_NBUF>
+__global__ __launch_bounds__(DWR_THREADS) void ppo_step_dw_bf16_ring_kernel(DwArgs a, const __bf16* __restrict__ st_tiles) {
+    extern __shared__ __align__(16) char dsm[];
+    static_assert(DW_NBUF >= 3 && 8 * (DW_NBUF - 2) < 64, "ring depth");
+    const rlx_mlp_layout& lay = a.lay;
+    const long long M = a.M;
+    const int tid = threadIdx.x;
+    const int gemm_blocks = round_up(a.gemm_items, 8);
+    int b = blockIdx.x;
+
+    if (b >= gemm_blocks) {
+        b -= gemm_blocks;
+        if (b < a.slabs * 2) {
+            if (tid < 256) head_reduce_block(a, b >> 1, b & 1, tid);
+        } else {
+            double* s_red = reinterpret_cast<double*>(dsm);
+            double acc[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+            for (int i = tid; i < a.tiles * 2; i += DWR_THREADS) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
+            }
+            block_sum<NS>(acc, s_red);
+            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+        }
+        return;
+    }
+    const int item = (b & 7) * (gemm_blocks >> 3) + (b >> 3);
+    if (item >= a.gemm_items) return;
+    const int s = item / 20, w = item % 20;
+    int y, l, i0, j0;
+    if (w < 16) {
+        const int mat = w >> 2, tile = w & 3;
+        y = mat >> 1; l = 1 + (mat & 1); i0 = (tile >> 1) * 128; j0 = (tile & 1) * 128;
+    } else {
+        y = (w - 16) >> 1; l = 0; i0 = ((w - 16) & 1) * 128; j0 = 0;
+    }
+    const int nrb = (int)((M + 31) / 32);
+    const size_t mat_elems = (size_t)16 * nrb * 512;
+    const int Kin = l == 0 ? lay.obs_dim : HID;
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.dz) + (size_t)(y * 3 + l) * mat_elems;
+    const __bf16* Bm = l == 0 ? st_tiles : reinterpret_cast<const __bf16*>(a.h) + (size_t)(y * 2 + l - 1) * mat_elems;
+    const int ncb_b = l == 0 ? 4 : 16;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, kq = lane >> 4;
+    const int rb0 = (int)((long long)s * a.rows_per_slab / 32);
+    const int rb1 = min(nrb, (int)(((long long)(s + 1) * a.rows_per_slab) / 32));
+    const int nkb = max(0, rb1 - rb0);
+    constexpr int AHEAD = DW_NBUF - 1;
+
+    if (wave >= 4) {  // ---- loader waves: wave 4 copies the 8 dZ^T tiles of every k-block (LDS slots 0-7), wave 5 the 8 H^T tiles (8-15)
+        const int op = wave - 4;
+        const __bf16* src[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            src[t] = (op == 0 ? A + ((size_t)(i0 / 16 + t) * nrb + rb0) * 512 : Bm + ((size_t)min(j0 / 16 + t, ncb_b - 1) * nrb + rb0) * 512) + lane * 8;
+        auto issue = [&](int kb, int buf) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + (size_t)kb * 512),
+                                                 (__attribute__((address_space(3))) void*)(dsm + buf * DW_BUF_BYTES + (8 * op + t) * 1024), 16, 0, 0);
+        };
+        int fill = 0;
+        for (int kb = 0; kb < AHEAD && kb < nkb; ++kb) {
+            issue(kb, fill);
+            fill = fill + 1 == DW_NBUF ? 0 : fill + 1;
+        }
+        for (int kb = 0; kb < nkb; ++kb) {
+            dwr_wait_behind<AHEAD - 1>(min(AHEAD - 1, nkb - 1 - kb));
+            __builtin_amdgcn_s_barrier();  // hand-off kb: k-block kb has landed, k-block kb - 1 has been read by everybody
+            asm volatile("" ::: "memory");
+            if (kb + AHEAD < nkb) {
+                issue(kb + AHEAD, fill);
+                fill = fill + 1 == DW_NBUF ? 0 : fill + 1;
+            }
+        }
+        return;
+    }
+
+    // ---- compute waves ---------------------------------------------------------------------------------------------------
+    const int wi = wave >> 1, wj = wave & 1;
+    const bool live = j0 + wj * 64 < Kin;  // first layers: only the first 64-column block holds inputs (the wave still synchronises)
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    long long* stp = (a.stamps != nullptr && item == 0 && tid == 0) ? a.stamps : nullptr;
+    if (stp) stp[0] = clock64();
+    bf16x8 fa[2][4], fb[2][4];
+    auto read_frags = [&](int kb, bf16x8 (&xa)[4], bf16x8 (&xb)[4]) {
+        const char* buf = dsm + (kb % DW_NBUF) * DW_BUF_BYTES + lane * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xa[t] = *reinterpret_cast<const bf16x8*>(buf + (wi * 4 + t) * 1024);
+            xb[t] = *reinterpret_cast<const bf16x8*>(buf + (8 + wj * 4 + t) * 1024);
+        }
+    };
+    auto mfmas = [&](const bf16x8 (&xa)[4], const bf16x8 (&xb)[4], int t0) {  // row tiles t0, t0 + 1 (+ the bias sums riding on the A fragments)
+        if (!live) return;
+#pragma unroll
+        for (int ti = t0; ti < t0 + 2; ++ti) {
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[ti], xb[tj], acc[ti][tj], 0, 0, 0);
+            float t8 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t8 += (float)xa[ti][e];
+            bsum[ti] += t8;
+        }
+    };
+    if (nkb > 0) {
+        dwr_barrier();  // hand-off 0
+        read_frags(0, fa[0], fb[0]);
+    }
+    for (int kb0 = 0; kb0 < nkb; kb0 += 2) {  // two k-blocks per trip: the register double buffer alternates without copies
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int kb = kb0 + d;
+            if (kb >= nkb) break;
+            mfmas(fa[d], fb[d], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) {
+                dwr_barrier();  // hand-off kb + 1
+                if (stp && kb < 12) stp[1 + kb] = clock64();
+                read_frags(kb + 1, fa[d ^ 1], fb[d ^ 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[d], fb[d], 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (stp) stp[14] = clock64();
+    dwr_barrier();  // every compute wave has read its last fragments (the loaders are gone): the ring becomes the store staging area
+    float* slab = a.grads + (size_t)s * lay.n_params;
+    float* dW = slab + lay.off_w[y][l];
+    const bool vec_ok = (lay.n_params & 3) == 0 && (reinterpret_cast<uintptr_t>(a.grads) & 15) == 0;  // 16-byte aligned rows in every slab
+    if (live && l != 0 && vec_ok) {
+        // 64 x 64 f32 of this wave -> [32][68] f32 in LDS (accumulator layout in, rows out), twice; 16-byte stores, a lane quad-row per
+        // instruction: 16 lanes write one full 256-byte row of the gradient
+        constexpr int SS = 68;
+        float* stage = reinterpret_cast<float*>(dsm) + wave * 32 * SS;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stage[(t2 * 16 + 4 * kq + r) * SS + tj * 16 + r16] = acc[2 * hp + t2][tj][r];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = lane + 64 * u, row = idx >> 4, c4 = idx & 15;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * SS + 4 * c4);
+                *reinterpret_cast<f32x4*>(dW + (size_t)(i0 + wi * 64 + hp * 32 + row) * HID + j0 + wj * 64 + 4 * c4) = v;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+    } else if (live) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const int col = j0 + wj * 64 + tj * 16 + r16;
+                if (col < Kin) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i0 + wi * 64 + ti * 16 + 4 * kq + r;
+                        dW[(size_t)row * Kin + col] = acc[ti][tj][r];
+                    }
+                }
+            }
+    }
+    if (live && j0 == 0 && wj == 0) {  // bias gradient = column sums of dZ: lane (r16, kq) holds 8 of the 32 rows of column ti*16 + r16
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            float tot = bsum[ti];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (kq == 0) slab[lay.off_b[y][l] + i0 + wi * 64 + ti * 16 + r16] = tot;
+        }
+    }
+    if (stp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stp[15] = clock64();
+    }
+}
+
 template <typename K>
 int set_lds_b(K kern, size_t bytes) {
     static thread_local const void* done[16] = {};
@@ -1121,6 +1346,23 @@ int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int til
     if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)
         hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
     } else {
+        if (dev_variant("RLX_DW_RING", 1) != 0) {
+#define RLX_DWR_LAUNCH(NB)                                                                                                         \
+    {                                                                                                                              \
+        const size_t rlds = (size_t)(NB) * DW_BUF_BYTES;                                                                           \
+        if (int rc = set_lds_b(ppo_step_dw_bf16_ring_kernel<NB>, rlds)) return rc;                                                 \
+        hipLaunchKernelGGL(ppo_step_dw_bf16_ring_kernel<NB>, dim3(dw_blocks), dim3(DWR_THREADS), rlds, st, d, static_cast<const __bf16*>(stt)); \
+    }
+            switch (dev_variant("RLX_DW_RING_NBUF", 4)) {
+                case 6: RLX_DWR_LAUNCH(6) break;
+                case 8: RLX_DWR_LAUNCH(8) break;
+                case 9: RLX_DWR_LAUNCH(9) break;
+                default: RLX_DWR_LAUNCH(4) break;
+            }
+#undef RLX_DWR_LAUNCH
+            RLX_LAUNCH_CHECK();
+            return RLX_OK;
+        }
 #define RLX_DW_LAUNCH(NB)                                                                                                       \
     {                                                                                                                           \
         const size_t dlds = (size_t)(NB) * DW_BUF_BYTES;                                                                          \

@@ -45,7 +45,7 @@ using namespace b16;
 constexpr int RW_NG = 4, RW_BM = 16 * RW_NG;                      // row groups per workgroup, rows
 constexpr int RW_NW = 2 * RW_NG, RW_NT = 64 * RW_NW;              // compute waves (a pair per row group), compute threads
 constexpr int RW_NL = 2, RW_THREADS = RW_NT + 64 * RW_NL;         // + loader waves
-constexpr int RW_CT = 8;                                          // column tiles per compute wave
+constexpr int RW_CT = 4;                                          // column tiles per compute wave (x 2 row groups)
 constexpr int RW_KSTEP = 16 * 1024;                               // one k-step of a layer: 16 column tiles x 1 KiB
 constexpr int RW_SLOT = 2 * RW_KSTEP;                             // a ring slot = two k-steps: one hand-off (barrier) per 16 MFMAs and wave
 constexpr int RW_STEPS = 1 + 4 + 4 + 4 + 4;                       // slots: W1 | W2 | W3 | W3^T | W2^T
@@ -71,6 +71,8 @@ struct RowsLds {
     static_assert(BYTES <= 160 * 1024, "LDS budget of a CU");
     static_assert(SLAB_BYTES >= (size_t)16 * 64 * sizeof(bf16x4), "the head-gradient exchange parks 16 tiles x 64 lanes x 8 B in a slab");
 };
+
+__device__ int g_rows_dev_skip_reads = 0;  // development switch (see read_frags)
 
 // lgkmcnt(0) as the BUILTIN (simm16 0xC07F: vmcnt / expcnt left at their maxima), not inline asm: hipcc's wait-count pass then
 // knows that every LDS read issued so far has landed and does not protect the MFMAs of k-step ks (operands read one k-step
@@ -100,11 +102,12 @@ __device__ __forceinline__ void wait_slots_behind(int behind) {  // vmcnt(16 x b
     }
 }
 template <int NSLOT>
-__device__ __forceinline__ void loader_main(const __bf16* __restrict__ tiles_y, char* ring, int lw, int lane) {
+__device__ __forceinline__ void loader_main(const __bf16* __restrict__ tiles_y, char* ring, int lw, int lane, int dev) {
     constexpr int AHEAD = NSLOT - 1;
     static_assert(AHEAD >= 1 && 16 * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
     const __bf16* src = tiles_y + lane * 8;
     auto issue = [&](int s, int buf) {  // slot s: W1 (its two k-steps) or k-steps 2 j, 2 j + 1 of a 256 x 256 matrix
+        if (dev & 1) return;  // development (RLX_ROWS_DEV bit 0, TIMING ONLY): no copies at all
         size_t off = 0;
         if (s >= 1) {
             const int t = s - 1, l = t >> 2, m = l == 0 ? 1 : l == 1 ? 2 : l == 2 ? 4 : 3;  // W2, W3, W3^T, W2^T
@@ -136,49 +139,62 @@ __device__ __forceinline__ void loader_main(const __bf16* __restrict__ tiles_y, 
     }
 }
 
-template <int NSLOT, int C0, int KS, int G>
-__device__ __forceinline__ void read_frag_group(const char* ring_tile, const __bf16* xa, bf16x8& a, bf16x8 (&b)[RW_CT]) {
+// k-step KS of a layer (slot C0 + KS / 2, half KS & 1): this wave's operands -- A fragments of its two row groups (their slabs), B
+// fragments of its four column tiles (the ring).
+template <int NSLOT, int C0, int KS>
+__device__ __forceinline__ void read_frags(const char* ring_tile, const __bf16* xa0, const __bf16* xa1, bf16x8 (&a)[2], bf16x8 (&b)[RW_CT]) {
+    if (KS > 0 && g_rows_dev_skip_reads) return;  // development (RLX_ROWS_DEV bit 1, TIMING ONLY): MFMAs on stale fragments
     const char* kstep = ring_tile + ((C0 + KS / 2) % NSLOT) * RW_SLOT + (KS & 1) * RW_KSTEP;
-    if constexpr (G == 0) a = *reinterpret_cast<const bf16x8*>(xa + KS * 32);
+    a[0] = *reinterpret_cast<const bf16x8*>(xa0 + KS * 32);
+    a[1] = *reinterpret_cast<const bf16x8*>(xa1 + KS * 32);
 #pragma unroll
-    for (int t = 4 * G; t < 4 * G + 4; ++t) b[t] = *reinterpret_cast<const bf16x8*>(kstep + t * 1024);
+    for (int t = 0; t < RW_CT; ++t) b[t] = *reinterpret_cast<const bf16x8*>(kstep + t * 1024);
 }
 
-// acc[t] = X[16 rows][0 : 32 NKS] . W^T for this wave's 8 column tiles; X = the row group's slab, W = ring slots C0 .. (two k-steps
-// each).  Software-pipelined by one k-step in two groups: 4 (+1) fragment reads of k-step ks + 1 (behind its slot's hand-off when it
-// opens a slot), 4 MFMAs of k-step ks.
+// acc[rt][t] = X[rows of group rt][0 : 32 NKS] . W^T for this wave's 2 row groups x 4 column tiles; X = the groups' slabs, W = ring
+// slots C0 .. (two k-steps each).  Software-pipelined by one k-step:  4 MFMAs of k-step ks | (hand-off when k-step ks + 1 opens a
+// slot) | the 6 fragment reads of k-step ks + 1 | the other 4 MFMAs of k-step ks.  MFMAs on BOTH sides of the hand-off: their
+// operands were read one k-step earlier, so the matrix pipe starts again the moment the barrier releases, while the reads issue
+// in its shadow (with the reads first the pipe idled ~150 cycles per hand-off).
 template <int NSLOT, int C0, int NKS, int KS>
 struct GemmSteps {
-    static __device__ __forceinline__ void run(const char* ring_tile, const __bf16* xa, f32x4 (&acc)[RW_CT], bf16x8 (&a)[2], bf16x8 (&b)[2][RW_CT]) {
+    static __device__ __forceinline__ void run(const char* ring_tile, const __bf16* xa0, const __bf16* xa1, f32x4 (&acc)[2][RW_CT], bf16x8 (&a)[2][2],
+                                               bf16x8 (&b)[2][RW_CT]) {
         constexpr bool more = KS + 1 < NKS;
-        if constexpr (more && ((KS + 1) & 1) == 0) ring_barrier();  // hand-off of slot C0 + (KS + 1) / 2
-#define RLX_ROWS_GROUP(G)                                                                                                       \
-        if constexpr (more) read_frag_group<NSLOT, C0, KS + 1, G>(ring_tile, xa, a[(KS + 1) & 1], b[(KS + 1) & 1]);             \
-        __builtin_amdgcn_sched_barrier(0);                                                                                      \
-        _Pragma("unroll") for (int t = 4 * G; t < 4 * G + 4; ++t)                                                               \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[KS & 1], b[KS & 1][t], acc[t], 0, 0, 0);                         \
+#define RLX_ROWS_MFMAS(G)                                                                                                            \
+        _Pragma("unroll") for (int t = 2 * G; t < 2 * G + 2; ++t) {                                                                  \
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[KS & 1][0], b[KS & 1][t], acc[0][t], 0, 0, 0);                     \
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[KS & 1][1], b[KS & 1][t], acc[1][t], 0, 0, 0);                     \
+        }
+        RLX_ROWS_MFMAS(0)
         __builtin_amdgcn_sched_barrier(0);
-        RLX_ROWS_GROUP(0)
-        RLX_ROWS_GROUP(1)
-#undef RLX_ROWS_GROUP
-        if constexpr (more) GemmSteps<NSLOT, C0, NKS, KS + 1>::run(ring_tile, xa, acc, a, b);
+        if constexpr (more) {
+            if constexpr (((KS + 1) & 1) == 0) ring_barrier();  // hand-off of slot C0 + (KS + 1) / 2
+            read_frags<NSLOT, C0, KS + 1>(ring_tile, xa0, xa1, a[(KS + 1) & 1], b[(KS + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        RLX_ROWS_MFMAS(1)
+        __builtin_amdgcn_sched_barrier(0);
+#undef RLX_ROWS_MFMAS
+        if constexpr (more) GemmSteps<NSLOT, C0, NKS, KS + 1>::run(ring_tile, xa0, xa1, acc, a, b);
     }
 };
-// `slab_reused`: one more workgroup barrier behind the last k-step -- the caller's epilogue overwrites the slab its partner may
+// `slab_reused`: one more workgroup barrier behind the last k-step -- the caller's epilogue overwrites the slabs its partners may
 // still be reading A fragments from.
 template <int NSLOT, int C0, int NKS>
-__device__ __forceinline__ void row_gemm(const char* ring, const __bf16* Xb, int half, bool slab_reused, f32x4 (&acc)[RW_CT]) {
+__device__ __forceinline__ void row_gemm(const char* ring, const __bf16* Xb0, const __bf16* Xb1, int cq, bool slab_reused, f32x4 (&acc)[2][RW_CT]) {
     static_assert(NKS % 2 == 0, "whole slots");
     const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
-    const char* ring_tile = ring + (half * RW_CT) * 1024 + lane * 16;
-    const __bf16* xa = Xb + r16 * XSB + 8 * kq;
+    const char* ring_tile = ring + (cq * RW_CT) * 1024 + lane * 16;
+    const __bf16 *xa0 = Xb0 + r16 * XSB + 8 * kq, *xa1 = Xb1 + r16 * XSB + 8 * kq;
 #pragma unroll
-    for (int t = 0; t < RW_CT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 a[2], b[2][RW_CT];
-    ring_barrier();  // hand-off C0 (and: the slab the previous phase wrote is complete)
-    read_frag_group<NSLOT, C0, 0, 0>(ring_tile, xa, a[0], b[0]);
-    read_frag_group<NSLOT, C0, 0, 1>(ring_tile, xa, a[0], b[0]);
-    GemmSteps<NSLOT, C0, NKS, 0>::run(ring_tile, xa, acc, a, b);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < RW_CT; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[2][2], b[2][RW_CT];
+    ring_barrier();  // hand-off C0 (and: the slabs the previous phase wrote are complete)
+    read_frags<NSLOT, C0, 0>(ring_tile, xa0, xa1, a[0], b[0]);
+    GemmSteps<NSLOT, C0, NKS, 0>::run(ring_tile, xa0, xa1, acc, a, b);
     if (slab_reused) ring_barrier();
 }
 
@@ -213,10 +229,24 @@ __device__ __forceinline__ void metric_partials(const double (&lacc)[NS], double
         for (int k = 0; k < NS; ++k) row[k] = tot[k];
     }
 }
+// x of lane + J inside a 16-lane row (row_shl: lanes past the row read 0), the VALU form of __shfl_down for J < 16
+template <int J>
+__device__ __forceinline__ float row_down(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + J, 0xF, 0xF, true));
+}
+// lp = ((0 + x[l]) + x[l + 1]) + ... + x[l + n - 1]  (n <= 16 lanes of one row, ascending like the reference's sum over the
+// action dimension); n is wave-uniform
+__device__ __forceinline__ float row_sum_ascending(float x, int n) {
+    float s = fadd(0.f, x);
+#define RLX_ROW_ADD(J) if (n > J) s = fadd(s, row_down<J>(x));
+    RLX_ROW_ADD(1) RLX_ROW_ADD(2) RLX_ROW_ADD(3) RLX_ROW_ADD(4) RLX_ROW_ADD(5) RLX_ROW_ADD(6) RLX_ROW_ADD(7) RLX_ROW_ADD(8)
+    RLX_ROW_ADD(9) RLX_ROW_ADD(10) RLX_ROW_ADD(11) RLX_ROW_ADD(12) RLX_ROW_ADD(13) RLX_ROW_ADD(14) RLX_ROW_ADD(15)
+#undef RLX_ROW_ADD
+    return s;
+}
 
-// this wave's 16 x 16 tiles (column tiles ct0 ..) in the accumulator layout -> the k-tiled transposed image, 8 B per lane
+// a row group's 16 x 16 tiles (column tiles ct0 .. ct0 + 3) in the accumulator layout -> the k-tiled transposed image, 8 B per lane
 __device__ __forceinline__ void store_image(const bf16x4 (&v)[RW_CT], __bf16* __restrict__ img, int nrb, int rb, int rhalf, int ct0) {
-    if (rb >= nrb) return;  // wave-uniform
     const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
     const int kblk = 2 * rhalf + (kq >> 1);
 #pragma unroll
@@ -232,21 +262,24 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
     const rlx_ppo_loss_params& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, kq = lane >> 4;
     const int tile = blockIdx.x, y = blockIdx.y, D = lay.obs_dim;
-    const int grp = wave >> 1, half = wave & 1, ct0 = half * RW_CT;       // row group, column half, first column tile
-    const long long M = a.M, mw = (long long)tile * RW_BM + 16 * grp;     // the row group's first row
+    // wave (rp, cq): row pair rp = the 32 rows of row groups 2 rp, 2 rp + 1; column quarter cq = column tiles 4 cq .. 4 cq + 3.
+    // A B fragment read from the ring serves both row groups: 6 LDS reads per 8 MFMAs (a wave per 16 rows x 128 columns needed 9 --
+    // the k-steps were bound by the LDS: ~530 cycles against 272 of MFMA time).
+    const int rp = wave >> 2, cq = wave & 3, ct0 = cq * RW_CT;
+    const long long M = a.M, mp = (long long)tile * RW_BM + 32 * rp;      // the row pair's first row
     const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
     const long long n_adv = M * (lay.act_dim / p.raw_per_adv);
     const bool has_mask = a.loss_mask != nullptr, has_msum = a.loss_mask_sum != nullptr;
     const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
     const TileGeom tg{(int)((M + 31) / 32)};
-    const int rb = (int)(mw >> 5), rhalf = grp & 1;  // 32-row block of the images, which half of it
+    const int rb = (int)(mp >> 5);            // the pair IS one 32-row block of the images (group rt = its half rt)
+    const bool img_live = rb < tg.nrb;        // wave-uniform: a pair past the last block stores no image
 
     char* ring = lds + L::RING;
-    __bf16* Xb = reinterpret_cast<__bf16*>(lds + L::SLAB + grp * L::SLAB_BYTES);
+    auto slab = [&](int g) { return reinterpret_cast<__bf16*>(lds + L::SLAB + g * L::SLAB_BYTES); };
+    auto scratch = [&](int g) { return reinterpret_cast<float*>(lds + L::SCR + g * L::SCR_BYTES); };  // sP0 | sP1 | sH, [16][MAX_OUT] each
+    __bf16 *Xb0 = slab(2 * rp), *Xb1 = slab(2 * rp + 1);
     float* sBias = reinterpret_cast<float*>(lds + L::BIAS);
-    float* sP0 = reinterpret_cast<float*>(lds + L::SCR + grp * L::SCR_BYTES);  // head partial 0, later d(loss)/d(log std) rows
-    float* sP1 = sP0 + 16 * MAX_OUT;                                           // head partial 1
-    float* sH = sP1 + 16 * MAX_OUT;                                            // dOut rows (zero outside [16][n_out])
     float* W4s = reinterpret_cast<float*>(lds + L::W4);
     float* b4s = W4s + W4R * W4S;
     float* sStd = b4s + MAX_OUT;
@@ -255,16 +288,7 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
     __bf16* hy = reinterpret_cast<__bf16*>(a.h) + (size_t)(y * 2) * tg.mat();
     __bf16* dzy = reinterpret_cast<__bf16*>(a.dz) + (size_t)(y * 3) * tg.mat();
 
-    {   // Touch every 64-byte line of the kernel-argument block NOW.  The loss parameters, partial-buffer pointers and strides are
-        // first read far into the kernel; each first touch of a kernarg line is a scalar-cache miss that goes out to memory (several
-        // microseconds when every CU of the chip is pulling weight tiles) with one wave per SIMD pair and nothing to overlap it.
-        typedef const __attribute__((address_space(4))) unsigned* kptr;
-        kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-        unsigned touch = 0;
-#pragma unroll
-        for (int i = 0; i < (int)((sizeof(StepArgs) + sizeof(void*) + 63) / 64); ++i) touch |= kp[16 * i];
-        asm volatile("" ::"s"(touch));
-    }
+    touch_kernargs<(int)(sizeof(StepArgs) + 8)>();  // (the loss parameters, partial-buffer pointers and strides are first read far into the kernel)
     StampsT<STAMPS> ts{a.stamps, 0};
     ts.mark();
     double nm = 0.0;
@@ -277,20 +301,22 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
         nm = sRed[RW_NW + RW_NL];
     }
     if (wave >= RW_NW) {
-        loader_main<NSLOT>(tiles + Tiles::mat(y, 0), ring, wave - RW_NW, lane);
+        loader_main<NSLOT>(tiles + Tiles::mat(y, 0), ring, wave - RW_NW, lane, a.xcd_rows);
         return;
     }
 
     // ---- the launch's global inputs ---------------------------------------------------------------------------------------------
-    // states: the pair splits the group's 16 rows (wave h: rows 8 h .. 8 h + 7), one (padded) column per lane
+    // states: the pair's four waves split its 32 rows (wave cq: rows 8 cq .. 8 cq + 7 = rows 8 (cq & 1) .. of group 2 rp + (cq >> 1)),
+    // one (padded) column per lane
     static_assert(Tiles::K1P == 64, "one column per lane assumes a 64-wide padded first layer");
     float xs[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xs[u] = a.states[(size_t)min(mw + 8 * half + u, M - 1) * D + min(lane, D - 1)];  // clamped, unconditional
-    // Loss inputs.  The group's [16][n_out] elements are walked in passes of 64 (element e = lane + 64 u: row = e / n_out,
-    // o = e % n_out; n_out is a power of two: fused_rows_eligible); the pair splits the passes (wave h: u = h, h + 2).
-    constexpr int NPW = W4R / 8;  // passes per wave: W4R / 4 passes cover 16 x n_out <= 16 W4R elements
-    const int epw = 16 * n_out, npass = (epw + 63) >> 6, osh = 31 - __builtin_clz(n_out);
+    for (int u = 0; u < 8; ++u) xs[u] = a.states[(size_t)min(mp + 8 * cq + u, M - 1) * D + min(lane, D - 1)];  // clamped, unconditional
+    // Loss inputs.  A group's [16][n_out] elements are walked in passes of 64 (element e = lane + 64 u: row = e / n_out, o = e % n_out;
+    // n_out is a power of two: fused_rows_eligible); the pair's 2 x npass (group, pass) jobs go round the four waves: wave cq takes
+    // jobs cq, cq + 4 (job j: group j / npass of the pair, pass j % npass).
+    constexpr int NPW = W4R / 8;  // jobs per wave: W4R / 4 passes cover 16 x n_out <= 16 W4R elements of a group
+    const int epw = 16 * n_out, npass = (epw + 63) >> 6, osh = 31 - __builtin_clz(n_out), psh = 31 - __builtin_clz(npass);
     float v_a[NPW], v_b[NPW], v_c[NPW];  // policy: old log-prob, action, advantage;  critic: prev value, return, -
     unsigned m_on[NPW];
     float m_w[NPW];
@@ -298,8 +324,9 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
     const int64_t* safe64 = reinterpret_cast<const int64_t*>(a.params);
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-        const int e = min(lane + 64 * (half + 2 * i), epw - 1), row = e >> osh, o = e & (n_out - 1);
-        const size_t gr = (size_t)min(mw + row, M - 1);
+        const int j = min(cq + 4 * i, 2 * npass - 1), jg = j >> psh, u = j & (npass - 1);
+        const int e = min(lane + 64 * u, epw - 1), row = e >> osh, o = e & (n_out - 1);
+        const size_t gr = (size_t)min(mp + 16 * jg + row, M - 1);
         const size_t ge = y == 1 ? gr : gr * n_out + o;  // loss element: one per row (action_level, one sub-group) / per value output
         if (y == 1) {
             v_a[i] = a.old_logprobs[gr * lay.act_dim + o];
@@ -316,83 +343,96 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
     }
     SmallInputsB<RW_NT> si;
     si.issue(a.params, lay, y, n_out);
+    {
+        __bf16* Xs = slab(2 * rp + (cq >> 1));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) Xb[(8 * half + u) * XSB + lane] = (__bf16)((lane < D && mw + 8 * half + u < M) ? xs[u] : 0.f);  // 64 columns: zero k tail
-    si.commit(n_out, sBias, W4s, b4s, sStd);
-    for (int i = n_out * W4S + tid; i < W4R * W4S; i += RW_NT) W4s[i] = 0.f;
-    for (int i = lane + 64 * half; i < 16 * MAX_OUT; i += 128) sH[i] = 0.f;
-    // The loss inputs are first USED behind the forward sweep: hipcc would wait for them there with a vmcnt count that is safe on
-    // every path -- including the one where the image stores are skipped (rows past M) -- i.e. on the normal path it waited for all
-    // but the last three of the h1 / h2 image stores to reach the L2 (measured: 3 - 11 k cycles in the loss phase).  Consumed here,
-    // behind the states commit, the wait costs nothing: everything above has been waited for already.
+        for (int u = 0; u < 8; ++u) Xs[(8 * (cq & 1) + u) * XSB + lane] = (__bf16)((lane < D && mp + 8 * cq + u < M) ? xs[u] : 0.f);  // 64 columns: zero k tail
+        si.commit(n_out, sBias, W4s, b4s, sStd);
+        for (int i = n_out * W4S + tid; i < W4R * W4S; i += RW_NT) W4s[i] = 0.f;
+        for (int i = tid; i < RW_NG * 3 * 16 * MAX_OUT; i += RW_NT) reinterpret_cast<float*>(lds + L::SCR)[i] = 0.f;  // (sH must be zero outside [16][n_out])
+        // The loss inputs are first USED behind the forward sweep: hipcc would wait for them there with a vmcnt count that is safe on
+        // every path -- including the one where the image stores are skipped (rows past M) -- i.e. on the normal path it waited for all
+        // but the last three of the h1 / h2 image stores to reach the L2 (measured: 3 - 11 k cycles in the loss phase).  Consumed here,
+        // behind the states commit, the wait costs nothing: everything above has been waited for already.
 #pragma unroll
-    for (int i = 0; i < NPW; ++i) asm volatile("" : "+v"(v_a[i]), "+v"(v_b[i]), "+v"(v_c[i]), "+v"(m_on[i]), "+v"(m_w[i]));
-    wave_lds_fence();
-    ts.mark();
-    if (y == 1 && rb < tg.nrb) {  // the states' k-tiled image (B operand of the first layers' weight gradients): 4 column blocks x this wave's 8 rows
-        const int cb = lane >> 4, c16 = lane & 15;
-        bf16x8 v;
+        for (int i = 0; i < NPW; ++i) asm volatile("" : "+v"(v_a[i]), "+v"(v_b[i]), "+v"(v_c[i]), "+v"(m_on[i]), "+v"(m_w[i]));
+        wave_lds_fence();
+        ts.mark();
+        if (y == 1 && img_live) {  // the states' k-tiled image (B operand of the first layers' weight gradients): 4 column blocks x this wave's 8 rows
+            const int cb = lane >> 4, c16 = lane & 15;
+            bf16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Xb[(8 * half + j) * XSB + cb * 16 + c16];
-        *reinterpret_cast<bf16x8*>(st_tiles + ((size_t)(cb * tg.nrb + rb) * 64 + (2 * rhalf + half) * 16 + c16) * 8) = v;
+            for (int jj = 0; jj < 8; ++jj) v[jj] = Xs[(8 * (cq & 1) + jj) * XSB + cb * 16 + c16];
+            *reinterpret_cast<bf16x8*>(st_tiles + ((size_t)(cb * tg.nrb + rb) * 64 + cq * 16 + c16) * 8) = v;
+        }
     }
 
     // ---- forward -----------------------------------------------------------------------------------------------------
-    f32x4 acc[RW_CT];
+    f32x4 acc[2][RW_CT];
     // The rounded activations in the accumulator layout (1 - h^2 of the backward sweep): h2, h3 stay in registers; every lane
     // reads back the 8-byte words it stored into the h1 image (requested before the last GEMM, used behind it).
-    bf16x4 kept[2][RW_CT], h1v[RW_CT];
-    auto epilogue_tanh = [&](auto lc, bf16x4 (&keep)[RW_CT]) {
+    bf16x4 kept[2][2][RW_CT], h1v[2][RW_CT];
+    auto epilogue_tanh = [&](auto lc, bf16x4 (&keep)[2][RW_CT]) {
         constexpr int l = decltype(lc)::value;
 #pragma unroll
         for (int t = 0; t < RW_CT; ++t) {
             const float bv = sBias[l * HID + (ct0 + t) * 16 + r16];
-            bf16x4 hv;
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const f32x2 h = tanh2_b(f32x2{acc[t][r] + bv, acc[t][r + 1] + bv});
-                hv[r] = (__bf16)h.x;
-                hv[r + 1] = (__bf16)h.y;
+            for (int rt = 0; rt < 2; ++rt) {
+                bf16x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 h = tanh2_b(f32x2{acc[rt][t][r] + bv, acc[rt][t][r + 1] + bv});
+                    hv[r] = (__bf16)h.x;
+                    hv[r + 1] = (__bf16)h.y;
+                }
+                store_slab_quad(rt == 0 ? Xb0 : Xb1, 0, (ct0 + t) * 16, hv);
+                keep[rt][t] = hv;
             }
-            store_slab_quad(Xb, 0, (ct0 + t) * 16, hv);
-            keep[t] = hv;
         }
     };
-    row_gemm<NSLOT, RW_C_L1, Tiles::K1P / 32>(ring, Xb, half, true, acc);
+    auto store_images = [&](const bf16x4 (&v)[2][RW_CT], __bf16* img) {
+        if (!img_live) return;
+        store_image(v[0], img, tg.nrb, rb, 0, ct0);
+        store_image(v[1], img, tg.nrb, rb, 1, ct0);
+    };
+    row_gemm<NSLOT, RW_C_L1, Tiles::K1P / 32>(ring, Xb0, Xb1, cq, true, acc);
     ts.mark();
     epilogue_tanh(std::integral_constant<int, 0>{}, h1v);
-    store_image(h1v, hy, tg.nrb, rb, rhalf, ct0);
+    store_images(h1v, hy);
     ts.mark();
-    row_gemm<NSLOT, RW_C_L2, HID / 32>(ring, Xb, half, true, acc);
+    row_gemm<NSLOT, RW_C_L2, HID / 32>(ring, Xb0, Xb1, cq, true, acc);
     ts.mark();
     epilogue_tanh(std::integral_constant<int, 1>{}, kept[0]);
-    store_image(kept[0], hy + tg.mat(), tg.nrb, rb, rhalf, ct0);
+    store_images(kept[0], hy + tg.mat());
     ts.mark();
-    row_gemm<NSLOT, RW_C_L3, HID / 32>(ring, Xb, half, true, acc);
+    row_gemm<NSLOT, RW_C_L3, HID / 32>(ring, Xb0, Xb1, cq, true, acc);
     ts.mark();
     epilogue_tanh(std::integral_constant<int, 2>{}, kept[1]);
-    ring_barrier();  // extra 2 of 5: the group's h3 slab is complete
+    ring_barrier();  // extra 2 of 5: the groups' h3 slabs are complete
     ts.mark();
 
-    // ---- head (f32 weights as three bf16 planes): wave h of the pair takes k half h; the partials are added afterwards, each over
-    // four k-steps in ascending order -- the rollout launch's order.
+    // ---- head (f32 weights as three bf16 planes): the pair's four waves take (group, k half) = (cq & 1, cq >> 1); the two partials
+    // of a group are added afterwards, each over four k-steps in ascending order -- the rollout launch's order.
     {
+        const int hg = cq & 1, kh = cq >> 1;
+        const __bf16* Xh = hg == 0 ? Xb0 : Xb1;
         f32x4 hacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < HID / 64; ++q) {
-            const int k0 = (half * (HID / 64) + q) * 32 + 8 * kq;
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(Xb + r16 * XSB + k0);
+            const int k0 = (kh * (HID / 64) + q) * 32 + 8 * kq;
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(Xh + r16 * XSB + k0);
             const int wr_row = W4R == MAX_OUT ? r16 : min(r16, W4R - 1);
             f32x4 w0 = *reinterpret_cast<const f32x4*>(W4s + wr_row * W4S + k0), w1 = *reinterpret_cast<const f32x4*>(W4s + wr_row * W4S + k0 + 4);
             if (W4R != MAX_OUT && r16 >= W4R) w0 = w1 = f32x4{0.f, 0.f, 0.f, 0.f};
             const float w[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
             hacc = mfma3(av, split3(w), hacc);
         }
-        float* P = half == 0 ? sP0 : sP1;
+        float* P = scratch(2 * rp + hg) + kh * 16 * MAX_OUT;  // sP0 / sP1 of that group
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[(4 * kq + r) * MAX_OUT + r16] = hacc[r];
     }
-    ring_barrier();  // extra 3 of 5: both partials of the group are complete
+    ring_barrier();  // extra 3 of 5: both partials of every group are complete
     ts.mark();
 
     // ---- loss element math (f32, identical to the column-split kernel) -----------------------------------------------------------
@@ -404,29 +444,27 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
     const bool has_b4 = lay.off_b[y][3] >= 0;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-        const int u = half + 2 * i;
-        if (u >= npass) break;  // wave-uniform
+        const int j = cq + 4 * i;
+        if (j >= 2 * npass) break;  // wave-uniform
+        const int jg = j >> psh, u = j & (npass - 1);
+        float *sP0 = scratch(2 * rp + jg), *sP1 = sP0 + 16 * MAX_OUT, *sH = sP1 + 16 * MAX_OUT;
+        const long long mg = mp + 16 * jg;
         const int e = lane + 64 * u;
         const bool mine = e < epw;
         const int row = mine ? e >> osh : 0, o = mine ? e & (n_out - 1) : 0;
-        const bool valid = mine && mw + row < M;
+        const bool valid = mine && mg + row < M;
         float sv = fadd(sP0[row * MAX_OUT + o], sP1[row * MAX_OUT + o]);
         if (has_b4) sv = fadd(sv, b4s[o]);
         const bool on = has_mask ? m_on[i] != 0 : true;
         const float w = m_w[i];
         if (y == 1) {
-            // A row's n_out lanes are neighbours (64 % n_out == 0: a row never straddles a pass): the row leader (o == 0) collects
-            // the per-dimension log-probs with n_out - 1 lane shifts, adds them in the reference's order (ascending, from 0.f),
-            // evaluates the loss element and hands d(loss)/d(logprob) back to its lanes.
+            // A row's n_out lanes are neighbours inside one 16-lane row of the wave (n_out divides 16): the row leader (o == 0) adds
+            // the per-dimension log-probs in the reference's order (ascending, from 0.f) over n_out - 1 lane shifts, evaluates the loss
+            // element and hands d(loss)/d(logprob) back to its lanes.
             const float d = fsub(v_b[i], sv);
             const float var = sStd[MAX_OUT + o], log_scale = sStd[2 * MAX_OUT + o];
             const float lpe = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
-            const float olde = v_a[i];
-            float lp = fadd(0.f, lpe), old = fadd(0.f, olde);
-            for (int j = 1; j < n_out; ++j) {
-                lp = fadd(lp, __shfl_down(lpe, j, 64));
-                old = fadd(old, __shfl_down(olde, j, 64));
-            }
+            const float lp = row_sum_ascending(lpe, n_out), old = row_sum_ascending(v_a[i], n_out);
             float gs = 0.f;
             if (valid && o == 0) {
                 lacc[S_NM] += on ? 1.0 : 0.0;
@@ -451,24 +489,25 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
         }
     }
     // Metric partials: every wave's sums -> its row of sRed (the other network's slots as zeros); behind the exchange barrier below
-    // wave 0 adds the eight rows in wave order and writes the workgroup's ONE partial row (the weight-gradient launch's last block
+    // one wave adds the eight rows in wave order and writes the workgroup's ONE partial row (the weight-gradient launch's last block
     // adds every row of every tile: one row per wave made that block's serial walk the tail of its launch).
     static_assert(RW_NW * NS * sizeof(double) <= 1024, "the metric rows live in the reduction scratch");
     if (y == 1) metric_partials<0, S_VLOSS>(lacc, sRed + wave * NS);
     else metric_partials<S_VLOSS, NS>(lacc, sRed + wave * NS);
     // ---- head parameter gradients of the workgroup's 64 rows -----------------------------------------------------------------
     // dW4[o][j] = sum_rows dOut[row][o] h3[row][j] on the matrix pipe: M = o, N = j, K = rows.  Every wave parks its h3 tiles
-    // (accumulator layout: lane (r16, kq) holds rows 4 kq .. 4 kq + 3 of column ct * 16 + r16) lane-linear in its group's -- now
-    // dead -- slab; wave w then takes column tiles 2 w, 2 w + 1 over all 64 rows: two k-steps of 32 rows, k slot jj <-> row
+    // (accumulator layout: lane (r16, kq) holds rows 4 kq .. 4 kq + 3 of column ct * 16 + r16) lane-linear in their groups' -- now
+    // dead -- slabs; wave w then takes column tiles 2 w, 2 w + 1 over all 64 rows: two k-steps of 32 rows, k slot jj <-> row
     // (jj >> 2) * 16 + 4 kq + (jj & 3) of a group pair, dOut split into three bf16 planes (exact, see split3).
-    {
-        bf16x4* park = reinterpret_cast<bf16x4*>(Xb);
 #pragma unroll
-        for (int t = 0; t < RW_CT; ++t) park[(ct0 + t) * 64 + lane] = kept[1][t];
+    for (int rt = 0; rt < 2; ++rt) {
+        bf16x4* park = reinterpret_cast<bf16x4*>(rt == 0 ? Xb0 : Xb1);
+#pragma unroll
+        for (int t = 0; t < RW_CT; ++t) park[(ct0 + t) * 64 + lane] = kept[1][rt][t];
     }
     ring_barrier();  // extra 4 of 5: parked tiles, dOut and d(log std) rows of every group, and the metric rows are complete
     ts.mark();
-    if (wave == 0 && lane < NS) {
+    if (wave == RW_NW - 1 && lane < NS) {  // (the last wave: wave 0 carries the bias / log-std gradients below)
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < RW_NW; ++w) v += sRed[w * NS + lane];
@@ -485,7 +524,7 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
             float av[8], lv[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const float* scr = reinterpret_cast<const float*>(lds + L::SCR + (2 * pr + (jj >> 2)) * L::SCR_BYTES);
+                const float* scr = scratch(2 * pr + (jj >> 2));
                 const int row = 4 * kq + (jj & 3);
                 av[jj] = scr[2 * 16 * MAX_OUT + row * MAX_OUT + r16];  // sH of that group
                 lv[jj] = scr[row * MAX_OUT + r16];                     // its d(loss)/d(log std) rows
@@ -493,8 +532,8 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
             const Split3 A = split3(av);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const bf16x4 lo = reinterpret_cast<const bf16x4*>(lds + L::SLAB + (2 * pr) * L::SLAB_BYTES)[(2 * wave + c) * 64 + lane];
-                const bf16x4 hi = reinterpret_cast<const bf16x4*>(lds + L::SLAB + (2 * pr + 1) * L::SLAB_BYTES)[(2 * wave + c) * 64 + lane];
+                const bf16x4 lo = reinterpret_cast<const bf16x4*>(slab(2 * pr))[(2 * wave + c) * 64 + lane];
+                const bf16x4 hi = reinterpret_cast<const bf16x4*>(slab(2 * pr + 1))[(2 * wave + c) * 64 + lane];
                 const bf16x8 B = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 g[c] = mfma3(A, B, g[c]);
             }
@@ -522,52 +561,66 @@ __global__ __launch_bounds__(RW_THREADS) void ppo_step_fused_bf16_rows_kernel(St
     }
     ts.mark();
     // ---- dZ3 = (dOut . W4) * (1 - h3^2): K = n_out is tiny, f32 operands -> v_mfma_f32_16x16x4_f32 -----------------------------
-    bf16x4 dv[RW_CT];
+    bf16x4 dv[2][RW_CT];
     {
-        f32x4 dz[RW_CT];
+        f32x4 dz[2][RW_CT];
 #pragma unroll
-        for (int t = 0; t < RW_CT; ++t) dz[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int t = 0; t < RW_CT; ++t) dz[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *sH0 = scratch(2 * rp) + 2 * 16 * MAX_OUT, *sH1 = scratch(2 * rp + 1) + 2 * 16 * MAX_OUT;
         for (int ks = 0; ks < (n_out + 3) / 4; ++ks) {
-            const float av = sH[r16 * MAX_OUT + 4 * ks + kq];
+            const float av0 = sH0[r16 * MAX_OUT + 4 * ks + kq], av1 = sH1[r16 * MAX_OUT + 4 * ks + kq];
 #pragma unroll
             for (int t = 0; t < RW_CT; ++t) {
                 const float bv = W4s[(4 * ks + kq) * W4S + (ct0 + t) * 16 + r16];
-                dz[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, dz[t], 0, 0, 0);
+                dz[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv, dz[0][t], 0, 0, 0);
+                dz[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv, dz[1][t], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int t = 0; t < RW_CT; ++t)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dv[t][r] = (__bf16)(dz[t][r] * dtanh_b(kept[1][t][r]));
+            for (int t = 0; t < RW_CT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dv[rt][t][r] = (__bf16)(dz[rt][t][r] * dtanh_b(kept[1][rt][t][r]));
     }
     ring_barrier();  // extra 5 of 5: every wave has read the parked h3 tiles and the dOut rows: the slabs may be overwritten
 #pragma unroll
-    for (int t = 0; t < RW_CT; ++t) store_slab_quad(Xb, 0, (ct0 + t) * 16, dv[t]);
-    store_image(dv, dzy + 2 * tg.mat(), tg.nrb, rb, rhalf, ct0);
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < RW_CT; ++t) store_slab_quad(rt == 0 ? Xb0 : Xb1, 0, (ct0 + t) * 16, dv[rt][t]);
+    store_images(dv, dzy + 2 * tg.mat());
     ts.mark();
 
     // ---- backward-data chain -----------------------------------------------------------------------------------------------
-    row_gemm<NSLOT, RW_C_B3, HID / 32>(ring, Xb, half, true, acc);  // dH2 = dZ3 . W3
+    row_gemm<NSLOT, RW_C_B3, HID / 32>(ring, Xb0, Xb1, cq, true, acc);  // dH2 = dZ3 . W3
 #pragma unroll
-    for (int t = 0; t < RW_CT; ++t) {
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dv[t][r] = (__bf16)(acc[t][r] * dtanh_b(kept[0][t][r]));
-        store_slab_quad(Xb, 0, (ct0 + t) * 16, dv[t]);
-    }
-    store_image(dv, dzy + tg.mat(), tg.nrb, rb, rhalf, ct0);
-    {   // h1 back from its image (clamped row block: a group past the last block reads finite junk it never stores)
-        const int rbc = min(rb, tg.nrb - 1), kblk = 2 * rhalf + (kq >> 1);
+        for (int t = 0; t < RW_CT; ++t) {
 #pragma unroll
-        for (int t = 0; t < RW_CT; ++t)
-            h1v[t] = *reinterpret_cast<const bf16x4*>(hy + ((size_t)((ct0 + t) * tg.nrb + rbc) * 64 + kblk * 16 + r16) * 8 + 4 * (kq & 1));
+            for (int r = 0; r < 4; ++r) dv[rt][t][r] = (__bf16)(acc[rt][t][r] * dtanh_b(kept[0][rt][t][r]));
+            store_slab_quad(rt == 0 ? Xb0 : Xb1, 0, (ct0 + t) * 16, dv[rt][t]);
+        }
+    store_images(dv, dzy + tg.mat());
+    {   // h1 back from its image (clamped row block: a pair past the last block reads finite junk it never stores)
+        const int rbc = min(rb, tg.nrb - 1);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int t = 0; t < RW_CT; ++t)
+                h1v[rt][t] = *reinterpret_cast<const bf16x4*>(hy + ((size_t)((ct0 + t) * tg.nrb + rbc) * 64 + (2 * rt + (kq >> 1)) * 16 + r16) * 8 + 4 * (kq & 1));
     }
     ts.mark();
-    row_gemm<NSLOT, RW_C_B2, HID / 32>(ring, Xb, half, false, acc);  // dH1 = dZ2 . W2
+    row_gemm<NSLOT, RW_C_B2, HID / 32>(ring, Xb0, Xb1, cq, false, acc);  // dH1 = dZ2 . W2
 #pragma unroll
-    for (int t = 0; t < RW_CT; ++t)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dv[t][r] = (__bf16)(acc[t][r] * dtanh_b(h1v[t][r]));
-    store_image(dv, dzy, tg.nrb, rb, rhalf, ct0);
+        for (int t = 0; t < RW_CT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[rt][t][r] = (__bf16)(acc[rt][t][r] * dtanh_b(h1v[rt][t][r]));
+    store_images(dv, dzy);
     ts.mark();
     if constexpr (STAMPS) {
         if (a.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 1 && threadIdx.x == 0) {
@@ -608,8 +661,19 @@ int launch_fused_rows_bf16(const StepArgs& a, void* st_tiles, int tiles64, hipSt
     {                                                                                                                                \
         const size_t bytes = RowsLds<NSLOT, W4R>::BYTES;                                                                             \
         if (int rc = set_lds_rows(ppo_step_fused_bf16_rows_kernel<NSLOT, W4R, ST>, bytes)) return rc;                                \
-        hipLaunchKernelGGL((ppo_step_fused_bf16_rows_kernel<NSLOT, W4R, ST>), dim3(tiles64, 2), dim3(RW_THREADS), bytes, st, a, stt); \
+        hipLaunchKernelGGL((ppo_step_fused_bf16_rows_kernel<NSLOT, W4R, ST>), dim3(tiles64, 2), dim3(RW_THREADS), bytes, st, ad, stt); \
     }
+    const int dev = dev_variant("RLX_ROWS_DEV", 0);
+    if (dev != 0 || a.xcd_rows != 0) {  // development only: timing experiments that break the results
+        static int last = -1;
+        if (last != dev) {
+            const int skip = (dev >> 1) & 1;
+            RLX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_dev_skip_reads), &skip, sizeof(int)));
+            last = dev;
+        }
+    }
+    StepArgs ad = a;
+    ad.xcd_rows = dev;
     const int nslot = dev_variant("RLX_ROWS_NSLOT", 3);  // 32 KiB ring slots (3 fit beside the 16-row head image, 2 beside the 8-row one too)
     if (a.stamps != nullptr) {
         if (op8) RLX_ROWS_LAUNCH(3, 8, true) else RLX_ROWS_LAUNCH(2, 16, true)

@@ -338,11 +338,16 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     pl.head_parts = (bf16 && rows) ? pl.tiles : pl.tiles * (bm / 32);
     pl.loss_slots = pl.tiles;
     // 20 GEMM items per slab.  Every slab is 1.15 MB written here and read back by the slab reduce through the memory side:
-    // measured (round 2, after the head-reduce tail fix) 16 slabs = 1.25 workgroups per CU is the best trade -- weight-gradient
-    // launch 16.2 us + slab reduce 9.1 us, against 15.8 + 10.4 us with 24 slabs (2 per CU, no second round)
+    // (round 2, the LDS-DMA kernel with the copies in the compute waves: 16 slabs = 1.25 workgroups per CU was its best trade --
+    // 16.2 us + slab reduce 9.1 us, against 15.8 + 10.4 us with 24 slabs)
     // (the exact-f32 launch is bound by the f32 matrix pipe, not by slab bytes: it keeps 2 workgroups per CU in one round --
     //  measured 71 us with 24 slabs against 97 us with 16)
-    int want = bf16 ? 5 * num_cu() / (4 * 20) : 2 * num_cu() / 20;
+    // bf16, round 4 (ring weight-gradient launch: loader waves, one 64 KiB workgroup per CU): every workgroup of the launch -- 20 GEMM
+    // items + 2 head-reduce blocks per slab + 1 -- resident at once, NONE sharing a CU: 10 slabs on 256 CUs.  Measured on one box
+    // (profiles/r04_dw_ring_slab_sweep.txt): 16 slabs 19.9 us (353 blocks: a CU with two of them sets the launch's duration),
+    // 12: 21.8 (265 blocks), 11: 15.6, 10: 15.6, 9: 16.4, 8: 17.2 -- against 16.8 for the previous kernel at its best (16 slabs);
+    // the slab reduce behind it 8.84 -> 8.16 us with 10.
+    int want = bf16 ? std::max(1, (num_cu() - 1) / 25) : 2 * num_cu() / 20;
     if (const char* e = getenv("RLX_DW_SLABS")) want = std::max(1, atoi(e));  // development: tools/bench_step.py sweeps it
     // ... and at least 256 rows (8 k-blocks) per slab: a data-parallel rank's small minibatch should not pay 16 slabs of traffic
     int slabs = std::max(1, std::min(want, ceil_div(m, 256)));

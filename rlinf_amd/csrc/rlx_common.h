@@ -69,6 +69,19 @@ __device__ __forceinline__ long long wave_sum(long long v) {
     return v;
 }
 
+// Touch every 64-byte line of the first BYTES of the kernel-argument block at kernel start (scalar loads, all in flight together).
+// A kernel whose argument structs span many lines otherwise pays one scalar-cache miss -- a trip to memory, microseconds when the
+// chip is busy -- at every FIRST use of a new line, serially, wherever in the kernel that use happens to be.
+template <int BYTES>
+__device__ __forceinline__ void touch_kernargs() {
+    typedef const __attribute__((address_space(4))) unsigned* kptr;
+    kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned touch = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) touch |= kp[16 * i];
+    asm volatile("" ::"s"(touch));
+}
+
 // Block-wide sum of K doubles per thread.  `scratch` must hold K * (blockDim.x/64) doubles.
 // Result valid in thread 0 only.  Deterministic (fixed tree).
 template <int K>

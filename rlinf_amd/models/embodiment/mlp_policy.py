@@ -96,7 +96,7 @@ class MLPPolicy(nn.Module):
                 off = (off + 3) // 4 * 4  # (the kernels want 16-byte aligned weight matrices)
                 self._phantom_offsets[name] = off
                 off += math.prod(shp)
-        self.n_params = off
+        self.n_params = off if self.has_value_head else (off + 3) // 4 * 4  # (whole float4s: the slab kernels' vector paths)
         self.flat = nn.Parameter(torch.empty(self.n_params, dtype=torch.float32))
         self.layout = self._make_layout()
         self._packed = None

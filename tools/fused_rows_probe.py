@@ -30,6 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--sizes", default="8192,4096,2048,1024")
+    ap.add_argument("--dev", action="store_true", help="add the development variants (RLX_ROWS_DEV: results are garbage, timing only)")
     args = ap.parse_args()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     raw.rlx_dev_set_timing_buffer.argtypes = [ctypes.c_void_p]
@@ -40,8 +41,11 @@ def main():
                              value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
     row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
     buf = torch.zeros(64, dtype=torch.int64, device="cuda")
-    variants = [("cols32", dict(RLX_FUSED_ROWS="0", RLX_FUSED_RT="2")), ("rows6", dict(RLX_FUSED_ROWS="1", RLX_ROWS_NSLOT="6")),
-                ("rows4", dict(RLX_FUSED_ROWS="1", RLX_ROWS_NSLOT="4")), ("rows3", dict(RLX_FUSED_ROWS="1", RLX_ROWS_NSLOT="3"))]
+    variants = [("cols32", dict(RLX_FUSED_ROWS="0", RLX_FUSED_RT="2", RLX_ROWS_DEV="0")), ("rows", dict(RLX_FUSED_ROWS="1", RLX_ROWS_NSLOT="3")),
+                ("rows-2slot", dict(RLX_ROWS_NSLOT="2"))]
+    if args.dev:  # timing experiments that break the results: no weight copies / no fragment reads / neither
+        variants += [("rows-nodma", dict(RLX_ROWS_NSLOT="3", RLX_ROWS_DEV="1")), ("rows-noread", dict(RLX_ROWS_DEV="2")),
+                     ("rows-neither", dict(RLX_ROWS_DEV="3"))]
     for M in [int(x) for x in args.sizes.split(",")]:
         mb = minibatch(M, torch.Generator().manual_seed(1))
         ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
@@ -65,9 +69,12 @@ def main():
             rel = float((g - ref).norm() / ref.norm())
             print(f"M={M:5d} {name:7s}: fused + dW {e0.elapsed_time(e1) * 1e3 / args.iters:7.2f} us eager   |grad - cols32| / |cols32| = {rel:.2e}"
                   f"   loss {float(row[0]):.6f}", flush=True)
-            if name == "rows6":
+            if name.startswith("rows"):
                 raw.rlx_dev_set_timing_buffer(buf.data_ptr())
-                for rep in range(3):
+                for rep in range(2 if name == "rows" else 1):
+                    buf.zero_()
+                    step()
+                    step()
                     buf.zero_()
                     step()
                     torch.cuda.synchronize()

@@ -29,6 +29,8 @@ for STEP in "$@"; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     rows_probe)
       timeout 300 python tools/fused_rows_probe.py > gpurun_out/${TAG}_rows_probe.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_probe.txt ;;
+    rows_dev)
+      timeout 300 python tools/fused_rows_probe.py --dev --sizes 8192,1024 --iters 100 > gpurun_out/${TAG}_rows_dev.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_dev.txt ;;
     rows_probe_prof)
       rm -rf gpurun_out/prof_rows
       timeout 400 rocprofv3 --kernel-trace -d gpurun_out/prof_rows -o rows -- python tools/fused_rows_probe.py --iters 100 > gpurun_out/${TAG}_rows_probe_prof.log 2>&1
@@ -52,6 +54,21 @@ for STEP in "$@"; do
         RLX_FUSED_ROWS=$ROWS timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_bench_rows${ROWS}.log 2>&1
         echo "rows=$ROWS rc=$? $(tail -1 gpurun_out/${TAG}_bench_rows${ROWS}.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"
       done ;;
+    dw_ab)
+      for RING in 0 1 0 1; do
+        RLX_DW_RING=$RING timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_bench_ring${RING}.log 2>&1
+        echo "ring=$RING rc=$? $(tail -1 gpurun_out/${TAG}_bench_ring${RING}.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"
+      done
+      timeout 120 python tools/phase_times.py 8192 2>/dev/null | grep "dw bf16" | tail -2 ;;
+    dw_slabs)
+      for CFG in ${DW_CFGS:-0:16 1:16 1:12 1:11 1:10 1:9 1:8 0:10}; do
+        set -- ${CFG//:/ }
+        rm -rf gpurun_out/prof_dw
+        export RLX_DW_RING_NBUF=${3:-4}
+        RLX_DW_RING=$1 RLX_DW_SLABS=$2 timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_dw -o dw -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_dw_prof.log 2>&1
+        echo "ring=$1 slabs=$2 nbuf=${3:-4}: $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_dw)" rlx | grep "dw_bf16\|grad_reduce\|clip_adamw\|fused_bf16" | awk '{printf "%s %s | ", substr($2,6,22), $(NF-7)}')"
+        RLX_DW_RING=$1 RLX_DW_SLABS=$2 timeout 300 python bench.py --steps 60 --no-cpu-baseline --no-roofline --no-variants 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   bench', d['ms_per_step'])"
+      done; rm -rf gpurun_out/prof_dw ;;
     bench_prof)
       rm -rf gpurun_out/prof_bench
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-traffic --no-variants > gpurun_out/${TAG}_bench_prof.log 2>&1
