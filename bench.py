@@ -607,6 +607,16 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         w = runner.actor.worker
+        # who actually took part: ranks from the process group, physical devices from every rank's (host, device uuid)
+        ranks_seen, devices_seen = 1, 1
+        if world > 1:
+            import socket
+            props = torch.cuda.get_device_properties(dev)
+            ident = (socket.gethostname(), str(getattr(props, "uuid", dev.index)))
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+            ranks_seen, devices_seen = dist.get_world_size(), len(set(idents))
+        xg = w._xgmi
         win = sorted((b - a) * 100.0 for a, b in zip(stamps[:-1], stamps[1:]))  # ms per iteration over each 10-step window
         updates = (envs // world * HORIZON // (gb // world)) * UPDATE_EPOCH
         return {"env_steps_per_sec": round(envs * HORIZON * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 3),
@@ -615,6 +625,11 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
                 "ppo_updates_per_sec": round(updates * steps / elapsed, 1), "steps": steps, "total_envs": envs, "global_batch": gb,
                 "grad_allreduce": w.grad_allreduce_backend + (f" ({w._xgmi.algo}, {w._xgmi.wait_mode} hand-shake)" if w._xgmi is not None else ""),
                 "update_graph_replayed": w._graph is not None, "elapsed_s": round(elapsed, 4),
+                "ranks_seen": ranks_seen, "devices_seen": devices_seen,
+                # the exchange this run REALLY used: the hand-written one only when its start-up validation against
+                # torch.distributed's all-reduce passed on every rank (scheduler.xgmi.build), else RCCL -- whatever was asked for
+                "xgmi": (None if xg is None else {"validated_against_torch_distributed": True, "algo": xg.algo, "wait_mode": xg.wait_mode,
+                                                  "mem_kind": getattr(xg, "mem_kind", None), "ranks_share_a_device": bool(xg.shared_device)}),
                 "metrics_read": "every iteration, one iteration late (runner.defer_metrics)" if DEFER_METRICS else "every iteration, before the next is queued",
                 "last_metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in m.items()
                                  if k in ("train/actor/total_loss", "train/actor/grad_norm", "train/actor/approx_kl", "rollout/rewards")}}
@@ -679,9 +694,16 @@ def main():
     # ---- the timed regions ------------------------------------------------------------------------------------------------
     runs, errors = {}, {}
 
+    def trusted(v):
+        """A run may carry the headline `value` if its gradient exchange is torch.distributed's (RCCL) -- or the hand-written xGMI
+        exchange AFTER its start-up validation passed with every rank on a device of its own (ranks sharing a device exercise the
+        protocol, not the links)."""
+        return v["xgmi"] is None or not v["xgmi"]["ranks_share_a_device"]
+
     def best(regime):
         c = [(v["env_steps_per_sec"], tr, v) for (rg, tr), v in runs.items() if rg == regime]
-        return max(c, key=lambda x: x[0]) if c else None
+        ok = [x for x in c if trusted(x[2])]
+        return max(ok or c, key=lambda x: x[0]) if c else None
 
     def assemble():
         """The JSON line from whatever has been measured so far (None before the first headline-regime run exists)."""
@@ -713,11 +735,19 @@ def main():
             "last_metrics": head["last_metrics"],
         }
         if args.gpus > 1:
+            line["ranks_seen"], line["devices_seen"] = head["ranks_seen"], head["devices_seen"]
+            line["value_transport"] = {"asked": top[1], "used": head["grad_allreduce"], "trusted": trusted(head)}
+            xr = [v for (rg, tr), v in runs.items() if v["xgmi"] is not None]
+            asked_xgmi = [f"{rg}/{tr}" for (rg, tr), v in runs.items() if tr == "xgmi"]
+            line["xgmi_validation"] = (dict(xr[0]["xgmi"], passed=True) if xr else
+                                       {"passed": False, "note": "no run used the hand-written exchange" + (
+                                           " (asked for in " + ", ".join(asked_xgmi) + ": validation failed or RLX_GRAD_ALLREDUCE forced RCCL; those runs used RCCL)"
+                                           if asked_xgmi else "")})
             other = "weak" if args.scaling == "strong" else "strong"
             ob = best(other)
             line[f"{other}_scaling"] = None if ob is None else {k: ob[2][k] for k in (
                 "env_steps_per_sec", "ms_per_step", "ms_per_step_windows", "ppo_updates_per_sec", "total_envs", "global_batch", "grad_allreduce")}
-            line["transports"] = {f"{rg}/{tr}": {k: v[k] for k in ("env_steps_per_sec", "ms_per_step", "grad_allreduce", "update_graph_replayed")}
+            line["transports"] = {f"{rg}/{tr}": {k: v[k] for k in ("env_steps_per_sec", "ms_per_step", "grad_allreduce", "update_graph_replayed", "devices_seen")}
                                   for (rg, tr), v in runs.items()}
             if errors:
                 line["transport_errors"] = dict(errors)

@@ -39,7 +39,7 @@ class XgmiAllReduce:
         self.ctx, self.n_max = ctx, int(n_max)
         self._lib = _lib.load()
         self._comm = ctypes.c_void_p()
-        self.algo = "direct"
+        self.algo = "rsag" if ctx.world_size >= 4 else "direct"  # the library's default (rlx_xgmi_create): configure() changes it only when asked
         self.wait_mode = "inline"
         handle = (ctypes.c_char * XGMI_HANDLE_BYTES)()
         err = None
@@ -93,7 +93,8 @@ class XgmiAllReduce:
         a = -1 if algo is None else self._ALGOS[algo]
         w = -1 if wait_mode is None else self._WAITS[wait_mode]
         _lib.check(self._lib.rlx_xgmi_configure(self._comm, a, w, int(timeout_ms)), "rlx_xgmi_configure")
-        self.algo = algo if algo is not None else ("rsag" if self.ctx.world_size >= 4 else "direct")
+        if algo is not None:
+            self.algo = algo
         if wait_mode is not None:
             self.wait_mode = wait_mode
 

@@ -1,4 +1,5 @@
-"""One rank of a world_size-2 job (launched by tests/test_distributed.py with RANK / WORLD_SIZE / MASTER_* set).
+"""One rank of a world_size-W job (W = 2, or 8 for the whole-learner test; launched by tests/test_distributed.py with RANK /
+WORLD_SIZE / MASTER_* set).
 
 mode "cpu": host-side data-parallel logic on CPU tensors over gloo (no kernels).
 mode "gpu": the full runner on a (shared) GPU, gradients all-reduced over gloo; dumps what the parent compares.
@@ -99,16 +100,17 @@ def gpu_main(out_path, precision, transport="xgmi", graph="0", backend="gloo"):
     os.environ["RLX_DIST_BACKEND"] = backend
     os.environ["RLX_GRAD_ALLREDUCE"] = transport
     T, B, GB = 12, 64, 192
-    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=GB // 2, hip_graph=graph == "1")
+    W = int(os.environ["WORLD_SIZE"])
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=GB // W, hip_graph=graph == "1")
     cfg.actor.model.precision = precision
     env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
     torch.manual_seed(11)
     sd = copy.deepcopy(O.OracleMLPPolicy(42, 8, 1).state_dict())
     runner = _build(cfg, env, sd)
     ctx = runner.actor.worker.ctx
-    assert ctx.world_size == 2
+    assert ctx.world_size == W
     eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
-    lo, hi = ctx.rank * (B // 2), (ctx.rank + 1) * (B // 2)
+    lo, hi = ctx.rank * (B // W), (ctx.rank + 1) * (B // W)
     metrics = runner.run_step(eps[:, lo:hi].cuda())
     rb = runner.actor.worker.rollout_batch
     first = dict(params=runner.actor.worker.model.flat.detach().cpu().clone(), advantages=rb["advantages"].cpu().clone(),
@@ -141,13 +143,15 @@ def gpu_main(out_path, precision, transport="xgmi", graph="0", backend="gloo"):
     if ctx.rank == 1:
         version = syncer.apply(replica, lambda: patch)
     dist.broadcast(master["w"], src=0), dist.broadcast(master["b"], src=0)
-    sync_ok = ctx.rank == 0 or all(torch.equal(replica[k], master[k].to(torch.bfloat16)) for k in master)
+    sync_ok = ctx.rank != 1 or all(torch.equal(replica[k], master[k].to(torch.bfloat16)) for k in master)  # (rank 1 is the replica)
     w = runner.actor.worker
     torch.save(dict(rank=ctx.rank, metrics=metrics, params=first["params"], advantages=first["advantages"], returns=first["returns"],
                     actions=first["actions"], rewards=first["rewards"], sync_ok=bool(sync_ok), sync_version=version,
                     patch_nnz=patch.nnz_per_tensor.tolist(), backend=w.grad_allreduce_backend, iters=iters,
                     final_params=w.model.flat.detach().cpu(), graph_live=w._graph is not None,
-                    graph_enabled=bool(w.enable_hip_graph)), out_path)
+                    graph_enabled=bool(w.enable_hip_graph),
+                    xgmi=(None if w._xgmi is None else dict(algo=w._xgmi.algo, wait_mode=w._xgmi.wait_mode, shared_device=w._xgmi.shared_device))),
+               out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -16,11 +16,11 @@ from conftest import ROOT
 WORKER = os.path.join(ROOT, "tests", "helpers", "dp_worker.py")
 
 
-def _launch(mode, tmp_path, *extra, port=29611, timeout=300, one_device=True):
+def _launch(mode, tmp_path, *extra, port=29611, timeout=300, one_device=True, world=2, env_extra=None):
     procs, outs = [], []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0" if one_device else str(rank), WORLD_SIZE="2",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0" if one_device else str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
         out = str(tmp_path / f"rank{rank}.out")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, WORKER, mode, out, *extra], env=env, stdout=subprocess.PIPE,
@@ -187,6 +187,75 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def _compare_with_the_sharded_oracle(outs, world):
+    """The reference arithmetic applied shard by shard for `world` ranks: per-rank rollout on its env slice, per-shard advantage
+    normalisation, per-rank shuffle with seed + rank, per-rank minibatches of global_batch / world, gradient MEAN, identical
+    clip + AdamW on every rank -- against what every rank dumped after its first iteration."""
+    from oracle import ppo_loop as L
+    from oracle import ppo_oracle as O
+    T, B, GB = 12, 64, 192
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    opt = O.build_adamw(ora)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    shards = []
+    for r in range(world):
+        sl = slice(r * B // world, (r + 1) * B // world)
+        env_r = {k: v[:, sl].contiguous() for k, v in env.items()}
+        batch = L.advantages(L.rollout(ora, env_r, eps[:, sl], 0.8, True), 0.8, 0.9, True)
+        perm = torch.randperm(T * B // world, generator=torch.Generator().manual_seed(1234 + r))
+        shards.append((batch, O.flatten_and_shuffle(batch, perm)))
+    n_mb = (T * B // world) // (GB // world)
+    for _ in range(2):  # update_epoch
+        chunks = [O.chunk_batch(flat, n_mb) for _, flat in shards]
+        for i in range(n_mb):
+            opt.zero_grad()
+            for r in range(world):
+                mb = chunks[r][i]
+                out = ora.evaluate(mb["forward_inputs"]["states"], mb["forward_inputs"]["action"])
+                shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8,
+                                             values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
+                loss, _ = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+                (loss / world).backward()  # DDP / FSDP average the per-rank gradients
+            gn = torch.nn.utils.clip_grad_norm_(ora.parameters(), 0.5)
+            if torch.isfinite(gn):
+                opt.step()
+    want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+    for r, o in enumerate(sorted(outs, key=lambda d: d["rank"])):
+        batch = shards[r][0]
+        torch.testing.assert_close(o["actions"], batch["forward_inputs"]["action"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(o["rewards"], batch["rewards"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(o["returns"], batch["returns"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(o["advantages"], batch["advantages"], rtol=1e-3, atol=1e-4)  # normalised per shard
+        diff = (o["params"] - want).abs()
+        steps = 2 * n_mb
+        assert float(diff.max()) <= 2 * 3e-4 * steps + 1e-6
+        assert float((diff > 2e-5).float().mean()) < 0.02
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["params"], o["params"])  # every rank holds the same weights after the update
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", ["1"])  # (iteration 0 of the graph case runs eagerly and captures: both launch styles in one ~2-minute run)
+def test_eight_ranks_on_one_gpu_match_the_sharded_oracle(tmp_path, graph):
+    """The WHOLE learner at world_size 8 -- the size the scaling benchmark runs at -- as eight processes sharing the one GPU of the
+    test box: env shards of 8, per-rank minibatches, the hand-written exchange in the form it takes from four ranks on
+    (reduce-scatter + the all-gather fused into the AdamW launch, hand-shake as a one-wave launch because the ranks share a
+    device), eager launches and the update phase as a replayed hipGraph on all eight ranks, against the reference arithmetic
+    applied shard by shard.  (Until round 4 world_size 8 was exercised in-process only, on the bare transport.)"""
+    outs = [torch.load(o, weights_only=False)
+            for o in _launch("gpu", tmp_path, "32", "xgmi", graph, "gloo", port=29671 + 2 * (graph == "1"), timeout=900, one_device=True, world=8,
+                             env_extra={"RLX_XGMI_TIMEOUT_MS": "120000"})]
+    assert len(outs) == 8 and all(o["backend"] == "xgmi" for o in outs), [o["backend"] for o in outs]
+    assert all(o["xgmi"] == dict(algo="rsag", wait_mode="kernel", shared_device=True) for o in outs), outs[0]["xgmi"]
+    if graph == "1":
+        assert all(o["iters"] == 3 and o["graph_live"] for o in outs), [(o["iters"], o["graph_live"]) for o in outs]
+        assert all(torch.equal(outs[0]["final_params"], o["final_params"]) for o in outs) and torch.isfinite(outs[0]["final_params"]).all()
+    assert all(o["sync_ok"] for o in outs)
+    _compare_with_the_sharded_oracle(outs, world=8)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("transport,graph,backend", [
     ("rccl", "0", "gloo"),   # torch.distributed all-reduce (gloo stands in for RCCL: it needs a device per rank)
@@ -204,10 +273,6 @@ def test_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph, backend,
     advantage normalisation, per-rank shuffle with seed + rank, per-rank minibatches of global_batch / 2, gradient mean
     (FSDP NO_SHARD, rlinf/hybrid_engines/fsdp/strategy/fsdp.py:480-496), identical clip + AdamW on every rank.  The two
     nccl cases run when the box has two GPUs (one rank per GPU, RCCL / xGMI for real)."""
-    import copy
-
-    from oracle import ppo_loop as L
-    from oracle import ppo_oracle as O
     outs = [torch.load(o, weights_only=False)
             for o in _launch("gpu", tmp_path, precision, transport, graph, backend, port=29613 + 2 * (graph == "1") + 4 * (transport == "rccl") + 8 * (backend == "nccl"),
                              timeout=300, one_device=backend != "nccl")]
@@ -221,45 +286,7 @@ def test_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph, backend,
     # the weight patch built by rank 0's kernels, broadcast, applied by rank 1's kernels onto its bf16 replica
     assert all(o["sync_ok"] for o in outs) and outs[1]["sync_version"] == 3
     assert outs[0]["patch_nnz"] == outs[1]["patch_nnz"] and sum(outs[0]["patch_nnz"]) > 0
-    T, B, GB = 12, 64, 192
-    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
-    torch.manual_seed(11)
-    ora = O.OracleMLPPolicy(42, 8, 1)
-    opt = O.build_adamw(ora)
-    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
-    shards = []
-    for r in range(2):
-        sl = slice(r * B // 2, (r + 1) * B // 2)
-        env_r = {k: v[:, sl].contiguous() for k, v in env.items()}
-        batch = L.advantages(L.rollout(ora, env_r, eps[:, sl], 0.8, True), 0.8, 0.9, True)
-        perm = torch.randperm(T * B // 2, generator=torch.Generator().manual_seed(1234 + r))
-        shards.append((batch, O.flatten_and_shuffle(batch, perm)))
-    n_mb = (T * B // 2) // (GB // 2)
-    for _ in range(2):  # update_epoch
-        chunks = [O.chunk_batch(flat, n_mb) for _, flat in shards]
-        for i in range(n_mb):
-            opt.zero_grad()
-            for r in range(2):
-                mb = chunks[r][i]
-                out = ora.evaluate(mb["forward_inputs"]["states"], mb["forward_inputs"]["action"])
-                shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8,
-                                             values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
-                loss, _ = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
-                (loss / 2).backward()  # DDP / FSDP average the per-rank gradients
-            gn = torch.nn.utils.clip_grad_norm_(ora.parameters(), 0.5)
-            if torch.isfinite(gn):
-                opt.step()
-    want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
-    for r, o in enumerate(sorted(outs, key=lambda d: d["rank"])):
-        batch = shards[r][0]
-        torch.testing.assert_close(o["actions"], batch["forward_inputs"]["action"], rtol=2e-4, atol=2e-5)
-        torch.testing.assert_close(o["rewards"], batch["rewards"], rtol=2e-4, atol=2e-5)
-        torch.testing.assert_close(o["returns"], batch["returns"], rtol=2e-4, atol=2e-5)
-        torch.testing.assert_close(o["advantages"], batch["advantages"], rtol=1e-3, atol=1e-4)  # normalised per shard
-        diff = (o["params"] - want).abs()
-        steps = 2 * n_mb
-        assert float(diff.max()) <= 2 * 3e-4 * steps + 1e-6
-        assert float((diff > 2e-5).float().mean()) < 0.02
+    _compare_with_the_sharded_oracle(outs, world=2)
     assert torch.equal(outs[0]["params"], outs[1]["params"])  # both ranks hold the same weights after the update
 
 
@@ -283,6 +310,12 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell(tmp_path):
     assert line["weak_scaling"]["total_envs"] == 2048 and line["weak_scaling"]["global_batch"] == 16384
     assert set(line["transports"]) == {"strong/rccl-eager", "strong/xgmi", "strong/rccl", "weak/xgmi", "weak/rccl"}, line.get("transport_errors")
     assert line["transports"]["strong/rccl-eager"]["update_graph_replayed"] is False
+    # who took part, and which run may carry `value`: both ranks share the box's one GPU, so the hand-written exchange -- validated,
+    # but not over links -- must NOT be the headline: the value comes from a torch.distributed run
+    assert line["ranks_seen"] == 2 and line["devices_seen"] == 1
+    assert line["xgmi_validation"]["passed"] is True and line["xgmi_validation"]["ranks_share_a_device"] is True
+    assert line["value_transport"]["trusted"] is True and line["value_transport"]["asked"] in ("rccl-eager", "rccl")
+    assert line["value"] == line["transports"]["strong/" + line["value_transport"]["asked"]]["env_steps_per_sec"]
     assert line["transports"]["strong/xgmi"]["grad_allreduce"].startswith("xgmi (direct, kernel hand-shake)")
     assert line["transports"]["strong/xgmi"]["update_graph_replayed"] is True    # a pure kernel chain: captured at any world size
     assert line["transports"]["strong/rccl"]["update_graph_replayed"] is False   # gloo cannot be captured: eager fallback, both ranks
