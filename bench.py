@@ -75,12 +75,16 @@ def build_cfg(world: int, use_graph: bool, precision: str = "32", pipeline: bool
                    fsdp_config=dict(strategy="fsdp", sharding_strategy="no_shard"))))
 
 
-def build_runner(cfg, ctx):
+def build_runner(cfg, ctx, learner: str = "sync"):
+    """``learner`` "async": AsyncPPOEmbodiedFSDPActor behind the same runner (decoupled actor-critic loss: SURVEY.md 8f-4)."""
     from rlinf_amd.config import validate_cfg
     from rlinf_amd.runners import EmbodiedRunner
     from rlinf_amd.workers.actor import EmbodiedFSDPActor
     from rlinf_amd.workers.env import EnvWorker
     from rlinf_amd.workers.rollout.hf import MultiStepRolloutWorker
+    if learner == "async":
+        from rlinf_amd.workers.actor.async_ppo_fsdp_worker import AsyncPPOEmbodiedFSDPActor as EmbodiedFSDPActor  # noqa: F811
+        cfg.algorithm.loss_type = "decoupled_actor_critic"
     cfg = validate_cfg(cfg)
     actor = EmbodiedFSDPActor.create_group(cfg, ctx).launch(None, name="ActorGroup")
     rollout = MultiStepRolloutWorker.create_group(cfg, ctx).launch(None, name="RolloutGroup")
@@ -387,69 +391,58 @@ def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 3
             "value_max_based": round(rows / t[-1], 1)}
 
 
-def _pick_cpu_threads(pol, budget_s: float = 6.0):
-    """torch's default (one thread per logical core) oversubscribes the small GEMMs of this path badly on a
-    many-core host (256 threads: ~2.7 s per rollout step).  Time one minibatch-sized forward at a few thread counts and
-    keep the fastest -- that is the thread count reported as `cores`."""
+CPU_BASELINE_THREADS = 32  # a FIXED, stated torch thread count (capped by the schedulable cores): no per-run timing probe
+
+
+def _cpu_threads():
+    """torch's default (one thread per logical core) oversubscribes the small GEMMs of this path badly on a many-core host (256
+    threads: ~2.7 s per rollout step); rounds 2-3 picked the count by a timing probe per run (it landed on 32 on every 256-core
+    box, but made the baseline depend on a few noisy samples).  Now: min(32, schedulable cores), stated in the line."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    x = torch.randn(GLOBAL_BATCH, OBS_DIM)
-    best, best_t, t_start = 1, float("inf"), time.perf_counter()
-    for nt in (1, 2, 4, 8, 16, 32, 64, 128):
-        if nt > avail or time.perf_counter() - t_start > budget_s:
-            break
-        torch.set_num_threads(nt)
-        with torch.no_grad():
-            pol.value_head.mlp(x)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                pol.value_head.mlp(x)
-            dt = time.perf_counter() - t0
-        if dt < best_t:
-            best, best_t = nt, dt
-    torch.set_num_threads(best)
-    return best, avail
+    threads = max(1, min(CPU_BASELINE_THREADS, avail))
+    torch.set_num_threads(threads)
+    return threads, avail
 
 
-def cpu_baseline_reference(update_budget_s: float = 15.0):
+def cpu_baseline_reference():
     """kind "reference": the reference's OWN functions on the host cores (oracle/reference_loop.py: its MLPPolicy, its
     calculate_adv_and_returns and policy_loss with their built-in callees, torch's clip_grad_norm_ + AdamW), loaded from the
-    staged copy oracle/_ref (or /root/reference).  One full rollout + advantage pass, then 3 untimed optimizer steps and ALL 128
-    timed ones when they fit in ``update_budget_s`` of CPU work (else as many as fit, the rest extrapolated from the median).
-    The step times of a many-core host are bimodal (thread placement), so the line carries the value under every reading --
-    measured total (the headline when all steps ran), min-, median- and mean-based -- and nobody has to quote one ratio."""
+    staged copy oracle/_ref (or /root/reference).  SURVEY.md 8d's recipe: one full rollout + advantage pass, then 3 warm-up and 10
+    timed optimizer steps; the update phase = MEDIAN step x 128.  The step times of a many-core host are bimodal (thread
+    placement: rounds 2-3 saw mean 43 ms against median 22 ms), so `value` rests on the median and the line also carries the
+    value under the lower / upper quartile step time -- that, not min / max, is the range a speed-up may be quoted with."""
     from oracle import ppo_loop as L
     from oracle import reference_loader as RL
     from oracle import reference_loop as RLoop
     if not RL.available():
         return None
-    ref, pol, _ = RLoop.build(OBS_DIM, ACT_DIM)
-    threads, avail = _pick_cpu_threads(pol)
+    threads, avail = _cpu_threads()
     env = L.synthetic_env_tensors(1234, HORIZON, ENVS, OBS_DIM, max_episode_steps=50)
     t0 = time.perf_counter()
     t = RLoop.timed_iteration(env, obs_dim=OBS_DIM, act_dim=ACT_DIM, gamma=GAMMA, gae_lambda=LAMBDA, global_batch=GLOBAL_BATCH,
-                              update_epoch=UPDATE_EPOCH, warmup_steps=3, timed_steps=None, update_budget_s=update_budget_s)
+                              update_epoch=UPDATE_EPOCH, warmup_steps=3, timed_steps=10)
     spent = time.perf_counter() - t0
     total, steps = t["update_steps_total"], sorted(t["timed_step_times_s"])
     fixed = t["rollout_s"] + t["advantages_s"]
-    full = len(steps) == total
-    med, mean = steps[len(steps) // 2], sum(steps) / len(steps)
-    iter_s = fixed + (sum(steps) if full else med * total)
+    q = lambda f: steps[min(len(steps) - 1, max(0, int(round(f * (len(steps) - 1)))))]  # noqa: E731
+    med, lo, hi = q(0.5), q(0.25), q(0.75)
     val = lambda per_step: round(ENVS * HORIZON / (fixed + per_step * total), 1)  # noqa: E731
-    return {"value": round(ENVS * HORIZON / iter_s, 1), "unit": "env-steps/s", "cores": threads, "kind": "reference",
+    return {"value": val(med), "unit": "env-steps/s", "cores": threads, "kind": "reference",
             "sample": f"the reference's own MLPPolicy / calculate_adv_and_returns / policy_loss + torch clip_grad_norm_ / AdamW "
                       f"(files staged under oracle/_ref): 1 full rollout of {HORIZON}x{ENVS} + GAE, then 3 warm-up + {len(steps)} timed "
-                      f"optimizer steps of {GLOBAL_BATCH} rows out of {total}"
-                      + (" (the whole update phase, measured)" if full else f" (update phase = median step x {total})")
-                      + f"; {spent:.1f} s of CPU work; torch threads picked by a timing probe out of {avail} schedulable cores",
-            "host_cores": avail, "value_is": "measured total" if full else "median-based",
-            "value_min_based": val(steps[0]), "value_median_based": val(med), "value_mean_based": val(mean), "value_max_based": val(steps[-1]),
-            "updates_per_sec": round(1.0 / mean, 2), "rollout_s": round(t["rollout_s"], 3),
-            "advantages_s": round(t["advantages_s"], 4), "update_s_per_step": {"min": round(steps[0], 4), "median": round(med, 4),
-                                                                               "mean": round(mean, 4), "max": round(steps[-1], 4)},
-            "update_steps_timed": len(steps), "iteration_s": round(iter_s, 3)}
+                      f"optimizer steps of {GLOBAL_BATCH} rows; update phase = median step x {total}; {spent:.1f} s of CPU work; "
+                      f"torch.set_num_threads({threads}) (fixed: min({CPU_BASELINE_THREADS}, {avail} schedulable cores))",
+            "host_cores": avail, "value_is": "median-based",
+            "value_lower_quartile_step": val(lo), "value_upper_quartile_step": val(hi),
+            "value_min_based": val(lo), "value_max_based": val(hi),  # (the keys speedup_vs_cpu_baseline_range reads: quartiles since round 4)
+            "updates_per_sec": round(1.0 / med, 2), "rollout_s": round(t["rollout_s"], 3),
+            "advantages_s": round(t["advantages_s"], 4),
+            "update_s_per_step": {"min": round(steps[0], 4), "lower_quartile": round(lo, 4), "median": round(med, 4),
+                                  "upper_quartile": round(hi, 4), "max": round(steps[-1], 4)},
+            "update_steps_timed": len(steps), "iteration_s": round(fixed + med * total, 3)}
 
 
 def cpu_baseline(budget_s: float = 20.0):
@@ -475,7 +468,7 @@ def cpu_baseline_port(budget_s: float = 20.0):
     torch.manual_seed(1234)
     pol = O.OracleMLPPolicy(OBS_DIM, ACT_DIM, 1)
     opt = O.build_adamw(pol)
-    threads, avail = _pick_cpu_threads(pol)
+    threads, avail = _cpu_threads()
     env = L.synthetic_env_tensors(1234, HORIZON, ENVS, OBS_DIM, max_episode_steps=50)
     eps = torch.randn(HORIZON, ENVS, ACT_DIM, generator=torch.Generator().manual_seed(1))
     total_updates = (ENVS * HORIZON // GLOBAL_BATCH) * UPDATE_EPOCH
@@ -495,8 +488,8 @@ def cpu_baseline_port(budget_s: float = 20.0):
     iter_s = (t1 - t0) + (t2 - t1) + per_update * total_updates
     return {"value": round(ENVS * HORIZON / iter_s, 1), "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"1 full rollout of {HORIZON}x{ENVS} + GAE + {len(done)} of {total_updates} optimizer steps "
-                      f"(rest of the update phase extrapolated); {t4 - t0:.1f} s of CPU work; torch threads picked by a "
-                      f"timing probe out of {avail} schedulable cores",
+                      f"(rest of the update phase extrapolated); {t4 - t0:.1f} s of CPU work; torch.set_num_threads({threads}) "
+                      f"(fixed: min({CPU_BASELINE_THREADS}, {avail} schedulable cores))",
             "host_cores": avail, "updates_per_sec": round(1.0 / per_update, 2), "rollout_s": round(t1 - t0, 3),
             "advantages_s": round(t2 - t1, 4), "update_s_per_step": round(per_update, 4),
             "iteration_s": round(iter_s, 3)}
@@ -549,7 +542,8 @@ def self_launch(args) -> int:
 
 
 def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup: int, use_graph: bool = True,
-            pipeline: bool = False, rollout_epochs: int = 1, overlap: bool = True, transport: str | None = None) -> dict:
+            pipeline: bool = False, rollout_epochs: int = 1, overlap: bool = True, transport: str | None = None,
+            learner: str = "sync") -> dict:
     """One timed region: W untimed iterations, then exactly ``steps`` iterations between barrier + synchronize on both sides,
     MAX over ranks.  ``scaling``: strong = 1024 envs / 8192-row global batch in total, weak = that much PER GPU.  Also returns
     the spread of the iteration time over 10-step windows (host time stamps taken when a window's last step has landed on the host)."""
@@ -564,7 +558,7 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
         os.environ["RLX_GRAD_ALLREDUCE"] = "rccl" if transport == "rccl-eager" else transport
         update_graph = False if transport == "rccl-eager" else None
     runner = build_runner(build_cfg(world, use_graph, precision, pipeline=pipeline, rollout_epochs=rollout_epochs, overlap=overlap,
-                                    total_envs=envs, global_batch=gb, update_graph=update_graph), ctx)
+                                    total_envs=envs, global_batch=gb, update_graph=update_graph), ctx, learner=learner)
 
     def barrier():
         if world > 1:
@@ -644,7 +638,12 @@ DEFER_METRICS = os.environ.get("RLX_BENCH_DEFER_METRICS", "1") != "0"  # 0: read
 WORKLOAD = ("ManiSkill PickCube-shaped PPO: 1024 envs x 128 steps, obs 42, act 8, MLP policy (3x256 tanh actor + value head), "
             "gamma 0.8 / lambda 0.9, 8 epochs x 16 minibatches of 8192 (128 optimizer steps), {prec}, synthetic env tensors "
             "resident in HBM")
-PREC_TEXT = {"bf16": "bf16 MFMA operands / f32 accumulate, master weights, losses, GAE, AdamW", "32": "exact-f32 MFMA"}
+PREC_TEXT = {"bf16": "bf16 MFMA operands / f32 accumulate, master weights, losses, GAE, AdamW",
+             # precision "32": the fused launch on the exact f32 MFMA; the weight-gradient launch forms its f32 products from 3 x bf16
+             # splits (6 of the 9 partial products: what is dropped lies below the f32 accumulation's own rounding) unless
+             # RLX_F32_EXACT_MFMA=1 selects the exact f32 MFMA there too
+             "32": ("f32: exact-f32 MFMA (fused launch and weight gradients)" if os.environ.get("RLX_F32_EXACT_MFMA", "0") not in ("", "0")
+                    else "f32: exact-f32 MFMA in the fused launch, f32-accurate 3 x bf16-split MFMA products in the weight-gradient launch")}
 
 
 def main():
@@ -823,14 +822,19 @@ def main():
                 out = []
                 vs = dict(steps=args.variant_steps, warmup=args.warmup, use_graph=use_graph)
                 other = "32" if args.precision == "bf16" else "bf16"
-                for name, kw in ((f"precision {'f32 (exact-f32 MFMA: the precision the reference YAML ships)' if other == '32' else 'bf16'}",
+                for name, kw in ((f"precision {'f32 (' + PREC_TEXT['32'] + ': the precision the reference YAML ships)' if other == '32' else 'bf16'}",
                                   dict(precision=other)),
                                  ("pipeline mode, 4 rollout epochs, rollout of epoch e + 1 overlapping the training on epoch e",
                                   dict(precision=args.precision, pipeline=True, rollout_epochs=4)),
                                  ("pipeline mode, 1 rollout epoch (statistics normalisation + per-stage shuffles only)",
-                                  dict(precision=args.precision, pipeline=True, rollout_epochs=1))):
+                                  dict(precision=args.precision, pipeline=True, rollout_epochs=1)),
+                                 # the learner of async / decoupled PPO at the same configuration.  Its update phase still
+                                 # runs stage by stage (f32 training forward -> decoupled loss -> backward, eager launches): measured,
+                                 # not yet on the fused / hipGraph path of the synchronous learner
+                                 ("async learner (decoupled actor-critic loss), stage-by-stage f32 update phase, eager",
+                                  dict(precision="32", learner="async", steps=max(5, args.variant_steps // 10)))):
                     try:
-                        r = measure(ctx, **vs, **kw)
+                        r = measure(ctx, **{**vs, **kw})
                         out.append({"variant": name, "dtype": "f32" if kw["precision"] == "32" else "bf16", "metric": "env_steps_per_sec",
                                     "value": r["env_steps_per_sec"], "ms_per_step": r["ms_per_step"], "ms_per_step_windows": r["ms_per_step_windows"],
                                     "ppo_updates_per_sec": r["ppo_updates_per_sec"], "steps": r["steps"]})

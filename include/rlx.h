@@ -774,6 +774,10 @@ int rlx_xgmi_configure(rlx_xgmi_comm* comm, int algo, int wait_mode, int timeout
 int rlx_xgmi_destroy(rlx_xgmi_comm* comm);
 /* 0 = ok, 1 = a peer wait timed out since the last call (cleared by the call; synchronises the stream's device first). */
 int rlx_xgmi_status(rlx_xgmi_comm* comm);
+/* Asynchronous form for a loop that reads its metrics late: *dst (device f32) = the status word as it stands when the launch runs on
+ * `stream`, i.e. behind the exchanges queued so far -- it travels to the host with the step's metric vector; nothing is cleared and
+ * the host is not blocked (rlx_xgmi_status above is a blocking read on the null stream that also clears the word). */
+int rlx_xgmi_status_snapshot(rlx_xgmi_comm* comm, float* dst, rlx_stream_t stream);
 /* out[i] = scale * sum_r in_r[i]; `in` is this rank's contribution ([slabs][n], summed first), out a local buffer. */
 int rlx_xgmi_allreduce_f32(rlx_xgmi_comm* comm, const float* in, int slabs, float* out, int64_t n, float scale,
                            void* workspace, size_t workspace_bytes /* rlx_adamw_workspace_bytes(n) */, rlx_stream_t stream);

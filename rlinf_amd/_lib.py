@@ -235,6 +235,7 @@ PROTOTYPES = {
     "rlx_xgmi_configure": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rlx_xgmi_destroy": (c_int, [c_void_p]),
     "rlx_xgmi_status": (c_int, [c_void_p]),
+    "rlx_xgmi_status_snapshot": (c_int, [c_void_p, c_void_p, c_void_p]),
     "rlx_xgmi_allreduce_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
     "rlx_xgmi_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          POINTER(AdamwParams), c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -890,7 +890,11 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     d.M = s->m; d.rows_per_slab = pl.rows_per_slab; d.slabs = pl.slabs; d.tiles = pl.loss_slots; d.head_parts = pl.head_parts;
     d.head_stride = pl.head_stride;
     d.gemm_items = pl.slabs * 20; d.grads = s->grads; d.p = p; d.has_mask = s->loss_mask != nullptr;
+#ifdef RLX_DEV_VARIANTS  // timing tool only (the sums come out multiplied): not reachable in the product build
     d.repeat = std::max(1, dev_variant("RLX_DW_REPEAT", 1));
+#else
+    d.repeat = 1;
+#endif
     d.has_msum = s->loss_mask_sum != nullptr; d.out = s->out;
     const int dw_blocks = round_up(d.gemm_items, 8) + pl.slabs * 2 + 1;
     if (bf16) {

@@ -663,7 +663,11 @@ int launch_fused_rows_bf16(const StepArgs& a, void* st_tiles, int tiles64, hipSt
         if (int rc = set_lds_rows(ppo_step_fused_bf16_rows_kernel<NSLOT, W4R, ST>, bytes)) return rc;                                \
         hipLaunchKernelGGL((ppo_step_fused_bf16_rows_kernel<NSLOT, W4R, ST>), dim3(tiles64, 2), dim3(RW_THREADS), bytes, st, ad, stt); \
     }
+#ifdef RLX_DEV_VARIANTS  // timing experiments that BREAK the results (no weight copies / no fragment reads): development builds only
     const int dev = dev_variant("RLX_ROWS_DEV", 0);
+#else
+    const int dev = 0;
+#endif
     if (dev != 0 || a.xcd_rows != 0) {  // development only: timing experiments that break the results
         static int last = -1;
         if (last != dev) {

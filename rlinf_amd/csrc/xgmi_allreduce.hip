@@ -275,6 +275,15 @@ extern "C" int rlx_xgmi_status(rlx_xgmi_comm* c) {
     return st != 0 ? 1 : 0;
 }
 
+__global__ void xgmi_status_snapshot_kernel(const int* __restrict__ status, float* __restrict__ dst) { *dst = (float)*status; }
+
+extern "C" int rlx_xgmi_status_snapshot(rlx_xgmi_comm* c, float* dst, rlx_stream_t stream) {
+    RLX_REQUIRE(c != nullptr && dst != nullptr, "rlx_xgmi_status_snapshot: NULL argument");
+    hipLaunchKernelGGL(xgmi_status_snapshot_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), c->status, dst);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
 extern "C" int rlx_xgmi_allreduce_f32(rlx_xgmi_comm* c, const float* in, int slabs, float* out, int64_t n, float scale,
                                       void* workspace, size_t workspace_bytes, rlx_stream_t stream) {
     if (int rc = check(c, n, "rlx_xgmi_allreduce_f32")) return rc;

@@ -120,6 +120,13 @@ class XgmiAllReduce:
         with torch.cuda.device(self.ctx.device):
             return self._lib.rlx_xgmi_status(self._comm) == 0
 
+    def status_snapshot(self, dst: torch.Tensor) -> torch.Tensor:
+        """dst[0] (device f32) = the status word behind everything queued on the current stream; asynchronous, clears nothing.  The
+        run-ahead loop appends it to a step's metric vector and calls check_status() only when it arrives non-zero."""
+        with torch.cuda.device(self.ctx.device):
+            _lib.check(self._lib.rlx_xgmi_status_snapshot(self._comm, dst.data_ptr(), _stream_ptr(self.ctx.device)), "rlx_xgmi_status_snapshot")
+        return dst
+
     def check_status(self):
         """Raises when a peer wait timed out since the last call (a rank died or never reached the all-reduce)."""
         if not self.status_ok():

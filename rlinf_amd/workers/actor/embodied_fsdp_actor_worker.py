@@ -802,8 +802,16 @@ class EmbodiedFSDPActor(Worker):
         # a replayed graph ran every step at the current rates and logs nothing per step
         log = list(self._lr_log) or [(self._lrs[0], self._lrs[1])]
         xgmi = self._xgmi
+        snap = xgmi is not None and self.defer_host_reads
+        if snap:  # the exchange's status word rides along with THIS step's numbers (a blocking read here would wait for the whole queue,
+            #       and one iteration late it would report -- and clear -- the NEXT step's time-out)
+            vec = torch.cat([vec, xgmi.status_snapshot(torch.empty(1, dtype=torch.float32, device=vec.device))])
 
         def finish(host: list) -> dict:
+            if snap:
+                timed_out, host = host[-1] != 0.0, host[:-1]
+                if timed_out:
+                    xgmi.check_status()  # raises (and clears the word): a peer never published its gradient during this step
             out = {k: host[PPO_OUT_NAMES[k]] for k in _ACTOR_KEYS}
             if has_critic:
                 out.update({k: host[PPO_OUT_NAMES[k]] for k in _CRITIC_KEYS})
@@ -816,8 +824,6 @@ class EmbodiedFSDPActor(Worker):
             critic = [c for _, c in log if c is not None]
             if critic:
                 out["critic/lr"] = float(np.mean(critic))
-            if xgmi is not None and self.defer_host_reads:
-                xgmi.check_status()  # a peer that never published its gradient: raise instead of reporting garbage
             return out
 
         if self.defer_host_reads:  # the runner reads one iteration late (utils/pending.py)

@@ -2,8 +2,8 @@
 ``runner.use_training_pipeline`` -- it trains micro-batches while the env side is still producing them.
 
 Mirrored here, with the reference's names: ``GlobalBatchState`` (:32-35), ``compute_micro_batches`` (:211-232),
-``try_recv_micro_batch`` / ``recv_micro_batch`` (:56-76), ``select_global_batch`` (:78-84) and the scheduling loop of
-``run_training`` (:86-196) -- newly arrived micro-batches first; a complete global batch gets its optimizer step and is stored with
+``try_recv_micro_batch`` / ``recv_micro_batch`` (:56-76), ``select_global_batch`` (:78-84); the scheduling policy of
+``run_training`` (:86-196) is restated over counters in ``training_schedule`` -- newly arrived micro-batches first; a complete global batch gets its optimizer step and is stored with
 train_count 1; with nothing pending the learner takes the stored global batch with the LOWEST train count (oldest first) and
 trains it again; with nothing stored either it blocks on the channel; done when every global batch has been trained
 ``update_epoch`` times.
@@ -21,7 +21,7 @@ scripted channel and checks that both produce the same training order, arrival p
 
 from __future__ import annotations
 
-from collections import defaultdict, deque
+from collections import deque
 from dataclasses import dataclass, field
 
 from .embodied_fsdp_actor_worker import EmbodiedFSDPActor
@@ -110,45 +110,36 @@ class PipelineEmbodiedFSDPActor(EmbodiedFSDPActor):
                 return global_batches[epoch].popleft()
         return None
 
-    # ---- the scheduling loop of run_training (:86-165), on descriptors ---------------------------------------------------
+    # ---- the training order, derived from the arrival pattern -----------------------------------------------------------------
     def training_schedule(self, input_channel) -> list:
-        """-> [(pass k, global batch g)] in training order.  ``train_micro_batch`` / ``finish_global_batch`` of the reference's
-        loop become "append to the order": the arithmetic runs afterwards, as prepared launches in exactly this order."""
+        """-> [(pass k, global batch g)] in training order -- the order the reference's run_training (:86-165) trains in, derived from
+        counters instead of queues of micro-batch objects (the arithmetic runs afterwards, as prepared launches in exactly this
+        order; tests/test_pipeline_schedule.py holds it to the reference's own loop, arrival pattern by arrival pattern).
+
+        The policy: (1) take every micro-batch that has ALREADY arrived; (2) global batch g -- arrivals g A .. (g + 1) A - 1 for
+        gradient-accumulation A -- gets its first pass as soon as its last micro-batch is there; (3) with no first pass to give,
+        revisit the stored global batch with the fewest passes so far, oldest first; (4) with nothing stored either, wait for one
+        more arrival; done when every global batch has had ``update_epoch`` passes."""
+        accum, n_micro, n_global, passes = self.gradient_accumulation, self.micro_batches_per_step, self.global_batches_per_step, self.update_epoch
         order: list = []
-        global_batches = defaultdict(deque)
-        current_global_batch: list = []
-        pending_global_batch: deque = deque()
-        received_micro_batch_count = 0
-        next_id = 0
-        while True:
-            while received_micro_batch_count < self.micro_batches_per_step:
-                micro_batch = self.try_recv_micro_batch(input_channel)
-                if micro_batch is None:
-                    break
-                pending_global_batch.append(micro_batch)
-                received_micro_batch_count += 1
-            while pending_global_batch:
-                micro_batch = pending_global_batch.popleft()
-                is_last_micro_batch = len(current_global_batch) == self.gradient_accumulation - 1
-                current_global_batch.append(micro_batch)
-                if is_last_micro_batch:  # finish_global_batch: the optimizer step of a first pass
-                    state = GlobalBatchState(micro_batches=current_global_batch, train_count=1)
-                    state.index = next_id
-                    next_id += 1
-                    order.append((0, state.index))
-                    global_batches[1].append(state)
-                    current_global_batch = []
-            if len(global_batches[self.update_epoch]) == self.global_batches_per_step:
-                break
-            global_batch = self.select_global_batch(global_batches)
-            if global_batch is None:
-                if received_micro_batch_count < self.micro_batches_per_step:
-                    pending_global_batch.append(self.recv_micro_batch(input_channel))
-                    received_micro_batch_count += 1
-                continue
-            order.append((global_batch.train_count, global_batch.index))
-            global_batch.train_count += 1
-            global_batches[global_batch.train_count].append(global_batch)
+        arrived = 0                                          # micro-batches taken off the channel
+        first_passes = 0                                     # global batches 0 .. first_passes - 1 have had pass 0
+        had = [deque() for _ in range(passes + 1)]           # had[c]: global batches with c passes behind them, oldest first
+        while len(had[passes]) < n_global:
+            while arrived < n_micro and self.try_recv_micro_batch(input_channel) is not None:
+                arrived += 1
+            while (first_passes + 1) * accum <= arrived:     # complete global batches, in arrival order
+                order.append((0, first_passes))
+                had[1].append(first_passes)
+                first_passes += 1
+            fewest = next((c for c in range(1, passes) if had[c]), None)
+            if fewest is not None:
+                g = had[fewest].popleft()
+                order.append((fewest, g))
+                had[fewest + 1].append(g)
+            elif arrived < n_micro and len(had[passes]) < n_global:
+                self.recv_micro_batch(input_channel)         # nothing to revisit: block for the next micro-batch
+                arrived += 1
         return order
 
     def _pipeline_schedule(self, E: int, n_e: int, passes: int) -> list:

@@ -267,8 +267,6 @@ def test_chunk_level_reward_with_token_level_logprobs(loss_type, masked, logprob
     keeps its own ratio.  With logprob_type='action_level' and C > 1 every chunk keeps a ratio (sum over action_dim) under the
     one advantage / mask element of its env step, and the ratio metrics divide by the UN-broadcast mask count (the reference
     only expands the mask for 3-D ratios, losses.py:288-290)."""
-    if logprob_type == "action_level" and loss_type == "decoupled_actor_critic":
-        pytest.skip("the decoupled loss is shipped with token_level log-probs only")
     from rlinf_amd.algorithms import registry
 
     g = torch.Generator().manual_seed(23)

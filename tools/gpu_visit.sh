@@ -29,6 +29,9 @@ for STEP in "$@"; do
       ( unset RANK LOCAL_RANK WORLD_SIZE MASTER_ADDR MASTER_PORT; export RLX_BENCH_ALLOW_SHARED_GPU=1 RLX_DIST_BACKEND=gloo RLX_XGMI_TIMEOUT_MS=120000
         T0=$SECONDS; timeout 1700 python bench.py --gpus 8 --steps 3 --warmup 1 --no-roofline --launch-timeout 1600 --pair-timeout 500 > gpurun_out/${TAG}_bench8.json 2> gpurun_out/${TAG}_bench8.err
         echo "rc=$? wall=$((SECONDS - T0)) s"; tail -1 gpurun_out/${TAG}_bench8.json | cut -c1-1500 ) ;;
+    loss_tests)
+      timeout 600 python -m pytest tests/test_gpu_losses.py -x -q -m gpu -k "chunk_level_reward_with_token_level" > gpurun_out/${TAG}_loss_tests.log 2>&1
+      echo "rc=$?"; tail -25 gpurun_out/${TAG}_loss_tests.log | cut -c1-300 ;;
     all_tests)
       timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1
       echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest_gpu.log ;;
