@@ -445,6 +445,28 @@ def cpu_baseline_reference():
             "update_steps_timed": len(steps), "iteration_s": round(fixed + med * total, 3)}
 
 
+def cpu_baseline_subprocess(timeout_s: float = 240.0):
+    """cpu_baseline() in a process of its own with its OpenMP team PINNED (OMP_NUM_THREADS = the stated thread count, OMP_PROC_BIND =
+    close, OMP_PLACES = cores).  In-process, behind the GPU work, the step times of a many-core host were bimodal (22 ms / 70 ms:
+    the OpenMP threads migrating between cores under the process's other threads): three slow samples in ten moved every quantile."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(CPU_BASELINE_THREADS, avail))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores",
+               OMP_WAIT_POLICY="active", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], env=env, capture_output=True, text=True,
+                       timeout=timeout_s)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu baseline subprocess failed (rc {r.returncode}): {r.stderr[-300:]}")
+    out = json.loads(lines[-1])
+    out["sample"] += "; own process, OpenMP team pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)"
+    return out
+
+
 def cpu_baseline(budget_s: float = 20.0):
     """The reference's own functions when its files are reachable (kind "reference"), else the oracle port (kind "port")."""
     try:
@@ -672,8 +694,12 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 job: kill it after this many seconds")
     ap.add_argument("--pair-timeout", type=float, default=240.0, help="N > 1: seconds one (regime, transport) measurement may take "
                     "before the watchdog prints the line assembled so far and ends the job")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline and print its object")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         sys.exit(self_launch(args))  # bare shell: become the launcher
 
@@ -847,7 +873,7 @@ def main():
             if not args.no_token_tier:
                 extra("roofline_widening", lambda: token_tier_roofline(dev))
         if not args.no_cpu_baseline:
-            extra("cpu_baseline", cpu_baseline)
+            extra("cpu_baseline", cpu_baseline_subprocess)
             if line.get("roofline_widening"):
                 extra("cpu_baseline_token_tier", token_tier_cpu_baseline)
             if line.get("cpu_baseline"):

@@ -1346,7 +1346,10 @@ int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int til
     if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)
         hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
     } else {
-        if (dev_variant("RLX_DW_RING", 1) != 0) {
+        // The ring kernel pays a longer prologue (the loaders' first hand-off) for its faster k-loop and store phase: it wins from
+        // 4096 rows on (8192 rows, one box: 15.6 against 16.8 us, the slab reduce behind it 8.2 against 8.8), at 1024 rows the
+        // previous kernel is ahead (9.4 against 10.5 us: profiles/r04_per_rank_share_*.txt).  RLX_DW_RING = 0 / 1 forces one.
+        if (dev_variant("RLX_DW_RING", d.M >= 4096 ? 1 : 0) != 0) {
 #define RLX_DWR_LAUNCH(NB)                                                                                                         \
     {                                                                                                                              \
         const size_t rlds = (size_t)(NB) * DW_BUF_BYTES;                                                                           \

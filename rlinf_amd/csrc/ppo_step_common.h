@@ -347,7 +347,7 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     // (profiles/r04_dw_ring_slab_sweep.txt): 16 slabs 19.9 us (353 blocks: a CU with two of them sets the launch's duration),
     // 12: 21.8 (265 blocks), 11: 15.6, 10: 15.6, 9: 16.4, 8: 17.2 -- against 16.8 for the previous kernel at its best (16 slabs);
     // the slab reduce behind it 8.84 -> 8.16 us with 10.
-    int want = bf16 ? std::max(1, (num_cu() - 1) / 25) : 2 * num_cu() / 20;
+    int want = bf16 ? (m >= 4096 ? std::max(1, (num_cu() - 1) / 25) : 5 * num_cu() / (4 * 20)) : 2 * num_cu() / 20;  // (below 4096 rows: the previous kernel and its plan)
     if (const char* e = getenv("RLX_DW_SLABS")) want = std::max(1, atoi(e));  // development: tools/bench_step.py sweeps it
     // ... and at least 256 rows (8 k-blocks) per slab: a data-parallel rank's small minibatch should not pay 16 slabs of traffic
     int slabs = std::max(1, std::min(want, ceil_div(m, 256)));

@@ -56,7 +56,7 @@ for STEP in "$@"; do
         RLX_FUSED_ROWS=$ROWS timeout 120 python tools/per_rank_share.py --share $SH --steps 50 2>/dev/null | grep "ms / iteration" | sed "s/^/untraced rows=$ROWS: /" | tee -a gpurun_out/${TAG}_share${SH}_rows${ROWS}.log
       done; done ;;
     bench)
-      timeout 600 python bench.py > gpurun_out/${TAG}_bench.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench.log | cut -c1-600 ;;
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench.json | cut -c1-300 ;;
     bench_quick)
       timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_bench_quick.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_quick.log | cut -c1-400 ;;
     bench_ab)
@@ -81,8 +81,8 @@ for STEP in "$@"; do
       done; rm -rf gpurun_out/prof_dw ;;
     bench_prof)
       rm -rf gpurun_out/prof_bench
-      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-traffic --no-variants > gpurun_out/${TAG}_bench_prof.log 2>&1
-      echo "rc=$?"; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_bench)" > gpurun_out/${TAG}_bench_kernels.txt 2>&1; head -14 gpurun_out/${TAG}_bench_kernels.txt; rm -rf gpurun_out/prof_bench ;;
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-variants --no-token-tier > gpurun_out/${TAG}_bench_prof.log 2>&1
+      echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_prof.log | cut -c1-200; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_bench)" > gpurun_out/${TAG}_bench_kernels.txt 2>&1; head -14 gpurun_out/${TAG}_bench_kernels.txt; rm -rf gpurun_out/prof_bench ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
