@@ -33,6 +33,10 @@
 
 #include <type_traits>
 
+#ifndef RLX_ROWS_NL
+#define RLX_ROWS_NL 2
+#endif
+
 #include "ppo_step_bf16_parts.h"
 
 namespace rlx {
@@ -44,7 +48,7 @@ using namespace b16;
 
 constexpr int RW_NG = 4, RW_BM = 16 * RW_NG;                      // row groups per workgroup, rows
 constexpr int RW_NW = 2 * RW_NG, RW_NT = 64 * RW_NW;              // compute waves (a pair per row group), compute threads
-constexpr int RW_NL = 2, RW_THREADS = RW_NT + 64 * RW_NL;         // + loader waves
+constexpr int RW_NL = RLX_ROWS_NL, RW_THREADS = RW_NT + 64 * RW_NL;  // + loader waves (4 = one per SIMD: measured slower, 32.7 vs 27.6 us)
 constexpr int RW_CT = 4;                                          // column tiles per compute wave (x 2 row groups)
 constexpr int RW_KSTEP = 16 * 1024;                               // one k-step of a layer: 16 column tiles x 1 KiB
 constexpr int RW_SLOT = 2 * RW_KSTEP;                             // a ring slot = two k-steps: one hand-off (barrier) per 16 MFMAs and wave
@@ -88,12 +92,14 @@ __device__ __forceinline__ void ring_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// Loader waves: wave lw copies column tiles 8 lw .. 8 lw + 7 of both k-steps of every slot, global -> LDS, AHEAD slots in flight.
+// Loader waves: wave lw copies column tiles TPL lw .. TPL lw + TPL - 1 (TPL = 16 / RW_NL) of both k-steps of every slot, global -> LDS,
+// AHEAD slots in flight.
+constexpr int RW_TPL = 16 / RW_NL, RW_DPS = 2 * RW_TPL;  // tiles per loader and k-step, copies per loader and slot
 template <int N>
-__device__ __forceinline__ void wait_slots_behind(int behind) {  // vmcnt(16 x behind): s_waitcnt takes an immediate
+__device__ __forceinline__ void wait_slots_behind(int behind) {  // vmcnt(RW_DPS x behind): s_waitcnt takes an immediate
     if constexpr (N > 0) {
         if (behind >= N) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * N) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RW_DPS * N) : "memory");
             return;
         }
         wait_slots_behind<N - 1>(behind);
@@ -104,7 +110,7 @@ __device__ __forceinline__ void wait_slots_behind(int behind) {  // vmcnt(16 x b
 template <int NSLOT>
 __device__ __forceinline__ void loader_main(const __bf16* __restrict__ tiles_y, char* ring, int lw, int lane, int dev) {
     constexpr int AHEAD = NSLOT - 1;
-    static_assert(AHEAD >= 1 && 16 * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
+    static_assert(AHEAD >= 1 && RW_DPS * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
     const __bf16* src = tiles_y + lane * 8;
     auto issue = [&](int s, int buf) {  // slot s: W1 (its two k-steps) or k-steps 2 j, 2 j + 1 of a 256 x 256 matrix
         if (dev & 1) return;  // development (RLX_ROWS_DEV bit 0, TIMING ONLY): no copies at all
@@ -116,8 +122,8 @@ __device__ __forceinline__ void loader_main(const __bf16* __restrict__ tiles_y, 
         const __bf16* g = src + off;
         char* dst = ring + buf * RW_SLOT;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int nt = (q >> 3) * 16 + 8 * lw + (q & 7);  // tile index inside the slot: k-step (q >> 3), column tile 8 lw + (q & 7)
+        for (int q = 0; q < RW_DPS; ++q) {
+            const int nt = (q / RW_TPL) * 16 + RW_TPL * lw + (q % RW_TPL);  // tile index inside the slot: k-step q / TPL, column tile TPL lw + q % TPL
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)nt * 512),
                                              (__attribute__((address_space(3))) void*)(dst + nt * 1024), 16, 0, 0);
         }
