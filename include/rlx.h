@@ -47,6 +47,12 @@ enum rlx_status {
 int rlx_version(void);
 const char* rlx_last_error(void);
 
+/* sizeof() of the argument structs below as THIS library was compiled, in declaration order (gae_params, ppo_loss_params,
+ * gather_field, adamw_group, adamw_params, mlp_layout, value_job, rollout_step, ppo_step_args, decoupled_loss_params,
+ * token_rows, token_loss_params, copy_segment): a binding written in another language checks its mirrors against these at
+ * load time instead of discovering a stale layout through a wrong result.  Writes min(n, 13) entries, returns 13. */
+int rlx_abi_struct_sizes(size_t* sizes, int n);
+
 /* Number of compute units / wave size of the current device (plumbing for launch heuristics). */
 int rlx_device_info(int* num_cu, int* wave_size);
 
@@ -222,6 +228,11 @@ int rlx_ppo_loss_bwd(const float* g_logp, const float* g_value, const float* out
  *     grad_logstd[a] -= entropy_bonus * grad_scale * elem_scale        (grad_scale = 1 / gradient_accumulation) */
 int rlx_gaussian_entropy_bonus(const float* logstd, int n_act, float* grad_logstd, float* out_row, float entropy_bonus,
                                float grad_scale, int has_mask, float elem_scale, rlx_stream_t stream);
+/* The same behind a decoupled rlx_ppo_step: grad_logstd is in SUM form there (a later multiplication by *actor_scale, a device
+ * float -- that step's out[RLX_PPO_ACTOR_GRAD_SCALE] -- finishes it), so the bonus term is divided by *actor_scale here. */
+int rlx_gaussian_entropy_bonus_deferred(const float* logstd, int n_act, float* grad_logstd, float* out_row, float entropy_bonus,
+                                        float grad_scale, int has_mask, float elem_scale, const float* actor_scale,
+                                        rlx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * a16  shuffle_gather  <- process_nested_dict_for_train, rlinf/utils/nested_dict_process.py:272-285
@@ -271,6 +282,14 @@ typedef struct rlx_adamw_params {
     const struct rlx_mlp_layout* tile_layout;
     float* tiles;
     int32_t tiles_bf16;      /* the image is the bf16 one (rlx_mlp_pack_tiles_bf16) */
+    /* optional: scales that only exist on the device when the slab sum runs (the decoupled rlx_ppo_step: 1 / count of the
+     * behaviour mask, left in its metric row).  The grad_partials slabs are deferred_groups consecutive groups (one per
+     * micro-batch); elements of the two ranges are multiplied by deferred_scale[g * deferred_stride] as group g is summed.
+     * NULL: none.  Single-rank rlx_clip_adamw_step only (the data-parallel exchanges refuse it). */
+    const float* deferred_scale;
+    int32_t deferred_stride;
+    int32_t deferred_groups;
+    int64_t deferred_range[2][2]; /* [begin, end) x 2; an empty range is begin == end */
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);
 /* out[i] = sum_k grads[k][i] (k < slabs): collapse the split-K slabs before a data-parallel all-reduce. */
@@ -425,6 +444,7 @@ int rlx_mlp_rollout_step(const rlx_rollout_step* step, rlx_stream_t stream);
  *   grads [slabs][n_params]: split-K gradient slabs, every element written (rlx_clip_adamw_step sums them);
  *   slabs must equal rlx_ppo_step_slabs(layout, m).  out: the rlx_ppo_out metric row (device).
  *   Needs obs_dim <= 64, act_dim, val_dim <= 16 and (has_critic) act_dim / raw_per_adv == val_dim. */
+struct rlx_decoupled_loss_params; /* a19b, below */
 typedef struct rlx_ppo_step_args {
     const float* params;
     const rlx_mlp_layout* layout;
@@ -447,6 +467,20 @@ typedef struct rlx_ppo_step_args {
     const float* tiles; /* optional: an up-to-date fragment-tile image of params (rlx_mlp_pack_tiles[_bf16], or -- f32 only --
                            kept fresh by rlx_clip_adamw_step); NULL = rlx_ppo_step packs one into its workspace first */
     int32_t bf16;       /* 1: bf16 MFMA operands; activations / gradients travel to the weight-gradient kernel as bf16 */
+    /* Optional: the DECOUPLED (asynchronous PPO) actor loss of a19b inside the fused step
+     *   <- AsyncPPOEmbodiedFSDPActor.run_training, rlinf/workers/actor/async_ppo_fsdp_worker.py:374-467
+     *      (policy_loss "decoupled_actor_critic": losses.py:27-167, :383-393).  NULL: the classic loss above.
+     *   decoupled->ppo is ignored (`loss` is used); proximal_logprobs (RLX_PROX_GIVEN) / versions (RLX_PROX_FROM_VERSIONS, else
+     *   optional): [m, act_dim] like old_logprobs.  current_version_dev: optional device float read when the launch EXECUTES
+     *   (instead of decoupled->current_version), so that a captured hipGraph can be replayed under the next policy version.
+     *   `out` is then the rlx_dppo_out row.  The denominator of the actor loss -- the count of the behaviour mask -- depends on
+     *   every row's forward, so the gradients of the ACTOR network (actor_logstd, backbone.*, actor_mean.*) leave in SUM form:
+     *   multiply them by out[RLX_PPO_ACTOR_GRAD_SCALE] (rlx_clip_adamw_step does: rlx_adamw_params.deferred_scale).  The value
+     *   network's gradients are final as always.  Not available on the row-split bf16 launch (RLX_FUSED_ROWS). */
+    const struct rlx_decoupled_loss_params* decoupled;
+    const float* proximal_logprobs;
+    const float* versions;
+    const float* current_version_dev;
 } rlx_ppo_step_args;
 int rlx_ppo_step_slabs(const rlx_mlp_layout* layout, int64_t m);                   /* bf16 == 0 */
 /* the split-K slab count depends on the operand precision (the f32 launch is bound by the matrix pipe and wants two

@@ -74,6 +74,8 @@ class AdamwParams(Structure):
         ("max_grad_norm", c_float), ("step", c_int32), ("n_groups", c_int32), ("grad_partials", c_int32),
         ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
         ("tile_layout", POINTER(MlpLayout)), ("tiles", c_void_p), ("tiles_bf16", c_int32),
+        ("deferred_scale", c_void_p), ("deferred_stride", c_int32), ("deferred_groups", c_int32),
+        ("deferred_range", (c_int64 * 2) * 2),
     ]
 
 
@@ -95,10 +97,12 @@ class PpoStepArgs(Structure):
                 ("states", c_void_p), ("action", c_void_p), ("old_logprobs", c_void_p), ("advantages", c_void_p),
                 ("prev_values", c_void_p), ("returns", c_void_p), ("loss_mask", c_void_p), ("loss_mask_sum", c_void_p),
                 ("m", c_int64), ("grad_out", c_float), ("grads", c_void_p), ("slabs", c_int32), ("out", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("tiles", c_void_p), ("bf16", c_int32)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("tiles", c_void_p), ("bf16", c_int32),
+                ("decoupled", c_void_p), ("proximal_logprobs", c_void_p), ("versions", c_void_p), ("current_version_dev", c_void_p)]
 
 
 PPO_OUT_FLOATS = 20
+PPO_ACTOR_GRAD_SCALE, PPO_CRITIC_GRAD_SCALE = 16, 17  # rlx_ppo_out / rlx_dppo_out: 1 / the loss denominators
 PPO_OUT_NAMES = {
     "loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, "actor/ratio": 3, "actor/ratio_abs": 4,
     "actor/clipped_ratio": 5, "actor/dual_cliped_ratio": 6, "actor/approx_kl": 7, "actor/clip_fraction": 8,
@@ -144,6 +148,7 @@ TOK_OUT_NAMES = {"loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, 
 PROTOTYPES = {
     "rlx_version": (c_int, []),
     "rlx_last_error": (c_char_p, []),
+    "rlx_abi_struct_sizes": (c_int, [c_void_p, c_int]),
     "rlx_device_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "rlx_done_prefix_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rlx_gae_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -159,6 +164,8 @@ PROTOTYPES = {
     "rlx_grpo_from_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rlx_episode_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rlx_gaussian_entropy_bonus": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_void_p]),
+    "rlx_gaussian_entropy_bonus_deferred": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_void_p,
+                                                    c_void_p]),
     "rlx_reward_filter_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "rlx_ppo_loss_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_ppo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
@@ -267,6 +274,15 @@ def load() -> ctypes.CDLL:
         fn.argtypes = argtypes
     if lib.rlx_version() < 100:
         raise RlxError("librlx_hip.so is older than this Python package; rebuild it")
+    mirrors = (GaeParams, PpoLossParams, GatherField, AdamwGroup, AdamwParams, MlpLayout, ValueJob, RolloutStep, PpoStepArgs,
+               DecoupledLossParams, TokenRows, TokenLossParams, CopySegment)  # the order rlx_abi_struct_sizes documents
+    sizes = (c_size_t * len(mirrors))()
+    if lib.rlx_abi_struct_sizes(ctypes.cast(sizes, c_void_p), len(mirrors)) != len(mirrors):
+        raise RlxError("librlx_hip.so and rlinf_amd/_lib.py disagree on the number of argument structs; rebuild the library")
+    for cls, size in zip(mirrors, sizes):
+        if ctypes.sizeof(cls) != size:
+            raise RlxError(f"{cls.__name__}: the ctypes mirror is {ctypes.sizeof(cls)} bytes, the library's struct {size}; "
+                           "rebuild librlx_hip.so (python -m rlinf_amd.csrc.build)")
     _lib = lib
     return lib
 

@@ -70,7 +70,16 @@ __global__ __launch_bounds__(64) void peer_wait_kernel(PeerWait w) {
     }
 }
 
-template <bool ADAM>
+// DEFER (single rank, one base): the slabs are a.deferred_groups consecutive groups (one per micro-batch of a decoupled
+// rlx_ppo_step); elements of a.deferred_range are multiplied by a.deferred_scale[g * a.deferred_stride] -- a value that step's
+// weight-gradient launch left on the device -- as group g is added.  Elements outside the ranges see x * 1.f: unchanged.
+__device__ __forceinline__ float deferred_factor(const rlx_adamw_params& a, long long idx, float sc) {
+    const bool in = (idx >= a.deferred_range[0][0] && idx < a.deferred_range[0][1]) ||
+                    (idx >= a.deferred_range[1][0] && idx < a.deferred_range[1][1]);
+    return in ? sc : 1.f;
+}
+
+template <bool ADAM, bool DEFER = false>
 __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* __restrict__ out, long long n, float scale,
                                                           double* __restrict__ partials, int* __restrict__ state,
                                                           rlx_adamw_params a, AdamScalars* __restrict__ scalars, PeerWait wait) {
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nslab = src.nslab, nbase = src.nbase;
-    const bool inplace_single = nbase == 1 && nslab == 1 && scale == 1.f && out == src.base[0];
+    const bool inplace_single = !DEFER && nbase == 1 && nslab == 1 && scale == 1.f && out == src.base[0];
     // float4 body (slab stride n*4 bytes keeps 16-byte alignment when n % 4 == 0), slabs unrolled four at a time so that
     // a lane has up to 64 bytes in flight; scalar tail / fallback below
     bool vec = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
@@ -99,7 +108,18 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
     const long long n4 = vec ? n / 4 : 0;
     for (long long i = tid0; i < n4; i += stride) {
         float4 g;
-        if (nbase == 1) {
+        if constexpr (DEFER) {
+            const int per = nslab / a.deferred_groups;
+            g = float4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < a.deferred_groups; ++q) {
+                const float4 x = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + (long long)q * per * n4 + i, n4, per);
+                const float sc = a.deferred_scale[(long long)q * a.deferred_stride];
+                const float4 f{deferred_factor(a, 4 * i, sc), deferred_factor(a, 4 * i + 1, sc), deferred_factor(a, 4 * i + 2, sc),
+                               deferred_factor(a, 4 * i + 3, sc)};
+                if (q == 0) { g.x = x.x * f.x; g.y = x.y * f.y; g.z = x.z * f.z; g.w = x.w * f.w; }
+                else { g.x += x.x * f.x; g.y += x.y * f.y; g.z += x.z * f.z; g.w += x.w * f.w; }
+            }
+        } else if (nbase == 1) {
             g = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + i, n4, nslab);  // opt_common.h
         } else {  // one staged gradient per rank, all peer loads in flight before the first add, fixed rank order
             float4 x[kMaxRanks];
@@ -116,8 +136,20 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
         acc[0] += (double)g.x * (double)g.x + (double)g.y * (double)g.y + (double)g.z * (double)g.z + (double)g.w * (double)g.w;
     }
     for (long long i = n4 * 4 + tid0; i < n; i += stride) {
-        float g = src.base[0][i];
-        for (int k = 1; k < nslab; ++k) g += src.base[0][(long long)k * n + i];
+        float g;
+        if constexpr (DEFER) {
+            const int per = nslab / a.deferred_groups;
+            g = 0.f;
+            for (int q = 0; q < a.deferred_groups; ++q) {
+                float x = src.base[0][(long long)q * per * n + i];
+                for (int k = 1; k < per; ++k) x += src.base[0][((long long)q * per + k) * n + i];
+                const float t = x * deferred_factor(a, i, a.deferred_scale[(long long)q * a.deferred_stride]);
+                g = q == 0 ? t : g + t;
+            }
+        } else {
+            g = src.base[0][i];
+            for (int k = 1; k < nslab; ++k) g += src.base[0][(long long)k * n + i];
+        }
         for (int b = 1; b < nbase; ++b) g += src.base[b][i];
         g *= scale;
         if (!inplace_single) out[i] = g;
@@ -484,8 +516,20 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
     AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + scalars_offset());
     PeerWait w{};
     if (wait != nullptr) w = *wait;
-    hipLaunchKernelGGL(grad_reduce_sqnorm<true>, dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
-                       step_state, *p, scalars, w);
+    if (p->deferred_scale != nullptr) {
+        RLX_REQUIRE(src.nbase == 1 && src.seq == nullptr && wait == nullptr,
+                    "rlx_clip_adamw_step: deferred_scale is a single-rank feature (the data-parallel exchanges do not apply it)");
+        RLX_REQUIRE(p->deferred_groups >= 1 && src.nslab % p->deferred_groups == 0 && p->deferred_stride >= 0,
+                    "rlx_clip_adamw_step: %d slabs do not split into deferred_groups=%d", src.nslab, p->deferred_groups);
+        for (int k = 0; k < 2; ++k)
+            RLX_REQUIRE(p->deferred_range[k][0] >= 0 && p->deferred_range[k][0] <= p->deferred_range[k][1] && p->deferred_range[k][1] <= n,
+                        "rlx_clip_adamw_step: deferred_range %d out of bounds", k);
+        hipLaunchKernelGGL((grad_reduce_sqnorm<true, true>), dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
+                           step_state, *p, scalars, w);
+    } else {
+        hipLaunchKernelGGL(grad_reduce_sqnorm<true>, dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
+                           step_state, *p, scalars, w);
+    }
     RLX_LAUNCH_CHECK();
     hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
                        partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc, status, GatherSrc{}, PeerWait{});

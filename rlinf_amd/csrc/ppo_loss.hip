@@ -129,13 +129,16 @@ __global__ __launch_bounds__(256) void ppo_loss_bwd_kernel(const float* g_lp, co
 // "token_level" and there is no loss mask (the mean then runs over the [mb, A] elements).
 __global__ __launch_bounds__(64) void entropy_bonus_kernel(const float* __restrict__ logstd, int n_act,
                                                            float* __restrict__ grad_logstd, float* __restrict__ out_row,
-                                                           float bonus, float grad_scale, int has_mask, float elem_scale) {
+                                                           float bonus, float grad_scale, int has_mask, float elem_scale,
+                                                           const float* __restrict__ actor_scale) {
     const int a = threadIdx.x;
+    // behind a decoupled rlx_ppo_step the logstd gradient is in sum form: pre-divide by the scale the slab sum applies later
+    const float undo = actor_scale != nullptr ? 1.f / actor_scale[0] : 1.f;
     const float on = (!has_mask || out_row[18] > 0.f) ? 1.f : 0.f;  // masked_mean over an all-False mask is the (zero) sum
     float e = 0.f;
     if (a < n_act) {
         e = 0.5f + 0.91893853320467274178f + logf(expf(logstd[a]));  // Normal.entropy() on scale = exp(logstd)
-        grad_logstd[a] -= bonus * grad_scale * elem_scale * on;
+        grad_logstd[a] -= bonus * grad_scale * elem_scale * on * undo;
     }
     e = wave_sum(e);
     if (a == 0) {
@@ -214,12 +217,26 @@ extern "C" int rlx_ppo_loss_bwd(const float* g_logp, const float* g_value, const
     return RLX_OK;
 }
 
+namespace {
+int entropy_bonus_launch(const float* logstd, int n_act, float* grad_logstd, float* out_row, float entropy_bonus, float grad_scale,
+                         int has_mask, float elem_scale, const float* actor_scale, rlx_stream_t stream) {
+    RLX_REQUIRE(logstd && grad_logstd && out_row && n_act >= 1 && n_act <= 64, "rlx_gaussian_entropy_bonus: bad argument");
+    hipLaunchKernelGGL(entropy_bonus_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), logstd, n_act,
+                       grad_logstd, out_row, entropy_bonus, grad_scale, has_mask, elem_scale, actor_scale);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+}  // namespace
+
 extern "C" int rlx_gaussian_entropy_bonus(const float* logstd, int n_act, float* grad_logstd, float* out_row,
                                           float entropy_bonus, float grad_scale, int has_mask, float elem_scale,
                                           rlx_stream_t stream) {
-    RLX_REQUIRE(logstd && grad_logstd && out_row && n_act >= 1 && n_act <= 64, "rlx_gaussian_entropy_bonus: bad argument");
-    hipLaunchKernelGGL(entropy_bonus_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), logstd, n_act,
-                       grad_logstd, out_row, entropy_bonus, grad_scale, has_mask, elem_scale);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
+    return entropy_bonus_launch(logstd, n_act, grad_logstd, out_row, entropy_bonus, grad_scale, has_mask, elem_scale, nullptr, stream);
+}
+
+extern "C" int rlx_gaussian_entropy_bonus_deferred(const float* logstd, int n_act, float* grad_logstd, float* out_row,
+                                                   float entropy_bonus, float grad_scale, int has_mask, float elem_scale,
+                                                   const float* actor_scale, rlx_stream_t stream) {
+    RLX_REQUIRE(actor_scale != nullptr, "rlx_gaussian_entropy_bonus_deferred: NULL actor_scale");
+    return entropy_bonus_launch(logstd, n_act, grad_logstd, out_row, entropy_bonus, grad_scale, has_mask, elem_scale, actor_scale, stream);
 }

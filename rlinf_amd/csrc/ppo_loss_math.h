@@ -101,6 +101,74 @@ __device__ __forceinline__ float critic_elem(const rlx_ppo_loss_params& p, float
     return gv;
 }
 
+// ---- decoupled (asynchronous) PPO actor, rlinf/algorithms/losses.py:27-167 -----------------------------------------------
+// The clipped surrogate is taken against the PROXIMAL policy (given, or the behaviour policy itself, or interpolated between
+// behaviour and current by the version distance of the sample: losses.py:72-89) and every term is importance-weighted by
+// exp(prox - behaviour), optionally masked where that weight exceeds behave_weight_threshold.  The proximal log-probs are
+// detached in the reference: no gradient flows through the interpolation.
+// Reduction slots of the decoupled actor: the classic actor's slots 1-8 re-used, plus the version sum (slot `ver_slot`: 16 in
+// the stand-alone kernel's 17-slot rows; the fused step parks it in slot S_VLOSS of the ACTOR network's partial row, which
+// the critic's sums -- they live in the value network's row -- leave free).
+enum { D_LOSS = S_LOSS, D_BM = S_ABS, D_PR = S_RATIO, D_CPR = S_RABS, D_CLIPF = S_CLIPPED, D_DUALF = S_DUAL, D_PKL = S_KL,
+       D_BKL = S_CLIPFRAC };
+struct DecoupledMode {
+    int mode;              // rlx_proximal_mode
+    int use_threshold;
+    float threshold;
+    float v_theta;         // current_version
+};
+// lp / old / px_given = summed log-probs of the element's slice (px_given only for RLX_PROX_GIVEN), vb = the slice's first
+// behaviour version (0 without versions).  Returns d(sum-form loss)/d(lp).
+template <int N>
+__device__ __forceinline__ float decoupled_actor_elem(const rlx_ppo_loss_params& p, const DecoupledMode& dm, float lp, float old,
+                                                      float px_given, float vb, float adv, bool on, float w, bool ratio_mode,
+                                                      double (&acc)[N], int ver_slot) {
+    const float mf = on ? 1.f : 0.f;
+    const float nadv = -adv;
+    float px = px_given;
+    if (dm.mode == RLX_PROX_FROM_VERSIONS) {
+        const float v_prox = dm.v_theta - 1.0f;
+        const float diff = fsub(dm.v_theta, vb), gap = fsub(v_prox, vb);
+        float alpha = (diff > 0.f && vb >= 0.f) ? gap / diff : 0.f;
+        alpha = fminf(fmaxf(alpha, 0.f), 1.f);
+        px = fadd(old, fmul(alpha, fsub(lp, old)));
+    } else if (dm.mode == RLX_PROX_IS_OLD) {
+        px = old;
+    }
+    const float lr = fsub(lp, px);
+    const float ratio = on ? expf(lr) : 0.f;
+    const float clipped = fminf(fmaxf(ratio, p.ratio_lo), p.ratio_hi);
+    const float pl1 = fmul(nadv, ratio), pl2 = fmul(nadv, clipped);
+    float pl = fmaxf(pl1, pl2);
+    const float w1 = tie_weight_gt(pl1, pl2);
+    const float in_rng = (ratio >= p.ratio_lo && ratio <= p.ratio_hi) ? 1.f : 0.f;
+    float dpl = nadv * (w1 + (1.f - w1) * in_rng);
+    bool dual = false;
+    if (p.use_dual_clip) {
+        const float sgn = adv > 0.f ? 1.f : (adv < 0.f ? -1.f : 0.f);
+        const float pl3 = fmul(fmul(sgn, p.clip_ratio_c), adv);
+        dual = pl3 < pl;
+        dpl *= tie_weight_lt(pl, pl3);
+        pl = fminf(pl, pl3);
+    }
+    const float bw = expf(fsub(px, old));
+    const bool bm = on && (!dm.use_threshold || bw <= dm.threshold);
+    const float bmf = bm ? 1.f : 0.f;
+    const float weighted = fmul(pl, bw);
+    acc[D_LOSS] += (double)(ratio_mode ? fmul(weighted / w, bmf) : fmul(weighted, bmf));
+    acc[D_BM] += bm ? 1.0 : 0.0;
+    acc[D_PR] += (double)fmul(ratio, mf);
+    acc[D_CPR] += (double)fmul(clipped, mf);
+    acc[D_CLIPF] += (pl1 < pl2 && on) ? 1.0 : 0.0;
+    acc[D_DUALF] += (dual && on) ? 1.0 : 0.0;
+    acc[D_PKL] += on ? (double)lr : 0.0;
+    acc[D_BKL] += bm ? (double)fsub(px, old) : 0.0;
+    acc[ver_slot] += on ? (double)vb : 0.0;
+    float g = p.critic_warmup ? 0.f : dpl * ratio * bw * bmf;
+    if (ratio_mode) g = g / w;
+    return g;
+}
+
 struct Denoms {
     double actor, critic, metric, count;
 };
@@ -146,6 +214,45 @@ __device__ __forceinline__ void finalize_row(const rlx_ppo_loss_params& p, long 
     out[RLX_PPO_CRITIC_GRAD_SCALE] = (float)(1.0 / d.critic);
     out[18] = (float)nm;
     out[19] = 0.f;
+}
+
+// the decoupled row (rlx_dppo_out): acc = the classic 16 sums with the decoupled actor's in slots 1-8, ver_sum = the version sum
+__device__ __forceinline__ void finalize_row_decoupled(const rlx_ppo_loss_params& p, bool use_threshold, long long n_adv, bool has_mask,
+                                                       bool has_msum, const double (&acc)[NS], double ver_sum, float* out) {
+    const double nm = acc[S_NM];
+    const Denoms d = denominators(p, n_adv, nm, has_mask, has_msum);
+    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
+    const double L = (double)n_adv * p.sub_per_adv, Lc = (double)n_adv;
+    // loss_mask.count_nonzero() or 1 (the UNbroadcast mask); behav_mask.count_nonzero() or 1 (broadcast to the loss shape)
+    const double n_valid = has_mask ? (nm > 0 ? nm : 1.0) : L;
+    // with a threshold behav_mask is built at the loss shape; without one it IS loss_mask, whose sum the reference takes
+    // before broadcasting (token_level: nm, not nm * action_dim)
+    const double behav_cnt = use_threshold ? acc[D_BM] : (has_mask ? nm : L);
+    const double n_behav = behav_cnt > 0 ? behav_cnt : 1.0;
+    const double actor_den = ratio_mode ? L : n_behav;  // masked_mean over behav_mask; all-False -> the (zero) sum
+    const float policy_loss = p.critic_warmup ? 0.f : (float)(acc[D_LOSS] / actor_den);
+    const float value_loss = p.has_critic ? (float)(acc[S_VLOSS] / d.critic) : 0.f;
+    out[RLX_DPPO_LOSS] = policy_loss + value_loss;
+    out[RLX_DPPO_POLICY_LOSS] = policy_loss;
+    out[RLX_DPPO_PROXIMAL_RATIO] = (float)(acc[D_PR] / n_valid);  // masked_mean with the unbroadcast mask (:147-150)
+    out[RLX_DPPO_CLIPPED_PROXIMAL_RATIO] = (float)(acc[D_CPR] / n_valid);
+    out[RLX_DPPO_DUAL_CLIP_FRACTION] = (float)(acc[D_DUALF] / n_valid);
+    out[RLX_DPPO_BEHAV_CLIP_FRACTION] = (float)(1.0 - n_behav / n_valid);
+    out[RLX_DPPO_PROXIMAL_APPROX_KL] = (float)(-acc[D_PKL] / n_valid);
+    out[RLX_DPPO_BEHAV_APPROX_KL] = (float)(-acc[D_BKL] / n_behav);
+    out[RLX_DPPO_CLIP_FRACTION] = (float)(acc[D_CLIPF] / n_valid);
+    out[RLX_PPO_VALUE_LOSS] = value_loss;
+    out[RLX_PPO_VALUE_CLIP_RATIO] = p.has_critic ? (float)(acc[S_VIND] / Lc) : 0.f;
+    out[RLX_PPO_EV_COUNT] = (float)acc[S_EVN];
+    out[RLX_PPO_EV_RETURNS_SUM] = (float)acc[S_EVR];
+    out[RLX_PPO_EV_RETURNS_SQ_SUM] = (float)acc[S_EVRR];
+    out[RLX_PPO_EV_ERRORS_SUM] = (float)acc[S_EVE];
+    out[RLX_PPO_EV_ERRORS_SQ_SUM] = (float)acc[S_EVEE];
+    out[RLX_PPO_ACTOR_GRAD_SCALE] = (float)(1.0 / actor_den);
+    out[RLX_PPO_CRITIC_GRAD_SCALE] = (float)(1.0 / d.critic);
+    out[18] = (float)nm;
+    // versions[loss_mask].mean(): only defined by the reference when versions and loss_mask share a shape (sub == 1)
+    out[RLX_DPPO_AVERAGE_VERSION] = (float)(ver_sum / (has_mask ? (nm > 0 ? nm : 1.0) : L));
 }
 
 }  // namespace loss

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RolloutArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // OP: head outputs padded to 8 or 16 (compile time): the loops over head outputs run unpredicated on zero padding --
 // a runtime "o < n_out" guard around an LDS read serialises every read behind its own lgkmcnt(0).
-template <int RT, int NW, int PD, int ABL, int OP>
+template <int RT, int NW, int PD, int ABL, int OP, bool DEC = false>  // DEC: the decoupled actor loss (StepArgs.dec)
 __global__ __launch_bounds__(64 * NW) void ppo_step_fused_kernel(StepArgs a) {
     typedef Geo<RT, NW> G;
     constexpr int BM = G::BM, CT = G::CT;
@@ -376,6 +376,8 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_kernel(StepArgs a) {
     double lacc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
+    DecoupledMode dmode{};
+    if constexpr (DEC) dmode = decoupled_mode_now(a.dec);
 
     for (int idx = tid; idx < BM * n_out; idx += G::NT) {
         const int row = idx / n_out, o = idx % n_out;
@@ -410,8 +412,19 @@ __global__ __launch_bounds__(64 * NW) void ppo_step_fused_kernel(StepArgs a) {
                     lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
                     old = fadd(old, olp[s * R + j]);
                 }
-                const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
-                sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                if constexpr (DEC) {  // sum form (the denominator is out[RLX_PPO_ACTOR_GRAD_SCALE] of the finished row); the slice's
+                                      // raw entries are [e * K + s * R, + R) of the [M, act_dim] arrays
+                    const size_t r0 = (size_t)e * K + s * R;
+                    float px = 0.f;
+                    if (dmode.mode == RLX_PROX_GIVEN)
+                        for (int j = 0; j < R; ++j) px = fadd(px, a.dec.proximal[r0 + j]);
+                    const float vb = a.dec.versions != nullptr ? a.dec.versions[r0] : 0.f;
+                    sG[row * MAX_OUT + c * S + s] =
+                        a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, adv, on, w, ratio_mode, lacc, S_VLOSS);
+                } else {
+                    const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
+                    sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                }
             }
         }
         lds_barrier();
@@ -602,15 +615,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_kernel(DwArgs a) {
             head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
             // ---- metric row: sum the per-tile partials of both networks ---------------------------------------
-            double acc[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-            for (int i = tid; i < a.tiles * 2; i += 256) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
-            }
-            block_sum<NS>(acc, s_red);
-            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+            metric_block(a, s_red, tid, 256);
         }
         return;
     }
@@ -865,7 +870,14 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
                 "rlx_ppo_step: NULL argument");
     RLX_REQUIRE(!p.has_critic || (s->prev_values && s->returns), "rlx_ppo_step: has_critic set but a critic tensor is NULL");
     const bool bf16 = s->bf16 != 0;
-    const bool rows = bf16 && fused_rows_bf16() && fused_rows_eligible(lay, p);
+    const rlx_decoupled_loss_params* dp = s->decoupled;
+    if (dp != nullptr) {
+        RLX_REQUIRE(dp->proximal_mode >= RLX_PROX_GIVEN && dp->proximal_mode <= RLX_PROX_FROM_VERSIONS,
+                    "rlx_ppo_step: unknown proximal_mode %d", dp->proximal_mode);
+        RLX_REQUIRE(dp->proximal_mode != RLX_PROX_GIVEN || s->proximal_logprobs, "rlx_ppo_step: proximal_mode GIVEN without proximal_logprobs");
+        RLX_REQUIRE(dp->proximal_mode != RLX_PROX_FROM_VERSIONS || s->versions, "rlx_ppo_step: proximal_mode FROM_VERSIONS without versions");
+    }
+    const bool rows = bf16 && dp == nullptr && fused_rows_bf16() && fused_rows_eligible(lay, p);
     const StepPlan pl = plan_step(&lay, s->m, bf16, rows);
     RLX_REQUIRE(s->slabs == pl.slabs, "rlx_ppo_step: grads holds %d slabs, rlx_ppo_step_slabs() says %d", s->slabs, pl.slabs);
     if (s->workspace_bytes < pl.bytes) {
@@ -884,6 +896,11 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     a.h = reinterpret_cast<float*>(ws + pl.off_h); a.dz = reinterpret_cast<float*>(ws + pl.off_dz);
     a.head_part = reinterpret_cast<float*>(ws + pl.off_head); a.loss_part = reinterpret_cast<double*>(ws + pl.off_loss);
     a.head_stride = pl.head_stride;
+    if (dp != nullptr) {
+        a.dec.on = 1;
+        a.dec.mode = loss::DecoupledMode{dp->proximal_mode, dp->use_behave_threshold, dp->behave_weight_threshold, dp->current_version};
+        a.dec.v_theta_dev = s->current_version_dev; a.dec.proximal = s->proximal_logprobs; a.dec.versions = s->versions;
+    }
     DwArgs d{};
     d.stamps = g_timing_buffer ? g_timing_buffer + 32 : nullptr;
     d.lay = lay; d.states = s->states; d.h = a.h; d.dz = a.dz; d.head_part = a.head_part; d.loss_part = a.loss_part;
@@ -896,6 +913,7 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
     d.repeat = 1;
 #endif
     d.has_msum = s->loss_mask_sum != nullptr; d.out = s->out;
+    d.decoupled = dp != nullptr; d.dec_use_threshold = dp != nullptr && dp->use_behave_threshold != 0;
     const int dw_blocks = round_up(d.gemm_items, 8) + pl.slabs * 2 + 1;
     if (bf16) {
         if (s->tiles != nullptr) {
@@ -923,7 +941,15 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
         hipLaunchKernelGGL((ppo_step_fused_kernel<4, 8, PDV, ABLV, OPV>), dim3(pl.tiles, 2), dim3(512), lds, st, a);      \
     } while (0)
     // ablation builds (RLX_STEP_VARIANT, development): compiled only with -DRLX_DEV_VARIANTS, see tools/bench_step.py
-    if (!op8) {
+    if (a.dec.on) {
+        if (op8) {
+            if (int rc = set_lds(ppo_step_fused_kernel<4, 8, 2, 0, 8, true>, lds)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_kernel<4, 8, 2, 0, 8, true>), dim3(pl.tiles, 2), dim3(512), lds, st, a);
+        } else {
+            if (int rc = set_lds(ppo_step_fused_kernel<4, 8, 2, 0, 16, true>, lds)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_kernel<4, 8, 2, 0, 16, true>), dim3(pl.tiles, 2), dim3(512), lds, st, a);
+        }
+    } else if (!op8) {
         RLX_LAUNCH_FUSED(2, 0, 16);
     } else {
 #ifdef RLX_DEV_VARIANTS

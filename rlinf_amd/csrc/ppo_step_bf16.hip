@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
 //   h  : [2 nets][2][16 cb][nrb] tiles    dz : [2 nets][3][16 cb][nrb] tiles    st : [4 cb][nrb] tiles (states)
 // ---------------------------------------------------------------------------------------------------------------
 
-template <int RT, int NW, int PD, int OP, bool STAMPS>
+template <int RT, int NW, int PD, int OP, bool STAMPS, bool DEC = false>  // DEC: the decoupled actor loss (StepArgs.dec)
 __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_kernel(StepArgs a, __bf16* st_tiles) {
     typedef GeoB<RT, NW> G;
     constexpr int BM = G::BM, CT = G::CT;
@@ -484,6 +484,8 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     double lacc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
+    DecoupledMode dmode{};
+    if constexpr (DEC) dmode = decoupled_mode_now(a.dec);
 
     head_forward_mfma<RT>(Xb, W4s, sG, sLp);  // the two k-half partials land in sG / sLp (both free until the passes below)
     lds_barrier();
@@ -510,9 +512,15 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
             const float lpe = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
             const float olde = sOld[row * MAX_OUT + o];
             float lp = fadd(0.f, lpe), old = fadd(0.f, olde);
+            float pxe = 0.f, px = 0.f;  // decoupled, given proximal policy: its per-dimension log-probs, summed like `old`
+            if constexpr (DEC) {
+                if (dmode.mode == RLX_PROX_GIVEN && mine) pxe = a.dec.proximal[(size_t)min(m0 + row, M - 1) * lay.act_dim + o];
+                px = fadd(0.f, pxe);
+            }
             for (int j = 1; j < n_out; ++j) {  // wave-uniform trip count; only the leaders' sums are used
                 lp = fadd(lp, __shfl_down(lpe, j, 64));
                 old = fadd(old, __shfl_down(olde, j, 64));
+                if constexpr (DEC) px = fadd(px, __shfl_down(pxe, j, 64));
             }
             float gs = 0.f;
             if (valid && o == 0) {
@@ -521,8 +529,13 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
                 float w = 1.f;
                 if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
                 lacc[S_NM] += on ? 1.0 : 0.0;
-                const float g = actor_elem(p, lp, old, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc);
-                gs = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                if constexpr (DEC) {  // sum form: the denominator is out[RLX_PPO_ACTOR_GRAD_SCALE] of the finished row
+                    const float vb = a.dec.versions != nullptr ? a.dec.versions[(size_t)e * lay.act_dim] : 0.f;
+                    gs = a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc, S_VLOSS);
+                } else {
+                    const float g = actor_elem(p, lp, old, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc);
+                    gs = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                }
             }
             gs = __shfl(gs, (lane - o) & 63, 64);  // from the row leader
             float dmu = 0.f, dls = 0.f;
@@ -592,8 +605,18 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
                         lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
                         old = fadd(old, olp[s * R + j]);
                     }
-                    const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
-                    sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                    if constexpr (DEC) {  // the slice's raw entries are [e * K + s * R, + R) of the [M, act_dim] arrays
+                        const size_t r0 = (size_t)e * K + s * R;
+                        float px = 0.f;
+                        if (dmode.mode == RLX_PROX_GIVEN)
+                            for (int j = 0; j < R; ++j) px = fadd(px, a.dec.proximal[r0 + j]);
+                        const float vb = a.dec.versions != nullptr ? a.dec.versions[r0] : 0.f;
+                        sG[row * MAX_OUT + c * S + s] =
+                            a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, adv, on, w, ratio_mode, lacc, S_VLOSS);
+                    } else {
+                        const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
+                        sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                    }
                 }
             }
         } else {
@@ -768,15 +791,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, cons
         if (b < a.slabs * 2) {
             head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
-            double acc[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-            for (int i = tid; i < a.tiles * 2; i += 256) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
-            }
-            block_sum<NS>(acc, s_red);
-            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+            metric_block(a, s_red, tid, 256);
         }
         return;
     }
@@ -918,15 +933,7 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_lds_kernel(DwArgs a, 
             head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
             double* s_red = reinterpret_cast<double*>(dsm);
-            double acc[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-            for (int i = tid; i < a.tiles * 2; i += 256) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
-            }
-            block_sum<NS>(acc, s_red);
-            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+            metric_block(a, s_red, tid, 256);
         }
         return;
     }
@@ -1095,15 +1102,7 @@ __global__ __launch_bounds__(DWR_THREADS) void ppo_step_dw_bf16_ring_kernel(DwAr
             if (tid < 256) head_reduce_block(a, b >> 1, b & 1, tid);
         } else {
             double* s_red = reinterpret_cast<double*>(dsm);
-            double acc[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-            for (int i = tid; i < a.tiles * 2; i += DWR_THREADS) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
-            }
-            block_sum<NS>(acc, s_red);
-            if (tid == 0) finalize_row(a.p, M * (lay.act_dim / a.p.raw_per_adv), a.has_mask != 0, a.has_msum != 0, acc, a.out);
+            metric_block(a, s_red, tid, DWR_THREADS);
         }
         return;
     }
@@ -1314,6 +1313,18 @@ int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int til
     __bf16* stt = static_cast<__bf16*>(st_tiles);
     if (rows) {  // `tiles` counts 64-row tiles
         if (int rc = launch_fused_rows_bf16(a, st_tiles, tiles, st)) return rc;
+    } else if (a.dec.on) {  // the decoupled actor loss: the default launch shape of each tile height, no development variants
+        if (fused_bm_bf16() == 32) {
+            const size_t lds2 = GeoB<2, 8>::LDS_BYTES;
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, false, true>, lds2)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, false, true>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
+        } else if (op8) {
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, false, true>, lds)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false, true>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
+        } else {
+            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16, false, true>, lds)) return rc;
+            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16, false, true>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
+        }
     } else if (fused_bm_bf16() == 32) {  // `tiles` counts 32-row tiles (plan_step)
         const size_t lds2 = GeoB<2, 8>::LDS_BYTES + (size_t)dev_variant("RLX_FUSED_LDS_PAD", 0);  // development: LDS-size sensitivity
         if (a.stamps != nullptr) {

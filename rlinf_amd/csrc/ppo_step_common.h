@@ -164,6 +164,24 @@ struct RolloutArgs {
     int tiles_policy, tiles_vj0, tiles_vj1;
 };
 
+// Decoupled (asynchronous PPO) actor loss inside the fused step (rlx_ppo_step_args.decoupled): the element math is
+// loss::decoupled_actor_elem, the actor gradients leave in sum form (their denominator -- the count of the behaviour mask --
+// needs every tile's forward), the version sum rides in slot S_VLOSS of the actor network's partial row.
+struct DecoupledArgs {
+    int on;
+    loss::DecoupledMode mode;
+    const float* v_theta_dev;   // optional: current version read at execution time (graph replay under the next version)
+    const float* proximal;      // [M, act_dim] (RLX_PROX_GIVEN)
+    const float* versions;      // [M, act_dim] or nullptr
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ loss::DecoupledMode decoupled_mode_now(const DecoupledArgs& d) {
+    loss::DecoupledMode m = d.mode;
+    if (d.v_theta_dev != nullptr) m.v_theta = *d.v_theta_dev;
+    return m;
+}
+#endif
+
 struct StepArgs {
     long long* stamps;
     const float* params;
@@ -187,6 +205,7 @@ struct StepArgs {
     float* head_part;           // [head_parts][2][head_stride]  per-32-row head gradients: dW4 [n_out][256], db4, dlogstd [n_out]
     double* loss_part;          // [tiles][2][NS]
     int head_stride;
+    DecoupledArgs dec;          // dec.on: the decoupled actor loss (the DEC instantiations)
 };
 
 struct DwArgs {
@@ -210,9 +229,42 @@ struct DwArgs {
     rlx_ppo_loss_params p;
     int has_mask, has_msum;
     float* out;              // metric row (RLX_PPO_OUT_FLOATS)
+    int decoupled;           // the row is the rlx_dppo_out one (finalize_row_decoupled)
+    int dec_use_threshold;
 };
 
 #if defined(__HIPCC__)
+// Metric block of the weight-gradient launches: the per-tile partial rows of both networks -> the metric row.  `scratch` holds
+// NS doubles per wave of the block.  (Decoupled loss: the actor network's rows -- odd i -- carry the version sum in slot S_VLOSS.)
+__device__ __forceinline__ void metric_block(const DwArgs& a, double* scratch, int tid, int nthreads) {
+    using namespace loss;
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    const long long n_adv = a.M * (a.lay.act_dim / a.p.raw_per_adv);
+    if (!a.decoupled) {
+        for (int i = tid; i < a.tiles * 2; i += nthreads) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) acc[k] += a.loss_part[(size_t)i * NS + k];
+        }
+        block_sum<NS>(acc, scratch);
+        if (tid == 0) finalize_row(a.p, n_adv, a.has_mask != 0, a.has_msum != 0, acc, a.out);
+        return;
+    }
+    double ver[1] = {0.0};
+    for (int i = tid; i < a.tiles * 2; i += nthreads) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const double v = a.loss_part[(size_t)i * NS + k];
+            if (k == S_VLOSS && (i & 1)) ver[0] += v;
+            else acc[k] += v;
+        }
+    }
+    block_sum<NS>(acc, scratch);
+    block_sum<1>(ver, scratch);
+    if (tid == 0) finalize_row_decoupled(a.p, a.dec_use_threshold != 0, n_adv, a.has_mask != 0, a.has_msum != 0, acc, ver[0], a.out);
+}
+
 // Head-gradient block of the weight-gradient launches: slab s takes the 32-row partials t == s (mod slabs), thread = hidden
 // column j.  The sums run in ascending t like a plain loop, but the loads do not: a loop of `acc += part[t]` costs one
 // memory round trip PER PARTIAL (the partials were written by other XCDs' workgroups: ~0.4 us each from the memory-side

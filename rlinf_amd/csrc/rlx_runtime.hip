@@ -35,6 +35,16 @@ extern "C" int rlx_version(void) { return RLX_VERSION; }
 
 extern "C" const char* rlx_last_error(void) { return rlx::g_err; }
 
+extern "C" int rlx_abi_struct_sizes(size_t* sizes, int n) {
+    const size_t all[] = {sizeof(rlx_gae_params), sizeof(rlx_ppo_loss_params), sizeof(rlx_gather_field), sizeof(rlx_adamw_group),
+                          sizeof(rlx_adamw_params), sizeof(rlx_mlp_layout), sizeof(rlx_value_job), sizeof(rlx_rollout_step),
+                          sizeof(rlx_ppo_step_args), sizeof(rlx_decoupled_loss_params), sizeof(rlx_token_rows),
+                          sizeof(rlx_token_loss_params), sizeof(rlx_copy_segment)};
+    const int count = (int)(sizeof(all) / sizeof(all[0]));
+    for (int i = 0; sizes != nullptr && i < n && i < count; ++i) sizes[i] = all[i];
+    return count;
+}
+
 extern "C" int rlx_device_info(int* num_cu_out, int* wave_size) {
     int dev = 0;
     RLX_HIP_CHECK(hipGetDevice(&dev));

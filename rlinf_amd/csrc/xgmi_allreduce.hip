@@ -312,6 +312,7 @@ extern "C" int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* c, float* params, const f
                                         void* workspace, size_t workspace_bytes, rlx_stream_t stream) {
     if (int rc = check(c, n, "rlx_xgmi_clip_adamw_step")) return rc;
     RLX_REQUIRE(p != nullptr && p->grad_partials >= 1 && grads && grad_flat, "rlx_xgmi_clip_adamw_step: NULL argument");
+    RLX_REQUIRE(p->deferred_scale == nullptr, "rlx_xgmi_clip_adamw_step: deferred_scale is not applied by the data-parallel exchange");
     if (n == 0) return RLX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = stage(c, grads, p->grad_partials, n, st)) return rc;

@@ -226,13 +226,21 @@ def grpo_from_scores(scores: torch.Tensor, loss_mask: torch.Tensor, group_size: 
 
 
 def gaussian_entropy_bonus_(params: torch.Tensor, layout: MlpLayout, grads_slab0: torch.Tensor, out_row: torch.Tensor,
-                            entropy_bonus: float, grad_scale: float, has_mask: bool, elem_scale: float = 1.0):
+                            entropy_bonus: float, grad_scale: float, has_mask: bool, elem_scale: float = 1.0,
+                            actor_scale: Optional[torch.Tensor] = None):
     """a22 for the Gaussian MLP policy: fold -entropy_bonus * masked_mean(entropy) into the loss row and the logstd
-    gradient (see include/rlx.h).  ``grads_slab0`` is the first gradient slab [n_params]."""
+    gradient (see include/rlx.h).  ``grads_slab0`` is the first gradient slab [n_params].  ``actor_scale`` (one device float):
+    the slab is in sum form behind a decoupled ppo_step and will be multiplied by it later -- the bonus is pre-divided."""
     dev = _dev(params, grads_slab0, out_row)
     off, A = int(layout.off_logstd), int(layout.act_dim)
     logstd = params[off:off + A]
     g = grads_slab0[off:off + A]
+    if actor_scale is not None:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().rlx_gaussian_entropy_bonus_deferred(
+                logstd.data_ptr(), A, g.data_ptr(), out_row.data_ptr(), float(entropy_bonus), float(grad_scale), int(bool(has_mask)),
+                float(elem_scale), actor_scale.data_ptr(), _stream_ptr(dev)), "rlx_gaussian_entropy_bonus_deferred")
+        return
     with torch.cuda.device(dev):
         _lib.check(_lib.load().rlx_gaussian_entropy_bonus(logstd.data_ptr(), A, g.data_ptr(), out_row.data_ptr(),
                                                           float(entropy_bonus), float(grad_scale), int(bool(has_mask)),
@@ -585,14 +593,42 @@ def gather_rows(fields: list, index: torch.Tensor, outs: Optional[list] = None) 
 # --------------------------------------------------------------------------------------------
 # a23  clip + AdamW on flat buffers
 # --------------------------------------------------------------------------------------------
+def actor_param_ranges(layout: MlpLayout) -> list:
+    """Element ranges of the flat buffer that belong to the ACTOR network (actor_logstd; backbone.* + actor_mean.*): the
+    gradients a decoupled ppo_step leaves in sum form."""
+    A = int(layout.act_dim)
+    lo = int(layout.off_w[1][0])
+    hi = max(int(layout.off_w[1][3]) + A * int(layout.hidden), (int(layout.off_b[1][3]) + A) if int(layout.off_b[1][3]) >= 0 else 0)
+    return [(int(layout.off_logstd), int(layout.off_logstd) + A), (lo, hi)]
+
+
+def deferred_actor_scale(layout: MlpLayout, rows: torch.Tensor, groups: int) -> dict:
+    """``deferred`` argument of the AdamW wrappers behind decoupled ppo_steps: ``rows`` = the [groups, PPO_OUT_FLOATS] metric rows
+    of the optimizer step's micro-batches (contiguous); their out[RLX_PPO_ACTOR_GRAD_SCALE] scale the actor ranges."""
+    assert rows.dim() == 2 and rows.shape[0] == groups and rows.stride(1) == 1
+    return dict(scale=rows[0, _lib.PPO_ACTOR_GRAD_SCALE:], stride=int(rows.stride(0)), groups=int(groups),
+                ranges=actor_param_ranges(layout), keep=rows)
+
+
+def _set_deferred(p: AdamwParams, deferred: Optional[dict]):
+    if deferred is None:
+        return
+    p.deferred_scale = deferred["scale"].data_ptr()
+    p.deferred_stride, p.deferred_groups = int(deferred["stride"]), int(deferred["groups"])
+    for k, (b, e) in enumerate(deferred["ranges"]):
+        p.deferred_range[k][0], p.deferred_range[k][1] = int(b), int(e)
+
+
 def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                      groups: list, step: int, *, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                      max_grad_norm: float = 0.5, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None,
                      step_state: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                     tile_layout: Optional[MlpLayout] = None, tiles: Optional[torch.Tensor] = None):
+                     tile_layout: Optional[MlpLayout] = None, tiles: Optional[torch.Tensor] = None,
+                     deferred: Optional[dict] = None):
     """In-place clip_grad_norm_ + AdamW over flat f32 buffers.  groups = [(begin, end, lr), ...].
     grads may be [n] or [slabs, n] (split-K slabs, summed first).  Returns stats f32[2] = (norm, applied).
-    step_state: device int32[2] keeping the step count on the device (then ``step`` is ignored)."""
+    step_state: device int32[2] keeping the step count on the device (then ``step`` is ignored).
+    deferred: see ``deferred_actor_scale`` (scales read on the device while the slabs are summed)."""
     lib = _lib.load()
     dev = _dev(params, grads, exp_avg, exp_avg_sq)
     n = params.numel()
@@ -613,6 +649,7 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
     if tile_layout is not None and tiles is not None:  # keep the fragment-tile weight image in step with the parameters
         p.tile_layout, p.tiles = ctypes_pointer(tile_layout), tiles.data_ptr()
         p.tiles_bf16 = int(tiles.dtype == torch.bfloat16)
+    _set_deferred(p, deferred)
     if stats is None:
         stats = torch.empty((2,), dtype=torch.float32, device=dev)
     ws_bytes = lib.rlx_adamw_workspace_bytes(n)
@@ -885,13 +922,7 @@ def ppo_step_workspace_bytes(layout: MlpLayout, m: int) -> int:
     return _lib.load().rlx_ppo_step_workspace_bytes(byref(layout), int(m))
 
 
-def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatch: dict, grads: torch.Tensor,
-             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0, tiles: Optional[torch.Tensor] = None,
-             bf16: bool = False):
-    """forward + loss + backward of one micro-batch (two launches).  ``mbatch``: states, action, prev_logprobs,
-    advantages [, prev_values, returns, loss_mask, loss_mask_sum] as flattened minibatch views; ``grads`` [slabs, n]."""
-    lib = _lib.load()
-    dev = params.device
+def _ppo_step_args(params, layout, loss, mbatch, grads, out_row, workspace, grad_out, tiles, bf16, decoupled) -> PpoStepArgs:
     a = PpoStepArgs()
     a.params, a.layout, a.loss = params.data_ptr(), ctypes_pointer(layout), ctypes_pointer(loss)
     st = mbatch["states"]
@@ -906,12 +937,40 @@ def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatc
     a.m, a.grad_out = st.shape[0], float(grad_out)
     a.grads, a.slabs, a.out = grads.data_ptr(), grads.shape[0], out_row.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
-    a.tiles = _ptr(tiles)
-    a.bf16 = int(bool(bf16))
+    a.tiles, a.bf16 = _ptr(tiles), int(bool(bf16))
     if tiles is not None and (tiles.dtype == torch.bfloat16) != bool(bf16):
         raise RlxError("ppo_step: the tile image's dtype does not match the requested precision")
+    if decoupled is not None:  # dict(params=DecoupledLossParams, proximal_logprobs, versions, current_version_dev): see decoupled_step_args
+        a.decoupled = ctypes.addressof(decoupled["params"])
+        a.proximal_logprobs, a.versions = _ptr(decoupled.get("proximal_logprobs")), _ptr(decoupled.get("versions"))
+        a.current_version_dev = _ptr(decoupled.get("current_version_dev"))
+    return a
+
+
+def decoupled_step_args(loss: PpoLossParams, mbatch: dict, *, current_version, behave_weight_threshold,
+                        current_version_dev: Optional[torch.Tensor] = None) -> dict:
+    """``decoupled`` argument of ppo_step / PreparedPpoStep: which proximal policy applies (losses.py:68-89) from what the
+    micro-batch carries -- ``proximal_logprobs`` (given), else ``versions`` (+ a current version: interpolated), else the
+    behaviour policy itself.  ``current_version_dev`` (one device float) is read when the launch executes."""
+    dp, prox, ver = _decoupled_params(loss, mbatch["prev_logprobs"], mbatch.get("proximal_logprobs"), mbatch.get("versions"),
+                                      current_version, behave_weight_threshold)
+    for name, t, src in (("proximal_logprobs", prox, mbatch.get("proximal_logprobs")), ("versions", ver, mbatch.get("versions"))):
+        if t is not None and t.data_ptr() != src.data_ptr():
+            raise RlxError(f"decoupled ppo_step needs contiguous float32 {name}")
+    return dict(params=dp, proximal_logprobs=prox, versions=ver, current_version_dev=current_version_dev)
+
+
+def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatch: dict, grads: torch.Tensor,
+             out_row: torch.Tensor, workspace: torch.Tensor, grad_out: float = 1.0, tiles: Optional[torch.Tensor] = None,
+             bf16: bool = False, decoupled: Optional[dict] = None):
+    """forward + loss + backward of one micro-batch (two launches).  ``mbatch``: states, action, prev_logprobs,
+    advantages [, prev_values, returns, loss_mask, loss_mask_sum] as flattened minibatch views; ``grads`` [slabs, n].
+    ``decoupled`` (decoupled_step_args): the asynchronous-PPO actor loss; the actor network's gradients then leave in sum
+    form (include/rlx.h) -- pass ``deferred_actor_scale`` of the row(s) to the AdamW step."""
+    dev = params.device
+    a = _ppo_step_args(params, layout, loss, mbatch, grads, out_row, workspace, grad_out, tiles, bf16, decoupled)
     with torch.cuda.device(dev):
-        _lib.check(lib.rlx_ppo_step(byref(a), _stream_ptr(dev)), "rlx_ppo_step")
+        _lib.check(_lib.load().rlx_ppo_step(byref(a), _stream_ptr(dev)), "rlx_ppo_step")
 
 
 # --------------------------------------------------------------------------------------------
@@ -921,26 +980,12 @@ def ppo_step(params: torch.Tensor, layout: MlpLayout, loss: PpoLossParams, mbatc
 class PreparedPpoStep:
     """rlx_ppo_step with every pointer fixed (persistent minibatch views and workspaces)."""
 
-    def __init__(self, params, layout, loss, mbatch, grads, out_row, workspace, grad_out=1.0, tiles=None, bf16=False):
+    def __init__(self, params, layout, loss, mbatch, grads, out_row, workspace, grad_out=1.0, tiles=None, bf16=False,
+                 decoupled=None):
         self._lib = _lib.load()
-        self._keep = (params, layout, loss, dict(mbatch), grads, out_row, workspace, tiles)
-        a = PpoStepArgs()
-        a.params, a.layout, a.loss = params.data_ptr(), ctypes_pointer(layout), ctypes_pointer(loss)
-        st = mbatch["states"]
-        a.states, a.action = st.data_ptr(), mbatch["action"].data_ptr()
-        a.old_logprobs, a.advantages = mbatch["prev_logprobs"].data_ptr(), mbatch["advantages"].data_ptr()
-        has_critic = bool(loss.has_critic)
-        a.prev_values = mbatch["prev_values"].data_ptr() if has_critic else None
-        a.returns = mbatch["returns"].data_ptr() if has_critic else None
-        lm = mbatch.get("loss_mask")
-        a.loss_mask = None if lm is None else lm.data_ptr()
-        a.loss_mask_sum = _ptr(mbatch.get("loss_mask_sum"))
-        a.m, a.grad_out = st.shape[0], float(grad_out)
-        a.grads, a.slabs, a.out = grads.data_ptr(), grads.shape[0], out_row.data_ptr()
-        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
-        a.tiles, a.bf16 = _ptr(tiles), int(bool(bf16))
-        self._args = a
-        self._ref = byref(a)
+        self._keep = (params, layout, loss, dict(mbatch), grads, out_row, workspace, tiles, decoupled)
+        self._args = _ppo_step_args(params, layout, loss, mbatch, grads, out_row, workspace, grad_out, tiles, bf16, decoupled)
+        self._ref = byref(self._args)
 
     def __call__(self, stream: int):
         rc = self._lib.rlx_ppo_step(self._ref, stream)
@@ -952,7 +997,7 @@ class PreparedAdamw:
     """rlx_clip_adamw_step with every pointer fixed; ``stats`` is this step's (norm, applied) row."""
 
     def __init__(self, params, grads, exp_avg, exp_avg_sq, groups, *, betas, eps, weight_decay, max_grad_norm, grad_scale,
-                 stats, step_state, workspace, tile_layout=None, tiles=None, xgmi=None, grad_flat=None):
+                 stats, step_state, workspace, tile_layout=None, tiles=None, xgmi=None, grad_flat=None, deferred=None):
         """``xgmi`` (scheduler.xgmi.XgmiAllReduce) + ``grad_flat`` [n]: rlx_xgmi_clip_adamw_step instead -- ``grads`` are this
         rank's slabs, the reduced gradient (scaled by grad_scale = 1 / world_size) lands in grad_flat, then clip + AdamW."""
         self._lib = _lib.load()
@@ -965,7 +1010,8 @@ class PreparedAdamw:
             p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
         if tile_layout is not None and tiles is not None:
             p.tile_layout, p.tiles, p.tiles_bf16 = ctypes_pointer(tile_layout), tiles.data_ptr(), int(tiles.dtype == torch.bfloat16)
-        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat)
+        _set_deferred(p, deferred)
+        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat, deferred)
         if xgmi is not None:
             self._fn, self._name = self._lib.rlx_xgmi_clip_adamw_step, "rlx_xgmi_clip_adamw_step"
             self._argv = (xgmi.handle, params.data_ptr(), grads.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(),

@@ -124,7 +124,8 @@ class EmbodiedFSDPActor(Worker):
         are dropped."""
         self._lrs = self.lr_scheduler.get_last_lr()
         self.groups = self.model.group_ranges(self._lrs[0], self._lrs[1], train_value_head=self.cfg.algorithm.loss_type != "actor")
-        self._ws.pop("prepared_key", None)
+        for key in ("prepared_key", "aplan_key", "agraph_key"):  # (the async learner's plan and graph: async_ppo_fsdp_worker.py)
+            self._ws.pop(key, None)
         self._graph = None
 
     def _step_lr_scheduler(self):
@@ -468,8 +469,10 @@ class EmbodiedFSDPActor(Worker):
         ops.mlp_train_bwd(m.flat.data, m.packed(), lay, mbatch["states"], mbatch["action"], ws["mean"], ws["acts"],
                           ws["d_lp"], None, ws["d_v"], grads=grads, workspace=ws["bwd_ws"])
 
-    def _entropy_bonus(self, mbatch: dict, grads: torch.Tensor, out_row: torch.Tensor, critic_warmup: bool = False):
-        """loss -= entropy_bonus * masked_mean(entropy) (:679-690); a no-op at the default entropy_bonus = 0."""
+    def _entropy_bonus(self, mbatch: dict, grads: torch.Tensor, out_row: torch.Tensor, critic_warmup: bool = False,
+                       actor_scale: torch.Tensor | None = None):
+        """loss -= entropy_bonus * masked_mean(entropy) (:679-690); a no-op at the default entropy_bonus = 0.
+        ``actor_scale``: see ops.gaussian_entropy_bonus_ (the decoupled fused step's sum-form actor gradients)."""
         alg = self.cfg.algorithm
         bonus = float(alg.get("entropy_bonus", 0) or 0)
         if bonus <= 0 or critic_warmup:
@@ -485,11 +488,11 @@ class EmbodiedFSDPActor(Worker):
             if C != 1:
                 raise RuntimeError(f"The size of tensor a ({mb}) must match the size of tensor b ({C}) at non-singleton dimension 1")
             ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
-                                        True, float(mb))
+                                        True, float(mb), actor_scale=actor_scale)
             return
         per_elem = alg.get("entropy_type", "action_level") == "token_level" and not has_mask
         ops.gaussian_entropy_bonus_(self.model.flat.data, self.model.layout, grads[0], out_row, bonus, self._grad_out_host,
-                                    has_mask, 1.0 / self.model.layout.act_dim if per_elem else 1.0)
+                                    has_mask, 1.0 / self.model.layout.act_dim if per_elem else 1.0, actor_scale=actor_scale)
 
     def optimizer_step(self, grads: torch.Tensor, stats: torch.Tensor | None = None, critic_warmup: bool = False):
         """clip_grad_norm_ + AdamW (+ data-parallel mean of the gradient) -> stats (norm, applied) on device.  The

@@ -396,21 +396,31 @@ def test_pipeline_rollout_epochs_overlap_matches_oracle(overlap, hip_graph, stag
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("auto_reset,entropy_bonus", [(True, 0.0), (True, 0.01), (False, 0.0)])
-def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus):
+@pytest.mark.parametrize("auto_reset,entropy_bonus,path", [
+    (True, 0.0, "fused"), (True, 0.01, "fused"), (False, 0.0, "fused"), (True, 0.01, "graph"), (False, 0.0, "graph"),
+    (True, 0.01, "staged"), (False, 0.0, "one-micro-batch"), (True, 0.0, "threshold")])
+def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus, path):
     """AsyncPPOEmbodiedFSDPActor (decoupled actor-critic) behind the ordinary runner: two iterations whose trajectories carry
     the version they were sampled with (proximal policy interpolated from the version distance), then the same buffer trained
-    again with half of it marked one version older and the proximal log-probs recomputed from the current weights."""
+    again with half of it marked one version older and the proximal log-probs recomputed from the current weights.
+    ``path``: the fused step (rlx_ppo_step with the decoupled loss + deferred actor scale; the default), the same replayed from
+    a hipGraph (the policy version is read on the device), the stage-by-stage entry points (actor.fused_step false), one
+    micro-batch per optimizer step, and a behaviour-weight threshold tight enough to mask samples."""
     from rlinf_amd.config import validate_cfg
     from rlinf_amd.runners import EmbodiedRunner
     from rlinf_amd.scheduler import init_distributed
     from rlinf_amd.workers.actor.async_ppo_fsdp_worker import AsyncPPOEmbodiedFSDPActor
     from rlinf_amd.workers.env import EnvWorker
     from rlinf_amd.workers.rollout.hf import MultiStepRolloutWorker
-    T, B, GB, MB = 10, 16, 80, 40
-    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=MB, auto_reset=auto_reset, entropy_bonus=entropy_bonus)
+    T, B, GB, MB = 10, 16, 80, (80 if path == "one-micro-batch" else 40)
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=MB, auto_reset=auto_reset, entropy_bonus=entropy_bonus,
+                   hip_graph=path == "graph")
     cfg.algorithm.loss_type = "decoupled_actor_critic"
     cfg.algorithm.normalize_advantages = True
+    if path == "staged":
+        cfg.actor.fused_step = False
+    if path == "threshold":
+        cfg.algorithm.behave_weight_threshold = 1.02
     cfg = validate_cfg(cfg)
     env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
     torch.manual_seed(11)
@@ -426,6 +436,8 @@ def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus):
     w.model.load_reference_state_dict(sd)
     kw = dict(seed=1234, global_batch=GB, micro_batch=MB, update_epoch=2, entropy_bonus=entropy_bonus,
               max_episode_steps=cfg.env.train.get("max_episode_steps"))
+    if path == "threshold":
+        kw["behave_weight_threshold"] = 1.02
 
     def check(metrics, om, norms, steps, it):
         mean = lambda k: sum(float(m[k]) for m in om) / len(om)  # noqa: E731
@@ -468,6 +480,9 @@ def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus):
     metrics = w.run_training()
     steps += len(norms)
     check(metrics, om, norms, steps, 2)
+    assert ("aplan_key" in w._ws) == (path != "staged"), "which learner loop ran"
+    if path == "graph":
+        assert "agraph" in w._ws
 
 
 @pytest.mark.gpu

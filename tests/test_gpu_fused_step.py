@@ -437,3 +437,146 @@ def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask, launch, monkey
     assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(loss32, rel=2e-2, abs=2e-3)
     for key in ("actor/ratio", "actor/clipped_ratio", "critic/value_loss"):
         assert float(host[PPO_OUT_NAMES[key]]) == pytest.approx(metrics32[key], rel=2e-2, abs=2e-3), key
+
+
+@pytest.mark.parametrize("M,prox_mode,with_mask,thr,bf16", [
+    (8192, "versions", False, 1.03, False),   # the shipped async configs: interpolated proximal policy + behaviour threshold
+    (700, "versions", True, 1.03, False),
+    (1000, "given", True, 1.05, False),
+    (333, "old", True, None, False),
+    (5, "versions", True, 1.03, False),
+    (8192, "versions", False, 1.03, True),    # bf16 operands
+    (700, "given", True, 1.05, True),
+])
+def test_ppo_step_decoupled_loss_vs_oracle(M, prox_mode, with_mask, thr, bf16):
+    """rlx_ppo_step with rlx_ppo_step_args.decoupled (async PPO, losses.py:27-167 + :383-393) against the oracle: the rlx_dppo_out
+    row, and the gradients once the ACTOR network's slabs -- left in sum form: their denominator, the behaviour-mask count, needs
+    every tile's forward -- are multiplied by out[RLX_PPO_ACTOR_GRAD_SCALE]; the value network's are final as they leave.
+    bf16: the yardstick of test_ppo_step_bf16_gradients_vs_autocast_oracle (no farther from the f32 gradient than twice the
+    reference arithmetic under bf16 autocast)."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import DPPO_OUT_NAMES, PPO_ACTOR_GRAD_SCALE, PPO_OUT_FLOATS
+    ora, pol = _bf16_policy(seed=13) if bf16 else _policies(seed=13)
+    g = torch.Generator().manual_seed(17)
+    mb = _minibatch(M, g, with_mask)
+    with torch.no_grad():
+        cur = ora.evaluate(mb["states"], mb["action"])["logprobs"]
+    mb["prev_logprobs"] = cur + torch.randn(M, 8, generator=g) * 0.08
+    versions = torch.randint(2, 6, (M, 1), generator=g).float().expand(M, 8).contiguous()  # behaviour versions 2..5, current 6
+    versions[:: 7] = -1.0  # "unknown": alpha = 0
+    prox = cur + torch.randn(M, 8, generator=g) * 0.02
+    kw = dict(proximal_logprobs=prox if prox_mode == "given" else None, versions=versions if prox_mode == "versions" else None)
+
+    def oracle(autocast):
+        ora.zero_grad()
+        with O.amp(autocast):
+            out = ora.evaluate(mb["states"], mb["action"])
+        shaped = O.shape_loss_inputs(out["logprobs"].float(), mb["prev_logprobs"], mb["advantages"], "action_level", 8,
+                                     loss_mask=mb.get("loss_mask"), values=out["values"].float(), prev_values=mb["prev_values"],
+                                     returns=mb["returns"])
+        p2, v2 = O.shape_decoupled_inputs(kw["proximal_logprobs"], kw["versions"], "action_level", 8, M, shaped["logprobs"].shape)
+        loss, metrics = O.decoupled_actor_critic_loss(
+            proximal_logprobs=p2, versions=v2, current_version=6 if prox_mode != "old" else None, behave_weight_threshold=thr,
+            clip_ratio_low=0.2, clip_ratio_high=0.2, clip_ratio_c=3.0, value_clip=1.0, huber_delta=10.0, **shaped)
+        (loss * 0.5).backward()
+        return {n: p.grad.clone() for n, p in ora.named_parameters()}, float(loss.detach()), {k: float(v) for k, v in metrics.items()}
+
+    g32, loss32, metrics = oracle(False)
+    g16 = oracle(True)[0] if bf16 else None
+
+    lay = pol.layout
+    lp = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
+                             value_clip=1.0, huber_delta=10.0, max_episode_steps=50, clip_ratio_c=3.0, has_critic=True)
+    slabs = ops.ppo_step_slabs(lay, M, bf16)
+    grads = torch.full((slabs, lay.n_params), float("nan"), device="cuda")
+    ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+    row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+    dev_mb = {k: v.cuda().contiguous() for k, v in mb.items()}
+    if with_mask:
+        dev_mb["loss_mask"] = dev_mb["loss_mask"].view(torch.uint8)
+    if kw["proximal_logprobs"] is not None:
+        dev_mb["proximal_logprobs"] = prox.cuda()
+    if kw["versions"] is not None:
+        dev_mb["versions"] = versions.cuda()
+    version_dev = torch.tensor([6.0], device="cuda")  # read at execution time; the host value below is deliberately stale
+    dec = ops.decoupled_step_args(lp, dev_mb, current_version=(-100 if prox_mode != "old" else None), behave_weight_threshold=thr,
+                                  current_version_dev=version_dev if prox_mode != "old" else None)
+    ops.ppo_step(pol.flat.data, lay, lp, dev_mb, grads, row, ws, grad_out=0.5, bf16=bf16, decoupled=dec)
+    host = row.cpu()
+    got = grads.sum(dim=0).cpu()
+    assert torch.isfinite(got).all()
+    for b, e in ops.actor_param_ranges(lay):
+        got[b:e] *= host[PPO_ACTOR_GRAD_SCALE]
+    if bf16:
+        cat = lambda d: torch.cat([d[n].reshape(-1) for n in d])  # noqa: E731
+        order = torch.cat([torch.arange(pol.offsets[n], pol.offsets[n] + g32[n].numel()) for n in g32])
+        w32, w16, ours = cat(g32), cat(g16), got[order]
+        rel_ours = float((ours - w32).norm() / w32.norm())
+        rel_auto = float((w16 - w32).norm() / w32.norm())
+        cos = float(torch.dot(ours, w32) / (ours.norm() * w32.norm()))
+        assert rel_ours <= max(2.0 * rel_auto, 0.05) and cos > 0.99, (rel_ours, rel_auto, cos)
+    else:
+        scale = max(float(w.abs().max()) for w in g32.values())
+        for name, w in g32.items():
+            o = pol.offsets[name]
+            w = w.reshape(-1)
+            tol = 3e-4 * max(float(w.abs().max()), 1e-3 * scale) + 1e-7
+            err = float((got[o:o + w.numel()] - w).abs().max())
+            assert err <= tol, (name, err, tol)
+    mtol = dict(rel=2e-2, abs=2e-3) if bf16 else dict(rel=5e-4, abs=5e-5)
+    assert float(host[DPPO_OUT_NAMES["loss"]]) == pytest.approx(loss32, **mtol)
+    for key in ("actor/policy_loss", "actor/proximal_ratio", "actor/clipped_proximal_ratio", "actor/clip_fraction",
+                "actor/dual_clip_fraction", "actor/behav_clip_fraction", "actor/proximal_approx_kl", "actor/behav_approx_kl",
+                "critic/value_loss"):
+        if bf16 and (key.endswith("fraction") or key.endswith("_kl")):  # counts of elements on a clip edge / sums of ~1e-2 log-ratios
+            assert float(host[DPPO_OUT_NAMES[key]]) == pytest.approx(metrics[key], abs=0.02), key
+        else:
+            assert float(host[DPPO_OUT_NAMES[key]]) == pytest.approx(metrics[key], **mtol), key
+    if prox_mode == "versions" and "actor/average_version" in metrics:
+        assert float(host[DPPO_OUT_NAMES["actor/average_version"]]) == pytest.approx(metrics["actor/average_version"], rel=1e-5)
+    if not bf16:  # the fused launch and the staged entry points (rlx_decoupled_loss_fwd on the same forward) agree on the row
+        lpg, _, val, _, _ = ops.mlp_train_fwd(pol.flat.data, pol.packed(), lay, dev_mb["states"], dev_mb["action"])
+        _, staged = ops.ppo_loss(lpg, dev_mb["prev_logprobs"], dev_mb["advantages"], logprob_type="action_level", action_dim=8,
+                                 clip_ratio_low=0.2, clip_ratio_high=0.2, values=val, prev_values=dev_mb["prev_values"],
+                                 returns=dev_mb["returns"], value_clip=1.0, huber_delta=10.0, loss_mask=dev_mb.get("loss_mask"),
+                                 max_episode_steps=50, clip_ratio_c=3.0, has_critic=True,
+                                 decoupled=dict(proximal_logprobs=dev_mb.get("proximal_logprobs"), versions=dev_mb.get("versions"),
+                                                current_version=6 if prox_mode != "old" else None, behave_weight_threshold=thr))
+        torch.testing.assert_close(row, staged, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("groups,per,n_act", [(1, 10, 8), (2, 3, 8), (3, 1, 7)])
+def test_clip_adamw_deferred_actor_scale_is_the_scaled_slab_sum(groups, per, n_act):
+    """rlx_adamw_params.deferred_scale: the slab sum multiplies the actor ranges of every micro-batch's slab group by that
+    micro-batch's device-side scale -- bit for bit the step a caller gets from forming that gradient itself."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    pol = MLPPolicy(42, n_act, 1, True, False).to("cuda")
+    lay, n = pol.layout, pol.n_params
+    g = torch.Generator(device="cuda").manual_seed(3)
+    slabs = torch.randn(groups * per, n, generator=g, device="cuda") * 1e-2
+    rows = torch.zeros(groups, PPO_OUT_FLOATS + 2, device="cuda")
+    rows[:, 16] = torch.tensor([1.0 / 913.0, 1.0 / 1024.0, 1.0 / 77.0], device="cuda")[:groups]
+    ranges = ops.actor_param_ranges(lay)
+    factor = torch.ones(groups, n, device="cuda")
+    for b, e in ranges:
+        factor[:, b:e] = rows[:, 16:17]
+    want_g = None
+    for q in range(groups):
+        x = slabs[q * per].clone()
+        for k in range(1, per):
+            x = x + slabs[q * per + k]
+        t = x * factor[q]
+        want_g = t if want_g is None else want_g + t
+    results = []
+    for deferred in (True, False):
+        params = pol.flat.data.clone()
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        grads = slabs.clone() if deferred else want_g.clone().view(1, n)
+        stats = ops.clip_adamw_step_(params, grads, m, v, [(0, n, 3e-4)], 1, max_grad_norm=0.5,
+                                     deferred=ops.deferred_actor_scale(lay, rows[:, :PPO_OUT_FLOATS], groups) if deferred else None)
+        results.append((params, m, v, stats))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    assert float(results[0][3][1]) == 1.0
