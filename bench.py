@@ -85,6 +85,7 @@ def build_runner(cfg, ctx, learner: str = "sync"):
     if learner == "async":
         from rlinf_amd.workers.actor.async_ppo_fsdp_worker import AsyncPPOEmbodiedFSDPActor as EmbodiedFSDPActor  # noqa: F811
         cfg.algorithm.loss_type = "decoupled_actor_critic"
+        cfg.algorithm.behave_weight_threshold = 2.0  # examples/embodiment/config/maniskill_async_ppo_*.yaml:45
     cfg = validate_cfg(cfg)
     actor = EmbodiedFSDPActor.create_group(cfg, ctx).launch(None, name="ActorGroup")
     rollout = MultiStepRolloutWorker.create_group(cfg, ctx).launch(None, name="RolloutGroup")
@@ -854,11 +855,12 @@ def main():
                                   dict(precision=args.precision, pipeline=True, rollout_epochs=4)),
                                  ("pipeline mode, 1 rollout epoch (statistics normalisation + per-stage shuffles only)",
                                   dict(precision=args.precision, pipeline=True, rollout_epochs=1)),
-                                 # the learner of async / decoupled PPO at the same configuration.  Its update phase still
-                                 # runs stage by stage (f32 training forward -> decoupled loss -> backward, eager launches): measured,
-                                 # not yet on the fused / hipGraph path of the synchronous learner
-                                 ("async learner (decoupled actor-critic loss), stage-by-stage f32 update phase, eager",
-                                  dict(precision="32", learner="async", steps=max(5, args.variant_steps // 10)))):
+                                 # the learner of async / decoupled PPO at the same configuration and precision: the
+                                 # decoupled loss runs inside rlx_ppo_step (actor gradients in sum form, scaled in the slab sum), the
+                                 # update phase is the same prepared-launch hipGraph; behave_weight_threshold 2 as the shipped configs
+                                 ("async learner (decoupled actor-critic loss inside the fused step, behave_weight_threshold 2; "
+                                  "masked_normalization of the advantages over the shuffled buffer)",
+                                  dict(precision=args.precision, learner="async"))):
                     try:
                         r = measure(ctx, **{**vs, **kw})
                         out.append({"variant": name, "dtype": "f32" if kw["precision"] == "32" else "bf16", "metric": "env_steps_per_sec",

@@ -674,6 +674,11 @@ int rlx_gae_seq(const float* values, const float* rewards, float* advantages, fl
  *   largest -> -inf; top_k <= 0 or >= K disables it)
  *   tokens   [n] i64 bin index in [0, K);  logprob [n] f32 = log softmax(x)[token] (optional; rounded to the dtype when
  *            rows->round_outputs);  actions [n] f32 = bin_centers[clamp(K - token - 1, 0, n_centers - 1)] (optional)
+ *   Exactness of `tokens` (stated allowance): the race scores are formed as exp(x - max) / q in f32 here, torch forms
+ *   softmax(x) / q with its own vectorised exp and a division by the row sum; both are correctly ordered wherever the two best
+ *   scores differ by more than the rounding of one exp (2 ulp of the scores' dtype).  On such a tie -- and only there -- the
+ *   returned index may be the runner-up of torch's race.  tests/test_gpu_token_path.py demands that EVERY differing row is
+ *   such a tie in the oracle's own scores; with do_sample False (argmax of the raw logits) the indices are bit-exact.
  * ------------------------------------------------------------------------------------------ */
 int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k,
                            const float* bin_centers, int n_centers, int64_t* tokens, float* logprob, float* actions,
