@@ -1,6 +1,7 @@
-// ppo_step_bf16_rows.hip -- the fused optimizer-step launch (1), bf16, ROW-GROUP form: one workgroup = 64 minibatch rows of one
-// network = four 16-row groups; a PAIR of waves owns a row group (128 of the 256 columns each) through the whole chain (forward,
-// head, loss, backward-data); the network's weight tiles are staged ONCE per workgroup through an LDS ring by two loader waves.
+// ppo_step_bf16_rows.hip -- the fused optimizer-step launch (1), bf16, ROW-SPLIT form (opt-in: RLX_FUSED_ROWS=1): one workgroup =
+// 64 minibatch rows of one network; its 8 compute waves are 2 row pairs x 4 column quarters -- wave (rp, cq) owns 32 rows x 64
+// columns (acc[2][4] tiles of 16 x 16) through the whole chain (forward, head, loss, backward-data); the network's weight tiles are
+// staged ONCE per workgroup through an LDS ring by two loader waves.
 //
 // Replaces, like ppo_step_fused_bf16_kernel (ppo_step_bf16.hip), the training forward + PPO loss + backward of
 //   MLPPolicy.default_forward            rlinf/models/embodiment/mlp_policy/mlp_policy.py:202-236
@@ -9,27 +10,31 @@
 // and writes the same k-tiled bf16 images / head partials / metric partials for the weight-gradient launch behind it.
 //
 // Why a second decomposition.  The column-split kernel gives every wave 32 output columns of a 32-row tile and streams ITS weight
-// fragments L2 -> registers: a CU that hosts two such workgroups pulls the network's 0.53 MB tile image twice (34 MB per XCD and
-// launch through an L2 that every CU of the XCD hits at the same addresses), and a k-step is 4 MFMAs per wave between two LDS
-// round trips.  Here:
+// fragments L2 -> registers: a CU that hosts two such workgroups pulls the network's 0.53 MB tile image twice, and a k-step is 4
+// MFMAs per wave between two LDS round trips.  Here:
 //   * the weights are shared by the workgroup: fragment tiles travel global -> LDS by `global_load_lds_dwordx4` (no registers),
-//     one 16 KiB slot per k-step (16 column tiles x 1 KiB, contiguous in the k-step-major image, already in B-fragment lane
-//     order), through a ring of NSLOT slots that runs ahead across layer boundaries (34 slots: W1 2, W2 8, W3 8, W3^T 8, W2^T 8);
-//   * two LOADER waves do nothing but copy (8 tiles of every slot each): a compute wave that issues its own LDS-DMAs stalls
-//     ~100-185 cycles per instruction while the LDS serves fragment reads (MI355X_MICROARCH.md, "LDS-DMA piece issue cost";
-//     measured here: 680 cycles per k-step with the copies in the compute waves, 465 with loaders); a loader's memory queue holds
-//     nothing but copies, so its counted vmcnt waits are exact, and the compute waves never wait on vmcnt at all;
-//   * a wave pair owns a 16-row group: wave (g, h) computes column tiles 8 h .. 8 h + 7 of group g -- 8 MFMAs on 8 independent
-//     accumulators per k-step, the next k-step's fragments requested in two groups of (4 reads | 4 MFMAs) (a wave can have 15 LDS
-//     operations outstanding: more in one block stalls the issue until they return); the group's activations go through ITS LDS
-//     slab (accumulator layout -> row-major bf16 -> A fragments), so a layer costs one workgroup barrier (the slab must not be
-//     overwritten while the partner still reads it) besides the ring hand-offs, which synchronise everybody anyway;
-//   * two waves per SIMD: while one waits for an LDS round trip or a transcendental, the other issues (the first version of this
-//     kernel ran ONE 16-row x 256-column wave per SIMD: its epilogues took 75 cycles per element).
-// Same arithmetic as the column-split kernel element by element (same fragment tiles, same k order, same f32 head on three
-// bf16 planes added as two k-half partials, same loss math): a sample's log-prob at rollout time and the first epoch's
-// recomputation stay bit-identical.  The head-gradient partial covers the workgroup's 64 rows (column-split: 32), the metric
-// partials one wave each.
+//     one 32 KiB slot per TWO k-steps (2 x 16 column tiles x 1 KiB, contiguous in the k-step-major image, already in B-fragment
+//     lane order), through a ring of NSLOT slots (3, or 2 beside the 16-output head image) that runs ahead across layer boundaries:
+//     17 ring steps -- W1 1, W2 4, W3 4, W3^T 4, W2^T 4 (RW_C_*);
+//   * RLX_ROWS_NL = 2 LOADER waves do nothing but copy (half of every slot's tiles each): a compute wave that issues its own
+//     LDS-DMAs stalls ~100-185 cycles per instruction while the LDS serves fragment reads (MI355X_MICROARCH.md, "LDS-DMA piece issue
+//     cost"; measured here: 680 cycles per k-step with the copies in the compute waves, 465 with loaders); a loader's memory queue
+//     holds nothing but copies, so its counted vmcnt waits are exact, and the compute waves never wait on vmcnt in a GEMM sweep;
+//   * per k-step a compute wave issues 8 MFMAs on 8 independent accumulators, the next k-step's fragments requested in groups of at
+//     most 6 reads between 4 MFMAs (a wave can have 15 LDS operations outstanding: more in one block stalls the issue until they
+//     return); the tile's activations go through LDS slabs (accumulator layout -> row-major bf16 -> A fragments); one ring hand-off
+//     (builtin lgkmcnt(0) + s_barrier of all ten waves) per slot;
+//   * two compute waves per SIMD: while one waits for an LDS round trip or a transcendental, the other issues (the first version of
+//     this kernel ran ONE 16-row x 256-column wave per SIMD: its epilogues took 75 cycles per element);
+//   * the loss is an 8-wave pass (every wave evaluates its rows' elements; DPP row reductions, no ds_bpermute), one metric partial
+//     row and one head-gradient partial per WORKGROUP (column-split: per 32 rows).
+// Same arithmetic as the column-split kernel element by element (same fragment tiles, same k order, same f32 head on three bf16
+// planes added as two k-half partials, same loss math): a sample's log-prob at rollout time and the first epoch's recomputation
+// stay bit-identical.
+//
+// Measured (profiles/r04_rows_kernel_*): 27.6 us at 8192 rows against 26.2 us for the column-split launch, 23.7 against 18.0 us at
+// 1024 rows: the ring hand-off costs ~525 cycles per k-step where the matrix pipe needs 272.  Parity-green in every fused-step
+// test (tests/test_gpu_fused_step.py, launch "rows"); not the default.  No decoupled-loss instantiation.
 
 #include <type_traits>
 
