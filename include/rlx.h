@@ -285,7 +285,9 @@ typedef struct rlx_adamw_params {
     /* optional: scales that only exist on the device when the slab sum runs (the decoupled rlx_ppo_step: 1 / count of the
      * behaviour mask, left in its metric row).  The grad_partials slabs are deferred_groups consecutive groups (one per
      * micro-batch); elements of the two ranges are multiplied by deferred_scale[g * deferred_stride] as group g is summed.
-     * NULL: none.  Single-rank rlx_clip_adamw_step only (the data-parallel exchanges refuse it). */
+     * NULL: none.  Applied wherever THIS rank's slabs are collapsed: rlx_clip_adamw_step (one rank), the staging launch of
+     * rlx_xgmi_clip_adamw_step, rlx_sum_slabs_deferred in front of an RCCL all-reduce -- every rank scales its own gradient by
+     * its own loss denominator before the mean over ranks, like the reference's per-rank loss.backward(). */
     const float* deferred_scale;
     int32_t deferred_stride;
     int32_t deferred_groups;
@@ -294,6 +296,9 @@ typedef struct rlx_adamw_params {
 size_t rlx_adamw_workspace_bytes(int64_t n);
 /* out[i] = sum_k grads[k][i] (k < slabs): collapse the split-K slabs before a data-parallel all-reduce. */
 int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* out, rlx_stream_t stream);
+/* ... with p->deferred_scale applied group by group (only the deferred_* fields of p are read). */
+int rlx_sum_slabs_deferred(const float* grads, int64_t n, int slabs, float* out, const struct rlx_adamw_params* p,
+                           rlx_stream_t stream);
 
 /* step_state: NULL (use p->step) or device int32[2] = {steps applied, pending flag}; the kernels then keep the
  * step count on the device (t = state[0] + 1, advanced only when the update was applied), which makes a
@@ -476,7 +481,8 @@ typedef struct rlx_ppo_step_args {
      *   `out` is then the rlx_dppo_out row.  The denominator of the actor loss -- the count of the behaviour mask -- depends on
      *   every row's forward, so the gradients of the ACTOR network (actor_logstd, backbone.*, actor_mean.*) leave in SUM form:
      *   multiply them by out[RLX_PPO_ACTOR_GRAD_SCALE] (rlx_clip_adamw_step does: rlx_adamw_params.deferred_scale).  The value
-     *   network's gradients are final as always.  Not available on the row-split bf16 launch (RLX_FUSED_ROWS). */
+     *   network's gradients are final as always.  The row-split bf16 launch (RLX_FUSED_ROWS) has no decoupled form: the
+     *   column-split one runs. */
     const struct rlx_decoupled_loss_params* decoupled;
     const float* proximal_logprobs;
     const float* versions;

@@ -186,6 +186,7 @@ PROTOTYPES = {
     "rlx_gather_rows": (c_int, [POINTER(GatherField), c_int, c_void_p, c_int64, c_void_p]),
     "rlx_adamw_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_sum_slabs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "rlx_sum_slabs_deferred": (c_int, [c_void_p, c_int64, c_int, c_void_p, POINTER(AdamwParams), c_void_p]),
     "rlx_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamwParams), c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "rlx_bootstrap_rewards": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

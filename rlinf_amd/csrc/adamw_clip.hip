@@ -70,19 +70,12 @@ __global__ __launch_bounds__(64) void peer_wait_kernel(PeerWait w) {
     }
 }
 
-// DEFER (single rank, one base): the slabs are a.deferred_groups consecutive groups (one per micro-batch of a decoupled
-// rlx_ppo_step); elements of a.deferred_range are multiplied by a.deferred_scale[g * a.deferred_stride] -- a value that step's
-// weight-gradient launch left on the device -- as group g is added.  Elements outside the ranges see x * 1.f: unchanged.
-__device__ __forceinline__ float deferred_factor(const rlx_adamw_params& a, long long idx, float sc) {
-    const bool in = (idx >= a.deferred_range[0][0] && idx < a.deferred_range[0][1]) ||
-                    (idx >= a.deferred_range[1][0] && idx < a.deferred_range[1][1]);
-    return in ? sc : 1.f;
-}
-
+// DEFER (one base): the slabs are summed group by group with the device-side scales of opt_common.h's DeferredScale.
 template <bool ADAM, bool DEFER = false>
 __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* __restrict__ out, long long n, float scale,
                                                           double* __restrict__ partials, int* __restrict__ state,
-                                                          rlx_adamw_params a, AdamScalars* __restrict__ scalars, PeerWait wait) {
+                                                          rlx_adamw_params a, AdamScalars* __restrict__ scalars, PeerWait wait,
+                                                          DeferredScale dfr) {
     __shared__ double s_red[4];
     if (ADAM && state != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && state[1] != 0) {
         state[0] += 1;  // the previous call applied its step: fold it in strictly before this call's AdamW launch reads it
@@ -109,16 +102,7 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
     for (long long i = tid0; i < n4; i += stride) {
         float4 g;
         if constexpr (DEFER) {
-            const int per = nslab / a.deferred_groups;
-            g = float4{0.f, 0.f, 0.f, 0.f};
-            for (int q = 0; q < a.deferred_groups; ++q) {
-                const float4 x = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + (long long)q * per * n4 + i, n4, per);
-                const float sc = a.deferred_scale[(long long)q * a.deferred_stride];
-                const float4 f{deferred_factor(a, 4 * i, sc), deferred_factor(a, 4 * i + 1, sc), deferred_factor(a, 4 * i + 2, sc),
-                               deferred_factor(a, 4 * i + 3, sc)};
-                if (q == 0) { g.x = x.x * f.x; g.y = x.y * f.y; g.z = x.z * f.z; g.w = x.w * f.w; }
-                else { g.x += x.x * f.x; g.y += x.y * f.y; g.z += x.z * f.z; g.w += x.w * f.w; }
-            }
+            g = sum_slab_groups_f4(reinterpret_cast<const float4*>(src.base[0]), i, n4, nslab, dfr);
         } else if (nbase == 1) {
             g = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + i, n4, nslab);  // opt_common.h
         } else {  // one staged gradient per rank, all peer loads in flight before the first add, fixed rank order
@@ -138,14 +122,7 @@ __global__ __launch_bounds__(256) void grad_reduce_sqnorm(ReduceSrc src, float* 
     for (long long i = n4 * 4 + tid0; i < n; i += stride) {
         float g;
         if constexpr (DEFER) {
-            const int per = nslab / a.deferred_groups;
-            g = 0.f;
-            for (int q = 0; q < a.deferred_groups; ++q) {
-                float x = src.base[0][(long long)q * per * n + i];
-                for (int k = 1; k < per; ++k) x += src.base[0][((long long)q * per + k) * n + i];
-                const float t = x * deferred_factor(a, i, a.deferred_scale[(long long)q * a.deferred_stride]);
-                g = q == 0 ? t : g + t;
-            }
+            g = sum_slab_groups(src.base[0], i, n, nslab, dfr);
         } else {
             g = src.base[0][i];
             for (int k = 1; k < nslab; ++k) g += src.base[0][(long long)k * n + i];
@@ -459,11 +436,18 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
     }
 }
 
-__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ g, long long n, int nslab, float* __restrict__ out) {
+template <bool DEFER>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ g, long long n, int nslab, float* __restrict__ out,
+                                                        DeferredScale dfr) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float s = g[i];
-        for (int k = 1; k < nslab; ++k) s += g[(long long)k * n + i];
+        float s;
+        if constexpr (DEFER) {
+            s = sum_slab_groups(g, i, n, nslab, dfr);
+        } else {
+            s = g[i];
+            for (int k = 1; k < nslab; ++k) s += g[(long long)k * n + i];
+        }
         out[i] = s;
     }
 }
@@ -473,6 +457,15 @@ __global__ void seq_inc_kernel(unsigned* seq) { *seq += 1u; }
 }  // namespace
 
 namespace opt {
+
+int check_deferred(const rlx_adamw_params* p, int nslab, int64_t n, const char* who) {
+    RLX_REQUIRE(p->deferred_groups >= 1 && nslab % p->deferred_groups == 0 && p->deferred_stride >= 0,
+                "%s: %d slabs do not split into deferred_groups=%d", who, nslab, p->deferred_groups);
+    for (int k = 0; k < 2; ++k)
+        RLX_REQUIRE(p->deferred_range[k][0] >= 0 && p->deferred_range[k][0] <= p->deferred_range[k][1] && p->deferred_range[k][1] <= n,
+                    "%s: deferred_range %d out of bounds", who, k);
+    return RLX_OK;
+}
 
 int grid_for(long long n) {  // one float4 per thread up to kMaxParts blocks, grid-stride beyond
     return (int)std::max<long long>(1, std::min<long long>((n / 4 + 255) / 256 + 1, (long long)kMaxParts));
@@ -516,19 +509,13 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
     AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + scalars_offset());
     PeerWait w{};
     if (wait != nullptr) w = *wait;
-    if (p->deferred_scale != nullptr) {
-        RLX_REQUIRE(src.nbase == 1 && src.seq == nullptr && wait == nullptr,
-                    "rlx_clip_adamw_step: deferred_scale is a single-rank feature (the data-parallel exchanges do not apply it)");
-        RLX_REQUIRE(p->deferred_groups >= 1 && src.nslab % p->deferred_groups == 0 && p->deferred_stride >= 0,
-                    "rlx_clip_adamw_step: %d slabs do not split into deferred_groups=%d", src.nslab, p->deferred_groups);
-        for (int k = 0; k < 2; ++k)
-            RLX_REQUIRE(p->deferred_range[k][0] >= 0 && p->deferred_range[k][0] <= p->deferred_range[k][1] && p->deferred_range[k][1] <= n,
-                        "rlx_clip_adamw_step: deferred_range %d out of bounds", k);
+    if (p->deferred_scale != nullptr && src.nbase == 1) {  // (with peers the staging launch has applied it already)
+        if (int rc = check_deferred(p, src.nslab, n, "rlx_clip_adamw_step")) return rc;
         hipLaunchKernelGGL((grad_reduce_sqnorm<true, true>), dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
-                           step_state, *p, scalars, w);
+                           step_state, *p, scalars, w, deferred_of(p));
     } else {
         hipLaunchKernelGGL(grad_reduce_sqnorm<true>, dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
-                           step_state, *p, scalars, w);
+                           step_state, *p, scalars, w, DeferredScale{});
     }
     RLX_LAUNCH_CHECK();
     hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
@@ -598,7 +585,7 @@ int launch_reduce_only(const ReduceSrc& src, float* out, int64_t n, float scale,
     if (wait != nullptr) w = *wait;
     rlx_adamw_params none{};
     hipLaunchKernelGGL(grad_reduce_sqnorm<false>, dim3(grid_for(n)), dim3(256), 0, s, src, out, (long long)n, scale,
-                       static_cast<double*>(workspace), (int*)nullptr, none, (AdamScalars*)nullptr, w);
+                       static_cast<double*>(workspace), (int*)nullptr, none, (AdamScalars*)nullptr, w, DeferredScale{});
     RLX_LAUNCH_CHECK();
     if (seq_inc != nullptr) {
         hipLaunchKernelGGL(seq_inc_kernel, dim3(1), dim3(1), 0, s, seq_inc);
@@ -622,8 +609,20 @@ extern "C" int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* ou
     RLX_REQUIRE(n >= 0 && slabs >= 1, "rlx_sum_slabs: bad sizes");
     if (n == 0) return RLX_OK;
     RLX_REQUIRE(grads && out, "rlx_sum_slabs: NULL argument");
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), grads, (long long)n,
-                       slabs, out);
+    hipLaunchKernelGGL(sum_slabs_kernel<false>, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), grads, (long long)n,
+                       slabs, out, DeferredScale{});
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+extern "C" int rlx_sum_slabs_deferred(const float* grads, int64_t n, int slabs, float* out, const rlx_adamw_params* p,
+                                      rlx_stream_t stream) {
+    RLX_REQUIRE(n >= 0 && slabs >= 1 && p != nullptr && p->deferred_scale != nullptr, "rlx_sum_slabs_deferred: bad sizes / no deferred_scale");
+    if (n == 0) return RLX_OK;
+    RLX_REQUIRE(grads && out, "rlx_sum_slabs_deferred: NULL argument");
+    if (int rc = check_deferred(p, slabs, n, "rlx_sum_slabs_deferred")) return rc;
+    hipLaunchKernelGGL(sum_slabs_kernel<true>, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), grads, (long long)n,
+                       slabs, out, deferred_of(p));
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

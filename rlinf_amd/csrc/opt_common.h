@@ -47,6 +47,57 @@ __device__ __forceinline__ float4 sum_slabs_f4(const float4* __restrict__ gp, lo
 }
 #endif
 
+// Slab groups with a device-side scale per group (rlx_adamw_params.deferred_*: the decoupled rlx_ppo_step leaves the actor network's
+// gradients in sum form and 1 / their denominator in its metric row).  The nslab slabs are `groups` consecutive groups; an element
+// inside one of the two ranges is multiplied by scale[g * stride] as group g is added; outside them by 1.f (bit-identical to the
+// plain sum for one group).  Shared by every kernel that collapses split-K slabs: the single-rank reduce, the xGMI staging launch
+// and rlx_sum_slabs in front of an RCCL all-reduce.
+struct DeferredScale {
+    const float* scale;  // nullptr: none
+    int stride, groups;
+    long long range[2][2];
+};
+inline DeferredScale deferred_of(const rlx_adamw_params* p) {
+    DeferredScale d{};
+    if (p != nullptr && p->deferred_scale != nullptr) {
+        d.scale = p->deferred_scale, d.stride = p->deferred_stride, d.groups = p->deferred_groups;
+        for (int k = 0; k < 2; ++k) d.range[k][0] = p->deferred_range[k][0], d.range[k][1] = p->deferred_range[k][1];
+    }
+    return d;
+}
+int check_deferred(const rlx_adamw_params* p, int nslab, int64_t n, const char* who);  // adamw_clip.hip
+#ifdef __HIPCC__
+__device__ __forceinline__ float deferred_factor(const DeferredScale& d, long long idx, float sc) {
+    const bool in = (idx >= d.range[0][0] && idx < d.range[0][1]) || (idx >= d.range[1][0] && idx < d.range[1][1]);
+    return in ? sc : 1.f;
+}
+__device__ __forceinline__ float4 sum_slab_groups_f4(const float4* __restrict__ gp, long long i, long long n4, int nslab,
+                                                     const DeferredScale& d) {
+    const int per = nslab / d.groups;
+    float4 g{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < d.groups; ++q) {
+        const float4 x = sum_slabs_f4(gp + (long long)q * per * n4 + i, n4, per);
+        const float sc = d.scale[(long long)q * d.stride];
+        const float4 f{deferred_factor(d, 4 * i, sc), deferred_factor(d, 4 * i + 1, sc), deferred_factor(d, 4 * i + 2, sc),
+                       deferred_factor(d, 4 * i + 3, sc)};
+        if (q == 0) { g.x = x.x * f.x; g.y = x.y * f.y; g.z = x.z * f.z; g.w = x.w * f.w; }
+        else { g.x += x.x * f.x; g.y += x.y * f.y; g.z += x.z * f.z; g.w += x.w * f.w; }
+    }
+    return g;
+}
+__device__ __forceinline__ float sum_slab_groups(const float* __restrict__ g0, long long i, long long n, int nslab, const DeferredScale& d) {
+    const int per = nslab / d.groups;
+    float g = 0.f;
+    for (int q = 0; q < d.groups; ++q) {
+        float x = g0[(long long)q * per * n + i];
+        for (int k = 1; k < per; ++k) x += g0[((long long)q * per + k) * n + i];
+        const float t = x * deferred_factor(d, i, d.scale[(long long)q * d.stride]);
+        g = q == 0 ? t : g + t;
+    }
+    return g;
+}
+#endif
+
 // Cross-GPU hand-shake in front of a peer read (xgmi_allreduce.hip): publish "my buffer number s of phase p is complete" to
 // every peer's flag array, then wait until every peer has published s.  world == 0: nothing to wait for (single GPU, or the
 // wait ran as its own one-wave launch in front of this one: `fence` then asks for the acquire that goes with it).

@@ -60,20 +60,28 @@ inline double* parts_ptr(char* base, int64_t n_max) {
 }
 
 // stage: dst = sum of this rank's slabs, into slot (seq + 1) & 1 of the local buffer
+template <bool DEFER>
 __global__ __launch_bounds__(256) void xgmi_stage_kernel(const float* __restrict__ g, long long n, int nslab, float* __restrict__ slot0,
-                                                         long long n_max, const unsigned* __restrict__ seq) {
+                                                         long long n_max, const unsigned* __restrict__ seq, DeferredScale dfr) {
     float* dst = slot0 + (size_t)((*seq + 1u) & 1u) * (size_t)n_max;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool vec = (n % 4 == 0) && (n_max % 4 == 0) && (reinterpret_cast<uintptr_t>(g) % 16 == 0);
     const long long n4 = vec ? n / 4 : 0;
     for (long long i = tid0; i < n4; i += stride) {
-        const float4 s = sum_slabs_f4(reinterpret_cast<const float4*>(g) + i, n4, nslab);  // all slabs in flight, ascending adds
+        float4 s;
+        if constexpr (DEFER) s = sum_slab_groups_f4(reinterpret_cast<const float4*>(g), i, n4, nslab, dfr);
+        else s = sum_slabs_f4(reinterpret_cast<const float4*>(g) + i, n4, nslab);  // all slabs in flight, ascending adds
         reinterpret_cast<float4*>(dst)[i] = s;
     }
     for (long long i = n4 * 4 + tid0; i < n; i += stride) {
-        float s = g[i];
-        for (int k = 1; k < nslab; ++k) s += g[(long long)k * n + i];
+        float s;
+        if constexpr (DEFER) {
+            s = sum_slab_groups(g, i, n, nslab, dfr);
+        } else {
+            s = g[i];
+            for (int k = 1; k < nslab; ++k) s += g[(long long)k * n + i];
+        }
         dst[i] = s;
     }
 }
@@ -145,9 +153,17 @@ void fill_gather_src(const rlx_xgmi_comm* c, const ShardPlan& p, GatherSrc& g) {
     g.seq = c->seq;
 }
 
-int stage(const rlx_xgmi_comm* c, const float* in, int slabs, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(xgmi_stage_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, (long long)n, slabs,
-                       slot_ptr(c->base_local, c->n_max, 0), (long long)c->n_max, c->seq);
+// (`deferred`: the per-micro-batch scales of a decoupled rlx_ppo_step's actor gradients, applied as the slabs are summed -- per rank,
+//  before the exchange, like every rank's own loss denominator)
+int stage(const rlx_xgmi_comm* c, const float* in, int slabs, int64_t n, hipStream_t st, const rlx_adamw_params* deferred = nullptr) {
+    if (deferred != nullptr && deferred->deferred_scale != nullptr) {
+        if (int rc = check_deferred(deferred, slabs, n, "rlx_xgmi_clip_adamw_step")) return rc;
+        hipLaunchKernelGGL(xgmi_stage_kernel<true>, dim3(grid_for(n)), dim3(256), 0, st, in, (long long)n, slabs,
+                           slot_ptr(c->base_local, c->n_max, 0), (long long)c->n_max, c->seq, deferred_of(deferred));
+    } else {
+        hipLaunchKernelGGL(xgmi_stage_kernel<false>, dim3(grid_for(n)), dim3(256), 0, st, in, (long long)n, slabs,
+                           slot_ptr(c->base_local, c->n_max, 0), (long long)c->n_max, c->seq, DeferredScale{});
+    }
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -312,10 +328,9 @@ extern "C" int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* c, float* params, const f
                                         void* workspace, size_t workspace_bytes, rlx_stream_t stream) {
     if (int rc = check(c, n, "rlx_xgmi_clip_adamw_step")) return rc;
     RLX_REQUIRE(p != nullptr && p->grad_partials >= 1 && grads && grad_flat, "rlx_xgmi_clip_adamw_step: NULL argument");
-    RLX_REQUIRE(p->deferred_scale == nullptr, "rlx_xgmi_clip_adamw_step: deferred_scale is not applied by the data-parallel exchange");
     if (n == 0) return RLX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rc = stage(c, grads, p->grad_partials, n, st)) return rc;
+    if (int rc = stage(c, grads, p->grad_partials, n, st, p)) return rc;  // (applies p->deferred_scale, if any, to this rank's slabs)
     ReduceSrc src{};
     fill_reduce_src(c, src);
     PeerWait w{};

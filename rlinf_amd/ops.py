@@ -751,15 +751,21 @@ def mlp_value(params, packed, layout: MlpLayout, states, out: Optional[torch.Ten
     return value
 
 
-def sum_slabs(grads: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[slabs, n] -> [n]."""
+def sum_slabs(grads: torch.Tensor, out: Optional[torch.Tensor] = None, deferred: Optional[dict] = None) -> torch.Tensor:
+    """[slabs, n] -> [n].  ``deferred`` (deferred_actor_scale): the slabs are micro-batch groups behind decoupled ppo_steps."""
     lib = _lib.load()
     dev = _dev(grads)
     slabs, n = grads.shape
     if out is None:
         out = torch.empty((n,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.rlx_sum_slabs(grads.data_ptr(), n, slabs, out.data_ptr(), _stream_ptr(dev)), "rlx_sum_slabs")
+        if deferred is not None:
+            p = AdamwParams()
+            _set_deferred(p, deferred)
+            _lib.check(lib.rlx_sum_slabs_deferred(grads.data_ptr(), n, slabs, out.data_ptr(), byref(p), _stream_ptr(dev)),
+                       "rlx_sum_slabs_deferred")
+        else:
+            _lib.check(lib.rlx_sum_slabs(grads.data_ptr(), n, slabs, out.data_ptr(), _stream_ptr(dev)), "rlx_sum_slabs")
     return out
 
 
@@ -997,7 +1003,8 @@ class PreparedAdamw:
     """rlx_clip_adamw_step with every pointer fixed; ``stats`` is this step's (norm, applied) row."""
 
     def __init__(self, params, grads, exp_avg, exp_avg_sq, groups, *, betas, eps, weight_decay, max_grad_norm, grad_scale,
-                 stats, step_state, workspace, tile_layout=None, tiles=None, xgmi=None, grad_flat=None, deferred=None):
+                 stats, step_state, workspace, tile_layout=None, tiles=None, xgmi=None, grad_flat=None, deferred=None,
+                 deferred_in_caller=False):
         """``xgmi`` (scheduler.xgmi.XgmiAllReduce) + ``grad_flat`` [n]: rlx_xgmi_clip_adamw_step instead -- ``grads`` are this
         rank's slabs, the reduced gradient (scaled by grad_scale = 1 / world_size) lands in grad_flat, then clip + AdamW."""
         self._lib = _lib.load()
@@ -1011,6 +1018,9 @@ class PreparedAdamw:
         if tile_layout is not None and tiles is not None:
             p.tile_layout, p.tiles, p.tiles_bf16 = ctypes_pointer(tile_layout), tiles.data_ptr(), int(tiles.dtype == torch.bfloat16)
         _set_deferred(p, deferred)
+        self.deferred = deferred  # (a data-parallel caller that collapses the slabs itself -- RCCL path -- applies it there)
+        if deferred is not None and deferred_in_caller:
+            p.deferred_scale = None  # the caller sums (and scales: sum_slabs(deferred=...)) the slabs in front of its all-reduce
         self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat, deferred)
         if xgmi is not None:
             self._fn, self._name = self._lib.rlx_xgmi_clip_adamw_step, "rlx_xgmi_clip_adamw_step"

@@ -91,10 +91,10 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
 
     # ---- the fused path: rlx_ppo_step with the decoupled loss + deferred actor scale, prepared launches, hipGraph -------
     def _fused_update_ok(self, flat: dict) -> bool:
-        """One rank (the data-parallel exchanges do not apply the deferred actor scale), no critic warm-up, loss-mask sums
-        already at the advantage shape."""
+        """No critic warm-up, loss-mask sums already at the advantage shape.  (Any world size: every rank applies its own
+        micro-batches' actor scales where its slabs are collapsed -- the xGMI staging launch or the slab sum in front of RCCL.)"""
         msum = flat.get("loss_mask_sum")
-        return (self.fused_step and self.critic_warmup_steps == 0 and self._world_size == 1
+        return (self.fused_step and self.critic_warmup_steps == 0
                 and (msum is None or (msum.dtype == torch.int64 and msum.numel() == flat["advantages"].numel())))
 
     def _decoupled_loss_params(self):
@@ -147,11 +147,15 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                                                      grad_out=1.0 / accum, tiles=tiles, bf16=bf16, decoupled=dec))
                     if bonus > 0:
                         calls.append(lambda _s, mb=mb, g=g, r=row: self._entropy_bonus_deferred(mb, g, r, ent_row))
+                multi, xg = self._world_size > 1, self._xgmi
                 adam = ops.PreparedAdamw(
-                    m.flat.data, grads, self.exp_avg, self.exp_avg_sq, self.groups, betas=(o.adam_beta1, o.adam_beta2),
-                    eps=o.adam_eps, weight_decay=o.weight_decay, max_grad_norm=o.clip_grad, grad_scale=1.0, stats=norms[step],
-                    step_state=self.step_state, workspace=self.adamw_ws, tile_layout=m.layout if tiles is not None else None,
-                    tiles=tiles, deferred=ops.deferred_actor_scale(m.layout, step_rows[:, :PPO_OUT_FLOATS], accum))
+                    m.flat.data, self.grad_flat if (multi and xg is None) else grads, self.exp_avg, self.exp_avg_sq, self.groups,
+                    betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay, max_grad_norm=o.clip_grad,
+                    grad_scale=1.0 / self._world_size if multi else 1.0, stats=norms[step], step_state=self.step_state,
+                    workspace=self.adamw_ws, tile_layout=m.layout if tiles is not None else None, tiles=tiles, xgmi=xg,
+                    grad_flat=self.grad_flat if xg is not None else None,
+                    deferred=ops.deferred_actor_scale(m.layout, step_rows[:, :PPO_OUT_FLOATS], accum),
+                    deferred_in_caller=multi and xg is None)
                 plan.append((calls, adam))
                 step += 1
         self._ws["aplan_key"], self._ws["aplan"] = pkey, plan
@@ -176,7 +180,8 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
         self._grad_out_host = 1.0 / accum
         plan = self._fused_plan(flat, N, rows, norms, grads, ws, n_global, per_rank, accum, micro)
         gkey2 = ("agraph", self._ws["aplan_key"])
-        use_graph = self.enable_hip_graph and self.lr_scheduler.is_static
+        # (at world_size > 1 only over the xGMI exchange -- pure kernels; RCCL capture needs the all-rank agreement of the base class)
+        use_graph = self.enable_hip_graph and self.lr_scheduler.is_static and (self._world_size == 1 or self._xgmi is not None)
         self._lr_log = []
         if use_graph and self._ws.get("agraph_key") == gkey2:
             self._ws["agraph"].replay()
@@ -192,6 +197,8 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                 self.optimizer_steps = before  # capture records, it does not execute
                 self._ws["agraph_key"], self._ws["agraph"] = gkey2, g
         out = self._collect_decoupled_metrics(rows, norms, accum, flat.get("versions") is not None)
+        if self._xgmi is not None:
+            self._xgmi.check_status()  # a peer that never published its gradient: raise instead of training on garbage
         self._step_lr_scheduler()  # :467
         return out
 

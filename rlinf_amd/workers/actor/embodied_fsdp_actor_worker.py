@@ -613,7 +613,7 @@ class EmbodiedFSDPActor(Worker):
                 for call in micro_calls:
                     call(stream)
                 if self._world_size > 1 and self._xgmi is None:
-                    ops.sum_slabs(grads, out=self.grad_flat)
+                    ops.sum_slabs(grads, out=self.grad_flat, deferred=adam.deferred)
                     all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1); capturable in a hipGraph
                 adam(stream)
         m.mark_updated(tiles_fresh=tiles_fresh)

@@ -156,8 +156,60 @@ def gpu_main(out_path, precision, transport="xgmi", graph="0", backend="gloo"):
     dist.destroy_process_group()
 
 
+def gpu_async_main(out_path, precision, transport="xgmi", graph="0", backend="gloo"):
+    """The ASYNC (decoupled PPO) learner at world_size W on a shared GPU: iteration 0 through the runner (every sample one version
+    behind: alpha = 0), then the same buffer again with mixed behaviour versions under a behaviour-weight threshold that masks
+    samples -- the fused step's actor gradients leave in sum form and every rank scales ITS slabs by ITS micro-batch's count
+    before the exchange.  Dumps the parameters after each phase."""
+    import copy
+
+    from oracle import ppo_oracle as O
+    from test_end_to_end import make_cfg
+
+    from oracle import ppo_loop as L
+    from rlinf_amd.config import validate_cfg
+    from rlinf_amd.runners import EmbodiedRunner
+    from rlinf_amd.scheduler import init_distributed
+    from rlinf_amd.workers.actor.async_ppo_fsdp_worker import AsyncPPOEmbodiedFSDPActor
+    from rlinf_amd.workers.env import EnvWorker
+    from rlinf_amd.workers.rollout.hf import MultiStepRolloutWorker
+    os.environ["RLX_DIST_BACKEND"] = backend
+    os.environ["RLX_GRAD_ALLREDUCE"] = transport
+    T, B, GB = 12, 64, 192
+    W = int(os.environ["WORLD_SIZE"])
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, micro_batch=GB // W // 2, hip_graph=graph == "1")  # two micro-batches per step
+    cfg.actor.model.precision = precision
+    cfg.algorithm.loss_type = "decoupled_actor_critic"
+    cfg.algorithm.behave_weight_threshold = 1.01
+    cfg = validate_cfg(cfg)
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    sd = copy.deepcopy(O.OracleMLPPolicy(42, 8, 1).state_dict())
+    ctx = init_distributed()
+    assert ctx.world_size == W
+    actor = AsyncPPOEmbodiedFSDPActor.create_group(cfg, ctx).launch(None, name="ActorGroup")
+    runner = EmbodiedRunner(cfg, actor, MultiStepRolloutWorker.create_group(cfg, ctx).launch(None, name="RolloutGroup"),
+                            EnvWorker.create_group(cfg, ctx).launch(None, name="EnvGroup"))
+    runner.init_workers(env_tensors=env)
+    w = actor.worker
+    w.model.load_reference_state_dict(sd)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    lo, hi = ctx.rank * (B // W), (ctx.rank + 1) * (B // W)
+    runner.run_step(eps[:, lo:hi].cuda())
+    first = w.model.flat.detach().cpu().clone()
+    w.set_global_step(2)  # current_version 3: alpha = 2/3 for version 0, 1/2 for version 1
+    w.rollout_batch["versions"][T // 2:] += 1.0
+    metrics = w.run_training()
+    torch.save(dict(rank=ctx.rank, first_params=first, final_params=w.model.flat.detach().cpu(), metrics=metrics,
+                    backend=w.grad_allreduce_backend, fused="aplan_key" in w._ws, graph="agraph" in w._ws), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "cpu":
         cpu_main(sys.argv[2])
+    elif sys.argv[1] == "gpu_async":
+        gpu_async_main(*sys.argv[2:])
     else:
         gpu_main(*sys.argv[2:])

@@ -237,6 +237,74 @@ def _compare_with_the_sharded_oracle(outs, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport,graph", [("xgmi", "1"), ("rccl", "0")])
+def test_async_learner_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph):
+    """The async (decoupled PPO) learner on its fused path at world_size 2 (two processes sharing the GPU): the actor network's
+    gradients leave rlx_ppo_step in sum form and each rank multiplies ITS slab groups by ITS micro-batches' 1 / behaviour-mask count
+    where it collapses them -- the xGMI staging launch, or rlx_sum_slabs_deferred in front of the (gloo) all-reduce -- before the mean
+    over ranks.  Against the reference arithmetic applied shard by shard: per-rank shuffle (seed + rank), masked_normalization of
+    the advantages with statistics over BOTH shards, per-rank micro-batches, (loss / accumulation / world).backward()."""
+    from oracle import ppo_loop as L
+    from oracle import ppo_oracle as O
+    world, T, B, GB = 2, 12, 64, 192
+    outs = [torch.load(o, weights_only=False) for o in _launch("gpu_async", tmp_path, "32", transport, graph, "gloo",
+                                                             port=29691 + (transport == "rccl"), timeout=600, world=world)]
+    assert all(o["fused"] for o in outs) and all(o["graph"] == (graph == "1") for o in outs)
+    assert all(o["backend"] == (transport if transport == "xgmi" else "rccl") for o in outs), [o["backend"] for o in outs]
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    ora = O.OracleMLPPolicy(42, 8, 1)
+    opt = O.build_adamw(ora)
+    eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100))
+    batches = []
+    for r in range(world):
+        sl = slice(r * B // world, (r + 1) * B // world)
+        batch = L.advantages(L.rollout(ora, {k: v[:, sl].contiguous() for k, v in env.items()}, eps[:, sl], 0.8, True), 0.8, 0.9, True)
+        batch["versions"] = torch.zeros_like(batch["prev_logprobs"])
+        batches.append(batch)
+
+    def sharded_async_update(version):
+        per_rank, micro = GB // world, GB // world // 2
+        flats = [O.flatten_and_shuffle(b, torch.randperm(T * B // world, generator=torch.Generator().manual_seed(1234 + r)))
+                 for r, b in enumerate(batches)]
+        adv = O.masked_normalization(torch.cat([f["advantages"] for f in flats]), None)  # statistics over every rank's rows
+        for r, f in enumerate(flats):
+            f["advantages"] = adv[r * (T * B // world):(r + 1) * (T * B // world)]
+        n_global, accum = (T * B // world) // per_rank, per_rank // micro
+        for _ in range(2):  # update_epoch
+            chunks = [O.chunk_batch(f, n_global) for f in flats]
+            for i in range(n_global):
+                opt.zero_grad()
+                for r in range(world):
+                    for mb in O.chunk_batch(chunks[r][i], accum):
+                        out = ora.evaluate(mb["forward_inputs"]["states"], mb["forward_inputs"]["action"])
+                        shaped = O.shape_loss_inputs(out["logprobs"], mb["prev_logprobs"], mb["advantages"], "action_level", 8,
+                                                     values=out["values"], prev_values=mb["prev_values"], returns=mb["returns"])
+                        _, ver = O.shape_decoupled_inputs(None, mb["versions"], "action_level", 8, out["logprobs"].shape[0],
+                                                          shaped["logprobs"].shape)
+                        loss, _ = O.decoupled_actor_critic_loss(versions=ver, current_version=version + 1, behave_weight_threshold=1.01,
+                                                                clip_ratio_low=0.2, clip_ratio_high=0.2, clip_ratio_c=3.0, value_clip=1.0,
+                                                                huber_delta=10.0, **shaped)
+                        (loss / accum / world).backward()
+                gn = torch.nn.utils.clip_grad_norm_(ora.parameters(), 0.5)
+                if torch.isfinite(gn):
+                    opt.step()
+        return torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
+
+    steps = 2 * ((T * B // world) // (GB // world))
+    for phase, key in enumerate(("first_params", "final_params")):
+        if phase == 1:
+            for b in batches:
+                b["versions"][T // 2:] += 1.0
+        want = sharded_async_update(version=0 if phase == 0 else 2)
+        for o in outs:
+            diff = (o[key] - want).abs()
+            assert float(diff.max()) <= 2 * 3e-4 * steps * (phase + 1) + 1e-6, (key, float(diff.max()))
+            assert float((diff > 2e-5 * (phase + 1)).float().mean()) < 0.02, (key, float((diff > 2e-5).float().mean()))
+        assert torch.equal(outs[0][key], outs[1][key])  # both ranks hold the same weights
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("graph", ["1"])  # (iteration 0 of the graph case runs eagerly and captures: both launch styles in one ~2-minute run)
 def test_eight_ranks_on_one_gpu_match_the_sharded_oracle(tmp_path, graph):
     """The WHOLE learner at world_size 8 -- the size the scaling benchmark runs at -- as eight processes sharing the one GPU of the

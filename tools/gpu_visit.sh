@@ -39,6 +39,8 @@ for STEP in "$@"; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     async_tests)
       timeout 900 python -m pytest tests/test_gpu_fused_step.py tests/test_gpu_losses.py tests/test_end_to_end.py -q -x -m gpu -k "decoupled or deferred or async" 2>&1 | tail -25 ;;
+    async_dist_tests)
+      timeout 1200 python -m pytest tests/test_distributed.py -q -x -m gpu -k "async_learner or two_ranks_match or xgmi_clip_adamw" 2>&1 | tail -25 | cut -c1-400 ;;
     rows_probe)
       timeout 300 python tools/fused_rows_probe.py > gpurun_out/${TAG}_rows_probe.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_probe.txt ;;
     rows_dev)
