@@ -133,3 +133,48 @@ def test_split_k_slab_plan_by_precision(lib):
         rows = -(-rows // 32) * 32          # rows per slab are whole 32-row k-blocks ...
         assert -(-m // rows) == f32, (m, f32)  # ... and every slab is non-empty: the launch writes each one
     assert lib.rlx_ppo_step_slabs_for(byref(lay), 0, 1) == 1 and lib.rlx_ppo_step_slabs_for(None, 8192, 1) == 1
+
+
+def test_struct_mirrors_match_the_library(lib):
+    """rlx_abi_struct_sizes: the ctypes mirrors of every argument struct have the size the library was compiled with (load()
+    refuses a mismatch; this names the struct when it happens) and a short buffer is honoured."""
+    from rlinf_amd import _lib
+    mirrors = (_lib.GaeParams, _lib.PpoLossParams, _lib.GatherField, _lib.AdamwGroup, _lib.AdamwParams, _lib.MlpLayout, _lib.ValueJob,
+               _lib.RolloutStep, _lib.PpoStepArgs, _lib.DecoupledLossParams, _lib.TokenRows, _lib.TokenLossParams, _lib.CopySegment)
+    sizes = (ctypes.c_size_t * 16)(*([0] * 16))
+    assert lib.rlx_abi_struct_sizes(ctypes.cast(sizes, ctypes.c_void_p), 16) == len(mirrors)
+    assert [ctypes.sizeof(c) for c in mirrors] == list(sizes)[:len(mirrors)] and list(sizes)[len(mirrors):] == [0, 0, 0]
+    short = (ctypes.c_size_t * 2)(7, 7)
+    assert lib.rlx_abi_struct_sizes(ctypes.cast(short, ctypes.c_void_p), 1) == len(mirrors) and short[1] == 7
+    assert lib.rlx_abi_struct_sizes(None, 0) == len(mirrors)
+
+
+def test_argument_validation_of_the_decoupled_step_entries(lib):
+    """The round-4 entries reject bad arguments before any HIP call: a decoupled rlx_ppo_step without the tensors its proximal mode
+    needs, slab groups that do not divide the slabs, a deferred range outside the buffer."""
+    from rlinf_amd import _lib
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    lay = MLPPolicy(42, 8, 1, True, False).layout
+    p = _lib.AdamwParams()
+    fake = ctypes.c_void_p(4096)  # never dereferenced: validation fails first
+    assert lib.rlx_sum_slabs_deferred(fake, 16, 4, fake, ctypes.byref(p), None) == -22 and b"deferred_scale" in lib.rlx_last_error()
+    p.deferred_scale, p.deferred_stride, p.deferred_groups = 4096, 22, 3
+    assert lib.rlx_sum_slabs_deferred(fake, 16, 4, fake, ctypes.byref(p), None) == -22 and b"deferred_groups=3" in lib.rlx_last_error()
+    p.deferred_groups = 2
+    p.deferred_range[0][0], p.deferred_range[0][1] = 0, 17
+    assert lib.rlx_sum_slabs_deferred(fake, 16, 4, fake, ctypes.byref(p), None) == -22 and b"deferred_range 0" in lib.rlx_last_error()
+    assert lib.rlx_gaussian_entropy_bonus_deferred(fake, 8, fake, fake, 0.01, 1.0, 0, 1.0, None, None) == -22
+    loss = _lib.PpoLossParams()
+    loss.raw_per_adv, loss.sub_per_adv, loss.has_critic = 8, 1, 0
+    dp = _lib.DecoupledLossParams()
+    a = _lib.PpoStepArgs()
+    a.layout, a.loss, a.m = ctypes.pointer(lay), ctypes.pointer(loss), 64
+    for f in ("params", "states", "action", "old_logprobs", "advantages", "grads", "out", "workspace"):
+        setattr(a, f, 4096)
+    a.decoupled = ctypes.addressof(dp)
+    dp.proximal_mode = 7
+    assert lib.rlx_ppo_step(ctypes.byref(a), None) == -22 and b"proximal_mode 7" in lib.rlx_last_error()
+    dp.proximal_mode = _lib.PROX_GIVEN
+    assert lib.rlx_ppo_step(ctypes.byref(a), None) == -22 and b"GIVEN without proximal_logprobs" in lib.rlx_last_error()
+    dp.proximal_mode = _lib.PROX_FROM_VERSIONS
+    assert lib.rlx_ppo_step(ctypes.byref(a), None) == -22 and b"FROM_VERSIONS without versions" in lib.rlx_last_error()
