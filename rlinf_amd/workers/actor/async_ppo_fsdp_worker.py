@@ -19,6 +19,7 @@ from ..._lib import DPPO_OUT_NAMES, PPO_ACTOR_GRAD_SCALE, PPO_OUT_FLOATS
 from ...algorithms.losses import _CRITIC_KEYS, _DECOUPLED_KEYS, _EV_MAP, explained_variance_from_stats
 from ...algorithms.registry import calculate_adv_and_returns
 from ...scheduler import all_reduce_flat_
+from ...utils.pending import PendingMetrics
 from .embodied_fsdp_actor_worker import CRITIC_EXPLAINED_VARIANCE_KEY, EmbodiedFSDPActor
 
 
@@ -197,7 +198,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                 self.optimizer_steps = before  # capture records, it does not execute
                 self._ws["agraph_key"], self._ws["agraph"] = gkey2, g
         out = self._collect_decoupled_metrics(rows, norms, accum, flat.get("versions") is not None)
-        if self._xgmi is not None:
+        if self._xgmi is not None and not self.defer_host_reads:
             self._xgmi.check_status()  # a peer that never published its gradient: raise instead of training on garbage
         self._step_lr_scheduler()  # :467
         return out
@@ -267,9 +268,10 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
             self._step_lr_scheduler()  # :467
             return out
 
-    def _collect_decoupled_metrics(self, rows, norms, accum: int, has_versions: bool) -> dict:
+    def _collect_decoupled_metrics(self, rows, norms, accum: int, has_versions: bool):
         """Means over micro-batches (the version metrics only over those that reported them: some element unmasked,
-        losses.py:156-165), AVG over ranks; EV sufficient statistics summed (:477-496).  One D2H copy."""
+        losses.py:156-165), AVG over ranks; EV sufficient statistics summed (:477-496).  One D2H copy -- behind the queued
+        launches and read one iteration late when the runner's run-ahead loop asks for that (utils/pending.py)."""
         m = rows.mean(dim=0)
         counted = (rows[:, DPPO_OUT_NAMES["mask_count"]] > 0).float()
         ver = (rows[:, DPPO_OUT_NAMES["actor/average_version"]] * counted).sum() / counted.sum().clamp_min(1.0)
@@ -278,17 +280,32 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
         if self._world_size > 1:
             all_reduce_flat_(avg, self.ctx, average=True)
             all_reduce_flat_(ev, self.ctx)
-        host, any_counted = torch.cat([avg, ev, counted.sum().view(1)]).tolist(), None
-        any_counted = host[-1] > 0
-        out = {k: host[DPPO_OUT_NAMES[k]] for k in _DECOUPLED_KEYS + _CRITIC_KEYS}
-        if has_versions and any_counted:
-            out["actor/average_version"] = host[PPO_OUT_FLOATS + 2]
-            out["actor/current_version"] = float(int(self.version) + 1)
-        n0 = PPO_OUT_FLOATS + 4
-        out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(
-            {name: host[n0 + i] for i, name in enumerate(_EV_MAP.values())})
-        out["actor/total_loss"] = (host[DPPO_OUT_NAMES["loss"]] + host[PPO_OUT_FLOATS]) / max(accum, 1)
-        out["actor/entropy_loss"] = host[PPO_OUT_FLOATS + 1]
-        out["actor/grad_norm"] = host[PPO_OUT_FLOATS + 3]
-        out["actor/lr"], out["critic/lr"] = self._lrs
-        return out
+        vec = torch.cat([avg, ev, counted.sum().view(1)])
+        current, lrs = float(int(self.version) + 1), tuple(self._lrs)
+        xgmi = self._xgmi
+        snap = xgmi is not None and self.defer_host_reads
+        if snap:  # the exchange's status word travels with this step's numbers (a blocking read would wait for the whole queue)
+            vec = torch.cat([vec, xgmi.status_snapshot(torch.empty(1, dtype=torch.float32, device=vec.device))])
+
+        def finish(host: list) -> dict:
+            if snap:
+                timed_out, host = host[-1] != 0.0, host[:-1]
+                if timed_out:
+                    xgmi.check_status()  # raises: a peer never published its gradient during this step
+            any_counted = host[-1] > 0
+            out = {k: host[DPPO_OUT_NAMES[k]] for k in _DECOUPLED_KEYS + _CRITIC_KEYS}
+            if has_versions and any_counted:
+                out["actor/average_version"] = host[PPO_OUT_FLOATS + 2]
+                out["actor/current_version"] = current
+            n0 = PPO_OUT_FLOATS + 4
+            out[CRITIC_EXPLAINED_VARIANCE_KEY] = explained_variance_from_stats(
+                {name: host[n0 + i] for i, name in enumerate(_EV_MAP.values())})
+            out["actor/total_loss"] = (host[DPPO_OUT_NAMES["loss"]] + host[PPO_OUT_FLOATS]) / max(accum, 1)
+            out["actor/entropy_loss"] = host[PPO_OUT_FLOATS + 1]
+            out["actor/grad_norm"] = host[PPO_OUT_FLOATS + 3]
+            out["actor/lr"], out["critic/lr"] = lrs
+            return out
+
+        if self.defer_host_reads:
+            return PendingMetrics(vec, finish)
+        return finish(vec.tolist())

@@ -145,6 +145,8 @@ def _build(cfg, env_tensors, state_dict):
     from rlinf_amd.workers.actor import EmbodiedFSDPActor
     from rlinf_amd.workers.env import EnvWorker
     from rlinf_amd.workers.rollout.hf import MultiStepRolloutWorker
+    if cfg.algorithm.loss_type == "decoupled_actor_critic":
+        from rlinf_amd.workers.actor.async_ppo_fsdp_worker import AsyncPPOEmbodiedFSDPActor as EmbodiedFSDPActor  # noqa: F811
     cfg = validate_cfg(cfg)
     ctx = init_distributed()
     actor = EmbodiedFSDPActor.create_group(cfg, ctx).launch(None, name="ActorGroup")
@@ -486,8 +488,9 @@ def test_async_ppo_learner_matches_oracle(auto_reset, entropy_bonus, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [dict(hip_graph=True), dict(hip_graph=False), dict(hip_graph=True, pipeline=True, rollout_epoch=2)],
-                         ids=["graph", "eager", "pipeline-e2"])
+@pytest.mark.parametrize("shape", [dict(hip_graph=True), dict(hip_graph=False), dict(hip_graph=True, pipeline=True, rollout_epoch=2),
+                                   dict(hip_graph=True, learner="async")],
+                         ids=["graph", "eager", "pipeline-e2", "async-learner-graph"])
 def test_run_ahead_loop_reads_the_same_metrics_one_iteration_late(shape):
     """EmbodiedRunner.run() queues iteration i + 1 before it reads iteration i's metrics (runner.defer_metrics, the default): every
     iteration's metric dict and the final weights are identical, bit for bit, to the loop that reads each step's numbers before it
@@ -498,8 +501,12 @@ def test_run_ahead_loop_reads_the_same_metrics_one_iteration_late(shape):
     torch.manual_seed(11)
     sd = copy.deepcopy(O.OracleMLPPolicy(42, 8, 1).state_dict())
     outs = []
+    shape = dict(shape)
+    learner = shape.pop("learner", "sync")
     for defer in (False, True):
         cfg = make_cfg(total_envs=B, steps=16, global_batch=256, **shape)
+        if learner == "async":  # the decoupled learner's metric vector travels the same way (its replayed graph reads the version word)
+            cfg.algorithm.loss_type, cfg.algorithm.behave_weight_threshold = "decoupled_actor_critic", 1.5
         cfg.runner.max_epochs = n_iter
         cfg.runner.defer_metrics = defer
         runner = _build(cfg, env, sd)

@@ -41,6 +41,11 @@ for STEP in "$@"; do
       timeout 900 python -m pytest tests/test_gpu_fused_step.py tests/test_gpu_losses.py tests/test_end_to_end.py -q -x -m gpu -k "decoupled or deferred or async" 2>&1 | tail -25 ;;
     async_dist_tests)
       timeout 1200 python -m pytest tests/test_distributed.py -q -x -m gpu -k "async_learner or two_ranks_match or xgmi_clip_adamw" 2>&1 | tail -25 | cut -c1-400 ;;
+    run_ahead_tests)
+      timeout 900 python -m pytest tests/test_end_to_end.py -q -x -m gpu -k "run_ahead or async" 2>&1 | tail -15 | cut -c1-300 ;;
+    bench_variants)
+      timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_bench_variants.json 2> gpurun_out/${TAG}_bench_variants.err
+      echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_variants.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('sync', d['ms_per_step']); [print(v.get('variant','')[:50], v.get('ms_per_step'), v.get('error')) for v in d.get('variants',[])]" ;;
     rows_probe)
       timeout 300 python tools/fused_rows_probe.py > gpurun_out/${TAG}_rows_probe.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_probe.txt ;;
     rows_dev)
