@@ -626,6 +626,9 @@ def main():
             extra("roofline", lambda: gae_roofline(dev, with_traffic=not args.no_traffic))
             if not args.no_token_tier:
                 extra("roofline_widening", lambda: token_tier_roofline(dev))
+                # SURVEY.md 8f-1 end to end: the reasoning learner's iteration (FSDPActor.run_training) around a stand-in LM
+                from tools.bench_reasoning_loop import measure as reasoning_loop
+                extra("reasoning_learner", reasoning_loop)
         if not args.no_cpu_baseline:
             extra("cpu_baseline", cpu_baseline_subprocess)
             if line.get("roofline_widening"):

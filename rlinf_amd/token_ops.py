@@ -90,10 +90,15 @@ def token_logprob_bwd(logits: torch.Tensor, labels: torch.Tensor, lse: torch.Ten
 
 class _TokenLogprobFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, temperature, with_entropy, round_outputs, inplace_grad):
-        logprob, entropy, lse = token_logprob_fwd(logits, labels, temperature, with_entropy, round_outputs)
+    def forward(ctx, logits, labels, temperature, with_entropy, round_outputs, inplace_grad, window):
+        # ``window`` = (start, stop) along dim 1 of a [bsz, S, V] tensor: the kernels address that slice in place and the backward
+        # hands autograd a gradient for the WHOLE tensor (zeros outside the window, written by two fills of the outside rows) --
+        # what SliceBackward would build as zeros(logits.shape) + a strided copy of the window gradient: 2 x [bsz, S, V] of
+        # traffic and one more allocation per micro-batch.
+        view = logits if window is None else logits[:, window[0]:window[1], :]
+        logprob, entropy, lse = token_logprob_fwd(view, labels, temperature, with_entropy, round_outputs)
         ctx.save_for_backward(logits, labels, lse, entropy if with_entropy else lse)
-        ctx.cfg = (float(temperature), bool(with_entropy), bool(inplace_grad))
+        ctx.cfg = (float(temperature), bool(with_entropy), bool(inplace_grad), window)
         ctx.mark_non_differentiable(lse)
         if with_entropy:
             return logprob, entropy, lse
@@ -102,22 +107,35 @@ class _TokenLogprobFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_logprob, d_entropy, _d_lse):
         logits, labels, lse, entropy = ctx.saved_tensors
-        temperature, with_entropy, inplace = ctx.cfg
+        temperature, with_entropy, inplace, window = ctx.cfg
         if d_logprob is None:
             d_logprob = torch.zeros_like(lse)
         use_ent = with_entropy and d_entropy is not None
-        dx = token_logprob_bwd(logits, labels, lse, entropy if use_ent else None, d_logprob.contiguous(),
-                               d_entropy.contiguous() if use_ent else None, temperature, out=logits if inplace else None)
-        return dx, None, None, None, None, None
+        if window is None:
+            dx = token_logprob_bwd(logits, labels, lse, entropy if use_ent else None, d_logprob.contiguous(),
+                                   d_entropy.contiguous() if use_ent else None, temperature, out=logits if inplace else None)
+            return dx, None, None, None, None, None, None
+        full = logits if inplace else torch.empty_like(logits)
+        token_logprob_bwd(logits[:, window[0]:window[1], :], labels, lse, entropy if use_ent else None, d_logprob.contiguous(),
+                          d_entropy.contiguous() if use_ent else None, temperature, out=full[:, window[0]:window[1], :])
+        full[:, :window[0], :].zero_()
+        full[:, window[1]:, :].zero_()
+        return full, None, None, None, None, None, None
 
 
 def token_logprobs(logits: torch.Tensor, labels: torch.Tensor, *, temperature: float = 1.0, with_entropy: bool = False,
-                   round_outputs: bool = False, inplace_grad: bool = False):
+                   round_outputs: bool = False, inplace_grad: bool = False, window: Optional[tuple] = None):
     """Differentiable (logprob, entropy or None).  ``inplace_grad`` lets the backward pass overwrite the logits
     buffer with its gradient (saves one [tokens, vocab] allocation; only valid when nothing else reads the logits
-    afterwards, which holds for an lm_head output feeding only this op)."""
+    afterwards, which holds for an lm_head output feeding only this op).  ``window`` = (start, stop): ``logits`` is the model's
+    whole [bsz, S, V] output and only rows start..stop-1 of every sequence are scored (``labels`` [bsz, stop - start]); the
+    gradient comes back for the whole tensor, zero outside the window."""
+    if window is not None:
+        if logits.dim() != 3 or not (0 <= window[0] < window[1] <= logits.shape[1]):
+            raise RlxError(f"window {window} does not fit logits of shape {tuple(logits.shape)}")
+        window = (int(window[0]), int(window[1]))
     logprob, entropy, _ = _TokenLogprobFn.apply(logits, labels, float(temperature), bool(with_entropy),
-                                                bool(round_outputs), bool(inplace_grad))
+                                                bool(round_outputs), bool(inplace_grad), window)
     return logprob, (entropy if with_entropy else None)
 
 

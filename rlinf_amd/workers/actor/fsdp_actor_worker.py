@@ -85,6 +85,9 @@ class TokenLearnerStep:
             importance_sampling_fix=bool(_get(algo, "importance_sampling_fix", False)),
             importance_sampling_clip=_get(algo, "importance_sampling_clip"),
             logprob_op_type=_get(algo, "logprob_op_type", "torch"),
+            # ours (no reference key): the backward writes d_logits into the logits buffer itself -- valid when the logits feed
+            # only this step, which holds for an lm_head output; saves one [bsz, S, V] allocation per micro-batch
+            inplace_grad=bool(_get(actor, "inplace_logits_grad", False)),
             adv_type=_get(algo, "adv_type", "grpo"), group_size=int(_get(algo, "group_size", 1)),
             reinpp_kl_beta=float(_get(algo, "reinpp_kl_beta", 0.0)),
             use_reinpp_baseline=bool(_get(algo, "use_reinpp_baseline", False)),
@@ -123,8 +126,16 @@ class TokenLearnerStep:
     # fsdp_actor_worker.py:476-505 (the fixed-length branch)
     def logprobs_and_entropy(self, logits: torch.Tensor, input_ids: torch.Tensor):
         resp = self.response_len
-        window = logits[:, -resp - 1:-1, :]  # a strided view; the kernels address it in place
         responses = input_ids[:, -resp:]
+        S = logits.shape[1]
+        if logits.dim() == 3 and S > resp and self.logprob_op_type in ("torch", "flash_attn", "liger_kernel"):
+            # logits[:, -resp - 1:-1, :] scored in place; the gradient comes back for the whole [bsz, S, V] tensor from the kernel's
+            # own launch + two fills of the rows outside the window, instead of autograd's zeros(logits.shape) + strided copy
+            from ... import token_ops
+            return token_ops.token_logprobs(logits, responses, temperature=self.temperature, with_entropy=self.calculate_entropy,
+                                            round_outputs=(self.logprob_op_type != "flash_attn"), inplace_grad=self.inplace_grad,
+                                            window=(S - resp - 1, S - 1))
+        window = logits[:, -resp - 1:-1, :]  # a strided view; the kernels address it in place
         if self.calculate_entropy:
             return compute_logprobs_and_entropy_from_logits(window, responses, temperature=self.temperature,
                                                             op_type=self.logprob_op_type,

@@ -82,6 +82,33 @@ def test_unaligned_rows_and_strided_slice():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_window_mode_gradient_equals_the_sliced_path(dtype, inplace):
+    """token_logprobs(window=(a, b)) on the model's whole [bsz, S, V] output (what TokenLearnerStep uses): outputs and the gradient
+    of the whole tensor are bit-identical to slicing first and letting autograd's SliceBackward pad the window gradient with
+    zeros -- also when the gradient overwrites the logits buffer."""
+    bsz, S, resp, V = 3, 13, 7, 1001
+    g = torch.Generator().manual_seed(9)
+    base = (torch.randn(bsz, S, V, generator=g) * 3).to(dtype).to(DEV)
+    labels = torch.randint(0, V, (bsz, resp), generator=g).to(DEV)
+    w_lp, w_ent = torch.randn(bsz, resp, generator=g).to(DEV), torch.randn(bsz, resp, generator=g).to(DEV)
+    a, b = S - resp - 1, S - 1
+    x0 = base.clone().requires_grad_(True)
+    lp0, ent0 = token_ops.token_logprobs(x0[:, a:b, :], labels, temperature=1.3, with_entropy=True, round_outputs=True)
+    ((lp0 * w_lp).sum() + (ent0 * w_ent).sum()).backward()
+    leaf = base.clone().requires_grad_(True)
+    x1 = leaf * 1.0  # a non-leaf like an lm_head output: its buffer may be overwritten by the gradient
+    lp1, ent1 = token_ops.token_logprobs(x1, labels, temperature=1.3, with_entropy=True, round_outputs=True, inplace_grad=inplace,
+                                         window=(a, b))
+    ((lp1 * w_lp).sum() + (ent1 * w_ent).sum()).backward()
+    assert torch.equal(lp0, lp1) and torch.equal(ent0, ent1)
+    assert torch.equal(x0.grad, leaf.grad)
+    assert float(leaf.grad[:, :a].abs().max()) == 0.0 and float(leaf.grad[:, b:].abs().max()) == 0.0
+    with pytest.raises(Exception, match="window"):
+        token_ops.token_logprobs(base, labels, window=(5, 99))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_entropy", [False, True])
 @pytest.mark.parametrize("temperature", [1.0, 1.3])
 def test_backward_vs_autograd_oracle(dtype, with_entropy, temperature):

@@ -46,6 +46,13 @@ for STEP in "$@"; do
     bench_variants)
       timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_bench_variants.json 2> gpurun_out/${TAG}_bench_variants.err
       echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_variants.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('sync', d['ms_per_step']); [print(v.get('variant','')[:50], v.get('ms_per_step'), v.get('error')) for v in d.get('variants',[])]" ;;
+    reasoning_loop)
+      timeout 300 python -m pytest tests/test_gpu_token_path.py tests/test_gpu_reasoning_loop.py -x -q 2>&1 | tail -3
+      timeout 600 python tools/bench_reasoning_loop.py > gpurun_out/${TAG}_reasoning_loop.json 2> gpurun_out/${TAG}_reasoning_loop.err; echo "rc=$?"; tail -3 gpurun_out/${TAG}_reasoning_loop.err; cat gpurun_out/${TAG}_reasoning_loop.json | cut -c1-900
+      timeout 600 python tools/bench_reasoning_loop.py --no-inplace-grad 2>/dev/null | tee -a gpurun_out/${TAG}_reasoning_loop.json | cut -c300-800
+      rm -rf gpurun_out/prof_reason
+      timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_reason -o reason -- python tools/bench_reasoning_loop.py --iters 2 > /dev/null 2>&1
+      python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_reason)" > gpurun_out/${TAG}_reasoning_loop_kernels.txt 2>&1; head -16 gpurun_out/${TAG}_reasoning_loop_kernels.txt | cut -c1-170; rm -rf gpurun_out/prof_reason ;;
     rows_probe)
       timeout 300 python tools/fused_rows_probe.py > gpurun_out/${TAG}_rows_probe.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_probe.txt ;;
     rows_dev)
