@@ -434,6 +434,9 @@ def main():
                     "shuffles; with --rollout-epochs > 1 the learner trains on epoch e while epoch e + 1 rolls out)")
     ap.add_argument("--rollout-epochs", type=int, default=1, help="split the 128-step horizon into this many rollout epochs")
     ap.add_argument("--no-overlap", action="store_true", help="pipeline mode on ONE stream (the comparison line for the overlap)")
+    ap.add_argument("--learner", default="sync", choices=["sync", "async"],
+                    help="async: AsyncPPOEmbodiedFSDPActor (decoupled actor-critic loss, SURVEY.md 8f-4) as the timed loop -- a variant "
+                         "line for traces and A/B runs, not the BASELINE.json configuration (the default run reports it under variants)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="what `value` measures at N > 1: strong = 1024 envs in total (north_star's regime; the default), weak = "
                          "1024 envs and an 8192-row minibatch per GPU.  The other regime rides along in the same line.")
@@ -468,6 +471,8 @@ def main():
     use_graph = not args.no_graph
     common = dict(precision=args.precision, steps=args.steps, warmup=args.warmup, use_graph=use_graph, pipeline=args.pipeline,
                   rollout_epochs=args.rollout_epochs, overlap=not args.no_overlap)
+    if args.learner != "sync":
+        common["learner"] = args.learner
 
     # ---- the timed regions ------------------------------------------------------------------------------------------------
     runs, errors = {}, {}
@@ -500,7 +505,9 @@ def main():
                        "update_epoch": UPDATE_EPOCH, "parallelism": f"dp{args.gpus}", "hip_graph": use_graph,
                        "grad_allreduce": head["grad_allreduce"], "update_graph_replayed": head["update_graph_replayed"],
                        **({"pipeline": True, "rollout_epochs": args.rollout_epochs, "overlap": not args.no_overlap}
-                          if args.pipeline else {})},
+                          if args.pipeline else {}),
+                       **({"learner": "async (decoupled actor-critic loss, behave_weight_threshold 2): a VARIANT of the BASELINE.json "
+                                      "configuration, not its headline"} if args.learner != "sync" else {})},
             "ms_per_step_windows": head["ms_per_step_windows"],
             "ppo_updates_per_sec": head["ppo_updates_per_sec"],
             # end-to-end parity AT THIS configuration (1024 x 128, 8192-row minibatches, 128 optimizer steps, hipGraph replay):

@@ -53,6 +53,10 @@ for STEP in "$@"; do
       rm -rf gpurun_out/prof_reason
       timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_reason -o reason -- python tools/bench_reasoning_loop.py --iters 2 > /dev/null 2>&1
       python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_reason)" > gpurun_out/${TAG}_reasoning_loop_kernels.txt 2>&1; head -16 gpurun_out/${TAG}_reasoning_loop_kernels.txt | cut -c1-170; rm -rf gpurun_out/prof_reason ;;
+    async_prof)
+      rm -rf gpurun_out/prof_async
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_async -o bench -- python bench.py --learner async --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-variants > gpurun_out/${TAG}_async_prof.log 2>&1
+      echo "rc=$?"; tail -1 gpurun_out/${TAG}_async_prof.log | cut -c1-200; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_async)" > gpurun_out/${TAG}_async_kernels.txt 2>&1; head -16 gpurun_out/${TAG}_async_kernels.txt | cut -c1-170; rm -rf gpurun_out/prof_async ;;
     rows_probe)
       timeout 300 python tools/fused_rows_probe.py > gpurun_out/${TAG}_rows_probe.txt 2>&1; echo "rc=$?"; cat gpurun_out/${TAG}_rows_probe.txt ;;
     rows_dev)
