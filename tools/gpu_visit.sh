@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit (gpurun): named steps, each under its own timeout, logs under gpurun_out/<tag>_*.
 #   tools/gpu_visit.sh <tag> <step> [<step> ...]
-# steps: fused_tests | all_tests | smoke | rows_probe | rows_probe_prof | share_prof | bench | bench_prof | step_prof
+# steps: see the case labels below (tests, smoke, bench lines, kernel traces, probes)
 set -u
 TAG=$1; shift
 mkdir -p gpurun_out
