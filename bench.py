@@ -103,7 +103,7 @@ def _lib_handle():
     return _lib.load()
 
 
-def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 3, timed: int = 5):
+def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 3, timed: int = 9):
     """The token tier on the host cores, bounded sample of the same shape: log-prob + entropy from bf16 logits, forward and
     backward, 3 warm-up + 5 timed passes (median).  kind "reference": the reference's OWN compute_logprobs_from_logits /
     compute_entropy_from_logits (rlinf/utils/utils.py:454-512, loaded from the staged copy oracle/_ref); kind "port" (the oracle's
@@ -122,6 +122,7 @@ def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 3
         from oracle import token_oracle as TO
         logp_fn, ent_fn = TO.logprobs_from_logits, TO.entropy_from_logits
 
+    threads, avail = _cpu_threads()  # fixed, stated: min(32, schedulable cores)
     g = torch.Generator().manual_seed(1)
     x0 = (torch.randn(rows, vocab, generator=g) * 4).to(torch.bfloat16)
     labels = torch.randint(0, vocab, (rows,), generator=g)
@@ -136,12 +137,12 @@ def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 3
     t = sorted(times[warmup:])
     med = t[len(t) // 2]
     return {"value": round(rows / med, 1), "unit": "tokens/s (log-prob + entropy forward and backward)",
-            "cores": torch.get_num_threads(), "kind": kind,
+            "cores": threads, "host_cores": avail, "kind": kind,
             "sample": f"{rows} tokens x {vocab} vocab, bf16 logits; {warmup} warm-up + {timed} timed passes, median; "
                       + ("rlinf/utils/utils.py compute_logprobs_from_logits + compute_entropy_from_logits from oracle/_ref"
                          if kind == "reference" else "oracle/token_oracle.py restatement (staged reference files absent)"),
-            "pass_times_s": [round(v, 4) for v in times], "value_min_based": round(rows / t[0], 1),
-            "value_max_based": round(rows / t[-1], 1)}
+            "pass_times_s": [round(v, 4) for v in times], "value_fastest_pass": round(rows / t[0], 1),
+            "value_slowest_pass": round(rows / t[-1], 1), "spread_slowest_over_fastest": round(t[-1] / t[0], 3)}
 
 
 CPU_BASELINE_THREADS = 32  # a FIXED, stated torch thread count (capped by the schedulable cores): no per-run timing probe
@@ -190,7 +191,7 @@ def cpu_baseline_reference():
                       f"torch.set_num_threads({threads}) (fixed: min({CPU_BASELINE_THREADS}, {avail} schedulable cores))",
             "host_cores": avail, "value_is": "median-based",
             "value_lower_quartile_step": val(lo), "value_upper_quartile_step": val(hi),
-            "value_min_based": val(lo), "value_max_based": val(hi),  # (the keys speedup_vs_cpu_baseline_range reads: quartiles since round 4)
+            "value_fastest_step": val(steps[0]), "value_slowest_step": val(steps[-1]),  # true min / max of the timed steps
             "updates_per_sec": round(1.0 / med, 2), "rollout_s": round(t["rollout_s"], 3),
             "advantages_s": round(t["advantages_s"], 4),
             "update_s_per_step": {"min": round(steps[0], 4), "lower_quartile": round(lo, 4), "median": round(med, 4),
@@ -217,6 +218,28 @@ def cpu_baseline_subprocess(timeout_s: float = 240.0):
         raise RuntimeError(f"cpu baseline subprocess failed (rc {r.returncode}): {r.stderr[-300:]}")
     out = json.loads(lines[-1])
     out["sample"] += "; own process, OpenMP team pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)"
+    return out
+
+
+def token_tier_cpu_baseline_subprocess(timeout_s: float = 240.0):
+    """token_tier_cpu_baseline() under the same policy as cpu_baseline: a process of its own, a FIXED stated thread count
+    (min(32, schedulable cores)), the OpenMP team pinned.  In-process with torch's default thread count (128 threads on a box with 2
+    schedulable cores) round 4's pass times spread 29 x."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(CPU_BASELINE_THREADS, avail))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores",
+               OMP_WAIT_POLICY="active", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--token-cpu-baseline-only"], env=env, capture_output=True,
+                       text=True, timeout=timeout_s)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"token-tier cpu baseline subprocess failed (rc {r.returncode}): {r.stderr[-300:]}")
+    out = json.loads(lines[-1])
+    out["sample"] += f"; own process, torch.set_num_threads({threads}), OpenMP team pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)"
     return out
 
 
@@ -408,6 +431,14 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
         torch.cuda.empty_cache()
 
 
+def _step_slabs(precision: str) -> int:
+    """Split-K slabs of one 8192-row optimizer step (the library's own plan)."""
+    from rlinf_amd import ops
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    lay = MLPPolicy(OBS_DIM, ACT_DIM, 1, True, False).layout
+    return int(ops.ppo_step_slabs(lay, GLOBAL_BATCH, bf16=precision == "bf16"))
+
+
 DEFER_METRICS = os.environ.get("RLX_BENCH_DEFER_METRICS", "1") != "0"  # 0: read every step's metrics before queueing the next
 
 WORKLOAD = ("ManiSkill PickCube-shaped PPO: 1024 envs x 128 steps, obs 42, act 8, MLP policy (3x256 tanh actor + value head), "
@@ -451,10 +482,23 @@ def main():
     ap.add_argument("--pair-timeout", type=float, default=240.0, help="N > 1: seconds one (regime, transport) measurement may take "
                     "before the watchdog prints the line assembled so far and ends the job")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline and print its object")
+    ap.add_argument("--token-cpu-baseline-only", action="store_true", help="(internal) run the token-tier CPU baseline and print its object")
+    ap.add_argument("--no-extras", action="store_true", help="skip scaling_model, in_loop_kernels and the exchange probe")
+    ap.add_argument("--exchange", default="none", choices=["none", "self"],
+                    help="self (N = 1): only print the measured per-step cost of the gradient exchange's own launches on this device "
+                         "(tools/exchange_self.py; also part of scaling_model in the default line)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
+        return
+    if args.token_cpu_baseline_only:
+        print(json.dumps(token_tier_cpu_baseline()), flush=True)
+        return
+    if args.exchange == "self":
+        from tools.exchange_self import measure as exchange_self
+        print(json.dumps({"metric": "gradient exchange launches per optimizer step, one device (peers aliased to self)",
+                          **exchange_self("cuda:0", 287504, 10)}), flush=True)
         return
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         sys.exit(self_launch(args))  # bare shell: become the launcher
@@ -629,8 +673,16 @@ def main():
                         out.append({"variant": name, "error": f"{type(e).__name__}: {e}"[:300]})
                 return out
             extra("variants", variants)
+        if not args.no_extras:
+            from tools import bench_extras as BX
+            n_params = 287504
+            extra("in_loop_kernels", lambda: BX.in_loop_kernels(args.precision, rows=GLOBAL_BATCH, envs=ENVS,
+                                                                slabs=_step_slabs(args.precision), n_params=n_params))
+            extra("scaling_model", lambda: BX.scaling_model(dev, args.precision, n_params, {1: _step_slabs(args.precision)}))
         if not args.no_roofline:
             extra("roofline", lambda: gae_roofline(dev, with_traffic=not args.no_traffic))
+            if not args.no_extras:
+                extra("roofline_normalised", lambda: BX.gae_normalised_rows(dev))
             if not args.no_token_tier:
                 extra("roofline_widening", lambda: token_tier_roofline(dev))
                 # SURVEY.md 8f-1 end to end: the reasoning learner's iteration (FSDPActor.run_training) around a stand-in LM
@@ -639,13 +691,16 @@ def main():
         if not args.no_cpu_baseline:
             extra("cpu_baseline", cpu_baseline_subprocess)
             if line.get("roofline_widening"):
-                extra("cpu_baseline_token_tier", token_tier_cpu_baseline)
+                extra("cpu_baseline_token_tier", token_tier_cpu_baseline_subprocess)
             if line.get("cpu_baseline"):
                 cb = line["cpu_baseline"]
                 line["speedup_vs_cpu_baseline"] = round(line["value"] / cb["value"], 1)
-                if "value_min_based" in cb:  # the spread of the CPU sample carried through: not one ratio to quote
-                    line["speedup_vs_cpu_baseline_range"] = [round(line["value"] / cb["value_min_based"], 1),
-                                                             round(line["value"] / cb["value_max_based"], 1)]
+                line["speedup_vs_cpu_baseline_cores"] = cb.get("cores")  # a ratio against THAT many host cores, not a many-core host
+                if "value_fastest_step" in cb:  # the spread of the CPU sample carried through (true min / max and the quartiles)
+                    line["speedup_vs_cpu_baseline_range"] = {
+                        "cpu_fastest_to_slowest_step": [round(line["value"] / cb["value_fastest_step"], 1), round(line["value"] / cb["value_slowest_step"], 1)],
+                        "cpu_lower_to_upper_quartile_step": [round(line["value"] / cb["value_lower_quartile_step"], 1),
+                                                             round(line["value"] / cb["value_upper_quartile_step"], 1)]}
     elif ctx.rank == 0 and not args.no_roofline:
         try:
             line["roofline"] = gae_roofline(dev, with_traffic=False)

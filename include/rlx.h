@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define RLX_VERSION 100 /* 0.1.0 */
+#define RLX_VERSION 110 /* 0.1.1: bumped whenever an argument struct or a signature changes (round 5: rlx_categorical_sample's
+                           * softmax_lanes; round 4's struct growth had left it at 100) */
 
 typedef void* rlx_stream_t; /* hipStream_t */
 
@@ -680,13 +681,14 @@ int rlx_gae_seq(const float* values, const float* rewards, float* advantages, fl
  *   largest -> -inf; top_k <= 0 or >= K disables it)
  *   tokens   [n] i64 bin index in [0, K);  logprob [n] f32 = log softmax(x)[token] (optional; rounded to the dtype when
  *            rows->round_outputs);  actions [n] f32 = bin_centers[clamp(K - token - 1, 0, n_centers - 1)] (optional)
- *   Exactness of `tokens` (stated allowance): the race scores are formed as exp(x - max) / q in f32 here, torch forms
- *   softmax(x) / q with its own vectorised exp and a division by the row sum; both are correctly ordered wherever the two best
- *   scores differ by more than the rounding of one exp (2 ulp of the scores' dtype).  On such a tie -- and only there -- the
- *   returned index may be the runner-up of torch's race.  tests/test_gpu_token_path.py demands that EVERY differing row is
- *   such a tie in the oracle's own scores; with do_sample False (argmax of the raw logits) the indices are bit-exact.
+ *   Exactness of `tokens`: BIT-EXACT against the reference's CPU path (torch.multinomial over torch.softmax on the host).  The
+ *   kernel replays ATen's vectorised last-dim softmax operation for operation -- Sleef's expf_u10, the row sum accumulated per SIMD
+ *   lane over W-element chunks and folded by a W-lane butterfly, p = e * (1 / sum), then p / q and the first-index argmax --
+ *   so no tie allowance is needed (tests/test_gpu_token_path.py: torch.equal).  `softmax_lanes` = W: 16 on AVX-512 builds of
+ *   torch (0 selects it; the committed golden files were written on such a host), 8 on AVX2 hosts -- the order of the f32
+ *   additions in the row sum is the one thing of the reference's result that depends on the host it ran on.
  * ------------------------------------------------------------------------------------------ */
-int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k,
+int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k, int softmax_lanes,
                            const float* bin_centers, int n_centers, int64_t* tokens, float* logprob, float* actions,
                            rlx_stream_t stream);
 
@@ -813,6 +815,11 @@ int rlx_xgmi_connect(rlx_xgmi_comm* comm, const void* all_handles);
 /* Same-process emulation of a W-rank group (tests: every "rank" on its own stream of ONE device, no IPC): wires W
  * communicators created with rank 0 .. W-1 to each other's buffers directly. */
 int rlx_xgmi_connect_local(rlx_xgmi_comm* const* comms, int world);
+/* TIMING TOOL (bench.py `scaling_model`): every peer of `comm` (created as rank r of W) is this rank's OWN buffer, so the chain of
+ * launches a rank of a W-GPU job runs per optimizer step -- stage, hand-shake, reduce(-scatter), hand-shake, gather + clip + AdamW --
+ * executes on one device with local-memory reads in place of xGMI reads and hand-shakes that are satisfied at once.  The reduced
+ * values are NOT a valid all-reduce (every shard is this rank's shard); use scratch parameter / moment buffers. */
+int rlx_xgmi_connect_self(rlx_xgmi_comm* comm);
 /* algo: 0 direct, 1 reduce-scatter + all-gather; wait_mode: 0 inline, 1 own launch; timeout_ms > 0: new bound of every peer
  * wait.  -1 (0 for the timeout) keeps the current value.  Every rank of a group must configure the same algo. */
 int rlx_xgmi_configure(rlx_xgmi_comm* comm, int algo, int wait_mode, int timeout_ms);

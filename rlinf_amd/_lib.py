@@ -210,7 +210,7 @@ PROTOTYPES = {
                                    POINTER(TokenLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
     "rlx_token_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
-    "rlx_categorical_sample": (c_int, [c_void_p, POINTER(TokenRows), c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+    "rlx_categorical_sample": (c_int, [c_void_p, POINTER(TokenRows), c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "rlx_patch_workspace_bytes": (c_size_t, [c_int64]),
     "rlx_patch_scan": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -240,6 +240,7 @@ PROTOTYPES = {
     "rlx_xgmi_create": (c_int, [c_int, c_int, c_int64, c_int, c_int, POINTER(c_void_p), c_void_p]),
     "rlx_xgmi_connect": (c_int, [c_void_p, c_void_p]),
     "rlx_xgmi_connect_local": (c_int, [POINTER(c_void_p), c_int]),
+    "rlx_xgmi_connect_self": (c_int, [c_void_p]),
     "rlx_xgmi_configure": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rlx_xgmi_destroy": (c_int, [c_void_p]),
     "rlx_xgmi_status": (c_int, [c_void_p]),
@@ -273,7 +274,7 @@ def load() -> ctypes.CDLL:
             raise RlxError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rlx_version() < 100:
+    if lib.rlx_version() < 110:
         raise RlxError("librlx_hip.so is older than this Python package; rebuild it")
     mirrors = (GaeParams, PpoLossParams, GatherField, AdamwGroup, AdamwParams, MlpLayout, ValueJob, RolloutStep, PpoStepArgs,
                DecoupledLossParams, TokenRows, TokenLossParams, CopySegment)  # the order rlx_abi_struct_sizes documents

@@ -551,6 +551,7 @@ struct CatArgs {
     const void* noise;  // Exp(1) draws, same dtype and [n, K] dense layout; NULL = argmax (do_sample False)
     RowGeom g;
     int top_k;
+    int lanes;  // 16 / 8: f32 lanes of the reference host's vector kernels (fixes the order of the row sum's additions)
     const float* bin_centers;
     int n_centers;
     long long* tokens;
@@ -573,21 +574,55 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return v;
 }
 
-template <typename T, int EPL, bool SCALE>
+// ---- the reference's CPU softmax, operation for operation --------------------------------------------------------------------
+// north_star: "bit-exact for action indices".  The reference samples with torch.multinomial(softmax(x), 1), i.e. argmax(softmax(x) / q)
+// for its internal Exp(1) draw q, and softmax on the host is ATen's vectorised last-dim kernel (aten/src/ATen/native/cpu/
+// SoftMaxKernel.cpp, _vec_softmax_lastdim): e = Sleef_expf{16,8}_u10(x - max) lane-wise, the row sum accumulated per SIMD lane over
+// consecutive W-element chunks and folded by a butterfly of W lanes, p = e * (1 / sum).  Every one of those steps is IEEE
+// arithmetic with a fixed order, so it can be replayed exactly: W = 16 (AVX-512 builds of torch, what the golden files were
+// written on) or 8 (AVX2) is `softmax_lanes`.  Verified element for element against torch.softmax (f32 and bf16, K = 7 .. 1024,
+// with and without chunk tails) by the numpy restatement in tests/test_token_host.py::test_cpu_softmax_restatement.
+//   f32 rows   : all K elements through the vector exp; lane c sums e[c], e[W + c], ... in order (a partial last chunk adds to
+//                its first K % W lanes); K < W: one sequential sum e0 + e1 + ...
+//   bf16 rows  : the K - K % W leading elements as above (accumulators start at 0), the tail through the scalar expf
+//                (correctly rounded) and added one by one BEHIND the butterfly; p rounded to bf16.
+__device__ __forceinline__ float pow2i(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
+__device__ __forceinline__ float sleef_expf_u10(float d) {
+    const float dc = fmaxf(d, -120.f);  // (-inf / hugely negative: the result is forced to 0 below; keeps q a small integer)
+    const float q = rintf(fmul(dc, 1.442695040888963407359924681001892137426645954152985934135449406931f));
+    float s = fmaf(q, -0.693145751953125f, dc);
+    s = fmaf(q, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = fadd(1.0f, fmaf(fmul(s, s), u, s));
+    const int qi = (int)q;
+    u = fmul(fmul(u, pow2i(qi >> 1)), pow2i(qi - (qi >> 1)));  // vldexp2
+    if (d < -104.f) u = 0.f;
+    if (d > 100.f) u = __builtin_inff();
+    return u;
+}
+
+template <typename T, int EPL>
 __global__ __launch_bounds__(256) void categorical_sample_kernel(CatArgs a) {
+    constexpr bool REDUCED = sizeof(T) == 2;
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.g.n_tokens) return;
-    const int K = a.g.vocab;
+    const int K = a.g.vocab, W = a.lanes;
     const T* base = static_cast<const T*>(a.logits) + row_offset(a.g, row, a.g.seq_stride, a.g.row_stride);
     const float NEG_INF = -__builtin_inff();
-    const bool sample = a.noise != nullptr;
+    const bool sample = a.noise != nullptr, scale = sample && a.g.temp != 1.0f;
     float x[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         const int idx = lane + 64 * j;
-        const float raw = Elem<T>::load(base + (idx < K ? idx : 0));
-        x[j] = idx < K ? (sample ? prep<T, SCALE>(raw, a.g.temp, a.g.rtemp) : raw) : NEG_INF;
+        float raw = Elem<T>::load(base + (idx < K ? idx : 0));
+        if (scale) raw = Elem<T>::round(raw / a.g.temp);  // tensor / python scalar: a true division, rounded to the tensor's dtype
+        x[j] = idx < K ? raw : NEG_INF;
     }
     if (sample && a.top_k > 0 && a.top_k < K) {
         // k-th largest score = the largest t with count(key >= t) >= k, built bit by bit
@@ -610,13 +645,33 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(CatArgs a) {
 #pragma unroll
     for (int j = 1; j < EPL; ++j) m = fmaxf(m, x[j]);
     m = wave_max_f(m);
-    float e[EPL], s = 0.f;
+    // indices below `limit` go through the W lane accumulators, the rest is added one by one
+    const int limit = REDUCED ? K - K % W : (K < W ? 0 : K);
+    float e[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
-        e[j] = expf(x[j] - m);
-        s += e[j];
+        const int idx = lane + 64 * j;
+        const float d = fsub(x[j], m);
+        e[j] = idx >= K ? 0.f : (REDUCED && idx >= limit) ? (float)exp((double)d) : sleef_expf_u10(d);
     }
-    s = wave_sum(s);
+    const int c = lane & (W - 1);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j)
+        for (int mm = 0; mm < 64 / W; ++mm) {  // chunk 64 j / W + mm: element W mm + c of register j (every lane group of W agrees)
+            const float v = __shfl(e[j], W * mm + c, RLX_WAVE);
+            if (64 * j + W * mm + c < limit) acc = fadd(acc, v);
+        }
+    for (int sh = W >> 1; sh > 0; sh >>= 1) acc = fadd(acc, __shfl_xor(acc, sh, RLX_WAVE));
+    float s = acc;
+    for (int i = limit; i < K; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            if ((i >> 6) == j) v = e[j];
+        s = fadd(s, __shfl(v, i & 63, RLX_WAVE));
+    }
+    const float rs = 1.0f / s;
     // the race: argmax_v softmax(x)_v / q_v (torch.multinomial, num_samples = 1), or argmax_v x_v without sampling;
     // the lowest index wins ties, as torch.argmax does
     float best = NEG_INF;
@@ -627,7 +682,7 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(CatArgs a) {
         if (idx >= K) continue;
         float score;
         if (sample) {
-            const float p = Elem<T>::round(e[j] / s);  // softmax output in the tensor's dtype
+            const float p = Elem<T>::round(fmul(e[j], rs));  // softmax output in the tensor's dtype
             const float q = Elem<T>::load(static_cast<const T*>(a.noise) + row * K + idx);
             score = Elem<T>::round(p / q);
         } else {
@@ -664,10 +719,7 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(CatArgs a) {
 template <typename T, int EPL>
 int launch_cat(const CatArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)((a.g.n_tokens + 3) / 4)), block(256);
-    if (a.noise && a.g.temp != 1.0f)
-        hipLaunchKernelGGL((categorical_sample_kernel<T, EPL, true>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((categorical_sample_kernel<T, EPL, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((categorical_sample_kernel<T, EPL>), grid, block, 0, s, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }
@@ -831,7 +883,7 @@ extern "C" int rlx_grpo_seq_adv(const float* rewards, const uint8_t* loss_mask, 
     return RLX_OK;
 }
 
-extern "C" int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k,
+extern "C" int rlx_categorical_sample(const void* logits, const rlx_token_rows* rows, const void* noise, int top_k, int softmax_lanes,
                                       const float* bin_centers, int n_centers, int64_t* tokens, float* logprob,
                                       float* actions, rlx_stream_t stream) {
     if (int rc = check_rows(rows, "rlx_categorical_sample")) return rc;
@@ -839,7 +891,9 @@ extern "C" int rlx_categorical_sample(const void* logits, const rlx_token_rows* 
     if (rows->n_tokens == 0) return RLX_OK;
     RLX_REQUIRE(logits && tokens, "rlx_categorical_sample: NULL argument");
     RLX_REQUIRE(actions == nullptr || (bin_centers != nullptr && n_centers >= 1), "rlx_categorical_sample: actions need bin_centers");
+    RLX_REQUIRE(softmax_lanes == 0 || softmax_lanes == 8 || softmax_lanes == 16, "rlx_categorical_sample: softmax_lanes must be 16 (AVX-512 hosts; 0 = 16) or 8 (AVX2), got %d", softmax_lanes);
     CatArgs a;
+    a.lanes = softmax_lanes == 0 ? 16 : softmax_lanes;
     a.logits = logits, a.noise = noise, a.g = geom_of(rows), a.top_k = top_k, a.bin_centers = bin_centers;
     a.n_centers = n_centers, a.tokens = reinterpret_cast<long long*>(tokens), a.logprob = logprob, a.actions = actions;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -39,6 +39,7 @@ struct rlx_xgmi_comm {
     unsigned* seq_snapshot;                // device word: copy of *seq taken by the reduce-scatter launch for the gather + AdamW launch
     int* status;                           // device word: timeout flag
     bool connected, local_peers;           // local_peers: same-process emulation, nothing to unmap
+    bool self_alias;                       // rlx_xgmi_connect_self: every peer is this rank's own buffer (timing tool, results invalid)
 };
 
 namespace rlx {
@@ -96,6 +97,9 @@ int check(const rlx_xgmi_comm* c, int64_t n, const char* who) {
 void fill_wait(const rlx_xgmi_comm* c, PeerWait& w, int phase) {
     w.flags_mine = reinterpret_cast<unsigned*>(c->base_local);
     for (int r = 0; r < c->world; ++r) w.flags_peer[r] = reinterpret_cast<unsigned*>(c->base_peer[r]);
+    // self-aliased: "peer r's slot [rank]" must land in OWN slot r, or the wait for peer r would never be satisfied
+    if (c->self_alias)
+        for (int r = 0; r < c->world; ++r) w.flags_peer[r] = w.flags_mine + r - c->rank;
     w.seq = c->seq;
     w.status = c->status;
     w.timeout_ticks = c->timeout_ticks;
@@ -251,6 +255,16 @@ extern "C" int rlx_xgmi_connect(rlx_xgmi_comm* c, const void* all_handles) {
         c->base_peer[r] = static_cast<char*>(p);
     }
     c->connected = true;
+    return RLX_OK;
+}
+
+extern "C" int rlx_xgmi_connect_self(rlx_xgmi_comm* c) {
+    RLX_REQUIRE(c != nullptr, "rlx_xgmi_connect_self: NULL communicator");
+    RLX_REQUIRE(!c->connected || c->world == 1, "rlx_xgmi_connect_self: already connected");
+    for (int q = 0; q < c->world; ++q) c->base_peer[q] = c->base_local;
+    c->connected = true;
+    c->local_peers = true;
+    c->self_alias = true;
     return RLX_OK;
 }
 

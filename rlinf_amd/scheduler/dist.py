@@ -23,10 +23,26 @@ class DistContext:
     world_size: int = 1
     device: Optional[torch.device] = None
     initialized_here: bool = False
+    # RLX_FORCE_EXCHANGE (rccl | xgmi | 1): run the data-parallel gradient exchange even with ONE rank -- a one-rank RCCL
+    # communicator is legal, so the worker's own multi-GPU branch (slab sum -> dist.all_reduce -> clip + AdamW, eagerly and inside
+    # the captured update graph) executes on a one-GPU box, and bench.py can time the exchange's launches (--exchange self)
+    force_exchange: bool = False
 
     @property
     def is_distributed(self) -> bool:
         return self.world_size > 1
+
+    @property
+    def exchanges_gradients(self) -> bool:
+        return self.world_size > 1 or self.force_exchange
+
+
+def forced_exchange() -> str:
+    """"" (off), "rccl" or "xgmi": what RLX_FORCE_EXCHANGE asks for ("1" = rccl)."""
+    v = os.environ.get("RLX_FORCE_EXCHANGE", "").strip().lower()
+    if v in ("", "0", "off", "none"):
+        return ""
+    return "xgmi" if v == "xgmi" else "rccl"
 
 
 def init_distributed(backend: Optional[str] = None, device_type: Optional[str] = None) -> DistContext:
@@ -38,7 +54,8 @@ def init_distributed(backend: Optional[str] = None, device_type: Optional[str] =
     if use_cuda:
         torch.cuda.set_device(device)
     ctx = DistContext(rank, local_rank, world, device)
-    if world > 1 and not dist.is_initialized():
+    ctx.force_exchange = bool(forced_exchange()) and world == 1 and use_cuda
+    if ctx.exchanges_gradients and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -55,9 +72,9 @@ def init_distributed(backend: Optional[str] = None, device_type: Optional[str] =
 
 def all_reduce_flat_(buf: torch.Tensor, ctx: DistContext, average: bool = False) -> torch.Tensor:
     """SUM (or mean) all-reduce of one flat buffer, in place.  No-op for world_size 1."""
-    if ctx.world_size > 1:
+    if ctx.exchanges_gradients:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        if average:
+        if average and ctx.world_size > 1:
             buf.div_(ctx.world_size)
     return buf
 

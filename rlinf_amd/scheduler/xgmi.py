@@ -204,11 +204,48 @@ def _attempt(ctx, n_max: int, mem_kind: int, rounds: int, validate_timeout_ms: i
     return comm, ""
 
 
+class SelfAliasedXgmi:
+    """TIMING TOOL (rlx_xgmi_connect_self; bench.py ``scaling_model``): the communicator of rank 0 of a ``world``-rank job whose
+    peers are all its own buffer -- the per-step launch chain of a rank (stage, hand-shake, reduce(-scatter), hand-shake, gather +
+    clip + AdamW) runs on one device.  Results are not a valid all-reduce: callers pass scratch parameter / moment buffers."""
+
+    def __init__(self, device, world: int, n_max: int, algo: Optional[str] = None, wait_mode: str = "inline", timeout_ms: int = 5000):
+        self._lib = _lib.load()
+        self.world, self.n_max, self.device = int(world), int(n_max), torch.device(device)
+        self._comm = ctypes.c_void_p()
+        handle = (ctypes.c_char * XGMI_HANDLE_BYTES)()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.rlx_xgmi_create(0, self.world, self.n_max, int(timeout_ms), 0, ctypes.byref(self._comm), handle),
+                       "rlx_xgmi_create")
+            _lib.check(self._lib.rlx_xgmi_connect_self(self._comm), "rlx_xgmi_connect_self")
+            self.algo = algo or ("rsag" if self.world >= 4 else "direct")
+            self.wait_mode = wait_mode
+            _lib.check(self._lib.rlx_xgmi_configure(self._comm, XgmiAllReduce._ALGOS[self.algo], XgmiAllReduce._WAITS[wait_mode], 0),
+                       "rlx_xgmi_configure")
+        self.shared_device = False
+
+    @property
+    def handle(self):
+        return self._comm
+
+    def status_ok(self) -> bool:
+        with torch.cuda.device(self.device):
+            return self._lib.rlx_xgmi_status(self._comm) == 0
+
+    def close(self):
+        if self._comm:
+            self._lib.rlx_xgmi_destroy(self._comm)
+            self._comm = ctypes.c_void_p()
+
+
 def build(ctx, n_max: int, rounds: int = 4) -> Optional[XgmiAllReduce]:
     """Create, connect and VALIDATE an xGMI communicator; returns None (on every rank alike) when any step fails on any rank.
     Fine-grained device memory first, uncached second (both are coherent across GPUs); plain hipMalloc is never used for the
     product (RLX_XGMI_MEM_KIND=2 forces it for experiments).  RLX_GRAD_ALLREDUCE=rccl skips the attempt."""
-    if ctx.world_size <= 1 or os.environ.get("RLX_GRAD_ALLREDUCE", "xgmi").lower() in ("rccl", "nccl", "torch"):
+    from .dist import forced_exchange
+    if ctx.world_size <= 1 and not (getattr(ctx, "force_exchange", False) and forced_exchange() == "xgmi"):
+        return None  # (RLX_FORCE_EXCHANGE=xgmi: the one-rank communicator, validated against the one-rank RCCL all-reduce)
+    if os.environ.get("RLX_GRAD_ALLREDUCE", "xgmi").lower() in ("rccl", "nccl", "torch"):
         return None
     forced = os.environ.get("RLX_XGMI_MEM_KIND")
     reasons = []

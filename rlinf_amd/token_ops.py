@@ -272,12 +272,24 @@ def reinpp_seq_adv(rewards: torch.Tensor, loss_mask: torch.Tensor, logprob: Opti
     return adv
 
 
+def reference_softmax_lanes() -> int:
+    """f32 lanes of the vector kernels torch's CPU softmax runs with on THIS host: 16 (AVX-512 builds) or 8 (AVX2).  The order of
+    the additions in the reference's row sum -- and with it the last bit of softmax(x), and with that a sampled index on a near
+    tie -- depends on it; ``categorical_sample`` replays that order (include/rlx.h, rlx_categorical_sample)."""
+    try:
+        cap = torch.backends.cpu.get_cpu_capability().upper()
+    except Exception:  # noqa: BLE001
+        return 16
+    return 8 if cap == "AVX2" else 16
+
+
 def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = None, *, temperature: float = 1.0,
                        top_k: int = -1, bin_centers: Optional[torch.Tensor] = None, with_logprob: bool = True,
-                       round_outputs: bool = True):
+                       round_outputs: bool = True, softmax_lanes: Optional[int] = None):
     """logits [..., K<=1024] (a view into the model's logits is fine) -> (tokens i64, logprobs f32 or None,
     actions f32 or None), each of shape ``logits.shape[:-1]``.  ``noise``: Exp(1) draws of the logits' dtype and
-    shape (what torch.multinomial draws internally); None = argmax."""
+    shape (what torch.multinomial draws internally); None = argmax.  The sampled indices are bit-exact against the reference's
+    CPU path on a host with ``softmax_lanes`` f32 SIMD lanes (None: this host's, see reference_softmax_lanes)."""
     dev = _dev(logits, noise, bin_centers)
     lead = logits.shape[:-1]
     x, rows = _rows_of(logits, temperature if noise is not None else 1.0, round_outputs)
@@ -292,7 +304,9 @@ def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = Non
     logprob = torch.empty(lead, dtype=torch.float32, device=dev) if with_logprob else None
     actions = torch.empty(lead, dtype=torch.float32, device=dev) if centers is not None else None
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().rlx_categorical_sample(x.data_ptr(), byref(rows), _ptr(noise), int(top_k), _ptr(centers),
+        _lib.check(_lib.load().rlx_categorical_sample(x.data_ptr(), byref(rows), _ptr(noise), int(top_k),
+                                                      int(softmax_lanes if softmax_lanes is not None else reference_softmax_lanes()),
+                                                      _ptr(centers),
                                                       0 if centers is None else centers.numel(), tokens.data_ptr(),
                                                       _ptr(logprob), _ptr(actions), _stream_ptr(dev)),
                    "rlx_categorical_sample")

@@ -148,7 +148,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                                                      grad_out=1.0 / accum, tiles=tiles, bf16=bf16, decoupled=dec))
                     if bonus > 0:
                         calls.append(lambda _s, mb=mb, g=g, r=row: self._entropy_bonus_deferred(mb, g, r, ent_row))
-                multi, xg = self._world_size > 1, self._xgmi
+                multi, xg = self._exchange, self._xgmi
                 adam = ops.PreparedAdamw(
                     m.flat.data, self.grad_flat if (multi and xg is None) else grads, self.exp_avg, self.exp_avg_sq, self.groups,
                     betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay, max_grad_norm=o.clip_grad,
@@ -168,7 +168,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
         ws = self._minibatch_workspace(micro)
         gkey = ("grads", micro, accum)
         if gkey not in self._ws:
-            self._ws[gkey] = torch.empty((ws["slabs"] * accum, m.n_params), dtype=torch.float32, device=self.device)
+            self._ws[gkey] = torch.zeros((ws["slabs"] * accum, m.n_params), dtype=torch.float32, device=self.device)
         grads = self._ws[gkey]
         mkey = ("arows", n_steps, accum)
         if mkey not in self._ws:
@@ -182,7 +182,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
         plan = self._fused_plan(flat, N, rows, norms, grads, ws, n_global, per_rank, accum, micro)
         gkey2 = ("agraph", self._ws["aplan_key"])
         # (at world_size > 1 only over the xGMI exchange -- pure kernels; RCCL capture needs the all-rank agreement of the base class)
-        use_graph = self.enable_hip_graph and self.lr_scheduler.is_static and (self._world_size == 1 or self._xgmi is not None)
+        use_graph = self.enable_hip_graph and self.lr_scheduler.is_static and (not self._exchange or self._xgmi is not None)
         self._lr_log = []
         if use_graph and self._ws.get("agraph_key") == gkey2:
             self._ws["agraph"].replay()
@@ -221,7 +221,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                 return self._run_training_fused(flat, N, n_global, per_rank, accum, micro)
             n_steps = n_global * int(alg.get("update_epoch", 1))
             slabs = ops.mlp_bwd_slabs(micro)
-            grads = torch.empty((slabs * accum, m.n_params), dtype=torch.float32, device=self.device)
+            grads = torch.zeros((slabs * accum, m.n_params), dtype=torch.float32, device=self.device)
             bwd_ws = torch.empty(ops._lib.load().rlx_mlp_bwd_workspace_bytes(ops.byref(lay), micro), dtype=torch.uint8,
                                  device=self.device)
             rows = torch.zeros(n_steps * accum, PPO_OUT_FLOATS + 2, device=self.device)  # + the bonus's part of the loss, entropy loss

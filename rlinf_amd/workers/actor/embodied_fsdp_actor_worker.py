@@ -107,10 +107,10 @@ class EmbodiedFSDPActor(Worker):
         # gradient all-reduce transport (world_size > 1): hand-written xGMI peer reads, validated against torch.distributed at
         # start-up on every rank; RCCL when that is unavailable.  Either way the update phase is graph-captured.
         self._xgmi = None
-        if self._world_size > 1 and dev is not None and dev.type == "cuda":
+        if self._exchange and dev is not None and dev.type == "cuda":
             from ...scheduler import xgmi
             self._xgmi = xgmi.build(self.ctx, n)
-        self.grad_allreduce_backend = "none" if self._world_size == 1 else ("xgmi" if self._xgmi is not None else "rccl")
+        self.grad_allreduce_backend = "none" if not self._exchange else ("xgmi" if self._xgmi is not None else "rccl")
         self._build_lr_scheduler()
 
     def _build_lr_scheduler(self):
@@ -513,7 +513,7 @@ class EmbodiedFSDPActor(Worker):
         if self._xgmi is not None:  # stage + peer-read reduce + clip + AdamW: three launches, no host round trip
             ops.PreparedAdamw(self.model.flat.data, grads, self.exp_avg, self.exp_avg_sq, groups, grad_scale=1.0 / self._world_size,
                               xgmi=self._xgmi, grad_flat=self.grad_flat, **kw)(torch.cuda.current_stream(self.device).cuda_stream)
-        elif self._world_size > 1:
+        elif self._exchange:
             ops.sum_slabs(grads, out=self.grad_flat)
             all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1)
             ops.clip_adamw_step_(self.model.flat.data, self.grad_flat, self.exp_avg, self.exp_avg_sq, groups, 0,
@@ -538,7 +538,7 @@ class EmbodiedFSDPActor(Worker):
         ws = self._minibatch_workspace(micro)
         key = ("grads", micro, accum)
         if key not in self._ws:
-            self._ws[key] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
+            self._ws[key] = torch.zeros((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
             self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
         grads, grad_out = self._ws[key], self._ws["grad_out"]
         self._grad_out_host = 1.0 / accum
@@ -571,7 +571,7 @@ class EmbodiedFSDPActor(Worker):
             bf16 = m.compute_dtype == torch.bfloat16
             tiles = m.tiles() if self.optimizer_writes_tiles else None
             lp = self._loss_params(False)
-            multi = self._world_size > 1
+            multi = self._exchange
             xg = self._xgmi
             plan, step = [], 0
             for _ in range(epochs):
@@ -612,7 +612,7 @@ class EmbodiedFSDPActor(Worker):
             for micro_calls, adam in steps:
                 for call in micro_calls:
                     call(stream)
-                if self._world_size > 1 and self._xgmi is None:
+                if self._exchange and self._xgmi is None:
                     ops.sum_slabs(grads, out=self.grad_flat, deferred=adam.deferred)
                     all_reduce_flat_(self.grad_flat, self.ctx)  # RCCL, one flat 1.15 MB buffer (C1); capturable in a hipGraph
                 adam(stream)
@@ -673,7 +673,7 @@ class EmbodiedFSDPActor(Worker):
         ws = self._minibatch_workspace(micro)
         gkey = ("grads", micro, accum)
         if gkey not in self._ws:
-            self._ws[gkey] = torch.empty((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
+            self._ws[gkey] = torch.zeros((ws["slabs"] * accum, self.model.n_params), dtype=torch.float32, device=self.device)
             self._ws["grad_out"] = torch.full((1,), 1.0 / accum, dtype=torch.float32, device=self.device)
         grads = self._ws[gkey]
         self._grad_out_host = 1.0 / accum
@@ -747,7 +747,7 @@ class EmbodiedFSDPActor(Worker):
         """The update phase can live in a hipGraph when its launches are all stream operations: always on one GPU; at
         world_size > 1 with the xGMI all-reduce (pure kernels) or with RCCL (stream-ordered, capturable) -- not with a
         host-staged backend such as gloo."""
-        if self._world_size == 1 or self._xgmi is not None:
+        if not self._exchange or self._xgmi is not None:
             return True
         import torch.distributed as dist
         return dist.get_backend() == "nccl"
@@ -766,13 +766,13 @@ class EmbodiedFSDPActor(Worker):
                 with torch.cuda.graph(g):
                     self._run_update(flat, N, metrics_dev, norms_dev)
             except Exception as e:  # noqa: BLE001 -- e.g. an RCCL build that cannot be stream-captured
-                if self._world_size == 1:
+                if not self._exchange:
                     raise
                 ok = 0
                 print(f"[rlinf_amd] rank {self._rank}: capturing the update phase failed ({type(e).__name__}: {e}); running it eagerly",
                       flush=True)
             self.optimizer_steps = steps_before  # capture records, it does not execute
-            if self._world_size > 1:  # every rank replays, or none does
+            if self._exchange:  # every rank replays, or none does
                 import torch.distributed as dist
                 verdict = torch.tensor([ok], dtype=torch.int32, device=self.device)
                 dist.all_reduce(verdict, op=dist.ReduceOp.MIN)

@@ -39,6 +39,8 @@ class Worker:
         self.cfg = cfg
         self.ctx = ctx or DistContext()
         self._rank, self._world_size = self.ctx.rank, self.ctx.world_size
+        # True at world_size > 1, and at world_size 1 under RLX_FORCE_EXCHANGE (scheduler/dist.py): the gradient exchange runs
+        self._exchange = bool(getattr(self.ctx, "exchanges_gradients", self._world_size > 1))
         self.device = self.ctx.device
         self._timer_metrics: dict = {}
 

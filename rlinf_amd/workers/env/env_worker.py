@@ -85,7 +85,11 @@ class EnvWorker(Worker):
             if self.device.type == "cuda":
                 self.epoch_events = [torch.cuda.Event() for _ in range(self.rollout_epoch)]
                 if self.overlap:
-                    self._rollout_stream = torch.cuda.Stream(self.device)
+                    # RLX_ROLLOUT_CUS / runner.rollout_cus: the rollout stream dispatches to that many CUs only (utils/streams.py)
+                    import os
+                    from ...utils.streams import rollout_stream
+                    n_cus = int(os.environ.get("RLX_ROLLOUT_CUS", "0") or 0) or int(self.cfg.runner.get("rollout_cus", 0) or 0)
+                    self._rollout_stream, self._rollout_stream_owner = rollout_stream(self.device, n_cus or None)
         else:
             # rollout epochs are laid out side by side on the batch axis: the learner's fold (a8) costs nothing
             self.buffer = TrajectoryBuffer(self.n_train_chunk_steps, self.num_envs * self.rollout_epoch, m.obs_dim, m.action_dim,

@@ -122,32 +122,35 @@ def gpu_main(out_path, precision, transport="xgmi", graph="0", backend="gloo"):
             eps_i = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
             metrics = runner.run_step(eps_i[:, lo:hi].cuda())
             iters += 1
-    # actor -> rollout weight sync over the sparse patch format: rank 0 plays the learner, rank 1 a rollout replica that
-    # holds bf16 copies; handshake and patch both travel over torch.distributed (gloo here, RCCL with a GPU per rank)
-    from rlinf_amd.hybrid_engines.weight_syncer import PatchWeightSyncer
-    from rlinf_amd.scheduler.dist import broadcast_weight_patch
-    gsync = torch.Generator().manual_seed(5)
-    master = {"w": torch.randn(96, 130, generator=gsync).cuda(), "b": torch.randn(130, generator=gsync).cuda()}
-    replica = {k: v.to(torch.bfloat16) for k, v in master.items()}
-    syncer = PatchWeightSyncer()
-    box = [None]
-    if ctx.rank == 1:
-        syncer.init_receiver(replica, None, lambda meta: box.__setitem__(0, meta))
-    dist.broadcast_object_list(box, src=1)
-    if ctx.rank == 0:
-        syncer.init_sender(master, ["w", "b"], None, lambda: box[0])
-        master["w"][::3, ::7] += 0.5
-        master["b"][5] = -2.0
-    patch = broadcast_weight_patch(syncer.create_patch(master, 3) if ctx.rank == 0 else None, ctx, src=0)
-    version = None
-    if ctx.rank == 1:
-        version = syncer.apply(replica, lambda: patch)
-    dist.broadcast(master["w"], src=0), dist.broadcast(master["b"], src=0)
-    sync_ok = ctx.rank != 1 or all(torch.equal(replica[k], master[k].to(torch.bfloat16)) for k in master)  # (rank 1 is the replica)
+    sync_ok, version, patch_nnz = True, None, []
+    if W > 1:
+        # actor -> rollout weight sync over the sparse patch format: rank 0 plays the learner, rank 1 a rollout replica that
+        # holds bf16 copies; handshake and patch both travel over torch.distributed (gloo here, RCCL with a GPU per rank)
+        from rlinf_amd.hybrid_engines.weight_syncer import PatchWeightSyncer
+        from rlinf_amd.scheduler.dist import broadcast_weight_patch
+        gsync = torch.Generator().manual_seed(5)
+        master = {"w": torch.randn(96, 130, generator=gsync).cuda(), "b": torch.randn(130, generator=gsync).cuda()}
+        replica = {k: v.to(torch.bfloat16) for k, v in master.items()}
+        syncer = PatchWeightSyncer()
+        box = [None]
+        if ctx.rank == 1:
+            syncer.init_receiver(replica, None, lambda meta: box.__setitem__(0, meta))
+        dist.broadcast_object_list(box, src=1)
+        if ctx.rank == 0:
+            syncer.init_sender(master, ["w", "b"], None, lambda: box[0])
+            master["w"][::3, ::7] += 0.5
+            master["b"][5] = -2.0
+        patch = broadcast_weight_patch(syncer.create_patch(master, 3) if ctx.rank == 0 else None, ctx, src=0)
+        version = None
+        if ctx.rank == 1:
+            version = syncer.apply(replica, lambda: patch)
+        dist.broadcast(master["w"], src=0), dist.broadcast(master["b"], src=0)
+        sync_ok = ctx.rank != 1 or all(torch.equal(replica[k], master[k].to(torch.bfloat16)) for k in master)  # (rank 1 is the replica)
+        patch_nnz = patch.nnz_per_tensor.tolist()
     w = runner.actor.worker
     torch.save(dict(rank=ctx.rank, metrics=metrics, params=first["params"], advantages=first["advantages"], returns=first["returns"],
                     actions=first["actions"], rewards=first["rewards"], sync_ok=bool(sync_ok), sync_version=version,
-                    patch_nnz=patch.nnz_per_tensor.tolist(), backend=w.grad_allreduce_backend, iters=iters,
+                    patch_nnz=patch_nnz, backend=w.grad_allreduce_backend, iters=iters, dist_backend=dist.get_backend(),
                     final_params=w.model.flat.detach().cpu(), graph_live=w._graph is not None,
                     graph_enabled=bool(w.enable_hip_graph),
                     xgmi=(None if w._xgmi is None else dict(algo=w._xgmi.algo, wait_mode=w._xgmi.wait_mode, shared_device=w._xgmi.shared_device))),

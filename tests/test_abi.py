@@ -36,7 +36,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.rlx_version() >= 100
+    assert lib.rlx_version() >= 110
     assert isinstance(lib.rlx_last_error(), bytes)
 
 
@@ -83,7 +83,7 @@ def test_argument_validation_of_the_widening_entries(lib):
     rows.temperature, rows.n_tokens = 1.0, 0
     assert lib.rlx_token_logprob_fwd(None, None, ctypes.byref(rows), None, None, None, None) == 0  # nothing to do
     rows.n_tokens, rows.vocab, rows.row_stride = 4, 2000, 2000
-    assert lib.rlx_categorical_sample(None, ctypes.byref(rows), None, -1, None, 0, None, None, None, None) == -22
+    assert lib.rlx_categorical_sample(None, ctypes.byref(rows), None, -1, 0, None, 0, None, None, None, None) == -22
     assert b"1024" in lib.rlx_last_error()
     tp = TokenLossParams()
     tp.loss_agg = 7

@@ -359,6 +359,25 @@ def test_two_ranks_match_the_sharded_oracle(tmp_path, transport, graph, backend,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport,graph", [("rccl", "0"), ("rccl", "1"), ("xgmi", "1")])
+def test_one_rank_drives_the_real_rccl_branch(tmp_path, transport, graph):
+    """RCCL itself, on a one-GPU box: a ONE-rank `nccl` communicator is legal, so under RLX_FORCE_EXCHANGE the learner takes its own
+    multi-GPU branch at world_size 1 -- rlx_sum_slabs -> dist.all_reduce on RCCL (stream-ordered) -> rlx_clip_adamw_step with the
+    reduced flat gradient -- eagerly ("0") and inside the captured update graph ("1": iteration 0 captures the update phase WITH the
+    RCCL call in it, two more iterations replay it), against the single-rank oracle (rlinf/hybrid_engines/fsdp/strategy/fsdp.py:480-496
+    with world 1).  "xgmi": the hand-written exchange's one-rank communicator, validated at start-up against that RCCL all-reduce."""
+    outs = [torch.load(o, weights_only=False)
+            for o in _launch("gpu", tmp_path, "32", transport, graph, "nccl", port=29651 + 2 * (graph == "1") + 4 * (transport == "xgmi"),
+                             timeout=300, world=1, env_extra={"RLX_FORCE_EXCHANGE": transport})]
+    assert len(outs) == 1 and outs[0]["backend"] == transport, outs[0]["backend"]
+    assert outs[0]["dist_backend"] == "nccl"
+    if graph == "1":
+        assert outs[0]["iters"] == 3 and outs[0]["graph_live"], "the update phase -- RCCL call included -- was captured and replayed"
+        assert torch.isfinite(outs[0]["final_params"]).all()
+    _compare_with_the_sharded_oracle(outs, world=1)
+
+
+@pytest.mark.gpu
 def test_bench_self_launches_its_ranks_from_a_bare_shell(tmp_path):
     """`python bench.py --gpus 2` WITHOUT a torchrun environment: bench.py spawns the two ranks itself, times every
     (regime, transport) pair and rank 0 prints ONE JSON line with the strong-scaling headline, the weak-scaling object and the

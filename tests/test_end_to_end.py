@@ -564,31 +564,39 @@ def test_example_entry_point_runs_the_shipped_config(precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hip_graph,precision", [(False, "32"), (True, "32"), (True, "bf16")])
-def test_value_free_grpo_whole_loop_matches_oracle(hip_graph, precision):
+@pytest.mark.parametrize("hip_graph,precision,A", [(False, "32", 8), (True, "32", 8), (True, "bf16", 8), (True, "32", 7), (False, "bf16", 7)])
+def test_value_free_grpo_whole_loop_matches_oracle(hip_graph, precision, A):
     """actor.model.add_value_head False (mlp_policy.py:42-66: the value-free MLP policy of the reference's GRPO / actor-only PPO
     configurations): the policy exposes the reference's parameter set without a value head, prev_values are zeros, nothing is
     bootstrapped, and rollout -> GRPO advantages -> actor loss -> clip + AdamW match oracle.ppo_loop.iteration run on the
     reference-shaped value-free oracle policy (pinned to the reference's own MLPPolicy(add_value_head=False) in
-    test_oracle_vs_reference.py) on identical seeds, weights, injected noise and shuffle order."""
+    test_oracle_vs_reference.py) on identical seeds, weights, injected noise and shuffle order.
+    A = 7 (any odd action_dim): the phantom value net is aligned to whole float4s, which leaves flat-buffer elements NO tensor owns
+    between the exposed parameters and the phantom ones; the gradient kernels never write them and the norm / slab sum run over
+    all n elements, so the slabs must be zero-filled once (round 4's advisor finding) -- garbage there reaches clip_grad_norm."""
     B, T, GB, group = 32, 12, 96, 4
     bf16 = precision == "bf16"
     cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, auto_reset=False, hip_graph=hip_graph, done_mode="bernoulli")
     cfg.actor.model.add_value_head = False
+    cfg.actor.model.action_dim = A
     cfg.actor.model.precision = precision
     alg = cfg.algorithm
     alg.adv_type, alg.loss_type, alg.group_size = "grpo", "actor", group
     cfg.env.train.group_size = group
     env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5, mode="bernoulli", p_done=0.05)
     torch.manual_seed(11)
-    ora = O.OracleMLPPolicy(42, 8, 1, add_value_head=False)
+    ora = O.OracleMLPPolicy(42, A, 1, add_value_head=False)
     sd = copy.deepcopy(ora.state_dict())
     opt = O.build_adamw(ora)
+    if A % 2:  # poison the allocator's free blocks: a slab that is not zero-filled would pick the NaNs up in its unowned gap
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]
+        del junk
     runner = _build(cfg, env, sd)
     w = runner.actor.worker
     assert not w.model.has_value_head and list(w.model.state_dict()) == list(sd)
+    assert (w.model.n_exposed % 4 != 0) == bool(A % 2)  # the odd case really has a gap
     for it in range(3 if hip_graph else 2):
-        eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it))
+        eps = torch.randn(T, B, A, generator=torch.Generator().manual_seed(100 + it))
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234, global_batch=GB, update_epoch=2,
                                 auto_reset=False, max_episode_steps=5, adv_type="grpo", loss_type="actor", group_size=group, autocast=bf16)
         metrics = runner.run_step(eps.cuda())

@@ -176,3 +176,27 @@ def test_async_entry_point_selects_the_learner_by_loss_type():
         ref_cfg = validate_cfg(load_config(os.path.join(ref_dir, "maniskill_async_ppo_mlp.yaml"), search_paths=[ref_dir]))
         assert ref_cfg.algorithm.loss_type == "decoupled_actor_critic"
         assert mod.select_actor_cls(ref_cfg) is AsyncPPOEmbodiedFSDPActor
+
+
+@pytest.mark.parametrize("K", [7, 16, 37, 100, 250, 256, 1000, 1024])
+def test_cpu_softmax_restatement(K):
+    """oracle/softmax_replay.py -- the arithmetic csrc/token_ops.hip's categorical sampler replays on the GPU -- IS torch's CPU
+    softmax: bit for bit, f32 and bf16 rows, whole chunks and chunk tails, rows masked to -inf by top-k.  (The lane count follows
+    this host's torch build: 16 on AVX-512, 8 on AVX2; any other build has no vector exp and is skipped.)"""
+    import numpy as np
+
+    from oracle import softmax_replay as SR
+    cap = torch.backends.cpu.get_cpu_capability().upper()
+    if cap not in ("AVX2", "AVX512"):
+        pytest.skip(f"torch CPU capability {cap}: no Sleef vector kernels to restate")
+    W = SR.host_lanes()
+    g = torch.Generator().manual_seed(K)
+    X = torch.randn(64, K, generator=g) * 4
+    X[::5] = X[::5].masked_fill(torch.rand(X[::5].shape, generator=g) < 0.5, float("-inf"))
+    X[:, 0] = X[:, 0].clamp_min(-50.0)  # (a row needs one finite entry)
+    for dtype, reduced in ((torch.float32, False), (torch.bfloat16, True)):
+        Xd = X.to(dtype)
+        want = torch.softmax(Xd, -1).float().numpy()
+        for i in range(X.shape[0]):
+            got = SR.softmax_row(Xd[i].float().numpy(), W, reduced)
+            assert np.array_equal(got.view(np.uint32), want[i].view(np.uint32)), (dtype, i)

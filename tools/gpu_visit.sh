@@ -103,6 +103,22 @@ for STEP in "$@"; do
       rm -rf gpurun_out/prof_bench
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-variants --no-token-tier > gpurun_out/${TAG}_bench_prof.log 2>&1
       echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_prof.log | cut -c1-200; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_bench)" > gpurun_out/${TAG}_bench_kernels.txt 2>&1; head -14 gpurun_out/${TAG}_bench_kernels.txt; rm -rf gpurun_out/prof_bench ;;
+    r5_tests)
+      timeout 900 python -m pytest tests/test_end_to_end.py tests/test_distributed.py tests/test_gpu_token_path.py -q -m gpu -k "value_free or one_rank_drives or categorical" > gpurun_out/${TAG}_r5_tests.log 2>&1
+      echo "rc=$?"; tail -30 gpurun_out/${TAG}_r5_tests.log | cut -c1-400 ;;
+    overlap_probe)
+      timeout 900 python tools/pipeline_overlap_probe.py --steps ${OVERLAP_STEPS:-60} --rounds ${OVERLAP_ROUNDS:-2} > gpurun_out/${TAG}_overlap_probe.txt 2> gpurun_out/${TAG}_overlap_probe.err
+      echo "rc=$?"; tail -14 gpurun_out/${TAG}_overlap_probe.txt; tail -3 gpurun_out/${TAG}_overlap_probe.err ;;
+    overlap_trace)
+      for OV in 1 0; do
+        rm -rf gpurun_out/prof_ov
+        EXTRA=""; [ $OV = 0 ] && EXTRA="--no-overlap"
+        timeout 200 rocprofv3 --kernel-trace -d gpurun_out/prof_ov -o ov -- python bench.py --pipeline --rollout-epochs 4 $EXTRA --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_overlap_trace_${OV}.log 2>&1
+        echo "overlap=$OV rc=$?"; tail -1 gpurun_out/${TAG}_overlap_trace_${OV}.log | cut -c1-160
+        python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_ov)" --streams > gpurun_out/${TAG}_overlap_streams_${OV}.txt 2>&1; cat gpurun_out/${TAG}_overlap_streams_${OV}.txt | cut -c1-200
+      done; rm -rf gpurun_out/prof_ov ;;
+    exchange_self)
+      timeout 300 python bench.py --exchange self > gpurun_out/${TAG}_exchange_self.json 2> gpurun_out/${TAG}_exchange_self.err; echo "rc=$?"; cat gpurun_out/${TAG}_exchange_self.json | cut -c1-1500; tail -3 gpurun_out/${TAG}_exchange_self.err ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
