@@ -51,7 +51,7 @@ HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def build_cfg(world: int, use_graph: bool, precision: str = "32", pipeline: bool = False, rollout_epochs: int = 1,
-              overlap: bool = True, total_envs: int = ENVS, global_batch: int = GLOBAL_BATCH, update_graph: bool | None = None):
+              overlap: bool = False, total_envs: int = ENVS, global_batch: int = GLOBAL_BATCH, update_graph: bool | None = None):
     """``pipeline`` / ``rollout_epochs`` / ``overlap``: runner.use_training_pipeline variants (NOT the headline configuration):
     the horizon is split into ``rollout_epochs`` epochs of HORIZON / rollout_epochs steps so that the work per iteration stays
     1024 x 128 env-steps and 128 optimizer steps."""
@@ -103,7 +103,7 @@ def _lib_handle():
     return _lib.load()
 
 
-def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 3, timed: int = 9):
+def token_tier_cpu_baseline(rows: int = 64, vocab: int = 151936, warmup: int = 6, timed: int = 9):
     """The token tier on the host cores, bounded sample of the same shape: log-prob + entropy from bf16 logits, forward and
     backward, 3 warm-up + 5 timed passes (median).  kind "reference": the reference's OWN compute_logprobs_from_logits /
     compute_entropy_from_logits (rlinf/utils/utils.py:454-512, loaded from the staged copy oracle/_ref); kind "port" (the oracle's
@@ -239,7 +239,7 @@ def token_tier_cpu_baseline_subprocess(timeout_s: float = 240.0):
     if r.returncode != 0 or not lines:
         raise RuntimeError(f"token-tier cpu baseline subprocess failed (rc {r.returncode}): {r.stderr[-300:]}")
     out = json.loads(lines[-1])
-    out["sample"] += f"; own process, torch.set_num_threads({threads}), OpenMP team pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)"
+    out["sample"] += f"; own process, torch.set_num_threads({out.get('cores')}), OpenMP team pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)"
     return out
 
 
@@ -340,7 +340,7 @@ def self_launch(args) -> int:
 
 
 def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup: int, use_graph: bool = True,
-            pipeline: bool = False, rollout_epochs: int = 1, overlap: bool = True, transport: str | None = None,
+            pipeline: bool = False, rollout_epochs: int = 1, overlap: bool = False, transport: str | None = None,
             learner: str = "sync") -> dict:
     """One timed region: W untimed iterations, then exactly ``steps`` iterations between barrier + synchronize on both sides,
     MAX over ranks.  ``scaling``: strong = 1024 envs / 8192-row global batch in total, weak = that much PER GPU.  Also returns
@@ -464,7 +464,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="runner.use_training_pipeline (statistics normalisation, per-stage "
                     "shuffles; with --rollout-epochs > 1 the learner trains on epoch e while epoch e + 1 rolls out)")
     ap.add_argument("--rollout-epochs", type=int, default=1, help="split the 128-step horizon into this many rollout epochs")
-    ap.add_argument("--no-overlap", action="store_true", help="pipeline mode on ONE stream (the comparison line for the overlap)")
+    ap.add_argument("--overlap", action="store_true", help="pipeline mode with the rollout of epoch e + 1 on its own stream (runner."
+                    "pipeline_overlap; off by default since round 5: profiles/r05_pipeline_overlap_*.txt)")
+    ap.add_argument("--no-overlap", action="store_true", help="(kept for old command lines: one stream is the default now)")
     ap.add_argument("--learner", default="sync", choices=["sync", "async"],
                     help="async: AsyncPPOEmbodiedFSDPActor (decoupled actor-critic loss, SURVEY.md 8f-4) as the timed loop -- a variant "
                          "line for traces and A/B runs, not the BASELINE.json configuration (the default run reports it under variants)")
@@ -514,7 +516,7 @@ def main():
     dev = ctx.device
     use_graph = not args.no_graph
     common = dict(precision=args.precision, steps=args.steps, warmup=args.warmup, use_graph=use_graph, pipeline=args.pipeline,
-                  rollout_epochs=args.rollout_epochs, overlap=not args.no_overlap)
+                  rollout_epochs=args.rollout_epochs, overlap=args.overlap and not args.no_overlap)
     if args.learner != "sync":
         common["learner"] = args.learner
 
@@ -548,7 +550,7 @@ def main():
                        "total_envs": head["total_envs"], "horizon": HORIZON, "global_batch": head["global_batch"],
                        "update_epoch": UPDATE_EPOCH, "parallelism": f"dp{args.gpus}", "hip_graph": use_graph,
                        "grad_allreduce": head["grad_allreduce"], "update_graph_replayed": head["update_graph_replayed"],
-                       **({"pipeline": True, "rollout_epochs": args.rollout_epochs, "overlap": not args.no_overlap}
+                       **({"pipeline": True, "rollout_epochs": args.rollout_epochs, "overlap": args.overlap and not args.no_overlap}
                           if args.pipeline else {}),
                        **({"learner": "async (decoupled actor-critic loss, behave_weight_threshold 2): a VARIANT of the BASELINE.json "
                                       "configuration, not its headline"} if args.learner != "sync" else {})},
@@ -654,8 +656,11 @@ def main():
                 other = "32" if args.precision == "bf16" else "bf16"
                 for name, kw in ((f"precision {'f32 (' + PREC_TEXT['32'] + ': the precision the reference YAML ships)' if other == '32' else 'bf16'}",
                                   dict(precision=other)),
-                                 ("pipeline mode, 4 rollout epochs, rollout of epoch e + 1 overlapping the training on epoch e",
+                                 ("pipeline mode, 4 rollout epochs, one stream (runner.pipeline_overlap false: the default)",
                                   dict(precision=args.precision, pipeline=True, rollout_epochs=4)),
+                                 ("pipeline mode, 4 rollout epochs, rollout of epoch e + 1 on its own stream (runner.pipeline_overlap true; "
+                                  "the two chains do not co-execute: profiles/r05_pipeline_overlap_*.txt)",
+                                  dict(precision=args.precision, pipeline=True, rollout_epochs=4, overlap=True)),
                                  ("pipeline mode, 1 rollout epoch (statistics normalisation + per-stage shuffles only)",
                                   dict(precision=args.precision, pipeline=True, rollout_epochs=1)),
                                  # the learner of async / decoupled PPO at the same configuration and precision: the

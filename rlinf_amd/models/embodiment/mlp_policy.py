@@ -85,11 +85,17 @@ class MLPPolicy(nn.Module):
         self.independent_std, self.final_tanh, self.action_scale = True, False, None
         full = _reference_shapes(self.obs_dim, self.action_dim, self.num_action_chunks, self.value_dim)
         self.shapes = OrderedDict((k, v) for k, v in full.items() if self.has_value_head or not k.startswith("value_head."))
+        # Every tensor starts on a 16-byte boundary of the flat buffer (the kernels stream the weight matrices with 16-byte
+        # accesses): an odd action_dim -- the reference's LIBERO MLP configurations use 7 -- leaves up to three unowned floats
+        # behind actor_logstd / actor_mean.bias.  Unowned elements are zero, get zero gradients (the learner zero-fills its
+        # slabs once; no kernel writes them) and therefore stay zero under AdamW; state_dict() exposes the owned views only.
         self.offsets, off = OrderedDict(), 0
         for name, shp in self.shapes.items():
+            off = (off + 3) // 4 * 4
             self.offsets[name] = off
             off += math.prod(shp)
-        self.n_exposed = off  # elements the reference's named_parameters() would hold
+        self.n_exposed = off  # END of the last exposed tensor (the span; == exposed_numel when every size is a multiple of 4)
+        self.exposed_numel = sum(math.prod(shp) for shp in self.shapes.values())  # what the reference's named_parameters() hold
         self._phantom_offsets = OrderedDict()
         for name, shp in full.items():
             if name not in self.shapes:
@@ -135,7 +141,7 @@ class MLPPolicy(nn.Module):
             b = self.offsets[name]
             e = b + math.prod(shp)
             r = value_lr if "value_head" in name else lr
-            if out and out[-1][2] == r and out[-1][1] == b:
+            if out and out[-1][2] == r and 0 <= b - out[-1][1] < 4:  # adjacent, or across an alignment gap (zeros: see __init__)
                 out[-1] = (out[-1][0], e, r)
             else:
                 out.append((b, e, r))
@@ -187,6 +193,11 @@ class MLPPolicy(nn.Module):
                 raise RuntimeError(f"size mismatch for {name}: {tuple(t.shape)} vs {tuple(shp)}")
             self.view(name).copy_(t.detach().to(torch.float32))
         self.mark_updated()
+
+    def exposed_flat(self) -> torch.Tensor:
+        """The owned elements in named_parameters() order, as ONE vector (a copy): what ``torch.cat([p.reshape(-1) for p in
+        reference_model.parameters()])`` is for the reference's module."""
+        return torch.cat([self.view(name).detach().reshape(-1) for name in self.shapes])
 
     def reference_state_dict(self):
         return OrderedDict((name, self.view(name).detach().clone()) for name in self.shapes)

@@ -57,9 +57,14 @@ class EnvWorker(Worker):
         # runner.use_training_pipeline with rollout_epoch > 1 (embodied_runner.py:565-642, env_worker.py:1074,1324-1330): the
         # reference hands every finished rollout epoch to the learner at once and rolls the next one out while the learner
         # trains on it.  Here: one trajectory buffer per epoch, the rollout loop on its own HIP stream with an event per epoch;
-        # the learner's stream waits on epoch e's event only (runner.pipeline_overlap: false keeps everything on one stream).
+        # the learner's stream waits on epoch e's event only (runner.pipeline_overlap: true; the default keeps everything on one
+        # stream).  Round 5 measured what the second stream buys on one MI355X (profiles/r05_pipeline_overlap_*.txt): nothing.
+        # The kernel trace shows 0.0 ms with kernels of both queues in flight -- every launch of either chain wants whole CUs (the
+        # fused step holds all 512 VGPRs per SIMD on every CU, the rollout step 41 KB of LDS and ~180 VGPRs per wave), so the
+        # hardware runs the two chains one kernel at a time; E = 4 overlapped costs 9.01 ms per iteration, on one stream 9.01 ms
+        # (synchronous mode 8.66 ms), and a rollout stream restricted to 16 / 32 / 64 CUs 13.6-14.5 ms.  Hence: off by default.
         self.pipeline_epochs = bool(cfg.runner.get("use_training_pipeline", False)) and self.rollout_epoch > 1
-        self.overlap = self.pipeline_epochs and bool(cfg.runner.get("pipeline_overlap", True))
+        self.overlap = self.pipeline_epochs and bool(cfg.runner.get("pipeline_overlap", False))
         self.buffers: list = []
         self.epoch_events: list = []
         self._rollout_stream = None

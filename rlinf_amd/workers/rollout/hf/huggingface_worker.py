@@ -38,7 +38,7 @@ class MultiStepRolloutWorker(Worker):
     def _overlapped_pipeline(self) -> bool:
         r = self.cfg.runner
         return (bool(r.get("use_training_pipeline", False)) and self.cfg.env.train.get("rollout_epoch", 1) > 1
-                and bool(r.get("pipeline_overlap", True)))
+                and bool(r.get("pipeline_overlap", False)))  # default off since round 5: see workers/env/env_worker.py
 
     def adopt_model(self, model):
         """Alias the collocated learner's policy object."""

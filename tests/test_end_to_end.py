@@ -594,7 +594,7 @@ def test_value_free_grpo_whole_loop_matches_oracle(hip_graph, precision, A):
     runner = _build(cfg, env, sd)
     w = runner.actor.worker
     assert not w.model.has_value_head and list(w.model.state_dict()) == list(sd)
-    assert (w.model.n_exposed % 4 != 0) == bool(A % 2)  # the odd case really has a gap
+    assert (w.model.n_exposed > w.model.exposed_numel) == bool(A % 2)  # the odd case really has unowned (alignment) elements
     for it in range(3 if hip_graph else 2):
         eps = torch.randn(T, B, A, generator=torch.Generator().manual_seed(100 + it))
         batch, om = L.iteration(ora, opt, env, eps, gamma=0.8, gae_lambda=0.9, seed=1234, global_batch=GB, update_epoch=2,
@@ -615,9 +615,13 @@ def test_value_free_grpo_whole_loop_matches_oracle(hip_graph, precision, A):
         assert "train/critic/value_loss" not in metrics
         got = w.model.flat.detach().cpu()
         want = torch.cat([p.detach().reshape(-1) for p in ora.parameters()])
-        diff = (got[:w.model.n_exposed] - want).abs()
+        diff = (w.model.exposed_flat().cpu() - want).abs()
         assert float(diff.max()) <= 2 * 3e-4 * len(om) * (it + 1) + 1e-6
         assert not got[w.model.n_exposed:].any()                                        # the phantom value net stays zero
+        owned = torch.zeros(w.model.n_params, dtype=torch.bool)
+        for nm in w.model.shapes:
+            owned[w.model.offsets[nm]:w.model.offsets[nm] + w.model.view(nm).numel()] = True
+        assert not got[~owned].any()                                                    # ... and so does every alignment gap
     runner.close() if hasattr(runner, "close") else None
 
 

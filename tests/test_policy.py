@@ -63,6 +63,40 @@ def test_value_free_policy_exposes_the_reference_parameter_set():
         MLPPolicy(42, 8, 1, False, True)                                       # the Q head (SAC) stays out of scope
 
 
+@pytest.mark.parametrize("add_value_head", [True, False])
+def test_odd_action_dim_layout_is_16_byte_aligned(add_value_head):
+    """action_dim 7 (the reference's LIBERO MLP configurations): every tensor of the flat buffer starts on a 16-byte boundary -- the
+    kernels' requirement for the weight matrices --, the up-to-three unowned floats behind actor_logstd / actor_mean.bias are zero,
+    belong to no state_dict entry, and the AdamW ranges run across them (they have zero gradients, so they stay zero); the
+    reference's parameter set, values and init stream are unchanged."""
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(5)
+    ora = O.OracleMLPPolicy(42, 7, 1, add_value_head=add_value_head)
+    torch.manual_seed(5)
+    pol = MLPPolicy(42, 7, 1, add_value_head, False)
+    assert list(pol.shapes) == [n for n, _ in ora.named_parameters()]
+    owned = torch.zeros(pol.n_params, dtype=torch.bool)
+    for n, p in ora.named_parameters():
+        assert pol.offsets[n] % 4 == 0, n
+        assert torch.equal(pol.view(n), p.detach()), n
+        owned[pol.offsets[n]:pol.offsets[n] + p.numel()] = True
+    assert pol.exposed_numel == sum(p.numel() for p in ora.parameters()) and pol.n_exposed > pol.exposed_numel
+    assert torch.equal(pol.exposed_flat(), torch.cat([p.detach().reshape(-1) for p in ora.parameters()]))
+    assert not pol.flat.detach()[~owned].any()
+    lay = pol.layout
+    assert all(lay.off_w[y][l] % 4 == 0 for y in range(2) for l in range(4)) and lay.off_logstd % 4 == 0
+    groups = pol.group_ranges(3e-4, 1e-3, train_value_head=add_value_head)
+    assert len(groups) <= 3 and groups[0][0] == 0                       # merged across the alignment gaps
+    covered = torch.zeros(pol.n_params, dtype=torch.bool)
+    for b, e, _ in groups:
+        covered[b:e] = True
+    assert bool(covered[owned].all())                                    # every owned element is in a range
+    if add_value_head:                                                   # value-head ranges carry value_lr, nothing else does
+        for b, e, lr in groups:
+            names = [n for n in pol.shapes if b <= pol.offsets[n] < e]
+            assert all(("value_head" in n) == (lr == 1e-3) for n in names), (b, e, lr)
+
+
 def test_model_registry_boundary():
     from rlinf_amd import models
     m = models.get_model(dict(model_type="mlp_policy", obs_dim=42, action_dim=8, num_action_chunks=1,

@@ -98,7 +98,8 @@ def in_loop_kernels(precision: str, *, rows: int, envs: int, slabs: int, n_param
         db = sqlite3.connect(dbs[0])
         rws = db.execute("select name, duration from kernels").fetchall()
     fwd, bwd, dw = _flops_per_row(obs, act)
-    want = (("rollout step", ("rollout_step",), "mfma", fwd * (envs + envs), "policy + bootstrap-value job rows"),
+    value_fwd = 2 * (obs * HID + 2 * HID * HID + HID * 1)  # the bootstrap-value job rides in the same grid: value network only
+    want = (("rollout step", ("rollout_step",), "mfma", (fwd + value_fwd) * envs, f"{envs} policy rows (both networks) + {envs} bootstrap-value rows"),
             ("fused forward + loss + backward-data", ("ppo_step_fused",), "mfma", (fwd + bwd) * rows, f"{rows} rows"),
             ("weight gradients", ("ppo_step_dw",), "mfma", dw * rows, f"{rows} rows, {slabs} split-K slabs"),
             ("slab sum + squared norm", ("grad_reduce_sqnorm",), "hbm", (slabs + 1) * n_params * 4, f"{slabs} slabs x {n_params} f32 -> 1"),

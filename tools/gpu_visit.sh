@@ -112,7 +112,7 @@ for STEP in "$@"; do
     overlap_trace)
       for OV in 1 0; do
         rm -rf gpurun_out/prof_ov
-        EXTRA=""; [ $OV = 0 ] && EXTRA="--no-overlap"
+        EXTRA=""; [ $OV = 1 ] && EXTRA="--overlap"
         timeout 200 rocprofv3 --kernel-trace -d gpurun_out/prof_ov -o ov -- python bench.py --pipeline --rollout-epochs 4 $EXTRA --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_overlap_trace_${OV}.log 2>&1
         echo "overlap=$OV rc=$?"; tail -1 gpurun_out/${TAG}_overlap_trace_${OV}.log | cut -c1-160
         python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_ov)" --streams > gpurun_out/${TAG}_overlap_streams_${OV}.txt 2>&1; cat gpurun_out/${TAG}_overlap_streams_${OV}.txt | cut -c1-200

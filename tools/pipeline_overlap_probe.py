@@ -33,8 +33,7 @@ def run(ctx, name, steps, *, pipeline, epochs=1, overlap=True, rollout_cus=0, tr
         return {"config": name, "error": f"{type(e).__name__}: {e}"[:300]}
     finally:
         os.environ["RLX_ROLLOUT_CUS"] = "0"
-        if owner is not None:
-            owner.close()
+        pass  # (the masked training stream is left alive: torch's allocator may still hold blocks tagged with it)
 
 
 def main():
