@@ -46,6 +46,10 @@ enum rlx_status {
 };
 
 int rlx_version(void);
+/* 1: a development build (-DRLX_DEV_VARIANTS): the refuted / experimental kernel variants are compiled in and the RLX_* variant
+ * environment switches are read; 0: the product build -- the measured-best path only, no variant switch is read, entry points asked
+ * for a variant that is not compiled return RLX_ENOSYS. */
+int rlx_dev_variants(void);
 const char* rlx_last_error(void);
 
 /* sizeof() of the argument structs below as THIS library was compiled, in declaration order (gae_params, ppo_loss_params,
@@ -391,15 +395,20 @@ int rlx_mlp_train_bwd(const float* params, const float* packed, const rlx_mlp_la
  *                   rewards[b, chunk-1] += gamma * V(states)[b, 0] where flags[b, chunk-1].
  *   Needs obs_dim <= 64, act_dim, val_dim <= 16.
  *
- * rlx_mlp_pack_tiles: the weight image the fused launches stream -- every 16 (out) x 16 (in) weight tile stored as one
- *   contiguous 1 KiB block in MFMA fragment order (first layer zero-padded to 64 inputs; the hidden layers also
- *   transposed, for the backward-data GEMMs).  rlx_mlp_tiles_bytes() bytes; rebuild after every optimizer step
- *   (rlx_ppo_step does so itself, into its workspace).
+ * rlx_mlp_pack_tiles: the weight image the fused launches stream at precision "32" -- an OPAQUE buffer of
+ *   rlx_mlp_tiles_bytes_for(layout, 0) bytes (rlx_mlp_tiles_bytes(): large enough for any format).  By default: every weight as three
+ *   bf16 planes hi | mid | lo (x = hi + mid + lo exactly), each plane the 16 (out) x 32 (in) k-step-major tile image of the bf16
+ *   variant -- the f32 launches run six of the nine plane products on the bf16 matrix pipe (csrc/ppo_step_f32x.hip: f32-accurate at
+ *   6 / 16 of the f32 MFMA time).  With RLX_F32_EXACT_MFMA=1 in the environment (read once per process): 16 x 16 f32 tiles in MFMA
+ *   fragment order for the exact-f32-MFMA launches.  First layer zero-padded to 64 inputs; the hidden layers also transposed, for
+ *   the backward-data GEMMs.  Rebuild after every change of params (rlx_ppo_step does so itself, into its workspace, when it is
+ *   given no image), or let rlx_clip_adamw_step keep it in step (rlx_adamw_params.tiles).
  * ------------------------------------------------------------------------------------------ */
 size_t rlx_mlp_tiles_bytes(const rlx_mlp_layout* layout);
+size_t rlx_mlp_tiles_bytes_for(const rlx_mlp_layout* layout, int32_t bf16); /* exact size of the f32 (0) / bf16 (1) image */
 int rlx_mlp_pack_tiles(const float* params, const rlx_mlp_layout* layout, float* tiles, rlx_stream_t stream);
 /* bf16 variant ("PPO bf16": bf16 operands of the dense layers, f32 accumulate / master weights / everything else):
- * 16 (out) x 32 (in) bf16 tiles of 1 KiB; needs rlx_mlp_tiles_bytes() / 2 bytes. */
+ * 16 (out) x 32 (in) bf16 tiles of 1 KiB; rlx_mlp_tiles_bytes_for(layout, 1) bytes. */
 int rlx_mlp_pack_tiles_bf16(const float* params, const rlx_mlp_layout* layout, void* tiles, rlx_stream_t stream);
 
 typedef struct rlx_value_job {
@@ -435,7 +444,8 @@ typedef struct rlx_rollout_step {
     float* states_copy;
     int32_t n_value_jobs; /* 0..2 */
     rlx_value_job value_jobs[2];
-    int32_t bf16;         /* 0: f32 MFMA, tiles from rlx_mlp_pack_tiles; 1: bf16 MFMA operands (f32 accumulate), tiles
+    int32_t bf16;         /* 0: precision "32" (f32-accurate products: bf16 planes on the bf16 matrix pipe, or the exact f32 MFMA with
+                             RLX_F32_EXACT_MFMA=1), tiles from rlx_mlp_pack_tiles; 1: bf16 MFMA operands (f32 accumulate), tiles
                              from rlx_mlp_pack_tiles_bf16 */
 } rlx_rollout_step;
 int rlx_mlp_rollout_step(const rlx_rollout_step* step, rlx_stream_t stream);

@@ -147,6 +147,7 @@ TOK_OUT_NAMES = {"loss": 0, "actor/policy_loss": 1, "actor/policy_loss_abs": 2, 
 # name -> (restype, argtypes); kept in one table so tests can check it against include/rlx.h
 PROTOTYPES = {
     "rlx_version": (c_int, []),
+    "rlx_dev_variants": (c_int, []),
     "rlx_last_error": (c_char_p, []),
     "rlx_abi_struct_sizes": (c_int, [c_void_p, c_int]),
     "rlx_device_info": (c_int, [POINTER(c_int), POINTER(c_int)]),
@@ -192,6 +193,7 @@ PROTOTYPES = {
     "rlx_bootstrap_rewards": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "rlx_store_env_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rlx_mlp_tiles_bytes": (c_size_t, [POINTER(MlpLayout)]),
+    "rlx_mlp_tiles_bytes_for": (c_size_t, [POINTER(MlpLayout), c_int32]),
     "rlx_mlp_pack_tiles": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
     "rlx_mlp_pack_tiles_bf16": (c_int, [c_void_p, POINTER(MlpLayout), c_void_p, c_void_p]),
     "rlx_mlp_rollout_step": (c_int, [POINTER(RolloutStep), c_void_p]),

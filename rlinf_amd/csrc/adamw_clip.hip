@@ -204,12 +204,26 @@ __device__ __forceinline__ size_t tile_slot_bf16(size_t mat_off, int nit, int n,
     (void)nit;
     return mat_off + (((size_t)(k >> 5) * 16 + (n >> 4)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
 }
-template <bool BF16>
+// FMT: 0 = f32 tiles (exact-f32 MFMA launches), 1 = bf16 tiles, 2 = three bf16 planes hi | mid | lo of the f32 weight (the default
+// f32 image: ppo_step_f32x.hip; plane stride = both networks' tiles)
+template <int FMT>
 __device__ __forceinline__ void tile_store(float* __restrict__ tiles, size_t mat_off, int nit, int n, int k, float val) {
-    if constexpr (BF16) reinterpret_cast<__bf16*>(tiles)[tile_slot_bf16(mat_off, nit, n, k)] = (__bf16)val;
-    else tiles[tile_slot(mat_off, nit, n, k)] = val;
+    if constexpr (FMT == 1) {
+        reinterpret_cast<__bf16*>(tiles)[tile_slot_bf16(mat_off, nit, n, k)] = (__bf16)val;
+    } else if constexpr (FMT == 2) {
+        constexpr size_t plane = 2 * ((size_t)256 * 64 + 4 * (size_t)256 * 256);
+        __bf16* t = reinterpret_cast<__bf16*>(tiles) + tile_slot_bf16(mat_off, nit, n, k);
+        const __bf16 h = (__bf16)val;
+        const float r1 = fsub(val, (float)h);
+        const __bf16 md = (__bf16)r1;
+        t[0] = h;
+        t[plane] = md;
+        t[2 * plane] = (__bf16)fsub(r1, (float)md);
+    } else {
+        tiles[tile_slot(mat_off, nit, n, k)] = val;
+    }
 }
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ void tile_scatter(const rlx_mlp_layout& lay, float* __restrict__ tiles, long long i, float val) {
     constexpr int HIDW = 256, K1P = 64;
     const size_t per_net = (size_t)HIDW * K1P + 4 * (size_t)HIDW * HIDW;
@@ -415,8 +429,9 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
                 const int gq = c == 0 ? q0 : (c == 1 ? q1 : (c == 2 ? q2 : q3));
                 if (skip || gq < 0) continue;
                 const long long idx = 4 * iw + 64 * e + lane;
-                if (a.tiles_bf16) tile_scatter<true>(lay, tiles, idx, val);
-                else tile_scatter<false>(lay, tiles, idx, val);
+                if (a.tiles_bf16 == 1) tile_scatter<1>(lay, tiles, idx, val);
+                else if (a.tiles_bf16 == 2) tile_scatter<2>(lay, tiles, idx, val);
+                else tile_scatter<0>(lay, tiles, idx, val);
             }
         }
     }
@@ -430,8 +445,9 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
         m[i] = mi;
         v[i] = vi;
         if (tiles != nullptr) {
-            if (a.tiles_bf16) tile_scatter<true>(lay, tiles, i, pi);
-            else tile_scatter<false>(lay, tiles, i, pi);
+            if (a.tiles_bf16 == 1) tile_scatter<1>(lay, tiles, i, pi);
+            else if (a.tiles_bf16 == 2) tile_scatter<2>(lay, tiles, i, pi);
+            else tile_scatter<0>(lay, tiles, i, pi);
         }
     }
 }
@@ -456,6 +472,10 @@ __global__ void seq_inc_kernel(unsigned* seq) { *seq += 1u; }
 
 }  // namespace
 
+namespace step {
+bool f32_split();  // ppo_step_f32x.hip
+}
+
 namespace opt {
 
 int check_deferred(const rlx_adamw_params* p, int nslab, int64_t n, const char* who) {
@@ -472,6 +492,13 @@ int grid_for(long long n) {  // one float4 per thread up to kMaxParts blocks, gr
 }
 
 namespace {
+// The kernel's copy of the parameters with the tile image's format resolved: an f32 image (tiles_bf16 == 0) is the three-plane one
+// unless the process runs the exact-f32-MFMA launches (RLX_F32_EXACT_MFMA=1) -- the same switch rlx_mlp_pack_tiles follows.
+rlx_adamw_params tile_format_resolved(const rlx_adamw_params* p, const float* tiles) {
+    rlx_adamw_params k = *p;
+    if (tiles != nullptr && k.tiles_bf16 == 0 && ::rlx::step::f32_split()) k.tiles_bf16 = 2;
+    return k;
+}
 int check_adamw_args(float* params, float* out, float* exp_avg, float* exp_avg_sq, int64_t n, const rlx_adamw_params* p, float* stats,
                      int32_t* step_state, rlx_mlp_layout& lay, float*& tiles) {
     RLX_REQUIRE(p != nullptr, "rlx_clip_adamw_step: NULL params struct");
@@ -518,7 +545,7 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
                            step_state, *p, scalars, w, DeferredScale{});
     }
     RLX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
+    hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, tile_format_resolved(p, tiles),
                        partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc, status, GatherSrc{}, PeerWait{});
     RLX_LAUNCH_CHECK();
     return RLX_OK;
@@ -557,7 +584,7 @@ int launch_gather_clip_adamw(float* params, const GatherSrc& src, float* out, fl
                  reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 == 0, "gather clip_adamw: buffers must be 16-byte aligned");
     PeerWait w{};
     if (wait != nullptr) w = *wait;
-    hipLaunchKernelGGL(clip_adamw_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, *p,
+    hipLaunchKernelGGL(clip_adamw_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, tile_format_resolved(p, tiles),
                        (const double*)nullptr, 0, (const AdamScalars*)nullptr, stats, step_state, lay, tiles, seq_inc, status, src, w);
     RLX_LAUNCH_CHECK();
     return RLX_OK;

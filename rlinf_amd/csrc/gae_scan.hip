@@ -30,6 +30,13 @@
 namespace rlx {
 namespace {
 
+#ifdef RLX_DEV_VARIANTS
+inline int dev_switch(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
+
 struct GaeArgs {
     const float* r;
     const float* v;      // nullptr => critic-free
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
     flush_moments(mo, a.partials, s_red, grp);
 }
 
+#ifdef RLX_DEV_VARIANTS  // register-resident segment scans: bit-exact, measured slower (32-44 us against 28 us): development builds only
 // ------------------------------------------------------------------------------------------
 // Register-resident segmented scan (C == 1).  grid = ceil(B / (64*VEC)), block = 64*NSEG threads.
 //   Wave s of a block owns time segment [s*SEG, (s+1)*SEG) of 64*VEC envs and issues EVERY load of that segment
@@ -516,6 +524,7 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_handoff(GaeArgs a) {
     flush_moments(mo, a.partials, s_red);
 }
 
+#endif  // RLX_DEV_VARIANTS
 // ------------------------------------------------------------------------------------------
 // Generic time-chunk layout (C > 1): one lane per env, sequential, strided addressing.
 //   time step t = k*C + c  ->  element ((k*B + b)*C + c); dones use flat rows shifted by C-1
@@ -633,15 +642,24 @@ int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk, int rows = 8, bool nt
     const bool critic = a.v != nullptr, mask = a.m != nullptr;
     if constexpr (NSEG == 1) {  // streaming-scan tuning variants (critic, no mask: the bench / sweep configuration)
         if (critic && !mask) {
+#ifdef RLX_DEV_VARIANTS
             if (rows == 16) return nt ? launch_c1<1, 1, 16, true, true, false>(a, s, nblk) : launch_c1<1, 1, 16, false, true, false>(a, s, nblk);
             if (rows == 32) return nt ? launch_c1<1, 1, 32, true, true, false>(a, s, nblk) : launch_c1<1, 1, 32, false, true, false>(a, s, nblk);
-            if (rows == 64 && nt) {
-                static const bool pair = getenv("RLX_GAE_PAIR") == nullptr || atoi(getenv("RLX_GAE_PAIR")) != 0;  // development: A / B
-                return pair ? launch_c1<1, 1, 64, true, true, false, true>(a, s, nblk) : launch_c1<1, 1, 64, true, true, false>(a, s, nblk);
-            }
-            if (rows == 64) return launch_c1<1, 1, 64, false, true, false>(a, s, nblk);
+            if (rows == 64 && nt && dev_switch("RLX_GAE_PAIR", 1) == 0) return launch_c1<1, 1, 64, true, true, false>(a, s, nblk);
+            if (rows == 64 && !nt) return launch_c1<1, 1, 64, false, true, false>(a, s, nblk);
             if (rows == 128) return nt ? launch_c1<1, 1, 128, true, true, false>(a, s, nblk) : launch_c1<1, 1, 128, false, true, false>(a, s, nblk);
-            if (nt) return launch_c1<1, 1, 8, true, true, false>(a, s, nblk);
+            if (nt && rows != 64) return launch_c1<1, 1, 8, true, true, false>(a, s, nblk);
+#else
+            if (rows != 64 && (rows != 8 || nt)) {
+                set_error("rlx_gae_scan: this streaming tuning variant (rows %d, nt %d) is compiled into development builds only", rows, (int)nt);
+                return RLX_ENOSYS;
+            }
+            if (rows == 64 && !nt) {
+                set_error("rlx_gae_scan: the 64-row streaming scan is compiled with non-temporal accesses only (development builds hold the other)");
+                return RLX_ENOSYS;
+            }
+#endif
+            if (rows == 64) return launch_c1<1, 1, 64, true, true, false, true>(a, s, nblk);  // the measured-best streaming scan (auto at HBM sizes)
         }
     }
     if (critic && !mask) return launch_c1<1, NSEG, 8, false, true, false>(a, s, nblk);
@@ -650,6 +668,7 @@ int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk, int rows = 8, bool nt
     return launch_c1<1, NSEG, 8, false, false, false>(a, s, nblk);
 }
 
+#ifdef RLX_DEV_VARIANTS
 template <int VEC, int NSEG, int SEG, bool NT>
 int launch_regseg(const GaeArgs& a, hipStream_t s) {
     const int nblk = ceil_div(a.B, 64 * VEC);
@@ -675,6 +694,8 @@ int dispatch_regseg(const GaeArgs& a, hipStream_t s) {
     set_error("rlx_gae_scan: the register-resident variant needs T <= %d (T=%d)", 16 * SEG, a.T);
     return RLX_EINVAL;
 }
+
+#endif  // RLX_DEV_VARIANTS
 
 int standardize_grid(size_t n) {
     const long long want = (long long)((n / 4 + 255) / 256);
@@ -758,6 +779,13 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         }
         const bool regseg = (p->variant >> 26) & 1;  // register-resident 32-step segments, serial carry chain
         const bool handoff = (p->variant >> 28) & 1;  // register-resident segments, early hand-off (gae_scan_handoff)
+#ifndef RLX_DEV_VARIANTS
+        if (handoff || regseg) {
+            set_error("rlx_gae_scan: the register-resident segment variants are compiled into development builds only (-DRLX_DEV_VARIANTS)");
+            return RLX_ENOSYS;
+        }
+        {
+#else
         if (handoff) {
             RLX_REQUIRE((unsigned long long)(a.T + 1) * (unsigned long long)batch * 4ull < (1ull << 31),
                         "rlx_gae_scan: the hand-off variant addresses rows through 32-bit buffer offsets: (T+1)*B*4 must stay below 2 GiB");
@@ -799,6 +827,7 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
             else rc = nt ? dispatch_regseg<1, 32, true>(a, s) : dispatch_regseg<1, 32, false>(a, s);
             if (rc != RLX_OK) return rc;
         } else {
+#endif
         if (vec != 1) {
             set_error("rlx_gae_scan: vec=%d is compiled out (no gain on MI355X, see profiles/r01_gae_variant_sweep.txt)", vec);
             return RLX_ENOSYS;

@@ -28,9 +28,13 @@
 namespace rlx {
 namespace {
 
-inline int dev_variant_gaeseq() {  // RLX_GAESEQ_VARIANT=2 -> one segment per workgroup with decoupled look-back (measured slower)
+inline int dev_variant_gaeseq() {  // RLX_GAESEQ_VARIANT=1 / 2 -> the round-1 walk / one segment per workgroup with decoupled look-back
+#ifdef RLX_DEV_VARIANTS             // (both measured slower; tested variants of development builds)
     const char* e = getenv("RLX_GAESEQ_VARIANT");
     return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
 }
 
 __device__ __forceinline__ int pad(int i) { return i + (i >> 5); }  // chunk starts land in distinct banks

@@ -802,6 +802,7 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
     if (blocks == 0) return RLX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (r->bf16) return launch_rollout_bf16(a, blocks, st);
+    if (f32_split()) return launch_rollout_f32x(a, blocks, st);
     const size_t lds = Geo<1, 8>::LDS_BYTES;
     const int v = dev_variant("RLX_ROLLOUT_PD", 2);
 #define RLX_LAUNCH_ROLLOUT(PDV)                                                                 \
@@ -825,12 +826,19 @@ extern "C" int rlx_mlp_rollout_step(const rlx_rollout_step* r, rlx_stream_t stre
 
 extern "C" size_t rlx_mlp_tiles_bytes(const rlx_mlp_layout* lay) {
     (void)lay;
-    return 2 * Tiles::per_net() * sizeof(float);
+    return std::max(2 * Tiles::per_net() * sizeof(float), f32x_tiles_bytes());  // any of the image formats fits
+}
+
+extern "C" size_t rlx_mlp_tiles_bytes_for(const rlx_mlp_layout* lay, int32_t bf16) {
+    (void)lay;
+    if (bf16) return 2 * Tiles::per_net() * sizeof(__bf16);
+    return f32_split() ? f32x_tiles_bytes() : 2 * Tiles::per_net() * sizeof(float);
 }
 
 extern "C" int rlx_mlp_pack_tiles(const float* params, const rlx_mlp_layout* lay, float* tiles, rlx_stream_t stream) {
     if (int rc = check_layout(lay, "rlx_mlp_pack_tiles")) return rc;
     RLX_REQUIRE(params && tiles, "rlx_mlp_pack_tiles: NULL argument");
+    if (f32_split()) return pack_tiles_f32x(params, *lay, tiles, static_cast<hipStream_t>(stream));
     return pack_tiles(params, *lay, tiles, static_cast<hipStream_t>(stream));
 }
 
@@ -925,6 +933,16 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
         }
         return launch_step_bf16(a, d, ws + pl.off_st, pl.tiles, dw_blocks, lay.act_dim <= 8 && lay.val_dim <= 8, rows, st);
     }
+    if (f32_split()) {  // the default f32 path: three bf16 planes per operand on the bf16 matrix pipe (ppo_step_f32x.hip)
+        if (s->tiles != nullptr) {
+            a.tiles = s->tiles;
+        } else {
+            void* tiles = ws + pl.off_tiles;
+            a.tiles = static_cast<const float*>(tiles);
+            if (int rc = pack_tiles_f32x(s->params, lay, tiles, st)) return rc;
+        }
+        return launch_step_f32x(a, d, ws + pl.off_st, pl.tiles, dw_blocks, st);
+    }
     if (s->tiles != nullptr) {
         a.tiles = s->tiles;
     } else {
@@ -970,11 +988,8 @@ extern "C" int rlx_ppo_step(const rlx_ppo_step_args* s, rlx_stream_t stream) {
 #undef RLX_LAUNCH_FUSED
     RLX_LAUNCH_CHECK();
     const int blocks = dw_blocks;
-    // exact-f32 MFMA on request (RLX_F32_EXACT_MFMA=1); default: the same f32-accurate products as 3 x bf16 splits, 2.7 x less
-    // matrix-pipe time (see dw_mfma6)
-    static const bool exact = getenv("RLX_F32_EXACT_MFMA") != nullptr && atoi(getenv("RLX_F32_EXACT_MFMA")) != 0;
-    if (exact) hipLaunchKernelGGL(ppo_step_dw_kernel<false>, dim3(blocks), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(ppo_step_dw_kernel<true>, dim3(blocks), dim3(256), 0, st, d);
+    // (reached with RLX_F32_EXACT_MFMA=1 only: exact f32 products on v_mfma_f32_32x32x2_f32)
+    hipLaunchKernelGGL(ppo_step_dw_kernel<false>, dim3(blocks), dim3(256), 0, st, d);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

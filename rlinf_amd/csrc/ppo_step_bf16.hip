@@ -387,11 +387,9 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
     const long long m0 = (long long)tile * BM, M = a.M;
     const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
-    const int K = p.raw_per_adv, S = p.sub_per_adv, R = K / S;
-    const int npr = lay.act_dim / K;
+    const int npr = lay.act_dim / p.raw_per_adv;
     const long long n_adv = M * npr;
-    const bool has_mask = a.loss_mask != nullptr, has_msum = a.loss_mask_sum != nullptr;
-    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
+    const bool has_mask = a.loss_mask != nullptr;
     const TileGeom tg{(int)((M + 31) / 32)};
     const __bf16* tiles = reinterpret_cast<const __bf16*>(a.tiles);
     __bf16* hy = reinterpret_cast<__bf16*>(a.h) + (size_t)(y * 2) * tg.mat();
@@ -477,194 +475,11 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     epilogue_tanh_b<RT, NW, true>(acc, sBias + 2 * HID, Xb, kept3, nullptr, nullptr, tg.nrb, m0);
     ts.mark();
 
-    // ---- head + loss element math (f32, identical to ppo_step.hip) ------------------------------------------------------
-    const double nm = has_mask ? sNm[0] : 0.0;
-    const Denoms den = denominators(p, n_adv, nm, has_mask, has_msum);
-    const float half_delta = (float)(0.5 * (double)p.huber_delta);
-    double lacc[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
-    DecoupledMode dmode{};
-    if constexpr (DEC) dmode = decoupled_mode_now(a.dec);
-
+    // ---- head + loss element math (f32, identical to ppo_step.hip): fused_loss_pass, ppo_step_bf16_parts.h -------------------------
     head_forward_mfma<RT>(Xb, W4s, sG, sLp);  // the two k-half partials land in sG / sLp (both free until the passes below)
     lds_barrier();
     ts.mark();
-    // Fast path (the embodied shapes: one loss element per row -- action_level log-probs, one sub-group --, or a value head of
-    // at most 64 / BM outputs): element math, loss element and dOut in ONE pass with no barrier in between.  A row's n_out lanes
-    // are neighbours (idx = row * n_out + o), so the row leader (o == 0) collects the per-dimension log-probs with n_out - 1
-    // lane shifts and adds them in the reference's order (j ascending, starting from 0.f), evaluates the loss element and hands
-    // d(loss)/d(logprob) back to its lanes.  Slot r of the metric partials is row r's element, exactly what wave 0's lane r
-    // held in the general path: the butterfly sums -- and so the metrics -- are bit-identical between the two paths.
-    double* sLacc = reinterpret_cast<double*>(Xb);  // [NS][64]; h3's slab is dead: the head gradients / dZ3 use registers + sHead
-    const bool fast = a.merged_loss_pass && BM * n_out <= G::NT && (y == 0 ? BM * n_out <= 64 : (npr == 1 && S == 1 && 64 % n_out == 0));
-    if (fast) {
-        for (int i = tid; i < NS * 64; i += G::NT)
-            if ((i & 63) >= (y == 0 ? BM * n_out : BM)) sLacc[i] = 0.0;  // the slots no element owns
-        const bool mine = tid < BM * n_out;
-        const int row = mine ? tid / n_out : 0, o = mine ? tid % n_out : 0;
-        const bool valid = mine && m0 + row < M;
-        float sv = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
-        if (lay.off_b[y][3] >= 0) sv = fadd(sv, b4s[o]);
-        if (y == 1) {
-            const float d = fsub(sAct[row * MAX_OUT + o], sv);
-            const float var = sStd[MAX_OUT + o], log_scale = sStd[2 * MAX_OUT + o];
-            const float lpe = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
-            const float olde = sOld[row * MAX_OUT + o];
-            float lp = fadd(0.f, lpe), old = fadd(0.f, olde);
-            float pxe = 0.f, px = 0.f;  // decoupled, given proximal policy: its per-dimension log-probs, summed like `old`
-            if constexpr (DEC) {
-                if (dmode.mode == RLX_PROX_GIVEN && mine) pxe = a.dec.proximal[(size_t)min(m0 + row, M - 1) * lay.act_dim + o];
-                px = fadd(0.f, pxe);
-            }
-            for (int j = 1; j < n_out; ++j) {  // wave-uniform trip count; only the leaders' sums are used
-                lp = fadd(lp, __shfl_down(lpe, j, 64));
-                old = fadd(old, __shfl_down(olde, j, 64));
-                if constexpr (DEC) px = fadd(px, __shfl_down(pxe, j, 64));
-            }
-            float gs = 0.f;
-            if (valid && o == 0) {
-                const long long e = m0 + row;
-                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
-                float w = 1.f;
-                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
-                lacc[S_NM] += on ? 1.0 : 0.0;
-                if constexpr (DEC) {  // sum form: the denominator is out[RLX_PPO_ACTOR_GRAD_SCALE] of the finished row
-                    const float vb = a.dec.versions != nullptr ? a.dec.versions[(size_t)e * lay.act_dim] : 0.f;
-                    gs = a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc, S_VLOSS);
-                } else {
-                    const float g = actor_elem(p, lp, old, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc);
-                    gs = (a.grad_out * (float)(1.0 / den.actor)) * g;
-                }
-            }
-            gs = __shfl(gs, (lane - o) & 63, 64);  // from the row leader
-            float dmu = 0.f, dls = 0.f;
-            if (valid) {
-                dmu = gs * d / var;
-                dls = gs * (d * d / var - 1.f);
-            }
-            if (mine) {
-                sHead[row * MAX_OUT + o] = dmu;
-                sLp[row * MAX_OUT + o] = dls;
-                if (o == 0) {
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) sLacc[k * 64 + row] = lacc[k];
-                }
-            }
-        } else if (mine) {
-            float gv = 0.f;
-            if (valid && p.has_critic) {
-                const long long e = (m0 + row) * n_out + o;
-                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
-                float w = 1.f;
-                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
-                gv = (a.grad_out * (float)(1.0 / den.critic)) *
-                     critic_elem(p, sv, sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
-            }
-            sHead[row * MAX_OUT + o] = gv;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) sLacc[k * 64 + tid] = lacc[k];
-        }
-        lds_barrier();
-        ts.mark();
-        ts.mark();  // (the general path's two intermediate stamps)
-    } else {
-        for (int idx = tid; idx < BM * n_out; idx += G::NT) {
-            const int row = idx / n_out, o = idx % n_out;
-            float s = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
-            if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[o]);
-            sHead[row * MAX_OUT + o] = s;
-            if (y == 1) {
-                const float d = fsub(sAct[row * MAX_OUT + o], s);
-                const float var = sStd[MAX_OUT + o];
-                const float log_scale = sStd[2 * MAX_OUT + o];
-                sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
-                sD[row * MAX_OUT + o] = d;
-            }
-        }
-        lds_barrier();
-        ts.mark();
-        // wave 0 walks the tile's loss elements (a fixed lane <-> element assignment keeps the f64 metric sums reproducible) and
-        // parks its 16 per-lane partial sums in the slab (h3 is dead: the head gradients and dZ3 work from registers and sHead);
-        // behind the barrier every wave butterfly-sums two of the 16 slots while all lanes run the dOut pass -- the same 64-lane
-        // butterfly wave 0 used to run 16 times in a row (~7 k cycles with the other seven waves parked at the barrier).
-        if (y == 1) {
-            for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {
-                const int row = idx / npr, c = idx % npr;
-                if (m0 + row >= M) continue;
-                const long long e = (m0 + row) * npr + c;
-                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
-                float w = 1.f;
-                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
-                const float adv = sAdv[row * MAX_OUT + c];
-                lacc[S_NM] += on ? 1.0 : 0.0;
-                const float* olp = sOld + row * MAX_OUT + c * K;
-                for (int s = 0; s < S; ++s) {
-                    float lp = 0.f, old = 0.f;
-                    for (int j = 0; j < R; ++j) {
-                        lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
-                        old = fadd(old, olp[s * R + j]);
-                    }
-                    if constexpr (DEC) {  // the slice's raw entries are [e * K + s * R, + R) of the [M, act_dim] arrays
-                        const size_t r0 = (size_t)e * K + s * R;
-                        float px = 0.f;
-                        if (dmode.mode == RLX_PROX_GIVEN)
-                            for (int j = 0; j < R; ++j) px = fadd(px, a.dec.proximal[r0 + j]);
-                        const float vb = a.dec.versions != nullptr ? a.dec.versions[r0] : 0.f;
-                        sG[row * MAX_OUT + c * S + s] =
-                            a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, adv, on, w, ratio_mode, lacc, S_VLOSS);
-                    } else {
-                        const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
-                        sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
-                    }
-                }
-            }
-        } else {
-            for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {
-                const int row = idx / n_out, o = idx % n_out;
-                float gv = 0.f;
-                if (m0 + row < M && p.has_critic) {
-                    const long long e = (m0 + row) * n_out + o;
-                    const bool on = has_mask ? a.loss_mask[e] != 0 : true;
-                    float w = 1.f;
-                    if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
-                    gv = (a.grad_out * (float)(1.0 / den.critic)) *
-                         critic_elem(p, sHead[row * MAX_OUT + o], sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
-                }
-                sHead[row * MAX_OUT + o] = gv;
-            }
-        }
-        if (wave == 0) {
-    #pragma unroll
-            for (int k = 0; k < NS; ++k) sLacc[k * 64 + lane] = lacc[k];
-        }
-        lds_barrier();
-        ts.mark();
-        if (y == 1) {
-            for (int idx = tid; idx < BM * n_out; idx += G::NT) {
-                const int row = idx / n_out, o = idx % n_out;
-                float dmu = 0.f, dls = 0.f;
-                if (m0 + row < M) {
-                    const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
-                    const float var = sStd[MAX_OUT + o], d = sD[row * MAX_OUT + o];
-                    dmu = dlp * d / var;
-                    dls = dlp * (d * d / var - 1.f);
-                }
-                sHead[row * MAX_OUT + o] = dmu;
-                sLp[row * MAX_OUT + o] = dls;
-            }
-        }
-    }
-    {
-        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
-        for (int k = wave; k < NS; k += NW) {
-            const double v = wave_sum(sLacc[k * 64 + lane]);
-            if (lane == 0) lp[k] = v;
-        }
-    }
-    lds_barrier();
-    ts.mark();
-
+    fused_loss_pass<BM, NW, DEC>(a, y, tile, m0, LossLds{b4s, sHead, sLp, sG, sD, sOld, sAct, sAdv, sRet, sStd, reinterpret_cast<double*>(Xb), sNm}, ts);
     // ---- head parameter gradients per 32-row half tile: dW4[o][j] = sum_rows dOut[row][o] h3[row][j] on the matrix pipe -------
     // M = o, N = j (this wave's 2 x 16 columns), K = the half's 32 rows.  K is only a summation index, so the k slots are
     // mapped to rows the way the accumulator layout already holds h3: lane (r16, kq) slot jj <-> row (jj >> 2) * 16 + 4 kq +
@@ -777,6 +592,7 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
 // fused optimizer-step kernel (2), bf16: weight gradients from the k-tiled transposed images, barrier-free.
 //   item = (slab, matrix, 128x128 tile); 4 waves as 2x2, each 4x4 tiles of 16x16 (v_mfma_f32_16x16x32_bf16, K = 32 batch rows)
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef RLX_DEV_VARIANTS  // the register-streaming weight-gradient kernel of round 2 (RLX_DW_BF16_REG=1): kept for comparison only
 template <int PD>
 __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, const __bf16* __restrict__ st_tiles) {
     __shared__ double s_red[NS * 4];
@@ -889,6 +705,8 @@ __global__ __launch_bounds__(256, 2) void ppo_step_dw_bf16_kernel(DwArgs a, cons
         }
     }
 }
+
+#endif  // RLX_DEV_VARIANTS
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradients, LDS-DMA variant: the 16 operand tiles of a k-block (8 of dZ^T, 8 of H^T, 1 KiB each, already in
@@ -1292,11 +1110,14 @@ int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles,
 }
 
 int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
+#ifdef RLX_DEV_VARIANTS
     if (rollout_bm_bf16() == 32) {
         const size_t lds = GeoB<2, 8>::LDS_BYTES;
         if (int rc = set_lds_b(rollout_step_bf16_kernel<2>, lds)) return rc;
         hipLaunchKernelGGL(rollout_step_bf16_kernel<2>, dim3(blocks), dim3(512), lds, st, a);
-    } else {
+    } else
+#endif
+    {
         const size_t lds = GeoB<1, 8>::LDS_BYTES;
         if (int rc = set_lds_b(rollout_step_bf16_kernel<1>, lds)) return rc;
         hipLaunchKernelGGL(rollout_step_bf16_kernel<1>, dim3(blocks), dim3(512), lds, st, a);
@@ -1309,90 +1130,87 @@ int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
 size_t bf16_image_bytes(int64_t m) { return (size_t)16 * ((m + 31) / 32) * 512 * sizeof(__bf16); }
 
 int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles, int dw_blocks, bool op8, bool rows, hipStream_t st) {
-    const size_t lds = GeoB<4, 8>::LDS_BYTES + GeoB<4, 8>::KEEP_BYTES;
     __bf16* stt = static_cast<__bf16*>(st_tiles);
+#define RLX_FUSED_LAUNCH(RTV, PDV, OPV, STV, DECV, LDSB)                                                                              \
+    {                                                                                                                              \
+        const size_t lb = (LDSB);                                                                                                  \
+        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<RTV, 8, PDV, OPV, STV, DECV>, lb)) return rc;                            \
+        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<RTV, 8, PDV, OPV, STV, DECV>), dim3(tiles, 2), dim3(512), lb, st, a, stt); \
+    }
+    const size_t lds32 = GeoB<2, 8>::LDS_BYTES;
+#ifdef RLX_DEV_VARIANTS
+    // development builds: the row-split launch, 64-row tiles (RLX_FUSED_RT=4), other weight-ring depths, phase stamps, LDS padding
+    const size_t lds64 = GeoB<4, 8>::LDS_BYTES + GeoB<4, 8>::KEEP_BYTES;
+    const int pd = dev_variant("RLX_FUSED_PD", 4);
     if (rows) {  // `tiles` counts 64-row tiles
         if (int rc = launch_fused_rows_bf16(a, st_tiles, tiles, st)) return rc;
-    } else if (a.dec.on) {  // the decoupled actor loss: the default launch shape of each tile height, no development variants
-        if (fused_bm_bf16() == 32) {
-            const size_t lds2 = GeoB<2, 8>::LDS_BYTES;
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, false, true>, lds2)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, false, true>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
-        } else if (op8) {
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, false, true>, lds)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false, true>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
-        } else {
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16, false, true>, lds)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16, false, true>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
-        }
-    } else if (fused_bm_bf16() == 32) {  // `tiles` counts 32-row tiles (plan_step)
-        const size_t lds2 = GeoB<2, 8>::LDS_BYTES + (size_t)dev_variant("RLX_FUSED_LDS_PAD", 0);  // development: LDS-size sensitivity
-        if (a.stamps != nullptr) {
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, true>, lds2)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, true>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
-        } else if (dev_variant("RLX_FUSED_PD", 4) == 2) {
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 2, 8, false>, lds2)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 2, 8, false>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
-        } else if (dev_variant("RLX_FUSED_PD", 4) == 3) {
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 3, 8, false>, lds2)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 3, 8, false>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
-        } else {
-            if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<2, 8, 4, 8, false>, lds2)) return rc;
-            hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<2, 8, 4, 8, false>), dim3(tiles, 2), dim3(512), lds2, st, a, stt);
-        }
-    } else if (op8 && a.stamps != nullptr) {
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, true>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
-    } else if (op8 && dev_variant("RLX_FUSED_PD", 4) == 8) {  // development: deeper weight-fragment rings
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 8, 8, false>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
-    } else if (op8) {
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 4, 8, false>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
+    } else if (fused_bm_bf16() == 64) {
+        if (a.dec.on) { if (op8) RLX_FUSED_LAUNCH(4, 4, 8, false, true, lds64) else RLX_FUSED_LAUNCH(4, 2, 16, false, true, lds64) }
+        else if (op8 && a.stamps != nullptr) RLX_FUSED_LAUNCH(4, 4, 8, true, false, lds64)
+        else if (op8 && pd == 8) RLX_FUSED_LAUNCH(4, 8, 8, false, false, lds64)
+        else if (op8) RLX_FUSED_LAUNCH(4, 4, 8, false, false, lds64)
+        else RLX_FUSED_LAUNCH(4, 2, 16, false, false, lds64)
+    } else if (a.dec.on) {
+        RLX_FUSED_LAUNCH(2, 4, 8, false, true, lds32)
+    } else if (a.stamps != nullptr) {
+        RLX_FUSED_LAUNCH(2, 4, 8, true, false, lds32)
+    } else if (pd == 2) {
+        RLX_FUSED_LAUNCH(2, 2, 8, false, false, lds32)
+    } else if (pd == 3) {
+        RLX_FUSED_LAUNCH(2, 3, 8, false, false, lds32)
     } else {
-        if (int rc = set_lds_b(ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>, lds)) return rc;
-        hipLaunchKernelGGL((ppo_step_fused_bf16_kernel<4, 8, 2, 16, false>), dim3(tiles, 2), dim3(512), lds, st, a, stt);
+        RLX_FUSED_LAUNCH(2, 4, 8, false, false, lds32 + (size_t)dev_variant("RLX_FUSED_LDS_PAD", 0))
     }
+#else
+    (void)rows;
+    (void)op8;
+    // the product launch: 32-row tiles (two workgroups per CU), weight ring of 4 stages; its decoupled-loss instantiation
+    if (a.dec.on) RLX_FUSED_LAUNCH(2, 4, 8, false, true, lds32)
+    else RLX_FUSED_LAUNCH(2, 4, 8, false, false, lds32)
+#endif
+#undef RLX_FUSED_LAUNCH
     RLX_LAUNCH_CHECK();
-    if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)
-        hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
-    } else {
-        // The ring kernel pays a longer prologue (the loaders' first hand-off) for its faster k-loop and store phase: it wins from
-        // 4096 rows on (8192 rows, one box: 15.6 against 16.8 us, the slab reduce behind it 8.2 against 8.8), at 1024 rows the
-        // previous kernel is ahead (9.4 against 10.5 us: profiles/r04_per_rank_share_*.txt).  RLX_DW_RING = 0 / 1 forces one.
-        if (dev_variant("RLX_DW_RING", d.M >= 4096 ? 1 : 0) != 0) {
 #define RLX_DWR_LAUNCH(NB)                                                                                                         \
     {                                                                                                                              \
         const size_t rlds = (size_t)(NB) * DW_BUF_BYTES;                                                                           \
         if (int rc = set_lds_b(ppo_step_dw_bf16_ring_kernel<NB>, rlds)) return rc;                                                 \
         hipLaunchKernelGGL(ppo_step_dw_bf16_ring_kernel<NB>, dim3(dw_blocks), dim3(DWR_THREADS), rlds, st, d, static_cast<const __bf16*>(stt)); \
     }
-            switch (dev_variant("RLX_DW_RING_NBUF", 4)) {
-                case 6: RLX_DWR_LAUNCH(6) break;
-                case 8: RLX_DWR_LAUNCH(8) break;
-                case 9: RLX_DWR_LAUNCH(9) break;
-                default: RLX_DWR_LAUNCH(4) break;
-            }
-#undef RLX_DWR_LAUNCH
-            RLX_LAUNCH_CHECK();
-            return RLX_OK;
-        }
 #define RLX_DW_LAUNCH(NB)                                                                                                       \
     {                                                                                                                           \
         const size_t dlds = (size_t)(NB) * DW_BUF_BYTES;                                                                          \
         if (int rc = set_lds_b(ppo_step_dw_bf16_lds_kernel<NB>, dlds)) return rc;                                               \
         hipLaunchKernelGGL(ppo_step_dw_bf16_lds_kernel<NB>, dim3(dw_blocks), dim3(256), dlds, st, d, static_cast<const __bf16*>(stt)); \
     }
+    // The ring kernel pays a longer prologue (the loaders' first hand-off) for its faster k-loop and store phase: it wins from
+    // 4096 rows on (8192 rows, one box: 15.6 against 16.8 us, the slab reduce behind it 8.2 against 8.8), at 1024 rows the
+    // previous kernel is ahead (9.4 against 10.5 us: profiles/r04_per_rank_share_*.txt).
+#ifdef RLX_DEV_VARIANTS
+    if (dev_variant("RLX_DW_BF16_REG", 0)) {  // the register-streaming variant (kept for comparison)
+        hipLaunchKernelGGL(ppo_step_dw_bf16_kernel<3>, dim3(dw_blocks), dim3(256), 0, st, d, static_cast<const __bf16*>(stt));
+    } else if (dev_variant("RLX_DW_RING", d.M >= 4096 ? 1 : 0) != 0) {
+        switch (dev_variant("RLX_DW_RING_NBUF", 4)) {
+            case 6: RLX_DWR_LAUNCH(6) break;
+            case 8: RLX_DWR_LAUNCH(8) break;
+            case 9: RLX_DWR_LAUNCH(9) break;
+            default: RLX_DWR_LAUNCH(4) break;
+        }
+    } else {
         switch (dw_nbuf()) {
             case 2: RLX_DW_LAUNCH(2) break;
-            case 3: RLX_DW_LAUNCH(3) break;
             case 4: RLX_DW_LAUNCH(4) break;
             case 6: RLX_DW_LAUNCH(6) break;
             case 9: RLX_DW_LAUNCH(9) break;
-            default: RLX_DW_LAUNCH(5) break;
+            case 5: RLX_DW_LAUNCH(5) break;
+            default: RLX_DW_LAUNCH(3) break;
         }
-#undef RLX_DW_LAUNCH
     }
+#else
+    if (d.M >= 4096) RLX_DWR_LAUNCH(4)
+    else RLX_DW_LAUNCH(3)
+#endif
+#undef RLX_DWR_LAUNCH
+#undef RLX_DW_LAUNCH
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

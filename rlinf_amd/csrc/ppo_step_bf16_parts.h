@@ -168,5 +168,216 @@ struct SmallInputsB {
     }
 };
 
+
+// ---- the loss pass of the fused optimizer-step launches (bf16: ppo_step_bf16.hip; f32 through bf16 splits: ppo_step_f32x.hip) ----
+// In: the head's two k-half partials in sG / sLp, the tile's loss inputs in sOld / sAct / sAdv / sRet, std | var | log(std) in sStd.
+// Out: d(loss)/d(head output) in sHead (policy: d/d mean; value: d/d value), d/d logstd per row in sLp, the tile's metric partial row in
+// a.loss_part.  Ends with an LDS barrier.  sLacc: [NS][64] doubles of scratch (the dead h3 slab).
+struct LossLds {
+    float *b4s, *sHead, *sLp, *sG, *sD, *sOld, *sAct, *sAdv, *sRet, *sStd;
+    double* sLacc;
+    const double* sNm;
+};
+template <int BM, int NW, bool DEC, typename TS>
+__device__ __forceinline__ void fused_loss_pass(const StepArgs& a, int y, int tile, long long m0, const LossLds& L, TS& ts) {
+    constexpr int NT = 64 * NW;
+    const rlx_mlp_layout& lay = a.lay;
+    const rlx_ppo_loss_params& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long M = a.M;
+    const int n_out = y == 1 ? lay.act_dim : lay.val_dim;
+    const int K = p.raw_per_adv, S = p.sub_per_adv, R = K / S;
+    const int npr = lay.act_dim / K;
+    const long long n_adv = M * npr;
+    const bool has_mask = a.loss_mask != nullptr, has_msum = a.loss_mask_sum != nullptr;
+    const bool ratio_mode = p.max_episode_steps > 0 && has_mask && has_msum;
+    float *b4s = L.b4s, *sHead = L.sHead, *sLp = L.sLp, *sG = L.sG, *sD = L.sD, *sOld = L.sOld, *sAct = L.sAct, *sAdv = L.sAdv,
+          *sRet = L.sRet, *sStd = L.sStd;
+    double* sLacc = L.sLacc;
+    const double* sNm = L.sNm;
+    const double nm = has_mask ? sNm[0] : 0.0;
+    const Denoms den = denominators(p, n_adv, nm, has_mask, has_msum);
+    const float half_delta = (float)(0.5 * (double)p.huber_delta);
+    double lacc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) lacc[k] = 0.0;
+    DecoupledMode dmode{};
+    if constexpr (DEC) dmode = decoupled_mode_now(a.dec);
+
+    // Fast path (the embodied shapes: one loss element per row -- action_level log-probs, one sub-group --, or a value head of
+    // at most 64 / BM outputs): element math, loss element and dOut in ONE pass with no barrier in between.  A row's n_out lanes
+    // are neighbours (idx = row * n_out + o), so the row leader (o == 0) collects the per-dimension log-probs with n_out - 1
+    // lane shifts and adds them in the reference's order (j ascending, starting from 0.f), evaluates the loss element and hands
+    // d(loss)/d(logprob) back to its lanes.  Slot r of the metric partials is row r's element, exactly what wave 0's lane r
+    // held in the general path: the butterfly sums -- and so the metrics -- are bit-identical between the two paths.
+    const bool fast = a.merged_loss_pass && BM * n_out <= NT && (y == 0 ? BM * n_out <= 64 : (npr == 1 && S == 1 && 64 % n_out == 0));
+    if (fast) {
+        for (int i = tid; i < NS * 64; i += NT)
+            if ((i & 63) >= (y == 0 ? BM * n_out : BM)) sLacc[i] = 0.0;  // the slots no element owns
+        const bool mine = tid < BM * n_out;
+        const int row = mine ? tid / n_out : 0, o = mine ? tid % n_out : 0;
+        const bool valid = mine && m0 + row < M;
+        float sv = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
+        if (lay.off_b[y][3] >= 0) sv = fadd(sv, b4s[o]);
+        if (y == 1) {
+            const float d = fsub(sAct[row * MAX_OUT + o], sv);
+            const float var = sStd[MAX_OUT + o], log_scale = sStd[2 * MAX_OUT + o];
+            const float lpe = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+            const float olde = sOld[row * MAX_OUT + o];
+            float lp = fadd(0.f, lpe), old = fadd(0.f, olde);
+            float pxe = 0.f, px = 0.f;  // decoupled, given proximal policy: its per-dimension log-probs, summed like `old`
+            if constexpr (DEC) {
+                if (dmode.mode == RLX_PROX_GIVEN && mine) pxe = a.dec.proximal[(size_t)min(m0 + row, M - 1) * lay.act_dim + o];
+                px = fadd(0.f, pxe);
+            }
+            for (int j = 1; j < n_out; ++j) {  // wave-uniform trip count; only the leaders' sums are used
+                lp = fadd(lp, __shfl_down(lpe, j, 64));
+                old = fadd(old, __shfl_down(olde, j, 64));
+                if constexpr (DEC) px = fadd(px, __shfl_down(pxe, j, 64));
+            }
+            float gs = 0.f;
+            if (valid && o == 0) {
+                const long long e = m0 + row;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                lacc[S_NM] += on ? 1.0 : 0.0;
+                if constexpr (DEC) {  // sum form: the denominator is out[RLX_PPO_ACTOR_GRAD_SCALE] of the finished row
+                    const float vb = a.dec.versions != nullptr ? a.dec.versions[(size_t)e * lay.act_dim] : 0.f;
+                    gs = a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc, S_VLOSS);
+                } else {
+                    const float g = actor_elem(p, lp, old, sAdv[row * MAX_OUT], on, w, ratio_mode, lacc);
+                    gs = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                }
+            }
+            gs = __shfl(gs, (lane - o) & 63, 64);  // from the row leader
+            float dmu = 0.f, dls = 0.f;
+            if (valid) {
+                dmu = gs * d / var;
+                dls = gs * (d * d / var - 1.f);
+            }
+            if (mine) {
+                sHead[row * MAX_OUT + o] = dmu;
+                sLp[row * MAX_OUT + o] = dls;
+                if (o == 0) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) sLacc[k * 64 + row] = lacc[k];
+                }
+            }
+        } else if (mine) {
+            float gv = 0.f;
+            if (valid && p.has_critic) {
+                const long long e = (m0 + row) * n_out + o;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                gv = (a.grad_out * (float)(1.0 / den.critic)) *
+                     critic_elem(p, sv, sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
+            }
+            sHead[row * MAX_OUT + o] = gv;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) sLacc[k * 64 + tid] = lacc[k];
+        }
+        lds_barrier();
+        ts.mark();
+        ts.mark();  // (the general path's two intermediate stamps)
+    } else {
+        for (int idx = tid; idx < BM * n_out; idx += NT) {
+            const int row = idx / n_out, o = idx % n_out;
+            float s = fadd(sG[row * MAX_OUT + o], sLp[row * MAX_OUT + o]);
+            if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[o]);
+            sHead[row * MAX_OUT + o] = s;
+            if (y == 1) {
+                const float d = fsub(sAct[row * MAX_OUT + o], s);
+                const float var = sStd[MAX_OUT + o];
+                const float log_scale = sStd[2 * MAX_OUT + o];
+                sLp[row * MAX_OUT + o] = fsub(fsub((-fmul(d, d)) / fmul(2.f, var), log_scale), LOG_SQRT_2PI);
+                sD[row * MAX_OUT + o] = d;
+            }
+        }
+        lds_barrier();
+        ts.mark();
+        // wave 0 walks the tile's loss elements (a fixed lane <-> element assignment keeps the f64 metric sums reproducible) and
+        // parks its 16 per-lane partial sums in the slab (h3 is dead: the head gradients and dZ3 work from registers and sHead);
+        // behind the barrier every wave butterfly-sums two of the 16 slots while all lanes run the dOut pass -- the same 64-lane
+        // butterfly wave 0 used to run 16 times in a row (~7 k cycles with the other seven waves parked at the barrier).
+        if (y == 1) {
+            for (int idx = tid; idx < BM * npr && wave == 0; idx += 64) {
+                const int row = idx / npr, c = idx % npr;
+                if (m0 + row >= M) continue;
+                const long long e = (m0 + row) * npr + c;
+                const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                float w = 1.f;
+                if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                const float adv = sAdv[row * MAX_OUT + c];
+                lacc[S_NM] += on ? 1.0 : 0.0;
+                const float* olp = sOld + row * MAX_OUT + c * K;
+                for (int s = 0; s < S; ++s) {
+                    float lp = 0.f, old = 0.f;
+                    for (int j = 0; j < R; ++j) {
+                        lp = fadd(lp, sLp[row * MAX_OUT + c * K + s * R + j]);
+                        old = fadd(old, olp[s * R + j]);
+                    }
+                    if constexpr (DEC) {  // the slice's raw entries are [e * K + s * R, + R) of the [M, act_dim] arrays
+                        const size_t r0 = (size_t)e * K + s * R;
+                        float px = 0.f;
+                        if (dmode.mode == RLX_PROX_GIVEN)
+                            for (int j = 0; j < R; ++j) px = fadd(px, a.dec.proximal[r0 + j]);
+                        const float vb = a.dec.versions != nullptr ? a.dec.versions[r0] : 0.f;
+                        sG[row * MAX_OUT + c * S + s] =
+                            a.grad_out * decoupled_actor_elem(p, dmode, lp, old, px, vb, adv, on, w, ratio_mode, lacc, S_VLOSS);
+                    } else {
+                        const float g = actor_elem(p, lp, old, adv, on, w, ratio_mode, lacc);
+                        sG[row * MAX_OUT + c * S + s] = (a.grad_out * (float)(1.0 / den.actor)) * g;
+                    }
+                }
+            }
+        } else {
+            for (int idx = tid; idx < BM * n_out && wave == 0; idx += 64) {
+                const int row = idx / n_out, o = idx % n_out;
+                float gv = 0.f;
+                if (m0 + row < M && p.has_critic) {
+                    const long long e = (m0 + row) * n_out + o;
+                    const bool on = has_mask ? a.loss_mask[e] != 0 : true;
+                    float w = 1.f;
+                    if (ratio_mode) w = ((float)a.loss_mask_sum[e] * 1.0f) / (float)p.max_episode_steps;
+                    gv = (a.grad_out * (float)(1.0 / den.critic)) *
+                         critic_elem(p, sHead[row * MAX_OUT + o], sAdv[row * MAX_OUT + o], sRet[row * MAX_OUT + o], on, w, ratio_mode, half_delta, lacc);
+                }
+                sHead[row * MAX_OUT + o] = gv;
+            }
+        }
+        if (wave == 0) {
+    #pragma unroll
+            for (int k = 0; k < NS; ++k) sLacc[k * 64 + lane] = lacc[k];
+        }
+        lds_barrier();
+        ts.mark();
+        if (y == 1) {
+            for (int idx = tid; idx < BM * n_out; idx += NT) {
+                const int row = idx / n_out, o = idx % n_out;
+                float dmu = 0.f, dls = 0.f;
+                if (m0 + row < M) {
+                    const float dlp = sG[row * MAX_OUT + (o / K) * S + (o % K) / R];
+                    const float var = sStd[MAX_OUT + o], d = sD[row * MAX_OUT + o];
+                    dmu = dlp * d / var;
+                    dls = dlp * (d * d / var - 1.f);
+                }
+                sHead[row * MAX_OUT + o] = dmu;
+                sLp[row * MAX_OUT + o] = dls;
+            }
+        }
+    }
+    {
+        double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
+        for (int k = wave; k < NS; k += NW) {
+            const double v = wave_sum(sLacc[k * 64 + lane]);
+            if (lane == 0) lp[k] = v;
+        }
+    }
+    lds_barrier();
+    ts.mark();
+}
+
 }  // namespace b16
 }  // namespace rlx

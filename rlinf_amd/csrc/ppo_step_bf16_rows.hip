@@ -1,4 +1,4 @@
-// ppo_step_bf16_rows.hip -- the fused optimizer-step launch (1), bf16, ROW-SPLIT form (opt-in: RLX_FUSED_ROWS=1): one workgroup =
+// ppo_step_bf16_rows.hip -- the fused optimizer-step launch (1), bf16, ROW-SPLIT form (development builds only: -DRLX_DEV_VARIANTS, RLX_FUSED_ROWS=1): one workgroup =
 // 64 minibatch rows of one network; its 8 compute waves are 2 row pairs x 4 column quarters -- wave (rp, cq) owns 32 rows x 64
 // columns (acc[2][4] tiles of 16 x 16) through the whole chain (forward, head, loss, backward-data); the network's weight tiles are
 // staged ONCE per workgroup through an LDS ring by two loader waves.
@@ -35,6 +35,8 @@
 // Measured (profiles/r04_rows_kernel_*): 27.6 us at 8192 rows against 26.2 us for the column-split launch, 23.7 against 18.0 us at
 // 1024 rows: the ring hand-off costs ~525 cycles per k-step where the matrix pipe needs 272.  Parity-green in every fused-step
 // test (tests/test_gpu_fused_step.py, launch "rows"); not the default.  No decoupled-loss instantiation.
+
+#ifdef RLX_DEV_VARIANTS  // measured slower than the default launch (see above): compiled into development builds only
 
 #include <type_traits>
 
@@ -702,3 +704,19 @@ int launch_fused_rows_bf16(const StepArgs& a, void* st_tiles, int tiles64, hipSt
 
 }  // namespace step
 }  // namespace rlx
+
+#else  // product build: the row-split launch is not compiled
+
+#include "ppo_step_common.h"
+
+namespace rlx {
+namespace step {
+bool fused_rows_eligible(const rlx_mlp_layout&, const rlx_ppo_loss_params&) { return false; }
+int launch_fused_rows_bf16(const StepArgs&, void*, int, hipStream_t) {
+    set_error("the row-split fused launch is compiled into development builds only (-DRLX_DEV_VARIANTS)");
+    return RLX_ENOSYS;
+}
+}  // namespace step
+}  // namespace rlx
+
+#endif  // RLX_DEV_VARIANTS

@@ -353,11 +353,18 @@ int set_lds(K kern, size_t bytes) {
     return RLX_OK;
 }
 
-// development switch: integer environment variable, read once
+// Development switches.  The PRODUCT build reads no kernel-variant environment variable at all: every switch returns its default --
+// the measured-best path -- and the variant kernels behind the switches are not even compiled (the `#ifdef RLX_DEV_VARIANTS`
+// blocks of the .hip files).  A development build (RLX_CXXFLAGS=-DRLX_DEV_VARIANTS RLX_BUILD_TAG=dev python -m rlinf_amd.csrc.build,
+// loaded with RLX_LIB_TAG=dev) reads the variable at every call; rlx_dev_variants() tells a caller which build it loaded.
+#ifdef RLX_DEV_VARIANTS
 inline int dev_variant(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+#else
+inline int dev_variant(const char*, int dflt) { return dflt; }
+#endif
 
 inline int head_stride_of(const rlx_mlp_layout* lay) {
     const int n = std::max(lay->act_dim, lay->val_dim);
@@ -383,9 +390,18 @@ inline int fused_bm_bf16() { return dev_variant("RLX_FUSED_RT", 2) == 4 ? 64 : 3
 // the shapes it covers (fused_rows_eligible), behind RLX_FUSED_ROWS=1 while it is being tuned.
 inline bool fused_rows_bf16() { return dev_variant("RLX_FUSED_ROWS", 0) != 0; }
 bool fused_rows_eligible(const rlx_mlp_layout& lay, const rlx_ppo_loss_params& p);
+// precision "32": true (default) = the f32 launches run on the bf16 matrix pipe with three-plane operands (ppo_step_f32x.hip),
+// false (RLX_F32_EXACT_MFMA=1, read once per process) = the exact-f32-MFMA launches of ppo_step.hip.  The f32 weight image
+// (rlx_mlp_pack_tiles / the optimizer's tile refresh) follows the same switch.
+bool f32_split();
+size_t f32x_tiles_bytes();
+// rows per workgroup of the f32x fused launch: 32 (the three-plane slab allows one workgroup per CU either way; 64 rows -- half the
+// weight bytes per row, ONE round of 256 workgroups at 8192 rows -- measured the same 82 us: development builds only, RLX_F32X_RT=4)
+inline int f32x_bm() { return dev_variant("RLX_F32X_RT", 2) == 4 ? 64 : 32; }
 inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = false, bool rows = false) {
     StepPlan pl{};
-    const int bm = (bf16 && rows) ? 64 : bf16 ? fused_bm_bf16() : STEP_BM;
+    const bool f32x = !bf16 && f32_split();
+    const int bm = (bf16 && rows) ? 64 : bf16 ? fused_bm_bf16() : f32x ? f32x_bm() : STEP_BM;
     pl.tiles = ceil_div(m, bm);
     pl.head_parts = (bf16 && rows) ? pl.tiles : pl.tiles * (bm / 32);
     pl.loss_slots = pl.tiles;
@@ -399,8 +415,10 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
     // (profiles/r04_dw_ring_slab_sweep.txt): 16 slabs 19.9 us (353 blocks: a CU with two of them sets the launch's duration),
     // 12: 21.8 (265 blocks), 11: 15.6, 10: 15.6, 9: 16.4, 8: 17.2 -- against 16.8 for the previous kernel at its best (16 slabs);
     // the slab reduce behind it 8.84 -> 8.16 us with 10.
-    int want = bf16 ? (m >= 4096 ? std::max(1, (num_cu() - 1) / 25) : 5 * num_cu() / (4 * 20)) : 2 * num_cu() / 20;  // (below 4096 rows: the previous kernel and its plan)
-    if (const char* e = getenv("RLX_DW_SLABS")) want = std::max(1, atoi(e));  // development: tools/bench_step.py sweeps it
+    // f32 through bf16 planes: the loader-wave ring at every size (144 KiB of LDS: one workgroup per CU) -> the same 10-slab plan
+    int want = bf16 ? (m >= 4096 ? std::max(1, (num_cu() - 1) / 25) : 5 * num_cu() / (4 * 20))   // (below 4096 rows: the previous kernel and its plan)
+                    : f32x ? std::max(1, (num_cu() - 1) / 25) : 2 * num_cu() / 20;
+    want = std::max(1, dev_variant("RLX_DW_SLABS", want));  // development: tools/bench_step.py sweeps it
     // ... and at least 256 rows (8 k-blocks) per slab: a data-parallel rank's small minibatch should not pay 16 slabs of traffic
     int slabs = std::max(1, std::min(want, ceil_div(m, 256)));
     pl.rows_per_slab = round_up(ceil_div(m, slabs), 32);
@@ -414,6 +432,12 @@ inline StepPlan plan_step(const rlx_mlp_layout* lay, int64_t m, bool bf16 = fals
         pl.off_dz = take(6 * img);
         pl.off_st = take(img / 4);  // states: 4 column blocks
         pl.off_tiles = take(2 * Tiles::per_net() * 2);
+    } else if (f32x) {  // three planes of every k-tiled image
+        const size_t img = (size_t)16 * ceil_div(m, 32) * 1024;
+        pl.off_h = take(3 * 4 * img);
+        pl.off_dz = take(3 * 6 * img);
+        pl.off_st = take(3 * img / 4);
+        pl.off_tiles = take(f32x_tiles_bytes());
     } else {
         pl.off_h = take((size_t)4 * m * HID * sizeof(float));
         pl.off_dz = take((size_t)6 * m * HID * sizeof(float));
@@ -433,6 +457,10 @@ int pack_tiles_bf16(const float* params, const rlx_mlp_layout& lay, void* tiles,
 int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st);
 int launch_step_bf16(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles64, int dw_blocks, bool op8, bool rows, hipStream_t st);
 int launch_fused_rows_bf16(const StepArgs& a, void* st_tiles, int tiles64, hipStream_t st);  // ppo_step_bf16_rows.hip
+// f32 on the bf16 matrix pipe (ppo_step_f32x.hip)
+int pack_tiles_f32x(const float* params, const rlx_mlp_layout& lay, void* tiles, hipStream_t st);
+int launch_rollout_f32x(const RolloutArgs& a, int blocks, hipStream_t st);
+int launch_step_f32x(const StepArgs& a, const DwArgs& d, void* st_tiles, int tiles32, int dw_blocks, hipStream_t st);
 
 }  // namespace step
 }  // namespace rlx

@@ -289,7 +289,11 @@ extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask
         // lanes per sequence (a tile is 4 x lanes tokens), measured on three shapes (profiles/r02_reinpp_lanes_sweep.txt):
         // rows of <= 2048 tokens want 64 lanes (0.65-0.66 of the HBM peak against 0.58-0.62 with 256: a row is 4-8 short tiles
         // of one wave each, no cross-wave hand-off, and many rows share a CU), rows of >= 4096 tokens 256 lanes (0.69 against 0.63)
+#ifdef RLX_DEV_VARIANTS
         static const int forced = getenv("RLX_REINPP_RT") ? atoi(getenv("RLX_REINPP_RT")) : 0;  // development override
+#else
+        constexpr int forced = 0;
+#endif
         const int rtv = forced ? forced : (seq <= 2048 ? 64 : (seq < 4096 ? 128 : 256));
         if (rtv == 64) hipLaunchKernelGGL(reinpp_returns_kernel<64>, dim3((unsigned)bsz), dim3(64), 0, st, rewards, loss_mask, logprob, ref_logprob, kl_type,
                        kl_beta, advantages, partials, (long long)bsz, (long long)seq, (int)((bits & 15) == 0));

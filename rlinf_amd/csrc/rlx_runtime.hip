@@ -33,6 +33,14 @@ int num_cu() {
 
 extern "C" int rlx_version(void) { return RLX_VERSION; }
 
+extern "C" int rlx_dev_variants(void) {
+#ifdef RLX_DEV_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" const char* rlx_last_error(void) { return rlx::g_err; }
 
 extern "C" int rlx_abi_struct_sizes(size_t* sizes, int n) {

@@ -922,6 +922,7 @@ extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_siz
     }
     // development: RLX_ZPLANE_SINGLE_PASS=1 selects the one-launch encoder (same bytes; measured SLOWER, see its comment); read per
     // call so that the tests can switch it
+#ifdef RLX_DEV_VARIANTS
     const char* sp_env = getenv("RLX_ZPLANE_SINGLE_PASS");
     const bool single_pass = sp_env != nullptr && atoi(sp_env) != 0;
     if (single_pass && nb > 0) {
@@ -932,11 +933,16 @@ extern "C" int rlx_zplane_compress(const void* in, int64_t n_elems, int elem_siz
         RLX_LAUNCH_CHECK();
         return RLX_OK;
     }
+#endif
     if (nb > 0) {
         {  // measure can walk its pieces grid-stride with at most `cap` workgroups (development: RLX_ZPLANE_MEASURE_GRID; 0 = one
            // workgroup per piece).  Measured (profiles/r03_zplane_codec_v4_kernels.txt): byte streams 52.6 -> 48.4 us with 2048,
            // 4-byte elements 57.1 -> 59.0 us -- the launch is NOT bound by the workgroup start rate; byte streams keep the walk.
+#ifdef RLX_DEV_VARIANTS
             const char* ge = getenv("RLX_ZPLANE_MEASURE_GRID");
+#else
+            const char* ge = nullptr;
+#endif
             const long long cap = ge != nullptr ? atoll(ge) : (elem_size == 1 ? 2048 : 0), pieces = elem_size == 1 ? (long long)grid1 : nb;
             const unsigned gm = (unsigned)(cap > 0 ? std::min(cap, pieces) : pieces);
             switch (elem_size) {

@@ -827,9 +827,9 @@ def mlp_pack_tiles(params: torch.Tensor, layout: MlpLayout, tiles: Optional[torc
     """Fragment-tile weight image the fused launches stream (rebuild after every change of ``params``); f32 or bf16."""
     lib = _lib.load()
     dev = _dev(params)
-    n = lib.rlx_mlp_tiles_bytes(byref(layout)) // 4
     dt = torch.bfloat16 if bf16 else torch.float32
-    if tiles is None or tiles.dtype != dt:
+    n = lib.rlx_mlp_tiles_bytes_for(byref(layout), 1 if bf16 else 0) // (2 if bf16 else 4)  # the f32 image is opaque (include/rlx.h)
+    if tiles is None or tiles.dtype != dt or tiles.numel() != n:
         tiles = torch.empty((n,), dtype=dt, device=dev)
     fn = lib.rlx_mlp_pack_tiles_bf16 if bf16 else lib.rlx_mlp_pack_tiles
     with torch.cuda.device(dev):

@@ -24,6 +24,19 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip_gpu)
 
 
+def dev_variants_build() -> bool:
+    """True when the loaded librlx_hip was compiled with -DRLX_DEV_VARIANTS (RLX_LIB_TAG selects such a build): only then do the
+    refuted / experimental kernel variants exist and are the RLX_* variant switches read.  The product build runs the measured-best
+    path only; tests of the variants skip there."""
+    from rlinf_amd import _lib
+    return bool(_lib.load().rlx_dev_variants())
+
+
+def need_dev_variants(what: str):
+    if not dev_variants_build():
+        pytest.skip(f"{what}: compiled into development builds only (-DRLX_DEV_VARIANTS; the product ships the measured-best path)")
+
+
 @pytest.fixture(scope="session")
 def ref():
     from oracle import reference_loader

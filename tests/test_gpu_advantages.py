@@ -223,6 +223,8 @@ def test_gae_handoff_variant_is_bit_identical(T, B, masked):
     bit-identical to the streaming scan and to the CPU loop -- ragged last segments, more / fewer envs than a wave, with and
     without a loss mask and the normalisation behind it.  (Built to test whether the 64-deep vmcnt window bounds the streaming
     scan at the roofline shape; it does not -- profiles/r03_gae_handoff_sweep_*.txt -- the variant stays as a tested alternative.)"""
+    from conftest import need_dev_variants
+    need_dev_variants("gae_scan_handoff")
     ops = _ops()
     r = synth_rollout(seed=7, T=T, B=B, p_done=0.03)
     lm = None

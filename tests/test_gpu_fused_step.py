@@ -320,12 +320,13 @@ def test_optimizer_keeps_tile_image_in_step(bf16):
     ops.clip_adamw_step_(pol.flat.data, g, m, v, pol.group_ranges(3e-3, 1e-3), 1, max_grad_norm=0.5, tile_layout=lay, tiles=tiles)
     assert not torch.equal(before, pol.flat.data)
     fresh = ops.mlp_pack_tiles(pol.flat.data, lay, bf16=bf16)
-    assert tiles.dtype == fresh.dtype and torch.equal(tiles, fresh)
+    bits = lambda t: t.view(torch.int16 if bf16 else torch.int32)  # noqa: E731 -- the f32 image is opaque bytes (bf16 planes): compare bits
+    assert tiles.dtype == fresh.dtype and torch.equal(bits(tiles), bits(fresh))
     # a skipped step (non-finite norm) leaves parameters and tiles alone
     g[0, 7] = float("inf")
     snap = pol.flat.data.clone()
     ops.clip_adamw_step_(pol.flat.data, g, m, v, pol.group_ranges(3e-3, 1e-3), 2, max_grad_norm=0.5, tile_layout=lay, tiles=tiles)
-    assert torch.equal(snap, pol.flat.data) and torch.equal(tiles, fresh)
+    assert torch.equal(snap, pol.flat.data) and torch.equal(bits(tiles), bits(fresh))
 
 
 # ---- bf16 MFMA operands ("PPO bf16", BASELINE.json configs[1]): parity against the oracle under bf16 autocast --------------
@@ -382,7 +383,10 @@ def test_ppo_step_bf16_gradients_vs_autocast_oracle(M, with_mask, launch, monkey
     twice its distance; the critic (smooth Huber loss) is held to a tight bound, tensor by tensor."""
     from rlinf_amd import ops
     from rlinf_amd._lib import PPO_OUT_FLOATS, PPO_OUT_NAMES
-    monkeypatch.setenv("RLX_FUSED_ROWS", "1" if launch == "rows" else "0")  # read at every plan / launch
+    if launch != "cols32":
+        from conftest import need_dev_variants
+        need_dev_variants(f"fused bf16 launch form {launch!r}")
+    monkeypatch.setenv("RLX_FUSED_ROWS", "1" if launch == "rows" else "0")  # read at every plan / launch (development builds)
     monkeypatch.setenv("RLX_FUSED_RT", "4" if launch == "cols64" else "2")
     ora, pol = _bf16_policy(seed=11)
     g = torch.Generator().manual_seed(5)

@@ -471,6 +471,9 @@ def test_gae_seq_lookback_many_rows_and_nan_rows(variant, monkeypatch):
     a decoupled look-back for the carry (thousands of workgroups in flight, neighbours racing) -- against the sequential
     oracle; a NaN row must come back NaN, and come back (the look-back never waits on a payload's value, only on its flag)."""
     from oracle import ppo_oracle as PO
+    if variant != "0":
+        from conftest import need_dev_variants
+        need_dev_variants(f"gae_seq variant {variant}")
     monkeypatch.setenv("RLX_GAESEQ_VARIANT", variant)
     bsz, seq = 1500, 6144 + 7
     g = torch.Generator().manual_seed(9)

@@ -214,6 +214,9 @@ def test_zplane_codec_large_streams(dtype, n, single_pass, monkeypatch):
     import numpy as np
 
     from oracle import zplane_oracle as Z
+    if single_pass == "1":
+        from conftest import need_dev_variants
+        need_dev_variants("the single-pass zplane encoder")
     monkeypatch.setenv("RLX_ZPLANE_SINGLE_PASS", single_pass)  # "1": the one-launch encoder with the decoupled look-back (kept selectable)
     g = torch.Generator().manual_seed(n)
     es = torch.empty((), dtype=dtype).element_size()

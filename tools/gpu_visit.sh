@@ -101,7 +101,7 @@ for STEP in "$@"; do
       done; rm -rf gpurun_out/prof_dw ;;
     bench_prof)
       rm -rf gpurun_out/prof_bench
-      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-variants --no-token-tier > gpurun_out/${TAG}_bench_prof.log 2>&1
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-variants --no-token-tier --no-extras --no-roofline > gpurun_out/${TAG}_bench_prof.log 2>&1
       echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_prof.log | cut -c1-200; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_bench)" > gpurun_out/${TAG}_bench_kernels.txt 2>&1; head -14 gpurun_out/${TAG}_bench_kernels.txt; rm -rf gpurun_out/prof_bench ;;
     r5_tests)
       timeout 900 python -m pytest tests/test_end_to_end.py tests/test_distributed.py tests/test_gpu_token_path.py -q -m gpu -k "value_free or one_rank_drives or categorical" > gpurun_out/${TAG}_r5_tests.log 2>&1
@@ -119,6 +119,45 @@ for STEP in "$@"; do
       done; rm -rf gpurun_out/prof_ov ;;
     exchange_self)
       timeout 300 python bench.py --exchange self > gpurun_out/${TAG}_exchange_self.json 2> gpurun_out/${TAG}_exchange_self.err; echo "rc=$?"; cat gpurun_out/${TAG}_exchange_self.json | cut -c1-1500; tail -3 gpurun_out/${TAG}_exchange_self.err ;;
+    f32_tests)
+      timeout 1200 python -m pytest tests/test_gpu_fused_step.py tests/test_policy.py tests/test_end_to_end_bench_config.py tests/test_end_to_end.py -q -m gpu -x > gpurun_out/${TAG}_f32_tests.log 2>&1
+      echo "rc=$?"; tail -40 gpurun_out/${TAG}_f32_tests.log | cut -c1-300 ;;
+    bench_f32_prof)
+      rm -rf gpurun_out/prof_f32
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_f32 -o bench -- python bench.py --precision 32 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_bench_f32_prof.log 2>&1
+      echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_f32_prof.log | cut -c1-200; python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_f32)" > gpurun_out/${TAG}_bench_kernels_f32.txt 2>&1; head -14 gpurun_out/${TAG}_bench_kernels_f32.txt; rm -rf gpurun_out/prof_f32
+      timeout 300 python bench.py --precision 32 --steps 50 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_bench_f32.json 2>gpurun_out/${TAG}_bench_f32.err; echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_f32.json | cut -c1-250 ;;
+    f32_pd_sweep)
+      for PD in ${F32_PDS:-2 3 1}; do
+        rm -rf gpurun_out/prof_f32
+        RLX_F32X_PD=$PD timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_f32 -o bench -- python bench.py --precision 32 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_f32_pd.log 2>&1
+        echo "PD=$PD rc=$? $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_f32)" rlx | grep "f32x\|grad_reduce\|clip_adamw" | awk '{printf "%s %s | ", substr($0,1,40), $(NF-7)}')"
+        RLX_F32X_PD=$PD timeout 300 python bench.py --precision 32 --steps 40 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   bench ms', d['ms_per_step'])"
+      done; rm -rf gpurun_out/prof_f32 ;;
+    f32_rt_ab)
+      for RTV in ${F32_RTS:-4 2 4 2}; do
+        rm -rf gpurun_out/prof_f32
+        RLX_F32X_RT=$RTV timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_f32 -o bench -- python bench.py --precision 32 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_f32_rt.log 2>&1
+        echo "RT=$RTV rc=$? $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_f32)" rlx | grep "f32x\|grad_reduce\|clip_adamw" | awk '{printf "%s %s | ", substr($0,1,40), $(NF-7)}')"
+        RLX_F32X_RT=$RTV timeout 300 python bench.py --precision 32 --steps 40 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   bench ms', d['ms_per_step'])"
+      done; rm -rf gpurun_out/prof_f32 ;;
+    f32_quick_tests)
+      timeout 900 python -m pytest tests/test_gpu_fused_step.py tests/test_end_to_end_bench_config.py -q -m gpu -x -k "not bf16" > gpurun_out/${TAG}_f32_quick_tests.log 2>&1
+      echo "rc=$?"; tail -15 gpurun_out/${TAG}_f32_quick_tests.log | cut -c1-300 ;;
+    f32_stamps)
+      for RTV in ${F32_RTS:-4 2}; do
+        echo "--- RLX_F32X_RT=$RTV"; RLX_F32X_RT=$RTV timeout 200 python tools/phase_times.py 8192 2>&1 | grep -A1 "ppo_step_fused M" | tail -4
+      done ;;
+    f32_lib_ab)
+      for LT in ${F32_LIBS:-a b c main a b c main}; do
+        export RLX_LIB_TAG=$LT; [ $LT = main ] && unset RLX_LIB_TAG
+        rm -rf gpurun_out/prof_f32
+        RLX_F32X_RT=${F32_RT:-2} timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_f32 -o bench -- python bench.py --precision 32 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_f32_lib.log 2>&1
+        echo "lib=$LT rc=$? $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_f32)" rlx | grep "f32x\|grad_reduce\|clip_adamw" | awk '{printf "%s %s | ", substr($0,1,34), $(NF-7)}')"
+      done; unset RLX_LIB_TAG; rm -rf gpurun_out/prof_f32 ;;
+    dev_variant_tests)
+      RLX_LIB_TAG=dev timeout 1200 python -m pytest tests/test_gpu_fused_step.py tests/test_gpu_advantages.py tests/test_gpu_token_path.py tests/test_gpu_weight_patch.py -q -m gpu -k "bf16_gradients or handoff or lookback or zplane_codec_large or variants_vs_oracle" > gpurun_out/${TAG}_dev_variant_tests.log 2>&1
+      echo "rc=$?"; tail -6 gpurun_out/${TAG}_dev_variant_tests.log | cut -c1-300 ;;
     *) echo "unknown step $STEP" ;;
   esac
 done

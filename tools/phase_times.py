@@ -27,8 +27,13 @@ for _ in range(3):
     ops.ppo_step(pol.flat.data, lay, lp, mb, grads, row, ws, grad_out=1.0)
 torch.cuda.synchronize()
 raw.rlx_dev_set_timing_buffer(buf.data_ptr())
-names = ["start", "states+head staged", "gemm L1", "epi1+flush", "gemm L2", "epi2+flush", "gemm L3", "epi3", "head+loss+reduce",
-         "head grads", "dz3+flush", "bwd gemm W3 + epi + flush", "bwd gemm W2 + epi + flush", "end"]
+if os.environ.get("RLX_F32_EXACT_MFMA", "0") in ("", "0"):  # the default f32 launches: ppo_step_f32x.hip, block (0, 1)
+    names = ["start", "inputs staged + states tiles", "gemm L1", "epi1 (tanh, split, slab + images)", "gemm L2", "epi2", "gemm L3", "epi3",
+             "head (mfma)", "loss pass a", "loss pass b", "loss pass c + metric sums", "head grads", "dz3 (mfma f32) + emit", "bwd gemm W3",
+             "emit dz2", "bwd gemm W2", "emit dz1", "stores drained"]
+else:
+    names = ["start", "states+head staged", "gemm L1", "epi1+flush", "gemm L2", "epi2+flush", "gemm L3", "epi3", "head+loss+reduce",
+             "head grads", "dz3+flush", "bwd gemm W3 + epi + flush", "bwd gemm W2 + epi + flush", "end"]
 for rep in range(3):
     buf.zero_()
     ops.ppo_step(pol.flat.data, lay, lp, mb, grads, row, ws, grad_out=1.0)
