@@ -587,6 +587,18 @@ typedef struct rlx_token_rows {
 } rlx_token_rows;
 int rlx_token_logprob_fwd(const void* logits, const int64_t* labels, const rlx_token_rows* rows, float* logprob,
                           float* entropy, float* lse, rlx_stream_t stream);
+/* Packed / variable-length sequences (FSDPActor.forward_batch with runner.enable_dynamic_batch_size or actor.model.
+ * variable_seq_lengths, rlinf/workers/actor/fsdp_actor_worker.py:450-505; unpack_fsdp_logprobs / unpack_sequences,
+ * rlinf/hybrid_engines/fsdp/utils.py:858-1010): `logits` are the rows of ONE packed stream (the valid windows of the batch's
+ * sequences back to back), labels[t] = the stream's token t + 1 (eos behind the last).  The unpack is fused into the stores:
+ *   logprob[lp_dst[t]]  = log softmax(x_t)[labels[t]]     (the reference shifts the packed log-probs right by one and scatters
+ *   entropy[ent_dst[t]] = H(softmax(x_t))                  segment i to columns [idx_start_i, idx_end_i) of row i, then keeps the
+ * last response_len columns: lp_dst / ent_dst are that map, flat indices into the [bsz, response_len] outputs, -1 = dropped --
+ * note the entropy is NOT shifted, as in the reference).  Outputs must be zero-filled by the caller (pad_val 0).  A row with no
+ * destination is not read at all (the prompt tokens: only their last one feeds a response log-prob); lse [n_tokens] is kept per
+ * packed row for rlx_token_logprob_bwd, which takes the gathered per-row gradients. */
+int rlx_token_logprob_fwd_packed(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const int32_t* lp_dst,
+                                 const int32_t* ent_dst, float* logprob, float* entropy, float* lse, rlx_stream_t stream);
 int rlx_token_logprob_bwd(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const float* lse,
                           const float* entropy, const float* d_logprob, const float* d_entropy, void* d_logits,
                           int64_t d_seq_stride, int64_t d_row_stride, rlx_stream_t stream);

@@ -68,6 +68,21 @@ def forward_logprobs(model, m_batch: dict, response_len: int, temperature: float
     return (lp, TO.entropy_from_logits(window)) if calculate_entropy else lp
 
 
+def dynamic_micro_batches(batch: dict, max_tokens_per_mbs: int, balanced_partitions):
+    """split_dynamic_batch_size / get_iterator_dynamic for one rank (rlinf/utils/data_iter_utils.py:505-600,675-700): the number of
+    micro-batches starts at the best-fit-decreasing bin count of the effective lengths and grows until none exceeds the token
+    budget; the sequences are dealt by the Karmarkar-Karp partitions (equal_size False).  -> (micro-batches, partitions)."""
+    lens = batch["attention_mask"].sum(dim=1).tolist()
+    assert max_tokens_per_mbs >= batch["attention_mask"].shape[-1]
+    n = len(TO.bfd_partitions(lens, max_tokens_per_mbs))
+    while True:
+        parts = balanced_partitions(lens, n, False)
+        micro = [{k: torch.stack([v[i] for i in part]) for k, v in batch.items() if isinstance(v, torch.Tensor)} for part in parts]
+        if all(int(m["prompt_lengths"].sum()) + int(m["response_lengths"].sum()) <= max_tokens_per_mbs for m in micro):
+            return micro, parts
+        n += 1
+
+
 def advantages(batch: dict, *, response_len: int, adv_type: str, group_size: int, reinpp_kl_beta: float = 0.0,
                kl_penalty_type: str = "low_var_kl"):
     if batch.get("advantages") is None:
@@ -89,8 +104,10 @@ def iteration(model, opt, batch: dict, *, response_len: int, micro_batch: int, n
               group_size: int = 1, normalize_advantages: bool = True, shuffle: bool = True, temperature: float = 1.0,
               loss_agg: str = "token-mean", clip_ratio_low: float = 0.2, clip_ratio_high: float = 0.2, clip_ratio_c: float = 3.0,
               calculate_entropy: bool = False, entropy_bonus: float = 0.0, kl_beta: float = 0.0, kl_penalty_type: str = "low_var_kl",
-              clip_grad: float = 1.0, reinpp_kl_beta: float = 0.0):
-    """-> (the shuffled global batch incl. advantages, per-optimizer-step metric dicts)."""
+              clip_grad: float = 1.0, reinpp_kl_beta: float = 0.0, pack: dict | None = None):
+    """-> (the shuffled global batch incl. advantages, per-optimizer-step metric dicts).  ``pack``: sequence packing on -- dict(
+    max_prompt_len, encoder_seq_length, max_tokens_per_mbs, variable_seq_lengths, eos_token_id[, dynamic: the balanced-partition
+    function -> runner.enable_dynamic_batch_size])."""
     batch = advantages(dict(batch), response_len=response_len, adv_type=adv_type, group_size=group_size,
                        reinpp_kl_beta=reinpp_kl_beta, kl_penalty_type=kl_penalty_type)
     if normalize_advantages:
@@ -104,27 +121,42 @@ def iteration(model, opt, batch: dict, *, response_len: int, micro_batch: int, n
     for i in range(n_minibatches):
         mini = {k: v[i * per:(i + 1) * per] for k, v in batch.items() if isinstance(v, torch.Tensor)}
         accum = per // micro_batch
-        micro = [{k: v[j * micro_batch:(j + 1) * micro_batch] for k, v in mini.items()} for j in range(accum)]
+        if pack is not None and pack.get("dynamic") is not None:
+            micro, _ = dynamic_micro_batches(mini, pack["max_tokens_per_mbs"], pack["dynamic"])
+        else:
+            micro = [{k: v[j * micro_batch:(j + 1) * micro_batch] for k, v in mini.items()} for j in range(accum)]
         out.append(optimizer_step(model, opt, micro, response_len=response_len, temperature=temperature, loss_agg=loss_agg,
                                   clip_ratio_low=clip_ratio_low, clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c,
                                   calculate_entropy=calculate_entropy, entropy_bonus=entropy_bonus, kl_beta=kl_beta,
-                                  kl_penalty_type=kl_penalty_type, clip_grad=clip_grad))
+                                  kl_penalty_type=kl_penalty_type, clip_grad=clip_grad, pack=pack))
     return batch, out
 
 
 def optimizer_step(model, opt, micro_batches: list, *, response_len: int, temperature: float, loss_agg: str, clip_ratio_low: float,
                    clip_ratio_high: float, clip_ratio_c: float, calculate_entropy: bool, entropy_bonus: float, kl_beta: float,
-                   kl_penalty_type: str, clip_grad: float) -> dict:
+                   kl_penalty_type: str, clip_grad: float, pack: dict | None = None) -> dict:
     """training_step (:659-813) over the micro-batches of one global batch -> its metric dict."""
     accum = len(micro_batches)
     opt.zero_grad()
     rows = []
     for mb in micro_batches:
-        logits = model(input_ids=mb["input_ids"], attention_mask=mb["attention_mask"], position_ids=mb["position_ids"],
-                       use_cache=False).logits
         old = mb.get("recomputed_logprobs")
         if old is None:
             old = mb["rollout_logprobs"]
+        if pack is not None:  # forward_batch's packed branch: log-probs / entropy arrive already unpacked to [bsz, response_len]
+            lp, ent = TO.packed_forward(model, mb, max_prompt_len=pack["max_prompt_len"], encoder_seq_length=pack["encoder_seq_length"],
+                                        response_len=response_len, max_tokens_per_mbs=pack["max_tokens_per_mbs"],
+                                        variable_seq_lengths=pack["variable_seq_lengths"], eos_token_id=pack["eos_token_id"],
+                                        temperature=temperature, calculate_entropy=calculate_entropy)
+            loss, metrics = TO.reasoning_loss_from_logprobs(
+                lp, ent, old, mb["advantages"], mb["response_mask"][:, -response_len:], loss_agg=loss_agg, clip_ratio_low=clip_ratio_low,
+                clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c, entropy_bonus=entropy_bonus,
+                ref_logprobs=mb.get("ref_logprobs"), kl_beta=kl_beta, kl_penalty_type=kl_penalty_type, gradient_accumulation=accum)
+            loss.backward()
+            rows.append(metrics)
+            continue
+        logits = model(input_ids=mb["input_ids"], attention_mask=mb["attention_mask"], position_ids=mb["position_ids"],
+                       use_cache=False).logits
         loss, metrics, _, _ = TO.reasoning_micro_batch_loss(
             logits[:, -response_len - 1:-1, :], mb["input_ids"][:, -response_len:], old, mb["advantages"],
             mb["response_mask"][:, -response_len:], temperature=temperature, loss_agg=loss_agg, clip_ratio_low=clip_ratio_low,

@@ -147,10 +147,24 @@ def reasoning_micro_batch_loss(logits, responses, old_logprobs, advantages, loss
                                gradient_accumulation=1):
     """logits [bsz, resp, V] are the response-aligned slice (``logits[:, -resp-1:-1]``); returns
     (loss_for_backward, metrics) — the loss already divided by ``gradient_accumulation``."""
-    agg = get_loss_agg_func(loss_agg)
     logits = logits / temperature  # the reference divides in place (fsdp_actor_worker.py:478)
     logprobs = logprobs_from_logits(logits, responses)
     entropy = entropy_from_logits(logits) if calculate_entropy else None
+    loss, metrics = reasoning_loss_from_logprobs(
+        logprobs, entropy, old_logprobs, advantages, loss_mask, loss_agg=loss_agg, clip_ratio_low=clip_ratio_low,
+        clip_ratio_high=clip_ratio_high, clip_ratio_c=clip_ratio_c, clip_log_ratio_min=clip_log_ratio_min,
+        clip_log_ratio_max=clip_log_ratio_max, entropy_bonus=entropy_bonus, ref_logprobs=ref_logprobs, kl_beta=kl_beta,
+        kl_penalty_type=kl_penalty_type, gradient_accumulation=gradient_accumulation)
+    return loss, metrics, logprobs, entropy
+
+
+def reasoning_loss_from_logprobs(logprobs, entropy, old_logprobs, advantages, loss_mask, *, loss_agg="token-mean", clip_ratio_low=0.2,
+                                 clip_ratio_high=0.2, clip_ratio_c=3.0, clip_log_ratio_min=None, clip_log_ratio_max=None,
+                                 entropy_bonus=0.0, ref_logprobs=None, kl_beta=0.0, kl_penalty_type="low_var_kl", gradient_accumulation=1):
+    """The part of training_step behind forward_batch (:694-781): PPO token loss, entropy bonus, KL penalty, / accumulation.
+    ``entropy`` None = calculate_entropy off."""
+    agg = get_loss_agg_func(loss_agg)
+    calculate_entropy = entropy is not None
     loss, metrics = token_actor_loss(
         logprobs, old_logprobs, advantages, clip_ratio_low, clip_ratio_high, loss_mask=loss_mask,
         clip_ratio_c=clip_ratio_c, loss_agg_func=agg, clip_log_ratio_min=clip_log_ratio_min,
@@ -167,7 +181,7 @@ def reasoning_micro_batch_loss(logits, responses, old_logprobs, advantages, loss
         loss = loss + kl_loss * kl_beta
     metrics.update({"actor/final_loss": loss.detach(), "actor/entropy_loss": entropy_loss.detach(),
                     "actor/kl_loss": kl_loss.detach()})
-    return loss / gradient_accumulation, metrics, logprobs, entropy
+    return loss / gradient_accumulation, metrics
 
 
 # --------------------------------------------------------------------------------------------
@@ -233,6 +247,83 @@ def reinpp_reasoning_advantages(rewards, loss_mask, group_size: int, use_reinpp_
     var = masked_mean((ret - mean).pow(2), mask)
     adv = (ret - mean) * var.clamp(min=1e-8).rsqrt()
     return adv.transpose(0, 1).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# t6b  sequence packing of the reasoning learner   rlinf/hybrid_engines/fsdp/utils.py:812-1022,
+#      FSDPActor.forward_batch's packed branch rlinf/workers/actor/fsdp_actor_worker.py:450-503
+# --------------------------------------------------------------------------------------------
+def prepare_pack(m_batch, max_prompt_len: int):
+    """prepare_pack_fsdp :917-934: the valid window [idx_start, idx_end) of every padded row."""
+    return (max_prompt_len - m_batch["prompt_lengths"]).tolist(), (max_prompt_len + m_batch["response_lengths"]).tolist()
+
+
+def pack_sequences(x, idx_starts, idx_ends, max_seq_len: int, pad_val, pad_to_fixed_len: bool = False):
+    """pack_sequences :812-855: the windows back to back, optionally padded at the end to max_seq_len."""
+    assert sum(idx_ends) - sum(idx_starts) <= max_seq_len
+    parts = [x[i, a:b] for i, (a, b) in enumerate(zip(idx_starts, idx_ends))]
+    if pad_to_fixed_len:
+        pad = max_seq_len - (sum(idx_ends) - sum(idx_starts))
+        if pad > 0:
+            parts.append(torch.full((pad,), pad_val, dtype=x.dtype))
+    return torch.cat(parts)
+
+
+def unpack_sequences(x, idx_starts, idx_ends, max_seq_len: int, pad_val):
+    """unpack_sequences :858-914: packed [1, L] -> [bsz, max_seq_len], segment i at columns [idx_start_i, idx_end_i), pad elsewhere."""
+    rows, cu = [], 0
+    for a, b in zip(idx_starts, idx_ends):
+        seg = x[0, cu:cu + (b - a)]
+        cu += b - a
+        rows.append(torch.cat([torch.full((a,), pad_val, dtype=x.dtype), seg, torch.full((max_seq_len - b,), pad_val, dtype=x.dtype)]))
+    return torch.stack(rows)
+
+
+def unpack_logprobs(logits, packed_ids, idx_starts, idx_ends, max_seq_len_unpack: int, eos_token_id: int):
+    """unpack_fsdp_logprobs :980-1022: targets = the packed ids shifted left (eos behind the last), log-probs of every packed
+    position, shifted RIGHT by one (a zero in front), scattered back to the padded layout with zeros."""
+    responses = torch.cat([packed_ids[:, 1:], torch.full((1, 1), eos_token_id, dtype=packed_ids.dtype)], dim=1)
+    lp = logprobs_from_logits(logits, responses)
+    lp = torch.cat([torch.zeros((1, 1), dtype=logits.dtype), lp[:, :-1]], dim=-1)
+    return unpack_sequences(lp, idx_starts, idx_ends, max_seq_len_unpack, 0)
+
+
+def packed_forward(model, m_batch, *, max_prompt_len: int, encoder_seq_length: int, response_len: int, max_tokens_per_mbs: int,
+                   variable_seq_lengths: bool, eos_token_id: int, temperature: float, calculate_entropy: bool):
+    """forward_batch with packing on (:450-503) -> (logprobs [bsz, max_response_len], entropy [bsz, response_len] | None).  Note
+    what the reference does with the entropy: it is computed per PACKED position and unpacked WITHOUT the one-position shift the
+    log-probs get, then cut to the last response_len columns."""
+    idx_starts, idx_ends = prepare_pack(m_batch, max_prompt_len)
+    ids = pack_sequences(m_batch["input_ids"], idx_starts, idx_ends, max_tokens_per_mbs, eos_token_id, not variable_seq_lengths).unsqueeze(0)
+    pos = pack_sequences(m_batch["position_ids"], idx_starts, idx_ends, max_tokens_per_mbs, 0, not variable_seq_lengths).unsqueeze(0)
+    logits = model(input_ids=ids, attention_mask=None, position_ids=pos, use_cache=False).logits
+    logits = logits / temperature
+    lp = unpack_logprobs(logits, ids, idx_starts, idx_ends, encoder_seq_length, eos_token_id)[:, -(encoder_seq_length - max_prompt_len):]
+    ent = None
+    if calculate_entropy:
+        ent = unpack_sequences(entropy_from_logits(logits), idx_starts, idx_ends, encoder_seq_length, 0)[:, -response_len:]
+    return lp, ent
+
+
+def bfd_partitions(seq_len_list, max_tokens_per_mbs: int):
+    """get_seqlen_BFD_partitions rlinf/utils/data_iter_utils.py:447-503 (best fit decreasing)."""
+    order = sorted(range(len(seq_len_list)), key=lambda i: seq_len_list[i], reverse=True)
+    parts, room = [], []
+    for i in order:
+        n = seq_len_list[i]
+        if n > max_tokens_per_mbs:
+            raise ValueError(f"Sequence length {n} exceeds the threshold {max_tokens_per_mbs}")
+        best, left = -1, float("inf")
+        for g, r in enumerate(room):
+            if r >= n and r - n < left:
+                best, left = g, r - n
+        if best >= 0:
+            parts[best].append(i)
+            room[best] -= n
+        else:
+            parts.append([i])
+            room.append(max_tokens_per_mbs - n)
+    return parts
 
 
 # --------------------------------------------------------------------------------------------

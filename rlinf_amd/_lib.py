@@ -205,6 +205,8 @@ PROTOTYPES = {
     "rlx_decoupled_loss_fwd": (c_int, [c_void_p] * 10 + [c_int64, POINTER(DecoupledLossParams), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),
     "rlx_token_logprob_fwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rlx_token_logprob_fwd_packed": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
     "rlx_token_logprob_bwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_int64, c_void_p]),
     "rlx_token_loss_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -184,15 +184,28 @@ __device__ __forceinline__ long long row_offset(const RowGeom& g, long long i, l
     return (i / g.rows_per_seq) * seq_stride + (i % g.rows_per_seq) * row_stride;
 }
 
-template <typename T, bool ENT, bool SCALE>
+// PACKED (rlx_token_logprob_fwd_packed): the rows are the tokens of a PACKED stream (sequences back to back, no padding) and the
+// results leave in the unpacked [bsz, response_len] layout -- row t's log-prob goes to logprob[lp_dst[t]], its entropy to
+// entropy[ent_dst[t]] (-1: nowhere); a row with no destination at all is not read.  lse stays per packed row (the backward's).
+template <typename T, bool ENT, bool SCALE, bool PACKED = false>
 __global__ __launch_bounds__(NT) void token_logprob_fwd_kernel(const T* __restrict__ logits,
                                                                const int64_t* __restrict__ labels, RowGeom g,
                                                                float* __restrict__ logprob, float* __restrict__ entropy,
-                                                               float* __restrict__ lse_out) {
+                                                               float* __restrict__ lse_out, const int32_t* __restrict__ lp_dst = nullptr,
+                                                               const int32_t* __restrict__ ent_dst = nullptr) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ Stat s_part[NT / RLX_WAVE];
     const int tid = threadIdx.x;
     for (long long row = blockIdx.x; row < g.n_tokens; row += gridDim.x) {
+        long long dl = row, de = row;
+        if constexpr (PACKED) {
+            dl = lp_dst[row];
+            de = ENT ? ent_dst[row] : -1;
+            if (dl < 0 && de < 0) {  // (uniform over the workgroup: nobody reaches this iteration's barrier)
+                if (tid == 0) lse_out[row] = 0.f;
+                continue;
+            }
+        }
         const T* __restrict__ base = logits + row_offset(g, row, g.seq_stride, g.row_stride);
         const int V = g.vocab;
         const int head = min(V, (int)(((16u - (unsigned)((uintptr_t)base & 15u)) & 15u) / sizeof(T)));
@@ -253,9 +266,9 @@ __global__ __launch_bounds__(NT) void token_logprob_fwd_kernel(const T* __restri
                 lp = lab == -100 ? -0.f : __builtin_nanf("");
             }
             if (g.round_outputs) lp = Elem<T>::round(lp);
-            logprob[row] = lp;
+            if (!PACKED || dl >= 0) logprob[dl] = lp;
             lse_out[row] = fmul(a.r + log2s, LN2);
-            if (ENT) entropy[row] = fmul(log2s - a.t / a.s, LN2);
+            if (ENT && (!PACKED || de >= 0)) entropy[de] = fmul(log2s - a.t / a.s, LN2);
         }
         __syncthreads();
     }
@@ -750,12 +763,17 @@ int row_grid(long long n_tokens) { return (int)(n_tokens < (1ll << 30) ? n_token
 
 template <typename T>
 int launch_fwd(const void* logits, const int64_t* labels, const RowGeom& g, float* logprob, float* entropy, float* lse,
-               hipStream_t s) {
+               hipStream_t s, const int32_t* lp_dst = nullptr, const int32_t* ent_dst = nullptr) {
     const T* x = static_cast<const T*>(logits);
     const dim3 grid(row_grid(g.n_tokens)), block(NT);
     const bool scale = g.temp != 1.0f;
-#define RLX_TOK_FWD(ENT, SCALE) \
-    hipLaunchKernelGGL((token_logprob_fwd_kernel<T, ENT, SCALE>), grid, block, 0, s, x, labels, g, logprob, entropy, lse)
+#define RLX_TOK_FWD(ENT, SCALE)                                                                                                   \
+    do {                                                                                                                          \
+        if (lp_dst != nullptr)                                                                                                    \
+            hipLaunchKernelGGL((token_logprob_fwd_kernel<T, ENT, SCALE, true>), grid, block, 0, s, x, labels, g, logprob, entropy, lse, lp_dst, ent_dst); \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((token_logprob_fwd_kernel<T, ENT, SCALE>), grid, block, 0, s, x, labels, g, logprob, entropy, lse, lp_dst, ent_dst);       \
+    } while (0)
     if (entropy) {
         if (scale) RLX_TOK_FWD(true, true); else RLX_TOK_FWD(true, false);
     } else {
@@ -800,6 +818,19 @@ extern "C" int rlx_token_logprob_fwd(const void* logits, const int64_t* labels, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     return rows->dtype == RLX_DTYPE_BF16 ? launch_fwd<__bf16>(logits, labels, g, logprob, entropy, lse, s)
                                          : launch_fwd<float>(logits, labels, g, logprob, entropy, lse, s);
+}
+
+extern "C" int rlx_token_logprob_fwd_packed(const void* logits, const int64_t* labels, const rlx_token_rows* rows,
+                                            const int32_t* lp_dst, const int32_t* ent_dst, float* logprob, float* entropy, float* lse,
+                                            rlx_stream_t stream) {
+    if (int rc = check_rows(rows, "rlx_token_logprob_fwd_packed")) return rc;
+    if (rows->n_tokens == 0) return RLX_OK;
+    RLX_REQUIRE(logits && labels && logprob && lse && lp_dst, "rlx_token_logprob_fwd_packed: NULL argument");
+    RLX_REQUIRE((entropy == nullptr) == (ent_dst == nullptr), "rlx_token_logprob_fwd_packed: entropy and ent_dst go together");
+    const RowGeom g = geom_of(rows);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return rows->dtype == RLX_DTYPE_BF16 ? launch_fwd<__bf16>(logits, labels, g, logprob, entropy, lse, s, lp_dst, ent_dst)
+                                         : launch_fwd<float>(logits, labels, g, logprob, entropy, lse, s, lp_dst, ent_dst);
 }
 
 extern "C" int rlx_token_logprob_bwd(const void* logits, const int64_t* labels, const rlx_token_rows* rows,

@@ -123,6 +123,72 @@ class _TokenLogprobFn(torch.autograd.Function):
         return full, None, None, None, None, None, None
 
 
+class _PackedLogprobFn(torch.autograd.Function):
+    """Packed-stream scoring with the unpack fused into the stores (include/rlx.h, rlx_token_logprob_fwd_packed)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, lp_dst, ent_dst, bsz, response_len, temperature, with_entropy, round_outputs, inplace_grad):
+        dev = _dev(logits, labels, lp_dst)
+        x, rows = _rows_of(logits, temperature, round_outputs)
+        n = rows.n_tokens
+        if labels.dtype != torch.int64 or labels.numel() != n or lp_dst.numel() != n or lp_dst.dtype != torch.int32:
+            raise RlxError("packed scoring needs int64 labels and int32 destination maps with one entry per packed row")
+        lab = labels.contiguous().reshape(-1)
+        logprob = torch.zeros((bsz, response_len), dtype=torch.float32, device=dev)   # pad_val 0 of unpack_sequences
+        entropy = torch.zeros((bsz, response_len), dtype=torch.float32, device=dev) if with_entropy else None
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().rlx_token_logprob_fwd_packed(x.data_ptr(), lab.data_ptr(), byref(rows), lp_dst.data_ptr(),
+                                                                _ptr(ent_dst if with_entropy else None), logprob.data_ptr(),
+                                                                _ptr(entropy), lse.data_ptr(), _stream_ptr(dev)),
+                       "rlx_token_logprob_fwd_packed")
+        ctx.save_for_backward(logits, lab, lse, lp_dst, ent_dst, entropy if with_entropy else lse)
+        ctx.cfg = (float(temperature), bool(with_entropy), bool(inplace_grad))
+        return (logprob, entropy) if with_entropy else (logprob, lse.new_empty(0))
+
+    @staticmethod
+    def backward(ctx, d_logprob, d_entropy):
+        logits, lab, lse, lp_dst, ent_dst, entropy = ctx.saved_tensors
+        temperature, with_entropy, inplace = ctx.cfg
+        n = lse.numel()
+        # per packed row: the upstream gradient of the element it fed (0 where it fed nothing: such rows are written as zeros
+        # without being read by the backward kernel)
+        def gather(d_out, dst):
+            if d_out is None:
+                return torch.zeros(n, dtype=torch.float32, device=lse.device)
+            flat = torch.cat([d_out.reshape(-1).float(), d_out.new_zeros(1, dtype=torch.float32)])  # index -1 -> the appended zero
+            return flat[dst.long()]
+        d_lp = gather(d_logprob, lp_dst)
+        use_ent = with_entropy and d_entropy is not None
+        ent_rows = d_ent = None
+        if use_ent:
+            d_ent = gather(d_entropy, ent_dst)
+            ent_rows = gather(entropy, ent_dst)  # the forward's entropy of row t (what the backward's entropy term needs)
+        dx = token_logprob_bwd(logits, lab.view(logits.shape[:-1]), lse.view(logits.shape[:-1]), None if ent_rows is None else ent_rows.view(logits.shape[:-1]),
+                               d_lp.view(logits.shape[:-1]), None if d_ent is None else d_ent.view(logits.shape[:-1]), temperature,
+                               out=logits if inplace else None)
+        return dx, None, None, None, None, None, None, None, None, None
+
+
+def packed_token_logprobs(logits: torch.Tensor, packed_input_ids: torch.Tensor, idx_starts, idx_ends, *, max_seq_len_unpack: int,
+                          response_len: int, eos_token_id: int, temperature: float = 1.0, with_entropy: bool = False,
+                          round_outputs: bool = False, inplace_grad: bool = False):
+    """``unpack_fsdp_logprobs`` + ``unpack_sequences`` of the entropy + the ``[:, -response_len:]`` slices in one scoring launch
+    (rlinf/hybrid_engines/fsdp/utils.py:980-1022, rlinf/workers/actor/fsdp_actor_worker.py:482-503): ``logits`` [1, L, V] (or [L, V])
+    of a packed stream, ``packed_input_ids`` [1, L] -> differentiable (logprobs [bsz, response_len], entropy or None), zeros where
+    the reference pads."""
+    from .hybrid_engines.fsdp.utils import unpack_index_maps
+    ids = packed_input_ids.reshape(-1)
+    L = ids.numel()
+    if logits.numel() // max(logits.shape[-1], 1) != L:
+        raise RlxError("packed logits and input_ids disagree on the stream length")
+    labels = torch.cat([ids[1:], ids.new_full((1,), int(eos_token_id))]).to(torch.int64)  # token t + 1, eos behind the last (:1000-1009)
+    lp_dst, ent_dst = unpack_index_maps(idx_starts, idx_ends, L, int(max_seq_len_unpack), int(response_len), logits.device)
+    out = _PackedLogprobFn.apply(logits, labels, lp_dst, ent_dst, len(idx_starts), int(response_len), float(temperature),
+                                 bool(with_entropy), bool(round_outputs), bool(inplace_grad))
+    return (out[0], out[1]) if with_entropy else (out[0], None)
+
+
 def token_logprobs(logits: torch.Tensor, labels: torch.Tensor, *, temperature: float = 1.0, with_entropy: bool = False,
                    round_outputs: bool = False, inplace_grad: bool = False, window: Optional[tuple] = None):
     """Differentiable (logprob, entropy or None).  ``inplace_grad`` lets the backward pass overwrite the logits

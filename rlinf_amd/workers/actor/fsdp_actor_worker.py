@@ -63,6 +63,10 @@ class TokenLearnerStep:
     reinpp_kl_beta: float = 0.0
     use_reinpp_baseline: bool = False
     normalize_advantages: bool = False
+    # sequence packing (fsdp_actor_worker.py:157-170,450-505): the lengths the unpack needs
+    max_prompt_length: int = 0
+    encoder_seq_length: int = 0
+    eos_token_id: int = 0
 
     @classmethod
     def from_cfg(cfg_cls, cfg) -> "TokenLearnerStep":
@@ -91,7 +95,10 @@ class TokenLearnerStep:
             adv_type=_get(algo, "adv_type", "grpo"), group_size=int(_get(algo, "group_size", 1)),
             reinpp_kl_beta=float(_get(algo, "reinpp_kl_beta", 0.0)),
             use_reinpp_baseline=bool(_get(algo, "use_reinpp_baseline", False)),
-            normalize_advantages=bool(_get(algo, "normalize_advantages", False)))
+            normalize_advantages=bool(_get(algo, "normalize_advantages", False)),
+            max_prompt_length=int(_get(data, "max_prompt_length")), encoder_seq_length=int(enc),
+            # (the reference asks its tokenizer; a run without one names the id: actor.tokenizer.eos_token_id / actor.eos_token_id)
+            eos_token_id=int(_get(_get(actor, "tokenizer"), "eos_token_id", _get(actor, "eos_token_id", 0)) or 0))
 
     # fsdp_actor_worker.py:941-978
     def compute_advantages_and_returns(self, batch: dict) -> dict:
@@ -143,9 +150,22 @@ class TokenLearnerStep:
         return compute_logprobs_from_logits(window, responses, self.logprob_op_type, temperature=self.temperature,
                                             inplace_grad=self.inplace_grad), None
 
+    # fsdp_actor_worker.py:450-503 (the packed branch): logits of ONE packed stream -> [bsz, response_len] log-probs / entropy
+    def logprobs_and_entropy_packed(self, logits: torch.Tensor, packed_input_ids: torch.Tensor, idx_starts, idx_ends):
+        from ... import token_ops
+        return token_ops.packed_token_logprobs(
+            logits, packed_input_ids, idx_starts, idx_ends, max_seq_len_unpack=self.encoder_seq_length,
+            response_len=self.response_len, eos_token_id=self.eos_token_id, temperature=self.temperature,
+            with_entropy=self.calculate_entropy, round_outputs=(self.logprob_op_type != "flash_attn"),
+            inplace_grad=self.inplace_grad)
+
     # fsdp_actor_worker.py:694-781
-    def __call__(self, logits: torch.Tensor, m_batch: Mapping, gradient_accumulation: int = 1):
-        logprobs, entropy = self.logprobs_and_entropy(logits, m_batch["input_ids"])
+    def __call__(self, logits: torch.Tensor, m_batch: Mapping, gradient_accumulation: int = 1, packed=None):
+        """``packed`` = (packed input_ids [1, L], idx_starts, idx_ends) when ``logits`` are those of a packed stream."""
+        if packed is not None:
+            logprobs, entropy = self.logprobs_and_entropy_packed(logits, *packed)
+        else:
+            logprobs, entropy = self.logprobs_and_entropy(logits, m_batch["input_ids"])
         old_logprobs = m_batch.get("recomputed_logprobs")
         if old_logprobs is None:
             old_logprobs = m_batch["rollout_logprobs"]
@@ -250,7 +270,9 @@ class FSDPActor:
     one write backward (token_ops.hip), the fused token loss, the advantage kernels, the data-parallel gradient mean and
     clip + AdamW on ONE flat f32 parameter buffer (the module's parameters are re-pointed at views of it, its gradients at views of
     a flat gradient buffer: adamw_clip.hip needs no per-tensor launches and the all-reduce is one call).  Sequence packing
-    (``enable_dynamic_batch_size`` / ``variable_seq_lengths``) belongs to the model backend and is refused."""
+    (``runner.enable_dynamic_batch_size`` / ``actor.model.variable_seq_lengths``, :450-505): the micro-batch's valid windows go
+    through the module as one packed stream (hybrid_engines/fsdp/utils.py) and the scoring kernel stores its results through the
+    unpack map (``rlx_token_logprob_fwd_packed``); dynamic batch sizes cut a global batch by a token budget (:393-414)."""
 
     ROLE = "actor"
 
@@ -259,9 +281,12 @@ class FSDPActor:
         self.cfg, self.ctx = cfg, ctx or DistContext()
         self._rank, self._world_size, self.device = self.ctx.rank, self.ctx.world_size, self.ctx.device
         algo, actor, data = _get(cfg, "algorithm"), _get(cfg, "actor"), _get(cfg, "data")
-        if _get(actor, "enable_dynamic_batch_size", False) or _get(actor, "variable_seq_lengths", False):
-            raise NotImplementedError("sequence packing (enable_dynamic_batch_size / variable_seq_lengths) is a model-backend "
-                                      "feature; this learner takes fixed [bsz, seq] batches")
+        # the reference's own keys (fsdp_actor_worker.py:157-170): runner.enable_dynamic_batch_size, runner.max_tokens_per_mbs,
+        # actor.model.variable_seq_lengths.  Either switch sends every micro-batch through the model as ONE packed stream.
+        runner = _get(cfg, "runner")
+        self.enable_dynamic_batch_size = bool(_get(runner, "enable_dynamic_batch_size", False))
+        self.max_tokens_per_mbs = int(_get(runner, "max_tokens_per_mbs", 2048))
+        self.variable_seq_lengths = bool(_get(_get(actor, "model"), "variable_seq_lengths", False))
         self.step = TokenLearnerStep.from_cfg(cfg)
         self.response_len = self.step.response_len
         self.micro_batch_size = int(_get(actor, "micro_batch_size"))
@@ -273,6 +298,7 @@ class FSDPActor:
         self.is_pipeline = bool(_get(actor, "pipeline", _get(_get(cfg, "cluster") or {}, "pipeline", False)))
         if self.is_pipeline:
             assert not self.enable_dp_load_balance, "DP load balance is not supported in pipeline mode."  # :160-163
+            assert not self.enable_dynamic_batch_size, "Dynamic batch size is not supported in pipeline mode."  # :164-166
         self.logprob_forward_micro_batch_size = int(_get(algo, "logprob_forward_micro_batch_size", self.micro_batch_size))
         self.shuffle_rollout = bool(_get(algo, "shuffle_rollout", True))
         self.seed = int(_get(actor, "seed", 1234))
@@ -313,17 +339,50 @@ class FSDPActor:
             self.ref_policy_flat = self.flat.clone()
 
     # ---- forward (fixed-length branch of forward_batch, :434-505) ----------------------------------------------------------
+    @property
+    def packs_sequences(self) -> bool:
+        return self.enable_dynamic_batch_size or self.variable_seq_lengths
+
+    def _model_forward(self, m_batch: Mapping):
+        """-> (logits, packed): the module on the padded [bsz, S] micro-batch, or -- packing on (:450-466) -- on ONE packed stream
+        [1, L] of the rows' valid windows (attention_mask None: the backend derives the boundaries from position_ids), padded to
+        ``max_tokens_per_mbs`` unless ``variable_seq_lengths``; ``packed`` = (packed ids, idx_starts, idx_ends) for the unpack."""
+        if not self.packs_sequences:
+            outputs = self.model(input_ids=m_batch["input_ids"], attention_mask=m_batch["attention_mask"],
+                                 position_ids=m_batch["position_ids"], use_cache=False)
+            return outputs.logits, None
+        from ...hybrid_engines.fsdp.utils import pack_fsdp_input, prepare_pack_fsdp
+        idx_starts, idx_ends = prepare_pack_fsdp(m_batch, self.max_prompt_length)
+        ids, pos, mask = pack_fsdp_input(m_batch["input_ids"], m_batch["position_ids"], idx_starts=idx_starts, idx_ends=idx_ends,
+                                         max_seq_len_pack=self.max_tokens_per_mbs, eos_token_id=self.step.eos_token_id,
+                                         pad_to_fixed_len=not self.variable_seq_lengths)
+        outputs = self.model(input_ids=ids, attention_mask=mask, position_ids=pos, use_cache=False)
+        return outputs.logits, (ids, idx_starts, idx_ends)
+
     def forward_batch(self, m_batch: Mapping, calculate_entropy: bool = False):
-        outputs = self.model(input_ids=m_batch["input_ids"], attention_mask=m_batch["attention_mask"],
-                             position_ids=m_batch["position_ids"], use_cache=False)
+        logits, packed = self._model_forward(m_batch)
         step = self.step
         if calculate_entropy and not step.calculate_entropy:
             step = TokenLearnerStep(**{**step.__dict__, "calculate_entropy": True})
-        logprobs, entropy = step.logprobs_and_entropy(outputs.logits, m_batch["input_ids"])  # temperature fused (:478)
+        if packed is not None:
+            logprobs, entropy = step.logprobs_and_entropy_packed(logits, *packed)
+        else:
+            logprobs, entropy = step.logprobs_and_entropy(logits, m_batch["input_ids"])  # temperature fused (:478)
         return (logprobs, entropy) if calculate_entropy else logprobs
 
     def _split_to_micro_batch(self, batch: Mapping, split_num: int):
-        """get_iterator_k_split without shuffle (:391-414, data_iter_utils.py:199-243): ``split_num`` equal row ranges, views."""
+        """-> (micro-batches, count, dynamic-batch index partitions | None).  get_iterator_k_split without shuffle (:391-414,
+        data_iter_utils.py:199-243): ``split_num`` equal row ranges, views; with ``runner.enable_dynamic_batch_size``:
+        split_dynamic_batch_size -- as many micro-batches as the token budget needs, sequences dealt by length."""
+        if self.enable_dynamic_batch_size:
+            from ...hybrid_engines.fsdp.utils import split_dynamic_batch_size
+            return split_dynamic_batch_size(batch, self.max_tokens_per_mbs, seqlen_balanced_partitions, self.ctx)
+        micro, n = self._k_split(batch, split_num)
+        return micro, n, None
+
+    @staticmethod
+    def _k_split(batch: Mapping, split_num: int):
+        """get_iterator_k_split without shuffle (data_iter_utils.py:199-243): ``split_num`` equal row ranges, views."""
         bsz = next(v for v in batch.values() if isinstance(v, torch.Tensor)).shape[0]
         assert bsz % split_num == 0, "Issue with batch size configuration!"
         per = bsz // split_num
@@ -334,15 +393,21 @@ class FSDPActor:
     def inference_step(self, batch: Mapping, num_sequences: int, compute_ref_logprobs: bool):
         """:509-558 -> (recomputed_logprobs, ref_logprobs | None), both [num_sequences, response_len] on the accelerator (the
         reference moves them to the host for its channel; here the next consumer is a kernel on the same device)."""
-        micro_batches, _ = self._split_to_micro_batch(batch, num_sequences // self.logprob_forward_micro_batch_size)
-        recomputed = torch.cat([self.forward_batch(mb) for mb in micro_batches])
+        micro_batches, _, dbs_indices = self._split_to_micro_batch(batch, num_sequences // self.logprob_forward_micro_batch_size)
+        revert = None
+        if dbs_indices is not None:  # dynamic batch sizes dealt the sequences by length: back to the batch's order (:522-539)
+            from ...hybrid_engines.fsdp.utils import get_reverse_idx
+            indices = sum((list(p) for p in dbs_indices), [])
+            revert = torch.tensor(get_reverse_idx(indices), dtype=torch.long, device=self.device)
+        undo = (lambda t: t[revert]) if revert is not None else (lambda t: t)  # noqa: E731
+        recomputed = undo(torch.cat([self.forward_batch(mb) for mb in micro_batches]))
         ref = None
         if compute_ref_logprobs:
             assert self.ref_policy_flat is not None, "Reference policy state dict is None but compute_ref_logprobs is True"
             live = self.flat.clone()  # cpu_weight_swap (:544-548): run the same module on the reference weights, then restore
             self.flat.copy_(self.ref_policy_flat)
             try:
-                ref = torch.cat([self.forward_batch(mb) for mb in micro_batches])
+                ref = undo(torch.cat([self.forward_batch(mb) for mb in micro_batches]))
             finally:
                 self.flat.copy_(live)
         return recomputed, ref
@@ -406,7 +471,7 @@ class FSDPActor:
             global_batch_size = batch["input_ids"].shape[0]
             assert global_batch_size % self.micro_batch_size == 0, (
                 f"global batch size {global_batch_size} can not divide micro_batch_size {self.micro_batch_size}")
-            micro_batches, cnt = self._split_to_micro_batch(batch, global_batch_size // self.micro_batch_size)
+            micro_batches, cnt, _ = self._split_to_micro_batch(batch, global_batch_size // self.micro_batch_size)
         else:
             cnt = (self.total_batch_size_per_dp // self.n_mini_batches) // self.micro_batch_size
             micro_batches = (next(batch) for _ in range(cnt))
@@ -414,9 +479,8 @@ class FSDPActor:
         self.grad_flat.zero_()  # optimizer.zero_grad(): the parameters' .grad are views of this buffer
         rows = []
         for m_batch in micro_batches:
-            outputs = self.model(input_ids=m_batch["input_ids"], attention_mask=m_batch["attention_mask"],
-                                 position_ids=m_batch["position_ids"], use_cache=False)
-            loss, metrics = self.step(outputs.logits, m_batch, cnt)
+            logits, packed = self._model_forward(m_batch)
+            loss, metrics = self.step(logits, m_batch, cnt, packed=packed)
             loss.backward()
             rows.append(metrics)
         grad_norm, lr_list = self.optimizer_step()
@@ -479,7 +543,7 @@ class FSDPActor:
             perm = torch.randperm(bsz, generator=torch.Generator().manual_seed(self.seed)).to(self.device)
             tensors = {k: (v[perm] if v.shape[:1] == (bsz,) else v) for k, v in tensors.items()}
         global_batch = {**global_batch, **tensors}
-        mini_batches, _ = self._split_to_micro_batch(tensors, self.n_mini_batches)
+        mini_batches, _ = self._k_split(tensors, self.n_mini_batches)
         self.model.train()
         training_metrics_list = [self.training_step(mb) for mb in mini_batches]
         return self.rollout_metrics(global_batch), training_metrics_list

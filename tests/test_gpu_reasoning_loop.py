@@ -15,16 +15,18 @@ DEV = "cuda"
 
 
 def _cfg(*, resp, prompt, micro, n_mini, total, group_size, case):
+    pack = case.get("pack") or {}
     return dict(
-        runner=dict(task_type="reasoning"),
+        runner=dict(task_type="reasoning", enable_dynamic_batch_size=bool(pack.get("dynamic", False)),
+                    max_tokens_per_mbs=pack.get("max_tokens_per_mbs", 2048)),
         algorithm=dict(adv_type=case.get("adv_type", "grpo"), group_size=group_size, n_minibatches=n_mini,
                        normalize_advantages=case.get("normalize", True), shuffle_rollout=True, loss_type="actor",
                        loss_agg_func=case.get("loss_agg", "token-mean"), ratio_clip_eps=0.2, clip_ratio_high=0.28,
                        sampling_params=dict(temperature=case.get("temperature", 1.0)), calculate_entropy=case.get("entropy_bonus", 0) > 0,
                        entropy_bonus=case.get("entropy_bonus", 0.0), kl_beta=case.get("kl_beta", 0.0),
                        kl_penalty_type=case.get("kl", "low_var_kl"), logprob_forward_micro_batch_size=micro),
-        actor=dict(seed=1234, micro_batch_size=micro, global_batch_size=total // n_mini,
-                   model=dict(encoder_seq_length=prompt + resp),
+        actor=dict(seed=1234, micro_batch_size=micro, global_batch_size=total // n_mini, tokenizer=dict(eos_token_id=pack.get("eos_token_id", 0)),
+                   model=dict(encoder_seq_length=prompt + resp, variable_seq_lengths=bool(pack.get("variable_seq_lengths", False))),
                    optim=dict(lr=1e-3, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, weight_decay=0.01, clip_grad=1.0)),
         data=dict(rollout_batch_size=total // group_size, max_prompt_length=prompt))
 
@@ -35,6 +37,11 @@ def _cfg(*, resp, prompt, micro, n_mini, total, group_size, case):
     dict(loss_agg="seq-mean-token-mean", temperature=1.3, kl_beta=0.05, kl="low_var_kl"),
     dict(adv_type="reinpp", normalize=False),
     dict(normalize=False, group_size=2),
+    # sequence packing (the reference's own keys: actor.model.variable_seq_lengths / runner.enable_dynamic_batch_size + max_tokens_per_mbs)
+    dict(pack=dict(variable_seq_lengths=True, max_tokens_per_mbs=160, eos_token_id=3)),
+    dict(pack=dict(variable_seq_lengths=True, max_tokens_per_mbs=160, eos_token_id=3), entropy_bonus=0.01, temperature=0.8),
+    dict(pack=dict(dynamic=True, variable_seq_lengths=False, max_tokens_per_mbs=100, eos_token_id=5), kl_beta=0.05),
+    dict(pack=dict(dynamic=True, variable_seq_lengths=True, max_tokens_per_mbs=60, eos_token_id=5), loss_agg="seq-mean-token-mean"),
 ], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()) or "default")
 def test_run_training_matches_the_oracle_loop(case):
     from rlinf_amd.scheduler import init_distributed
@@ -42,9 +49,16 @@ def test_run_training_matches_the_oracle_loop(case):
     resp, prompt, vocab, dim = 12, 6, 211, 32
     total, micro, n_mini, group = 32, 8, 2, case.get("group_size", 4)
     torch.manual_seed(5)
-    base = TL.TinyCausalLM(vocab, dim, prompt + resp)
+    pack = case.get("pack")
+    base = TL.TinyCausalLM(vocab, dim, max(prompt + resp, (pack or {}).get("max_tokens_per_mbs", 0)))
     batch = TL.synthetic_rollout_batch(7, total, prompt, resp, vocab)
     temp = case.get("temperature", 1.0)
+    opack = None
+    if pack:
+        from rlinf_amd.workers.actor.fsdp_actor_worker import seqlen_balanced_partitions
+        opack = dict(max_prompt_len=prompt, encoder_seq_length=prompt + resp, max_tokens_per_mbs=pack["max_tokens_per_mbs"],
+                     variable_seq_lengths=pack["variable_seq_lengths"], eos_token_id=pack["eos_token_id"],
+                     dynamic=seqlen_balanced_partitions if pack.get("dynamic") else None)  # (pinned to the reference's partitions)
     ctx = init_distributed()
     actor = FSDPActor(_cfg(resp=resp, prompt=prompt, micro=micro, n_mini=n_mini, total=total, group_size=group, case=case), ctx,
                       model=copy.deepcopy(base))
@@ -56,6 +70,8 @@ def test_run_training_matches_the_oracle_loop(case):
         actor.run_inference(dev_batch, compute_ref_logprobs=True)
         with torch.no_grad():
             want = TL.forward_logprobs(base, batch, resp, temp)
+            if pack:  # packed scoring leaves zeros where the reference's unpack pads (the fixed-length branch scores the padding too)
+                want = want * batch["response_mask"][:, -resp:]
         torch.testing.assert_close(dev_batch["recomputed_logprobs"].cpu(), want, rtol=2e-4, atol=2e-5)
         torch.testing.assert_close(dev_batch["ref_logprobs"].cpu(), want, rtol=2e-4, atol=2e-5)
         assert torch.equal(actor.flat, actor.ref_policy_flat)  # the weight swap restored the live weights
@@ -68,7 +84,7 @@ def test_run_training_matches_the_oracle_loop(case):
         adv_type=case.get("adv_type", "grpo"), group_size=group, normalize_advantages=case.get("normalize", True), temperature=temp,
         loss_agg=case.get("loss_agg", "token-mean"), clip_ratio_low=0.2, clip_ratio_high=0.28,
         calculate_entropy=case.get("entropy_bonus", 0) > 0, entropy_bonus=case.get("entropy_bonus", 0.0),
-        kl_beta=case.get("kl_beta", 0.0), kl_penalty_type=case.get("kl", "low_var_kl"), clip_grad=1.0)
+        kl_beta=case.get("kl_beta", 0.0), kl_penalty_type=case.get("kl", "low_var_kl"), clip_grad=1.0, pack=opack)
     rollout_metrics, got_metrics = actor.run_training([dev_batch])
     assert len(got_metrics) == n_mini == len(want_metrics)
     for w, g in zip(want_metrics, got_metrics):

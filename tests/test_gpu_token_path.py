@@ -360,6 +360,60 @@ def test_llm_vocab_properties(dtype):
     assert torch.equal(x2, d)
 
 
+# ---- packed / variable-length sequences: the unpack fused into the scoring kernel's stores ---------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bsz,prompt,resp,vocab,pad,temperature", [(6, 5, 9, 1000, 0, 1.0), (3, 4, 12, 151936, 7, 0.7), (9, 0, 6, 333, 0, 1.3),
+                                                                 (1, 3, 3, 50, 2, 1.0)])
+def test_packed_token_logprobs_vs_oracle(dtype, bsz, prompt, resp, vocab, pad, temperature):
+    """rlx_token_logprob_fwd_packed + the gathered backward against the reference's arithmetic for a packed stream
+    (oracle.token_oracle.unpack_logprobs / unpack_sequences, pinned to unpack_fsdp_logprobs / unpack_sequences of
+    rlinf/hybrid_engines/fsdp/utils.py in tests/test_reference_reasoning_loop.py): log-probs land shifted right by one inside every
+    row's window, the entropy unshifted, zeros where the reference pads, and the gradient w.r.t. the packed logits is the
+    reference's autograd -- zero rows (prompt tokens that feed nothing, the padding of a fixed-length pack) included.  prompt 0: a
+    sequence's first response log-prob comes from the LAST row of the sequence packed in front of it (or is the prepended zero),
+    as the reference has it."""
+    g = torch.Generator().manual_seed(bsz * 1000 + resp)
+    plen = torch.randint(0, prompt + 1, (bsz,), generator=g)
+    rlen = torch.randint(1, resp + 1, (bsz,), generator=g)
+    S = prompt + resp
+    idx_starts, idx_ends = (prompt - plen).tolist(), (prompt + rlen).tolist()
+    L = sum(idx_ends) - sum(idx_starts) + pad
+    ids = torch.randint(0, vocab, (1, L), generator=g)
+    logits = (torch.randn(1, L, vocab, generator=g) * 3).to(dtype)
+    eos = 2
+    # oracle on the same stored logits: f32 arithmetic like the reference -- at the Qwen-size vocabulary in f64 (the f32 sums over
+    # 1.5e5 terms carry ~1e-4 of rounding of their own: test_large_vocab_properties measures it), the kernel must match the f64 value
+    x = (logits.float() / temperature if dtype == torch.float32 else (logits / temperature).float())
+    x = (x.double() if vocab > 10000 else x).requires_grad_(True)
+    want_lp = TO.unpack_logprobs(x, ids, idx_starts, idx_ends, S, eos)[:, -resp:]
+    want_ent = TO.unpack_sequences(TO.entropy_from_logits(x), idx_starts, idx_ends, S, 0)[:, -resp:]
+    d_lp, d_ent = torch.randn(bsz, resp, generator=g), torch.randn(bsz, resp, generator=g) * 0.1
+    (want_lp * d_lp + want_ent * d_ent).sum().backward()
+    want_dx = (x.grad / temperature).float()
+    want_lp, want_ent = want_lp.float(), want_ent.float()
+    dl = logits.to(DEV).requires_grad_(True)
+    lp, ent = token_ops.packed_token_logprobs(dl, ids.to(DEV), idx_starts, idx_ends, max_seq_len_unpack=S, response_len=resp,
+                                              eos_token_id=eos, temperature=temperature, with_entropy=True, round_outputs=False)
+    assert lp.shape == (bsz, resp) and ent.shape == (bsz, resp)
+    close(lp, want_lp, 2e-5, what="packed logprob")
+    close(ent, want_ent, 2e-5, what="packed entropy")
+    assert torch.equal(lp.cpu() == 0, want_lp.detach() == 0) and torch.equal(ent.cpu() == 0, want_ent.detach() == 0)  # the padding pattern
+    (lp * d_lp.to(DEV) + ent * d_ent.to(DEV)).sum().backward()
+    got_dx = dl.grad.float().cpu()
+    if dtype == torch.float32:
+        close(got_dx, want_dx, 1e-6, 2e-5, "packed d_logits")
+    else:
+        ulp = want_dx.abs().amax(dim=-1, keepdim=True) * 2.0 ** -7 + 1e-6
+        assert ((got_dx - want_dx).abs() <= ulp).all()
+    zero_rows = want_dx.abs().amax(dim=-1) == 0
+    assert bool(zero_rows.any()) or prompt == 0
+    assert not got_dx[zero_rows].any()                      # rows that feed nothing: exact zeros (written without being read)
+    # log-probs only (no entropy requested): the same values
+    lp2, none = token_ops.packed_token_logprobs(logits.to(DEV), ids.to(DEV), idx_starts, idx_ends, max_seq_len_unpack=S, response_len=resp,
+                                                eos_token_id=eos, temperature=temperature)
+    assert none is None and torch.equal(lp2, lp.detach())
+
+
 # ---- K2: categorical action sampling ------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("K", [256, 100, 1000])

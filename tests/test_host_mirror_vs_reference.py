@@ -103,3 +103,115 @@ def test_aggregations_and_kl(ref):
     a, b = torch.randn(5, 6, generator=g), torch.randn(5, 6, generator=g) * 30
     for kind in ("kl", "k1", "abs", "mse", "k2", "low_var_kl", "k3"):
         _same(ref.algo_utils.kl_penalty(a, b, kind), AU.kl_penalty(a, b, kind), kind)
+
+
+# ---- sequence packing of the reasoning learner (rlinf/hybrid_engines/fsdp/utils.py:812-1022, rlinf/utils/data_iter_utils.py:447-700) ----
+def _pack_case(seed, bsz, prompt, resp):
+    g = torch.Generator().manual_seed(seed)
+    plen = torch.randint(0, prompt + 1, (bsz,), generator=g)   # (0: a row without a prompt -- its first response log-prob is the
+    rlen = torch.randint(1, resp + 1, (bsz,), generator=g)     #  prepended zero when it opens the packed stream)
+    m_batch = {"prompt_lengths": plen, "response_lengths": rlen}
+    ids = torch.randint(1, 97, (bsz, prompt + resp), generator=g)
+    return m_batch, ids
+
+
+@pytest.mark.parametrize("seed,bsz,prompt,resp", [(0, 5, 4, 6), (1, 1, 3, 3), (2, 8, 7, 9), (3, 4, 0, 5)])
+def test_sequence_packing_host_side_matches_the_reference(ref, seed, bsz, prompt, resp):
+    """The product's pack gathers and -- the part the scoring kernel stores through -- its unpack index maps, against the reference's
+    own pack_sequences / prepare_pack_fsdp / unpack_fsdp_logprobs / unpack_sequences compiled from source: the log-prob of packed
+    row t must land exactly where the reference's shift-right + scatter + [:, -response_len:] puts it, the entropy where its
+    unshifted unpack puts it, and nothing else may be written."""
+    from oracle import reference_loader as R
+    from rlinf_amd.hybrid_engines.fsdp import utils as PK
+    fs = "rlinf/hybrid_engines/fsdp/utils.py"
+    r_pack = R.load_function(fs, "pack_sequences", torch=torch)
+    r_unpack = R.load_function(fs, "unpack_sequences", torch=torch)
+    r_prepare = R.load_function(fs, "prepare_pack_fsdp")
+    r_unpack_lp = R.load_function(fs, "unpack_fsdp_logprobs", torch=torch, unpack_sequences=r_unpack)
+    m_batch, ids = _pack_case(seed, bsz, prompt, resp)
+    S = prompt + resp
+    want_se = r_prepare(m_batch, prompt)
+    got_se = PK.prepare_pack_fsdp(m_batch, prompt)
+    assert want_se == got_se
+    idx_starts, idx_ends = got_se
+    total = sum(idx_ends) - sum(idx_starts)
+    for fixed, budget in ((False, total), (True, total + 5), (True, total)):
+        want = r_pack(ids, idx_starts, idx_ends, budget, 7, fixed)
+        got = PK.pack_sequences(ids, idx_starts, idx_ends, budget, 7, fixed)
+        _same(want, got, f"pack_sequences fixed={fixed}")
+        L = got.numel()
+        # the unpack: give every packed row a recognisable value and push it through the reference's own functions
+        lp_rows = torch.arange(1, L + 1, dtype=torch.float32).unsqueeze(0) * -1.0      # "log-prob computed from row t" = -(t + 1)
+        ent_rows = torch.arange(1, L + 1, dtype=torch.float32).unsqueeze(0) * 0.5
+        want_lp = r_unpack_lp(torch.zeros(1, L, 3), got.unsqueeze(0), idx_starts=idx_starts, idx_ends=idx_ends, max_seq_len_unpack=S,
+                              eos_token_id=7, compute_logprobs_fn=lambda _l, _t: lp_rows)[:, -resp:]
+        want_ent = r_unpack(ent_rows, idx_starts, idx_ends, S, pad_val=0)[:, -resp:]
+        lp_dst, ent_dst = PK.unpack_index_maps(idx_starts, idx_ends, L, S, resp, "cpu")
+        got_lp, got_ent = torch.zeros(bsz * resp), torch.zeros(bsz * resp)
+        keep = lp_dst >= 0
+        got_lp[lp_dst[keep].long()] = lp_rows[0][keep]
+        keep = ent_dst >= 0
+        got_ent[ent_dst[keep].long()] = ent_rows[0][keep]
+        _same(want_lp, got_lp.view(bsz, resp), "log-prob unpack map")
+        _same(want_ent, got_ent.view(bsz, resp), "entropy unpack map")
+        assert lp_dst[lp_dst >= 0].unique().numel() == int((lp_dst >= 0).sum())     # no destination written twice
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dynamic_batch_split_matches_the_reference(ref, seed):
+    """runner.enable_dynamic_batch_size: get_seqlen_BFD_partitions and split_dynamic_batch_size (-> get_iterator_dynamic) of the
+    reference, compiled from source (its two device="cuda" one-element tensors built on the host), against the product's."""
+    import heapq
+    import itertools
+    from collections import UserDict
+
+    import torch.distributed as dist
+
+    from oracle import reference_loader as R
+    from rlinf_amd.hybrid_engines.fsdp import utils as PK
+    from rlinf_amd.workers.actor.fsdp_actor_worker import seqlen_balanced_partitions
+    it_py = "rlinf/utils/data_iter_utils.py"
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29639", rank=0, world_size=1)
+    try:
+        class CpuTorch:
+            def __getattr__(self, name):
+                return getattr(torch, name)
+
+            @staticmethod
+            def tensor(data, device=None, **kw):
+                return torch.tensor(data, **kw)
+
+        kk = R.load_function(it_py, "karmarkar_karp", heapq=heapq)
+        balanced = R.load_function(it_py, "get_seqlen_balanced_partitions", karmarkar_karp=kk)
+        bfd = R.load_function(it_py, "get_seqlen_BFD_partitions")
+        dyn = R.load_function(it_py, "get_iterator_dynamic", torch=CpuTorch(), dist=dist, UserDict=UserDict, itertools=itertools,
+                              get_seqlen_BFD_partitions=bfd, get_seqlen_balanced_partitions=balanced,
+                              roundup_divisible=R.load_function(it_py, "roundup_divisible"), Union=None, Optional=None)
+        split = R.load_function(it_py, "split_dynamic_batch_size", get_iterator_dynamic=dyn)
+        g = torch.Generator().manual_seed(seed)
+        bsz, prompt, resp = 12, 6, 10
+        plen = torch.randint(1, prompt + 1, (bsz,), generator=g)
+        rlen = torch.randint(1, resp + 1, (bsz,), generator=g)
+        pos = torch.arange(prompt + resp).unsqueeze(0)
+        attn = (pos >= (prompt - plen).unsqueeze(1)) & (pos < (prompt + rlen).unsqueeze(1))
+        batch = dict(input_ids=torch.randint(1, 50, (bsz, prompt + resp), generator=g), attention_mask=attn, prompt_lengths=plen,
+                     response_lengths=rlen, tags=[f"s{i}" for i in range(bsz)])
+        budget = int(torch.randint(prompt + resp, 3 * (prompt + resp), (1,), generator=g))
+        lens = attn.sum(dim=1).tolist()
+        assert PK.get_seqlen_bfd_partitions(lens, budget) == bfd(lens, budget)
+        it, _, n_want, parts_want = split(batch=dict(batch), cp_world_size=1, vpp_world_size=1, max_tokens_per_mbs=budget,
+                                          microbatch_group_size_per_vp_stage=1)
+        micro_want = list(it)
+        micro_got, n_got, parts_got = PK.split_dynamic_batch_size(dict(batch), budget, seqlen_balanced_partitions, None)
+        assert n_got == n_want and [list(p) for p in parts_got] == [list(p) for p in parts_want]
+        for w, o in zip(micro_want, micro_got):
+            assert set(w) == set(o)
+            for k in w:
+                _same(w[k], o[k], k)
+        assert PK.get_reverse_idx(sum((list(p) for p in parts_got), [])) == R.load_function(it_py, "get_reverse_idx", copy=__import__("copy"))(
+            sum((list(p) for p in parts_want), []))
+    finally:
+        if started:
+            dist.destroy_process_group()

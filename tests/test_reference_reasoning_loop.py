@@ -39,7 +39,40 @@ def one_rank_group():
         dist.destroy_process_group()
 
 
-def reference_learner(ref, model, *, resp, prompt, micro, n_mini, total, case):
+def _packing_helpers(R):
+    """The reference's own pack / unpack helpers and its dynamic-batch split, compiled from the files where they lie."""
+    import heapq
+    import itertools
+    fs = "rlinf/hybrid_engines/fsdp/utils.py"
+    it_py = "rlinf/utils/data_iter_utils.py"
+    pack_sequences = R.load_function(fs, "pack_sequences", torch=torch)
+    unpack_sequences = R.load_function(fs, "unpack_sequences", torch=torch)
+    helpers = dict(
+        prepare_pack_fsdp=R.load_function(fs, "prepare_pack_fsdp"),
+        pack_fsdp_input=R.load_function(fs, "pack_fsdp_input", pack_sequences=pack_sequences),
+        unpack_fsdp_logprobs=R.load_function(fs, "unpack_fsdp_logprobs", torch=torch, unpack_sequences=unpack_sequences),
+        unpack_sequences=unpack_sequences, pack_sequences=pack_sequences)
+
+    class CpuTorch:  # get_iterator_dynamic builds its two one-element tensors on "cuda": the same integers, on the host
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def tensor(data, device=None, **kw):
+            return torch.tensor(data, **kw)
+
+    kk = R.load_function(it_py, "karmarkar_karp", heapq=heapq)
+    balanced = R.load_function(it_py, "get_seqlen_balanced_partitions", karmarkar_karp=kk)
+    bfd = R.load_function(it_py, "get_seqlen_BFD_partitions")
+    dyn = R.load_function(it_py, "get_iterator_dynamic", torch=CpuTorch(), dist=dist, UserDict=UserDict, itertools=itertools,
+                          get_seqlen_BFD_partitions=bfd, get_seqlen_balanced_partitions=balanced,
+                          roundup_divisible=R.load_function(it_py, "roundup_divisible"), Union=None, Optional=None)
+    helpers["split_dynamic_batch_size"] = R.load_function(it_py, "split_dynamic_batch_size", get_iterator_dynamic=dyn)
+    helpers["balanced"], helpers["bfd"] = balanced, bfd
+    return helpers
+
+
+def reference_learner(ref, model, *, resp, prompt, micro, n_mini, total, case, pack=None):
     from oracle import reference_loader as R
     du = R.load_distributed_utils()
     py = "rlinf/workers/actor/fsdp_actor_worker.py"
@@ -65,10 +98,15 @@ def reference_learner(ref, model, *, resp, prompt, micro, n_mini, total, case):
     alg = Cfg(sampling_params=Cfg(temperature=case.get("temperature", 1.0)), ratio_clip_eps=0.2, clip_ratio_high=0.28, loss_type="actor",
               entropy_bonus=bonus, adv_type=case.get("adv_type", "grpo"), group_size=case.get("group_size", 4),
               normalize_advantages=case.get("normalize", True), n_minibatches=n_mini, shuffle_rollout=True)
-    cfg = Cfg(algorithm=alg, actor=Cfg(seed=1234, global_batch_size=total // n_mini, micro_batch_size=micro), data=Cfg(max_prompt_length=prompt))
+    cfg = Cfg(algorithm=alg, actor=Cfg(seed=1234, global_batch_size=total // n_mini, micro_batch_size=micro,
+                                       model=Cfg(encoder_seq_length=prompt + resp)), data=Cfg(max_prompt_length=prompt))
+    pk = pack or {}
+    helpers = _packing_helpers(R) if pack else {}
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     me = SimpleNamespace(
-        cfg=cfg, model=model, response_len=resp, enable_dynamic_batch_size=False, variable_seq_lengths=False, max_tokens_per_mbs=None,
+        cfg=cfg, model=model, response_len=resp, enable_dynamic_batch_size=bool(pk.get("dynamic", False)),
+        variable_seq_lengths=bool(pk.get("variable_seq_lengths", False)), max_tokens_per_mbs=pk.get("max_tokens_per_mbs"),
+        tokenizer=SimpleNamespace(eos_token_id=pk.get("eos_token_id", 0)),
         amp_context=contextlib.nullcontext(), before_micro_batch=lambda *_a, **_k: contextlib.nullcontext(), task_type="reasoning",
         loss_agg_func=ref.utils.get_loss_agg_func(case.get("loss_agg", "token-mean")), calculate_entropy=bonus > 0,
         calculate_entropy_loss=bonus > 0, kl_beta=beta, kl_penalty_type=case.get("kl", "low_var_kl"), entropy_op_type="torch",
@@ -87,9 +125,12 @@ def reference_learner(ref, model, *, resp, prompt, micro, n_mini, total, case):
     me.optimizer_step = optimizer_step
     me.compute_logprobs = lambda logits, target: ref.utils.compute_logprobs_from_logits(logits, target, op_type="torch")
     forward_batch = R.load_function(py, "FSDPActor.forward_batch", torch=torch, Worker=worker_stub,
-                                    compute_entropy_from_logits=ref.utils.compute_entropy_from_logits)
+                                    compute_entropy_from_logits=ref.utils.compute_entropy_from_logits,
+                                    **{k: helpers[k] for k in ("prepare_pack_fsdp", "pack_fsdp_input", "unpack_fsdp_logprobs",
+                                                               "unpack_sequences") if k in helpers})
     me.forward_batch = lambda m_batch, calculate_entropy=False: forward_batch(me, m_batch, calculate_entropy)
-    split = R.load_function(py, "FSDPActor._split_to_micro_batch", get_iterator_k_split=k_split, Optional=None)
+    split = R.load_function(py, "FSDPActor._split_to_micro_batch", get_iterator_k_split=k_split, Optional=None,
+                            split_dynamic_batch_size=helpers.get("split_dynamic_batch_size"))
     me._split_to_micro_batch = lambda *a, **k: split(*a, **k)
     training_step = R.load_function(
         py, "FSDPActor.training_step", torch=torch, Worker=worker_stub, policy_loss=ref.registry.policy_loss,
@@ -146,6 +187,53 @@ def test_oracle_iteration_matches_the_reference_run_training(ref, one_rank_group
     for w, g in zip(want_metrics, got_metrics):
         for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/clip_fraction", "actor/entropy_loss",
                   "actor/kl_loss", "actor/grad_norm"):
+            assert float(w[k]) == pytest.approx(g[k], rel=1e-6, abs=1e-9), k
+
+
+@pytest.mark.parametrize("pack", [
+    dict(variable_seq_lengths=True, max_tokens_per_mbs=40, eos_token_id=3),                      # the packed stream as long as it is
+    dict(variable_seq_lengths=True, max_tokens_per_mbs=48, eos_token_id=3, entropy_bonus=0.02),  # + the (unshifted) entropy unpack
+    dict(dynamic=True, variable_seq_lengths=False, max_tokens_per_mbs=28, eos_token_id=5),        # micro-batches cut by tokens, the
+    dict(dynamic=True, variable_seq_lengths=False, max_tokens_per_mbs=33, eos_token_id=5, entropy_bonus=0.02),  # stream padded to the budget
+    dict(dynamic=True, variable_seq_lengths=True, max_tokens_per_mbs=21, eos_token_id=5, temperature=0.8, kl_beta=0.05),
+], ids=lambda p: "-".join(f"{k}={v}" for k, v in p.items()))
+def test_oracle_iteration_with_sequence_packing_matches_the_reference(ref, one_rank_group, pack):
+    """Packing on (runner.enable_dynamic_batch_size / actor.model.variable_seq_lengths): the reference's forward_batch packs the
+    micro-batch (prepare_pack_fsdp, pack_fsdp_input), scores the packed stream and unpacks (unpack_fsdp_logprobs, unpack_sequences)
+    -- all compiled from rlinf/hybrid_engines/fsdp/utils.py --, its _split_to_micro_batch cuts global batches by the token budget
+    (split_dynamic_batch_size -> get_iterator_dynamic: best-fit-decreasing count, Karmarkar-Karp partitions).  The oracle loop
+    with the same switches lands on the same parameters bit for bit."""
+    resp, prompt, vocab, dim = 6, 4, 53, 16
+    total, micro, n_mini = 16, 4, 2
+    case = {k: pack[k] for k in ("entropy_bonus", "temperature", "kl_beta") if k in pack}
+    torch.manual_seed(5)
+    base = TL.TinyCausalLM(vocab, dim, max(prompt + resp, pack["max_tokens_per_mbs"]))
+    batch = TL.synthetic_rollout_batch(7, total, prompt, resp, vocab)
+    if case.get("kl_beta", 0) > 0:
+        with torch.no_grad():
+            batch["ref_logprobs"] = TL.forward_logprobs(base, batch, resp, case.get("temperature", 1.0)) + 0.05 * torch.randn(total, resp)
+    m_ref, m_ora = copy.deepcopy(base), copy.deepcopy(base)
+    me = reference_learner(ref, m_ref, resp=resp, prompt=prompt, micro=micro, n_mini=n_mini, total=total, case=case, pack=pack)
+    feed = [{k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}]
+    me.get_batch = lambda _ch: (feed.pop(0), SimpleNamespace(num_sequence=total))
+    _, want_metrics = me.run_training(None)
+    from oracle import reference_loader as R
+    helpers = _packing_helpers(R)
+    opt = torch.optim.AdamW(m_ora.parameters(), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opack = dict(max_prompt_len=prompt, encoder_seq_length=prompt + resp, max_tokens_per_mbs=pack["max_tokens_per_mbs"],
+                 variable_seq_lengths=pack["variable_seq_lengths"], eos_token_id=pack["eos_token_id"],
+                 dynamic=(lambda lens, k, eq: helpers["balanced"](lens, k, eq)) if pack.get("dynamic") else None)
+    _, got_metrics = TL.iteration(
+        m_ora, opt, {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}, response_len=resp,
+        micro_batch=micro, n_minibatches=n_mini, seed=1234, adv_type="grpo", group_size=4, normalize_advantages=True,
+        temperature=case.get("temperature", 1.0), loss_agg="token-mean", clip_ratio_low=0.2, clip_ratio_high=0.28,
+        calculate_entropy=case.get("entropy_bonus", 0) > 0, entropy_bonus=case.get("entropy_bonus", 0.0),
+        kl_beta=case.get("kl_beta", 0.0), kl_penalty_type="low_var_kl", clip_grad=1.0, pack=opack)
+    for (n, a), (_, b) in zip(m_ref.named_parameters(), m_ora.named_parameters()):
+        assert torch.equal(a, b), n
+    assert not torch.equal(next(m_ref.parameters()), next(base.parameters()))
+    for w, g in zip(want_metrics, got_metrics):
+        for k in ("actor/final_loss", "actor/policy_loss", "actor/approx_kl", "actor/entropy_loss", "actor/kl_loss", "actor/grad_norm"):
             assert float(w[k]) == pytest.approx(g[k], rel=1e-6, abs=1e-9), k
 
 

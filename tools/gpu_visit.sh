@@ -158,6 +158,9 @@ for STEP in "$@"; do
     dev_variant_tests)
       RLX_LIB_TAG=dev timeout 1200 python -m pytest tests/test_gpu_fused_step.py tests/test_gpu_advantages.py tests/test_gpu_token_path.py tests/test_gpu_weight_patch.py -q -m gpu -k "bf16_gradients or handoff or lookback or zplane_codec_large or variants_vs_oracle" > gpurun_out/${TAG}_dev_variant_tests.log 2>&1
       echo "rc=$?"; tail -6 gpurun_out/${TAG}_dev_variant_tests.log | cut -c1-300 ;;
+    pack_tests)
+      timeout 900 python -m pytest tests/test_gpu_token_path.py tests/test_gpu_reasoning_loop.py -q -m gpu -k "packed or run_training_matches" > gpurun_out/${TAG}_pack_tests.log 2>&1
+      echo "rc=$?"; tail -25 gpurun_out/${TAG}_pack_tests.log | cut -c1-300 ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
