@@ -480,6 +480,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-token-tier", action="store_true", help="skip the token-tier (LLM logits) roofline rows")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--with-codec", action="store_true", help="add the opt-in patch codec (rlx_zplane) to roofline_widening")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched N > 1 job: kill it after this many seconds")
     ap.add_argument("--pair-timeout", type=float, default=240.0, help="N > 1: seconds one (regime, transport) measurement may take "
                     "before the watchdog prints the line assembled so far and ends the job")
@@ -689,7 +690,7 @@ def main():
             if not args.no_extras:
                 extra("roofline_normalised", lambda: BX.gae_normalised_rows(dev))
             if not args.no_token_tier:
-                extra("roofline_widening", lambda: token_tier_roofline(dev))
+                extra("roofline_widening", lambda: token_tier_roofline(dev, with_codec=args.with_codec))
                 # SURVEY.md 8f-1 end to end: the reasoning learner's iteration (FSDPActor.run_training) around a stand-in LM
                 from tools.bench_reasoning_loop import measure as reasoning_loop
                 extra("reasoning_learner", reasoning_loop)

@@ -173,6 +173,48 @@ struct SmallInputsB {
 // In: the head's two k-half partials in sG / sLp, the tile's loss inputs in sOld / sAct / sAdv / sRet, std | var | log(std) in sStd.
 // Out: d(loss)/d(head output) in sHead (policy: d/d mean; value: d/d value), d/d logstd per row in sLp, the tile's metric partial row in
 // a.loss_part.  Ends with an LDS barrier.  sLacc: [NS][64] doubles of scratch (the dead h3 slab).
+// Lane l's value of lane l + J of the same 16-lane DPP row (0 past the row's end): one VALU slot, where __shfl_down is a
+// ds_bpermute, i.e. a round trip through the LDS pipe.  The loss pass's row sums use it: a row's n_out lanes are neighbours and
+// (n_out dividing 16) never straddle a DPP row.
+template <int J>
+__device__ __forceinline__ float dpp_row_shl(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + J /* row_shl:J */, 0xF, 0xF, true));
+}
+// x[k] + (the row-mates to the right, in lane order): lp_0 + lp_1 + ... + lp_{n-1} with the additions in that order
+template <int J, int OP>
+__device__ __forceinline__ void row_sums(float& lp, float lpe, float& old, float olde, float& px, float pxe, int n_out, bool with_px) {
+    if constexpr (J < OP) {
+        if (J < n_out) {  // (wave-uniform)
+            lp = fadd(lp, dpp_row_shl<J>(lpe));
+            old = fadd(old, dpp_row_shl<J>(olde));
+            if (with_px) px = fadd(px, dpp_row_shl<J>(pxe));
+        }
+        row_sums<J + 1, OP>(lp, lpe, old, olde, px, pxe, n_out, with_px);
+    }
+}
+// Sum of a double over the wave's 64 lanes, result in every lane ... of the LAST row (lane 63 holds the total; callers read it
+// there): DPP row shifts inside the 16-lane rows, two row broadcasts across them.  12 VALU moves + 6 f64 additions instead of
+// six butterfly steps of two ds_bpermute each.
+__device__ __forceinline__ double dpp_wave_sum_to_lane63(double v) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+#define RLX_DPP_ADD(CTRL, ROWMASK)                                                                                          \
+    {                                                                                                                        \
+        const i32x2 b = __builtin_bit_cast(i32x2, v);                                                                         \
+        i32x2 s;                                                                                                             \
+        s[0] = __builtin_amdgcn_update_dpp(0, b[0], CTRL, ROWMASK, 0xF, false);                                               \
+        s[1] = __builtin_amdgcn_update_dpp(0, b[1], CTRL, ROWMASK, 0xF, false);                                               \
+        v += __builtin_bit_cast(double, s);                                                                                   \
+    }
+    RLX_DPP_ADD(0x111, 0xF)  // row_shr:1
+    RLX_DPP_ADD(0x112, 0xF)  // row_shr:2
+    RLX_DPP_ADD(0x114, 0xF)  // row_shr:4
+    RLX_DPP_ADD(0x118, 0xF)  // row_shr:8   -> lane 15 of every row holds the row's sum
+    RLX_DPP_ADD(0x142, 0xA)  // row_bcast:15 into rows 1 and 3: lane 31 = rows 0 + 1, lane 63 = rows 2 + 3
+    RLX_DPP_ADD(0x143, 0xC)  // row_bcast:31 into rows 2 and 3: lane 63 = everything
+#undef RLX_DPP_ADD
+    return v;
+}
+
 struct LossLds {
     float *b4s, *sHead, *sLp, *sG, *sD, *sOld, *sAct, *sAdv, *sRet, *sStd;
     double* sLacc;
@@ -180,6 +222,7 @@ struct LossLds {
 };
 template <int BM, int NW, bool DEC, typename TS>
 __device__ __forceinline__ void fused_loss_pass(const StepArgs& a, int y, int tile, long long m0, const LossLds& L, TS& ts) {
+    constexpr int OP = MAX_OUT;  // bound of the unrolled row sums
     constexpr int NT = 64 * NW;
     const rlx_mlp_layout& lay = a.lay;
     const rlx_ppo_loss_params& p = a.p;
@@ -230,11 +273,7 @@ __device__ __forceinline__ void fused_loss_pass(const StepArgs& a, int y, int ti
                 if (dmode.mode == RLX_PROX_GIVEN && mine) pxe = a.dec.proximal[(size_t)min(m0 + row, M - 1) * lay.act_dim + o];
                 px = fadd(0.f, pxe);
             }
-            for (int j = 1; j < n_out; ++j) {  // wave-uniform trip count; only the leaders' sums are used
-                lp = fadd(lp, __shfl_down(lpe, j, 64));
-                old = fadd(old, __shfl_down(olde, j, 64));
-                if constexpr (DEC) px = fadd(px, __shfl_down(pxe, j, 64));
-            }
+            row_sums<1, OP>(lp, lpe, old, olde, px, pxe, n_out, DEC);  // only the leaders' sums are used
             float gs = 0.f;
             if (valid && o == 0) {
                 const long long e = m0 + row;
@@ -371,8 +410,8 @@ __device__ __forceinline__ void fused_loss_pass(const StepArgs& a, int y, int ti
     {
         double* lp = a.loss_part + ((size_t)tile * 2 + y) * NS;
         for (int k = wave; k < NS; k += NW) {
-            const double v = wave_sum(sLacc[k * 64 + lane]);
-            if (lane == 0) lp[k] = v;
+            const double v = dpp_wave_sum_to_lane63(sLacc[k * 64 + lane]);
+            if (lane == 63) lp[k] = v;
         }
     }
     lds_barrier();

@@ -339,8 +339,9 @@ __device__ __forceinline__ void head_forward_mfma_x(const __bf16* Xb, const floa
 // ---------------------------------------------------------------------------------------------------------------
 // rollout step (RT = 1, NW = 8): the launch of rollout_step_bf16_kernel with three-plane operands
 // ---------------------------------------------------------------------------------------------------------------
+template <int PD>  // weight-ring depth (development: RLX_F32X_ROLLOUT_PD)
 __global__ __launch_bounds__(512) void rollout_step_f32x_kernel(RolloutArgs a) {
-    constexpr int RT = 1, NW = 8, PD = 2;
+    constexpr int RT = 1, NW = 8;
     touch_kernargs<(int)sizeof(RolloutArgs)>();
     typedef GeoX<RT, NW> G;
     extern __shared__ __align__(16) float smem[];
@@ -862,8 +863,22 @@ int pack_tiles_f32x(const float* params, const rlx_mlp_layout& lay, void* tiles,
 
 int launch_rollout_f32x(const RolloutArgs& a, int blocks, hipStream_t st) {
     const size_t lds = GeoX<1, 8>::LDS_BYTES;
-    if (int rc = set_lds_x(rollout_step_f32x_kernel, lds)) return rc;
-    hipLaunchKernelGGL(rollout_step_f32x_kernel, dim3(blocks), dim3(512), lds, st, a);
+#ifdef RLX_DEV_VARIANTS
+    if (dev_variant("RLX_F32X_ROLLOUT_PD", 2) == 4) {
+        if (int rc = set_lds_x(rollout_step_f32x_kernel<4>, lds)) return rc;
+        hipLaunchKernelGGL(rollout_step_f32x_kernel<4>, dim3(blocks), dim3(512), lds, st, a);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
+    if (dev_variant("RLX_F32X_ROLLOUT_PD", 2) == 8) {
+        if (int rc = set_lds_x(rollout_step_f32x_kernel<8>, lds)) return rc;
+        hipLaunchKernelGGL(rollout_step_f32x_kernel<8>, dim3(blocks), dim3(512), lds, st, a);
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
+#endif
+    if (int rc = set_lds_x(rollout_step_f32x_kernel<2>, lds)) return rc;
+    hipLaunchKernelGGL(rollout_step_f32x_kernel<2>, dim3(blocks), dim3(512), lds, st, a);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

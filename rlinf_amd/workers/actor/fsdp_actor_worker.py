@@ -135,7 +135,10 @@ class TokenLearnerStep:
         resp = self.response_len
         responses = input_ids[:, -resp:]
         S = logits.shape[1]
-        if logits.dim() == 3 and S > resp and self.logprob_op_type in ("torch", "flash_attn", "liger_kernel"):
+        # (window mode needs the model's dense [bsz, S, V] output: a transposed / expanded lm_head result goes the sliced way below,
+        #  whose copy the kernels then address -- the strided in-place gradient of window mode has nothing to alias there)
+        if (logits.dim() == 3 and S > resp and logits.is_contiguous()
+                and self.logprob_op_type in ("torch", "flash_attn", "liger_kernel")):
             # logits[:, -resp - 1:-1, :] scored in place; the gradient comes back for the whole [bsz, S, V] tensor from the kernel's
             # own launch + two fills of the rows outside the window, instead of autograd's zeros(logits.shape) + strided copy
             from ... import token_ops

@@ -147,7 +147,7 @@ def gae_roofline(device, iters: int = 30, with_traffic: bool = True):
     return out
 
 
-def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: int = 10):
+def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: int = 10, with_codec: bool = False):
     """SURVEY.md 8f item 1 (the widening after rows a-e): the reasoning learner's logits -> log-prob/entropy kernel and
     its backward at a Qwen-size vocabulary, bf16 logits, timed with HIP events on the launch stream.  Algorithmic bytes:
     forward = tokens * vocab * 2 (one read); backward = twice that (one read + one write)."""
@@ -240,7 +240,11 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
     del masters, packer
     # compressed patch transport (csrc/zplane_codec.hip): the two index streams of a sparse weight patch, 100 MB each.
     # Algorithmic bytes: compress reads the stream twice (measure, pack) and writes the compressed form; decompress reads the
-    # compressed form and writes the stream.
+    # compressed form and writes the stream.  NOT part of the default set since round 5 (bench.py --with-codec): `compression: none`
+    # is the default and the only setting a reference peer can decode; the codec (this build's own "RLXZ" format, 0.35-0.60 of the
+    # HBM peak: its compressor reads its input twice) is an opt-in for homogeneous deployments.
+    if not with_codec:
+        return rows
     try:
         from rlinf_amd import _lib
         from rlinf_amd.ops import _stream_ptr

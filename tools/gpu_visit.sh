@@ -161,6 +161,14 @@ for STEP in "$@"; do
     pack_tests)
       timeout 900 python -m pytest tests/test_gpu_token_path.py tests/test_gpu_reasoning_loop.py -q -m gpu -k "packed or run_training_matches" > gpurun_out/${TAG}_pack_tests.log 2>&1
       echo "rc=$?"; tail -25 gpurun_out/${TAG}_pack_tests.log | cut -c1-300 ;;
+    f32_rollout_pd)
+      for PD in 2 4 8 2 4 8; do
+        rm -rf gpurun_out/prof_f32
+        RLX_LIB_TAG=dev RLX_F32X_ROLLOUT_PD=$PD timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_f32 -o bench -- python bench.py --precision 32 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_f32_pd.log 2>&1
+        echo "rollout PD=$PD rc=$? $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_f32)" rlx | grep "rollout_step" | awk '{printf "%s %s | ", substr($0,1,40), $(NF-7)}')"
+      done; rm -rf gpurun_out/prof_f32 ;;
+    bf16_stamps)
+      RLX_LIB_TAG=dev timeout 200 python tools/phase_times.py 8192 2>&1 | grep -A1 "ppo_step_fused_bf16\|rollout_step B" | tail -12 ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
