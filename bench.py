@@ -445,11 +445,13 @@ WORKLOAD = ("ManiSkill PickCube-shaped PPO: 1024 envs x 128 steps, obs 42, act 8
             "gamma 0.8 / lambda 0.9, 8 epochs x 16 minibatches of 8192 (128 optimizer steps), {prec}, synthetic env tensors "
             "resident in HBM")
 PREC_TEXT = {"bf16": "bf16 MFMA operands / f32 accumulate, master weights, losses, GAE, AdamW",
-             # precision "32": the fused launch on the exact f32 MFMA; the weight-gradient launch forms its f32 products from 3 x bf16
-             # splits (6 of the 9 partial products: what is dropped lies below the f32 accumulation's own rounding) unless
-             # RLX_F32_EXACT_MFMA=1 selects the exact f32 MFMA there too
-             "32": ("f32: exact-f32 MFMA (fused launch and weight gradients)" if os.environ.get("RLX_F32_EXACT_MFMA", "0") not in ("", "0")
-                    else "f32: exact-f32 MFMA in the fused launch, f32-accurate 3 x bf16-split MFMA products in the weight-gradient launch")}
+             # precision "32" (the reference YAML's shipped precision): every f32 operand travels as three bf16 planes (hi + mid + lo = x
+             # exactly) and every product is six of the nine plane products on the bf16 matrix pipe with f32 accumulation -- what is
+             # dropped lies below the f32 accumulation's own rounding (csrc/ppo_step_f32x.hip); RLX_F32_EXACT_MFMA=1 selects the
+             # exact-f32-MFMA launches of round 1-4 instead
+             "32": ("f32: exact-f32 MFMA (fused launch and weight gradients; RLX_F32_EXACT_MFMA=1)" if os.environ.get("RLX_F32_EXACT_MFMA", "0") not in ("", "0")
+                    else "f32: f32-accurate products as 3 x bf16 planes (six plane products, f32 accumulate) on the bf16 matrix pipe, in the "
+                         "rollout, fused and weight-gradient launches")}
 
 
 def main():
@@ -460,7 +462,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "32"],
                     help="operand precision of the policy's dense layers: bf16 (BASELINE.json configs[1], f32 accumulate and "
-                         "master weights) or 32 (exact-f32 MFMA)")
+                         "master weights) or 32 (f32-accurate products: three bf16 planes per operand on the bf16 matrix pipe)")
     ap.add_argument("--pipeline", action="store_true", help="runner.use_training_pipeline (statistics normalisation, per-stage "
                     "shuffles; with --rollout-epochs > 1 the learner trains on epoch e while epoch e + 1 rolls out)")
     ap.add_argument("--rollout-epochs", type=int, default=1, help="split the 128-step horizon into this many rollout epochs")
