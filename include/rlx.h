@@ -32,8 +32,8 @@
 extern "C" {
 #endif
 
-#define RLX_VERSION 110 /* 0.1.1: bumped whenever an argument struct or a signature changes (round 5: rlx_categorical_sample's
-                           * softmax_lanes; round 4's struct growth had left it at 100) */
+#define RLX_VERSION 111 /* 0.1.1: bumped whenever an argument struct or a signature changes (round 5: rlx_categorical_sample's
+                           * softmax_lanes, rlx_adamw_params.sync_words; round 4's struct growth had left it at 100) */
 
 typedef void* rlx_stream_t; /* hipStream_t */
 
@@ -297,8 +297,15 @@ typedef struct rlx_adamw_params {
     int32_t deferred_stride;
     int32_t deferred_groups;
     int64_t deferred_range[2][2]; /* [begin, end) x 2; an empty range is begin == end */
+    /* optional (round 5): rlx_adamw_sync_words(n) 64-bit words of device memory, 16-byte aligned, ZEROED ONCE by the caller and
+     * from then on owned by the library (one buffer per parameter set; calls that share it must be stream-ordered).  With it
+     * rlx_clip_adamw_step runs slab sum + norm + clip + AdamW as ONE launch -- the blocks exchange their norm partials through
+     * these words instead of through a launch boundary -- whenever the plan allows it (n % 4 == 0, 16-byte aligned buffers,
+     * one float4 per thread, every workgroup resident); same arithmetic, bit-identical results.  NULL: two launches. */
+    uint64_t* sync_words;
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);
+size_t rlx_adamw_sync_words(int64_t n);
 /* out[i] = sum_k grads[k][i] (k < slabs): collapse the split-K slabs before a data-parallel all-reduce. */
 int rlx_sum_slabs(const float* grads, int64_t n, int slabs, float* out, rlx_stream_t stream);
 /* ... with p->deferred_scale applied group by group (only the deferred_* fields of p are read). */

@@ -75,7 +75,7 @@ class AdamwParams(Structure):
         ("grad_scale", c_float), ("groups", AdamwGroup * ADAMW_MAX_GROUPS),
         ("tile_layout", POINTER(MlpLayout)), ("tiles", c_void_p), ("tiles_bf16", c_int32),
         ("deferred_scale", c_void_p), ("deferred_stride", c_int32), ("deferred_groups", c_int32),
-        ("deferred_range", (c_int64 * 2) * 2),
+        ("deferred_range", (c_int64 * 2) * 2), ("sync_words", c_void_p),
     ]
 
 
@@ -186,6 +186,7 @@ PROTOTYPES = {
                                   c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "rlx_gather_rows": (c_int, [POINTER(GatherField), c_int, c_void_p, c_int64, c_void_p]),
     "rlx_adamw_workspace_bytes": (c_size_t, [c_int64]),
+    "rlx_adamw_sync_words": (c_size_t, [c_int64]),
     "rlx_sum_slabs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "rlx_sum_slabs_deferred": (c_int, [c_void_p, c_int64, c_int, c_void_p, POINTER(AdamwParams), c_void_p]),
     "rlx_clip_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamwParams), c_void_p,
@@ -278,7 +279,7 @@ def load() -> ctypes.CDLL:
             raise RlxError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rlx_version() < 110:
+    if lib.rlx_version() < 111:
         raise RlxError("librlx_hip.so is older than this Python package; rebuild it")
     mirrors = (GaeParams, PpoLossParams, GatherField, AdamwGroup, AdamwParams, MlpLayout, ValueJob, RolloutStep, PpoStepArgs,
                DecoupledLossParams, TokenRows, TokenLossParams, CopySegment)  # the order rlx_abi_struct_sizes documents

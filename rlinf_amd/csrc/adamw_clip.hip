@@ -300,6 +300,54 @@ __device__ __forceinline__ void adamw_elem(float& pi, float& gi, float& mi, floa
     pi = pi - sc.step_size[grp] * (mi / denom);               // addcdiv_(m, denom, -step_size)
 }
 
+// Clip + AdamW on one float4 of parameters per lane (element 4 * (iw + lane) .. + 3), the clipped gradient written back, and the
+// fragment-tile weight image kept in step.  `iw` is wave-uniform: the tile scatter shuffles across lanes.
+__device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          long long iw, int lane, bool live, float4 p4, float4 g4, float4 m4, float4 v4, float coef,
+                                          bool skip, const AdamScalars& sc, const rlx_adamw_params& a, const rlx_mlp_layout& lay,
+                                          float* __restrict__ tiles) {
+    const long long i = iw + lane;
+    float pe[4] = {p4.x, p4.y, p4.z, p4.w}, ge[4] = {g4.x, g4.y, g4.z, g4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w},
+          ve[4] = {v4.x, v4.y, v4.z, v4.w};
+    int grp[4] = {-1, -1, -1, -1};
+    if (live) {
+        const int g_first = group_of(a, 4 * i), g_last = group_of(a, 4 * i + 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            grp[e] = (e == 0) ? g_first : (e == 3 ? g_last : (g_first == g_last ? g_first : group_of(a, 4 * i + e)));
+            adamw_elem(pe[e], ge[e], me[e], ve[e], coef, grp[e], skip, sc);
+        }
+        reinterpret_cast<float4*>(g)[i] = float4{ge[0], ge[1], ge[2], ge[3]};
+        if (!skip && (grp[0] >= 0 || grp[1] >= 0 || grp[2] >= 0 || grp[3] >= 0)) {
+            reinterpret_cast<float4*>(p)[i] = float4{pe[0], pe[1], pe[2], pe[3]};
+            reinterpret_cast<float4*>(m)[i] = float4{me[0], me[1], me[2], me[3]};
+            reinterpret_cast<float4*>(v)[i] = float4{ve[0], ve[1], ve[2], ve[3]};
+        }
+    }
+    if (tiles != nullptr) {
+        // The scatter wants CONSECUTIVE parameters in consecutive lanes (a weight row's 64 neighbours land in a handful of
+        // full tile lines); a lane that scatters its own four values writes 4 bytes of every 16 per instruction instead --
+        // measured on the f32 image: AdamW 12 -> 16.5 us and the next fused launch 102 -> 120 us behind the partial-line
+        // writes.  So the wave transposes: instruction e covers elements 4 * iw + 64 e .. + 63, lane L takes component L % 4
+        // of lane 16 e + L / 4.
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int srcl = 16 * e + (lane >> 2), c = lane & 3;
+            const float v0 = __shfl(pe[0], srcl, 64), v1 = __shfl(pe[1], srcl, 64), v2 = __shfl(pe[2], srcl, 64),
+                        v3 = __shfl(pe[3], srcl, 64);
+            const int q0 = __shfl(grp[0], srcl, 64), q1 = __shfl(grp[1], srcl, 64), q2 = __shfl(grp[2], srcl, 64),
+                      q3 = __shfl(grp[3], srcl, 64);
+            const float val = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
+            const int gq = c == 0 ? q0 : (c == 1 ? q1 : (c == 2 ? q2 : q3));
+            if (skip || gq < 0) continue;
+            const long long idx = 4 * iw + 64 * e + lane;
+            if (a.tiles_bf16 == 1) tile_scatter<1>(lay, tiles, idx, val);
+            else if (a.tiles_bf16 == 2) tile_scatter<2>(lay, tiles, idx, val);
+            else tile_scatter<0>(lay, tiles, idx, val);
+        }
+    }
+}
+
 // One float4 of parameters per thread (p, g, m, v: four 16-byte loads in flight per lane); the (<= 1024) norm partials are
 // re-reduced by every block (a device-wide "last block" finalisation would serialise one memory-side atomic per block).
 // GATHER (the RS + AG all-reduce): the reduced gradient and its norm partials are read from every rank's shard area (peer reads
@@ -395,45 +443,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
             m4 = reinterpret_cast<const float4*>(m)[i];
             v4 = reinterpret_cast<const float4*>(v)[i];
         }
-        float pe[4] = {p4.x, p4.y, p4.z, p4.w}, ge[4] = {g4.x, g4.y, g4.z, g4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w},
-              ve[4] = {v4.x, v4.y, v4.z, v4.w};
-        int grp[4] = {-1, -1, -1, -1};
-        if (live) {
-            const int g_first = group_of(a, 4 * i), g_last = group_of(a, 4 * i + 3);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                grp[e] = (e == 0) ? g_first : (e == 3 ? g_last : (g_first == g_last ? g_first : group_of(a, 4 * i + e)));
-                adamw_elem(pe[e], ge[e], me[e], ve[e], coef, grp[e], skip, s_sc);
-            }
-            reinterpret_cast<float4*>(g)[i] = float4{ge[0], ge[1], ge[2], ge[3]};
-            if (!skip && (grp[0] >= 0 || grp[1] >= 0 || grp[2] >= 0 || grp[3] >= 0)) {
-                reinterpret_cast<float4*>(p)[i] = float4{pe[0], pe[1], pe[2], pe[3]};
-                reinterpret_cast<float4*>(m)[i] = float4{me[0], me[1], me[2], me[3]};
-                reinterpret_cast<float4*>(v)[i] = float4{ve[0], ve[1], ve[2], ve[3]};
-            }
-        }
-        if (tiles != nullptr) {
-            // The scatter wants CONSECUTIVE parameters in consecutive lanes (a weight row's 64 neighbours land in a handful of
-            // full tile lines); a lane that scatters its own four values writes 4 bytes of every 16 per instruction instead --
-            // measured on the f32 image: AdamW 12 -> 16.5 us and the next fused launch 102 -> 120 us behind the partial-line
-            // writes.  So the wave transposes: instruction e covers elements 4 * iw + 64 e .. + 63, lane L takes component L % 4
-            // of lane 16 e + L / 4.
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int srcl = 16 * e + (lane >> 2), c = lane & 3;
-                const float v0 = __shfl(pe[0], srcl, 64), v1 = __shfl(pe[1], srcl, 64), v2 = __shfl(pe[2], srcl, 64),
-                            v3 = __shfl(pe[3], srcl, 64);
-                const int q0 = __shfl(grp[0], srcl, 64), q1 = __shfl(grp[1], srcl, 64), q2 = __shfl(grp[2], srcl, 64),
-                          q3 = __shfl(grp[3], srcl, 64);
-                const float val = c == 0 ? v0 : (c == 1 ? v1 : (c == 2 ? v2 : v3));
-                const int gq = c == 0 ? q0 : (c == 1 ? q1 : (c == 2 ? q2 : q3));
-                if (skip || gq < 0) continue;
-                const long long idx = 4 * iw + 64 * e + lane;
-                if (a.tiles_bf16 == 1) tile_scatter<1>(lay, tiles, idx, val);
-                else if (a.tiles_bf16 == 2) tile_scatter<2>(lay, tiles, idx, val);
-                else tile_scatter<0>(lay, tiles, idx, val);
-            }
-        }
+        update_f4(p, g, m, v, iw, lane, live, p4, g4, m4, v4, coef, skip, s_sc, a, lay, tiles);
     }
     for (long long i = n4 * 4 + i0; i < n; i += stride) {  // scalar tail / unaligned fallback
         const int grp = group_of(a, i);
@@ -450,6 +460,114 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
             else tile_scatter<0>(lay, tiles, i, pi);
         }
     }
+}
+
+// The whole optimizer step as ONE launch (rlx_adamw_params.sync_words): slab sum + norm partial, a device-wide exchange of the
+// partials, clip + AdamW on the gradient still in registers.  What it saves against the two launches above: a launch boundary
+// (drain, cache write-back, ramp), the reduced gradient's trip through memory, and p / m / v are in flight while the norm forms.
+// The exchange is NOT a counter: a block publishes its f64 partial as two 64-bit words (epoch << 32 | half) in its own slot and
+// every block polls all slots -- no same-address atomics (the device-wide-barrier attempt of round 2 serialised 280 of them:
+// 33-49 us), one store and one load round trip to the memory-side cache, and the words carry their own validity (64-bit
+// accesses are single-copy atomic), so no fence orders data against a flag.  The epoch lives in sync[0]; block 0 advances it
+// after ITS poll completed, i.e. after every block has read it.  Needs every block resident (launch_reduce_clip_adamw checks the
+// occupancy once) -- a poll that expires anyway (2 s) reports a non-finite norm and skips.
+constexpr int kSyncSlot0 = 2;  // sync[0] = epoch, sync[1] = reserved, then two words per block
+template <bool DEFER>
+__global__ __launch_bounds__(256) void reduce_clip_adamw_one_launch(ReduceSrc src, float* __restrict__ p, float* __restrict__ g,
+                                                                    float* __restrict__ m, float* __restrict__ v, long long n4,
+                                                                    float scale, rlx_adamw_params a, float* __restrict__ stats,
+                                                                    int* __restrict__ state, rlx_mlp_layout lay,
+                                                                    float* __restrict__ tiles, const int* status,
+                                                                    unsigned long long* sync, DeferredScale dfr) {
+    __shared__ double s_red[4];
+    __shared__ float s_coef;
+    __shared__ int s_skip;
+    __shared__ AdamScalars s_sc;
+    const unsigned e1 = (unsigned)__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // step count: the two-launch form folds the previous call's "applied" flag in its first launch; here every block folds it
+    // for itself (both words are stable until block 0 writes them back, which it does behind the exchange)
+    int st0 = 0, st1 = 0;
+    if (state != nullptr) st0 = state[0], st1 = state[1];
+    const int steps_done = st0 + (st1 != 0 ? 1 : 0);
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n4;
+    float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
+    if (live) {
+        p4 = reinterpret_cast<const float4*>(p)[i];
+        m4 = reinterpret_cast<const float4*>(m)[i];
+        v4 = reinterpret_cast<const float4*>(v)[i];
+        if constexpr (DEFER) g4 = sum_slab_groups_f4(reinterpret_cast<const float4*>(src.base[0]), i, n4, src.nslab, dfr);
+        else g4 = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + i, n4, src.nslab);
+        g4.x *= scale; g4.y *= scale; g4.z *= scale; g4.w *= scale;
+    }
+    double acc[1] = {(double)g4.x * (double)g4.x + (double)g4.y * (double)g4.y + (double)g4.z * (double)g4.z + (double)g4.w * (double)g4.w};
+    if (threadIdx.x == 64) form_scalars(a, state != nullptr ? steps_done + 1 : a.step, &s_sc);
+    block_sum<1>(acc, s_red);
+    if (threadIdx.x == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc[0]), tag = (unsigned long long)e1 << 32;
+        unsigned long long* slot = sync + kSyncSlot0 + 2 * (size_t)blockIdx.x;
+        __hip_atomic_store(slot, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every block's partial, thread t takes blocks t, t + 256, ...; summed in the order the two-launch form uses
+    const int nparts = gridDim.x;
+    double pv[4] = {0.0, 0.0, 0.0, 0.0};
+    bool expired = false;
+    {
+        const long long t0 = wall_clock64();
+        unsigned pending = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((int)threadIdx.x + u * 256 < nparts) pending |= 1u << u;
+        int spins = 0;
+        while (pending != 0) {
+            unsigned long long lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (pending & (1u << u)) {
+                    const unsigned long long* slot = sync + kSyncSlot0 + 2 * (size_t)(threadIdx.x + u * 256);
+                    lo[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[u] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if ((pending & (1u << u)) && (unsigned)(lo[u] >> 32) == e1 && (unsigned)(hi[u] >> 32) == e1) {
+                    pv[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xffffffffull)));
+                    pending &= ~(1u << u);
+                }
+            if (pending != 0 && ++spins > 16) {
+                if (wall_clock64() - t0 > 200000000ll) {  // 2 s at 100 MHz: a block of this launch never became resident
+                    expired = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+    acc[0] = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((int)threadIdx.x + u * 256 < nparts) acc[0] += pv[u];
+    const int any_expired = __syncthreads_or(expired ? 1 : 0);
+    block_sum<1>(acc, s_red);
+    if (threadIdx.x == 0) {
+        const float total_norm = any_expired ? __builtin_nanf("") : (float)sqrt(acc[0]);
+        float coef = 1.f;
+        if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
+        s_coef = coef;
+        s_skip = !isfinite(total_norm) || (status != nullptr && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+        if (blockIdx.x == 0 || any_expired) {
+            stats[0] = total_norm;
+            stats[1] = s_skip ? 0.f : 1.f;
+        }
+        if (blockIdx.x == 0) {
+            if (state != nullptr) state[0] = steps_done, state[1] = s_skip ? 0 : 1;
+            __hip_atomic_store(&sync[0], (unsigned long long)e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    update_f4(p, g, m, v, i - lane, lane, live, p4, g4, m4, v4, s_coef, s_skip != 0, s_sc, a, lay, tiles);
 }
 
 template <bool DEFER>
@@ -499,6 +617,17 @@ rlx_adamw_params tile_format_resolved(const rlx_adamw_params* p, const float* ti
     if (tiles != nullptr && k.tiles_bf16 == 0 && ::rlx::step::f32_split()) k.tiles_bf16 = 2;
     return k;
 }
+// Can `nblk` blocks of the one-launch kernel be resident together on this device?  (Asked once; the answer is for a stream
+// that may use every CU -- a CU-masked stream shrinks it, and the kernel's own bound then reports instead of hanging.)
+bool one_launch_resident(int nblk) {
+    static const int capacity = [] {
+        int a = 0, b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reduce_clip_adamw_one_launch<false>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reduce_clip_adamw_one_launch<true>, 256, 0) != hipSuccess) return 0;
+        return std::min(a, b) * num_cu();
+    }();
+    return nblk <= capacity;
+}
 int check_adamw_args(float* params, float* out, float* exp_avg, float* exp_avg_sq, int64_t n, const rlx_adamw_params* p, float* stats,
                      int32_t* step_state, rlx_mlp_layout& lay, float*& tiles) {
     RLX_REQUIRE(p != nullptr, "rlx_clip_adamw_step: NULL params struct");
@@ -536,8 +665,27 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
     AdamScalars* scalars = reinterpret_cast<AdamScalars*>(static_cast<char*>(workspace) + scalars_offset());
     PeerWait w{};
     if (wait != nullptr) w = *wait;
-    if (p->deferred_scale != nullptr && src.nbase == 1) {  // (with peers the staging launch has applied it already)
+    const bool defer = p->deferred_scale != nullptr && src.nbase == 1;  // (with peers the staging launch has applied it already)
+    if (defer)
         if (int rc = check_deferred(p, src.nslab, n, "rlx_clip_adamw_step")) return rc;
+    // one launch instead of two (see reduce_clip_adamw_one_launch): this rank's own slabs, no peer hand-shake, one float4 per
+    // thread, every block resident
+    if (p->sync_words != nullptr && src.nbase == 1 && src.seq == nullptr && seq_inc == nullptr && w.world <= 1 && !w.fence && n % 4 == 0 &&
+        n / 4 <= (long long)nblk * 256 && one_launch_resident(nblk) &&
+        (reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(src.base[0]) | reinterpret_cast<uintptr_t>(p->sync_words)) % 16 == 0) {
+        const rlx_adamw_params k = tile_format_resolved(p, tiles);
+        unsigned long long* sync = reinterpret_cast<unsigned long long*>(p->sync_words);
+        if (defer)
+            hipLaunchKernelGGL(reduce_clip_adamw_one_launch<true>, dim3(nblk), dim3(256), 0, s, src, params, out, exp_avg, exp_avg_sq,
+                               (long long)(n / 4), p->grad_scale, k, stats, step_state, lay, tiles, status, sync, deferred_of(p));
+        else
+            hipLaunchKernelGGL(reduce_clip_adamw_one_launch<false>, dim3(nblk), dim3(256), 0, s, src, params, out, exp_avg, exp_avg_sq,
+                               (long long)(n / 4), p->grad_scale, k, stats, step_state, lay, tiles, status, sync, DeferredScale{});
+        RLX_LAUNCH_CHECK();
+        return RLX_OK;
+    }
+    if (defer) {
         hipLaunchKernelGGL((grad_reduce_sqnorm<true, true>), dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,
                            step_state, *p, scalars, w, deferred_of(p));
     } else {
@@ -626,6 +774,11 @@ int launch_reduce_only(const ReduceSrc& src, float* out, int64_t n, float scale,
 
 using namespace rlx;
 using namespace rlx::opt;
+
+extern "C" size_t rlx_adamw_sync_words(int64_t n) {
+    (void)n;
+    return (size_t)kSyncSlot0 + 2 * (size_t)kMaxParts;
+}
 
 extern "C" size_t rlx_adamw_workspace_bytes(int64_t n) {
     (void)n;

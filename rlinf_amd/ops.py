@@ -9,6 +9,7 @@ from ctypes import byref
 from typing import Optional
 
 import ctypes
+import os
 
 import torch
 
@@ -610,6 +611,15 @@ def deferred_actor_scale(layout: MlpLayout, rows: torch.Tensor, groups: int) -> 
                 ranges=actor_param_ranges(layout), keep=rows)
 
 
+def adamw_sync_words(n: int, device) -> Optional[torch.Tensor]:
+    """Zeroed ``rlx_adamw_params.sync_words`` buffer for a set of ``n`` parameters: with it the optimizer step is ONE launch
+    (slab sum, norm, clip and AdamW around a device-side exchange of the norm partials) where the plan allows it.  One buffer per
+    parameter set, reused by every step on it.  ``RLX_ADAMW_ONE_LAUNCH=0`` -> None (the two-launch form)."""
+    if os.environ.get("RLX_ADAMW_ONE_LAUNCH", "1") == "0":
+        return None
+    return torch.zeros((int(_lib.load().rlx_adamw_sync_words(int(n))),), dtype=torch.int64, device=device)
+
+
 def _set_deferred(p: AdamwParams, deferred: Optional[dict]):
     if deferred is None:
         return
@@ -624,8 +634,9 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
                      max_grad_norm: float = 0.5, grad_scale: float = 1.0, stats: Optional[torch.Tensor] = None,
                      step_state: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
                      tile_layout: Optional[MlpLayout] = None, tiles: Optional[torch.Tensor] = None,
-                     deferred: Optional[dict] = None):
+                     deferred: Optional[dict] = None, sync: Optional[torch.Tensor] = None):
     """In-place clip_grad_norm_ + AdamW over flat f32 buffers.  groups = [(begin, end, lr), ...].
+    sync: ``adamw_sync_words(n, device)`` -> the one-launch form.
     grads may be [n] or [slabs, n] (split-K slabs, summed first).  Returns stats f32[2] = (norm, applied).
     step_state: device int32[2] keeping the step count on the device (then ``step`` is ignored).
     deferred: see ``deferred_actor_scale`` (scales read on the device while the slabs are summed)."""
@@ -650,6 +661,8 @@ def clip_adamw_step_(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.T
         p.tile_layout, p.tiles = ctypes_pointer(tile_layout), tiles.data_ptr()
         p.tiles_bf16 = int(tiles.dtype == torch.bfloat16)
     _set_deferred(p, deferred)
+    if sync is not None:
+        p.sync_words = sync.data_ptr()
     if stats is None:
         stats = torch.empty((2,), dtype=torch.float32, device=dev)
     ws_bytes = lib.rlx_adamw_workspace_bytes(n)
@@ -1004,7 +1017,7 @@ class PreparedAdamw:
 
     def __init__(self, params, grads, exp_avg, exp_avg_sq, groups, *, betas, eps, weight_decay, max_grad_norm, grad_scale,
                  stats, step_state, workspace, tile_layout=None, tiles=None, xgmi=None, grad_flat=None, deferred=None,
-                 deferred_in_caller=False):
+                 deferred_in_caller=False, sync=None):
         """``xgmi`` (scheduler.xgmi.XgmiAllReduce) + ``grad_flat`` [n]: rlx_xgmi_clip_adamw_step instead -- ``grads`` are this
         rank's slabs, the reduced gradient (scaled by grad_scale = 1 / world_size) lands in grad_flat, then clip + AdamW."""
         self._lib = _lib.load()
@@ -1021,7 +1034,9 @@ class PreparedAdamw:
         self.deferred = deferred  # (a data-parallel caller that collapses the slabs itself -- RCCL path -- applies it there)
         if deferred is not None and deferred_in_caller:
             p.deferred_scale = None  # the caller sums (and scales: sum_slabs(deferred=...)) the slabs in front of its all-reduce
-        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat, deferred)
+        if sync is not None and xgmi is None:  # (the exchange's launches have their own hand-shake)
+            p.sync_words = sync.data_ptr()
+        self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat, deferred, sync)
         if xgmi is not None:
             self._fn, self._name = self._lib.rlx_xgmi_clip_adamw_step, "rlx_xgmi_clip_adamw_step"
             self._argv = (xgmi.handle, params.data_ptr(), grads.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(),

@@ -156,7 +156,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
                     workspace=self.adamw_ws, tile_layout=m.layout if tiles is not None else None, tiles=tiles, xgmi=xg,
                     grad_flat=self.grad_flat if xg is not None else None,
                     deferred=ops.deferred_actor_scale(m.layout, step_rows[:, :PPO_OUT_FLOATS], accum),
-                    deferred_in_caller=multi and xg is None)
+                    deferred_in_caller=multi and xg is None, sync=self.adamw_sync)
                 plan.append((calls, adam))
                 step += 1
         self._ws["aplan_key"], self._ws["aplan"] = pkey, plan

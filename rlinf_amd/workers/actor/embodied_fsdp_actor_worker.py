@@ -102,6 +102,7 @@ class EmbodiedFSDPActor(Worker):
         self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
         self.opt_stats = torch.zeros(2, device=dev)
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        self.adamw_sync = ops.adamw_sync_words(n, dev)  # -> slab sum + norm + clip + AdamW as one launch (None: two)
         self.grad_flat = torch.zeros(n, device=dev)
         self._ws = {}
         # gradient all-reduce transport (world_size > 1): hand-written xGMI peer reads, validated against torch.distributed at
@@ -509,7 +510,7 @@ class EmbodiedFSDPActor(Worker):
         tiles = self.model.tiles() if (self.fused_step and self.optimizer_writes_tiles) else None
         kw = dict(betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay, max_grad_norm=o.clip_grad,
                   stats=self.opt_stats if stats is None else stats, step_state=self.step_state, workspace=self.adamw_ws,
-                  tile_layout=self.model.layout if tiles is not None else None, tiles=tiles)
+                  tile_layout=self.model.layout if tiles is not None else None, tiles=tiles, sync=self.adamw_sync)
         if self._xgmi is not None:  # stage + peer-read reduce + clip + AdamW: three launches, no host round trip
             ops.PreparedAdamw(self.model.flat.data, grads, self.exp_avg, self.exp_avg_sq, groups, grad_scale=1.0 / self._world_size,
                               xgmi=self._xgmi, grad_flat=self.grad_flat, **kw)(torch.cuda.current_stream(self.device).cuda_stream)
@@ -591,7 +592,7 @@ class EmbodiedFSDPActor(Worker):
                         betas=(o.adam_beta1, o.adam_beta2), eps=o.adam_eps, weight_decay=o.weight_decay,
                         max_grad_norm=o.clip_grad, grad_scale=1.0 / self._world_size if multi else 1.0, stats=norms_dev[step],
                         step_state=self.step_state, workspace=self.adamw_ws, tile_layout=m.layout if tiles is not None else None,
-                        tiles=tiles, xgmi=xg, grad_flat=self.grad_flat if xg is not None else None)
+                        tiles=tiles, xgmi=xg, grad_flat=self.grad_flat if xg is not None else None, sync=self.adamw_sync)
                     plan.append((micro_calls, adam))
                     step += 1
             self._ws["prepared_key"], self._ws["prepared_plan"] = pkey, plan

@@ -334,6 +334,7 @@ class FSDPActor:
         self.step_state = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.opt_stats = torch.zeros(2, device=self.device)
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=self.device)
+        self.adamw_sync = ops.adamw_sync_words(n, self.device)  # one-launch optimizer step where the plan allows it (small models)
         self._optim = dict(betas=(float(_get(o, "adam_beta1", 0.9)), float(_get(o, "adam_beta2", 0.999))), eps=float(_get(o, "adam_eps", 1e-8)),
                            weight_decay=float(_get(o, "weight_decay", 1e-2)), max_grad_norm=float(_get(o, "clip_grad", 1.0)))
         self.lr = float(_get(o, "lr", 1e-6))
@@ -463,7 +464,7 @@ class FSDPActor:
             all_reduce_flat_(self.grad_flat, self.ctx)
         ops.clip_adamw_step_(self.flat, self.grad_flat, self.exp_avg, self.exp_avg_sq, [(0, self.flat.numel(), self.lr)], 0,
                              grad_scale=1.0 / self._world_size, stats=self.opt_stats, step_state=self.step_state,
-                             workspace=self.adamw_ws, **self._optim)
+                             workspace=self.adamw_ws, sync=self.adamw_sync, **self._optim)
         self.optimizer_steps += 1
         return self.opt_stats[0], [self.lr]
 

@@ -155,8 +155,9 @@ def _flat_from(pol):
     return names, sizes
 
 
+@pytest.mark.parametrize("one_launch", [False, True])
 @pytest.mark.parametrize("slabs", [1, 3])
-def test_clip_adamw_matches_torch(slabs):
+def test_clip_adamw_matches_torch(slabs, one_launch):
     from rlinf_amd import ops
     torch.manual_seed(0)
     pol = O.OracleMLPPolicy(42, 8, 1)
@@ -174,6 +175,7 @@ def test_clip_adamw_matches_torch(slabs):
     c0, c1 = starts[crit[0]], starts[crit[-1]] + sizes[crit[-1]]
     groups = [(0, c0, 3e-4), (c0, c1, 1e-3), (c1, n, 3e-4)]
     g = torch.Generator().manual_seed(1)
+    sync = ops.adamw_sync_words(n, "cuda") if one_launch else None
     for step in range(1, 5):
         grads = [torch.randn(p.shape, generator=g) * (0.05 if step % 2 else 0.0005) for p in pol.parameters()]
         for p, gr in zip(pol.parameters(), grads):
@@ -187,7 +189,7 @@ def test_clip_adamw_matches_torch(slabs):
             scale = 0.5
         else:
             gdev, scale = gflat.cuda().clone(), 1.0
-        stats = ops.clip_adamw_step_(flat, gdev, m, v, groups, step, max_grad_norm=0.5, grad_scale=scale)
+        stats = ops.clip_adamw_step_(flat, gdev, m, v, groups, step, max_grad_norm=0.5, grad_scale=scale, sync=sync)
         assert float(stats[0]) == pytest.approx(float(gn), rel=1e-5)
         assert float(stats[1]) == 1.0
         want = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
@@ -198,8 +200,74 @@ def test_clip_adamw_matches_torch(slabs):
     before = flat.clone()
     bad = torch.zeros(n, device="cuda")
     bad[5] = float("inf")
-    stats = ops.clip_adamw_step_(flat, bad, m, v, groups, 5, max_grad_norm=0.5)
+    stats = ops.clip_adamw_step_(flat, bad, m, v, groups, 5, max_grad_norm=0.5, sync=sync)
     assert float(stats[1]) == 0.0 and torch.equal(flat, before)
+
+
+@pytest.mark.parametrize("image", ["none", "bf16", "f32"])
+@pytest.mark.parametrize("slabs,deferred", [(1, False), (10, False), (8, True)])
+def test_one_launch_optimizer_step_is_bit_identical(slabs, deferred, image):
+    """rlx_adamw_params.sync_words: slab sum + norm + clip + AdamW as one launch around a device-side exchange of the norm
+    partials.  Same arithmetic as the two launches -- parameters, moments, clipped gradient, weight image, norm and the device
+    step counter compared bit for bit over a run of steps, eager and as a replayed hipGraph (the exchange's epoch advances on
+    the device), with a skipped step (non-finite norm) in the middle."""
+    from rlinf_amd import ops
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    if ops.adamw_sync_words(8, "cuda") is None:
+        pytest.skip("RLX_ADAMW_ONE_LAUNCH=0")
+    torch.manual_seed(3)
+    dt = torch.bfloat16 if image == "bf16" else torch.float32
+    runs = []
+    for one in (False, True):
+        pol = MLPPolicy(42, 8, 1, True, False, compute_dtype=dt).to("cuda")
+        torch.manual_seed(4)
+        with torch.no_grad():
+            pol.flat.copy_(torch.randn_like(pol.flat) * 0.1)
+        n, lay = pol.n_params, pol.layout
+        tiles = pol.tiles() if image != "none" else None
+        m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        state = torch.zeros(2, dtype=torch.int32, device="cuda")
+        stats = torch.zeros(2, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(5)
+        grads = torch.empty(slabs, n, device="cuda")
+        rows = torch.zeros(4, ops._lib.PPO_OUT_FLOATS, device="cuda")
+        rows[:, ops._lib.PPO_ACTOR_GRAD_SCALE] = torch.tensor([0.5, 0.25, 2.0, 1.5], device="cuda")
+        dfr = ops.deferred_actor_scale(lay, rows, 4) if deferred else None
+        ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        step = ops.PreparedAdamw(pol.flat.data, grads, m, v, pol.group_ranges(3e-4, 1e-3), betas=(0.9, 0.999), eps=1e-8,
+                                 weight_decay=0.01, max_grad_norm=0.5, grad_scale=0.5, stats=stats, step_state=state, workspace=ws,
+                                 tile_layout=lay if tiles is not None else None, tiles=tiles, deferred=dfr,
+                                 sync=ops.adamw_sync_words(n, "cuda") if one else None)
+        trace = []
+        stream = torch.cuda.current_stream().cuda_stream
+        for it in range(6):
+            grads.normal_(generator=g).mul_(0.02 if it % 2 else 0.0002)
+            if it == 3:
+                grads[0, 17] = float("nan")
+            step(stream)
+            trace.append((stats.clone(), state.clone(), grads[0].clone()))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            grads.normal_(generator=g).mul_(0.01)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(8):
+                    step(side.cuda_stream)
+            for _ in range(25):
+                graph.replay()
+        side.synchronize()
+        torch.cuda.synchronize()
+        runs.append(dict(p=pol.flat.data.clone(), m=m, v=v, tiles=None if tiles is None else tiles.clone().view(torch.int16 if image == "bf16" else torch.int32),
+                         trace=trace, stats=stats.clone(), state=state.clone()))
+    a, b = runs
+    for k in ("p", "m", "v", "stats", "state"):
+        assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+    if a["tiles"] is not None:
+        assert torch.equal(a["tiles"], b["tiles"])
+    for (s0, t0, g0), (s1, t1, g1) in zip(a["trace"], b["trace"]):
+        assert torch.equal(s0.view(torch.int32), s1.view(torch.int32)) and torch.equal(t0, t1)
+        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32))
+    assert int(b["state"][0]) + int(b["state"][1]) == 5 + 8 * 25  # one eager step skipped (nan), every replayed step applied
 
 
 # ---- decoupled (async) PPO loss: registry name "decoupled_actor_critic" -------------------------------------

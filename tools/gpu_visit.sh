@@ -169,6 +169,25 @@ for STEP in "$@"; do
       done; rm -rf gpurun_out/prof_f32 ;;
     bf16_stamps)
       RLX_LIB_TAG=dev timeout 200 python tools/phase_times.py 8192 2>&1 | grep -A1 "ppo_step_fused_bf16\|rollout_step B" | tail -12 ;;
+    adamw_one_tests)
+      timeout 600 python -m pytest tests/test_gpu_losses.py -x -q -m gpu -k "clip_adamw or one_launch" > gpurun_out/${TAG}_adamw_one_tests.log 2>&1
+      echo "rc=$?"; tail -15 gpurun_out/${TAG}_adamw_one_tests.log | cut -c1-300 ;;
+    adamw_one_ab)
+      for ONE in 0 1 0 1; do
+        rm -rf gpurun_out/prof_one
+        RLX_ADAMW_ONE_LAUNCH=$ONE timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_one -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_one_prof.log 2>&1
+        echo "one_launch=$ONE: $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_one)" rlx | grep "dw_bf16\|grad_reduce\|clip_adamw\|fused_bf16" | awk '{printf "%s %s | ", substr($2,6,26), $(NF-7)}')"
+        RLX_ADAMW_ONE_LAUNCH=$ONE timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   bench', d['ms_per_step'], d.get('ms_per_step_windows'))"
+      done
+      for ONE in 0 1; do
+        RLX_ADAMW_ONE_LAUNCH=$ONE timeout 300 python bench.py --precision 32 --steps 50 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   f32 bench one_launch=$ONE', d['ms_per_step'])"
+      done; rm -rf gpurun_out/prof_one ;;
+    adamw_one_parts)
+      for TAGX in "" x1 x2 x3 ""; do
+        rm -rf gpurun_out/prof_one
+        RLX_LIB_TAG=$TAGX timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_one -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_one_prof.log 2>&1
+        echo "lib=${TAGX:-product}: $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_one)" rlx | grep "dw_bf16\|one_launch\|fused_bf16" | awk '{printf "%s med %s min %s | ", substr($2,6,26), $(NF-7), $(NF-6)}')"
+      done; rm -rf gpurun_out/prof_one ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
