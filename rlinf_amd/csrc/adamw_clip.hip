@@ -302,14 +302,13 @@ __device__ __forceinline__ void adamw_elem(float& pi, float& gi, float& mi, floa
 
 // Clip + AdamW on one float4 of parameters per lane (element 4 * (iw + lane) .. + 3), the clipped gradient written back, and the
 // fragment-tile weight image kept in step.  `iw` is wave-uniform: the tile scatter shuffles across lanes.
-__device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                          long long iw, int lane, bool live, float4 p4, float4 g4, float4 m4, float4 v4, float coef,
-                                          bool skip, const AdamScalars& sc, const rlx_adamw_params& a, const rlx_mlp_layout& lay,
-                                          float* __restrict__ tiles) {
-    const long long i = iw + lane;
-    float pe[4] = {p4.x, p4.y, p4.z, p4.w}, ge[4] = {g4.x, g4.y, g4.z, g4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w},
-          ve[4] = {v4.x, v4.y, v4.z, v4.w};
-    int grp[4] = {-1, -1, -1, -1};
+__device__ __forceinline__ void update_values_f4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, long long i, bool live, float4 p4, float4 g4, float4 m4, float4 v4,
+                                                 float coef, bool skip, const AdamScalars& sc, const rlx_adamw_params& a,
+                                                 float (&pe)[4], int (&grp)[4]) {
+    float ge[4] = {g4.x, g4.y, g4.z, g4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w}, ve[4] = {v4.x, v4.y, v4.z, v4.w};
+    pe[0] = p4.x, pe[1] = p4.y, pe[2] = p4.z, pe[3] = p4.w;
+    grp[0] = grp[1] = grp[2] = grp[3] = -1;
     if (live) {
         const int g_first = group_of(a, 4 * i), g_last = group_of(a, 4 * i + 3);
 #pragma unroll
@@ -324,6 +323,10 @@ __device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restri
             reinterpret_cast<float4*>(v)[i] = float4{ve[0], ve[1], ve[2], ve[3]};
         }
     }
+}
+// The weight image's copy of the float4 a lane just updated (any parameter: the slot search of tile_scatter).
+__device__ __forceinline__ void scatter_tiles_f4(long long iw, int lane, const float (&pe)[4], const int (&grp)[4], bool skip,
+                                                 const rlx_adamw_params& a, const rlx_mlp_layout& lay, float* __restrict__ tiles) {
     if (tiles != nullptr) {
         // The scatter wants CONSECUTIVE parameters in consecutive lanes (a weight row's 64 neighbours land in a handful of
         // full tile lines); a lane that scatters its own four values writes 4 bytes of every 16 per instruction instead --
@@ -346,6 +349,15 @@ __device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restri
             else tile_scatter<0>(lay, tiles, idx, val);
         }
     }
+}
+__device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          long long iw, int lane, bool live, float4 p4, float4 g4, float4 m4, float4 v4, float coef,
+                                          bool skip, const AdamScalars& sc, const rlx_adamw_params& a, const rlx_mlp_layout& lay,
+                                          float* __restrict__ tiles) {
+    float pe[4];
+    int grp[4];
+    update_values_f4(p, g, m, v, iw + lane, live, p4, g4, m4, v4, coef, skip, sc, a, pe, grp);
+    scatter_tiles_f4(iw, lane, pe, grp, skip, a, lay, tiles);
 }
 
 // One float4 of parameters per thread (p, g, m, v: four 16-byte loads in flight per lane); the (<= 1024) norm partials are
@@ -466,39 +478,57 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
 // partials, clip + AdamW on the gradient still in registers.  What it saves against the two launches above: a launch boundary
 // (drain, cache write-back, ramp), the reduced gradient's trip through memory, and p / m / v are in flight while the norm forms.
 // The exchange is NOT a counter: a block publishes its f64 partial as two 64-bit words (epoch << 32 | half) in its own slot and
-// every block polls all slots -- no same-address atomics (the device-wide-barrier attempt of round 2 serialised 280 of them:
-// 33-49 us), one store and one load round trip to the memory-side cache, and the words carry their own validity (64-bit
-// accesses are single-copy atomic), so no fence orders data against a flag.  The epoch lives in sync[0]; block 0 advances it
-// after ITS poll completed, i.e. after every block has read it.  Needs every block resident (launch_reduce_clip_adamw checks the
-// occupancy once) -- a poll that expires anyway (2 s) reports a non-finite norm and skips.
+// every block polls all slots (one per thread) -- no same-address atomics (the device-wide-barrier attempt of round 2 serialised
+// 280 of them: 33-49 us), one store and one load round trip to the memory-side cache (4.0 us measured), and the words carry
+// their own validity (64-bit accesses are single-copy atomic), so no fence orders data against a flag.  The epoch lives in
+// sync[0]; block 0 advances it after ITS poll completed, i.e. after every block has read it.  Needs every block resident
+// (launch_reduce_clip_adamw checks the occupancy once) -- a poll that expires anyway (2 s) reports a non-finite norm and skips.
+//
+// Blocks are 512 threads = 2048 consecutive parameters, dealt out segment by segment (SegPlan): a 256 x 256 hidden matrix of the
+// MLP is a segment of its own, so that a block holds EIGHT WHOLE ROWS of it.  That is what the weight image wants: the forward
+// image takes a lane's four consecutive inputs as one 8-byte store, and the transposed image -- eight consecutive OUTPUTS per
+// 16-byte fragment slot, i.e. one value from each of eight rows -- is assembled through LDS and written as full 16-byte stores.
+// (The generic scatter writes the transposed image as 2-byte stores 16 bytes apart: 3.1 of the first version's 17.0 us.)
 constexpr int kSyncSlot0 = 2;  // sync[0] = epoch, sync[1] = reserved, then two words per block
-template <bool DEFER>
-__global__ __launch_bounds__(256) void reduce_clip_adamw_one_launch(ReduceSrc src, float* __restrict__ p, float* __restrict__ g,
-                                                                    float* __restrict__ m, float* __restrict__ v, long long n4,
-                                                                    float scale, rlx_adamw_params a, float* __restrict__ stats,
-                                                                    int* __restrict__ state, rlx_mlp_layout lay,
-                                                                    float* __restrict__ tiles, const int* status,
-                                                                    unsigned long long* sync, DeferredScale dfr) {
-    __shared__ double s_red[4];
+constexpr int kOneThreads = 512, kMaxSegs = 10;
+struct SegPlan {
+    int nseg, nblk;
+    int blk0[kMaxSegs];                          // first block of segment k
+    long long start4[kMaxSegs], end4[kMaxSegs];  // its float4 range
+    int mat[kMaxSegs];                           // -1, or y * 2 + (l - 1): the segment IS hidden matrix l of network y
+};
+template <bool DEFER, int SB>
+__global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(
+    ReduceSrc src, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n4, float scale,
+    rlx_adamw_params a, float* __restrict__ stats, int* __restrict__ state, rlx_mlp_layout lay, float* __restrict__ tiles,
+    const int* status, unsigned long long* sync, DeferredScale dfr, SegPlan plan) {
+    __shared__ double s_red[kOneThreads / 64];
     __shared__ float s_coef;
     __shared__ int s_skip;
     __shared__ AdamScalars s_sc;
+    __shared__ __bf16 s_t[3][8][256 + 8];  // [plane][row of the block][input]: the transposed image's staging (12.4 KiB)
     const unsigned e1 = (unsigned)__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     // step count: the two-launch form folds the previous call's "applied" flag in its first launch; here every block folds it
     // for itself (both words are stable until block 0 writes them back, which it does behind the exchange)
     int st0 = 0, st1 = 0;
     if (state != nullptr) st0 = state[0], st1 = state[1];
     const int steps_done = st0 + (st1 != 0 ? 1 : 0);
+    // this block's segment (scalar selects over the argument block)
+    long long s4 = plan.start4[0], e4 = plan.end4[0];
+    int b0 = 0, mat = plan.mat[0];
+#pragma unroll
+    for (int k = 1; k < kMaxSegs; ++k)
+        if (k < plan.nseg && (int)blockIdx.x >= plan.blk0[k]) s4 = plan.start4[k], e4 = plan.end4[k], b0 = plan.blk0[k], mat = plan.mat[k];
     const int lane = threadIdx.x & 63;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n4;
+    const long long i = s4 + (long long)((int)blockIdx.x - b0) * kOneThreads + threadIdx.x;
+    const bool live = i < e4;
     float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
     if (live) {
+        if constexpr (DEFER) g4 = sum_slab_groups_f4<SB>(reinterpret_cast<const float4*>(src.base[0]), i, n4, src.nslab, dfr);
+        else g4 = sum_slabs_f4<SB>(reinterpret_cast<const float4*>(src.base[0]) + i, n4, src.nslab);
         p4 = reinterpret_cast<const float4*>(p)[i];
         m4 = reinterpret_cast<const float4*>(m)[i];
         v4 = reinterpret_cast<const float4*>(v)[i];
-        if constexpr (DEFER) g4 = sum_slab_groups_f4(reinterpret_cast<const float4*>(src.base[0]), i, n4, src.nslab, dfr);
-        else g4 = sum_slabs_f4(reinterpret_cast<const float4*>(src.base[0]) + i, n4, src.nslab);
         g4.x *= scale; g4.y *= scale; g4.z *= scale; g4.w *= scale;
     }
     double acc[1] = {(double)g4.x * (double)g4.x + (double)g4.y * (double)g4.y + (double)g4.z * (double)g4.z + (double)g4.w * (double)g4.w};
@@ -510,33 +540,20 @@ __global__ __launch_bounds__(256) void reduce_clip_adamw_one_launch(ReduceSrc sr
         __hip_atomic_store(slot, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // every block's partial, thread t takes blocks t, t + 256, ...; summed in the order the two-launch form uses
-    const int nparts = gridDim.x;
-    double pv[4] = {0.0, 0.0, 0.0, 0.0};
+    // every block's partial: thread t takes block t (gridDim.x <= 512), block_sum adds them in ascending order
+    acc[0] = 0.0;
     bool expired = false;
-    {
+    if (threadIdx.x < gridDim.x) {
+        const unsigned long long* slot = sync + kSyncSlot0 + 2 * (size_t)threadIdx.x;
         const long long t0 = wall_clock64();
-        unsigned pending = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if ((int)threadIdx.x + u * 256 < nparts) pending |= 1u << u;
-        int spins = 0;
-        while (pending != 0) {
-            unsigned long long lo[4], hi[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (pending & (1u << u)) {
-                    const unsigned long long* slot = sync + kSyncSlot0 + 2 * (size_t)(threadIdx.x + u * 256);
-                    lo[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi[u] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if ((pending & (1u << u)) && (unsigned)(lo[u] >> 32) == e1 && (unsigned)(hi[u] >> 32) == e1) {
-                    pv[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xffffffffull)));
-                    pending &= ~(1u << u);
-                }
-            if (pending != 0 && ++spins > 16) {
+        for (int spins = 0;; ++spins) {
+            const unsigned long long lo = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(lo >> 32) == e1 && (unsigned)(hi >> 32) == e1) {
+                acc[0] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                break;
+            }
+            if (spins > 16) {
                 if (wall_clock64() - t0 > 200000000ll) {  // 2 s at 100 MHz: a block of this launch never became resident
                     expired = true;
                     break;
@@ -545,10 +562,6 @@ __global__ __launch_bounds__(256) void reduce_clip_adamw_one_launch(ReduceSrc sr
             }
         }
     }
-    acc[0] = 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-        if ((int)threadIdx.x + u * 256 < nparts) acc[0] += pv[u];
     const int any_expired = __syncthreads_or(expired ? 1 : 0);
     block_sum<1>(acc, s_red);
     if (threadIdx.x == 0) {
@@ -567,7 +580,49 @@ __global__ __launch_bounds__(256) void reduce_clip_adamw_one_launch(ReduceSrc sr
         }
     }
     __syncthreads();
-    update_f4(p, g, m, v, i - lane, lane, live, p4, g4, m4, v4, s_coef, s_skip != 0, s_sc, a, lay, tiles);
+    const bool skip = s_skip != 0;
+    float pe[4];
+    int grp[4];
+    update_values_f4(p, g, m, v, i, live, p4, g4, m4, v4, s_coef, skip, s_sc, a, pe, grp);
+    if (tiles == nullptr) return;
+    if (mat < 0 || a.tiles_bf16 == 0) {  // (block-uniform)
+        scatter_tiles_f4(i - lane, lane, pe, grp, skip, a, lay, tiles);
+        return;
+    }
+    // eight whole rows of hidden matrix l of network y: rows row0 .. row0 + 7, this thread's four inputs in0 .. in0 + 3
+    const int touched = __syncthreads_or((!skip && (grp[0] >= 0 || grp[1] >= 0 || grp[2] >= 0 || grp[3] >= 0)) ? 1 : 0);
+    if (!touched) return;  // no optimizer group holds this matrix (critic warm-up) or the step is skipped: the image stands
+    constexpr size_t per_net = (size_t)256 * 64 + 4 * (size_t)256 * 256, plane = 2 * per_net;
+    const int y = mat >> 1, l = (mat & 1) + 1, nplanes = a.tiles_bf16 == 2 ? 3 : 1;
+    const size_t hid = (size_t)y * per_net + (size_t)256 * 64;
+    const int row0 = ((int)blockIdx.x - b0) * 8, rr = threadIdx.x >> 6, in0 = 4 * lane;
+    __bf16 pl[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)pe[e];
+        const float r1 = fsub(pe[e], (float)h);
+        const __bf16 md = (__bf16)r1;
+        pl[0][e] = h, pl[1][e] = md, pl[2][e] = (__bf16)fsub(r1, (float)md);
+    }
+    __bf16* img = reinterpret_cast<__bf16*>(tiles);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (q < nplanes) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 w = {pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
+            *reinterpret_cast<bf16x4*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l - 1) * 65536, 8, row0 + rr, in0)) = w;  // W_l
+            *reinterpret_cast<bf16x4*>(&s_t[q][rr][in0]) = w;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nplanes * 256; idx += kOneThreads) {
+        const int q = idx >> 8, in = idx & 255;
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        bf16x8 w;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = s_t[q][r][in];
+        *reinterpret_cast<bf16x8*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l + 1) * 65536, 8, in, row0)) = w;  // W_l^T
+    }
 }
 
 template <bool DEFER>
@@ -617,16 +672,53 @@ rlx_adamw_params tile_format_resolved(const rlx_adamw_params* p, const float* ti
     if (tiles != nullptr && k.tiles_bf16 == 0 && ::rlx::step::f32_split()) k.tiles_bf16 = 2;
     return k;
 }
-// Can `nblk` blocks of the one-launch kernel be resident together on this device?  (Asked once; the answer is for a stream
+// How many blocks of the one-launch kernel can be resident together on this device?  (Asked once; the answer is for a stream
 // that may use every CU -- a CU-masked stream shrinks it, and the kernel's own bound then reports instead of hanging.)
-bool one_launch_resident(int nblk) {
+int one_launch_capacity() {
     static const int capacity = [] {
-        int a = 0, b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reduce_clip_adamw_one_launch<false>, 256, 0) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reduce_clip_adamw_one_launch<true>, 256, 0) != hipSuccess) return 0;
-        return std::min(a, b) * num_cu();
+        int best = 1 << 30;
+        const void* kernels[4] = {(const void*)reduce_clip_adamw_one_launch<false, 9>, (const void*)reduce_clip_adamw_one_launch<false, 24>,
+                                  (const void*)reduce_clip_adamw_one_launch<true, 9>, (const void*)reduce_clip_adamw_one_launch<true, 24>};
+        for (const void* k : kernels) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kOneThreads, 0) != hipSuccess) return 0;
+            best = std::min(best, per_cu);
+        }
+        return std::min(best * num_cu(), kOneThreads);  // (and one slot per polling thread)
     }();
-    return nblk <= capacity;
+    return capacity;
+}
+// Blocks of 2048 parameters dealt out segment by segment; with a bf16 / three-plane weight image to keep, every 256 x 256 hidden
+// matrix of the layout is a segment of its own (see the kernel).  nblk == 0: the layout is not one this plan understands.
+SegPlan plan_segments(long long n4, const rlx_mlp_layout* lay, bool image) {
+    SegPlan sp{};
+    struct Mat { long long at4; int id; } mats[4];
+    int nm = 0;
+    if (image && lay != nullptr) {
+        for (int y = 0; y < 2; ++y)
+            for (int l = 1; l <= 2; ++l) {
+                const long long off = lay->off_w[y][l];
+                if (off < 0 || off % 4 != 0 || off / 4 + 16384 > n4) return sp;
+                mats[nm++] = Mat{off / 4, y * 2 + (l - 1)};
+            }
+        std::sort(mats, mats + nm, [](const Mat& u, const Mat& w) { return u.at4 < w.at4; });
+        for (int k = 1; k < nm; ++k)
+            if (mats[k].at4 < mats[k - 1].at4 + 16384) return sp;  // overlapping matrices: not a layout of ours
+    }
+    long long cur = 0;
+    auto push = [&](long long lo, long long hi, int id) {
+        if (hi <= lo) return;
+        sp.blk0[sp.nseg] = sp.nblk, sp.start4[sp.nseg] = lo, sp.end4[sp.nseg] = hi, sp.mat[sp.nseg] = id;
+        sp.nblk += (int)((hi - lo + kOneThreads - 1) / kOneThreads);
+        ++sp.nseg;
+    };
+    for (int k = 0; k < nm; ++k) {
+        push(cur, mats[k].at4, -1);
+        push(mats[k].at4, mats[k].at4 + 16384, mats[k].id);
+        cur = mats[k].at4 + 16384;
+    }
+    push(cur, n4, -1);
+    return sp;
 }
 int check_adamw_args(float* params, float* out, float* exp_avg, float* exp_avg_sq, int64_t n, const rlx_adamw_params* p, float* stats,
                      int32_t* step_state, rlx_mlp_layout& lay, float*& tiles) {
@@ -668,22 +760,32 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
     const bool defer = p->deferred_scale != nullptr && src.nbase == 1;  // (with peers the staging launch has applied it already)
     if (defer)
         if (int rc = check_deferred(p, src.nslab, n, "rlx_clip_adamw_step")) return rc;
-    // one launch instead of two (see reduce_clip_adamw_one_launch): this rank's own slabs, no peer hand-shake, one float4 per
-    // thread, every block resident
+    // one launch instead of two (see reduce_clip_adamw_one_launch): this rank's own slabs, no peer hand-shake, every block resident
     if (p->sync_words != nullptr && src.nbase == 1 && src.seq == nullptr && seq_inc == nullptr && w.world <= 1 && !w.fence && n % 4 == 0 &&
-        n / 4 <= (long long)nblk * 256 && one_launch_resident(nblk) &&
+        n / 4 <= (long long)kOneThreads * kOneThreads &&
         (reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(exp_avg) |
-         reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(src.base[0]) | reinterpret_cast<uintptr_t>(p->sync_words)) % 16 == 0) {
+         reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(src.base[0]) | reinterpret_cast<uintptr_t>(p->sync_words) |
+         reinterpret_cast<uintptr_t>(tiles)) % 16 == 0) {
         const rlx_adamw_params k = tile_format_resolved(p, tiles);
-        unsigned long long* sync = reinterpret_cast<unsigned long long*>(p->sync_words);
-        if (defer)
-            hipLaunchKernelGGL(reduce_clip_adamw_one_launch<true>, dim3(nblk), dim3(256), 0, s, src, params, out, exp_avg, exp_avg_sq,
-                               (long long)(n / 4), p->grad_scale, k, stats, step_state, lay, tiles, status, sync, deferred_of(p));
-        else
-            hipLaunchKernelGGL(reduce_clip_adamw_one_launch<false>, dim3(nblk), dim3(256), 0, s, src, params, out, exp_avg, exp_avg_sq,
-                               (long long)(n / 4), p->grad_scale, k, stats, step_state, lay, tiles, status, sync, DeferredScale{});
-        RLX_LAUNCH_CHECK();
-        return RLX_OK;
+        const SegPlan sp = plan_segments(n / 4, &lay, tiles != nullptr && k.tiles_bf16 != 0);
+        if (sp.nblk >= 1 && sp.nblk <= one_launch_capacity()) {
+            unsigned long long* sync = reinterpret_cast<unsigned long long*>(p->sync_words);
+            const int per_group = defer ? src.nslab / p->deferred_groups : src.nslab;
+            const DeferredScale dfr = defer ? deferred_of(p) : DeferredScale{};
+#define RLX_ONE_LAUNCH(DEFER_, SB_)                                                                                                      \
+    hipLaunchKernelGGL((reduce_clip_adamw_one_launch<DEFER_, SB_>), dim3(sp.nblk), dim3(kOneThreads), 0, s, src, params, out, exp_avg,  \
+                       exp_avg_sq, (long long)(n / 4), p->grad_scale, k, stats, step_state, lay, tiles, status, sync, dfr, sp)
+            if (defer) {
+                if (per_group <= 10) RLX_ONE_LAUNCH(true, 9);
+                else RLX_ONE_LAUNCH(true, 24);
+            } else {
+                if (per_group <= 10) RLX_ONE_LAUNCH(false, 9);
+                else RLX_ONE_LAUNCH(false, 24);
+            }
+#undef RLX_ONE_LAUNCH
+            RLX_LAUNCH_CHECK();
+            return RLX_OK;
+        }
     }
     if (defer) {
         hipLaunchKernelGGL((grad_reduce_sqnorm<true, true>), dim3(nblk), dim3(256), 0, s, src, out, (long long)n, p->grad_scale, partials,

@@ -27,8 +27,8 @@ struct ReduceSrc {
 // requested before the first add -- clamped, unconditional loads; the adds keep the ascending-slab order and skip the slots
 // past nslab.  (Batches of 8 / 4 / 1 made 24 slabs seven dependent trips.)
 #ifdef __HIPCC__
+template <int SB = 24>  // slabs requested per batch beyond the first (24: the exact-f32 plan; 9: the 10-slab bf16 / three-plane plans)
 __device__ __forceinline__ float4 sum_slabs_f4(const float4* __restrict__ gp, long long n4, int nslab) {
-    constexpr int SB = 24;
     float4 x[SB];
     float4 g = gp[0];
 #pragma unroll
@@ -71,12 +71,13 @@ __device__ __forceinline__ float deferred_factor(const DeferredScale& d, long lo
     const bool in = (idx >= d.range[0][0] && idx < d.range[0][1]) || (idx >= d.range[1][0] && idx < d.range[1][1]);
     return in ? sc : 1.f;
 }
+template <int SB = 24>
 __device__ __forceinline__ float4 sum_slab_groups_f4(const float4* __restrict__ gp, long long i, long long n4, int nslab,
                                                      const DeferredScale& d) {
     const int per = nslab / d.groups;
     float4 g{0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < d.groups; ++q) {
-        const float4 x = sum_slabs_f4(gp + (long long)q * per * n4 + i, n4, per);
+        const float4 x = sum_slabs_f4<SB>(gp + (long long)q * per * n4 + i, n4, per);
         const float sc = d.scale[(long long)q * d.stride];
         const float4 f{deferred_factor(d, 4 * i, sc), deferred_factor(d, 4 * i + 1, sc), deferred_factor(d, 4 * i + 2, sc),
                        deferred_factor(d, 4 * i + 3, sc)};

@@ -8,6 +8,8 @@ atol 1e-7 after several steps.
 
 import os
 
+import math
+
 import pytest
 import torch
 
@@ -206,11 +208,14 @@ def test_clip_adamw_matches_torch(slabs, one_launch):
 
 @pytest.mark.parametrize("image", ["none", "bf16", "f32"])
 @pytest.mark.parametrize("slabs,deferred", [(1, False), (10, False), (8, True)])
-def test_one_launch_optimizer_step_is_bit_identical(slabs, deferred, image):
+def test_one_launch_optimizer_step(slabs, deferred, image):
     """rlx_adamw_params.sync_words: slab sum + norm + clip + AdamW as one launch around a device-side exchange of the norm
-    partials.  Same arithmetic as the two launches -- parameters, moments, clipped gradient, weight image, norm and the device
-    step counter compared bit for bit over a run of steps, eager and as a replayed hipGraph (the exchange's epoch advances on
-    the device), with a skipped step (non-finite norm) in the middle."""
+    partials.  Same element arithmetic as the two launches; the norm's f64 partials are formed over different blocks (2048
+    parameters, hidden matrices as segments of their own), so the comparison allows the last bit of the norm to move --
+    parameters, moments, clipped gradient, norm and the device step counter over a run of steps, eager and as a replayed hipGraph
+    (the exchange's epoch advances on the device), with a skipped step (non-finite norm) in the middle.  The weight image the
+    optimizer keeps (8-byte forward stores, the transposed image assembled through LDS) must equal a fresh pack of the final
+    parameters bit for bit."""
     from rlinf_amd import ops
     from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
     if ops.adamw_sync_words(8, "cuda") is None:
@@ -257,17 +262,23 @@ def test_one_launch_optimizer_step_is_bit_identical(slabs, deferred, image):
                 graph.replay()
         side.synchronize()
         torch.cuda.synchronize()
-        runs.append(dict(p=pol.flat.data.clone(), m=m, v=v, tiles=None if tiles is None else tiles.clone().view(torch.int16 if image == "bf16" else torch.int32),
-                         trace=trace, stats=stats.clone(), state=state.clone()))
+        if tiles is not None:  # the image the optimizer kept == the image of its parameters
+            fresh = ops.mlp_pack_tiles(pol.flat.data, lay, None, bf16=image == "bf16")
+            iv = torch.int16 if image == "bf16" else torch.int32
+            assert torch.equal(tiles.view(iv), fresh.view(iv)), ("weight image out of step with the parameters", one)
+        runs.append(dict(p=pol.flat.data.clone(), m=m, v=v, trace=trace, stats=stats.clone(), state=state.clone()))
     a, b = runs
-    for k in ("p", "m", "v", "stats", "state"):
-        assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
-    if a["tiles"] is not None:
-        assert torch.equal(a["tiles"], b["tiles"])
-    for (s0, t0, g0), (s1, t1, g1) in zip(a["trace"], b["trace"]):
-        assert torch.equal(s0.view(torch.int32), s1.view(torch.int32)) and torch.equal(t0, t1)
-        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32))
+    assert torch.equal(a["state"], b["state"]) and float(a["stats"][1]) == float(b["stats"][1]) == 1.0
     assert int(b["state"][0]) + int(b["state"][1]) == 5 + 8 * 25  # one eager step skipped (nan), every replayed step applied
+    for k in ("p", "m", "v"):
+        torch.testing.assert_close(b[k], a[k], rtol=1e-5, atol=1e-9, msg=lambda t, k=k: f"{k}: {t}")
+    for it, ((s0, t0, g0), (s1, t1, g1)) in enumerate(zip(a["trace"], b["trace"])):
+        assert torch.equal(t0, t1) and float(s0[1]) == float(s1[1]) == (0.0 if it == 3 else 1.0)
+        if it != 3:
+            assert float(s1[0]) == pytest.approx(float(s0[0]), rel=1e-6)
+            torch.testing.assert_close(g1, g0, rtol=1e-6, atol=0.0)
+        else:
+            assert not math.isfinite(float(s0[0])) and not math.isfinite(float(s1[0]))
 
 
 # ---- decoupled (async) PPO loss: registry name "decoupled_actor_critic" -------------------------------------
