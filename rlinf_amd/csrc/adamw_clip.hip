@@ -489,71 +489,121 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
 // image takes a lane's four consecutive inputs as one 8-byte store, and the transposed image -- eight consecutive OUTPUTS per
 // 16-byte fragment slot, i.e. one value from each of eight rows -- is assembled through LDS and written as full 16-byte stores.
 // (The generic scatter writes the transposed image as 2-byte stores 16 bytes apart: 3.1 of the first version's 17.0 us.)
-constexpr int kSyncSlot0 = 2;  // sync[0] = epoch, sync[1] = reserved, then two words per block
-constexpr int kOneThreads = 512, kMaxSegs = 10;
+constexpr int kSyncSlot0 = 2, kSlotStride = 2;  // sync[0] = epoch, sync[1] = reserved, then one slot of two words per block
+constexpr int kOneThreads = 512, kMaxSegs = 10, kOneRows = kOneThreads / 64;  // rows of a hidden matrix per block
+constexpr int kMaxOneBlocks = 512;  // slots a polling wave covers (8 per lane)
 struct SegPlan {
     int nseg, nblk;
     int blk0[kMaxSegs];                          // first block of segment k
     long long start4[kMaxSegs], end4[kMaxSegs];  // its float4 range
     int mat[kMaxSegs];                           // -1, or y * 2 + (l - 1): the segment IS hidden matrix l of network y
 };
+struct OneLaunchArgs {
+    ReduceSrc src;
+    float *p, *g, *m, *v;
+    long long n4;
+    float scale;
+    rlx_adamw_params a;
+    float* stats;
+    int* state;
+    rlx_mlp_layout lay;
+    float* tiles;
+    const int* status;
+    unsigned long long* sync;
+    DeferredScale dfr;
+    SegPlan plan;
+};
 template <bool DEFER, int SB>
-__global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(
-    ReduceSrc src, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n4, float scale,
-    rlx_adamw_params a, float* __restrict__ stats, int* __restrict__ state, rlx_mlp_layout lay, float* __restrict__ tiles,
-    const int* status, unsigned long long* sync, DeferredScale dfr, SegPlan plan) {
+__global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(OneLaunchArgs k) {
+    touch_kernargs<(int)sizeof(OneLaunchArgs)>();
     __shared__ double s_red[kOneThreads / 64];
-    __shared__ float s_coef;
-    __shared__ int s_skip;
     __shared__ AdamScalars s_sc;
-    __shared__ __bf16 s_t[3][8][256 + 8];  // [plane][row of the block][input]: the transposed image's staging (12.4 KiB)
+    __shared__ double s_tot;
+    __shared__ int s_exp;
+    __shared__ __bf16 s_t[3][kOneRows][256 + 8];  // [plane][row of the block][input]: the transposed image's staging (12.4 KiB)
+    const rlx_adamw_params& a = k.a;
+    float* __restrict__ p = k.p;
+    float* __restrict__ g = k.g;
+    float* __restrict__ m = k.m;
+    float* __restrict__ v = k.v;
+    unsigned long long* sync = k.sync;
+#ifdef RLX_ONE_LAUNCH_STAMPS  /* timing experiment: wall-clock (100 MHz) stamps of every block behind the slots */
+#define RLX_OL_STAMP(q) do { if (threadIdx.x == 0) sync[kSyncSlot0 + kSlotStride * kMaxOneBlocks + 8 * blockIdx.x + (q)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define RLX_OL_STAMP(q) do { } while (0)
+#endif
+    RLX_OL_STAMP(0);
     const unsigned e1 = (unsigned)__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    // step count: the two-launch form folds the previous call's "applied" flag in its first launch; here every block folds it
+    // step count: the two-launch form folds the previous call's "applied" flag in its first launch; here every wave folds it
     // for itself (both words are stable until block 0 writes them back, which it does behind the exchange)
     int st0 = 0, st1 = 0;
-    if (state != nullptr) st0 = state[0], st1 = state[1];
+    if (k.state != nullptr) st0 = k.state[0], st1 = k.state[1];
     const int steps_done = st0 + (st1 != 0 ? 1 : 0);
     // this block's segment (scalar selects over the argument block)
-    long long s4 = plan.start4[0], e4 = plan.end4[0];
-    int b0 = 0, mat = plan.mat[0];
+    long long s4 = k.plan.start4[0], e4 = k.plan.end4[0];
+    int b0 = 0, mat = k.plan.mat[0];
 #pragma unroll
-    for (int k = 1; k < kMaxSegs; ++k)
-        if (k < plan.nseg && (int)blockIdx.x >= plan.blk0[k]) s4 = plan.start4[k], e4 = plan.end4[k], b0 = plan.blk0[k], mat = plan.mat[k];
+    for (int q = 1; q < kMaxSegs; ++q)
+        if (q < k.plan.nseg && (int)blockIdx.x >= k.plan.blk0[q])
+            s4 = k.plan.start4[q], e4 = k.plan.end4[q], b0 = k.plan.blk0[q], mat = k.plan.mat[q];
     const int lane = threadIdx.x & 63;
-    const long long i = s4 + (long long)((int)blockIdx.x - b0) * kOneThreads + threadIdx.x;
+    const long long blk4 = s4 + (long long)((int)blockIdx.x - b0) * kOneThreads;
+    const long long i = blk4 + threadIdx.x;
     const bool live = i < e4;
     float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
     if (live) {
-        if constexpr (DEFER) g4 = sum_slab_groups_f4<SB>(reinterpret_cast<const float4*>(src.base[0]), i, n4, src.nslab, dfr);
-        else g4 = sum_slabs_f4<SB>(reinterpret_cast<const float4*>(src.base[0]) + i, n4, src.nslab);
+        if constexpr (DEFER) g4 = sum_slab_groups_f4<SB>(reinterpret_cast<const float4*>(k.src.base[0]), i, k.n4, k.src.nslab, k.dfr);
+        else g4 = sum_slabs_f4<SB>(reinterpret_cast<const float4*>(k.src.base[0]) + i, k.n4, k.src.nslab);
         p4 = reinterpret_cast<const float4*>(p)[i];
         m4 = reinterpret_cast<const float4*>(m)[i];
         v4 = reinterpret_cast<const float4*>(v)[i];
-        g4.x *= scale; g4.y *= scale; g4.z *= scale; g4.w *= scale;
+        g4.x *= k.scale; g4.y *= k.scale; g4.z *= k.scale; g4.w *= k.scale;
     }
     double acc[1] = {(double)g4.x * (double)g4.x + (double)g4.y * (double)g4.y + (double)g4.z * (double)g4.z + (double)g4.w * (double)g4.w};
-    if (threadIdx.x == 64) form_scalars(a, state != nullptr ? steps_done + 1 : a.step, &s_sc);
+    RLX_OL_STAMP(1);
     block_sum<1>(acc, s_red);
     if (threadIdx.x == 0) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(acc[0]), tag = (unsigned long long)e1 << 32;
-        unsigned long long* slot = sync + kSyncSlot0 + 2 * (size_t)blockIdx.x;
+        unsigned long long* slot = sync + kSyncSlot0 + kSlotStride * (size_t)blockIdx.x;
         __hip_atomic_store(slot, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // every block's partial: thread t takes block t (gridDim.x <= 512), block_sum adds them in ascending order
-    acc[0] = 0.0;
+    RLX_OL_STAMP(2);
+    // Wave 0 polls for the block: lane L takes blocks L, L + 64, ... (up to 8), adds them in a fixed order (the same in every block ->
+    // the same norm everywhere) and forms the step's scalars while its first polls are in flight (they cost ~1 us of f64 math on
+    // one lane: in front of the publication they delayed every block's partial).  Measured alternatives, alternating in one
+    // process (tools/ab_opt_libs.py, profiles/r05_one_launch_optimizer_step_ab.txt): every wave polling for itself (no barrier behind
+    // the exchange, 8 x the poll traffic) +0.6 us; slots 256 bytes apart: no difference; one 16-byte system-scope load per slot
+    // instead of two 8-byte agent-scope ones +1.2 us; 256-thread blocks (all CUs loading) +0.5 us, 1024-thread blocks +2.3 us.
+    const int nparts = gridDim.x;
+    double pv[8];
+    unsigned pending = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        pv[u] = 0.0;
+        if (lane + 64 * u < nparts) pending |= 1u << u;
+    }
+    AdamScalars& sc = s_sc;
     bool expired = false;
-    if (threadIdx.x < gridDim.x) {
-        const unsigned long long* slot = sync + kSyncSlot0 + 2 * (size_t)threadIdx.x;
+    if (threadIdx.x < 64) {
         const long long t0 = wall_clock64();
-        for (int spins = 0;; ++spins) {
-            const unsigned long long lo = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long hi = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(lo >> 32) == e1 && (unsigned)(hi >> 32) == e1) {
-                acc[0] = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-                break;
-            }
-            if (spins > 16) {
+        for (int spins = 0; pending != 0; ++spins) {
+            unsigned long long lo[8], hi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (pending & (1u << u)) {
+                    const unsigned long long* slot = sync + kSyncSlot0 + kSlotStride * (size_t)(lane + 64 * u);
+                    lo[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi[u] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            if (spins == 0 && lane == 0) form_scalars(a, k.state != nullptr ? steps_done + 1 : a.step, &sc);  // (behind the first polls' latency)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if ((pending & (1u << u)) && (unsigned)(lo[u] >> 32) == e1 && (unsigned)(hi[u] >> 32) == e1) {
+                    pv[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xffffffffull)));
+                    pending &= ~(1u << u);
+                }
+            if (pending != 0 && spins > 16) {
                 if (wall_clock64() - t0 > 200000000ll) {  // 2 s at 100 MHz: a block of this launch never became resident
                     expired = true;
                     break;
@@ -562,40 +612,52 @@ __global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(
             }
         }
     }
-    const int any_expired = __syncthreads_or(expired ? 1 : 0);
-    block_sum<1>(acc, s_red);
-    if (threadIdx.x == 0) {
-        const float total_norm = any_expired ? __builtin_nanf("") : (float)sqrt(acc[0]);
-        float coef = 1.f;
-        if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
-        s_coef = coef;
-        s_skip = !isfinite(total_norm) || (status != nullptr && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
-        if (blockIdx.x == 0 || any_expired) {
-            stats[0] = total_norm;
-            stats[1] = s_skip ? 0.f : 1.f;
-        }
+    RLX_OL_STAMP(3);
+    double tot = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tot += pv[u];
+    tot = wave_sum(tot);
+    const int wave_expired = __any(expired ? 1 : 0);
+    if (threadIdx.x == 0) s_tot = tot, s_exp = wave_expired != 0 ? 1 : 0;  // (wave 0 polled for the block)
+    __syncthreads();
+    tot = s_tot;
+    const bool any_expired = s_exp != 0;
+    const float total_norm = any_expired ? __builtin_nanf("") : (float)sqrt(tot);
+    float coef = 1.f;
+    if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
+    const bool skip = !isfinite(total_norm) ||
+                      (k.status != nullptr && __hip_atomic_load(k.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || any_expired)) {
+        k.stats[0] = total_norm;
+        k.stats[1] = skip ? 0.f : 1.f;
         if (blockIdx.x == 0) {
-            if (state != nullptr) state[0] = steps_done, state[1] = s_skip ? 0 : 1;
+            if (k.state != nullptr) k.state[0] = steps_done, k.state[1] = skip ? 0 : 1;
             __hip_atomic_store(&sync[0], (unsigned long long)e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __syncthreads();
-    const bool skip = s_skip != 0;
+    RLX_OL_STAMP(4);
     float pe[4];
     int grp[4];
-    update_values_f4(p, g, m, v, i, live, p4, g4, m4, v4, s_coef, skip, s_sc, a, pe, grp);
+    update_values_f4(p, g, m, v, i, live, p4, g4, m4, v4, coef, skip, sc, a, pe, grp);
+    RLX_OL_STAMP(5);
+    float* __restrict__ tiles = k.tiles;
     if (tiles == nullptr) return;
     if (mat < 0 || a.tiles_bf16 == 0) {  // (block-uniform)
-        scatter_tiles_f4(i - lane, lane, pe, grp, skip, a, lay, tiles);
+        scatter_tiles_f4(i - lane, lane, pe, grp, skip, a, k.lay, tiles);
         return;
     }
-    // eight whole rows of hidden matrix l of network y: rows row0 .. row0 + 7, this thread's four inputs in0 .. in0 + 3
-    const int touched = __syncthreads_or((!skip && (grp[0] >= 0 || grp[1] >= 0 || grp[2] >= 0 || grp[3] >= 0)) ? 1 : 0);
-    if (!touched) return;  // no optimizer group holds this matrix (critic warm-up) or the step is skipped: the image stands
+    // eight whole rows of hidden matrix l of network y: rows row0 .. row0 + 7, this thread's four inputs in0 .. in0 + 3.  Does any
+    // optimizer group reach into this block's 2048 parameters (scalar)?  If not (critic warm-up), or the step is skipped, the image
+    // stands; otherwise every value is written -- an unchanged parameter rewrites what the image already holds.
+    bool touched = false;
+#pragma unroll
+    for (int q = 0; q < RLX_ADAMW_MAX_GROUPS; ++q)
+        touched = touched || (q < a.n_groups && a.groups[q].begin < 4 * blk4 + 4 * kOneThreads && a.groups[q].end > 4 * blk4);
+    if (skip || !touched) return;
     constexpr size_t per_net = (size_t)256 * 64 + 4 * (size_t)256 * 256, plane = 2 * per_net;
     const int y = mat >> 1, l = (mat & 1) + 1, nplanes = a.tiles_bf16 == 2 ? 3 : 1;
     const size_t hid = (size_t)y * per_net + (size_t)256 * 64;
-    const int row0 = ((int)blockIdx.x - b0) * 8, rr = threadIdx.x >> 6, in0 = 4 * lane;
+    const int row0 = ((int)blockIdx.x - b0) * kOneRows, rr = threadIdx.x >> 6, in0 = 4 * lane;
     __bf16 pl[3][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -615,14 +677,17 @@ __global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nplanes * 256; idx += kOneThreads) {
-        const int q = idx >> 8, in = idx & 255;
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        bf16x8 w;
+    constexpr int RG = kOneRows < 8 ? kOneRows : 8, NG = kOneRows / RG;  // outputs per store (a 16-byte slot holds 8), stores per input
+    for (int idx = threadIdx.x; idx < nplanes * NG * 256; idx += kOneThreads) {
+        const int q = idx / (NG * 256), gq = (idx / 256) % NG, in = idx & 255;
+        typedef __bf16 bf16xr __attribute__((ext_vector_type(RG)));
+        bf16xr w;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) w[r] = s_t[q][r][in];
-        *reinterpret_cast<bf16x8*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l + 1) * 65536, 8, in, row0)) = w;  // W_l^T
+        for (int r = 0; r < RG; ++r) w[r] = s_t[q][gq * RG + r][in];
+        *reinterpret_cast<bf16xr*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l + 1) * 65536, 8, in, row0 + gq * RG)) = w;  // W_l^T
     }
+    RLX_OL_STAMP(6);
+#undef RLX_OL_STAMP
 }
 
 template <bool DEFER>
@@ -684,7 +749,7 @@ int one_launch_capacity() {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kOneThreads, 0) != hipSuccess) return 0;
             best = std::min(best, per_cu);
         }
-        return std::min(best * num_cu(), kOneThreads);  // (and one slot per polling thread)
+        return std::min(best * num_cu(), kMaxOneBlocks);
     }();
     return capacity;
 }
@@ -762,7 +827,7 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
         if (int rc = check_deferred(p, src.nslab, n, "rlx_clip_adamw_step")) return rc;
     // one launch instead of two (see reduce_clip_adamw_one_launch): this rank's own slabs, no peer hand-shake, every block resident
     if (p->sync_words != nullptr && src.nbase == 1 && src.seq == nullptr && seq_inc == nullptr && w.world <= 1 && !w.fence && n % 4 == 0 &&
-        n / 4 <= (long long)kOneThreads * kOneThreads &&
+        n / 4 <= (long long)kOneThreads * kMaxOneBlocks &&
         (reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(src.base[0]) | reinterpret_cast<uintptr_t>(p->sync_words) |
          reinterpret_cast<uintptr_t>(tiles)) % 16 == 0) {
@@ -772,9 +837,11 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
             unsigned long long* sync = reinterpret_cast<unsigned long long*>(p->sync_words);
             const int per_group = defer ? src.nslab / p->deferred_groups : src.nslab;
             const DeferredScale dfr = defer ? deferred_of(p) : DeferredScale{};
-#define RLX_ONE_LAUNCH(DEFER_, SB_)                                                                                                      \
-    hipLaunchKernelGGL((reduce_clip_adamw_one_launch<DEFER_, SB_>), dim3(sp.nblk), dim3(kOneThreads), 0, s, src, params, out, exp_avg,  \
-                       exp_avg_sq, (long long)(n / 4), p->grad_scale, k, stats, step_state, lay, tiles, status, sync, dfr, sp)
+            OneLaunchArgs oa{};
+            oa.src = src, oa.p = params, oa.g = out, oa.m = exp_avg, oa.v = exp_avg_sq, oa.n4 = n / 4, oa.scale = p->grad_scale, oa.a = k;
+            oa.stats = stats, oa.state = step_state, oa.lay = lay, oa.tiles = tiles, oa.status = status, oa.sync = sync, oa.dfr = dfr, oa.plan = sp;
+#define RLX_ONE_LAUNCH(DEFER_, SB_) \
+    hipLaunchKernelGGL((reduce_clip_adamw_one_launch<DEFER_, SB_>), dim3(sp.nblk), dim3(kOneThreads), 0, s, oa)
             if (defer) {
                 if (per_group <= 10) RLX_ONE_LAUNCH(true, 9);
                 else RLX_ONE_LAUNCH(true, 24);
@@ -879,7 +946,7 @@ using namespace rlx::opt;
 
 extern "C" size_t rlx_adamw_sync_words(int64_t n) {
     (void)n;
-    return (size_t)kSyncSlot0 + 2 * (size_t)kMaxParts;
+    return (size_t)kSyncSlot0 + (size_t)kSlotStride * (size_t)kMaxOneBlocks + 8 * (size_t)kMaxOneBlocks;  // (+ room for the development stamps)
 }
 
 extern "C" size_t rlx_adamw_workspace_bytes(int64_t n) {
