@@ -360,6 +360,90 @@ __device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restri
     scatter_tiles_f4(iw, lane, pe, grp, skip, a, lay, tiles);
 }
 
+constexpr int kSyncSlot0 = 2, kSlotStride = 2;  // sync[0] = epoch, sync[1] = "a poll expired" (sticky), then one slot of two words per block
+constexpr int kOneThreads = 512, kMaxSegs = 10, kOneRows = kOneThreads / 64;  // rows of a hidden matrix per block
+constexpr int kMaxOneBlocks = 512;  // slots a polling wave covers (8 per lane)
+struct SegPlan {
+    int nseg, nblk;
+    int blk0[kMaxSegs];                          // first block of segment k
+    long long start4[kMaxSegs], end4[kMaxSegs];  // its float4 range
+    int mat[kMaxSegs];                           // -1, or y * 2 + (l - 1): the segment IS hidden matrix l of network y
+};
+// A block's place under a SegPlan: its first float4, this thread's float4, its segment's first block and matrix id.
+struct SegBlock {
+    long long blk4, i;
+    int b0, mat;
+    bool live;
+};
+__device__ __forceinline__ SegBlock seg_block(const SegPlan& plan) {  // (scalar selects over the argument block)
+    long long s4 = plan.start4[0], e4 = plan.end4[0];
+    int b0 = 0, mat = plan.mat[0];
+#pragma unroll
+    for (int q = 1; q < kMaxSegs; ++q)
+        if (q < plan.nseg && (int)blockIdx.x >= plan.blk0[q]) s4 = plan.start4[q], e4 = plan.end4[q], b0 = plan.blk0[q], mat = plan.mat[q];
+    SegBlock sb;
+    sb.blk4 = s4 + (long long)((int)blockIdx.x - b0) * kOneThreads;
+    sb.i = sb.blk4 + threadIdx.x;
+    sb.b0 = b0, sb.mat = mat, sb.live = sb.i < e4;
+    return sb;
+}
+typedef __bf16 (*ImageStage)[kOneRows][256 + 8];  // [plane][row of the block][input]: the transposed image's staging (12.4 KiB)
+// Clip + AdamW on this thread's float4 and the weight image's copy of it.  LAST thing a kernel does (it returns early per block).
+__device__ __forceinline__ void apply_seg_block(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                const SegBlock& sb, float4 p4, float4 g4, float4 m4, float4 v4, float coef, bool skip,
+                                                const AdamScalars& sc, const rlx_adamw_params& a, const rlx_mlp_layout& lay,
+                                                float* __restrict__ tiles, ImageStage s_t) {
+    const int lane = threadIdx.x & 63;
+    float pe[4];
+    int grp[4];
+    update_values_f4(p, g, m, v, sb.i, sb.live, p4, g4, m4, v4, coef, skip, sc, a, pe, grp);
+    if (tiles == nullptr) return;
+    if (sb.mat < 0 || a.tiles_bf16 == 0) {  // (block-uniform)
+        scatter_tiles_f4(sb.i - lane, lane, pe, grp, skip, a, lay, tiles);
+        return;
+    }
+    // eight whole rows of hidden matrix l of network y: rows row0 .. row0 + 7, this thread's four inputs in0 .. in0 + 3.  Does any
+    // optimizer group reach into this block's 2048 parameters (scalar)?  If not (critic warm-up), or the step is skipped, the image
+    // stands; otherwise every value is written -- an unchanged parameter rewrites what the image already holds.
+    bool touched = false;
+#pragma unroll
+    for (int q = 0; q < RLX_ADAMW_MAX_GROUPS; ++q)
+        touched = touched || (q < a.n_groups && a.groups[q].begin < 4 * sb.blk4 + 4 * kOneThreads && a.groups[q].end > 4 * sb.blk4);
+    if (skip || !touched) return;
+    constexpr size_t per_net = (size_t)256 * 64 + 4 * (size_t)256 * 256, plane = 2 * per_net;
+    const int y = sb.mat >> 1, l = (sb.mat & 1) + 1, nplanes = a.tiles_bf16 == 2 ? 3 : 1;
+    const size_t hid = (size_t)y * per_net + (size_t)256 * 64;
+    const int row0 = ((int)blockIdx.x - sb.b0) * kOneRows, rr = threadIdx.x >> 6, in0 = 4 * lane;
+    __bf16 pl[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)pe[e];
+        const float r1 = fsub(pe[e], (float)h);
+        const __bf16 md = (__bf16)r1;
+        pl[0][e] = h, pl[1][e] = md, pl[2][e] = (__bf16)fsub(r1, (float)md);
+    }
+    __bf16* img = reinterpret_cast<__bf16*>(tiles);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (q < nplanes) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 w = {pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
+            *reinterpret_cast<bf16x4*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l - 1) * 65536, 8, row0 + rr, in0)) = w;  // W_l
+            *reinterpret_cast<bf16x4*>(&s_t[q][rr][in0]) = w;
+        }
+    }
+    __syncthreads();
+    constexpr int RG = kOneRows < 8 ? kOneRows : 8, NG = kOneRows / RG;  // outputs per store (a 16-byte slot holds 8), stores per input
+    for (int idx = threadIdx.x; idx < nplanes * NG * 256; idx += kOneThreads) {
+        const int q = idx / (NG * 256), gq = (idx / 256) % NG, in = idx & 255;
+        typedef __bf16 bf16xr __attribute__((ext_vector_type(RG)));
+        bf16xr w;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) w[r] = s_t[q][gq * RG + r][in];
+        *reinterpret_cast<bf16xr*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l + 1) * 65536, 8, in, row0 + gq * RG)) = w;  // W_l^T
+    }
+}
+
 // One float4 of parameters per thread (p, g, m, v: four 16-byte loads in flight per lane); the (<= 1024) norm partials are
 // re-reduced by every block (a device-wide "last block" finalisation would serialise one memory-side atomic per block).
 // GATHER (the RS + AG all-reduce): the reduced gradient and its norm partials are read from every rank's shard area (peer reads
@@ -489,15 +573,6 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
 // image takes a lane's four consecutive inputs as one 8-byte store, and the transposed image -- eight consecutive OUTPUTS per
 // 16-byte fragment slot, i.e. one value from each of eight rows -- is assembled through LDS and written as full 16-byte stores.
 // (The generic scatter writes the transposed image as 2-byte stores 16 bytes apart: 3.1 of the first version's 17.0 us.)
-constexpr int kSyncSlot0 = 2, kSlotStride = 2;  // sync[0] = epoch, sync[1] = reserved, then one slot of two words per block
-constexpr int kOneThreads = 512, kMaxSegs = 10, kOneRows = kOneThreads / 64;  // rows of a hidden matrix per block
-constexpr int kMaxOneBlocks = 512;  // slots a polling wave covers (8 per lane)
-struct SegPlan {
-    int nseg, nblk;
-    int blk0[kMaxSegs];                          // first block of segment k
-    long long start4[kMaxSegs], end4[kMaxSegs];  // its float4 range
-    int mat[kMaxSegs];                           // -1, or y * 2 + (l - 1): the segment IS hidden matrix l of network y
-};
 struct OneLaunchArgs {
     ReduceSrc src;
     float *p, *g, *m, *v;
@@ -514,7 +589,7 @@ struct OneLaunchArgs {
     SegPlan plan;
 };
 template <bool DEFER, int SB>
-__global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(OneLaunchArgs k) {
+__global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(OneLaunchArgs k) {  // (4 waves per SIMD = two blocks per CU: <= 128 VGPRs)
     touch_kernargs<(int)sizeof(OneLaunchArgs)>();
     __shared__ double s_red[kOneThreads / 64];
     __shared__ AdamScalars s_sc;
@@ -539,17 +614,10 @@ __global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(OneL
     int st0 = 0, st1 = 0;
     if (k.state != nullptr) st0 = k.state[0], st1 = k.state[1];
     const int steps_done = st0 + (st1 != 0 ? 1 : 0);
-    // this block's segment (scalar selects over the argument block)
-    long long s4 = k.plan.start4[0], e4 = k.plan.end4[0];
-    int b0 = 0, mat = k.plan.mat[0];
-#pragma unroll
-    for (int q = 1; q < kMaxSegs; ++q)
-        if (q < k.plan.nseg && (int)blockIdx.x >= k.plan.blk0[q])
-            s4 = k.plan.start4[q], e4 = k.plan.end4[q], b0 = k.plan.blk0[q], mat = k.plan.mat[q];
+    const SegBlock sb = seg_block(k.plan);
     const int lane = threadIdx.x & 63;
-    const long long blk4 = s4 + (long long)((int)blockIdx.x - b0) * kOneThreads;
-    const long long i = blk4 + threadIdx.x;
-    const bool live = i < e4;
+    const long long i = sb.i;
+    const bool live = sb.live;
     float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
     if (live) {
         if constexpr (DEFER) g4 = sum_slab_groups_f4<SB>(reinterpret_cast<const float4*>(k.src.base[0]), i, k.n4, k.src.nslab, k.dfr);
@@ -628,6 +696,7 @@ __global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(OneL
     const bool skip = !isfinite(total_norm) ||
                       (k.status != nullptr && __hip_atomic_load(k.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
     if (threadIdx.x == 0 && (blockIdx.x == 0 || any_expired)) {
+        if (any_expired) __hip_atomic_store(&sync[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: the host raises
         k.stats[0] = total_norm;
         k.stats[1] = skip ? 0.f : 1.f;
         if (blockIdx.x == 0) {
@@ -636,58 +705,93 @@ __global__ __launch_bounds__(kOneThreads) void reduce_clip_adamw_one_launch(OneL
         }
     }
     RLX_OL_STAMP(4);
-    float pe[4];
-    int grp[4];
-    update_values_f4(p, g, m, v, i, live, p4, g4, m4, v4, coef, skip, sc, a, pe, grp);
-    RLX_OL_STAMP(5);
-    float* __restrict__ tiles = k.tiles;
-    if (tiles == nullptr) return;
-    if (mat < 0 || a.tiles_bf16 == 0) {  // (block-uniform)
-        scatter_tiles_f4(i - lane, lane, pe, grp, skip, a, k.lay, tiles);
-        return;
+    apply_seg_block(p, g, m, v, sb, p4, g4, m4, v4, coef, skip, sc, a, k.lay, k.tiles, s_t);
+    RLX_OL_STAMP(6);
+#undef RLX_OL_STAMP
+}
+
+// clip_adamw_kernel on the SegPlan's blocks (2048 parameters, hidden matrices as segments of their own -> the weight image's fast
+// stores, see reduce_clip_adamw_one_launch): the second launch of the two-launch form and of the xGMI exchange whenever the
+// buffers are float4-shaped.  The norm partials come from the launch in front, so the block shape here is free.
+struct ClipSegArgs {
+    float *p, *g, *m, *v;
+    rlx_adamw_params a;
+    const double* partials;
+    int nparts;
+    float* stats;
+    int* state;
+    rlx_mlp_layout lay;
+    float* tiles;
+    unsigned* seq_inc;
+    const int* status;
+    GatherSrc gsrc;
+    PeerWait wait;
+    SegPlan plan;
+};
+template <bool GATHER>
+__global__ __launch_bounds__(kOneThreads) void clip_adamw_seg_kernel(ClipSegArgs k) {
+    touch_kernargs<(int)sizeof(ClipSegArgs)>();
+    __shared__ double s_red[kOneThreads / 64];
+    __shared__ float s_coef;
+    __shared__ int s_skip;
+    __shared__ AdamScalars s_sc;
+    __shared__ __bf16 s_t[3][kOneRows][256 + 8];
+    const rlx_adamw_params& a = k.a;
+    size_t goff = 0;
+    if constexpr (GATHER) {
+        peer_handshake(k.wait);
+        goff = (size_t)((*k.gsrc.seq + 1u) & 1u) * (size_t)k.gsrc.slot_stride;
     }
-    // eight whole rows of hidden matrix l of network y: rows row0 .. row0 + 7, this thread's four inputs in0 .. in0 + 3.  Does any
-    // optimizer group reach into this block's 2048 parameters (scalar)?  If not (critic warm-up), or the step is skipped, the image
-    // stands; otherwise every value is written -- an unchanged parameter rewrites what the image already holds.
-    bool touched = false;
-#pragma unroll
-    for (int q = 0; q < RLX_ADAMW_MAX_GROUPS; ++q)
-        touched = touched || (q < a.n_groups && a.groups[q].begin < 4 * blk4 + 4 * kOneThreads && a.groups[q].end > 4 * blk4);
-    if (skip || !touched) return;
-    constexpr size_t per_net = (size_t)256 * 64 + 4 * (size_t)256 * 256, plane = 2 * per_net;
-    const int y = mat >> 1, l = (mat & 1) + 1, nplanes = a.tiles_bf16 == 2 ? 3 : 1;
-    const size_t hid = (size_t)y * per_net + (size_t)256 * 64;
-    const int row0 = ((int)blockIdx.x - b0) * kOneRows, rr = threadIdx.x >> 6, in0 = 4 * lane;
-    __bf16 pl[3][4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 h = (__bf16)pe[e];
-        const float r1 = fsub(pe[e], (float)h);
-        const __bf16 md = (__bf16)r1;
-        pl[0][e] = h, pl[1][e] = md, pl[2][e] = (__bf16)fsub(r1, (float)md);
+    const SegBlock sb = seg_block(k.plan);
+    float4 p4 = {0, 0, 0, 0}, g4 = p4, m4 = p4, v4 = p4;
+    if (sb.live) {  // issued before the norm is known: they do not depend on it
+        p4 = reinterpret_cast<const float4*>(k.p)[sb.i];
+        if constexpr (GATHER) g4 = gather_f4(k.gsrc, goff, sb.i);
+        else g4 = reinterpret_cast<const float4*>(k.g)[sb.i];
+        m4 = reinterpret_cast<const float4*>(k.m)[sb.i];
+        v4 = reinterpret_cast<const float4*>(k.v)[sb.i];
     }
-    __bf16* img = reinterpret_cast<__bf16*>(tiles);
+    // the norm partials (<= kMaxParts = 2 x 512): all of a lane's loads in flight together, added in ascending order
+    double acc[1] = {0.0};
+    {
+        const int total = GATHER ? k.gsrc.world * k.gsrc.nparts : k.nparts;
+        const size_t poff = GATHER ? (size_t)((*k.gsrc.seq + 1u) & 1u) * (size_t)k.gsrc.nparts : 0;
+        double pv[kMaxParts / kOneThreads];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (q < nplanes) {
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            const bf16x4 w = {pl[q][0], pl[q][1], pl[q][2], pl[q][3]};
-            *reinterpret_cast<bf16x4*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l - 1) * 65536, 8, row0 + rr, in0)) = w;  // W_l
-            *reinterpret_cast<bf16x4*>(&s_t[q][rr][in0]) = w;
+        for (int u = 0; u < kMaxParts / kOneThreads; ++u) {
+            const int idx = min((int)threadIdx.x + u * kOneThreads, total - 1);
+            if constexpr (GATHER) {  // world x nparts partials, rank-major: the same tree on every rank -> the same norm on every rank
+                const int owner = idx / k.gsrc.nparts;
+                const double* base = k.gsrc.parts[0];
+#pragma unroll
+                for (int r = 1; r < kMaxRanks; ++r)
+                    if (r == owner) base = k.gsrc.parts[r];
+                pv[u] = base[poff + (idx - owner * k.gsrc.nparts)];
+            } else {
+                pv[u] = k.partials[idx];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kMaxParts / kOneThreads; ++u)
+            if ((int)threadIdx.x + u * kOneThreads < total) acc[0] += pv[u];
+    }
+    if (threadIdx.x == 64) form_scalars(a, k.state != nullptr ? k.state[0] + 1 : a.step, &s_sc);  // state[0] is stable for the whole launch
+    block_sum<1>(acc, s_red);
+    if (threadIdx.x == 0) {
+        const float total_norm = (float)sqrt(acc[0]);
+        float coef = 1.f;
+        if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
+        s_coef = coef;
+        s_skip = !isfinite(total_norm) || (k.status != nullptr && __hip_atomic_load(k.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+        if (blockIdx.x == 0) {
+            k.stats[0] = total_norm;
+            k.stats[1] = s_skip ? 0.f : 1.f;
+            if (k.state != nullptr) k.state[1] = s_skip ? 0 : 1;
+            if (k.seq_inc != nullptr) *k.seq_inc += 1u;  // this all-reduce is consumed: the next staging launch uses the other buffer
         }
     }
     __syncthreads();
-    constexpr int RG = kOneRows < 8 ? kOneRows : 8, NG = kOneRows / RG;  // outputs per store (a 16-byte slot holds 8), stores per input
-    for (int idx = threadIdx.x; idx < nplanes * NG * 256; idx += kOneThreads) {
-        const int q = idx / (NG * 256), gq = (idx / 256) % NG, in = idx & 255;
-        typedef __bf16 bf16xr __attribute__((ext_vector_type(RG)));
-        bf16xr w;
-#pragma unroll
-        for (int r = 0; r < RG; ++r) w[r] = s_t[q][gq * RG + r][in];
-        *reinterpret_cast<bf16xr*>(img + q * plane + tile_slot_bf16(hid + (size_t)(l + 1) * 65536, 8, in, row0 + gq * RG)) = w;  // W_l^T
-    }
-    RLX_OL_STAMP(6);
-#undef RLX_OL_STAMP
+    apply_seg_block(k.p, k.g, k.m, k.v, sb, p4, g4, m4, v4, s_coef, s_skip != 0, s_sc, a, k.lay, k.tiles, s_t);
 }
 
 template <bool DEFER>
@@ -805,6 +909,39 @@ int check_adamw_args(float* params, float* out, float* exp_avg, float* exp_avg_s
 }
 }  // namespace
 
+// The clip + AdamW launch behind a reduce (GATHER false: gradient and norm partials local) or behind a reduce-scatter (true: read
+// from every rank's shard area): SegPlan blocks with the weight image's fast stores when the buffers are float4-shaped, else the
+// general grid-stride kernel.
+static int launch_clip_adamw(bool gather, float* params, float* out, float* exp_avg, float* exp_avg_sq, int64_t n, const rlx_adamw_params* p,
+                             const double* partials, int nparts, const AdamScalars* scalars, float* stats, int32_t* step_state,
+                             const rlx_mlp_layout& lay, float* tiles, unsigned* seq_inc, const int* status, const GatherSrc& gsrc,
+                             const PeerWait& w, hipStream_t s) {
+    const rlx_adamw_params k = tile_format_resolved(p, tiles);
+    const bool vec = n % 4 == 0 && (reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(exp_avg) |
+                                    reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(tiles)) % 16 == 0;
+    if (vec && n / 4 / kOneThreads < (1ll << 30)) {
+        const SegPlan sp = plan_segments(n / 4, &lay, tiles != nullptr && k.tiles_bf16 != 0);
+        if (sp.nblk >= 1) {
+            ClipSegArgs ca{};
+            ca.p = params, ca.g = out, ca.m = exp_avg, ca.v = exp_avg_sq, ca.a = k, ca.partials = partials, ca.nparts = nparts, ca.stats = stats;
+            ca.state = step_state, ca.lay = lay, ca.tiles = tiles, ca.seq_inc = seq_inc, ca.status = status, ca.gsrc = gsrc, ca.wait = w, ca.plan = sp;
+            if (gather) hipLaunchKernelGGL(clip_adamw_seg_kernel<true>, dim3(sp.nblk), dim3(kOneThreads), 0, s, ca);
+            else hipLaunchKernelGGL(clip_adamw_seg_kernel<false>, dim3(sp.nblk), dim3(kOneThreads), 0, s, ca);
+            RLX_LAUNCH_CHECK();
+            return RLX_OK;
+        }
+    }
+    const int nblk = grid_for(n);
+    if (gather)
+        hipLaunchKernelGGL(clip_adamw_kernel<true>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, k, partials, nparts,
+                           scalars, stats, step_state, lay, tiles, seq_inc, status, gsrc, w);
+    else
+        hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, k, partials, nparts,
+                           scalars, stats, step_state, lay, tiles, seq_inc, status, gsrc, w);
+    RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
 int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, float* exp_avg, float* exp_avg_sq, int64_t n,
                              const rlx_adamw_params* p, float* stats, int32_t* step_state, void* workspace, size_t workspace_bytes,
                              const PeerWait* wait, unsigned* seq_inc, const int* status, hipStream_t s) {
@@ -862,9 +999,9 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
                            step_state, *p, scalars, w, DeferredScale{});
     }
     RLX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, tile_format_resolved(p, tiles),
-                       partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc, status, GatherSrc{}, PeerWait{});
-    RLX_LAUNCH_CHECK();
+    if (int rc = launch_clip_adamw(false, params, out, exp_avg, exp_avg_sq, n, p, partials, nblk, scalars, stats, step_state, lay, tiles, seq_inc,
+                                   status, GatherSrc{}, PeerWait{}, s))
+        return rc;
     return RLX_OK;
 }
 
@@ -901,10 +1038,7 @@ int launch_gather_clip_adamw(float* params, const GatherSrc& src, float* out, fl
                  reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 == 0, "gather clip_adamw: buffers must be 16-byte aligned");
     PeerWait w{};
     if (wait != nullptr) w = *wait;
-    hipLaunchKernelGGL(clip_adamw_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, tile_format_resolved(p, tiles),
-                       (const double*)nullptr, 0, (const AdamScalars*)nullptr, stats, step_state, lay, tiles, seq_inc, status, src, w);
-    RLX_LAUNCH_CHECK();
-    return RLX_OK;
+    return launch_clip_adamw(true, params, out, exp_avg, exp_avg_sq, n, p, nullptr, 0, nullptr, stats, step_state, lay, tiles, seq_inc, status, src, w, s);
 }
 
 int launch_gather_only(const GatherSrc& src, float* out, int64_t n, const PeerWait* wait, unsigned* seq_inc, hipStream_t s) {

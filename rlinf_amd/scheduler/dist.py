@@ -37,6 +37,23 @@ class DistContext:
         return self.world_size > 1 or self.force_exchange
 
 
+def ranks_share_a_device(ctx: "DistContext") -> bool:
+    """Collective (every rank calls it at the same point): do two ranks of this job sit on ONE GPU (test set-ups, an oversubscribed
+    node)?  Kernels that need all their workgroups resident together -- the one-launch optimizer step -- are not used then: two
+    processes' launches can each hold half the device and wait for the other half."""
+    if ctx.world_size <= 1 or not dist.is_initialized():
+        return False
+    import socket
+    try:
+        props = torch.cuda.get_device_properties(ctx.device)
+        dev_id = (socket.gethostname(), str(props.uuid) if hasattr(props, "uuid") else int(ctx.device.index or 0))
+    except Exception:  # noqa: BLE001
+        dev_id = (socket.gethostname(), int(getattr(ctx.device, "index", 0) or 0))
+    ids = [None] * ctx.world_size
+    dist.all_gather_object(ids, dev_id)
+    return len(set(ids)) < len(ids)
+
+
 def forced_exchange() -> str:
     """"" (off), "rccl" or "xgmi": what RLX_FORCE_EXCHANGE asks for ("1" = rccl)."""
     v = os.environ.get("RLX_FORCE_EXCHANGE", "").strip().lower()

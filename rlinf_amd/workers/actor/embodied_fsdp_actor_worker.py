@@ -102,7 +102,10 @@ class EmbodiedFSDPActor(Worker):
         self.step_state = torch.zeros(2, dtype=torch.int32, device=dev)
         self.opt_stats = torch.zeros(2, device=dev)
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        self.adamw_sync = ops.adamw_sync_words(n, dev)  # -> slab sum + norm + clip + AdamW as one launch (None: two)
+        # slab sum + norm + clip + AdamW as ONE launch (None: two).  It needs all its workgroups resident together, so not when
+        # two ranks of the job share a GPU: their launches could each hold half the device and wait for the other half
+        from ...scheduler import ranks_share_a_device
+        self.adamw_sync = None if ranks_share_a_device(self.ctx) else ops.adamw_sync_words(n, dev)
         self.grad_flat = torch.zeros(n, device=dev)
         self._ws = {}
         # gradient all-reduce transport (world_size > 1): hand-written xGMI peer reads, validated against torch.distributed at
@@ -824,6 +827,7 @@ class EmbodiedFSDPActor(Worker):
             out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
             out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
             out["actor/grad_norm"] = host[-1]
+            ops.check_adamw_sync(self.adamw_sync, host[-1])
             out["actor/lr"] = float(np.mean([a for a, _ in log]))
             critic = [c for _, c in log if c is not None]
             if critic:

@@ -2,8 +2,9 @@
 that starts at the model's logits and ends at ``loss.backward()`` -- lines 476-505 (logits -> log-probs / entropy)
 and 694-781 (micro-batch loss) -- on the kernels of token_ops.hip.
 
-The transformer itself, FSDP wrapping, sequence packing and weight sync are outside this path (SURVEY.md 8:
-model backends are out of scope); ``TokenLearnerStep`` is what a maintainer drops into ``training_step`` in
+The transformer itself, FSDP wrapping and weight sync are outside this path (model backends are out of
+scope); sequence packing and dynamic batches are in (``hybrid_engines/fsdp/utils.py``, the reference's own config
+keys); ``TokenLearnerStep`` is what a maintainer drops into ``training_step`` in
 place of ``forward_batch``'s tail + the loss block:
 
     step = TokenLearnerStep.from_cfg(cfg)
@@ -334,7 +335,9 @@ class FSDPActor:
         self.step_state = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.opt_stats = torch.zeros(2, device=self.device)
         self.adamw_ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=self.device)
-        self.adamw_sync = ops.adamw_sync_words(n, self.device)  # one-launch optimizer step where the plan allows it (small models)
+        from ...scheduler import ranks_share_a_device
+        # one-launch optimizer step where the plan allows it (small models; not when ranks share a GPU: see the embodied worker)
+        self.adamw_sync = None if ranks_share_a_device(self.ctx) else ops.adamw_sync_words(n, self.device)
         self._optim = dict(betas=(float(_get(o, "adam_beta1", 0.9)), float(_get(o, "adam_beta2", 0.999))), eps=float(_get(o, "adam_eps", 1e-8)),
                            weight_decay=float(_get(o, "weight_decay", 1e-2)), max_grad_norm=float(_get(o, "clip_grad", 1.0)))
         self.lr = float(_get(o, "lr", 1e-6))
@@ -497,6 +500,7 @@ class FSDPActor:
         host = torch.cat([stacked, grad_norm.reshape(1)]).tolist()  # ONE read-back per optimizer step
         out = dict(zip(keys, host[:-1]))
         out["actor/grad_norm"], out["actor/lr"] = host[-1], lr_list[0]
+        ops.check_adamw_sync(self.adamw_sync, host[-1])
         return out
 
     # ---- the iteration (:860-939) ----------------------------------------------------------------------------------------------

@@ -102,6 +102,9 @@ def in_loop_kernels(precision: str, *, rows: int, envs: int, slabs: int, n_param
     want = (("rollout step", ("rollout_step",), "mfma", (fwd + value_fwd) * envs, f"{envs} policy rows (both networks) + {envs} bootstrap-value rows"),
             ("fused forward + loss + backward-data", ("ppo_step_fused",), "mfma", (fwd + bwd) * rows, f"{rows} rows"),
             ("weight gradients", ("ppo_step_dw",), "mfma", dw * rows, f"{rows} rows, {slabs} split-K slabs"),
+            # the optimizer step is ONE launch (rlx_adamw_params.sync_words); the two-launch form's kernels when that is switched off
+            ("slab sum + norm + clip + AdamW (+ weight-image refresh), one launch", ("reduce_clip_adamw_one_launch",), "hbm",
+             (slabs * 4 + 28) * n_params, f"{slabs} slabs x {n_params} f32 + 28 B per parameter"),
             ("slab sum + squared norm", ("grad_reduce_sqnorm",), "hbm", (slabs + 1) * n_params * 4, f"{slabs} slabs x {n_params} f32 -> 1"),
             ("clip + AdamW (+ weight-tile refresh)", ("clip_adamw_kernel",), "hbm", 28 * n_params, "28 B per parameter"))
     out = []
@@ -122,7 +125,7 @@ def in_loop_kernels(precision: str, *, rows: int, envs: int, slabs: int, n_param
                         "of": what})
     step = [r for r in out if r["launch"] != "rollout step"]
     return {"source": "rocprofv3 --kernel-trace over `bench.py --steps 3 --warmup 2` spawned by this run (medians over all launches)",
-            "optimizer_step_us": round(sum(r["median_us"] for r in step), 2) if len(step) == 4 else None, "kernels": out,
+            "optimizer_step_us": round(sum(r["median_us"] for r in step), 2) if len(step) in (3, 4) else None, "kernels": out,
             "note": "the matrix kernels are latency-bound chains on small tiles (SURVEY.md 8d: graded on time, not on MFMA fraction); "
                     "the fractions are here so the record states them"}
 

@@ -49,7 +49,9 @@ def measure(device, n_params: int, slabs: int, worlds=(2, 4, 8), steps: int = 40
     out = {"n_params": n_params, "slabs": slabs, "steps": steps}
     with torch.cuda.device(dev):
         p, m, v, st, ss, gf = fresh()
-        single = ops.PreparedAdamw(p, grads, m, v, groups, grad_scale=1.0, stats=st, step_state=ss, workspace=ws, **kw)
+        # what one GPU runs: the optimizer step as one launch (rlx_adamw_params.sync_words); the exchange's chains keep their launches
+        single = ops.PreparedAdamw(p, grads, m, v, groups, grad_scale=1.0, stats=st, step_state=ss, workspace=ws,
+                                   sync=ops.adamw_sync_words(n_params, dev), **kw)
         out["single_gpu_chain_us"] = round(time_chain(single), 3)
         for W in worlds:
             comm = SelfAliasedXgmi(dev, W, n_params)
