@@ -278,10 +278,29 @@ def validate_mlp_kernel_shapes(model_cfg) -> None:
         f"{lim['action_outputs_max']} head outputs per policy step")
 
 
+def _refuse_foreign_patch_codecs(node, path=""):
+    """A weight-syncer ``patch`` section that names the reference's nvCOMP container (``compression_algorithm`` / ``compression``:
+    rlinf/hybrid_engines/weight_syncer/base.py:112-119) is refused when the configuration is validated, not when the first
+    patch is built: this build cannot produce that wire format (hybrid_engines/weight_syncer/compressor.py says what to use)."""
+    if not isinstance(node, dict):
+        return
+    for key, val in node.items():
+        here = f"{path}.{key}" if path else str(key)
+        if key == "patch" and isinstance(val, dict):
+            name = val.get("compression_algorithm", val.get("compression", "none"))
+            from .hybrid_engines.weight_syncer.compressor import NVCOMP_ALGORITHMS
+            if name in NVCOMP_ALGORITHMS and os.environ.get("RLX_NVCOMP_LZ4_AS_ZPLANE", "0") in ("", "0"):
+                raise ValueError(f"{here}.compression_algorithm={name!r}: the reference's nvCOMP LZ4 container cannot be produced or read by "
+                                 "this gfx950 build. Use 'none' (what a reference peer decodes) or 'rlx_zplane' (both ends run rlinf_amd); "
+                                 "RLX_NVCOMP_LZ4_AS_ZPLANE=1 maps the name to 'rlx_zplane' for configuration files that must stay unchanged.")
+        _refuse_foreign_patch_codecs(val, here)
+
+
 def validate_cfg(cfg) -> DictConfig:
     """Fill defaults and assert consistency; returns the config (rlinf/config.py:1455-1566)."""
     if not isinstance(cfg, DictConfig):
         cfg = DictConfig(cfg)
+    _refuse_foreign_patch_codecs(cfg)
     # rlinf/config.py:1458-1464: per-worker logging defaults the entry point hands to Cluster
     cfg.runner.per_worker_log = cfg.runner.get("per_worker_log", False)
     cfg.runner.per_worker_log_path = None

@@ -248,3 +248,19 @@ def test_zplane_oracle_round_trip_and_known_sizes():
                     assert s.size < d.size / 20
                 if k == 0 and n >= 4096:
                     assert s.size <= 24 + 8 * nb * es + nb * es * 4096
+
+
+def test_validate_cfg_refuses_the_nvcomp_name_at_parse_time(monkeypatch):
+    """The reference's compression name is refused when the configuration is validated (the advisor's round-4 note: it used to
+    surface only when the first patch was built)."""
+    from rlinf_amd.config import _refuse_foreign_patch_codecs
+    cfg = {"actor": {"weight_syncer": {"type": "patch", "patch": {"compression_algorithm": "nvcomp_lz4"}}}}
+    monkeypatch.delenv("RLX_NVCOMP_LZ4_AS_ZPLANE", raising=False)
+    with pytest.raises(ValueError, match="actor.weight_syncer.patch.compression_algorithm"):
+        _refuse_foreign_patch_codecs(cfg)
+    with pytest.raises(ValueError, match="nvCOMP"):
+        _refuse_foreign_patch_codecs({"rollout": {"weight_syncer": {"patch": {"compression": "nvcomp_lz4"}}}})
+    monkeypatch.setenv("RLX_NVCOMP_LZ4_AS_ZPLANE", "1")
+    _refuse_foreign_patch_codecs(cfg)  # the documented opt-in
+    monkeypatch.delenv("RLX_NVCOMP_LZ4_AS_ZPLANE")
+    _refuse_foreign_patch_codecs({"actor": {"weight_syncer": {"patch": {"compression_algorithm": "rlx_zplane"}}, "x": [1, 2]}})

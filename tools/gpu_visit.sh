@@ -33,8 +33,8 @@ for STEP in "$@"; do
       timeout 600 python -m pytest tests/test_gpu_losses.py -x -q -m gpu -k "chunk_level_reward_with_token_level" > gpurun_out/${TAG}_loss_tests.log 2>&1
       echo "rc=$?"; tail -25 gpurun_out/${TAG}_loss_tests.log | cut -c1-300 ;;
     all_tests)
-      timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_pytest_gpu.log 2>&1
-      echo "rc=$?"; tail -5 gpurun_out/${TAG}_pytest_gpu.log ;;
+      timeout 1500 python -m pytest tests -m gpu -x -q --durations=30 > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+      echo "rc=$?"; tail -42 gpurun_out/${TAG}_pytest_gpu.log | cut -c1-180 ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     async_tests)
