@@ -183,6 +183,24 @@ def token_tier_roofline(device, tokens: int = 4096, vocab: int = 151936, iters: 
         rows.append({"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(gbps / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1), "algorithmic_bytes": nbytes,
                      "shape": f"{tokens} tokens x {vocab} vocab, bf16 logits"})
+    # the packed form (round 5): the same pass with the reference's unpack fused into its stores -- rows without a destination
+    # (prompt rows outside the response window, eos fill) are not read, so the algorithmic bytes are those of the rows that are
+    try:
+        from rlinf_amd.hybrid_engines.fsdp.utils import unpack_index_maps
+        seq, prompt = 2048, 256
+        starts = [0] * (tokens // seq)   # (valid columns of every sequence in the unpacked [bsz, seq] matrix: all of them)
+        ends = [seq] * (tokens // seq)
+        lp_dst, ent_dst = unpack_index_maps(starts, ends, tokens, seq, seq - prompt, device)
+        read_rows = int(((lp_dst >= 0) | (ent_dst >= 0)).sum())
+        with torch.no_grad():
+            us = avg_us(lambda: token_ops._PackedLogprobFn.apply(x, labels, lp_dst, ent_dst, len(starts), seq - prompt, 1.0, True, False, False))
+        nb = read_rows * vocab * 2
+        rows.append({"kernel": "token_logprob_fwd_packed (+ entropy, unpack fused)", "bound": "hbm", "achieved": round(nb / us / 1e3, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nb / us / 1e3 / HBM_PEAK_GBPS, 4), "avg_launch_us": round(us, 1),
+                     "algorithmic_bytes": nb, "shape": f"{len(starts)} packed sequences x ({prompt} prompt + {seq - prompt} response) tokens x "
+                     f"{vocab} vocab, bf16 logits: {read_rows} of {tokens} rows have a destination (host-side output allocation included)"})
+    except Exception as e:  # noqa: BLE001 -- a probe must not cost the rows above
+        rows.append({"kernel": "token_logprob_fwd_packed", "error": f"{type(e).__name__}: {e}"[:200]})
     # reasoning GAE along the contiguous axis (12 B/token) and the weight-patch scan (tensor + snapshot read once)
     v = torch.randn(4096, 8192, device=device, generator=g)
     r = torch.randn(4096, device=device, generator=g)
