@@ -195,6 +195,11 @@ for STEP in "$@"; do
         echo "lib=$TAGX: $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_one)" rlx | grep "dw_bf16\|one_launch\|fused_bf16" | awk '{printf "%s med %s min %s | ", substr($2,6,26), $(NF-7), $(NF-6)}')"
         RLX_LIB_TAG=$TAGX timeout 300 python bench.py --steps 60 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   bench', d['ms_per_step'])"
       done; rm -rf gpurun_out/prof_one ;;
+    bench_prof_roofline)
+      rm -rf gpurun_out/prof_bench
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-variants --no-token-tier --no-extras > gpurun_out/${TAG}_bench_prof_roofline.log 2>&1
+      echo "rc=$?"; tail -1 gpurun_out/${TAG}_bench_prof_roofline.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'])"
+      python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_bench)" > gpurun_out/${TAG}_bench_kernels_with_roofline_probe.txt 2>&1; grep -n "gae_scan\|kernel  " gpurun_out/${TAG}_bench_kernels_with_roofline_probe.txt | head -6; rm -rf gpurun_out/prof_bench ;;
     *) echo "unknown step $STEP" ;;
   esac
 done
