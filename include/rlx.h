@@ -301,7 +301,11 @@ typedef struct rlx_adamw_params {
      * from then on owned by the library (one buffer per parameter set; calls that share it must be stream-ordered).  With it
      * rlx_clip_adamw_step runs slab sum + norm + clip + AdamW as ONE launch -- the blocks exchange their norm partials through
      * these words instead of through a launch boundary -- whenever the plan allows it (n % 4 == 0, 16-byte aligned buffers,
-     * one float4 per thread, every workgroup resident); same arithmetic, bit-identical results.  NULL: two launches. */
+     * <= 512 blocks of 2048 parameters, all resident); same element arithmetic (the norm's f64 partials are formed over different
+     * blocks, so its last bit may differ from the two-launch form's).  The launch needs ALL its workgroups resident at once: one
+     * process per GPU.  Should a poll expire anyway (2 s: another process holds part of the device) the step reports a NaN norm,
+     * is skipped, and word 1 of the buffer is set and stays set -- a caller that sees a non-finite norm checks it.  NULL: two
+     * launches. */
     uint64_t* sync_words;
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);
