@@ -102,3 +102,18 @@ def test_batch_iterator_tops_up_small_pieces_only_when_a_global_handler_needs_wh
         merge_batches([{"a": rows}, {"b": rows}])
     with pytest.raises(AssertionError, match="Issue with batch size configuration"):
         list(k_split({"input_ids": rows}, 3))
+
+
+def test_ranks_share_a_device_and_sync_words_switch(monkeypatch):
+    """The one-launch optimizer step needs all its workgroups resident together: a job whose ranks share a GPU does not get it
+    (scheduler.ranks_share_a_device: collective, False for one rank), and RLX_ADAMW_ONE_LAUNCH=0 switches it off everywhere."""
+    from rlinf_amd import ops
+    from rlinf_amd.scheduler import DistContext, ranks_share_a_device
+    assert ranks_share_a_device(DistContext(0, 0, 1, torch.device("cpu"))) is False
+    monkeypatch.setenv("RLX_ADAMW_ONE_LAUNCH", "0")
+    assert ops.adamw_sync_words(1024, "cpu") is None
+    with pytest.raises(ops.RlxError, match="one process per GPU|one-launch optimizer step"):
+        ops.check_adamw_sync(torch.tensor([3, 1, 0], dtype=torch.int64), float("nan"))
+    ops.check_adamw_sync(torch.tensor([3, 0, 0], dtype=torch.int64), float("nan"))   # a real non-finite norm: the step was skipped
+    ops.check_adamw_sync(torch.tensor([3, 1, 0], dtype=torch.int64), 0.25)           # finite norm: nothing is read
+    ops.check_adamw_sync(None, float("inf"))
