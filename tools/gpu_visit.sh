@@ -182,19 +182,6 @@ for STEP in "$@"; do
       for ONE in 0 1; do
         RLX_ADAMW_ONE_LAUNCH=$ONE timeout 300 python bench.py --precision 32 --steps 50 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   f32 bench one_launch=$ONE', d['ms_per_step'])"
       done; rm -rf gpurun_out/prof_one ;;
-    adamw_one_parts)
-      for TAGX in "" x1 x2 x3 ""; do
-        rm -rf gpurun_out/prof_one
-        RLX_LIB_TAG=$TAGX timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_one -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_one_prof.log 2>&1
-        echo "lib=${TAGX:-product}: $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_one)" rlx | grep "dw_bf16\|one_launch\|fused_bf16" | awk '{printf "%s med %s min %s | ", substr($2,6,26), $(NF-7), $(NF-6)}')"
-      done; rm -rf gpurun_out/prof_one ;;
-    ol_variants)
-      for TAGX in ${OL_TAGS:-olv2 ola olb olc old olv2 ola olb olc old}; do
-        rm -rf gpurun_out/prof_one
-        RLX_LIB_TAG=$TAGX timeout 300 rocprofv3 --kernel-trace -d gpurun_out/prof_one -o bench -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-variants --no-extras > gpurun_out/${TAG}_one_prof.log 2>&1
-        echo "lib=$TAGX: $(python tools/rocpd_stats.py "$(prof_db gpurun_out/prof_one)" rlx | grep "dw_bf16\|one_launch\|fused_bf16" | awk '{printf "%s med %s min %s | ", substr($2,6,26), $(NF-7), $(NF-6)}')"
-        RLX_LIB_TAG=$TAGX timeout 300 python bench.py --steps 60 --no-cpu-baseline --no-roofline --no-variants --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   bench', d['ms_per_step'])"
-      done; rm -rf gpurun_out/prof_one ;;
     bench_prof_roofline)
       rm -rf gpurun_out/prof_bench
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic --no-variants --no-token-tier --no-extras > gpurun_out/${TAG}_bench_prof_roofline.log 2>&1
