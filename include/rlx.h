@@ -607,9 +607,15 @@ int rlx_token_logprob_fwd(const void* logits, const int64_t* labels, const rlx_t
  * last response_len columns: lp_dst / ent_dst are that map, flat indices into the [bsz, response_len] outputs, -1 = dropped --
  * note the entropy is NOT shifted, as in the reference).  Outputs must be zero-filled by the caller (pad_val 0).  A row with no
  * destination is not read at all (the prompt tokens: only their last one feeds a response log-prob); lse [n_tokens] is kept per
- * packed row for rlx_token_logprob_bwd, which takes the gathered per-row gradients. */
+ * packed row for the backward.  rlx_token_logprob_bwd_packed is rlx_token_logprob_bwd with the same maps: d_logprob / d_entropy
+ * and the forward's `entropy` are the UNPACKED [bsz, response_len] tensors, row t takes the gradient of the element it fed
+ * (a row that fed none is written as zeros without being read). */
 int rlx_token_logprob_fwd_packed(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const int32_t* lp_dst,
                                  const int32_t* ent_dst, float* logprob, float* entropy, float* lse, rlx_stream_t stream);
+int rlx_token_logprob_bwd_packed(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const float* lse,
+                                 const float* entropy, const int32_t* lp_dst, const int32_t* ent_dst, const float* d_logprob,
+                                 const float* d_entropy, void* d_logits, int64_t d_seq_stride, int64_t d_row_stride,
+                                 rlx_stream_t stream);
 int rlx_token_logprob_bwd(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const float* lse,
                           const float* entropy, const float* d_logprob, const float* d_entropy, void* d_logits,
                           int64_t d_seq_stride, int64_t d_row_stride, rlx_stream_t stream);

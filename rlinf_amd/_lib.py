@@ -210,6 +210,8 @@ PROTOTYPES = {
                                              c_void_p]),
     "rlx_token_logprob_bwd": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_int64, c_int64, c_void_p]),
+    "rlx_token_logprob_bwd_packed": (c_int, [c_void_p, c_void_p, POINTER(TokenRows), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "rlx_token_loss_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "rlx_token_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    POINTER(TokenLossParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -275,13 +275,17 @@ __global__ __launch_bounds__(NT) void token_logprob_fwd_kernel(const T* __restri
 }
 
 // d_logits = (glp * (onehot - p) - gH * p * (log p + H)) / T
-template <typename T, bool ENT, bool SCALE>
+// PACKED: d_logprob / d_entropy / entropy are the UNPACKED [bsz, response_len] tensors and lp_dst / ent_dst the forward's maps --
+// row t takes the upstream gradient of the element it fed (0 where it fed none: the row is then written as zeros unread).
+template <typename T, bool ENT, bool SCALE, bool PACKED = false>
 __global__ __launch_bounds__(NT) void token_logprob_bwd_kernel(const T* logits, const int64_t* __restrict__ labels,
                                                                RowGeom g, const float* __restrict__ lse,
                                                                const float* __restrict__ entropy,
                                                                const float* __restrict__ d_logprob,
                                                                const float* __restrict__ d_entropy, T* d_logits,
-                                                               long long d_seq_stride, long long d_row_stride) {
+                                                               long long d_seq_stride, long long d_row_stride,
+                                                               const int32_t* __restrict__ lp_dst = nullptr,
+                                                               const int32_t* __restrict__ ent_dst = nullptr) {
     constexpr int VEC = Elem<T>::VEC;
     const int tid = threadIdx.x;
     __shared__ float s_xy;
@@ -289,8 +293,13 @@ __global__ __launch_bounds__(NT) void token_logprob_bwd_kernel(const T* logits, 
         const T* base = logits + row_offset(g, row, g.seq_stride, g.row_stride);
         T* out = d_logits + row_offset(g, row, d_seq_stride, d_row_stride);
         const int V = g.vocab;
-        const float glp = d_logprob[row];
-        const float gh = ENT ? d_entropy[row] : 0.f;
+        int dl = (int)row, de = (int)row;
+        if constexpr (PACKED) {
+            dl = lp_dst[row];
+            de = ENT ? ent_dst[row] : -1;
+        }
+        const float glp = (!PACKED || dl >= 0) ? d_logprob[PACKED ? dl : row] : 0.f;
+        const float gh = (ENT && (!PACKED || de >= 0)) ? d_entropy[PACKED ? de : row] : 0.f;
         const bool same_phase = (((uintptr_t)base ^ (uintptr_t)out) & 15u) == 0;
         const int head = same_phase ? min(V, (int)(((16u - (unsigned)((uintptr_t)base & 15u)) & 15u) / sizeof(T))) : V;
         const int nvec = (V - head) / VEC;
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(NT) void token_logprob_bwd_kernel(const T* logits, 
         __syncthreads();  // the label's logit is read before any lane may overwrite it (in-place use)
         const float L = lse[row];
         const float nL2 = -fmul(L, LOG2E);
-        const float H = ENT ? entropy[row] : 0.f;
+        const float H = (ENT && (!PACKED || de >= 0)) ? entropy[PACKED ? de : row] : 0.f;
         const float HmL = H - L;  // log p + H = x + (H - lse)
         const u32x4* vb = reinterpret_cast<const u32x4*>(base + head);
 
@@ -786,18 +795,25 @@ int launch_fwd(const void* logits, const int64_t* labels, const RowGeom& g, floa
 
 template <typename T>
 int launch_bwd(const void* logits, const int64_t* labels, const RowGeom& g, const float* lse, const float* entropy,
-               const float* d_logprob, const float* d_entropy, void* d_logits, long long dss, long long drs, hipStream_t s) {
+               const float* d_logprob, const float* d_entropy, void* d_logits, long long dss, long long drs, hipStream_t s,
+               const int32_t* lp_dst = nullptr, const int32_t* ent_dst = nullptr) {
     const T* x = static_cast<const T*>(logits);
     T* dx = static_cast<T*>(d_logits);
     const dim3 grid(row_grid(g.n_tokens)), block(NT);
     const bool scale = g.temp != 1.0f;
-#define RLX_TOK_BWD(ENT, SCALE)                                                                                         \
-    hipLaunchKernelGGL((token_logprob_bwd_kernel<T, ENT, SCALE>), grid, block, 0, s, x, labels, g, lse, entropy, d_logprob, \
-                       d_entropy, dx, dss, drs)
+#define RLX_TOK_BWD(ENT, SCALE)                                                                                                    \
+    {                                                                                                                              \
+        if (lp_dst != nullptr)                                                                                                     \
+            hipLaunchKernelGGL((token_logprob_bwd_kernel<T, ENT, SCALE, true>), grid, block, 0, s, x, labels, g, lse, entropy,     \
+                               d_logprob, d_entropy, dx, dss, drs, lp_dst, ent_dst);                                               \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((token_logprob_bwd_kernel<T, ENT, SCALE, false>), grid, block, 0, s, x, labels, g, lse, entropy,    \
+                               d_logprob, d_entropy, dx, dss, drs, lp_dst, ent_dst);                                               \
+    }
     if (d_entropy) {
-        if (scale) RLX_TOK_BWD(true, true); else RLX_TOK_BWD(true, false);
+        if (scale) RLX_TOK_BWD(true, true) else RLX_TOK_BWD(true, false)
     } else {
-        if (scale) RLX_TOK_BWD(false, true); else RLX_TOK_BWD(false, false);
+        if (scale) RLX_TOK_BWD(false, true) else RLX_TOK_BWD(false, false)
     }
 #undef RLX_TOK_BWD
     RLX_LAUNCH_CHECK();
@@ -847,6 +863,23 @@ extern "C" int rlx_token_logprob_bwd(const void* logits, const int64_t* labels, 
     return rows->dtype == RLX_DTYPE_BF16
                ? launch_bwd<__bf16>(logits, labels, g, lse, entropy, d_logprob, d_entropy, d_logits, d_seq_stride, d_row_stride, s)
                : launch_bwd<float>(logits, labels, g, lse, entropy, d_logprob, d_entropy, d_logits, d_seq_stride, d_row_stride, s);
+}
+
+extern "C" int rlx_token_logprob_bwd_packed(const void* logits, const int64_t* labels, const rlx_token_rows* rows, const float* lse,
+                                            const float* entropy, const int32_t* lp_dst, const int32_t* ent_dst,
+                                            const float* d_logprob, const float* d_entropy, void* d_logits, int64_t d_seq_stride,
+                                            int64_t d_row_stride, rlx_stream_t stream) {
+    if (int rc = check_rows(rows, "rlx_token_logprob_bwd_packed")) return rc;
+    if (rows->n_tokens == 0) return RLX_OK;
+    RLX_REQUIRE(logits && labels && lse && d_logprob && d_logits && lp_dst, "rlx_token_logprob_bwd_packed: NULL argument");
+    RLX_REQUIRE(d_entropy == nullptr || (entropy != nullptr && ent_dst != nullptr),
+                "rlx_token_logprob_bwd_packed: d_entropy needs the forward's entropy and ent_dst");
+    RLX_REQUIRE(d_row_stride >= rows->vocab, "rlx_token_logprob_bwd_packed: bad d_logits row stride");
+    const RowGeom g = geom_of(rows);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return rows->dtype == RLX_DTYPE_BF16
+               ? launch_bwd<__bf16>(logits, labels, g, lse, entropy, d_logprob, d_entropy, d_logits, d_seq_stride, d_row_stride, s, lp_dst, ent_dst)
+               : launch_bwd<float>(logits, labels, g, lse, entropy, d_logprob, d_entropy, d_logits, d_seq_stride, d_row_stride, s, lp_dst, ent_dst);
 }
 
 extern "C" size_t rlx_token_loss_workspace_bytes(int64_t bsz, int64_t seq) {

@@ -144,30 +144,34 @@ class _PackedLogprobFn(torch.autograd.Function):
                        "rlx_token_logprob_fwd_packed")
         ctx.save_for_backward(logits, lab, lse, lp_dst, ent_dst, entropy if with_entropy else lse)
         ctx.cfg = (float(temperature), bool(with_entropy), bool(inplace_grad))
+        ctx.out_shape = (int(bsz), int(response_len))
         return (logprob, entropy) if with_entropy else (logprob, lse.new_empty(0))
 
     @staticmethod
     def backward(ctx, d_logprob, d_entropy):
         logits, lab, lse, lp_dst, ent_dst, entropy = ctx.saved_tensors
         temperature, with_entropy, inplace = ctx.cfg
-        n = lse.numel()
-        # per packed row: the upstream gradient of the element it fed (0 where it fed nothing: such rows are written as zeros
-        # without being read by the backward kernel)
-        def gather(d_out, dst):
-            if d_out is None:
-                return torch.zeros(n, dtype=torch.float32, device=lse.device)
-            flat = torch.cat([d_out.reshape(-1).float(), d_out.new_zeros(1, dtype=torch.float32)])  # index -1 -> the appended zero
-            return flat[dst.long()]
-        d_lp = gather(d_logprob, lp_dst)
+        dev = logits.device
+        # the upstream gradients stay in their unpacked [bsz, response_len] shape: the kernel follows the forward's maps (a packed row
+        # that fed nothing is written as zeros without being read)
         use_ent = with_entropy and d_entropy is not None
-        ent_rows = d_ent = None
-        if use_ent:
-            d_ent = gather(d_entropy, ent_dst)
-            ent_rows = gather(entropy, ent_dst)  # the forward's entropy of row t (what the backward's entropy term needs)
-        dx = token_logprob_bwd(logits, lab.view(logits.shape[:-1]), lse.view(logits.shape[:-1]), None if ent_rows is None else ent_rows.view(logits.shape[:-1]),
-                               d_lp.view(logits.shape[:-1]), None if d_ent is None else d_ent.view(logits.shape[:-1]), temperature,
-                               out=logits if inplace else None)
-        return dx, None, None, None, None, None, None, None, None, None
+        if d_logprob is None:
+            d_logprob = torch.zeros(ctx.out_shape, dtype=torch.float32, device=dev)
+        x, rows = _rows_of(logits, temperature, False)
+        out = logits if inplace else torch.empty(logits.shape, dtype=logits.dtype, device=dev)
+        if rows.seq_stride == 0:
+            if not out.is_contiguous():
+                raise RlxError("packed scoring needs contiguous logits")
+            dss, drs = 0, rows.vocab
+        else:
+            dss, drs = out.stride(0), out.stride(1)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().rlx_token_logprob_bwd_packed(
+                x.data_ptr(), lab.data_ptr(), byref(rows), lse.data_ptr(), _ptr(entropy if use_ent else None), lp_dst.data_ptr(),
+                _ptr(ent_dst if use_ent else None), _as_f32(d_logprob, "d_logprob").data_ptr(),
+                _ptr(_as_f32(d_entropy, "d_entropy") if use_ent else None), out.data_ptr(), dss, drs, _stream_ptr(dev)),
+                "rlx_token_logprob_bwd_packed")
+        return out, None, None, None, None, None, None, None, None, None
 
 
 def packed_token_logprobs(logits: torch.Tensor, packed_input_ids: torch.Tensor, idx_starts, idx_ends, *, max_seq_len_unpack: int,
