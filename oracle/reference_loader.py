@@ -50,6 +50,15 @@ _FILES_POLICY = [
     ("rlinf.models.embodiment.mlp_policy.mlp_policy", "rlinf/models/embodiment/mlp_policy/mlp_policy.py"),
 ]
 
+# files whose modules cannot be imported here (Ray, FSDP, hydra, omegaconf): single functions / classes of them are compiled
+# on their own (load_function / load_class / load_models_registry); staged so that the -m gpu tests can do the same on the GPU box
+_FILES_SOURCE_ONLY = [
+    "rlinf/config.py",
+    "rlinf/models/__init__.py",
+    "rlinf/workers/actor/embodied_fsdp_actor_worker.py",
+    "rlinf/hybrid_engines/fsdp/fsdp_model_manager.py",
+]
+
 _cache: SimpleNamespace | None = None
 
 
@@ -211,6 +220,58 @@ def load_class(rel_path: str, name: str, **globs):
     ns = dict(globs)
     exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
     return ns[name]
+
+
+_mr_cache = None
+
+
+def load_models_registry():
+    """The reference's MODEL REGISTRY, rlinf/models/__init__.py (register_model / get_model and the built-in registrations),
+    executed as the module ``rlinf.models`` behind a ``rlinf.config`` that holds the REAL ``SupportedModel`` class with all its
+    module-level registrations, ``EMBODIED_MODEL`` / ``DIFFUSION_MODELS`` and ``torch_dtype_from_precision`` -- those top-level
+    statements of rlinf/config.py compiled on their own (the rest of that file needs omegaconf, Ray and the env packages)."""
+    global _mr_cache
+    if _mr_cache is not None:
+        return _mr_cache
+    import ast
+    import dataclasses
+    import typing
+
+    import torch
+
+    load()
+    path = os.path.join(REFERENCE_ROOT, "rlinf/config.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    wanted = ("SupportedModel", "DIFFUSION_MODELS", "EMBODIED_MODEL")
+    keep = []
+    for n in tree.body:
+        if isinstance(n, ast.ClassDef) and n.name == "SupportedModel":
+            keep.append(n)
+        elif isinstance(n, ast.FunctionDef) and n.name == "torch_dtype_from_precision":
+            n.returns = None
+            for a in n.args.args:
+                a.annotation = None
+            keep.append(n)
+        elif isinstance(n, ast.Assign) and any(isinstance(x, ast.Name) and x.id in wanted for t in n.targets for x in ast.walk(t)):
+            keep.append(n)
+    ns = {"dataclasses": dataclasses, "ClassVar": typing.ClassVar, "torch": torch}
+    # dont_inherit: this file's own `from __future__ import annotations` would turn the dataclass's ClassVar annotation into a string
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec", dont_inherit=True), ns)
+    _stub("rlinf.config", _rlx_stub=True, **{k: ns[k] for k in wanted + ("torch_dtype_from_precision",)})
+    if "omegaconf" not in sys.modules:
+        _stub("omegaconf", DictConfig=dict, OmegaConf=type("OmegaConf", (), {}), _rlx_stub=True)
+    sched = sys.modules["rlinf.scheduler"]
+    if not hasattr(sched.Worker, "torch_device_type"):
+        sched.Worker.torch_device_type = "cpu"
+    spec = importlib.util.spec_from_file_location("rlinf.models", os.path.join(REFERENCE_ROOT, "rlinf/models/__init__.py"),
+                                                  submodule_search_locations=[])
+    mod = importlib.util.module_from_spec(spec)
+    mod._rlx_stub = True  # (still not a real install: load() may be called again)
+    sys.modules["rlinf.models"] = mod
+    sys.modules["rlinf"].models = mod
+    spec.loader.exec_module(mod)
+    _mr_cache = SimpleNamespace(models=mod, config=sys.modules["rlinf.config"])
+    return _mr_cache
 
 
 _tb_cache = None

@@ -3,8 +3,10 @@
 RLinf imports the module named by that environment variable in every worker process and calls its
 ``register()`` once (rlinf/scheduler/cluster/utils.py:81-110, invoked from Worker._env_setup_before_init,
 rlinf/scheduler/worker/worker.py:348-394).  ``register()`` re-registers the hot-path names in RLinf's own
-registries -- the last registration wins (rlinf/algorithms/registry.py:33-53) -- so the unmodified
-learner (rlinf/workers/actor/embodied_fsdp_actor_worker.py:286-321,591-700) calls the HIP kernels.
+registries -- the last registration wins (rlinf/algorithms/registry.py:33-53) -- and the ``mlp_policy`` builder in its model
+registry (rlinf/models/__init__.py:31-53, ``force=True``), so the unmodified learner
+(rlinf/workers/actor/embodied_fsdp_actor_worker.py:117-127,286-321,591-700) and rollout worker
+(rlinf/workers/rollout/hf/huggingface_worker.py:137-151,500-530) call the HIP kernels.
 
 Because RLinf's ``policy_loss`` runs preprocess_loss_inputs BEFORE the registered callee and ``.item()``s
 every metric after it, the callees registered here take the already-shaped tensors (sub_per_adv == raw
@@ -93,6 +95,14 @@ def register() -> None:
             metrics["actor/average_version"] = out[DPPO_OUT_NAMES["actor/average_version"]]
             metrics["actor/current_version"] = out.new_tensor(float(cur))
         return loss, metrics
+
+    # the model leg (rlinf/models/__init__.py:31-53): cfg.actor.model.model_type == "mlp_policy" now builds the HIP module in
+    # the learner (embodied_fsdp_actor_worker.py:117-127) and in the rollout worker (huggingface_worker.py:137-151)
+    from rlinf import models as ref_models
+
+    from rlinf_amd.models.embodiment.mlp_policy_module import build_reference_named_mlp_policy
+
+    ref_models.register_model("mlp_policy", build_reference_named_mlp_policy, category="embodied", force=True)
 
     ref_registry.register_policy_loss("actor_critic")(_shaped_loss(True))
     ref_registry.register_policy_loss("actor")(_shaped_loss(False))

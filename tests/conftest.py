@@ -11,6 +11,15 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+def free_port() -> int:
+    """A free TCP port on 127.0.0.1 (one-rank gloo groups of the reference-side tests; fixed ports collide under pytest -n)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
     config.addinivalue_line("markers", "reference: needs the reference tree under /root/reference")

@@ -4,6 +4,8 @@ no oracle in between.  Runs where /root/reference exists."""
 import pytest
 import torch
 
+from conftest import free_port
+
 from rlinf_amd.algorithms import utils as AU
 from rlinf_amd.utils import utils as UU
 
@@ -173,7 +175,7 @@ def test_dynamic_batch_split_matches_the_reference(ref, seed):
     it_py = "rlinf/utils/data_iter_utils.py"
     started = not dist.is_initialized()
     if started:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29639", rank=0, world_size=1)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
     try:
         class CpuTorch:
             def __getattr__(self, name):

@@ -9,7 +9,7 @@ import copy
 import pytest
 import torch
 
-from conftest import synth_rollout
+from conftest import free_port, synth_rollout
 from oracle import ppo_oracle as O
 
 pytestmark = pytest.mark.reference
@@ -541,7 +541,7 @@ def test_rollout_metrics(ref, masked, monkeypatch):
     monkeypatch.setitem(sys.modules, "rlinf.scheduler.worker.worker", wmod)
     started = False
     if not dist.is_initialized():
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
         started = True
     try:
         g = torch.Generator().manual_seed(3)

@@ -17,6 +17,8 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 import torch
+
+from conftest import free_port
 import torch.distributed as dist
 
 from oracle import ppo_loop as L
@@ -29,11 +31,14 @@ class Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-def _learner(ref, policy, batch, *, global_batch, micro_batch, update_epoch, entropy_bonus, critic_warmup_steps, auto_reset):
+def _learner(ref, policy, batch, *, global_batch, micro_batch, update_epoch, entropy_bonus, critic_warmup_steps, auto_reset,
+             device="cpu"):
+    """``device="cuda"`` (tests/test_gpu_ext_model_registry.py): the same stand-in learner with the reference's own
+    put_tensor_device moving every micro-batch to the accelerator, as the real worker does (embodied_fsdp_actor_worker.py:598)."""
     from oracle import reference_loader as R
     mu, utils, nested = ref.metric_utils, ref.utils, ref.nested
-    worker_stub = SimpleNamespace(torch_device_type="cpu", timer=lambda *_a, **_k: (lambda f: f),
-                                  torch_platform=SimpleNamespace(current_device=lambda: torch.device("cpu"), is_available=lambda: False))
+    worker_stub = SimpleNamespace(torch_device_type=device, timer=lambda *_a, **_k: (lambda f: f),
+                                  torch_platform=SimpleNamespace(current_device=lambda: torch.device(device), is_available=lambda: False))
     models = SimpleNamespace(OPENVLA="openvla", OPENVLA_OFT="openvla_oft", GR00T="gr00t", GR00T_N1D6="gr00t_n1d6",
                              GR00T_N1D7="gr00t_n1d7", ABOT_M0="abot_m0")
     supported = type("SupportedModel", (), {"__new__": staticmethod(lambda cls, name: name), **vars(models)})
@@ -46,7 +51,8 @@ def _learner(ref, policy, batch, *, global_batch, micro_batch, update_epoch, ent
         compute_critic_explained_variance_from_stats=mu.compute_critic_explained_variance_from_stats,
         CRITIC_EXPLAINED_VARIANCE_KEY=mu.CRITIC_EXPLAINED_VARIANCE_KEY)
     train_micro_batch = R.load_function(
-        actor_py, "EmbodiedFSDPActor.train_micro_batch", torch=torch, put_tensor_device=lambda d, _dev: d, SupportedModel=supported,
+        actor_py, "EmbodiedFSDPActor.train_micro_batch", torch=torch,
+        put_tensor_device=(lambda d, _dev: d) if device == "cpu" else nested.put_tensor_device, SupportedModel=supported,
         policy_loss=ref.registry.policy_loss, Worker=worker_stub, reshape_entropy=utils.reshape_entropy, masked_mean=utils.masked_mean,
         append_to_dict=mu.append_to_dict)
     optimizer_step = R.load_function(manager_py, "FSDPModelManager.optimizer_step", torch=torch)
@@ -62,7 +68,7 @@ def _learner(ref, policy, batch, *, global_batch, micro_batch, update_epoch, ent
                                        model=Cfg(model_type="mlp_policy", action_dim=8)))
     me = SimpleNamespace(
         cfg=cfg, _cfg=Cfg(optim=optim, fsdp_config={"sharding_strategy": "no_shard"}), model=policy, rollout_batch=batch, _rank=0,
-        _world_size=1, device="cpu", is_weight_offloaded=False, is_optimizer_offloaded=False, enable_sft_co_train=False,
+        _world_size=1, device=device, is_weight_offloaded=False, is_optimizer_offloaded=False, enable_sft_co_train=False,
         gradient_accumulation=global_batch // micro_batch, optimizer_steps=0, critic_warmup_steps=critic_warmup_steps,
         amp_context=contextlib.nullcontext(), before_micro_batch=lambda *_a, **_k: contextlib.nullcontext(),
         torch_platform=SimpleNamespace(empty_cache=lambda: None), store_requires_grad_param_name=[],
@@ -83,7 +89,7 @@ def _learner(ref, policy, batch, *, global_batch, micro_batch, update_epoch, ent
 def one_rank_group():
     started = not dist.is_initialized()
     if started:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29633", rank=0, world_size=1)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
     yield
     if started:
         dist.destroy_process_group()

@@ -15,6 +15,8 @@ from types import SimpleNamespace
 
 import pytest
 import torch
+
+from conftest import free_port
 import torch.distributed as dist
 
 from oracle import token_loop as TL
@@ -33,7 +35,7 @@ class Cfg(dict):
 def one_rank_group():
     started = not dist.is_initialized()
     if started:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29637", rank=0, world_size=1)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
     yield
     if started:
         dist.destroy_process_group()
