@@ -399,12 +399,11 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         w = runner.actor.worker
-        # who actually took part: ranks from the process group, physical devices from every rank's (host, device uuid)
+        # who actually took part: ranks from the process group, physical devices from every rank's (host, PCI location)
         ranks_seen, devices_seen = 1, 1
         if world > 1:
-            import socket
-            props = torch.cuda.get_device_properties(dev)
-            ident = (socket.gethostname(), str(getattr(props, "uuid", dev.index)))
+            from rlinf_amd.scheduler.dist import device_identity
+            ident = device_identity(dev)
             idents = [None] * world
             dist.all_gather_object(idents, ident)
             ranks_seen, devices_seen = dist.get_world_size(), len(set(idents))

@@ -302,10 +302,13 @@ typedef struct rlx_adamw_params {
      * rlx_clip_adamw_step runs slab sum + norm + clip + AdamW as ONE launch -- the blocks exchange their norm partials through
      * these words instead of through a launch boundary -- whenever the plan allows it (n % 4 == 0, 16-byte aligned buffers,
      * <= 512 blocks of 2048 parameters, all resident); same element arithmetic (the norm's f64 partials are formed over different
-     * blocks, so its last bit may differ from the two-launch form's).  The launch needs ALL its workgroups resident at once: one
-     * process per GPU.  Should a poll expire anyway (2 s: another process holds part of the device) the step reports a NaN norm,
-     * is skipped, and word 1 of the buffer is set and stays set -- a caller that sees a non-finite norm checks it.  NULL: two
-     * launches. */
+     * blocks, so its last bit may differ from the two-launch form's).  The launch needs ALL its workgroups resident at once; the
+     * library takes the bound against the compute units the launch stream may use (hipExtStreamGetCUMask) and falls back to two
+     * launches when they cannot hold the plan, but it cannot see what ANOTHER process or stream holds.  Should a poll expire for
+     * that reason (2 s) the step is skipped as a whole and word 1 of the buffer is set and STAYS set: every later call on these
+     * words reports a NaN norm and skips as a whole too (no block ever applies an update another block skipped), until the
+     * caller -- who sees the non-finite norm, reads word 1 and finds it set -- passes NULL from then on (what rlinf_amd.ops.
+     * check_adamw_sync makes the learners do) or zeroes the buffer to try again.  NULL: two launches. */
     uint64_t* sync_words;
 } rlx_adamw_params;
 size_t rlx_adamw_workspace_bytes(int64_t n);

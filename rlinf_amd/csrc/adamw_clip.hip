@@ -587,6 +587,7 @@ struct OneLaunchArgs {
     unsigned long long* sync;
     DeferredScale dfr;
     SegPlan plan;
+    long long poll_ticks;  // bound of the exchange's poll in 100 MHz ticks (2 s; RLX_ONE_LAUNCH_POLL_MS shortens it for the expiry tests)
 };
 template <bool DEFER, int SB>
 __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(OneLaunchArgs k) {  // (4 waves per SIMD = two blocks per CU: <= 128 VGPRs)
@@ -609,6 +610,12 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
 #endif
     RLX_OL_STAMP(0);
     const unsigned e1 = (unsigned)__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // sync[1], sticky: the exchange of an EARLIER launch on these words expired.  Every launch since then skips AS A WHOLE -- each
+    // block reads the word here, before anything else, and it was set before this launch started -- so slots left behind by
+    // blocks that arrived late (with tags of an epoch they should not have) are never taken for partials, and the parameters
+    // stay exactly as the last complete step left them until the host has seen the word (ops.check_adamw_sync: two launches from
+    // then on).
+    const bool poisoned = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
     // step count: the two-launch form folds the previous call's "applied" flag in its first launch; here every wave folds it
     // for itself (both words are stable until block 0 writes them back, which it does behind the exchange)
     int st0 = 0, st1 = 0;
@@ -652,11 +659,16 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
         if (lane + 64 * u < nparts) pending |= 1u << u;
     }
     AdamScalars& sc = s_sc;
-    bool expired = false;
+    bool expired = poisoned;
+    if (poisoned) pending = 0;
     if (threadIdx.x < 64) {
         const long long t0 = wall_clock64();
         for (int spins = 0; pending != 0; ++spins) {
             unsigned long long lo[8], hi[8];
+            // (every polling lane reads the sticky word with its slots -- one address, one request per wave, no latency of its own:
+            // a block whose poll expires sets it, and a block still polling then gives up with it instead of completing on partials
+            // it already holds and applying an update the expired block skipped)
+            const unsigned long long stick = __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (pending & (1u << u)) {
@@ -671,8 +683,12 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
                     pv[u] = __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xffffffffull)));
                     pending &= ~(1u << u);
                 }
+            if (stick != 0ull) {
+                expired = true;
+                break;
+            }
             if (pending != 0 && spins > 16) {
-                if (wall_clock64() - t0 > 200000000ll) {  // 2 s at 100 MHz: a block of this launch never became resident
+                if (wall_clock64() - t0 > k.poll_ticks) {  // (2 s at 100 MHz: a block of this launch never became resident)
                     expired = true;
                     break;
                 }
@@ -695,14 +711,20 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
     if (a.max_grad_norm > 0.f) coef = fminf(a.max_grad_norm / (total_norm + 1e-6f), 1.0f);  // clip_grad_norm_
     const bool skip = !isfinite(total_norm) ||
                       (k.status != nullptr && __hip_atomic_load(k.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
-    if (threadIdx.x == 0 && (blockIdx.x == 0 || any_expired)) {
-        if (any_expired) __hip_atomic_store(&sync[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: the host raises
+    if (threadIdx.x == 0 && any_expired && !poisoned) {
+        // the sticky word first (pollers watch it), then this block's own slot again with a NaN payload: a block that becomes resident
+        // only now and finds every slot published still forms a non-finite norm and skips with the rest
+        __hip_atomic_store(&sync[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long nan_bits = 0x7ff8000000000000ull, tag = (unsigned long long)e1 << 32;
+        unsigned long long* slot = sync + kSyncSlot0 + kSlotStride * (size_t)blockIdx.x;
+        __hip_atomic_store(slot, tag | (nan_bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 1, tag | (nan_bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) {  // (ONE writer of the step's stats: an expiry elsewhere is the sticky word's to report)
         k.stats[0] = total_norm;
         k.stats[1] = skip ? 0.f : 1.f;
-        if (blockIdx.x == 0) {
-            if (k.state != nullptr) k.state[0] = steps_done, k.state[1] = skip ? 0 : 1;
-            __hip_atomic_store(&sync[0], (unsigned long long)e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (k.state != nullptr) k.state[0] = steps_done, k.state[1] = skip ? 0 : 1;
+        __hip_atomic_store(&sync[0], (unsigned long long)e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     RLX_OL_STAMP(4);
     apply_seg_block(p, g, m, v, sb, p4, g4, m4, v4, coef, skip, sc, a, k.lay, k.tiles, s_t);
@@ -841,9 +863,38 @@ rlx_adamw_params tile_format_resolved(const rlx_adamw_params* p, const float* ti
     if (tiles != nullptr && k.tiles_bf16 == 0 && ::rlx::step::f32_split()) k.tiles_bf16 = 2;
     return k;
 }
-// How many blocks of the one-launch kernel can be resident together on this device?  (Asked once; the answer is for a stream
-// that may use every CU -- a CU-masked stream shrinks it, and the kernel's own bound then reports instead of hanging.)
-int one_launch_capacity() {
+// Compute units a stream may dispatch to: hipExtStreamCreateWithCUMask streams (utils/streams.py) see a subset, and the
+// one-launch kernel's residency bound has to be taken against THAT.  Not asked while the stream is capturing (a query on a
+// capturing stream may invalidate the capture; graphs are captured on ordinary streams).
+int stream_cus(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s != nullptr && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) {
+        (void)hipGetLastError();
+        return num_cu();
+    }
+    if (s == nullptr) return num_cu();
+    uint32_t mask[32] = {0};
+    if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return num_cu();
+    }
+    int n = 0;
+    for (uint32_t w : mask) n += __builtin_popcount(w);
+    return n > 0 ? std::min(n, num_cu()) : num_cu();
+}
+// Test hooks of the expiry path (tests/test_gpu_losses.py::test_one_launch_expiry_*), read at every launch: the poll's bound in ms
+// (default 2000), and "launch even though the stream cannot hold every block" -- which is how a test gets a poll to expire.
+long long one_launch_poll_ticks() {  // 100 MHz ticks
+    const char* e = getenv("RLX_ONE_LAUNCH_POLL_MS");
+    const long long ms = (e != nullptr && atoll(e) > 0) ? atoll(e) : 2000ll;
+    return ms * 100000ll;
+}
+bool one_launch_ignores_capacity() {
+    const char* e = getenv("RLX_ONE_LAUNCH_TEST_OVERSUBSCRIBE");
+    return e != nullptr && e[0] == '1';
+}
+// How many blocks of the one-launch kernel can be resident together on ONE compute unit?  (Asked once per process.)
+int one_launch_blocks_per_cu() {
     static const int capacity = [] {
         int best = 1 << 30;
         const void* kernels[4] = {(const void*)reduce_clip_adamw_one_launch<false, 9>, (const void*)reduce_clip_adamw_one_launch<false, 24>,
@@ -853,10 +904,14 @@ int one_launch_capacity() {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kOneThreads, 0) != hipSuccess) return 0;
             best = std::min(best, per_cu);
         }
-        return std::min(best * num_cu(), kMaxOneBlocks);
+        return best;
     }();
     return capacity;
 }
+// ... and on the compute units THIS stream may use (an unmasked stream: the whole device).  The bound is against an otherwise idle
+// device: what another process or another stream holds is not visible from here -- for that case the kernel's poll is bounded
+// and its expiry is sticky (see the kernel), and ranks of one job that share a GPU do not use the form at all.
+int one_launch_capacity(hipStream_t s) { return std::min(one_launch_blocks_per_cu() * stream_cus(s), kMaxOneBlocks); }
 // Blocks of 2048 parameters dealt out segment by segment; with a bf16 / three-plane weight image to keep, every 256 x 256 hidden
 // matrix of the layout is a segment of its own (see the kernel).  nblk == 0: the layout is not one this plan understands.
 SegPlan plan_segments(long long n4, const rlx_mlp_layout* lay, bool image) {
@@ -970,13 +1025,13 @@ int launch_reduce_clip_adamw(float* params, const ReduceSrc& src, float* out, fl
          reinterpret_cast<uintptr_t>(tiles)) % 16 == 0) {
         const rlx_adamw_params k = tile_format_resolved(p, tiles);
         const SegPlan sp = plan_segments(n / 4, &lay, tiles != nullptr && k.tiles_bf16 != 0);
-        if (sp.nblk >= 1 && sp.nblk <= one_launch_capacity()) {
+        if (sp.nblk >= 1 && (sp.nblk <= one_launch_capacity(s) || one_launch_ignores_capacity())) {
             unsigned long long* sync = reinterpret_cast<unsigned long long*>(p->sync_words);
             const int per_group = defer ? src.nslab / p->deferred_groups : src.nslab;
             const DeferredScale dfr = defer ? deferred_of(p) : DeferredScale{};
             OneLaunchArgs oa{};
             oa.src = src, oa.p = params, oa.g = out, oa.m = exp_avg, oa.v = exp_avg_sq, oa.n4 = n / 4, oa.scale = p->grad_scale, oa.a = k;
-            oa.stats = stats, oa.state = step_state, oa.lay = lay, oa.tiles = tiles, oa.status = status, oa.sync = sync, oa.dfr = dfr, oa.plan = sp;
+            oa.stats = stats, oa.state = step_state, oa.lay = lay, oa.tiles = tiles, oa.status = status, oa.sync = sync, oa.dfr = dfr, oa.plan = sp, oa.poll_ticks = one_launch_poll_ticks();
 #define RLX_ONE_LAUNCH(DEFER_, SB_) \
     hipLaunchKernelGGL((reduce_clip_adamw_one_launch<DEFER_, SB_>), dim3(sp.nblk), dim3(kOneThreads), 0, s, oa)
             if (defer) {

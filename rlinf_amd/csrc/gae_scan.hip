@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NSEG) void gae_scan_c1(GaeArgs a) {
                 ld<VEC, NT>(a.r + t * B + e0, bt.r[u]);
                 if constexpr (critic) ld<VEC, NT>(a.v + t * B + e0, bt.v[u]);
                 bt.dn[u] = ldb<VEC, NT && !PAIR>(a.d + (t + 1) * B + e0);
-                if constexpr (MASK) bt.mk[u] = ldb<VEC, NT>(a.m + t * B + e0);
+                if constexpr (MASK) bt.mk[u] = ldb<VEC, NT && !PAIR>(a.m + t * B + e0);  // (a 64-byte row like `done`: see PAIR)
                 else bt.mk[u] = 0x01010101u;
             }
         };
@@ -575,11 +575,34 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, const uint
 }
 
 // which = 0: use {sum_adv, sumsq_adv}; which = 1: {sum_ret, sumsq_ret}.
+// A read-modify-write stream behind a small reduction.  A thread owns kStdU float4s per sweep and ALL of a sweep's loads are issued
+// before anything else -- in front of the reduction of the moment partials, whose latency (a few L2 round trips and two barriers)
+// then passes while the first sweep's data is in flight; round 5's form (load -> divide -> store, one float4 at a time, behind
+// the reduction) left every wave with one request in flight: 3.8 TB/s.  NT: the array is streamed once and far larger than the
+// caches (the 65 536-env shape) -> non-temporal both ways; the contract shape lives in L2 and uses ordinary accesses.
+template <bool NT, int kStdU>
 __global__ __launch_bounds__(256) void standardize_kernel(float* x, size_t n, const double* partials, int nparts,
                                                           int which, float eps) {
     __shared__ double s_red[3 * 4];
     __shared__ float s_mean, s_den;
     __shared__ int s_skip;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const size_t n4 = (reinterpret_cast<uintptr_t>(x) % 16 == 0) ? n / 4 : 0;
+    v4f* x4 = reinterpret_cast<v4f*>(x);
+    const size_t sweep = (size_t)gridDim.x * 256 * kStdU;
+    size_t bb = (size_t)blockIdx.x * 256 * kStdU;  // a block's sweep is one contiguous 16 KiB run; thread t owns float4s bb + t + 256 u
+    v4f q[kStdU];
+    auto load_sweep = [&](size_t b) {
+#pragma unroll
+        for (int u = 0; u < kStdU; ++u) {
+            const size_t i = b + threadIdx.x + (size_t)u * 256;
+            if (i < n4) {
+                if constexpr (NT) q[u] = __builtin_nontemporal_load(x4 + i);
+                else q[u] = x4[i];
+            }
+        }
+    };
+    load_sweep(bb);
     double acc[3] = {0.0, 0.0, 0.0};
     for (int p = threadIdx.x; p < nparts; p += blockDim.x) {
         acc[0] += partials[(size_t)p * 5 + 0];
@@ -598,19 +621,37 @@ __global__ __launch_bounds__(256) void standardize_kernel(float* x, size_t n, co
     __syncthreads();
     if (s_skip) return;
     const float mean = s_mean, den = s_den;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t n4 = (reinterpret_cast<uintptr_t>(x) % 16 == 0) ? n / 4 : 0;
-    float4* x4 = reinterpret_cast<float4*>(x);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 q = x4[i];
-        q.x = fsub(q.x, mean) / den;
-        q.y = fsub(q.y, mean) / den;
-        q.z = fsub(q.z, mean) / den;
-        q.w = fsub(q.w, mean) / den;
-        x4[i] = q;
+    // a / den with the reciprocal hoisted out of the stream: y = RN(1 / den), q0 = RN(a y), one residual step q = fma(fma(-q0,
+    // den, a), y, q0) -- Markstein's correction: the correctly rounded quotient unless den's significand is all ones (then at most
+    // one ulp off); 4 VALU operations per element instead of the division sequence's ~12, which at 16-32 elements per lane was
+    // a measurable share of the launch (14.4 -> 13.6 us at 65 536 x 128).
+    const float rden = 1.0f / den;
+    auto quot = [&](float a) -> float {
+        const float q0 = a * rden;
+        return __builtin_fmaf(__builtin_fmaf(-q0, den, a), rden, q0);
+    };
+    for (; bb < n4; bb += sweep) {
+        v4f r[kStdU];
+#pragma unroll
+        for (int u = 0; u < kStdU; ++u) {
+            r[u].x = quot(fsub(q[u].x, mean));
+            r[u].y = quot(fsub(q[u].y, mean));
+            r[u].z = quot(fsub(q[u].z, mean));
+            r[u].w = quot(fsub(q[u].w, mean));
+        }
+        if (bb + sweep < n4) load_sweep(bb + sweep);  // the next sweep's loads in front of this sweep's stores
+#pragma unroll
+        for (int u = 0; u < kStdU; ++u) {
+            const size_t i = bb + threadIdx.x + (size_t)u * 256;
+            if (i < n4) {
+                if constexpr (NT) __builtin_nontemporal_store(r[u], x4 + i);
+                else x4[i] = r[u];
+            }
+        }
     }
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        x[i] = fsub(x[i], mean) / den;
+        x[i] = quot(fsub(x[i], mean));
 }
 
 constexpr int kMaxParts = 4096;
@@ -661,6 +702,9 @@ int dispatch_c1(const GaeArgs& a, hipStream_t s, int nblk, int rows = 8, bool nt
 #endif
             if (rows == 64) return launch_c1<1, 1, 64, true, true, false, true>(a, s, nblk);  // the measured-best streaming scan (auto at HBM sizes)
         }
+        // ... and with a loss mask (round 6): the same streaming form at 32 rows per register batch -- the mask byte is a fourth
+        // register per row, and two 64-row batches of four would not fit the register file
+        if (critic && mask && rows == 64 && nt) return launch_c1<1, 1, 32, true, true, true, true>(a, s, nblk);
     }
     if (critic && !mask) return launch_c1<1, NSEG, 8, false, true, false>(a, s, nblk);
     if (critic && mask) return launch_c1<1, NSEG, 8, false, true, true>(a, s, nblk);
@@ -697,10 +741,19 @@ int dispatch_regseg(const GaeArgs& a, hipStream_t s) {
 
 #endif  // RLX_DEV_VARIANTS
 
-int standardize_grid(size_t n) {
-    const long long want = (long long)((n / 4 + 255) / 256);
-    const long long cap = (long long)num_cu() * 8;
+int standardize_grid(size_t n, int u, int per_cu) {
+    const long long want = (long long)((n / 4 + 256 * u - 1) / (256 * u));
+    const long long cap = (long long)num_cu() * per_cu;
     return (int)std::max<long long>(1, std::min(want, cap));
+}
+// (x - mean) / (std + eps) in place from the moment partials.  Arrays beyond the caches are streamed non-temporally, eight float4s
+// per lane and sweep on four blocks per CU (rocprofv3 medians at 65 536 x 128, profiles/r06_standardize_sweep.txt: 13.6 us against
+// 14.4-14.8 for four float4s on eight blocks, 16.3 for two; round 5's unbatched loop: 17.5).
+void launch_standardize(float* x, size_t n, const double* partials, int nparts, int which, float eps, hipStream_t s) {
+    if (n * sizeof(float) > ((size_t)16 << 20))
+        hipLaunchKernelGGL((standardize_kernel<true, 8>), dim3(standardize_grid(n, 8, 4)), dim3(256), 0, s, x, n, partials, nparts, which, eps);
+    else
+        hipLaunchKernelGGL((standardize_kernel<false, 4>), dim3(standardize_grid(n, 4, 8)), dim3(256), 0, s, x, n, partials, nparts, which, eps);
 }
 
 }  // namespace
@@ -773,7 +826,7 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         if (p->variant == 0 && nseg == 1 && a.T >= 128 && a.T % 64 == 0 && ceil_div(batch, 64) >= 4 * num_cu()) {
             // HBM-regime sweep (profiles/r01_gae_hbm_sweep_stream.txt): with the buffer far larger than the caches, 64-row
             // register batches (two of them = a 128-step trajectory entirely in flight) + nontemporal accesses is the
-            // fastest streaming variant (60.5 % of 8 TB/s vs 58 %); it only exists for the critic / no-mask case
+            // fastest streaming variant (60.5 % of 8 TB/s vs 58 %); critic only (with a loss mask: 32-row batches, dispatch_c1)
             rows_sel = 64;
             nt_sel = true;
         }
@@ -849,13 +902,11 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
         }
     }
     if (p->normalize_advantages) {
-        hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, advantages, n,
-                           a.partials, nblk, 0, p->norm_eps);
+        launch_standardize(advantages, n, a.partials, nblk, 0, p->norm_eps, s);
         RLX_LAUNCH_CHECK();
     }
     if (p->normalize_returns) {
-        hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, returns, n, a.partials,
-                           nblk, 1, p->norm_eps);
+        launch_standardize(returns, n, a.partials, nblk, 1, p->norm_eps, s);
         RLX_LAUNCH_CHECK();
     }
     return RLX_OK;
@@ -875,7 +926,7 @@ extern "C" int rlx_masked_standardize(float* x, const uint8_t* mask, size_t n, f
     double* partials = static_cast<double*>(workspace);
     hipLaunchKernelGGL(moments_kernel, dim3(nblk), dim3(256), 0, s, x, mask, n, partials);
     RLX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(standardize_kernel, dim3(standardize_grid(n)), dim3(256), 0, s, x, n, partials, nblk, 0, eps);
+    launch_standardize(x, n, partials, nblk, 0, eps, s);
     RLX_LAUNCH_CHECK();
     return RLX_OK;
 }

@@ -24,18 +24,29 @@ def prepare_pack_fsdp(m_batch, max_prompt_len: int):
     return idx_starts, idx_ends
 
 
+def _packed_rows(idx_starts: Sequence[int], idx_ends: Sequence[int], device):
+    """For every position of the packed stream (the windows back to back): (row, column in that row), built on ``device`` from the two
+    window lists -- one small host-to-device copy of the 2 x bsz window bounds, no per-row aranges, no blocking gather."""
+    a = torch.tensor([int(x) for x in idx_starts], dtype=torch.int64)
+    b = torch.tensor([int(x) for x in idx_ends], dtype=torch.int64)
+    lens = b - a
+    total = int(lens.sum())
+    bounds = torch.stack([a, lens, torch.cumsum(lens, 0) - lens]).to(device, non_blocking=True)
+    a_d, lens_d, cu_d = bounds[0], bounds[1], bounds[2]
+    row = torch.repeat_interleave(torch.arange(a.numel(), dtype=torch.int64, device=device), lens_d, output_size=total)
+    col = torch.arange(total, dtype=torch.int64, device=device) - cu_d[row] + a_d[row]
+    return row, col, total
+
+
 def pack_sequences(input_tensor: torch.Tensor, idx_starts: Sequence[int], idx_ends: Sequence[int], max_seq_len: int, pad_val,
                    pad_to_fixed_len: bool = False) -> torch.Tensor:
     """:812-855: the windows back to back (1-D); ``pad_to_fixed_len`` pads the end to ``max_seq_len`` with ``pad_val``.  One gather
-    instead of bsz slices + cat."""
+    instead of bsz slices + cat, its index built on the tensor's device."""
     assert input_tensor.dim() == 2
     assert input_tensor.shape[0] == len(idx_starts) == len(idx_ends)
-    total = sum(idx_ends) - sum(idx_starts)
+    row, col, total = _packed_rows(idx_starts, idx_ends, input_tensor.device)
     assert total <= max_seq_len
-    S = input_tensor.shape[1]
-    pieces = [torch.arange(i * S + a, i * S + b, dtype=torch.int64) for i, (a, b) in enumerate(zip(idx_starts, idx_ends))]
-    src = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.int64)
-    out = input_tensor.reshape(-1)[src.to(input_tensor.device)]
+    out = input_tensor.reshape(-1)[row * input_tensor.shape[1] + col]
     if pad_to_fixed_len and max_seq_len > total:
         out = torch.cat([out, torch.full((max_seq_len - total,), pad_val, dtype=input_tensor.dtype, device=input_tensor.device)])
     return out
@@ -55,21 +66,16 @@ def unpack_index_maps(idx_starts: Sequence[int], idx_ends: Sequence[int], packed
     right by one before scattering, so row t feeds packed position t + 1 --, ``ent_dst[t]``: where row t's entropy lands (not
     shifted: ``unpack_sequences(entropy, ...)``, fsdp_actor_worker.py:497-501).  Flat indices into [bsz, response_len]; -1 = the
     value is dropped (left of the response window, or padding of a fixed-length pack)."""
-    lp = torch.full((packed_len,), -1, dtype=torch.int32)
-    ent = torch.full((packed_len,), -1, dtype=torch.int32)
     first_col = max_seq_len_unpack - response_len
-    cu = 0
-    for i, (a, b) in enumerate(zip(idx_starts, idx_ends)):
-        lo = max(a, first_col)  # first kept column of this row
-        if b > lo:
-            cols = torch.arange(lo, b, dtype=torch.int64)
-            pos = cu + (cols - a)                       # packed position that lands on column `cols` of row i
-            dst = (i * response_len + (cols - first_col)).to(torch.int32)
-            ent[pos] = dst
-            keep = pos >= 1                              # packed position 0 holds the prepended zero
-            lp[pos[keep] - 1] = dst[keep]
-        cu += b - a
-    return lp.to(device), ent.to(device)
+    row, col, total = _packed_rows(idx_starts, idx_ends, device)
+    keep = col >= first_col                                   # columns left of the response window are dropped
+    dst = torch.where(keep, row * response_len + (col - first_col), torch.full_like(col, -1)).to(torch.int32)
+    lp = torch.full((packed_len,), -1, dtype=torch.int32, device=device)
+    ent = torch.full((packed_len,), -1, dtype=torch.int32, device=device)
+    ent[:total] = dst
+    if total > 1:
+        lp[:total - 1] = dst[1:]                              # packed position p >= 1 is fed by row p - 1 (position 0: the prepended zero)
+    return lp, ent
 
 
 def get_seqlen_bfd_partitions(seq_len_list: Sequence[int], max_tokens_per_mbs: int) -> list:

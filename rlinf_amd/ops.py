@@ -620,16 +620,22 @@ def adamw_sync_words(n: int, device) -> Optional[torch.Tensor]:
     return torch.zeros((int(_lib.load().rlx_adamw_sync_words(int(n))),), dtype=torch.int64, device=device)
 
 
-def check_adamw_sync(sync: Optional[torch.Tensor], grad_norm: float):
-    """Call with a step's gradient norm once it is on the host: a NON-FINITE norm is either a real one (the step was skipped, like the
-    reference's) or the one-launch optimizer step reporting that one of its workgroups never became resident within its 2 s
-    bound (word 1 of the sync buffer, sticky) -- the GPU is shared with another process that holds part of it.  That raises."""
+def check_adamw_sync(sync: Optional[torch.Tensor], grad_norm: float) -> bool:
+    """Call with a step's gradient norm once it is on the host.  A NON-FINITE norm is either a real one (the step was skipped, like
+    the reference's) or the one-launch optimizer step reporting that one of its workgroups never became resident within its 2 s
+    bound (word 1 of the sync buffer, sticky) -- another process or stream holds part of the GPU.  Steps since then were skipped
+    as a whole (the kernel reads the word first thing), so the parameters are those of the last complete step.  Returns True in
+    that case, after a warning: the caller drops ``sync`` (and whatever captured its pointer) and continues on two launches."""
     import math
     if sync is None or math.isfinite(grad_norm):
-        return
-    if int(sync[1].item()) != 0:
-        raise RlxError("the one-launch optimizer step timed out waiting for its own workgroups: another process holds part of this GPU. "
-                       "Steps since then were skipped. Run one process per GPU, or set RLX_ADAMW_ONE_LAUNCH=0 (two launches).")
+        return False
+    if int(sync[1].item()) == 0:
+        return False
+    import warnings
+    warnings.warn("the one-launch optimizer step timed out waiting for its own workgroups (another process or stream holds part of "
+                  "this GPU); the optimizer steps since then were skipped. Continuing with the two-launch form "
+                  "(RLX_ADAMW_ONE_LAUNCH=0 selects it from the start).", RuntimeWarning, stacklevel=2)
+    return True
 
 
 def _set_deferred(p: AdamwParams, deferred: Optional[dict]):

@@ -43,15 +43,37 @@ def ranks_share_a_device(ctx: "DistContext") -> bool:
     processes' launches can each hold half the device and wait for the other half."""
     if ctx.world_size <= 1 or not dist.is_initialized():
         return False
-    import socket
-    try:
-        props = torch.cuda.get_device_properties(ctx.device)
-        dev_id = (socket.gethostname(), str(props.uuid) if hasattr(props, "uuid") else int(ctx.device.index or 0))
-    except Exception:  # noqa: BLE001
-        dev_id = (socket.gethostname(), int(getattr(ctx.device, "index", 0) or 0))
     ids = [None] * ctx.world_size
-    dist.all_gather_object(ids, dev_id)
-    return len(set(ids)) < len(ids)
+    dist.all_gather_object(ids, device_identity(ctx.device))
+    shared = len(set(ids)) < len(ids)
+    if ctx.rank == 0:
+        import logging
+        logging.getLogger("rlinf_amd").info("ranks_share_a_device: %s (%d ranks on %d devices: %s)", shared, len(ids), len(set(ids)),
+                                            sorted(set(ids)))
+    return shared
+
+
+def device_identity(device) -> tuple:
+    """(host, PCI domain:bus:device) of a GPU: the same for every process that has it open, whatever HIP_VISIBLE_DEVICES made of
+    its index.  (The uuid torch reports is missing / zero / identical across devices on some ROCm builds, and with one visible
+    device per rank every rank's index is 0.)  Only when the PCI location cannot be read: the uuid, then the index -- with a
+    warning, because two ranks sharing a GPU can then go unnoticed."""
+    import socket
+    host = socket.gethostname()
+    try:
+        props = torch.cuda.get_device_properties(device)
+        return (host, "pci", int(props.pci_domain_id), int(props.pci_bus_id), int(props.pci_device_id))
+    except Exception:  # noqa: BLE001
+        pass
+    import warnings
+    warnings.warn("the GPU's PCI location is not readable through torch: telling devices apart by uuid / index")
+    try:
+        u = str(torch.cuda.get_device_properties(device).uuid)
+        if u.strip("0-") != "":
+            return (host, "uuid", u)
+    except Exception:  # noqa: BLE001
+        pass
+    return (host, "index", int(getattr(device, "index", 0) or 0))
 
 
 def forced_exchange() -> str:

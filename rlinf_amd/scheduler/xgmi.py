@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import ctypes
 import os
-import socket
 from typing import Optional
 
 import torch
@@ -57,11 +56,8 @@ class XgmiAllReduce:
             # collective part: ALWAYS entered.  (handle or None, device identity) per rank
             dev_id = None
             if err is None:
-                try:
-                    dev_id = (socket.gethostname(), str(torch.cuda.get_device_properties(ctx.device).uuid)
-                              if hasattr(torch.cuda.get_device_properties(ctx.device), "uuid") else int(ctx.device.index or 0))
-                except Exception:  # noqa: BLE001
-                    dev_id = (socket.gethostname(), int(ctx.device.index or 0))
+                from .dist import device_identity
+                dev_id = device_identity(ctx.device)  # (host, PCI location)
             gathered = [None] * ctx.world_size
             dist.all_gather_object(gathered, (None if err is not None else bytes(handle), dev_id, err))
             bad = [(r, g[2]) for r, g in enumerate(gathered) if g[0] is None]

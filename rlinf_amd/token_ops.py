@@ -7,6 +7,8 @@ plumbing.
 
 from __future__ import annotations
 
+import os
+
 from ctypes import byref
 from typing import Optional
 
@@ -160,8 +162,9 @@ class _PackedLogprobFn(torch.autograd.Function):
         x, rows = _rows_of(logits, temperature, False)
         out = logits if inplace else torch.empty(logits.shape, dtype=logits.dtype, device=dev)
         if rows.seq_stride == 0:
-            if not out.is_contiguous():
-                raise RlxError("packed scoring needs contiguous logits")
+            if not out.is_contiguous():  # (a transposed lm_head output with inplace_grad: the forward scored a contiguous copy,
+                #                          so there is no buffer of the logits' own layout to overwrite -- a fresh gradient instead)
+                out = torch.empty(logits.shape, dtype=logits.dtype, device=dev)
             dss, drs = 0, rows.vocab
         else:
             dss, drs = out.stride(0), out.stride(1)
@@ -345,12 +348,31 @@ def reinpp_seq_adv(rewards: torch.Tensor, loss_mask: torch.Tensor, logprob: Opti
 def reference_softmax_lanes() -> int:
     """f32 lanes of the vector kernels torch's CPU softmax runs with on THIS host: 16 (AVX-512 builds) or 8 (AVX2).  The order of
     the additions in the reference's row sum -- and with it the last bit of softmax(x), and with that a sampled index on a near
-    tie -- depends on it; ``categorical_sample`` replays that order (include/rlx.h, rlx_categorical_sample)."""
+    tie -- depends on it; ``categorical_sample`` replays that order (include/rlx.h, rlx_categorical_sample).  Builds whose vector
+    width this package has not pinned (NEON, SVE, DEFAULT ...) get 16 with a warning."""
     try:
         cap = torch.backends.cpu.get_cpu_capability().upper()
     except Exception:  # noqa: BLE001
-        return 16
-    return 8 if cap == "AVX2" else 16
+        cap = "?"
+    if cap == "AVX2":
+        return 8
+    if cap != "AVX512":
+        import warnings
+        warnings.warn(f"torch CPU capability {cap!r}: its softmax summation order is not one this package replays; using 16 lanes")
+    return 16
+
+
+def default_softmax_lanes() -> int:
+    """What ``categorical_sample`` uses when the caller names no lane count: a FIXED 16 (the C ABI's own default, the golden
+    fixtures' order), so that the same seed samples the same tokens on every node of a job whatever CPUs the hosts have.
+    ``RLX_SOFTMAX_LANES=host`` (or 8 / 16) opts in to matching THIS host's torch CPU softmax instead -- for side-by-side parity
+    runs against a CPU reference on the same machine."""
+    v = os.environ.get("RLX_SOFTMAX_LANES", "16").strip().lower()
+    if v == "host":
+        return reference_softmax_lanes()
+    if v not in ("8", "16"):
+        raise RlxError(f"RLX_SOFTMAX_LANES must be 8, 16 or host (got {v!r})")
+    return int(v)
 
 
 def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = None, *, temperature: float = 1.0,
@@ -359,7 +381,8 @@ def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = Non
     """logits [..., K<=1024] (a view into the model's logits is fine) -> (tokens i64, logprobs f32 or None,
     actions f32 or None), each of shape ``logits.shape[:-1]``.  ``noise``: Exp(1) draws of the logits' dtype and
     shape (what torch.multinomial draws internally); None = argmax.  The sampled indices are bit-exact against the reference's
-    CPU path on a host with ``softmax_lanes`` f32 SIMD lanes (None: this host's, see reference_softmax_lanes)."""
+    CPU path on a host with ``softmax_lanes`` f32 SIMD lanes (None: default_softmax_lanes() -- 16 unless RLX_SOFTMAX_LANES says
+    otherwise; ``reference_softmax_lanes()`` is this host's)."""
     dev = _dev(logits, noise, bin_centers)
     lead = logits.shape[:-1]
     x, rows = _rows_of(logits, temperature if noise is not None else 1.0, round_outputs)
@@ -375,7 +398,7 @@ def categorical_sample(logits: torch.Tensor, noise: Optional[torch.Tensor] = Non
     actions = torch.empty(lead, dtype=torch.float32, device=dev) if centers is not None else None
     with torch.cuda.device(dev):
         _lib.check(_lib.load().rlx_categorical_sample(x.data_ptr(), byref(rows), _ptr(noise), int(top_k),
-                                                      int(softmax_lanes if softmax_lanes is not None else reference_softmax_lanes()),
+                                                      int(softmax_lanes if softmax_lanes is not None else default_softmax_lanes()),
                                                       _ptr(centers),
                                                       0 if centers is None else centers.numel(), tokens.data_ptr(),
                                                       _ptr(logprob), _ptr(actions), _stream_ptr(dev)),

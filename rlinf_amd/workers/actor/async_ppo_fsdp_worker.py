@@ -303,7 +303,7 @@ class AsyncPPOEmbodiedFSDPActor(EmbodiedFSDPActor):
             out["actor/total_loss"] = (host[DPPO_OUT_NAMES["loss"]] + host[PPO_OUT_FLOATS]) / max(accum, 1)
             out["actor/entropy_loss"] = host[PPO_OUT_FLOATS + 1]
             out["actor/grad_norm"] = host[PPO_OUT_FLOATS + 3]
-            ops.check_adamw_sync(self.adamw_sync, host[PPO_OUT_FLOATS + 3])
+            self._one_launch_expired(host[PPO_OUT_FLOATS + 3])
             out["actor/lr"], out["critic/lr"] = lrs
             return out
 

@@ -132,6 +132,17 @@ class EmbodiedFSDPActor(Worker):
             self._ws.pop(key, None)
         self._graph = None
 
+    def _one_launch_expired(self, grad_norm: float):
+        """ops.check_adamw_sync's verdict on an iteration's gradient norm: when the one-launch optimizer step's exchange expired
+        (a foreign process or stream held part of the GPU), continue on the two-launch form -- the sync words are retired (kept
+        alive: launches already queued still point at them and skip as a whole), prepared launches and graphs that captured their
+        pointer are dropped."""
+        if ops.check_adamw_sync(self.adamw_sync, grad_norm):
+            self._retired_adamw_sync, self.adamw_sync = self.adamw_sync, None
+            for key in ("prepared_key", "aplan_key", "agraph_key"):
+                self._ws.pop(key, None)
+            self._graph = None
+
     def _step_lr_scheduler(self):
         """lr_scheduler.step() once per run_training (embodied_fsdp_actor_worker.py:568)."""
         self.lr_scheduler.step()
@@ -827,7 +838,7 @@ class EmbodiedFSDPActor(Worker):
             out["actor/total_loss"] = host[PPO_OUT_NAMES["loss"]] / max(accum, 1)
             out["actor/entropy_loss"] = host[PPO_OUT_NAMES["actor/entropy_loss"]]
             out["actor/grad_norm"] = host[-1]
-            ops.check_adamw_sync(self.adamw_sync, host[-1])
+            self._one_launch_expired(host[-1])
             out["actor/lr"] = float(np.mean([a for a, _ in log]))
             critic = [c for _, c in log if c is not None]
             if critic:

@@ -500,7 +500,8 @@ class FSDPActor:
         host = torch.cat([stacked, grad_norm.reshape(1)]).tolist()  # ONE read-back per optimizer step
         out = dict(zip(keys, host[:-1]))
         out["actor/grad_norm"], out["actor/lr"] = host[-1], lr_list[0]
-        ops.check_adamw_sync(self.adamw_sync, host[-1])
+        if ops.check_adamw_sync(self.adamw_sync, host[-1]):  # the one-launch form's exchange expired: two launches from here on
+            self._retired_adamw_sync, self.adamw_sync = self.adamw_sync, None
         return out
 
     # ---- the iteration (:860-939) ----------------------------------------------------------------------------------------------

@@ -215,6 +215,29 @@ def test_scaled_buffer_streaming_vs_segmented_agree():
             torch.testing.assert_close(ret, base_ret, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("normalize", [False, True])
+def test_scaled_buffer_with_a_loss_mask(normalize):
+    """65536 x 128 WITH a loss mask -- what `roofline_normalised`'s second row times: the auto heuristic picks the masked streaming
+    scan (32-row non-temporal register batches, env groups paired per XCD) + the batched standardize pass.  The scan is the CPU
+    loop's operation order (bit for bit against the plain variant and the oracle); the normalised advantages follow the
+    reference's safe_normalize over the masked elements."""
+    ops = _ops()
+    r = synth_rollout(seed=98, T=128, B=65536, p_done=0.004)
+    lm, _ = O.loss_mask_from_dones(r["dones"])
+    assert 0.3 < float(lm.float().mean()) < 0.95
+    rc, vc, dc, mc = r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda(), lm.cuda()
+    adv, ret = ops.gae_scan(rc, vc, dc, mc, 0.99, 0.95, normalize_advantages=normalize)  # variant 0: auto
+    base_adv, base_ret = ops.gae_scan(rc, vc, dc, mc, 0.99, 0.95, normalize_advantages=False, variant=1)
+    assert torch.equal(ret, base_ret)
+    want_adv, want_ret = O.gae_tb(r["rewards"][..., 0], r["dones"][..., 0], r["values"][..., 0], 0.99, 0.95,
+                                  normalize_advantages=normalize, loss_mask=lm[..., 0])
+    assert torch.equal(ret.cpu()[..., 0], want_ret)
+    if not normalize:
+        assert torch.equal(adv, base_adv) and torch.equal(adv.cpu()[..., 0], want_adv)
+    else:
+        torch.testing.assert_close(adv.cpu()[..., 0], want_adv, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("T,B", [(128, 65536), (128, 1024), (100, 700), (130, 129), (40, 64), (512, 256)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_gae_handoff_variant_is_bit_identical(T, B, masked):

@@ -281,6 +281,92 @@ def test_one_launch_optimizer_step(slabs, deferred, image):
             assert not math.isfinite(float(s0[0])) and not math.isfinite(float(s1[0]))
 
 
+def _one_launch_setup(image="bf16"):
+    from rlinf_amd import ops
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    torch.manual_seed(4)
+    pol = MLPPolicy(42, 8, 1, True, False, compute_dtype=torch.bfloat16 if image == "bf16" else torch.float32).to("cuda")
+    n = pol.n_params
+    tiles = pol.tiles()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    state, stats = torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(2, device="cuda")
+    grads = torch.randn(10, n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 0.01
+    ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    sync = ops.adamw_sync_words(n, "cuda")
+    mk = lambda sy: ops.PreparedAdamw(pol.flat.data, grads, m, v, pol.group_ranges(3e-4, 1e-3), betas=(0.9, 0.999), eps=1e-8,  # noqa: E731
+                                      weight_decay=0.01, max_grad_norm=0.5, grad_scale=1.0, stats=stats, step_state=state,
+                                      workspace=ws, tile_layout=pol.layout, tiles=tiles, sync=sy)
+    return ops, pol, tiles, m, v, state, stats, grads, sync, mk
+
+
+def test_one_launch_sticky_word_skips_every_later_step_as_a_whole():
+    """Word 1 of the sync buffer (set by a launch whose exchange expired) is read by every block before anything else: the step
+    then skips as a whole -- parameters, moments, weight image and step counter untouched, a NaN norm reported -- however often
+    it is called, eagerly or replayed; ops.check_adamw_sync turns that into a warning and tells the caller to continue on two
+    launches, which then apply the update the sticky launches withheld."""
+    ops, pol, tiles, m, v, state, stats, grads, sync, mk = _one_launch_setup()
+    if sync is None:
+        pytest.skip("RLX_ADAMW_ONE_LAUNCH=0")
+    step = mk(sync)
+    stream = torch.cuda.current_stream().cuda_stream
+    step(stream)  # a normal step first: epoch 1, slots published
+    torch.cuda.synchronize()
+    assert float(stats[1]) == 1.0 and ops.check_adamw_sync(sync, float(stats[0])) is False
+    before = [t.clone() for t in (pol.flat.data, m, v, tiles.view(torch.int16), state)]
+    sync[1] = 1  # what an expired poll leaves behind
+    for _ in range(3):
+        step(stream)
+    torch.cuda.synchronize()
+    assert not math.isfinite(float(stats[0])) and float(stats[1]) == 0.0
+    for a, b in zip(before[:4], (pol.flat.data, m, v, tiles.view(torch.int16))):
+        assert torch.equal(a, b)
+    assert int(state[0]) == 1 and int(state[1]) == 0  # one applied step on record, none pending
+    with pytest.warns(RuntimeWarning, match="timed out waiting for its own workgroups"):
+        assert ops.check_adamw_sync(sync, float(stats[0])) is True
+    assert ops.check_adamw_sync(None, float("nan")) is False and ops.check_adamw_sync(sync, 1.0) is False
+    mk(None)(stream)  # the fallback: two launches, same buffers
+    torch.cuda.synchronize()
+    assert math.isfinite(float(stats[0])) and float(stats[1]) == 1.0 and int(state[0]) + int(state[1]) == 2
+    assert not torch.equal(before[0], pol.flat.data)
+
+
+def test_one_launch_expiry_on_a_stream_that_cannot_hold_the_plan(monkeypatch):
+    """A REAL expiry: the launch is forced onto a stream of 8 compute units (16 resident blocks of the plan's 144; the library's
+    own residency bound -- taken against the stream's CU mask -- would pick two launches, RLX_ONE_LAUNCH_TEST_OVERSUBSCRIBE
+    overrides it) with a 20 ms poll bound.  The resident blocks expire, set the sticky word and poison their slots; the blocks
+    that become resident afterwards read the word first thing: nobody applies anything.  Without the override the same call on
+    the same stream is the two-launch form and simply works."""
+    from rlinf_amd.utils.streams import MaskedStream
+    ops, pol, tiles, m, v, state, stats, grads, sync, mk = _one_launch_setup()
+    if sync is None:
+        pytest.skip("RLX_ADAMW_ONE_LAUNCH=0")
+    small = MaskedStream("cuda", 8)
+    try:
+        before = [t.clone() for t in (pol.flat.data, m, v, tiles.view(torch.int16))]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(small.stream):
+            mk(sync)(small.stream.cuda_stream)  # capacity 16 < 144 blocks -> two launches
+        small.stream.synchronize()
+        assert float(stats[1]) == 1.0 and int(sync[1]) == 0 and int(sync[0]) == 0  # (the exchange words were not used)
+        after_two = pol.flat.data.clone()
+        assert not torch.equal(before[0], after_two)
+        monkeypatch.setenv("RLX_ONE_LAUNCH_TEST_OVERSUBSCRIBE", "1")
+        monkeypatch.setenv("RLX_ONE_LAUNCH_POLL_MS", "20")
+        held = [t.clone() for t in (pol.flat.data, m, v, tiles.view(torch.int16))]
+        with torch.cuda.stream(small.stream):
+            mk(sync)(small.stream.cuda_stream)
+        small.stream.synchronize()
+        assert int(sync[1]) == 1, "the poll should have expired"
+        assert not math.isfinite(float(stats[0])) and float(stats[1]) == 0.0
+        for a, b in zip(held, (pol.flat.data, m, v, tiles.view(torch.int16))):
+            assert torch.equal(a, b), "a block applied its update although the exchange expired"
+        monkeypatch.delenv("RLX_ONE_LAUNCH_TEST_OVERSUBSCRIBE")
+        with pytest.warns(RuntimeWarning):
+            assert ops.check_adamw_sync(sync, float(stats[0])) is True
+    finally:
+        small.close()
+
+
 # ---- decoupled (async) PPO loss: registry name "decoupled_actor_critic" -------------------------------------
 @pytest.mark.parametrize("logprob_type", ["action_level", "token_level", "chunk_level"])
 @pytest.mark.parametrize("prox_mode", ["given", "old", "versions"])

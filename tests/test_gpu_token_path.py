@@ -427,8 +427,10 @@ def test_categorical_sample_vs_oracle(dtype, K, temperature, top_k):
     centers = torch.linspace(-1, 1, K - 1)
     wtok, wlp, processed, wact = TO.categorical_sample(window, q, temperature, top_k, bin_centers=centers)
     dwin = full.to(DEV)[..., V - pad - K:V - pad]
+    # (softmax_lanes: the oracle runs torch.softmax on THIS host, so the kernel replays this host's summation order; the
+    # product default is a fixed 16 -- test_categorical_default_lane_count_is_fixed)
     tok, lp, act = token_ops.categorical_sample(dwin, q.to(DEV), temperature=temperature, top_k=top_k,
-                                                bin_centers=centers.to(DEV))
+                                                bin_centers=centers.to(DEV), softmax_lanes=token_ops.reference_softmax_lanes())
     # north_star: "bit-exact for action indices".  The kernel replays the reference's CPU softmax operation for operation (Sleef's
     # expf, the per-SIMD-lane row sum of this host's torch build, e * (1 / sum), p / q, first-index argmax): no tie allowance.
     assert torch.equal(tok.cpu(), wtok), (int((tok.cpu() != wtok).sum()), tok.numel())
@@ -454,8 +456,28 @@ def test_categorical_sample_bit_exact_over_many_rows(dtype):
     x = (torch.randn(n, K, generator=g) * torch.rand(n, 1, generator=g) * 4).to(dtype)
     q = torch.empty(n, K, dtype=dtype).exponential_(1, generator=g)
     wtok, _, _, _ = TO.categorical_sample(x, q, 0.8, 40)
-    tok, _, _ = token_ops.categorical_sample(x.to(DEV), q.to(DEV), temperature=0.8, top_k=40)
+    tok, _, _ = token_ops.categorical_sample(x.to(DEV), q.to(DEV), temperature=0.8, top_k=40,
+                                             softmax_lanes=token_ops.reference_softmax_lanes())
     assert torch.equal(tok.cpu(), wtok), int((tok.cpu() != wtok).sum())
+
+
+def test_categorical_default_lane_count_is_fixed(monkeypatch):
+    """Without an explicit lane count the sampler uses 16 on every host (same seed -> same tokens on every node of a job);
+    RLX_SOFTMAX_LANES=host / 8 / 16 is the opt-in to a particular host's order."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(4096, 256, generator=g) * 3).to(DEV)
+    q = torch.empty(4096, 256).exponential_(1, generator=g).to(DEV)
+    monkeypatch.delenv("RLX_SOFTMAX_LANES", raising=False)
+    assert token_ops.default_softmax_lanes() == 16
+    base = token_ops.categorical_sample(x, q)[0]
+    assert torch.equal(base, token_ops.categorical_sample(x, q, softmax_lanes=16)[0])
+    monkeypatch.setenv("RLX_SOFTMAX_LANES", "8")
+    assert torch.equal(token_ops.categorical_sample(x, q)[0], token_ops.categorical_sample(x, q, softmax_lanes=8)[0])
+    monkeypatch.setenv("RLX_SOFTMAX_LANES", "host")
+    assert token_ops.default_softmax_lanes() == token_ops.reference_softmax_lanes()
+    monkeypatch.setenv("RLX_SOFTMAX_LANES", "12")
+    with pytest.raises(token_ops.RlxError):
+        token_ops.default_softmax_lanes()
 
 
 def test_categorical_sample_follows_the_distribution():
