@@ -190,7 +190,16 @@ def _placement_world_size(cfg, component: str) -> int:
     """Number of processes of a component.  The reference derives it from cluster.component_placement
     (rlinf/utils/placement.py:86); here every component runs in every rank of the torchrun-style world
     (collocated placement, the shipped `env,rollout,actor: 0` pattern scaled to N GPUs)."""
-    return int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    placement = (cfg.get("cluster", None) or {}).get("component_placement", None) if hasattr(cfg, "get") else None
+    if placement is not None and world > 1:
+        # a SPLIT placement (utils/placement.py: actor and rollout rank sets disjoint) gives a component its own ranks only
+        from .utils.placement import parse_component_placement
+        ranks = parse_component_placement(placement, world)
+        a, r = ranks.get("actor"), ranks.get("rollout")
+        if a is not None and r is not None and not (set(a) & set(r)) and ranks.get(component) is not None:
+            return len(ranks[component])
+    return world
 
 
 def validate_fsdp_cfg(cfg):

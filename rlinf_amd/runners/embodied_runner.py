@@ -57,6 +57,12 @@ class EmbodiedRunner:
         self.metrics_history: list = []
         self.eval_history: list = []
         self._last_landed = None  # host time at which the previous deferred step's metrics landed
+        # split placement (utils/placement.py): a group that lives on other ranks is an absent handle here
+        self._has = {name: getattr(h, "worker", None) is not None for name, h in (("actor", actor), ("rollout", rollout), ("env", env))}
+        self.placement = next((getattr(getattr(h, "worker", None), "placement", None) for h in (actor, rollout, env)
+                               if getattr(h, "worker", None) is not None), None)
+        self.split = self.placement is not None and bool(getattr(self.placement, "split", False))
+        self._landing = None  # the learner rank's persistent landing buffer for shipped trajectories
 
     def set_max_steps(self):
         r = self.cfg.runner
@@ -84,9 +90,13 @@ class EmbodiedRunner:
         rollout_handle.wait()
         env_handle.wait()
         self.actor.init_worker().wait()
-        self.env.worker.connect(self.rollout.worker)
+        if self._has["env"]:
+            self.env.worker.connect(self.rollout.worker)
+        if self.split:
+            assert not self.cfg.runner.get("use_training_pipeline", False), \
+                "runner.use_training_pipeline with a split placement is not served (per-epoch hand-off over the trajectory route)"
         resume_dir = self.cfg.runner.get("resume_dir", None)
-        if resume_dir is None:
+        if resume_dir is None or not self._has["actor"]:
             return
         actor_checkpoint_path = os.path.join(resume_dir, "actor")
         assert os.path.exists(actor_checkpoint_path), f"resume_dir {actor_checkpoint_path} does not exist."
@@ -106,6 +116,36 @@ class EmbodiedRunner:
             w._graph = None
             xg.close()
             w._xgmi = None
+
+    def _ship_trajectories(self):
+        """Split placement: the finished trajectory buffer of rollout rank i -> learner rank i (the reference's actor channel,
+        env_worker.py:1463-1467 -> embodied_fsdp_actor_worker.py:186-207, is a Ray channel between actor processes).  The fields
+        travel in a fixed order into a persistent landing buffer of the same shape; the learner then finds the usual trajectory
+        views on its channel."""
+        from ..data.embodied_types import TrajectoryBuffer
+        from ..scheduler.dist import recv_tensors, send_tensors
+        fields = ("states", "actions", "prev_logprobs", "versions", "prev_values", "rewards", "dones", "terminations", "truncations")
+        if self._has["env"]:
+            w = self.env.worker
+            while not self.actor_channel.empty():
+                self.actor_channel.get()  # (the views stay on this rank: the buffer itself is what travels)
+            send_tensors([getattr(w.buffer, f) for f in fields], self.placement.peer_of("env", "actor"))
+        if self._has["actor"]:
+            a, cfg = self.actor.worker, self.cfg
+            m, tr = cfg.actor.model, cfg.env.train
+            if self._landing is None:
+                stage_num = int(cfg.rollout.get("pipeline_stage_num", 1))
+                envs = tr.total_num_envs // a._world_size // stage_num * stage_num * int(tr.get("rollout_epoch", 1))
+                self._landing = TrajectoryBuffer(tr.max_steps_per_rollout_epoch // int(m.num_action_chunks), envs, m.obs_dim,
+                                                 m.action_dim, m.num_action_chunks, device=a.device,
+                                                 max_episode_length=int(tr.get("max_episode_steps", 0)))
+                self._landing_split = (a._world_size * stage_num, stage_num)
+            recv_tensors([getattr(self._landing, f) for f in fields], self.placement.peer_of("actor", "env"))
+            from ..scheduler import compute_split_num
+            send_num, stage_num = self._landing_split
+            split = compute_split_num(a._world_size, send_num)
+            for traj in self._landing.to_splited_trajectories(split * stage_num):
+                self.actor_channel.put(traj)
 
     def update_rollout_weights(self):
         rollout_handle = self.rollout.sync_model_from_actor()
@@ -149,7 +189,7 @@ class EmbodiedRunner:
         device and return a ``PendingStep`` instead of its metric dict -- the numbers are copied to pinned host memory behind the
         kernels that produce them and read when ``.result()`` is called.  ``run()`` calls it one iteration late, so the host
         never waits with an empty device queue (no idle between the rollout, the update phase and the next rollout)."""
-        dev = self.actor.worker.device
+        dev = (self.actor.worker if self._has["actor"] else self.rollout.worker).device
         step = self.global_step
         t0 = time.perf_counter()
         worker = getattr(self.actor, "worker", self.actor)
@@ -162,6 +202,8 @@ class EmbodiedRunner:
         env_handle = self.env.interact(input_channel=self.env_channel, rollout_channel=self.rollout_channel,
                                        reward_channel=self.reward_channel, actor_channel=self.actor_channel, eps=eps)
         rollout_handle = self.rollout.generate(input_channel=self.rollout_channel, output_channel=self.env_channel)
+        if self.split:
+            self._ship_trajectories()
         self.actor.recv_rollout_trajectories(input_channel=self.actor_channel).wait()
         rollout_handle.wait()
         env_handle.wait()
@@ -173,14 +215,15 @@ class EmbodiedRunner:
         train_metrics = actor_training_handle.wait()[0]
         if env_bootstrap_handle is not None:
             env_bootstrap_handle.wait()
-        if not rollout_metrics and hasattr(self.actor.worker, "pop_rollout_metrics"):
+        if not rollout_metrics and self._has["actor"] and hasattr(self.actor.worker, "pop_rollout_metrics"):
             rollout_metrics = self.actor.worker.pop_rollout_metrics()  # pipeline learner: produced inside run_training
         self.global_step += 1
         tr = self.cfg.env.train
         env_steps = tr.total_num_envs * tr.max_steps_per_rollout_epoch * tr.get("rollout_epoch", 1)
 
         def finish() -> dict:
-            rm, tm = resolve(rollout_metrics), resolve(train_metrics)  # waits for this step's copies only
+            rm, tm = resolve(rollout_metrics) or {}, resolve(train_metrics) or {}  # waits for this step's copies only
+            # (a rollout-only rank of a split placement has neither)
             now = time.perf_counter()
             # deferred: the iteration time is the time between two consecutive steps landing (the steady-state rate)
             dt = (now - self._last_landed) if (defer and self._last_landed is not None) else now - t0

@@ -27,6 +27,13 @@ class DistContext:
     # communicator is legal, so the worker's own multi-GPU branch (slab sum -> dist.all_reduce -> clip + AdamW, eagerly and inside
     # the captured update graph) executes on a one-GPU box, and bench.py can time the exchange's launches (--exchange self)
     force_exchange: bool = False
+    # a COMPONENT's context under a split placement (utils/placement.py): ``group`` is the process group of the component's ranks,
+    # ``global_ranks`` their ranks in the job (rank / world_size above are the component's own); None / None: the whole job
+    group: Optional[object] = None
+    global_ranks: Optional[list] = None
+
+    def global_rank_of(self, r: int) -> int:
+        return r if self.global_ranks is None else int(self.global_ranks[r])
 
     @property
     def is_distributed(self) -> bool:
@@ -44,7 +51,7 @@ def ranks_share_a_device(ctx: "DistContext") -> bool:
     if ctx.world_size <= 1 or not dist.is_initialized():
         return False
     ids = [None] * ctx.world_size
-    dist.all_gather_object(ids, device_identity(ctx.device))
+    dist.all_gather_object(ids, device_identity(ctx.device), group=ctx.group)
     shared = len(set(ids)) < len(ids)
     if ctx.rank == 0:
         import logging
@@ -112,7 +119,7 @@ def init_distributed(backend: Optional[str] = None, device_type: Optional[str] =
 def all_reduce_flat_(buf: torch.Tensor, ctx: DistContext, average: bool = False) -> torch.Tensor:
     """SUM (or mean) all-reduce of one flat buffer, in place.  No-op for world_size 1."""
     if ctx.exchanges_gradients:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
         if average and ctx.world_size > 1:
             buf.div_(ctx.world_size)
     return buf
@@ -122,9 +129,9 @@ def all_reduce_scalars(sums: torch.Tensor, maxs: Optional[torch.Tensor], ctx: Di
     """One SUM call for (sum, count) pairs and one MAX call for (-min, max) pairs
     (rlinf/utils/metric_utils.py:451-454 does two per metric; merged here)."""
     if ctx.world_size > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=ctx.group)
         if maxs is not None:
-            dist.all_reduce(maxs, op=dist.ReduceOp.MAX)
+            dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=ctx.group)
     return sums, maxs
 
 
@@ -149,7 +156,7 @@ def broadcast_weight_patch(patch, ctx: DistContext, src: int = 0, device: Option
         else:
             header = torch.tensor([0, int(patch.version), 0, 0, 0, 0, 0, 0], dtype=torch.int64, device=dev)
     if ctx.world_size > 1:
-        dist.broadcast(header, src=src)
+        dist.broadcast(header, src=ctx.global_rank_of(src), group=ctx.group)
     kind, version, k, nnz, nbytes, rcode, ccode, _ = header.tolist()
     vt = torch.tensor(version, dtype=torch.int64, device=dev)
     if kind == 0:
@@ -163,7 +170,7 @@ def broadcast_weight_patch(patch, ctx: DistContext, src: int = 0, device: Option
     if ctx.world_size > 1:
         for t in fields:
             if t.numel():
-                dist.broadcast(t, src=src)
+                dist.broadcast(t, src=ctx.global_rank_of(src), group=ctx.group)
     return WeightPatch(vt, *fields)
 
 
@@ -180,10 +187,100 @@ def broadcast_weight_bucket(bucket, ctx: DistContext, src: int = 0, device: Opti
         meta = {k: int(bucket[k]) for k in (TOTAL_BUCKETS_KEY, SYNCER_VERSION_KEY) if k in bucket}
         head[0] = (bucket.layout, meta, bucket.flat.numel())
     if ctx.world_size > 1:
-        dist.broadcast_object_list(head, src=src)
+        dist.broadcast_object_list(head, src=ctx.global_rank_of(src), group=ctx.group)
     layout, meta, nbytes = head[0]
     flat = bucket.flat.to(dev) if ctx.rank == src else torch.empty(nbytes, dtype=torch.uint8, device=dev)
     if ctx.world_size > 1:
-        dist.broadcast(flat, src=src)
+        dist.broadcast(flat, src=ctx.global_rank_of(src), group=ctx.group)
     return WeightBucket.from_flat(flat, layout, {k: torch.tensor(v, dtype=torch.int32, device=dev) for k, v in meta.items()})
 
+
+
+# ---- generic payload transport of the weight syncers (actor rank 0 -> the rollout ranks: Worker.broadcast in the reference,
+# embodied_fsdp_actor_worker.py:142-154; receiver metadata back: Worker.send / recv, huggingface_worker.py:645-655) ----
+def _staged(t: torch.Tensor) -> torch.Tensor:
+    """gloo moves host memory only: device tensors are staged through the host when it is the backend (shared-GPU test set-ups)."""
+    return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
+
+
+def broadcast_payload(obj, ctx: DistContext, src: int = 0, device: Optional[torch.device] = None):
+    """Rank ``src`` of ``ctx`` passes a syncer payload -- WeightBucket, WeightPatch / EmptyWeightPatch / CompressedWeightPatch, or
+    any picklable object (metadata dicts) --, every other rank None; all ranks return an equal payload with its tensors on
+    ``device``.  One small object broadcast names the kind; buckets and patches then travel through the typed broadcasts above
+    (one flat byte buffer per bucket, one broadcast per patch field)."""
+    from ..hybrid_engines.weight_syncer.bucket_syncer import WeightBucket
+    from ..hybrid_engines.weight_syncer.patch_syncer import CompressedWeightPatch, EmptyWeightPatch, WeightPatch
+
+    dev = device or ctx.device or torch.device("cpu")
+    kind = [None]
+    if ctx.rank == src:
+        kind[0] = ("bucket" if isinstance(obj, WeightBucket) else "patch" if isinstance(obj, (WeightPatch, EmptyWeightPatch))
+                   else "compressed" if isinstance(obj, CompressedWeightPatch) else "object")
+    if ctx.world_size > 1:
+        dist.broadcast_object_list(kind, src=ctx.global_rank_of(src), group=ctx.group)
+    if kind[0] == "bucket":
+        if ctx.world_size == 1:
+            return obj
+        # (under gloo the flat buffer arrives in host memory: load_bucket moves a host-staged bucket with ONE copy)
+        return broadcast_weight_bucket(obj, ctx, src, torch.device("cpu") if dist.get_backend() == "gloo" else dev)
+    if kind[0] == "patch":
+        if ctx.world_size == 1:
+            return obj
+        stage = torch.device("cpu") if dist.get_backend() == "gloo" else dev
+        got = broadcast_weight_patch(obj if obj is None else obj.to(stage), ctx, src, stage)
+        return got.to(dev)
+    if kind[0] == "compressed":
+        import dataclasses
+        head = [None]
+        if ctx.rank == src:
+            fields = {f.name: getattr(obj, f.name) for f in dataclasses.fields(obj)}
+            head[0] = {k: (("t", v.dtype, tuple(v.shape)) if isinstance(v, torch.Tensor) else ("v", v)) for k, v in fields.items()}
+        if ctx.world_size > 1:
+            dist.broadcast_object_list(head, src=ctx.global_rank_of(src), group=ctx.group)
+        out = {}
+        for k, spec in head[0].items():
+            if spec[0] == "v":
+                out[k] = spec[1]
+                continue
+            stage = torch.device("cpu") if (ctx.world_size > 1 and dist.get_backend() == "gloo") else dev
+            t = getattr(obj, k).to(stage).contiguous() if ctx.rank == src else torch.empty(spec[2], dtype=spec[1], device=stage)
+            if ctx.world_size > 1 and t.numel():
+                dist.broadcast(t, src=ctx.global_rank_of(src), group=ctx.group)
+            out[k] = t.to(dev)
+        return CompressedWeightPatch(**out)
+    box = [obj]
+    if ctx.world_size > 1:
+        dist.broadcast_object_list(box, src=ctx.global_rank_of(src), group=ctx.group)
+    return box[0]
+
+
+def send_object(obj, dst_global_rank: int) -> None:
+    """Point-to-point pickled object (the receiver's metadata on its way to an actor rank)."""
+    dist.send_object_list([obj], dst=dst_global_rank)
+
+
+def recv_object(src_global_rank: int):
+    box = [None]
+    dist.recv_object_list(box, src=src_global_rank)
+    return box[0]
+
+
+def send_tensors(tensors: list, dst_global_rank: int) -> None:
+    """A list of tensors to one peer, in order (the finished trajectory buffer on its way from a rollout rank to its learner rank:
+    env_worker.py:1463-1467 -> embodied_fsdp_actor_worker.py:186-207 in the reference, over its channel).  bool travels as uint8."""
+    for t in tensors:
+        t = t.contiguous()
+        dist.send(_staged(t.view(torch.uint8) if t.dtype == torch.bool else t), dst=dst_global_rank)
+
+
+def recv_tensors(into: list, src_global_rank: int) -> None:
+    """Counterpart of send_tensors: fills the given (preallocated, contiguous) tensors."""
+    for t in into:
+        assert t.is_contiguous()
+        view = t.view(torch.uint8) if t.dtype == torch.bool else t
+        if view.is_cuda and dist.get_backend() == "gloo":
+            host = torch.empty(view.shape, dtype=view.dtype)
+            dist.recv(host, src=src_global_rank)
+            view.copy_(host)
+        else:
+            dist.recv(view, src=src_global_rank)

@@ -56,6 +56,13 @@ class EmbodiedFSDPActor(Worker):
         self.version = 0
         self.optimizer_steps = 0
         a = cfg.actor
+        # cfg.weight_syncer (embodied_fsdp_actor_worker.py:80-83,97): bucket or patch; None when the configuration names none (a
+        # collocated rollout worker that aliases this learner's policy object needs no transport at all)
+        from ..weight_link import weight_syncer_config
+        from ...hybrid_engines.weight_syncer import WeightSyncer
+        ws_cfg = weight_syncer_config(cfg)
+        self.weight_syncer = WeightSyncer.create(ws_cfg) if ws_cfg is not None else None
+        self._is_weight_sender = self._rank == 0
         self.gradient_accumulation = a.global_batch_size // a.micro_batch_size // self._world_size  # :91-95
         self.critic_warmup_steps = int(a.optim.get("critic_warmup_steps", 0))
         self.enable_hip_graph = bool(a.get("enable_hip_graph", False))
@@ -111,7 +118,8 @@ class EmbodiedFSDPActor(Worker):
         # gradient all-reduce transport (world_size > 1): hand-written xGMI peer reads, validated against torch.distributed at
         # start-up on every rank; RCCL when that is unavailable.  Either way the update phase is graph-captured.
         self._xgmi = None
-        if self._exchange and dev is not None and dev.type == "cuda":
+        if self._exchange and dev is not None and dev.type == "cuda" and self.ctx.group is None:
+            # (a split placement's learner group exchanges over RCCL: the xGMI communicator is set up over the whole job's ranks)
             from ...scheduler import xgmi
             self._xgmi = xgmi.build(self.ctx, n)
         self.grad_allreduce_backend = "none" if not self._exchange else ("xgmi" if self._xgmi is not None else "rccl")
@@ -153,8 +161,29 @@ class EmbodiedFSDPActor(Worker):
         self.version = global_step
 
     def sync_model_to_rollout(self):
-        """Weights for the rollout worker (embodied_fsdp_actor_worker.py:142-154): the flat buffer itself."""
+        """Weights for the rollout workers (embodied_fsdp_actor_worker.py:131-178).  Split placement: the reference's sequence --
+        ``init_sender`` once (the receiver's metadata in, an init sync out when the patch syncer asks for one), then
+        ``sync(state_dict, send, version)`` -- over the placement's weight-sync group.  Collocated: the rollout worker of this
+        process either aliases this learner's policy object (nothing to send) or drives both halves of the sync itself over an
+        in-process link (MultiStepRolloutWorker.sync_model_from_actor); returns the flat buffer for this package's own callers."""
+        placement = getattr(self, "placement", None)
+        if placement is not None and placement.split:
+            from ..weight_link import GroupLink
+            assert self.weight_syncer is not None, "weight_syncer config must be provided for a split placement"
+            if getattr(self, "_weight_link", None) is None:
+                self._weight_link = GroupLink(placement, self.device)
+            self.serve_weight_sync(self._weight_link)
         return self.model.flat.data
+
+    def serve_weight_sync(self, link) -> None:
+        """The sender half (:131-178) over ``link`` (workers/weight_link.py): the state dict is the policy's reference-named views,
+        ``param_names_need_sync`` all of them (collect_param_names_need_sync: trainable parameters and persistent buffers)."""
+        state_dict = self.model.state_dict()
+        syncer = self.weight_syncer
+        if not syncer.sender_initialized():
+            syncer.init_sender(state_dict=state_dict, send=link.actor_send, recv=link.actor_recv,
+                               param_names_need_sync=list(state_dict.keys()), is_sender=self._is_weight_sender)
+        syncer.sync(state_dict, link.actor_send, version=self.version)
 
     def state_dict(self):
         return self.model.reference_state_dict()
@@ -187,7 +216,7 @@ class EmbodiedFSDPActor(Worker):
             torch.save(state["model"], os.path.join(sd_dir, "full_weights.pt"))
         if self._world_size > 1:
             import torch.distributed as dist
-            dist.barrier()
+            dist.barrier(group=self.ctx.group)
 
     def load_checkpoint(self, load_path: str) -> None:
         """FSDPModelManager.load_checkpoint (:342-358): restores what save_checkpoint wrote, IN PLACE -- every device buffer
@@ -790,7 +819,7 @@ class EmbodiedFSDPActor(Worker):
             if self._exchange:  # every rank replays, or none does
                 import torch.distributed as dist
                 verdict = torch.tensor([ok], dtype=torch.int32, device=self.device)
-                dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.ctx.group)
                 ok = int(verdict.item())
             if not ok:
                 self.enable_hip_graph = False

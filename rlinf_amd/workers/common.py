@@ -98,6 +98,12 @@ class _Group:
 
     def launch(self, cluster=None, name: str = "", placement_strategy=None):
         ctx = self._ctx
+        placement = getattr(placement_strategy, "placement", None)
+        if placement is not None and getattr(placement, "split", False):
+            # split placement (utils/placement.py): the component runs on ITS ranks only, in the component's own rank context
+            if not placement_strategy.present:
+                return _AbsentProxy(_role_of(self._cls), name)
+            ctx = placement_strategy.ctx
         if ctx is None and cluster is not None:
             ctx = getattr(cluster, "ctx", None)
         if ctx is None and placement_strategy is not None:
@@ -107,6 +113,7 @@ class _Group:
             ctx = init_distributed()
         worker = self._cls(self._cfg, ctx)
         worker.group_name = name
+        worker.placement = placement  # None: launched without a placement (collocated, this package's own callers)
         _PEERS[_role_of(self._cls)] = worker
         return _HandleProxy(worker)
 
@@ -128,3 +135,23 @@ class _HandleProxy:
             return Handle(out, time.perf_counter() - t0)
 
         return call
+
+
+class _AbsentProxy:
+    """The handle of a worker group none of whose workers runs in THIS process (split placement): the reference's runner calls
+    every group from its one driver process and the call reaches the ranks that host the group; here every rank runs the runner,
+    and a call on a group that is elsewhere is simply not this rank's to execute."""
+
+    worker = None
+
+    def __init__(self, role: str, name: str):
+        object.__setattr__(self, "role", role)
+        object.__setattr__(self, "group_name", name)
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        return lambda *a, **kw: Handle(None)
+
+    def __bool__(self):
+        return False

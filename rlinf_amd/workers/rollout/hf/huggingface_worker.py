@@ -20,6 +20,13 @@ class MultiStepRolloutWorker(Worker):
         self.version = 0
         self._shares_actor_weights = False
         self._pending: list = []  # bootstrap-value jobs waiting for the next launch
+        # cfg.weight_syncer (huggingface_worker.py:118-126): used whenever this worker holds its OWN copy of the weights -- a split
+        # placement, or a collocated one with rollout.share_actor_weights off
+        from ...weight_link import weight_syncer_config
+        from ....hybrid_engines.weight_syncer import WeightSyncer
+        ws_cfg = weight_syncer_config(cfg)
+        self.weight_syncer = WeightSyncer.create(ws_cfg) if ws_cfg is not None else None
+        self._weight_link = None
 
     def init_worker(self, model=None):
         """``model``: when rollout and learner are collocated (component_placement ``env,rollout,actor: 0``) the
@@ -30,10 +37,24 @@ class MultiStepRolloutWorker(Worker):
         if self._overlapped_pipeline():  # the rollout of epoch e + 1 runs WHILE the learner updates: it needs its own frozen copy
             self.cfg.rollout.share_actor_weights = False
             model = None
+        if self._split():
+            assert self.weight_syncer is not None, "rollout.weight_syncer config must be provided"  # huggingface_worker.py:122-124
+            self.hf_model = self._own_model()
+            return
         if model is not None:
             self.hf_model, self._shares_actor_weights = model, True
         elif not (bool(self.cfg.rollout.get("share_actor_weights", True)) and peer("actor", self.cfg) is not None):
-            self.hf_model = get_model(self.cfg.actor.model).to(self.device)
+            self.hf_model = self._own_model()
+
+    def _split(self) -> bool:
+        placement = getattr(self, "placement", None)
+        return placement is not None and placement.split
+
+    def _own_model(self):
+        """This worker's own policy object, built from the learner's seed (embodied_fsdp_actor_worker.py: every rank builds
+        identical initial weights) so that a patch syncer without an init sync starts from equal states on both sides."""
+        torch.manual_seed(int(self.cfg.actor.get("seed", 1234)))
+        return get_model(self.cfg.actor.model).to(self.device)
 
     def _overlapped_pipeline(self) -> bool:
         r = self.cfg.runner
@@ -51,6 +72,12 @@ class MultiStepRolloutWorker(Worker):
         """Apply the learner's weights (huggingface_worker.py:629-675).  Flat-buffer copy, or nothing when aliased; then
         rebuild the fragment-tile weight image HERE, eagerly: the rollout loop may be a replayed hipGraph, which must
         find fresh tiles in the same buffer (a lazy rebuild inside the captured region would be frozen out of it)."""
+        if self._split():
+            from ...weight_link import GroupLink
+            if self._weight_link is None:
+                self._weight_link = GroupLink(self.placement, self.device)
+            self._receive_weights(self._weight_link)
+            return
         actor = peer("actor", self.cfg)
         if self.hf_model is None:  # deferred by init_worker(): collocated -> alias the learner's policy object
             if actor is None or actor.model is None:
@@ -58,12 +85,35 @@ class MultiStepRolloutWorker(Worker):
             if bool(self.cfg.rollout.get("share_actor_weights", True)):
                 self.adopt_model(actor.model)
             else:
-                self.hf_model = get_model(self.cfg.actor.model).to(self.device)
-        if flat_params is None and not self._shares_actor_weights and actor is not None and actor.model is not None:
+                self.hf_model = self._own_model()
+        own_copy = not self._shares_actor_weights
+        if (own_copy and flat_params is None and self.weight_syncer is not None and actor is not None and actor.model is not None
+                and getattr(actor, "weight_syncer", None) is not None):
+            # an own copy next to the learner in one process: the configured syncer moves the weights, both halves driven from
+            # here over an in-process link (the learner's sync_model_to_rollout, called next by the runner, has nothing left to do)
+            from ...weight_link import InProcessLink
+            if self._weight_link is None:
+                self._weight_link = InProcessLink()
+            link = self._weight_link
+            link.run(lambda: actor.serve_weight_sync(link), lambda: self._receive_weights(link))
+            return
+        if flat_params is None and own_copy and actor is not None and actor.model is not None:
             flat_params = actor.model.flat.data  # the reference's call carries no argument: the weights come over its channel
         if not (self._shares_actor_weights or flat_params is None):
             with torch.no_grad():
                 self.hf_model.flat.data.copy_(flat_params)
+        self._weights_landed()
+
+    def _receive_weights(self, link) -> None:
+        """The receiver half (huggingface_worker.py:657-672): ``init_receiver`` once, ``apply``, the applied version becomes this
+        worker's version."""
+        syncer = self.weight_syncer
+        if not syncer.receiver_initialized():
+            syncer.init_receiver(state_dict=self.hf_model.state_dict(), recv=link.rollout_recv, send=link.rollout_send)
+        self.version = int(syncer.apply(self.hf_model, link.rollout_recv))
+        self._weights_landed()
+
+    def _weights_landed(self):
         self.hf_model.mark_updated()
         if self.hf_model.flat.is_cuda:
             self.hf_model.tiles()

@@ -209,9 +209,150 @@ def gpu_async_main(out_path, precision, transport="xgmi", graph="0", backend="gl
     dist.destroy_process_group()
 
 
+# ---- split placement (actor ranks != rollout ranks) and the weight syncers in the worker path -----------------------------------
+def _split_cfg(syncer: str, placement: dict, *, T=12, B=32, GB=96, init_sync=False, precision="32"):
+    from test_end_to_end import make_cfg
+    cfg = make_cfg(total_envs=B, steps=T, global_batch=GB, update_epoch=2)
+    cfg.actor.model.precision = precision
+    cfg.cluster = {"num_nodes": 1, "component_placement": placement}
+    if syncer == "bucket":
+        cfg.weight_syncer = {"type": "bucket", "bucket": {"bucket_size": 128 * 1024, "bucket_dtype": None, "is_agent": False,
+                                                           "load_instant": True}}
+    elif syncer == "patch":
+        cfg.weight_syncer = {"type": "patch", "patch": {"snapshot_device": "cuda", "delta_encoding": True, "compression": "none",
+                                                         "init_sync": {"enabled": init_sync, "prefixes": None,
+                                                                       "bucket_size": 64 * 1024}}}
+    return cfg
+
+
+def _launch_runner(cfg, env_tensors, state_dict):
+    """The reference entry point's sequence (examples/embodiment/train_embodied_agent.py): Cluster, HybridComponentPlacement, the
+    three groups launched with their placement strategies, the runner."""
+    from rlinf_amd.config import validate_cfg
+    from rlinf_amd.runners import EmbodiedRunner
+    from rlinf_amd.scheduler import Cluster, init_distributed
+    from rlinf_amd.utils.placement import HybridComponentPlacement
+    from rlinf_amd.workers.actor import EmbodiedFSDPActor
+    from rlinf_amd.workers.env import EnvWorker
+    from rlinf_amd.workers.rollout.hf import MultiStepRolloutWorker
+    cfg = validate_cfg(cfg)
+    cluster = Cluster(cluster_cfg=cfg.cluster, ctx=init_distributed())
+    placement = HybridComponentPlacement(cfg, cluster)
+    actor = EmbodiedFSDPActor.create_group(cfg).launch(cluster, name="ActorGroup", placement_strategy=placement.get_strategy("actor"))
+    rollout = MultiStepRolloutWorker.create_group(cfg).launch(cluster, name="RolloutGroup",
+                                                              placement_strategy=placement.get_strategy("rollout"))
+    env = EnvWorker.create_group(cfg).launch(cluster, name="EnvGroup", placement_strategy=placement.get_strategy("env"))
+    runner = EmbodiedRunner(cfg, actor, rollout, env)
+    runner.init_workers(share_weights=False, env_tensors=env_tensors)
+    if actor.worker is not None:
+        actor.worker.model.load_reference_state_dict(state_dict)
+    return runner, placement
+
+
+def split_gpu_main(out_path, syncer, init_sync="0", backend="gloo", layout="split"):
+    """world 2, ``layout`` "split": rank 0 = learner, rank 1 = env + rollout (component_placement actor: 0 / env,rollout: 1), the
+    weights through the configured syncer over the weight-sync group, the trajectory buffer over the 1 : 1 route; or world 1,
+    ``layout`` "collocated": the same job in one process with the rollout keeping its own copy (in-process link).  Three
+    iterations, then one more weight sync; dumps what the parent compares."""
+    import copy
+
+    from oracle import ppo_loop as L
+    from oracle import ppo_oracle as O
+    os.environ["RLX_DIST_BACKEND"] = backend
+    W = int(os.environ["WORLD_SIZE"])
+    T, B = 12, 32
+    placement = {"actor": "0", "env,rollout": "1"} if layout == "split" else {"env,rollout,actor": "all"}
+    cfg = _split_cfg(syncer, placement, T=T, B=B, init_sync=init_sync == "1")
+    env = L.synthetic_env_tensors(0, T, B, 42, max_episode_steps=5)
+    torch.manual_seed(11)
+    sd = copy.deepcopy(O.OracleMLPPolicy(42, 8, 1).state_dict())
+    runner, pl = _launch_runner(cfg, env, sd)
+    assert pl.split == (layout == "split") and (W == 2) == pl.split
+    has_actor, has_rollout = runner._has["actor"], runner._has["rollout"]
+    metrics, versions, synced = [], [], []
+    for it in range(3):
+        eps = torch.randn(T, B, 8, generator=torch.Generator().manual_seed(100 + it)).cuda()
+        metrics.append(runner.run_step(eps))
+        if has_rollout:
+            versions.append(int(runner.rollout.worker.version))
+    runner.actor.set_global_step(runner.global_step).wait()
+    runner.update_rollout_weights()  # one more sync: the rollout's copy must now equal the learner's final weights byte for byte
+    torch.cuda.synchronize()
+    out = dict(rank=int(os.environ["RANK"]), layout=layout, has_actor=has_actor, has_rollout=has_rollout, metrics=metrics,
+               versions=versions, dist_backend=dist.get_backend() if dist.is_initialized() else None)
+    if has_actor:
+        a = runner.actor.worker
+        out.update(actor_params=a.model.flat.detach().cpu().clone(), actor_world=a._world_size, actor_rank=a._rank,
+                   grad_backend=a.grad_allreduce_backend, sender_initialized=a.weight_syncer.sender_initialized())
+    if has_rollout:
+        r = runner.rollout.worker
+        out.update(rollout_params=r.hf_model.flat.detach().cpu().clone(), final_version=int(r.version),
+                   shares=bool(r._shares_actor_weights), receiver_initialized=r.weight_syncer.receiver_initialized(),
+                   env_world=runner.env.worker._world_size, num_envs=runner.env.worker.num_envs)
+    torch.save(out, out_path)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def split_cpu_main(out_path):
+    """The split placement's host side on CPU over gloo (world 2): rank sets and groups from component_placement, the weight link's
+    four closures carrying reference-built payloads, the trajectory route."""
+    from rlinf_amd.config import DictConfig
+    from rlinf_amd.hybrid_engines.weight_syncer import EmptyWeightPatch, WeightBucket, WeightPatch
+    from rlinf_amd.scheduler import Cluster, init_distributed
+    from rlinf_amd.scheduler.dist import recv_tensors, send_tensors
+    from rlinf_amd.utils.placement import HybridComponentPlacement
+    from rlinf_amd.workers.weight_link import GroupLink
+    ctx = init_distributed(device_type="cpu")
+    cfg = DictConfig(dict(cluster=dict(num_nodes=1, component_placement={"actor": 0, "env,rollout": "1"})))
+    pl = HybridComponentPlacement(cfg, Cluster(cluster_cfg=cfg.cluster, ctx=ctx))
+    res = {"rank": ctx.rank, "split": pl.split, "worlds": [pl.get_world_size(c) for c in ("actor", "rollout", "env")],
+           "present": [pl.get_strategy(c).present for c in ("actor", "rollout", "env")]}
+    me = pl.get_strategy("actor" if ctx.rank == 0 else "rollout").ctx
+    res["component_ctx"] = [me.rank, me.world_size, me.global_ranks]
+    link = GroupLink(pl, torch.device("cpu"))
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "weight_patch.pt"), weights_only=False)[0]["patches"]
+    fields = ("version", "ordinals", "nnz_per_tensor", "rows", "cols", "values")
+    layout = (("w", torch.bfloat16, (3, 5), 0), ("steps", torch.int64, (), 256))
+    if ctx.rank == 0:  # the learner: metadata in, then a bucket, a patch, an empty patch out
+        meta = link.actor_recv()
+        res["meta"] = meta
+        b = WeightBucket.from_flat(torch.zeros(512, dtype=torch.uint8), layout,
+                                   {"total_buckets": torch.tensor(1, dtype=torch.int32), "syncer_version": torch.tensor(4, dtype=torch.int32)})
+        b["w"].copy_(torch.arange(15).reshape(3, 5)), b["steps"].fill_(9)
+        link.actor_send(b)
+        link.actor_send(WeightPatch(**{f: fx[0][f] for f in fields}))
+        link.actor_send(EmptyWeightPatch(torch.tensor(12)))
+        traj = [torch.empty(4, 6), torch.empty(5, 6, 1, dtype=torch.bool)]
+        recv_tensors(traj, pl.peer_of("actor", "env"))
+        res["traj_ok"] = bool(torch.equal(traj[0], torch.arange(24.).reshape(4, 6)) and traj[1][::2].all() and not traj[1][1::2].any())
+    else:  # the rollout rank
+        link.rollout_send({"ordered_keys": ["a", "b"], "receiver_dtypes": {"a": torch.bfloat16}})
+        b = link.rollout_recv()
+        res["bucket_ok"] = bool(isinstance(b, WeightBucket) and int(b["syncer_version"]) == 4 and int(b["steps"]) == 9
+                                and b["w"].float().flatten().tolist() == list(range(15)))
+        p = link.rollout_recv()
+        res["patch_ok"] = bool(isinstance(p, WeightPatch) and all(torch.equal(getattr(p, f), fx[0][f]) for f in fields))
+        e = link.rollout_recv()
+        res["empty_ok"] = bool(isinstance(e, EmptyWeightPatch) and int(e.version) == 12)
+        done = torch.zeros(5, 6, 1, dtype=torch.bool)
+        done[::2] = True
+        send_tensors([torch.arange(24.).reshape(4, 6), done], pl.peer_of("env", "actor"))
+    res["meta"] = {k: (v if not isinstance(v, dict) else {a: str(b) for a, b in v.items()}) for k, v in res.get("meta", {}).items()}
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "cpu":
         cpu_main(sys.argv[2])
+    elif sys.argv[1] == "split_cpu":
+        split_cpu_main(sys.argv[2])
+    elif sys.argv[1] == "split_gpu":
+        split_gpu_main(*sys.argv[2:])
     elif sys.argv[1] == "gpu_async":
         gpu_async_main(*sys.argv[2:])
     else:

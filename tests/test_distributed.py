@@ -407,3 +407,62 @@ def test_bench_self_launches_its_ranks_from_a_bare_shell(tmp_path):
     assert line["transports"]["strong/xgmi"]["grad_allreduce"].startswith("xgmi (direct, kernel hand-shake)")
     assert line["transports"]["strong/xgmi"]["update_graph_replayed"] is True    # a pure kernel chain: captured at any world size
     assert line["transports"]["strong/rccl"]["update_graph_replayed"] is False   # gloo cannot be captured: eager fallback, both ranks
+
+
+# ---- split placement (actor ranks != rollout ranks) + the weight syncers in the worker path -----------------------
+def test_split_placement_host_logic_over_gloo(tmp_path):
+    """component_placement ``actor: 0`` / ``env,rollout: 1`` at world 2, CPU: rank sets, per-component contexts and groups, the
+    weight link's closures (metadata point to point, bucket / patch / empty patch over the sync group's broadcast) and the 1 : 1
+    trajectory route (bool fields travel as bytes)."""
+    r0, r1 = (json.load(open(o)) for o in _launch("split_cpu", tmp_path, port=29691))
+    for r in (r0, r1):
+        assert r["split"] is True and r["worlds"] == [1, 1, 1]
+    assert r0["present"] == [True, False, False] and r1["present"] == [False, True, True]
+    assert r0["component_ctx"] == [0, 1, [0]] and r1["component_ctx"] == [0, 1, [1]]
+    assert r0["meta"]["ordered_keys"] == ["a", "b"] and r0["meta"]["receiver_dtypes"] == {"a": "torch.bfloat16"}
+    assert r1["bucket_ok"] and r1["patch_ok"] and r1["empty_ok"] and r0["traj_ok"]
+
+
+def test_component_placement_parsing():
+    from rlinf_amd.utils.placement import parse_component_placement, parse_rank_spec
+    assert parse_rank_spec("all", 4) == [0, 1, 2, 3] and parse_rank_spec(2, 4) == [2] and parse_rank_spec("0-1,3", 4) == [0, 1, 3]
+    assert parse_component_placement({"actor": "0-3", "env,rollout": "4-7"}, 8) == {
+        "actor": [0, 1, 2, 3], "env": [4, 5, 6, 7], "rollout": [4, 5, 6, 7]}
+    assert parse_component_placement({"env,rollout,actor": 0}, 1) == {"env": [0], "rollout": [0], "actor": [0]}
+    with pytest.raises(ValueError):
+        parse_component_placement({"actor": "0", "actor,env": "1"}, 2)
+    with pytest.raises(ValueError):
+        parse_rank_spec("3-1", 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("syncer,init_sync", [("bucket", "0"), ("patch", "0"), ("patch", "1")])
+def test_split_placement_whole_loop_matches_the_collocated_run(tmp_path, syncer, init_sync):
+    """Learner on rank 0, env + rollout on rank 1 (two processes on the one GPU, gloo standing in for RCCL) against the SAME job in
+    one process: after every sync the rollout worker's weights are the learner's byte for byte (so every iteration's rollout,
+    advantages and update are the collocated run's: metrics equal), versions advance with the global step, and the syncer ran
+    its init hand-shake once on each side."""
+    (tmp_path / "split").mkdir(), (tmp_path / "one").mkdir()
+    split = [torch.load(o, weights_only=False) for o in _launch("split_gpu", tmp_path / "split", syncer, init_sync, "gloo", "split",
+                                                               port=29693 + 2 * (syncer == "patch") + 4 * (init_sync == "1"))]
+    one = [torch.load(o, weights_only=False) for o in _launch("split_gpu", tmp_path / "one", syncer, init_sync, "gloo", "collocated",
+                                                             world=1, port=29701 + 2 * (syncer == "patch") + 4 * (init_sync == "1"))][0]
+    learner, rollout = split
+    assert learner["has_actor"] and not learner["has_rollout"] and rollout["has_rollout"] and not rollout["has_actor"]
+    assert learner["actor_world"] == 1 and rollout["env_world"] == 1 and rollout["num_envs"] == 32
+    assert learner["sender_initialized"] and rollout["receiver_initialized"] and not rollout["shares"]
+    # weights: the rollout rank's copy after the closing sync == the learner's final weights, byte for byte
+    assert torch.equal(rollout["rollout_params"].view(torch.int32), learner["actor_params"].view(torch.int32))
+    assert rollout["versions"] == [0, 1, 2] and rollout["final_version"] == 3
+    # the single-process run with its own rollout copy over the in-process link: same weights, same versions
+    assert one["has_actor"] and one["has_rollout"] and not one["shares"]
+    assert torch.equal(one["rollout_params"].view(torch.int32), one["actor_params"].view(torch.int32))
+    assert one["versions"] == [0, 1, 2] and one["final_version"] == 3
+    assert torch.equal(one["actor_params"].view(torch.int32), learner["actor_params"].view(torch.int32))
+    for it in range(3):
+        got, want = learner["metrics"][it], one["metrics"][it]
+        keys = [k for k in want if k.startswith(("train/", "rollout/"))]
+        assert keys and all(k in got for k in keys)
+        for k in keys:
+            assert got[k] == pytest.approx(want[k], rel=1e-6, abs=1e-9), (it, k)
+        assert not any(k.startswith("train/") for k in rollout["metrics"][it])  # a rollout-only rank trains nothing

@@ -18,9 +18,12 @@ class Cfg(dict):
 @pytest.fixture(scope="module")
 def registry(ref):
     mr = RL.load_models_registry()
-    saved = dict(mr.models._MODEL_REGISTRY)
+    reg = ref.registry  # ext.register() also re-registers the advantage / loss callees: everything is put back afterwards
+    saved = dict(mr.models._MODEL_REGISTRY), dict(reg.ADV_REGISTRY), dict(reg.LOSS_REGISTRY)
     yield mr
-    mr.models._MODEL_REGISTRY.clear(), mr.models._MODEL_REGISTRY.update(saved)
+    mr.models._MODEL_REGISTRY.clear(), mr.models._MODEL_REGISTRY.update(saved[0])
+    reg.ADV_REGISTRY.clear(), reg.ADV_REGISTRY.update(saved[1])
+    reg.LOSS_REGISTRY.clear(), reg.LOSS_REGISTRY.update(saved[2])
 
 
 def _register():
