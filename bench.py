@@ -414,13 +414,18 @@ def measure(ctx, *, precision: str, scaling: str = "strong", steps: int, warmup:
                 "ms_per_step_windows": ({"window": 10, "n": len(win), "min": round(win[0], 3), "median": round(win[len(win) // 2], 3),
                                          "max": round(win[-1], 3)} if win else None),
                 "ppo_updates_per_sec": round(updates * steps / elapsed, 1), "steps": steps, "total_envs": envs, "global_batch": gb,
-                "grad_allreduce": w.grad_allreduce_backend + (f" ({w._xgmi.algo}, {w._xgmi.wait_mode} hand-shake)" if w._xgmi is not None else ""),
+                "grad_allreduce": w.grad_allreduce_backend + ((" (one launch per step: pushed self-validating words)" if (getattr(w._xgmi, "one_launch", False) and w.adamw_sync is not None)
+                                                               else f" ({w._xgmi.algo}, {w._xgmi.wait_mode} hand-shake)") if w._xgmi is not None else ""),
                 "update_graph_replayed": w._graph is not None, "elapsed_s": round(elapsed, 4),
                 "ranks_seen": ranks_seen, "devices_seen": devices_seen,
                 # the exchange this run REALLY used: the hand-written one only when its start-up validation against
                 # torch.distributed's all-reduce passed on every rank (scheduler.xgmi.build), else RCCL -- whatever was asked for
                 "xgmi": (None if xg is None else {"validated_against_torch_distributed": True, "algo": xg.algo, "wait_mode": xg.wait_mode,
-                                                  "mem_kind": getattr(xg, "mem_kind", None), "ranks_share_a_device": bool(xg.shared_device)}),
+                                                  "mem_kind": getattr(xg, "mem_kind", None), "ranks_share_a_device": bool(xg.shared_device),
+                                                  # the exchange inside the one-launch optimizer step (pushed self-validating words):
+                                                  # used when ITS start-up validation passed, else the launch chain
+                                                  "one_launch_exchange": bool(getattr(xg, "one_launch", False) and w.adamw_sync is not None),
+                                                  "one_launch_verdict": getattr(xg, "one_launch_verdict", None)}),
                 "metrics_read": "every iteration, one iteration late (runner.defer_metrics)" if DEFER_METRICS else "every iteration, before the next is queued",
                 "last_metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in m.items()
                                  if k in ("train/actor/total_loss", "train/actor/grad_norm", "train/actor/approx_kl", "rollout/rewards")}}

@@ -862,6 +862,13 @@ int rlx_xgmi_connect_local(rlx_xgmi_comm* const* comms, int world);
  * executes on one device with local-memory reads in place of xGMI reads and hand-shakes that are satisfied at once.  The reduced
  * values are NOT a valid all-reduce (every shard is this rank's shard); use scratch parameter / moment buffers. */
 int rlx_xgmi_connect_self(rlx_xgmi_comm* comm);
+/* How a self-connected communicator plays the ONE-LAUNCH exchange (rlx_xgmi_clip_adamw_step with rlx_adamw_params.sync_words):
+ * 0 (default) EXACT -- a block plays its own W - 1 contributors / the owner that answers it: with W a power of two the result is
+ * the single-GPU step's bit for bit (parity tests); 1 TIMING -- the rank's blocks b, b + nblk / W, ... play ranks 0, 1, ...'s
+ * copies of owned block b, so an owner's contributions come from, and its answers go to, other workgroups running concurrently
+ * (a rank's real communication structure on one device; values are sums of different blocks' gradients: scratch buffers only;
+ * needs nblk % W == 0, else the exact form runs). */
+int rlx_xgmi_self_timing(rlx_xgmi_comm* comm, int on);
 /* algo: 0 direct, 1 reduce-scatter + all-gather; wait_mode: 0 inline, 1 own launch; timeout_ms > 0: new bound of every peer
  * wait.  -1 (0 for the timeout) keeps the current value.  Every rank of a group must configure the same algo. */
 int rlx_xgmi_configure(rlx_xgmi_comm* comm, int algo, int wait_mode, int timeout_ms);

@@ -248,6 +248,7 @@ PROTOTYPES = {
     "rlx_xgmi_connect": (c_int, [c_void_p, c_void_p]),
     "rlx_xgmi_connect_local": (c_int, [POINTER(c_void_p), c_int]),
     "rlx_xgmi_connect_self": (c_int, [c_void_p]),
+    "rlx_xgmi_self_timing": (c_int, [c_void_p, c_int]),
     "rlx_xgmi_configure": (c_int, [c_void_p, c_int, c_int, c_int]),
     "rlx_xgmi_destroy": (c_int, [c_void_p]),
     "rlx_xgmi_status": (c_int, [c_void_p]),

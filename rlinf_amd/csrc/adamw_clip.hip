@@ -363,6 +363,7 @@ __device__ __forceinline__ void update_f4(float* __restrict__ p, float* __restri
 constexpr int kSyncSlot0 = 2, kSlotStride = 2;  // sync[0] = epoch, sync[1] = "a poll expired" (sticky), then one slot of two words per block
 constexpr int kOneThreads = 512, kMaxSegs = 10, kOneRows = kOneThreads / 64;  // rows of a hidden matrix per block
 constexpr int kMaxOneBlocks = 512;  // slots a polling wave covers (8 per lane)
+static_assert(kMaxOneBlocks == kExchangeSlots, "the exchange's partial slots (opt_common.h) are the one-launch kernel's");
 struct SegPlan {
     int nseg, nblk;
     int blk0[kMaxSegs];                          // first block of segment k
@@ -375,14 +376,15 @@ struct SegBlock {
     int b0, mat;
     bool live;
 };
-__device__ __forceinline__ SegBlock seg_block(const SegPlan& plan) {  // (scalar selects over the argument block)
+__device__ __forceinline__ SegBlock seg_block(const SegPlan& plan, int bidx = -1) {  // (scalar selects over the argument block)
+    if (bidx < 0) bidx = (int)blockIdx.x;
     long long s4 = plan.start4[0], e4 = plan.end4[0];
     int b0 = 0, mat = plan.mat[0];
 #pragma unroll
     for (int q = 1; q < kMaxSegs; ++q)
-        if (q < plan.nseg && (int)blockIdx.x >= plan.blk0[q]) s4 = plan.start4[q], e4 = plan.end4[q], b0 = plan.blk0[q], mat = plan.mat[q];
+        if (q < plan.nseg && bidx >= plan.blk0[q]) s4 = plan.start4[q], e4 = plan.end4[q], b0 = plan.blk0[q], mat = plan.mat[q];
     SegBlock sb;
-    sb.blk4 = s4 + (long long)((int)blockIdx.x - b0) * kOneThreads;
+    sb.blk4 = s4 + (long long)(bidx - b0) * kOneThreads;
     sb.i = sb.blk4 + threadIdx.x;
     sb.b0 = b0, sb.mat = mat, sb.live = sb.i < e4;
     return sb;
@@ -573,6 +575,37 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* __restrict__ p, 
 // image takes a lane's four consecutive inputs as one 8-byte store, and the transposed image -- eight consecutive OUTPUTS per
 // 16-byte fragment slot, i.e. one value from each of eight rows -- is assembled through LDS and written as full 16-byte stores.
 // (The generic scatter writes the transposed image as 2-byte stores 16 bytes apart: 3.1 of the first version's 17.0 us.)
+// The gradient exchange INSIDE the one-launch optimizer step (world_size > 1, one rank per GPU; rlx_xgmi_clip_adamw_step with
+// rlx_adamw_params.sync_words).  The four-launch chain (stage -> hand-shake -> reduce(-scatter) -> gather + clip + AdamW) moved the
+// DATA by peer reads behind flag hand-shakes; here the data travels the way round 5's norm partials do: every value is PUSHED into
+// the consumer's fine-grained buffer as a self-validating 64-bit word, epoch << 32 | float bits -- a single-copy-atomic store that
+// carries its own validity -- and the consumer polls the payload itself in its LOCAL memory.  No stage launch, no hand-shake
+// launch, no flag, no fence, no remote read; one kernel per rank and step:
+//
+//   every block   sums its 2048 parameters' slabs (the gradient stays in registers)
+//   block b is OWNED by rank b * W / nblk (contiguous blocks = contiguous parameters: the reduce-scatter's shards)
+//     non-owner    pushes its float4s into the owner's inbox row [its rank]
+//     owner        polls the W - 1 inbox rows of its own buffer, adds the W gradients in RANK order (one sum per element,
+//                  formed once, on the owner: every replica receives the same bits), scales by 1 / W, publishes the block's
+//                  squared-norm partial to every rank's slot b and pushes the reduced float4s into every other rank's gather area
+//     non-owner    polls its float4s of its own gather area
+//   every block   polls all nblk partial slots of its own buffer (wave 0, fixed order: the same norm in every block of every
+//                  rank), then clip + AdamW + weight-image refresh as on one GPU.
+//
+// Two one-way trips over xGMI on the critical path (contribution in, reduced value out) and (W - 1) / W x 2 x 8 bytes per parameter
+// and direction on a rank's links.  Buffers are reused every step with the next epoch: a rank can only push step s + 1 after its
+// step-s kernel ended, i.e. after it polled every step-s partial, i.e. after every owner consumed every step-s inbox row; a
+// gather word of step s + 1 needs all ranks' step-s + 1 contributions, which follow their step-s kernels in stream order.
+// Protocol model with torn-word and stale-epoch negative controls: tests/test_xgmi_protocol_model.py.
+struct XchgPeers {
+    unsigned long long* inbox[kMaxRanks];   // rank q's inbox: [world rows][n_cap words]; this rank writes row [rank]
+    unsigned long long* gather[kMaxRanks];  // rank q's gather area: [n_cap words]
+    unsigned long long* parts[kMaxRanks];   // rank q's norm-partial slots: [kMaxOneBlocks][2 words]
+    long long n_cap;                        // words per inbox row (the communicator's n_max)
+    int rank, world;                        // world <= 1: no exchange (the single-GPU launch)
+    int self_alias;                         // timing / single-device emulation: every peer is this rank's own buffer (see below)
+    int* status;                            // the communicator's time-out word (host: rlx_xgmi_status)
+};
 struct OneLaunchArgs {
     ReduceSrc src;
     float *p, *g, *m, *v;
@@ -588,14 +621,63 @@ struct OneLaunchArgs {
     DeferredScale dfr;
     SegPlan plan;
     long long poll_ticks;  // bound of the exchange's poll in 100 MHz ticks (2 s; RLX_ONE_LAUNCH_POLL_MS shortens it for the expiry tests)
+    XchgPeers x;
 };
-template <bool DEFER, int SB>
+// One tagged float4: four 64-bit words, each a single-copy-atomic store / load of its own.  Word e of float4 i lives at
+// xword(i) + 64 e: the four components of 64 consecutive float4s are four runs of 64 words, so that ONE store / load instruction of
+// a wave covers 512 contiguous bytes (component-major inside a 64-float4 group; lane-major put 8 bytes into every 32: sixteen
+// partially written lines per instruction on memory that no cache merges).
+__device__ __forceinline__ size_t xword(long long i) { return (size_t)(i & ~63ll) * 4 + (size_t)(i & 63ll); }
+template <int SCOPE>
+__device__ __forceinline__ void push_f4(unsigned long long* dst, float4 v, unsigned e1) {
+    const unsigned long long t = (unsigned long long)e1 << 32;
+    __hip_atomic_store(dst + 0, t | (unsigned long long)__float_as_uint(v.x), __ATOMIC_RELAXED, SCOPE);
+    __hip_atomic_store(dst + 64, t | (unsigned long long)__float_as_uint(v.y), __ATOMIC_RELAXED, SCOPE);
+    __hip_atomic_store(dst + 128, t | (unsigned long long)__float_as_uint(v.z), __ATOMIC_RELAXED, SCOPE);
+    __hip_atomic_store(dst + 192, t | (unsigned long long)__float_as_uint(v.w), __ATOMIC_RELAXED, SCOPE);
+}
+// Poll `nsrc` tagged float4s (this lane's, one per source) until every word carries epoch e1; false: the bound expired or the sticky
+// word was set meanwhile.  All loads of a round are issued before the first check.
+template <int SCOPE, int MAXSRC>
+__device__ __forceinline__ bool poll_f4(unsigned long long* const (&src)[MAXSRC], unsigned pending, unsigned e1, const unsigned long long* sticky,
+                                        long long ticks, float4 (&out)[MAXSRC]) {  // pending: bit q set = src[q] is to be polled
+    const long long t0 = wall_clock64();
+    for (int spins = 0; pending != 0; ++spins) {
+        unsigned long long w[MAXSRC][4];
+#pragma unroll
+        for (int q = 0; q < MAXSRC; ++q)
+            if (pending & (1u << q)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[q][e] = __hip_atomic_load(src[q] + 64 * e, __ATOMIC_RELAXED, SCOPE);
+            }
+        const unsigned long long stick = __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < MAXSRC; ++q)
+            if ((pending & (1u << q)) && (unsigned)(w[q][0] >> 32) == e1 && (unsigned)(w[q][1] >> 32) == e1 &&
+                (unsigned)(w[q][2] >> 32) == e1 && (unsigned)(w[q][3] >> 32) == e1) {
+                out[q] = float4{__uint_as_float((unsigned)w[q][0]), __uint_as_float((unsigned)w[q][1]), __uint_as_float((unsigned)w[q][2]),
+                                __uint_as_float((unsigned)w[q][3])};
+                pending &= ~(1u << q);
+            }
+        if (pending == 0) break;
+        if (stick != 0ull) return false;
+        if (spins > 8) {
+            if (wall_clock64() - t0 > ticks) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return true;
+}
+template <bool DEFER, int SB, bool XCHG = false>
 __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(OneLaunchArgs k) {  // (4 waves per SIMD = two blocks per CU: <= 128 VGPRs)
     touch_kernargs<(int)sizeof(OneLaunchArgs)>();
     __shared__ double s_red[kOneThreads / 64];
     __shared__ AdamScalars s_sc;
     __shared__ double s_tot;
     __shared__ int s_exp;
+    __shared__ int s_xexp;  // XCHG: a data poll of this block expired
+    // partial slots and payload words live in the communicator's fine-grained buffers and are written by OTHER devices: system scope
+    constexpr int SCOPE = XCHG ? __HIP_MEMORY_SCOPE_SYSTEM : __HIP_MEMORY_SCOPE_AGENT;
     __shared__ __bf16 s_t[3][kOneRows][256 + 8];  // [plane][row of the block][input]: the transposed image's staging (12.4 KiB)
     const rlx_adamw_params& a = k.a;
     float* __restrict__ p = k.p;
@@ -629,19 +711,131 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
     if (live) {
         if constexpr (DEFER) g4 = sum_slab_groups_f4<SB>(reinterpret_cast<const float4*>(k.src.base[0]), i, k.n4, k.src.nslab, k.dfr);
         else g4 = sum_slabs_f4<SB>(reinterpret_cast<const float4*>(k.src.base[0]) + i, k.n4, k.src.nslab);
-        p4 = reinterpret_cast<const float4*>(p)[i];
-        m4 = reinterpret_cast<const float4*>(m)[i];
-        v4 = reinterpret_cast<const float4*>(v)[i];
-        g4.x *= k.scale; g4.y *= k.scale; g4.z *= k.scale; g4.w *= k.scale;
+        if constexpr (!XCHG) {  // (under the exchange they are requested behind the data polls: registers)
+            p4 = reinterpret_cast<const float4*>(p)[i];
+            m4 = reinterpret_cast<const float4*>(m)[i];
+            v4 = reinterpret_cast<const float4*>(v)[i];
+            g4.x *= k.scale; g4.y *= k.scale; g4.z *= k.scale; g4.w *= k.scale;
+        }
     }
+    // where this launch's partial slots are: the caller's sync words (one GPU), or this rank's slots in its exchange buffer
+    unsigned long long* slots_mine = XCHG ? k.x.parts[k.x.rank] : sync + kSyncSlot0;
+    bool is_owner = true;
+    if constexpr (XCHG) {
+        const XchgPeers& x = k.x;
+        const int W = x.world, me = x.rank;
+        const int owner = (int)(((long long)blockIdx.x * W) / gridDim.x);
+        is_owner = owner == me;
+        if (threadIdx.x == 0) s_xexp = 0;
+        __syncthreads();
+        bool ok = true;
+        const size_t w4 = xword(i);  // this lane's first word in a row
+        // self_alias 2 (timing): this rank's blocks b, b + per, b + 2 per, ... play ranks 0, 1, 2, ...'s copies of owned block b -- the
+        // W - 1 contributions an owner waits for come from OTHER workgroups running concurrently, and its answers go to theirs,
+        // like over the links (values are then sums of different blocks' gradients: scratch buffers only)
+        const int per = (int)gridDim.x / W, vb = (int)blockIdx.x % per, vp = (int)blockIdx.x / per;
+        const bool timing = x.self_alias == 2;
+        if (timing && !poisoned) {
+            if (!is_owner) {
+                const SegBlock ob = seg_block(k.plan, vb);  // the owned block this workgroup is rank vp's copy of
+                if (ob.live) push_f4<SCOPE>(x.inbox[me] + (size_t)vp * (size_t)x.n_cap + xword(ob.i), g4, e1);
+            }
+        }
+        if (live && !poisoned) {
+            if (!is_owner) {
+                if (!timing) push_f4<SCOPE>(x.inbox[owner] + (size_t)me * (size_t)x.n_cap + w4, g4, e1);  // contribution -> the owner's inbox row [me]
+            } else {
+                if (x.self_alias == 1)  // single-device emulation, exact: this block also plays the W - 1 peers that contribute to it
+                    for (int p = 0; p < W; ++p)
+                        if (p != me) push_f4<SCOPE>(x.inbox[me] + (size_t)p * (size_t)x.n_cap + w4, g4, e1);
+                // rank order: ranks 0 .. me - 1 from the inbox, this rank's own, then me + 1 .. W - 1 -- four ranks' rows per
+                // round of loads (the rows arrive concurrently; one row per round made W - 1 dependent trips to memory: 14 us of
+                // the W = 8 step against 9 this way; all seven at once does not fit 128 registers)
+                float4 sum{0.f, 0.f, 0.f, 0.f};
+                for (int base = 0; base < W; base += 4) {
+                    unsigned long long* src[4];
+                    float4 got[4];
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = base + u;
+                        src[u] = x.inbox[me] + (size_t)(r < W ? r : 0) * (size_t)x.n_cap + w4;
+                        got[u] = float4{0.f, 0.f, 0.f, 0.f};
+                        if (r < W && r != me) mask |= 1u << u;
+                    }
+                    if (mask != 0) ok = poll_f4<SCOPE, 4>(src, mask, e1, &sync[1], k.poll_ticks, got) && ok;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = base + u;
+                        if (r < W) {
+                            const float4 t = r == me ? g4 : got[u];
+                            if (r == 0) sum = t;
+                            else { sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w; }
+                        }
+                    }
+                }
+                g4 = sum;
+            }
+            if (!is_owner && x.self_alias == 1) {  // ... and the owner this block's contribution went to: W copies of its own gradient
+                float4 sum = g4;
+                for (int p = 1; p < W; ++p) { sum.x += g4.x; sum.y += g4.y; sum.z += g4.z; sum.w += g4.w; }
+                g4 = sum;
+            }
+            if (is_owner || x.self_alias == 1) {
+                g4.x *= k.scale; g4.y *= k.scale; g4.z *= k.scale; g4.w *= k.scale;
+                if (is_owner && x.self_alias == 0) {
+                    for (int p = 0; p < W; ++p)
+                        if (p != me) push_f4<SCOPE>(x.gather[p] + w4, g4, e1);  // reduced value -> every other rank's gather area
+                } else if (!is_owner) {
+                    push_f4<SCOPE>(x.gather[me] + w4, g4, e1);  // (exact emulation: the answer the remote owner would have pushed)
+                }
+            }
+            if (is_owner && timing) {  // the answers to ranks 1 .. W - 1's copies of this block: their own gather words
+                for (int p = 1; p < W; ++p) {
+                    const SegBlock cb = seg_block(k.plan, vb + p * per);
+                    if (cb.live) push_f4<SCOPE>(x.gather[me] + xword(cb.i), g4, e1);
+                }
+            }
+            if (!is_owner) {
+                unsigned long long* src[1] = {x.gather[me] + w4};
+                float4 got[1] = {float4{0.f, 0.f, 0.f, 0.f}};
+                ok = poll_f4<SCOPE, 1>(src, 1u, e1, &sync[1], k.poll_ticks, got) && ok;
+                g4 = got[0];
+            }
+        }
+        if (!ok) atomicOr(&s_xexp, 1);
+        if (live) {  // in flight while the norm forms
+            p4 = reinterpret_cast<const float4*>(p)[i];
+            m4 = reinterpret_cast<const float4*>(m)[i];
+            v4 = reinterpret_cast<const float4*>(v)[i];
+        }
+    }
+    // the squared-norm partial of this block's 2048 REDUCED, scaled values: every block on one GPU, the owner (once per block
+    // across the job) under the exchange -- which publishes it to every rank's slot
+    const bool publishes = !XCHG || is_owner || k.x.self_alias;
     double acc[1] = {(double)g4.x * (double)g4.x + (double)g4.y * (double)g4.y + (double)g4.z * (double)g4.z + (double)g4.w * (double)g4.w};
+    if (!live) acc[0] = 0.0;
     RLX_OL_STAMP(1);
-    block_sum<1>(acc, s_red);
-    if (threadIdx.x == 0) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(acc[0]), tag = (unsigned long long)e1 << 32;
-        unsigned long long* slot = sync + kSyncSlot0 + kSlotStride * (size_t)blockIdx.x;
-        __hip_atomic_store(slot, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (publishes) block_sum<1>(acc, s_red);
+    else __syncthreads();
+    if (threadIdx.x == 0 && publishes) {
+        double part = acc[0];
+        if constexpr (XCHG) {
+            if (s_xexp != 0) part = __longlong_as_double(0x7ff8000000000000ll);  // an expired data poll: a NaN partial -> every rank skips
+        }
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(part), tag = (unsigned long long)e1 << 32;
+        if constexpr (XCHG) {
+            for (int p = 0; p < k.x.world; ++p) {
+                if (k.x.self_alias && p != k.x.rank) continue;
+                unsigned long long* slot = k.x.parts[p] + kSlotStride * (size_t)blockIdx.x;
+                __hip_atomic_store(slot, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, SCOPE);
+                __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, SCOPE);
+            }
+        } else {
+            unsigned long long* slot = slots_mine + kSlotStride * (size_t)blockIdx.x;
+            __hip_atomic_store(slot, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, SCOPE);
+            __hip_atomic_store(slot + 1, tag | (bits >> 32), __ATOMIC_RELAXED, SCOPE);
+        }
     }
     RLX_OL_STAMP(2);
     // Wave 0 polls for the block: lane L takes blocks L, L + 64, ... (up to 8), adds them in a fixed order (the same in every block ->
@@ -672,9 +866,9 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (pending & (1u << u)) {
-                    const unsigned long long* slot = sync + kSyncSlot0 + kSlotStride * (size_t)(lane + 64 * u);
-                    lo[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hi[u] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long* slot = slots_mine + kSlotStride * (size_t)(lane + 64 * u);
+                    lo[u] = __hip_atomic_load(slot, __ATOMIC_RELAXED, SCOPE);
+                    hi[u] = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, SCOPE);
                 }
             if (spins == 0 && lane == 0) form_scalars(a, k.state != nullptr ? steps_done + 1 : a.step, &sc);  // (behind the first polls' latency)
 #pragma unroll
@@ -702,7 +896,7 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
     for (int u = 0; u < 8; ++u) tot += pv[u];
     tot = wave_sum(tot);
     const int wave_expired = __any(expired ? 1 : 0);
-    if (threadIdx.x == 0) s_tot = tot, s_exp = wave_expired != 0 ? 1 : 0;  // (wave 0 polled for the block)
+    if (threadIdx.x == 0) s_tot = tot, s_exp = (wave_expired != 0 || (XCHG && s_xexp != 0)) ? 1 : 0;  // (wave 0 polled for the block)
     __syncthreads();
     tot = s_tot;
     const bool any_expired = s_exp != 0;
@@ -716,9 +910,12 @@ __global__ __launch_bounds__(kOneThreads, 4) void reduce_clip_adamw_one_launch(O
         // only now and finds every slot published still forms a non-finite norm and skips with the rest
         __hip_atomic_store(&sync[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long nan_bits = 0x7ff8000000000000ull, tag = (unsigned long long)e1 << 32;
-        unsigned long long* slot = sync + kSyncSlot0 + kSlotStride * (size_t)blockIdx.x;
-        __hip_atomic_store(slot, tag | (nan_bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, tag | (nan_bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* slot = slots_mine + kSlotStride * (size_t)blockIdx.x;
+        __hip_atomic_store(slot, tag | (nan_bits & 0xffffffffull), __ATOMIC_RELAXED, SCOPE);
+        __hip_atomic_store(slot + 1, tag | (nan_bits >> 32), __ATOMIC_RELAXED, SCOPE);
+        if constexpr (XCHG) {  // a peer never delivered: the communicator's time-out word (the host raises: rlx_xgmi_status)
+            if (k.x.status != nullptr) __hip_atomic_store(k.x.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) {  // (ONE writer of the step's stats: an expiry elsewhere is the sticky word's to report)
         k.stats[0] = total_norm;
@@ -908,6 +1105,20 @@ int one_launch_blocks_per_cu() {
     }();
     return capacity;
 }
+int xchg_blocks_per_cu() {
+    static const int capacity = [] {
+        int best = 1 << 30;
+        const void* kernels[4] = {(const void*)reduce_clip_adamw_one_launch<false, 9, true>, (const void*)reduce_clip_adamw_one_launch<false, 24, true>,
+                                  (const void*)reduce_clip_adamw_one_launch<true, 9, true>, (const void*)reduce_clip_adamw_one_launch<true, 24, true>};
+        for (const void* k : kernels) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kOneThreads, 0) != hipSuccess) return 0;
+            best = std::min(best, per_cu);
+        }
+        return best;
+    }();
+    return capacity;
+}
 // ... and on the compute units THIS stream may use (an unmasked stream: the whole device).  The bound is against an otherwise idle
 // device: what another process or another stream holds is not visible from here -- for that case the kernel's poll is bounded
 // and its expiry is sticky (see the kernel), and ranks of one job that share a GPU do not use the form at all.
@@ -994,6 +1205,57 @@ static int launch_clip_adamw(bool gather, float* params, float* out, float* exp_
         hipLaunchKernelGGL(clip_adamw_kernel<false>, dim3(nblk), dim3(256), 0, s, params, out, exp_avg, exp_avg_sq, (long long)n, k, partials, nparts,
                            scalars, stats, step_state, lay, tiles, seq_inc, status, gsrc, w);
     RLX_LAUNCH_CHECK();
+    return RLX_OK;
+}
+
+// The optimizer step WITH the gradient exchange as one launch per rank (see XchgPeers).  *used = false: the plan does not allow it
+// (buffers not float4-shaped, too many blocks for the stream / for `co_resident` ranks sharing this device) -- the caller falls
+// back to its launch chain.  `grads`: this rank's split-K slabs; `out`: receives the clipped mean gradient.
+int launch_exchange_clip_adamw_one_launch(float* params, const float* grads, int nslab, float* out, float* exp_avg, float* exp_avg_sq,
+                                          int64_t n, const rlx_adamw_params* p, float* stats, int32_t* step_state, const ExchangeBuffers& xb,
+                                          unsigned long long* xsync, int co_resident, long long timeout_ticks, int* status, hipStream_t s, bool* used) {
+    *used = false;
+    if (n == 0 || p->sync_words == nullptr) return RLX_OK;
+    rlx_mlp_layout lay{};
+    float* tiles = nullptr;
+    if (int rc = check_adamw_args(params, out, exp_avg, exp_avg_sq, n, p, stats, step_state, lay, tiles)) return rc;
+    const bool defer = p->deferred_scale != nullptr;
+    if (defer)
+        if (int rc = check_deferred(p, nslab, n, "rlx_xgmi_clip_adamw_step")) return rc;
+    if (n % 4 != 0 || (n + 255) / 256 * 256 > xb.n_cap || n / 4 > (long long)kOneThreads * kMaxOneBlocks ||
+        (reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(p->sync_words) |
+         reinterpret_cast<uintptr_t>(tiles)) % 16 != 0)
+        return RLX_OK;
+    const rlx_adamw_params k = tile_format_resolved(p, tiles);
+    const SegPlan sp = plan_segments(n / 4, &lay, tiles != nullptr && k.tiles_bf16 != 0);
+    const int capacity = std::min(xchg_blocks_per_cu() * stream_cus(s), kMaxOneBlocks);
+    if (sp.nblk < 1 || sp.nblk < xb.world || ((long long)sp.nblk * std::max(1, co_resident) > capacity && !one_launch_ignores_capacity()))
+        return RLX_OK;
+    OneLaunchArgs oa{};
+    oa.src.nbase = 1, oa.src.nslab = nslab, oa.src.base[0] = grads;
+    oa.p = params, oa.g = out, oa.m = exp_avg, oa.v = exp_avg_sq, oa.n4 = n / 4, oa.scale = p->grad_scale, oa.a = k;
+    oa.stats = stats, oa.state = step_state, oa.lay = lay, oa.tiles = tiles, oa.status = status;
+    oa.sync = xsync;  // (the communicator's epoch / sticky words; p->sync_words only says that the caller allows the form)
+    oa.dfr = defer ? deferred_of(p) : DeferredScale{};
+    oa.plan = sp;
+    oa.poll_ticks = timeout_ticks;  // (a peer that died, not a block that is not resident: the communicator's bound)
+    XchgPeers& x = oa.x;
+    for (int r = 0; r < xb.world; ++r) x.inbox[r] = xb.inbox[r], x.gather[r] = xb.gather[r], x.parts[r] = xb.parts[r];
+    x.n_cap = xb.n_cap, x.rank = xb.rank, x.world = xb.world, x.self_alias = (xb.self_alias == 2 && (sp.nblk % xb.world != 0 || xb.rank != 0)) ? 1 : xb.self_alias, x.status = status;
+    const int per_group = defer ? nslab / p->deferred_groups : nslab;
+#define RLX_XCHG(DEFER_, SB_) \
+    hipLaunchKernelGGL((reduce_clip_adamw_one_launch<DEFER_, SB_, true>), dim3(sp.nblk), dim3(kOneThreads), 0, s, oa)
+    if (defer) {
+        if (per_group <= 10) RLX_XCHG(true, 9);
+        else RLX_XCHG(true, 24);
+    } else {
+        if (per_group <= 10) RLX_XCHG(false, 9);
+        else RLX_XCHG(false, 24);
+    }
+#undef RLX_XCHG
+    RLX_LAUNCH_CHECK();
+    *used = true;
     return RLX_OK;
 }
 

@@ -164,7 +164,22 @@ int launch_gather_clip_adamw(float* params, const GatherSrc& src, float* out, fl
                              const int* status, hipStream_t stream);
 // plain gather (validation / plain all-reduce): out = the reduced gradient, no optimizer state touched
 int launch_gather_only(const GatherSrc& src, float* out, int64_t n, const PeerWait* wait, unsigned* seq_inc, hipStream_t stream);
-int rsag_parts(long long shard_n4);  // blocks (= norm partials) of the reduce-scatter launch for a shard of this many float4
+int rsag_parts(long long shard_n4);
+
+// The exchange areas of every rank's communicator buffer, as rlx_xgmi_clip_adamw_step hands them to the one-launch form
+// (adamw_clip.hip: XchgPeers).  All areas hold self-validating 64-bit words (epoch << 32 | payload).
+struct ExchangeBuffers {
+    unsigned long long* inbox[kMaxRanks];   // rank q's inbox: [world rows][n_cap words]
+    unsigned long long* gather[kMaxRanks];  // rank q's gather area: [n_cap words]
+    unsigned long long* parts[kMaxRanks];   // rank q's norm-partial slots: [512][2 words]
+    long long n_cap;
+    int rank, world;
+    int self_alias;  // 0 real peers; 1 self-connected, exact emulation; 2 self-connected, timing emulation (rlx_xgmi_self_timing)
+};
+constexpr int kExchangeSlots = 512;  // (= kMaxOneBlocks of adamw_clip.hip)
+int launch_exchange_clip_adamw_one_launch(float* params, const float* grads, int nslab, float* out, float* exp_avg, float* exp_avg_sq,
+                                          int64_t n, const rlx_adamw_params* p, float* stats, int32_t* step_state, const ExchangeBuffers& xb,
+                                          unsigned long long* xsync, int co_resident, long long timeout_ticks, int* status, hipStream_t stream, bool* used);  // blocks (= norm partials) of the reduce-scatter launch for a shard of this many float4
 
 }  // namespace opt
 }  // namespace rlx

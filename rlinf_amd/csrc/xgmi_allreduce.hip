@@ -38,8 +38,12 @@ struct rlx_xgmi_comm {
     unsigned* seq;                         // device word (plain memory): all-reduces completed
     unsigned* seq_snapshot;                // device word: copy of *seq taken by the reduce-scatter launch for the gather + AdamW launch
     int* status;                           // device word: timeout flag
+    unsigned long long* xsync;             // device words of the one-launch exchange: [0] its epoch, [1] "a poll expired" (sticky).  The
+                                           // communicator's own, NOT the caller's sync words: the tags in the exchange areas count THIS
+                                           // communicator's exchanges, whichever parameter set (learner, start-up validation) ran them
     bool connected, local_peers;           // local_peers: same-process emulation, nothing to unmap
     bool self_alias;                       // rlx_xgmi_connect_self: every peer is this rank's own buffer (timing tool, results invalid)
+    bool self_timing;                      // rlx_xgmi_self_timing: the one-launch exchange's timing emulation instead of the exact one
 };
 
 namespace rlx {
@@ -50,8 +54,19 @@ using namespace opt;
 constexpr size_t kFlagBytes = 4096;                      // flags[2 phases][kMaxRanks] u32, padded
 constexpr int kPartsPerRank = kMaxParts / kMaxRanks;     // norm partials a rank publishes with its shard
 
-// [flags][slot 0][slot 1][shard 0][shard 1][parts 0][parts 1]
-inline size_t buffer_bytes(int64_t n_max) { return kFlagBytes + 4 * (size_t)n_max * sizeof(float) + 2 * kPartsPerRank * sizeof(double); }
+// [flags][slot 0][slot 1][shard 0][shard 1][parts 0][parts 1] | the one-launch exchange's areas, 64-bit tagged words:
+// [xparts: kExchangeSlots x 2][xgather: n_max][xinbox: world x n_max]
+inline size_t chain_bytes(int64_t n_max) {
+    return (kFlagBytes + 4 * (size_t)n_max * sizeof(float) + 2 * kPartsPerRank * sizeof(double) + 255) / 256 * 256;
+}
+// (rows are laid out in groups of 64 float4s = 256 words: a row holds n_max words rounded up to whole groups)
+inline size_t xrow_words(int64_t n_max) { return ((size_t)n_max + 255) / 256 * 256; }
+inline size_t buffer_bytes(int64_t n_max, int world) {
+    return chain_bytes(n_max) + 8 * ((size_t)kExchangeSlots * 2 + xrow_words(n_max) * (1 + (size_t)world));
+}
+inline unsigned long long* xparts_ptr(char* base, int64_t n_max) { return reinterpret_cast<unsigned long long*>(base + chain_bytes(n_max)); }
+inline unsigned long long* xgather_ptr(char* base, int64_t n_max) { return xparts_ptr(base, n_max) + (size_t)kExchangeSlots * 2; }
+inline unsigned long long* xinbox_ptr(char* base, int64_t n_max) { return xgather_ptr(base, n_max) + xrow_words(n_max); }
 inline float* slot_ptr(char* base, int64_t n_max, int slot) {
     return reinterpret_cast<float*>(base + kFlagBytes) + (size_t)slot * (size_t)n_max;
 }
@@ -200,7 +215,7 @@ extern "C" int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_m
     c->rank = rank; c->world = world; c->n_max = n_max;
     c->timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 300000) * 100000ll;  // wall_clock64: 100 MHz
     c->algo = world >= 4 ? 1 : 0;
-    const size_t bytes = buffer_bytes(n_max);
+    const size_t bytes = buffer_bytes(n_max, world);
     void *p = nullptr, *words = nullptr;
     hipError_t e = mem_kind == 2 ? hipMalloc(&p, bytes)
                                  : hipExtMallocWithFlags(&p, bytes, mem_kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
@@ -216,6 +231,7 @@ extern "C" int rlx_xgmi_create(int rank, int world, int64_t n_max, int timeout_m
         c->seq = static_cast<unsigned*>(words);
         c->status = reinterpret_cast<int*>(static_cast<char*>(words) + 128);
         c->seq_snapshot = reinterpret_cast<unsigned*>(static_cast<char*>(words) + 64);
+        c->xsync = reinterpret_cast<unsigned long long*>(static_cast<char*>(words) + 192);
         what = "hipMemset";
         e = hipMemset(words, 0, 256);
     }
@@ -265,6 +281,12 @@ extern "C" int rlx_xgmi_connect_self(rlx_xgmi_comm* c) {
     c->connected = true;
     c->local_peers = true;
     c->self_alias = true;
+    return RLX_OK;
+}
+
+extern "C" int rlx_xgmi_self_timing(rlx_xgmi_comm* c, int on) {
+    RLX_REQUIRE(c != nullptr && c->self_alias, "rlx_xgmi_self_timing: not a self-connected communicator");
+    c->self_timing = on != 0;
     return RLX_OK;
 }
 
@@ -344,6 +366,24 @@ extern "C" int rlx_xgmi_clip_adamw_step(rlx_xgmi_comm* c, float* params, const f
     RLX_REQUIRE(p != nullptr && p->grad_partials >= 1 && grads && grad_flat, "rlx_xgmi_clip_adamw_step: NULL argument");
     if (n == 0) return RLX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // One launch per rank and step (rlx_adamw_params.sync_words; adamw_clip.hip, XchgPeers): the gradient travels as pushed,
+    // self-validating words inside the optimizer launch.  Needs every rank's kernel resident at once, so not with the hand-shake as
+    // its own launch (ranks that share a device); in-process groups of one device count all their ranks against the residency.
+    if (p->sync_words != nullptr && c->world >= 2 && c->wait_mode == 0) {
+        ExchangeBuffers xb{};
+        for (int r = 0; r < c->world; ++r) {
+            xb.inbox[r] = xinbox_ptr(c->base_peer[r], c->n_max);
+            xb.gather[r] = xgather_ptr(c->base_peer[r], c->n_max);
+            xb.parts[r] = xparts_ptr(c->base_peer[r], c->n_max);
+        }
+        xb.n_cap = (long long)xrow_words(c->n_max), xb.rank = c->rank, xb.world = c->world, xb.self_alias = c->self_alias ? (c->self_timing ? 2 : 1) : 0;
+        bool used = false;
+        const int co_resident = (c->local_peers && !c->self_alias) ? c->world : 1;
+        if (int rc = launch_exchange_clip_adamw_one_launch(params, grads, p->grad_partials, grad_flat, exp_avg, exp_avg_sq, n, p, stats,
+                                                           step_state, xb, c->xsync, co_resident, c->timeout_ticks, c->status, st, &used))
+            return rc;
+        if (used) return RLX_OK;
+    }
     if (int rc = stage(c, grads, p->grad_partials, n, st, p)) return rc;  // (applies p->deferred_scale, if any, to this rank's slabs)
     ReduceSrc src{};
     fill_reduce_src(c, src);

@@ -1052,7 +1052,9 @@ class PreparedAdamw:
         self.deferred = deferred  # (a data-parallel caller that collapses the slabs itself -- RCCL path -- applies it there)
         if deferred is not None and deferred_in_caller:
             p.deferred_scale = None  # the caller sums (and scales: sum_slabs(deferred=...)) the slabs in front of its all-reduce
-        if sync is not None and xgmi is None:  # (the exchange's launches have their own hand-shake)
+        # one GPU: slab sum + norm + clip + AdamW as one launch.  Over xGMI: the exchange INSIDE that launch, when the communicator's
+        # start-up validation has passed it (XgmiAllReduce.one_launch); otherwise the exchange's launch chain with its hand-shakes
+        if sync is not None and (xgmi is None or getattr(xgmi, "one_launch", False)):
             p.sync_words = sync.data_ptr()
         self._keep = (params, grads, exp_avg, exp_avg_sq, stats, step_state, workspace, tile_layout, tiles, p, xgmi, grad_flat, deferred, sync)
         if xgmi is not None:

@@ -40,6 +40,10 @@ class XgmiAllReduce:
         self._comm = ctypes.c_void_p()
         self.algo = "rsag" if ctx.world_size >= 4 else "direct"  # the library's default (rlx_xgmi_create): configure() changes it only when asked
         self.wait_mode = "inline"
+        # True once the start-up validation has seen the ONE-LAUNCH exchange (the gradient pushed as self-validating words inside
+        # the optimizer launch: csrc/adamw_clip.hip, XchgPeers) deliver the right mean on every rank; the learners then hand
+        # rlx_xgmi_clip_adamw_step their sync words.  Never with ranks that share a device (the kernels spin device-wide).
+        self.one_launch = False
         handle = (ctypes.c_char * XGMI_HANDLE_BYTES)()
         err = None
         try:  # local part: may fail on some ranks only
@@ -197,7 +201,59 @@ def _attempt(ctx, n_max: int, mem_kind: int, rounds: int, validate_timeout_ms: i
         if comm is not None:
             comm.close()
         return None, why or "a peer failed the validation"
+    # the one-launch form of the exchange (csrc/adamw_clip.hip, XchgPeers) is a protocol of its own -- remote WRITES of
+    # self-validating words instead of remote reads behind flags -- and gets its own verdict: failing it costs the form, not the
+    # transport (the learners then run the validated launch chain)
+    one, one_why = 1, ""
+    try:
+        one, one_why = _validate_one_launch(comm, ctx, n_max, g, min(validate_timeout_ms, product_timeout), product_timeout)
+    except Exception as e:  # noqa: BLE001
+        one, one_why = 0, f"{type(e).__name__}: {e}"
+    comm.one_launch = _agree(one, ctx)
+    comm.one_launch_verdict = "passed" if comm.one_launch else (one_why or "a peer failed it")
+    if not comm.one_launch and ctx.rank == 0 and one_why != "off":
+        print(f"[rlinf_amd] xGMI one-launch exchange not used ({comm.one_launch_verdict}); the launch chain runs", flush=True)
     return comm, ""
+
+
+def _validate_one_launch(comm, ctx, n_max: int, g, validate_timeout_ms: int, product_timeout_ms: int, rounds: int = 3):
+    """(1 | 0, reason) on this rank; every rank issues the same torch.distributed calls.  A step of rlx_xgmi_clip_adamw_step with
+    learning rate 0 and no clipping on scratch buffers: what lands in grad_flat is the exchange's mean gradient, stats[0] its norm."""
+    from ..ops import PreparedAdamw, adamw_sync_words
+    n, dev, W = int(n_max), ctx.device, ctx.world_size
+    usable = (not comm.shared_device) and n % 4 == 0 and W >= 2 and os.environ.get("RLX_XGMI_ONE_LAUNCH", "1") != "0"
+    sync = adamw_sync_words(n, dev) if usable else None
+    ok, why = (1, "") if sync is not None else (0, "off")
+    x = torch.zeros(2, n, device=dev)
+    scratch = [torch.zeros(n, device=dev) for _ in range(4)]  # params, exp_avg, exp_avg_sq, grad_flat
+    stats, state = torch.zeros(2, device=dev), torch.zeros(2, dtype=torch.int32, device=dev)
+    ws = torch.empty(comm._lib.rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    step = None
+    if ok:
+        comm.one_launch = True
+        comm.configure(timeout_ms=validate_timeout_ms)
+        step = PreparedAdamw(scratch[0], x, scratch[1], scratch[2], [(0, n, 0.0)], max_grad_norm=0.0, grad_scale=1.0 / W, stats=stats,
+                             step_state=state, workspace=ws, xgmi=comm, grad_flat=scratch[3], sync=sync)
+    for k in range(rounds):
+        x.copy_(torch.randn(2, n, device=dev, generator=g))
+        want = x.sum(0)
+        dist.all_reduce(want)  # unconditional
+        if not ok:
+            continue
+        with torch.cuda.device(dev):
+            step(_stream_ptr(dev))
+        torch.cuda.synchronize(dev)
+        got = scratch[3] * W
+        if not comm.status_ok():
+            ok, why = 0, f"one-launch round {k}: a peer's words never arrived"
+        elif not torch.allclose(got, want, rtol=1e-5, atol=1e-5):
+            ok, why = 0, f"one-launch round {k}: max |diff| {float((got - want).abs().max()):.3e}"
+        elif not abs(float(stats[0]) - float((want / W).double().norm())) <= 1e-4 * max(1.0, float(stats[0])):
+            ok, why = 0, f"one-launch round {k}: norm {float(stats[0])} vs {float((want / W).double().norm())}"
+    comm.one_launch = False
+    if step is not None:
+        comm.configure(timeout_ms=product_timeout_ms)
+    return ok, why
 
 
 class SelfAliasedXgmi:
@@ -205,7 +261,8 @@ class SelfAliasedXgmi:
     peers are all its own buffer -- the per-step launch chain of a rank (stage, hand-shake, reduce(-scatter), hand-shake, gather +
     clip + AdamW) runs on one device.  Results are not a valid all-reduce: callers pass scratch parameter / moment buffers."""
 
-    def __init__(self, device, world: int, n_max: int, algo: Optional[str] = None, wait_mode: str = "inline", timeout_ms: int = 5000):
+    def __init__(self, device, world: int, n_max: int, algo: Optional[str] = None, wait_mode: str = "inline", timeout_ms: int = 5000,
+                 timing: bool = False):
         self._lib = _lib.load()
         self.world, self.n_max, self.device = int(world), int(n_max), torch.device(device)
         self._comm = ctypes.c_void_p()
@@ -218,7 +275,10 @@ class SelfAliasedXgmi:
             self.wait_mode = wait_mode
             _lib.check(self._lib.rlx_xgmi_configure(self._comm, XgmiAllReduce._ALGOS[self.algo], XgmiAllReduce._WAITS[wait_mode], 0),
                        "rlx_xgmi_configure")
+            if timing:  # the one-launch exchange with a rank's real communication structure instead of exact values (include/rlx.h)
+                _lib.check(self._lib.rlx_xgmi_self_timing(self._comm, 1), "rlx_xgmi_self_timing")
         self.shared_device = False
+        self.one_launch = wait_mode == "inline"  # (the caller decides per PreparedAdamw whether it passes sync words)
 
     @property
     def handle(self):
@@ -261,7 +321,7 @@ class LocalXgmiGroup:
     torch.distributed); the hand-shake runs as its own one-wave launch so that W spinning grids never fill the device."""
 
     def __init__(self, world: int, n_max: int, device, algo: str = "direct", timeout_ms: int = 20000, mem_kind: int = 0,
-                 streams=None):
+                 streams=None, one_launch: bool = False):
         """``streams``: reuse these (one per rank) instead of creating new ones -- every "rank" needs a hardware queue of its own
         (GPU_MAX_HW_QUEUES >= world), and a process that keeps creating streams eventually shares queues between them."""
         self._lib = _lib.load()
@@ -276,8 +336,12 @@ class LocalXgmiGroup:
                 self.comms.append(c)
             arr = (ctypes.c_void_p * world)(*[c.value for c in self.comms])
             _lib.check(self._lib.rlx_xgmi_connect_local(arr, world), "rlx_xgmi_connect_local")
+            # one_launch: the exchange inside the optimizer launch (pushed self-validating words; csrc/adamw_clip.hip, XchgPeers) --
+            # inline waits, and all W kernels of this device must be resident together (the library checks: W <= 3 here)
             for c in self.comms:
-                _lib.check(self._lib.rlx_xgmi_configure(c, XgmiAllReduce._ALGOS[algo], 1, 0), "rlx_xgmi_configure")
+                _lib.check(self._lib.rlx_xgmi_configure(c, XgmiAllReduce._ALGOS[algo], 0 if one_launch else 1, 0), "rlx_xgmi_configure")
+        self.one_launch = bool(one_launch)
+        self._permit = torch.zeros(4, dtype=torch.int64, device=self.device) if one_launch else None  # rlx_adamw_params.sync_words
         self.streams = list(streams) if streams is not None else [torch.cuda.Stream(self.device) for _ in range(world)]
         assert len(self.streams) == world
         self._ws = [torch.empty(self._lib.rlx_adamw_workspace_bytes(self.n_max), dtype=torch.uint8, device=self.device)
@@ -316,6 +380,8 @@ class LocalXgmiGroup:
             p.grad_partials, p.grad_scale = grads[r].numel() // n, 1.0 / self.world
             for k, (b, e, lr) in enumerate(groups):
                 p.groups[k] = AdamwGroup(int(b), int(e), float(lr))
+            if self._permit is not None:
+                p.sync_words = self._permit.data_ptr()
             keep.append(p)
             with torch.cuda.stream(self.streams[r]):
                 _lib.check(self._lib.rlx_xgmi_clip_adamw_step(self.comms[r], params[r].data_ptr(), grads[r].data_ptr(),

@@ -466,3 +466,139 @@ def test_split_placement_whole_loop_matches_the_collocated_run(tmp_path, syncer,
         for k in keys:
             assert got[k] == pytest.approx(want[k], rel=1e-6, abs=1e-9), (it, k)
         assert not any(k.startswith("train/") for k in rollout["metrics"][it])  # a rollout-only rank trains nothing
+
+
+# ---- the gradient exchange INSIDE the one-launch optimizer step (pushed self-validating words; csrc/adamw_clip.hip, XchgPeers) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_xgmi_one_launch_exchange_in_process_group(world):
+    """W "ranks" of one process, one stream each, the REAL protocol: non-owner blocks push their float4s into the owner's inbox row,
+    the owner adds the W rows in rank order and pushes the reduced words into every other rank's gather area, the norm partials go
+    to every rank's slots -- one launch per rank and step (W x 144 blocks resident together: W <= 3 on one device).  Against the
+    launch chain (direct form: the same rank-order sums) on the same inputs: without clipping every buffer is bit-identical; with
+    clipping the norm's partials are formed over different blocks (last bit of the coefficient).  Replicas bit-identical always."""
+    code = f"""
+import sys, torch
+sys.path.insert(0, {ROOT!r})
+from rlinf_amd.scheduler.xgmi import LocalXgmiGroup
+W = {world}
+dev = torch.device("cuda:0")
+n = 287504
+groups = [(0, n // 2, 3e-4), (n // 2, n, 1e-3)]
+streams = [torch.cuda.Stream(dev) for _ in range(W)]
+runs = []
+for one in (False, True):
+    g = torch.Generator(device=dev).manual_seed(11)
+    grp = LocalXgmiGroup(W, n, dev, algo="direct", timeout_ms=15000, streams=streams, one_launch=one)
+    p0 = torch.randn(n, device=dev, generator=g) * 0.1
+    params = [p0.clone() for _ in range(W)]
+    m = [torch.zeros(n, device=dev) for _ in range(W)]
+    v = [torch.zeros(n, device=dev) for _ in range(W)]
+    flat = [torch.empty(n, device=dev) for _ in range(W)]
+    stats = [torch.zeros(2, device=dev) for _ in range(W)]
+    state = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(W)]
+    trace = []
+    for it in range(8):
+        big = it in (3, 6)
+        slabs = [torch.randn(1 + (r + it) % 3, n, device=dev, generator=g) * (5.0 if big else 1e-4) for r in range(W)]
+        if it == 5:
+            slabs[W - 1][0, 123] = float("nan")   # one rank's non-finite gradient: every rank skips the step
+        grp.clip_adamw_step(params, slabs, flat, m, v, groups, stats, state)
+        torch.cuda.synchronize()
+        assert grp.status_ok(), f"one={{one}} it={{it}}: a wait timed out"
+        for r in range(1, W):
+            assert torch.equal(params[r], params[0]) and torch.equal(m[r], m[0]) and torch.equal(v[r], v[0]), (one, it, r)
+            assert torch.equal(flat[r].view(torch.int32), flat[0].view(torch.int32)) and torch.equal(stats[r].view(torch.int32), stats[0].view(torch.int32))
+        trace.append((params[0].clone(), m[0].clone(), v[0].clone(), flat[0].clone(), stats[0].clone(), state[0].clone(), big))
+    runs.append(trace)
+    grp.close()
+for it, (a, b) in enumerate(zip(*runs)):
+    assert torch.equal(a[5], b[5]), it
+    if it == 5:
+        assert float(a[4][1]) == float(b[4][1]) == 0.0
+        continue
+    if it < 3:  # no clipping yet: bit for bit
+        for k in range(4):
+            assert torch.equal(a[k], b[k]), (it, k)
+    else:
+        for k in range(4):
+            torch.testing.assert_close(b[k], a[k], rtol=2e-6, atol=1e-9)
+    assert float(b[4][0]) == __import__("pytest").approx(float(a[4][0]), rel=1e-6)
+assert int(runs[1][-1][5][0]) + int(runs[1][-1][5][1]) == 7
+print("OK")
+"""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("image", ["none", "bf16"])
+def test_xgmi_one_launch_exchange_self_aliased_equals_the_single_gpu_step(world, image):
+    """rlx_xgmi_connect_self: rank 0 of a W-rank job whose peers are its own buffer -- owned blocks play their W - 1 contributors,
+    the others the owner that answers them -- so the launch does a rank's pushes and polls on ONE device.  With W a power of two
+    the mean of W copies of a gradient is that gradient exactly: parameters, moments, clipped gradient, norm, step counter and the
+    weight image must equal the single-GPU one-launch step's, bit for bit, eagerly and over a replayed hipGraph."""
+    from rlinf_amd import ops
+    from rlinf_amd.models.embodiment.mlp_policy import MLPPolicy
+    from rlinf_amd.scheduler.xgmi import SelfAliasedXgmi
+    if ops.adamw_sync_words(8, "cuda") is None:
+        pytest.skip("RLX_ADAMW_ONE_LAUNCH=0")
+    runs = []
+    for xchg in (False, True):
+        torch.manual_seed(4)
+        pol = MLPPolicy(42, 8, 1, True, False, compute_dtype=torch.bfloat16).to("cuda")
+        n, lay = pol.n_params, pol.layout
+        tiles = pol.tiles() if image != "none" else None
+        m, v, flat = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        state, stats = torch.zeros(2, dtype=torch.int32, device="cuda"), torch.zeros(2, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(5)
+        grads = torch.empty(10, n, device="cuda")
+        ws = torch.empty(ops._lib.load().rlx_adamw_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        comm = SelfAliasedXgmi("cuda", world, n) if xchg else None
+        step = ops.PreparedAdamw(pol.flat.data, grads, m, v, pol.group_ranges(3e-4, 1e-3), betas=(0.9, 0.999), eps=1e-8,
+                                 weight_decay=0.01, max_grad_norm=0.5, grad_scale=1.0 / world if xchg else 1.0, stats=stats,
+                                 step_state=state, workspace=ws, tile_layout=lay if tiles is not None else None, tiles=tiles,
+                                 xgmi=comm, grad_flat=flat if xchg else None, sync=ops.adamw_sync_words(n, "cuda"))
+        trace, stream = [], torch.cuda.current_stream().cuda_stream
+        for it in range(5):
+            grads.normal_(generator=g).mul_(0.02 if it % 2 else 0.0002)
+            if it == 3:
+                grads[2, 99] = float("inf")
+            step(stream)
+            trace.append((stats.clone(), state.clone()))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            master = torch.randn(10, n, device="cuda", generator=g) * 0.01
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(6):
+                    grads.copy_(master)  # (the single-GPU step leaves its clipped gradient in slab 0: every step gets fresh slabs)
+                    step(side.cuda_stream)
+            for _ in range(10):
+                graph.replay()
+        side.synchronize()
+        torch.cuda.synchronize()
+        if comm is not None:
+            assert comm.status_ok()
+        runs.append(dict(p=pol.flat.data.clone(), m=m, v=v, trace=trace, stats=stats.clone(), state=state.clone(),
+                         g=(flat if xchg else grads[0]).clone(), tiles=None if tiles is None else tiles.view(torch.int16).clone()))
+        if comm is not None:
+            comm.close()
+    a, b = runs
+    assert torch.equal(a["state"], b["state"])
+    if world <= 4:  # g + g and ((g + g) + g) + g round to 2 g and 4 g exactly; from the fifth copy on a rank-order sum may be an ulp off
+        for k in ("p", "m", "v"):
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a["stats"].view(torch.int32), b["stats"].view(torch.int32))
+        assert torch.equal(a["g"].view(torch.int32), b["g"].view(torch.int32))
+        if image != "none":
+            assert torch.equal(a["tiles"], b["tiles"])
+    else:
+        for k, (rt, at) in dict(g=(2e-6, 1e-10), m=(2e-5, 1e-9), v=(2e-5, 1e-12), p=(2e-3, 2e-5)).items():  # (AdamW's m / sqrt(v) amplifies)
+            torch.testing.assert_close(b[k], a[k], rtol=rt, atol=at, msg=lambda t, k=k: f"{k}: {t}")
+    for it, ((s0, t0), (s1, t1)) in enumerate(zip(a["trace"], b["trace"])):
+        assert torch.equal(t0, t1) and float(s0[1]) == float(s1[1]) == (0.0 if it == 3 else 1.0)
+        assert it == 3 or float(s0[0]) == pytest.approx(float(s1[0]), rel=0 if world <= 4 else 1e-6)
+    assert int(b["state"][0]) + int(b["state"][1]) == 4 + 6 * 10

@@ -488,15 +488,17 @@ def test_ext_hook_callees_behind_a_reference_shaped_registry():
     from oracle import token_oracle as TO
     from oracle.make_golden import token_batch
 
-    captured = {"adv": {}, "loss": {}}
+    captured = {"adv": {}, "loss": {}, "model": {}}
+    fake_models = types.ModuleType("rlinf.models")
+    fake_models.register_model = lambda name, builder, category="embodied", force=False: captured["model"].__setitem__(name, (builder, category, force))
     fake = types.ModuleType("rlinf.algorithms.registry")
     fake.register_advantage = lambda name: (lambda fn: captured["adv"].__setitem__(name, fn) or fn)
     fake.register_policy_loss = lambda name: (lambda fn: captured["loss"].__setitem__(name, fn) or fn)
-    saved = {k: sys.modules.get(k) for k in ("rlinf", "rlinf.algorithms", "rlinf.algorithms.registry")}
+    saved = {k: sys.modules.get(k) for k in ("rlinf", "rlinf.algorithms", "rlinf.algorithms.registry", "rlinf.models")}
     pkg, sub = types.ModuleType("rlinf"), types.ModuleType("rlinf.algorithms")
     pkg.__path__, sub.__path__ = [], []
-    pkg.algorithms, sub.registry = sub, fake
-    sys.modules.update({"rlinf": pkg, "rlinf.algorithms": sub, "rlinf.algorithms.registry": fake})
+    pkg.algorithms, sub.registry, pkg.models = sub, fake, fake_models
+    sys.modules.update({"rlinf": pkg, "rlinf.algorithms": sub, "rlinf.algorithms.registry": fake, "rlinf.models": fake_models})
     try:
         from rlinf_amd import ext
         ext.register()
@@ -508,6 +510,8 @@ def test_ext_hook_callees_behind_a_reference_shaped_registry():
                 sys.modules[k] = v
     assert set(captured["adv"]) == {"gae", "grpo", "reinpp"}
     assert set(captured["loss"]) == {"actor_critic", "actor", "decoupled_actor_critic"}
+    from rlinf_amd.models.embodiment.mlp_policy_module import build_reference_named_mlp_policy
+    assert captured["model"] == {"mlp_policy": (build_reference_named_mlp_policy, "embodied", True)}  # the model leg (rlinf/models/__init__.py:31-53)
 
     # reasoning "actor": the learner's kwargs, the REFERENCE-named aggregation function object
     b = token_batch(91, 8, 21, 5)

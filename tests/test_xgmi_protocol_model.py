@@ -98,3 +98,174 @@ def test_one_slot_is_caught_by_the_model():
                 assert "deadlock" not in str(e)
                 tripped += 1
     assert tripped > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The exchange INSIDE the one-launch optimizer step (csrc/adamw_clip.hip: XchgPeers, reduce_clip_adamw_one_launch<.., XCHG = true>):
+# no flags at all -- every value is PUSHED into the consumer's buffer as a self-validating word (epoch << 32 | payload, one
+# single-copy-atomic store) and the consumer polls the payload itself.  Per launch, block b of rank r:
+#
+#     e1 = this rank's epoch + 1
+#     owner(b) = b * W // nblk
+#     non-owner:  push its K words into the owner's inbox row [r]                     (K separate stores, any order in time)
+#     owner:      poll rows p != r of its own inbox (word by word), reduced = sum over ranks IN RANK ORDER,
+#                 push `reduced` into every other rank's gather words, publish the block's partial to every rank's slot b
+#     non-owner:  poll its own gather words
+#     everybody:  poll all nblk partial slots of its own buffer; block 0 then stores the rank's epoch = e1
+#
+# and a rank's launch L + 1 starts when its launch L has ended (stream order) -- the RANKS are not synchronised with each other: a
+# fast rank is already pushing launch L + 1 while a slow one still polls launch L.  Claims: under any interleaving every block of
+# every rank ends launch L with exactly launch L's rank-ordered sum and total, nothing stale, nothing mixed, nobody waits forever.
+# Negative controls: a word whose two halves are stored separately under ONE tag (torn word), and an epoch that belongs to the
+# CALLER instead of the communicator (two parameter sets alternating on one communicator reuse tags).
+K_WORDS = 2
+
+
+class ExchangeDeadlock(AssertionError):
+    pass
+
+
+def _poll(cell, e1, who):
+    spins = 0
+    while True:
+        tag, val = cell["w"]
+        if tag == e1:
+            return val
+        spins += 1
+        if spins > 600:
+            raise ExchangeDeadlock(f"{who} polls for tag {e1} forever (word holds tag {tag})")
+        yield None
+
+
+def _store(cell, e1, val, variant):
+    if variant == "torn" and isinstance(val, tuple):  # negative control: two halves under one tag, stored one after the other
+        old = cell["w"][1] if isinstance(cell["w"][1], tuple) else (0, 0)
+        cell["w"] = (e1, (val[0], old[1]))
+        yield None
+        cell["w"] = (e1, val)
+    else:
+        cell["w"] = (e1, val)
+    yield None
+
+
+def _xblock(r, b, W, nblk, mem, truth, expect, e1, variant):
+    me = mem[r]
+    owner = b * W // nblk
+    g = truth[r][b]
+    if owner != r:
+        for k in range(K_WORDS):
+            yield from _store(mem[owner]["inbox"][r][b][k], e1, g[k], variant)
+        reduced = []
+        for k in range(K_WORDS):
+            v = yield from _poll(me["gather"][b][k], e1, f"rank {r} block {b} (gather word {k})")
+            reduced.append(v)
+    else:
+        reduced = []
+        for k in range(K_WORDS):
+            acc = None
+            for p in range(W):  # rank order, own contribution at position r
+                if p == r:
+                    t = g[k]
+                else:
+                    t = yield from _poll(me["inbox"][p][b][k], e1, f"rank {r} block {b} (inbox row {p} word {k})")
+                acc = t if acc is None else (acc[0] + t[0], acc[1] + t[1])
+            reduced.append(acc)
+        for p in range(W):
+            if p != r:
+                for k in range(K_WORDS):
+                    yield from _store(mem[p]["gather"][b][k], e1, reduced[k], variant)
+        for p in range(W):
+            yield from _store(mem[p]["parts"][b], e1, sum(x[0] + x[1] for x in reduced), "product")
+    assert reduced == expect["reduced"][b], f"rank {r} block {b}: {reduced} != {expect['reduced'][b]}"
+    total = 0
+    for j in range(nblk):
+        v = yield from _poll(me["parts"][j], e1, f"rank {r} block {b} (partial {j})")
+        total += v
+    assert total == expect["total"], f"rank {r} block {b}: total {total} != {expect['total']}"
+    if b == 0:
+        me["epoch_done"] = e1
+    yield None
+
+
+def _run_exchange(W, nblk, n_launches, seed, variant="product", bias=None):
+    rng = random.Random(seed)
+    cell = lambda: {"w": (0, (0, 0))}  # noqa: E731
+    mem = [{"epoch_done": 0, "inbox": [[[cell() for _ in range(K_WORDS)] for _ in range(nblk)] for _ in range(W)],
+            "gather": [[cell() for _ in range(K_WORDS)] for _ in range(nblk)], "parts": [{"w": (0, 0)} for _ in range(nblk)]}
+           for _ in range(W)]
+    truths, expects = [], []
+    for L in range(1, n_launches + 1):
+        truth = [[[(rng.getrandbits(12) + (L << 16), rng.getrandbits(12) + (L << 16)) for _ in range(K_WORDS)] for _ in range(nblk)]
+                 for _ in range(W)]
+        red = [[(sum(truth[p][b][k][0] for p in range(W)), sum(truth[p][b][k][1] for p in range(W))) for k in range(K_WORDS)]
+               for b in range(nblk)]
+        truths.append(truth)
+        expects.append({"reduced": red, "total": sum(x[0] + x[1] for b in range(nblk) for x in red[b])})
+    launch_of = [0] * W          # launch a rank is in (1-based), 0 = not started
+    progs = {}                   # (rank, block) -> generator
+
+    def start(r):
+        launch_of[r] += 1
+        L = launch_of[r]
+        # the communicator's epoch counts ITS exchanges; negative control "epoch_per_caller": two callers alternate on one
+        # communicator, each counting its own launches -> launches 1 and 2 both use tag 1
+        e1 = (L + 1) // 2 if variant == "epoch_per_caller" else L
+        for b in range(nblk):
+            progs[(r, b)] = _xblock(r, b, W, nblk, mem, truths[L - 1], expects[L - 1], e1, variant)
+
+    for r in range(W):
+        start(r)
+    steps = 0
+    while progs:
+        keys = sorted(progs)
+        if bias == "rank0_fast" and rng.random() < 0.8 and any(k[0] == 0 for k in keys):
+            key = rng.choice([k for k in keys if k[0] == 0])
+        elif bias == "last_rank_slow" and rng.random() < 0.9 and any(k[0] != W - 1 for k in keys):
+            key = rng.choice([k for k in keys if k[0] != W - 1])
+        else:
+            key = rng.choice(keys)
+        try:
+            next(progs[key])
+        except StopIteration:
+            del progs[key]
+            r = key[0]
+            if not any(k[0] == r for k in progs) and launch_of[r] < n_launches:
+                start(r)  # stream order: the rank's next launch starts when this one has ended
+        steps += 1
+        assert steps < 2_000_000
+    assert all(launch_of[r] == n_launches for r in range(W))
+    return True
+
+
+@pytest.mark.parametrize("bias", [None, "rank0_fast", "last_rank_slow"])
+@pytest.mark.parametrize("W,nblk", [(2, 2), (2, 5), (3, 6), (4, 4)])
+def test_pushed_word_exchange_is_correct_under_any_interleaving(W, nblk, bias):
+    for seed in range(25):
+        assert _run_exchange(W, nblk, 4, seed, bias=bias)
+
+
+def test_negative_control_torn_word():
+    """A 16-byte payload under ONE tag whose halves land one after the other: a poller accepts the tag with one half still the
+    previous launch's.  (The kernel tags every 64-bit word: what is single-copy atomic is exactly what carries a tag.)"""
+    caught = 0
+    for seed in range(40):
+        try:
+            _run_exchange(2, 3, 4, seed, variant="torn", bias="rank0_fast")
+        except ExchangeDeadlock:
+            raise
+        except AssertionError:
+            caught += 1
+    assert caught >= 20, caught
+
+
+def test_negative_control_epoch_owned_by_the_caller():
+    """Two parameter sets (the learner's and the start-up validation's) taking turns on one communicator, each with its own epoch
+    counter: the second set's launch polls for a tag the first set's launch left in every word -- stale values pass.  (The
+    communicator owns the epoch: rlx_xgmi_comm::xsync.)"""
+    caught = 0
+    for seed in range(40):
+        try:
+            _run_exchange(2, 3, 4, seed, variant="epoch_per_caller")
+        except (AssertionError, ExchangeDeadlock):
+            caught += 1
+    assert caught >= 30, caught

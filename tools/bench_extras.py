@@ -131,7 +131,7 @@ def in_loop_kernels(precision: str, *, rows: int, envs: int, slabs: int, n_param
 
 
 # ---- scaling model: measured per-rank compute share + measured exchange launch cost --------------------------------------------
-def per_rank_share_ms(device, precision: str, share: int, steps: int = 12) -> float:
+def per_rank_share_ms(device, precision: str, share: int, steps: int = 8) -> float:
     """ONE GPU running what a rank of a `share`-GPU strong-scaling job runs (1024 / share envs, 8192 / share minibatch rows, no
     exchange): ms per iteration of the run-ahead loop."""
     import bench
@@ -142,16 +142,21 @@ def per_rank_share_ms(device, precision: str, share: int, steps: int = 12) -> fl
         for _ in range(4):
             runner.run_step()
         torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        pending = None
-        for _ in range(steps):
-            step = runner.run_step(defer=True)
-            if pending is not None:
-                pending.result()
-            pending = step
-        pending.result()
-        torch.cuda.synchronize(device)
-        return (time.perf_counter() - t0) / steps * 1e3
+        # the FASTEST of three windows: a window that catches a clock ramp or a host hiccup (one 12-step window read 10.3 ms for the
+        # 1/2 share on a box where the others read 6.6) must not become the model's per-rank share
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            pending = None
+            for _ in range(steps):
+                step = runner.run_step(defer=True)
+                if pending is not None:
+                    pending.result()
+                pending = step
+            pending.result()
+            torch.cuda.synchronize(device)
+            best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+        return best
     finally:
         runner.close()
         del runner
@@ -178,8 +183,9 @@ def scaling_model(device, precision: str, n_params: int, slabs_by_share: dict | 
     return {"per_rank_share_ms_no_exchange": {str(k): v for k, v in shares.items()},
             "exchange_launches_on_one_device": ex, "optimizer_steps_per_iteration": opt_steps,
             "predicted_strong": strong, "predicted_weak": weak,
-            "reading": "predicted = measured per-rank share + 128 x measured exchange-launch extra; a LOWER bound of the real iteration "
-                       "time (no link latency, no peer skew, no RCCL).  Strong scaling at N = 8 is expected near "
+            "reading": "predicted = measured per-rank share + 128 x the measured extra of the exchange (inside the optimizer launch: "
+                       "pushed self-validating words) per optimizer step; a LOWER bound of the real iteration time (no link latency, no "
+                       "peer skew, no RCCL).  Strong scaling at N = 8 is expected near "
                        f"{strong['8']['speedup_vs_1']} x (north_star asks >= 6 x: that assumes a throughput-bound step; this loop is "
-                       "bound by the latency of four dependent launches per optimizer step), weak scaling near "
-                       f"{weak['8']['throughput_x_vs_1']} x at N = 8."}
+                       "bound by the latency of three dependent launches per optimizer step -- an eighth of the rows costs three quarters "
+                       f"of the time), weak scaling near {weak['8']['throughput_x_vs_1']} x at N = 8."}
