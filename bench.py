@@ -40,6 +40,7 @@ import time
 
 import torch
 
+T_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -585,7 +586,7 @@ def main():
             ob = best(other)
             line[f"{other}_scaling"] = None if ob is None else {k: ob[2][k] for k in (
                 "env_steps_per_sec", "ms_per_step", "ms_per_step_windows", "ppo_updates_per_sec", "total_envs", "global_batch", "grad_allreduce")}
-            line["transports"] = {f"{rg}/{tr}": {k: v[k] for k in ("env_steps_per_sec", "ms_per_step", "grad_allreduce", "update_graph_replayed", "devices_seen")}
+            line["transports"] = {f"{rg}/{tr}": {k: v[k] for k in ("env_steps_per_sec", "ms_per_step", "grad_allreduce", "update_graph_replayed", "devices_seen", "done_at_s") if k in v}
                                   for (rg, tr), v in runs.items()}
             if errors:
                 line["transport_errors"] = dict(errors)
@@ -624,6 +625,7 @@ def main():
             dog.start()
             try:
                 runs[(rg, tr)] = measure(ctx, scaling=rg, transport=tr, **common)
+                runs[(rg, tr)]["done_at_s"] = round(time.perf_counter() - T_START, 1)  # since this process started
             except Exception as e:  # noqa: BLE001 -- reported in the line; collectively consistent only if it failed everywhere
                 errors[f"{rg}/{tr}"] = f"{type(e).__name__}: {e}"[:300]
             # a transport failing on ONE rank only would leave the ranks in different collectives: agree on what exists

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define RLX_VERSION 111 /* 0.1.1: bumped whenever an argument struct or a signature changes (round 5: rlx_categorical_sample's
+#define RLX_VERSION 112 /* 0.1.2: bumped whenever an argument struct or a signature changes (round 6: rlx_xgmi_self_timing, the
+                           * exchange inside rlx_xgmi_clip_adamw_step under sync_words; round 5: rlx_categorical_sample's
                            * softmax_lanes, rlx_adamw_params.sync_words; round 4's struct growth had left it at 100) */
 
 typedef void* rlx_stream_t; /* hipStream_t */

@@ -282,7 +282,7 @@ def load() -> ctypes.CDLL:
             raise RlxError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.rlx_version() < 111:
+    if lib.rlx_version() < 112:
         raise RlxError("librlx_hip.so is older than this Python package; rebuild it")
     mirrors = (GaeParams, PpoLossParams, GatherField, AdamwGroup, AdamwParams, MlpLayout, ValueJob, RolloutStep, PpoStepArgs,
                DecoupledLossParams, TokenRows, TokenLossParams, CopySegment)  # the order rlx_abi_struct_sizes documents

@@ -36,7 +36,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.rlx_version() >= 111
+    assert lib.rlx_version() >= 112
     assert isinstance(lib.rlx_last_error(), bytes)
 
 

@@ -80,7 +80,7 @@ def test_xgmi_allreduce_two_ranks_on_one_gpu(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641",
                    RLX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", RLX_XGMI_TIMEOUT_MS="30000", RLX_XGMI_PROBE_LIGHT="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "xgmi_probe.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "xgmi_probe.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
