@@ -569,6 +569,7 @@ def test_xgmi_one_launch_exchange_self_aliased_equals_the_single_gpu_step(world,
             step(stream)
             trace.append((stats.clone(), state.clone()))
         side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())  # (the eager steps' trace clones still read `grads` on the default stream)
         with torch.cuda.stream(side):
             master = torch.randn(10, n, device="cuda", generator=g) * 0.01
             graph = torch.cuda.CUDAGraph()

@@ -22,8 +22,10 @@ def hooked():
     if not RL.available():
         pytest.skip("neither /root/reference nor the staged oracle/_ref copy is present")
     ref = RL.load()
+    mr = RL.load_models_registry()  # (register() also re-registers the model builder: the real rlinf/models/__init__.py must be there)
     reg = ref.registry
     saved = dict(reg.ADV_REGISTRY), dict(reg.LOSS_REGISTRY)
+    saved_models = dict(mr.models._MODEL_REGISTRY)
     builtin = SimpleRegistry(reg, *saved)
     from rlinf_amd import ext
     ext.register()  # `from rlinf.algorithms import registry` inside resolves to the real module loaded above
@@ -31,6 +33,7 @@ def hooked():
     yield ref, builtin
     reg.ADV_REGISTRY.clear(), reg.ADV_REGISTRY.update(saved[0])
     reg.LOSS_REGISTRY.clear(), reg.LOSS_REGISTRY.update(saved[1])
+    mr.models._MODEL_REGISTRY.clear(), mr.models._MODEL_REGISTRY.update(saved_models)
 
 
 class SimpleRegistry:

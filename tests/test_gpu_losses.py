@@ -252,6 +252,7 @@ def test_one_launch_optimizer_step(slabs, deferred, image):
             step(stream)
             trace.append((stats.clone(), state.clone(), grads[0].clone()))
         side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())  # (the eager steps' trace clones still read `grads` on the default stream)
         with torch.cuda.stream(side):
             grads.normal_(generator=g).mul_(0.01)
             graph = torch.cuda.CUDAGraph()

@@ -7,14 +7,17 @@ export TMPDIR=/tmp
 out=gpurun_out/pmc_l2
 mkdir -p $out
 i=0
-for set in "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum TCC_WRITE_sum GRBM_GUI_ACTIVE" \
-           "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-           "TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum TCC_TAG_STALL_sum TCC_BUSY_sum TCC_EA_RDREQ_32B_sum" \
-           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD" \
-           "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_NC_READ_REQ_sum TCP_TCC_UC_READ_REQ_sum TCP_TCC_CC_READ_REQ_sum TCP_TCC_RW_READ_REQ_sum"; do
+# (at most four counters of one hardware block per pass: a bigger request is refused -- "exceeds the capabilities of the hardware" --
+# and the refused run then sits until the timeout)
+for set in "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" \
+           "TCC_READ_sum TCC_WRITE_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum" \
+           "TCC_BUSY_sum TCC_TAG_STALL_sum" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
   rm -rf $out/p$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o pmc -f csv -- python tools/run_step_once.py ${1:-8192} ${2:-bf16} > $out/p$i.log 2>&1
+  timeout 100 rocprofv3 --kernel-trace --pmc $set -d $out/p$i -o pmc -f csv -- python tools/run_step_once.py ${1:-8192} ${2:-bf16} > $out/p$i.log 2>&1
   echo "pass $i rc=$? ($set)"
 done
 python - <<'PY'
