@@ -218,8 +218,9 @@ def _split_cfg(syncer: str, placement: dict, *, T=12, B=32, GB=96, init_sync=Fal
     if syncer == "bucket":
         cfg.weight_syncer = {"type": "bucket", "bucket": {"bucket_size": 128 * 1024, "bucket_dtype": None, "is_agent": False,
                                                            "load_instant": True}}
-    elif syncer == "patch":
-        cfg.weight_syncer = {"type": "patch", "patch": {"snapshot_device": "cuda", "delta_encoding": True, "compression": "none",
+    elif syncer in ("patch", "patch_cpu"):  # patch_cpu: the reference's shipped default (weight_syncer/patch_syncer.yaml: host snapshot)
+        cfg.weight_syncer = {"type": "patch", "patch": {"snapshot_device": "cpu" if syncer == "patch_cpu" else "cuda",
+                                                         "delta_encoding": True, "compression": "none",
                                                          "init_sync": {"enabled": init_sync, "prefixes": None,
                                                                        "bucket_size": 64 * 1024}}}
     return cfg

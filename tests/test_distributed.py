@@ -436,7 +436,7 @@ def test_component_placement_parsing():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("syncer,init_sync", [("bucket", "0"), ("patch", "0"), ("patch", "1")])
+@pytest.mark.parametrize("syncer,init_sync", [("bucket", "0"), ("patch", "0"), ("patch", "1"), ("patch_cpu", "1")])
 def test_split_placement_whole_loop_matches_the_collocated_run(tmp_path, syncer, init_sync):
     """Learner on rank 0, env + rollout on rank 1 (two processes on the one GPU, gloo standing in for RCCL) against the SAME job in
     one process: after every sync the rollout worker's weights are the learner's byte for byte (so every iteration's rollout,
@@ -444,9 +444,9 @@ def test_split_placement_whole_loop_matches_the_collocated_run(tmp_path, syncer,
     its init hand-shake once on each side."""
     (tmp_path / "split").mkdir(), (tmp_path / "one").mkdir()
     split = [torch.load(o, weights_only=False) for o in _launch("split_gpu", tmp_path / "split", syncer, init_sync, "gloo", "split",
-                                                               port=29693 + 2 * (syncer == "patch") + 4 * (init_sync == "1"))]
+                                                               port=29693 + 2 * (syncer == "patch") + 4 * (init_sync == "1") + 16 * (syncer == "patch_cpu"))]
     one = [torch.load(o, weights_only=False) for o in _launch("split_gpu", tmp_path / "one", syncer, init_sync, "gloo", "collocated",
-                                                             world=1, port=29701 + 2 * (syncer == "patch") + 4 * (init_sync == "1"))][0]
+                                                             world=1, port=29701 + 2 * (syncer == "patch") + 4 * (init_sync == "1") + 16 * (syncer == "patch_cpu"))][0]
     learner, rollout = split
     assert learner["has_actor"] and not learner["has_rollout"] and rollout["has_rollout"] and not rollout["has_actor"]
     assert learner["actor_world"] == 1 and rollout["env_world"] == 1 and rollout["num_envs"] == 32
