@@ -98,14 +98,26 @@ struct Moments {
     }
 };
 
+// In FRONT of the partials (the workspace starts with them): the finished moments of the two arrays a normalisation can follow
+// (`which` = 0 advantages, 1 returns) as published words valid << 32 | payload -- (mean, denominator, skip) -- in kNormReplicas
+// copies, a 128-byte line each (see standardize_kernel).  The launch that writes the partials clears them.
+constexpr int kNormReplicas = 16;
+constexpr int kNormWords = 2 * kNormReplicas * 16;
+__device__ __forceinline__ unsigned long long* norm_words(double* partials, int which, int replica) {
+    return reinterpret_cast<unsigned long long*>(partials) - kNormWords + (which * kNormReplicas + replica) * 16;
+}
+
 __device__ __forceinline__ void flush_moments(const Moments& mo, double* partials, double* scratch, long long slot = -1) {
     double v[5] = {mo.n, mo.sa, mo.qa, mo.sr, mo.qr};
     block_sum<5>(v, scratch);
+    const size_t at = slot >= 0 ? (size_t)slot : (size_t)blockIdx.x;  // the env group's slot: the final sum keeps its order
     if (threadIdx.x == 0) {
-        const size_t at = slot >= 0 ? (size_t)slot : (size_t)blockIdx.x;  // the env group's slot: the final sum keeps its order
 #pragma unroll
         for (int k = 0; k < 5; ++k) partials[at * 5 + k] = v[k];
     }
+    if (at == 0)  // ONE block per launch takes back the words of the previous normalisation: the standardize launches behind this
+        //           one (stream order) read "published" as "published from THESE partials", whatever the workspace held before
+        for (int t = threadIdx.x; t < 2 * kNormReplicas * 3; t += blockDim.x) norm_words(partials, 0, t / 3)[t % 3] = 0ull;
 }
 
 // One backward step of the reference loop (advantages.py:66-77), op for op.
@@ -583,9 +595,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* x, const uint
 template <bool NT, int kStdU>
 __global__ __launch_bounds__(256) void standardize_kernel(float* x, size_t n, const double* partials, int nparts,
                                                           int which, float eps) {
-    __shared__ double s_red[3 * 4];
-    __shared__ float s_mean, s_den;
-    __shared__ int s_skip;
+    __shared__ double s_red[5 * 4];
+    __shared__ unsigned s_pub[6];
     typedef float v4f __attribute__((ext_vector_type(4)));
     const size_t n4 = (reinterpret_cast<uintptr_t>(x) % 16 == 0) ? n / 4 : 0;
     v4f* x4 = reinterpret_cast<v4f*>(x);
@@ -602,25 +613,79 @@ __global__ __launch_bounds__(256) void standardize_kernel(float* x, size_t n, co
             }
         }
     };
-    load_sweep(bb);
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int p = threadIdx.x; p < nparts; p += blockDim.x) {
-        acc[0] += partials[(size_t)p * 5 + 0];
-        acc[1] += partials[(size_t)p * 5 + 1 + 2 * which];
-        acc[2] += partials[(size_t)p * 5 + 2 + 2 * which];
-    }
-    block_sum<3>(acc, s_red);
-    if (threadIdx.x == 0) {
-        const double cnt = acc[0];
-        s_skip = cnt <= 0.0;  // "if len(valid_array) > 0" (utils.py:399)
-        const double mean = acc[1] / cnt;
-        const double var = (acc[2] - acc[1] * acc[1] / cnt) / (cnt - 1.0);  // unbiased; NaN for cnt == 1, as torch
-        s_mean = (float)mean;
-        s_den = fadd((float)sqrt(var > 0.0 || var != var ? var : 0.0), eps);
+    // The moments are FINISHED ONCE: block 0 reduces the partials (fixed order), forms mean and denominator of BOTH arrays (the
+    // partial records hold them side by side, so the returns' launch finds its words ready) and publishes them as 64-bit words
+    // valid << 32 | f32 bits (relaxed agent-scope stores: single-copy atomic, no fence); every other block requests its sweep
+    // first and has three lanes poll one of kNormReplicas copies while that data is in flight.  Round 6's first form let all 1024
+    // blocks reduce the 1024 partials themselves: 24 MB of reads on the same few hundred L2 lines at the same moment -- 2.9 of the
+    // launch's 13.8 us (with 8 partials: 10.9), and no ordering of the loads hid it (partials first: 15.7); a single published
+    // copy polled by 1024 blocks still queued 3072 requests on one line (12.6).
+    double* parts = const_cast<double*>(partials);
+    if (blockIdx.x == 0) {
+        double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        constexpr int PB = 4;
+        double pa[PB][5];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {  // (one batch of loads: 4 x 5 doubles per lane cover 1024 partials)
+            const size_t pi = (size_t)min((int)threadIdx.x + 256 * u, nparts - 1);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pa[u][k] = partials[pi * 5 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u)
+            if ((int)threadIdx.x + 256 * u < nparts) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc[k] += pa[u][k];
+            }
+        for (int p = threadIdx.x + 256 * PB; p < nparts; p += blockDim.x) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[k] += partials[(size_t)p * 5 + k];
+        }
+        block_sum<5>(acc, s_red);
+        if (threadIdx.x == 0) {
+            const double cnt = acc[0];
+            const unsigned skip = cnt <= 0.0;  // "if len(valid_array) > 0" (utils.py:399)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const double sum = acc[1 + 2 * w], sq = acc[2 + 2 * w];
+                const double mean = sum / cnt;
+                const double var = (sq - sum * sum / cnt) / (cnt - 1.0);  // unbiased; NaN for cnt == 1, as torch
+                const float mf = (float)mean, df = fadd((float)sqrt(var > 0.0 || var != var ? var : 0.0), eps);
+                s_pub[w * 3 + 0] = __float_as_uint(mf), s_pub[w * 3 + 1] = __float_as_uint(df), s_pub[w * 3 + 2] = skip;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * kNormReplicas * 3) {  // (in the returns' launch this republishes the same words; nobody waits for it)
+            const int rep = threadIdx.x / 3, k = threadIdx.x % 3;  // rep counts through both arrays' copies
+            __hip_atomic_store(norm_words(parts, 0, rep) + k, 1ull << 32 | s_pub[(rep / kNormReplicas) * 3 + k], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        load_sweep(bb);  // (behind the partials: a wave's loads return in order, and the sweep queues with the whole chip's)
+    } else {
+        load_sweep(bb);
+        if (threadIdx.x < 64) {  // waits for a block with a LOWER index (dispatched first: forward progress), bounded all the same
+            const unsigned long long* mine = norm_words(parts, which, blockIdx.x % kNormReplicas) + (threadIdx.x < 3 ? threadIdx.x : 0);
+            unsigned long long w = 0;
+            const long long t0 = wall_clock64();
+            bool late = false;
+            for (int spins = 0;; ++spins) {
+                if (threadIdx.x < 3) w = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((__ballot((w >> 32) != 0ull) & 7ull) == 7ull) break;
+                if (spins > 16) {
+                    if (wall_clock64() - t0 > 200000000ll) {  // 2 s: block 0 never ran -- leave the array as it is rather than hang
+                        late = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (threadIdx.x < 3) s_pub[which * 3 + threadIdx.x] = late ? 1u : (unsigned)w;
+        }
     }
     __syncthreads();
-    if (s_skip) return;
-    const float mean = s_mean, den = s_den;
+    __syncthreads();
+    if (s_pub[which * 3 + 2]) return;
+    const float mean = __uint_as_float(s_pub[which * 3 + 0]), den = __uint_as_float(s_pub[which * 3 + 1]);
     // a / den with the reciprocal hoisted out of the stream: y = RN(1 / den), q0 = RN(a y), one residual step q = fma(fma(-q0,
     // den, a), y, q0) -- Markstein's correction: the correctly rounded quotient unless den's significand is all ones (then at most
     // one ulp off); 4 VALU operations per element instead of the division sequence's ~12, which at 16-32 elements per lane was
@@ -765,12 +830,12 @@ extern "C" size_t rlx_gae_workspace_bytes(int n_chunk, int batch, int chunk) {
     (void)n_chunk;
     (void)chunk;
     if (batch <= 0) return 0;
-    return (size_t)(ceil_div(batch, 64)) * 5 * sizeof(double);
+    return (size_t)kNormWords * 8 + (size_t)(ceil_div(batch, 64)) * 5 * sizeof(double);
 }
 
 extern "C" size_t rlx_standardize_workspace_bytes(size_t n) {
     (void)n;
-    return (size_t)kMaxParts * 5 * sizeof(double);
+    return (size_t)kNormWords * 8 + (size_t)kMaxParts * 5 * sizeof(double);
 }
 
 extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
@@ -791,7 +856,7 @@ extern "C" int rlx_gae_scan(const float* rewards, const float* values, const uin
     hipStream_t s = static_cast<hipStream_t>(stream);
     GaeArgs a;
     a.r = rewards; a.v = values; a.d = dones; a.m = loss_mask; a.adv = advantages; a.ret = returns;
-    a.partials = static_cast<double*>(workspace);
+    a.partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kNormWords * 8);  // (the normalisation words come first)
     a.T = n_chunk * chunk; a.B = batch; a.C = chunk;
     a.gamma = p->gamma; a.gl = p->gamma_lambda;
     const size_t n = (size_t)a.T * batch;
@@ -923,7 +988,7 @@ extern "C" int rlx_masked_standardize(float* x, const uint8_t* mask, size_t n, f
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nblk = (int)std::max<long long>(1, std::min<long long>((long long)((n + 255) / 256), std::min(kMaxParts, num_cu() * 8)));
-    double* partials = static_cast<double*>(workspace);
+    double* partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kNormWords * 8);
     hipLaunchKernelGGL(moments_kernel, dim3(nblk), dim3(256), 0, s, x, mask, n, partials);
     RLX_LAUNCH_CHECK();
     launch_standardize(x, n, partials, nblk, 0, eps, s);

@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu(lib):
     assert rc == -22
     assert b"NULL" in lib.rlx_last_error()
     assert lib.rlx_gae_scan(None, None, None, None, None, None, None, 0, 0, 4, 1, ctypes.byref(p), None) == 0  # empty
-    assert lib.rlx_gae_workspace_bytes(128, 1024, 1) == 16 * 5 * 8
+    assert lib.rlx_gae_workspace_bytes(128, 1024, 1) == 4096 + 16 * 5 * 8  # the published normalisation words, then a partial per 64 envs
     rc = lib.rlx_grpo_group_adv(None, None, None, None, None, 4, 10, 1, 4, 1e-6, None)
     assert rc == -22 and b"group_size" in lib.rlx_last_error()
 
