@@ -174,6 +174,49 @@ def test_masked_standardize_standalone():
         torch.testing.assert_close(got.cpu(), want, rtol=RTOL, atol=1e-5)
 
 
+def test_standardize_published_moments_do_not_leak_between_launches():
+    """The standardize pass reads mean / denominator / skip from words its block 0 publishes in front of the moment partials
+    (gae_scan.hip); the launch that writes the partials clears them.  One stream, back-to-back launches whose answers differ --
+    a normal array, an all-False mask (array untouched: utils.py:399), one valid element (NaN: unbiased std of one sample), a
+    16-byte-misaligned view, a single-block array -- and a hipGraph whose replays see new data each time."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    big = torch.randn(4096 * 70 + 3, generator=g) * 2 - 1
+    cases = [(big, None), (big, torch.zeros_like(big, dtype=torch.bool)), (big * 3 + 4, torch.rand(big.shape, generator=g) < 0.3),
+             (big, torch.arange(big.numel()) == 17), (torch.randn(100, generator=g), None), (big[:1000] + 9, None)]
+    for rep in range(3):
+        for x, m in cases:
+            want = O.masked_standardize(x, m)
+            got = ops.masked_standardize_(x.clone().cuda(), None if m is None else m.cuda()).cpu()
+            torch.testing.assert_close(got, want, rtol=RTOL, atol=1e-5, equal_nan=True)
+    # misaligned start (the kernel's scalar path): a view one float into an allocation
+    base = torch.empty(big.numel() + 1).cuda()
+    view = base[1:]
+    view.copy_(big)
+    torch.testing.assert_close(ops.masked_standardize_(view).cpu(), O.masked_standardize(big, None), rtol=RTOL, atol=1e-5)
+    # the scan's normalisation under graph replay: both arrays, new rewards per replay, against the eager launches
+    r = synth_rollout(seed=21, T=64, B=1024, p_done=0.03)
+    rew, val, don = r["rewards"].cuda(), r["values"].cuda(), r["dones"].cuda()
+    out = (torch.empty_like(rew), torch.empty_like(rew))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gae_scan(rew, val, don, None, 0.99, 0.95, normalize_returns=True, out=out)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ops.gae_scan(rew, val, don, None, 0.99, 0.95, normalize_returns=True, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    for k in range(4):
+        rew.copy_(torch.randn(rew.shape, generator=g) * (k + 1))
+        graph.replay()
+        torch.cuda.synchronize()
+        adv, ret = ops.gae_scan(rew, val, don, None, 0.99, 0.95, normalize_returns=True)
+        assert torch.equal(out[0], adv) and torch.equal(out[1], ret)
+        want = O.embodied_adv_and_returns(adv_type="gae", rewards=rew.cpu(), dones=r["dones"], values=r["values"], gamma=0.99,
+                                          gae_lambda=0.95, loss_mask=None)
+        torch.testing.assert_close(adv.cpu(), want["advantages"], rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("T,B,C,G", [(128, 1024, 1, 8), (80, 256, 1, 8), (12, 24, 2, 4), (20, 64, 1, 2), (5, 6, 1, 3)])
 def test_grpo_vs_oracle(T, B, C, G):
     ops = _ops()
