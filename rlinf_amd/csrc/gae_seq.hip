@@ -8,11 +8,13 @@
 // With that shaping the recurrence of sequence b is, for t = seq-1 .. 0,
 //     delta_t = (t == seq-1 ? r_b : gamma * V[b,t+1]) - V[b,t]        g_t = delta_t + (gamma*lambda) * g_{t+1},  g_seq = 0
 //     returns = g + V,   advantages = returns - V
-// i.e. a first-order linear recurrence ALONG THE CONTIGUOUS AXIS: a wavefront segmented scan.  One workgroup per sequence
-// walks it in segments of up to SEG tokens from the end; a segment is staged in LDS with coalesced loads, every lane
-// owns a contiguous chunk, reduces it to the affine map g_in -> K * g_in + G, the 256 maps are composed right-to-left
-// through LDS, and each lane then replays its chunk sequentially from its exact carry-in, writing through LDS so that the
-// stores are coalesced too.  13 B per token (values 4 + advantages 4 + returns 4 + mask 1 in the normalisation).
+// i.e. a first-order linear recurrence ALONG THE CONTIGUOUS AXIS: a wavefront segmented scan.  Rows whose length is a multiple
+// of four tokens (16-byte aligned rows, up to 32 768 tokens) take gae_seq_reg_kernel: one wave per 2048 tokens, registers only,
+// one barrier (0.72-0.77 of the HBM peak at 4096 x 8192, 0.79-0.85 where the arrays fit the memory-side cache).  Every other
+// shape takes the LDS kernels: one workgroup per sequence walks it in segments of up to SEG tokens from the end; a segment is
+// staged in LDS with coalesced loads, every lane owns a contiguous chunk, reduces it to the affine map g_in -> K * g_in + G, the
+// 256 maps are composed right-to-left through LDS, and each lane then replays its chunk sequentially from its exact carry-in,
+// writing through LDS so that the stores are coalesced too.  12 B per token (values 4 + advantages 4 + returns 4).
 //
 // The replay uses the reference's own operations in its order, so a result differs from the sequential loop only
 // through the carry-in of its chunk (affine composition instead of a chain: a few f32 ulp).
@@ -389,6 +391,166 @@ __global__ __launch_bounds__(ST) void gae_seq_lb_kernel(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Rows of 16-byte aligned length: REGISTERS ONLY, one wavefront per 2048-token segment.
+// The kernels above stage a segment in LDS so that a lane can own a contiguous chunk: load / scan / replay / store phases with
+// a workgroup barrier between each, during which that workgroup's memory pipes idle (0.55-0.63 of the HBM peak).  Here a lane
+// keeps the float4s it loaded: 64 lanes x 4 tokens = one 256-token group per load instruction, a wave requests ALL (up to
+// eight) groups of its segment before it touches any.  S waves of a workgroup share a row (S = 1: four rows per workgroup),
+// segment 0 at the row's END.
+//   pass 1 (no carry needed): per group, 4 tokens per lane -> the affine map g_in -> K g_in + G, a suffix composition over the
+//     64 lanes (DPP row shifts + lane reads: no LDS) -> every lane's exclusive map and the group's aggregate; the groups' aggregates composed
+//     give the segment's, which goes to LDS;
+//   ONE barrier; a wave chains the aggregates of the segments to its right from g = 0: its carry-in;
+//   pass 2: per group, the carry chained through the groups' aggregates, the lane's g_in from its exclusive map, the replay
+//     with the reference's own operations in its order, two float4 stores.
+// Every byte is read once and written once, each wave is one batch of loads and one batch of stores.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int WV_U = 8;  // groups (256 tokens each) per wave
+
+__device__ __forceinline__ float uniform(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+__device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+// DPP move: a lane whose source lies outside its row (row_shl) / the wave (wave_shl) keeps `old`
+template <int CTRL>
+__device__ __forceinline__ float dpp_or(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_ROW_SHL = 0x100, DPP_WAVE_SHL1 = 0x130;
+
+// Suffix composition of 64 per-lane maps g -> K g + G (the lane on the LEFT applies last) on the VALU: four DPP row shifts inside
+// the rows of 16 lanes, the three row aggregates by v_readlane.  -> the lane's EXCLUSIVE map (lanes lane + 1 .. 63) and the
+// wave's aggregate.  (The first form used six ds_bpermute steps per value: 15 LDS-pipe round trips per group on the critical
+// path of every wave.)  Identity is composed as (1, 0): K is a product of finite constants, so K * 0 never makes a NaN.
+__device__ __forceinline__ void suffix_maps(float K, float G, int lane, float& eK, float& eG, float& aK, float& aG) {
+    float iK = K, iG = G;
+#define RLX_STEP(OFF)                                                                  \
+    {                                                                                  \
+        const float oK = dpp_or<DPP_ROW_SHL + OFF>(1.f, iK), oG = dpp_or<DPP_ROW_SHL + OFF>(0.f, iG); \
+        iG = fadd(iG, fmul(iK, oG));                                                   \
+        iK = fmul(iK, oK);                                                             \
+    }
+    RLX_STEP(1) RLX_STEP(2) RLX_STEP(4) RLX_STEP(8)
+#undef RLX_STEP
+    const float k0 = lane_value(iK, 0), g0 = lane_value(iG, 0), k1 = lane_value(iK, 16), g1 = lane_value(iG, 16);
+    const float k2 = lane_value(iK, 32), g2 = lane_value(iG, 32), k3 = lane_value(iK, 48), g3 = lane_value(iG, 48);
+    // everything right of row 2 / 1 / 0
+    const float t1K = fmul(k2, k3), t1G = fadd(g2, fmul(k2, g3));
+    const float t0K = fmul(k1, t1K), t0G = fadd(g1, fmul(k1, t1G));
+    const int rowi = lane >> 4;
+    const float tK = rowi == 3 ? 1.f : rowi == 2 ? k3 : rowi == 1 ? t1K : t0K;
+    const float tG = rowi == 3 ? 0.f : rowi == 2 ? g3 : rowi == 1 ? t1G : t0G;
+    const float xK = dpp_or<DPP_ROW_SHL + 1>(1.f, iK), xG = dpp_or<DPP_ROW_SHL + 1>(0.f, iG);  // in-row exclusive
+    eK = fmul(xK, tK);
+    eG = fadd(xG, fmul(xK, tG));
+    aK = fmul(k0, t0K);
+    aG = fadd(g0, fmul(k0, t0G));
+}
+
+template <int S, bool NT>  // waves per row (a power of two <= 16)
+__global__ __launch_bounds__(64 * (S < 4 ? 4 : S)) void gae_seq_reg_kernel(const float* __restrict__ values,
+                                                                          const float* __restrict__ rewards, float* __restrict__ adv,
+                                                                          float* __restrict__ ret, long long bsz, int seq, float gamma,
+                                                                          float gamma_lambda) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int WAVES = S < 4 ? 4 : S, ROWS = WAVES / S;
+    __shared__ float sK[WAVES], sG[WAVES];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int w = wid % S;  // this wave's segment, counted from the row's end
+    const long long row_raw = (long long)blockIdx.x * ROWS + wid / S;
+    const bool row_live = row_raw < bsz;
+    const long long row = row_live ? row_raw : bsz - 1;  // (a dead wave of the last workgroup repeats a row, stores nothing)
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(values + row * (long long)seq);
+    f32x4* r4 = reinterpret_cast<f32x4*>(ret + row * (long long)seq);
+    f32x4* a4 = reinterpret_cast<f32x4*>(adv + row * (long long)seq);
+    const int nq = seq / 4, ngroups = (nq + 63) / 64;  // group k (from the END) holds float4s [nq - 64 (k + 1), nq - 64 k)
+    const int per = (ngroups + S - 1) / S;             // <= WV_U
+    const int k0 = w * per, k1 = min(ngroups, k0 + per);
+    f32x4 x[WV_U];
+#pragma unroll
+    for (int u = 0; u < WV_U; ++u) {  // (clamped, unconditional: all in flight together)
+        const int q = min(max(nq - 64 * (k0 + u + 1) + lane, 0), nq - 1);
+        if constexpr (NT) x[u] = __builtin_nontemporal_load(v4 + q);
+        else x[u] = v4[q];
+    }
+    const float r = rewards[row];
+    // V of the first token right of this segment (segment 0: the row ends there)
+    const float vseg = k0 > 0 && k0 < ngroups ? values[row * (long long)seq + (long long)(nq - 64 * k0) * 4] : 0.f;
+    float eK[WV_U], eG[WV_U], aK[WV_U], aG[WV_U];
+    float wK = 1.f, wG = 0.f;
+#pragma unroll
+    for (int u = 0; u < WV_U; ++u) {
+        const int k = k0 + u;
+        aK[u] = 1.f, aG[u] = 0.f, eK[u] = 1.f, eG[u] = 0.f;
+        if (k < k1) {  // (wave-uniform)
+            const bool live = nq - 64 * (k + 1) + lane >= 0;
+            const float vright = u == 0 ? vseg : uniform(x[u > 0 ? u - 1 : 0].x);  // (read with the whole wave active)
+            const float vn = dpp_or<DPP_WAVE_SHL1>(vright, x[u].x);  // V of the next lane's first token; lane 63: the next group's
+            const bool last = k == 0 && lane == 63;  // this lane's fourth token is the row's last: reward, recurrence cut
+            const float k3 = last ? 0.f : gamma_lambda;
+            const float d3 = fsub(last ? r : fmul(gamma, vn), x[u].w);
+            const float d2 = fsub(fmul(gamma, x[u].w), x[u].z);
+            const float d1 = fsub(fmul(gamma, x[u].z), x[u].y);
+            const float d0 = fsub(fmul(gamma, x[u].y), x[u].x);
+            float K = k3, G = d3;
+            G = fadd(d2, fmul(gamma_lambda, G)), K = fmul(K, gamma_lambda);
+            G = fadd(d1, fmul(gamma_lambda, G)), K = fmul(K, gamma_lambda);
+            G = fadd(d0, fmul(gamma_lambda, G)), K = fmul(K, gamma_lambda);
+            if (!live) K = 1.f, G = 0.f;
+            suffix_maps(K, G, lane, eK[u], eG[u], aK[u], aG[u]);
+            wG = fadd(aG[u], fmul(aK[u], wG));
+            wK = fmul(aK[u], wK);
+        }
+    }
+    float carry = 0.f;  // g at the first token right of the segment
+    if constexpr (S > 1) {
+        if (lane == 0) sK[wid] = wK, sG[wid] = wG;
+        __syncthreads();
+        const int base = wid - w;
+        for (int j = 0; j < w; ++j) carry = fadd(sG[base + j], fmul(sK[base + j], carry));
+    }
+#pragma unroll
+    for (int u = 0; u < WV_U; ++u) {
+        const int k = k0 + u;
+        if (k < k1) {
+            const int q = nq - 64 * (k + 1) + lane;
+            const float vright = u == 0 ? vseg : uniform(x[u > 0 ? u - 1 : 0].x);  // (read with the whole wave active)
+            const float vn = dpp_or<DPP_WAVE_SHL1>(vright, x[u].x);  // V of the next lane's first token; lane 63: the next group's
+            const bool last = k == 0 && lane == 63;
+            const float k3 = last ? 0.f : gamma_lambda;
+            const float d3 = fsub(last ? r : fmul(gamma, vn), x[u].w);
+            const float d2 = fsub(fmul(gamma, x[u].w), x[u].z);
+            const float d1 = fsub(fmul(gamma, x[u].z), x[u].y);
+            const float d0 = fsub(fmul(gamma, x[u].y), x[u].x);
+            float g = fadd(eG[u], fmul(eK[u], carry));  // g at the first token right of this lane's four
+            carry = fadd(aG[u], fmul(aK[u], carry));
+            f32x4 rt, at;
+            g = fadd(d3, fmul(k3, g)), rt.w = fadd(g, x[u].w), at.w = fsub(rt.w, x[u].w);
+            g = fadd(d2, fmul(gamma_lambda, g)), rt.z = fadd(g, x[u].z), at.z = fsub(rt.z, x[u].z);
+            g = fadd(d1, fmul(gamma_lambda, g)), rt.y = fadd(g, x[u].y), at.y = fsub(rt.y, x[u].y);
+            g = fadd(d0, fmul(gamma_lambda, g)), rt.x = fadd(g, x[u].x), at.x = fsub(rt.x, x[u].x);
+            if (q >= 0 && row_live) {
+                if constexpr (NT) {
+                    __builtin_nontemporal_store(rt, r4 + q);
+                    __builtin_nontemporal_store(at, a4 + q);
+                } else {
+                    r4[q] = rt;
+                    a4[q] = at;
+                }
+            }
+        }
+    }
+}
+
+template <int S>
+void launch_reg(bool nt, const float* values, const float* rewards, float* adv, float* ret, long long bsz, int seq, float gamma,
+                float gl, hipStream_t st) {
+    constexpr int WAVES = S < 4 ? 4 : S, ROWS = WAVES / S;
+    const unsigned grid = (unsigned)((bsz + ROWS - 1) / ROWS);
+    if (nt) hipLaunchKernelGGL((gae_seq_reg_kernel<S, true>), dim3(grid), dim3(64 * WAVES), 0, st, values, rewards, adv, ret, bsz, seq, gamma, gl);
+    else hipLaunchKernelGGL((gae_seq_reg_kernel<S, false>), dim3(grid), dim3(64 * WAVES), 0, st, values, rewards, adv, ret, bsz, seq, gamma, gl);
+}
+
 }  // namespace
 }  // namespace rlx
 
@@ -412,7 +574,23 @@ extern "C" int rlx_gae_seq(const float* values, const float* rewards, float* adv
         const int cap = (int)(seq < seg ? seq : seg);
         return (size_t)(2 * (cap + 1 + (cap + 1) / 32) + 8) * sizeof(float);
     };
-    if (seq <= 2048) {
+    // 16-byte aligned rows: the register kernel, one wave per 2048 tokens (rows up to 32 768 tokens).  Non-temporal accesses once
+    // the three arrays together exceed the memory-side cache (profiles/r06_gae_seq_register_kernel.txt).
+    // RLX_GAESEQ_REG=0 keeps the LDS kernels for every shape, 1 / 2 force ordinary / non-temporal accesses.
+    const int reg_mode = [] { const char* e = getenv("RLX_GAESEQ_REG"); return e ? atoi(e) : -1; }();
+    const int64_t ngroups = (seq / 4 + 63) / 64;
+    const bool reg_ok = seq % 4 == 0 && ngroups <= 16 * WV_U &&
+                        ((reinterpret_cast<uintptr_t>(values) | reinterpret_cast<uintptr_t>(advantages) |
+                          reinterpret_cast<uintptr_t>(returns)) & 15u) == 0;
+    if (reg_ok && reg_mode != 0) {
+        const int need = (int)((ngroups + WV_U - 1) / WV_U);
+        const bool nt = reg_mode == 1 ? false : reg_mode == 2 ? true : (size_t)bsz * (size_t)seq * 12 > ((size_t)256 << 20);
+        if (need <= 1) launch_reg<1>(nt, values, rewards, advantages, returns, bsz, (int)seq, gamma, gamma_lambda, st);
+        else if (need <= 2) launch_reg<2>(nt, values, rewards, advantages, returns, bsz, (int)seq, gamma, gamma_lambda, st);
+        else if (need <= 4) launch_reg<4>(nt, values, rewards, advantages, returns, bsz, (int)seq, gamma, gamma_lambda, st);
+        else if (need <= 8) launch_reg<8>(nt, values, rewards, advantages, returns, bsz, (int)seq, gamma, gamma_lambda, st);
+        else launch_reg<16>(nt, values, rewards, advantages, returns, bsz, (int)seq, gamma, gamma_lambda, st);
+    } else if (seq <= 2048) {
         // short sequences: one 128-lane workgroup each (longer chunks, fewer barriers per token), 17 KB of LDS -> nine per CU
         const int v = dev_variant_gaeseq();  // development: 20 = 256 lanes, 21 = 64 lanes, 22 = 1024-token segments
         if (v == 20)

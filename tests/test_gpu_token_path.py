@@ -570,6 +570,42 @@ def test_gae_seq_lookback_many_rows_and_nan_rows(variant, monkeypatch):
     assert torch.isnan(ret[3, :4001]).all() and torch.isfinite(ret[3, 4002 + 200:]).all()  # NaN flows towards t = 0 only
 
 
+@pytest.mark.parametrize("bsz,seq", [(7, 3000), (5, 4100), (3, 32768), (9, 260), (1500, 6144 + 8), (2, 32772)])
+def test_gae_seq_register_kernel_against_the_lds_kernels_and_the_oracle(bsz, seq, monkeypatch):
+    """Rows of 16-byte aligned length take gae_seq_reg_kernel (one wave per 2048 tokens, DPP suffix composition, one barrier):
+    two / four / sixteen waves per row, an odd row count with two rows per workgroup (a dead wave), a group that only the row's
+    first lanes fill, a row longer than sixteen waves cover (falls back to the LDS walk), thousands of rows with a NaN in one.
+    Against the LDS kernels (RLX_GAESEQ_REG=0) to rounding, and against the sequential oracle."""
+    from oracle import ppo_oracle as PO
+    g = torch.Generator().manual_seed(seq + bsz)
+    values = torch.randn(bsz, seq, generator=g)
+    rewards = torch.randn(bsz, generator=g)
+    nan_row = bsz > 1000
+    if nan_row:
+        values[3, 4000] = float("nan")
+    for forced in ("1", "2", None):  # ordinary / non-temporal accesses / the size rule
+        if forced is None:
+            monkeypatch.delenv("RLX_GAESEQ_REG", raising=False)
+        else:
+            monkeypatch.setenv("RLX_GAESEQ_REG", forced)
+        adv, ret = token_ops.gae_seq(values.to(DEV), rewards.to(DEV), 0.99, 0.95)
+        monkeypatch.setenv("RLX_GAESEQ_REG", "0")
+        adv0, ret0 = token_ops.gae_seq(values.to(DEV), rewards.to(DEV), 0.99, 0.95)
+        ok = torch.ones(bsz, dtype=torch.bool, device=DEV)
+        if nan_row:
+            ok[3] = False
+            assert torch.isnan(ret[3, :4001]).all() and torch.isfinite(ret[3, 4001:]).all()  # NaN flows towards t = 0 only
+        close(ret[ok], ret0[ok], 2e-5, 1e-5, "returns vs the LDS kernels")
+        close(adv[ok], adv0[ok], 2e-5, 1e-5, "advantages vs the LDS kernels")
+        assert torch.equal(adv[ok], ret[ok] - values.to(DEV)[ok])  # the reference's own last operation (advantages.py:79)
+    if bsz * seq <= 200000:
+        pre = TO.preprocess_reasoning(rewards, torch.ones(bsz, seq, dtype=torch.bool), "gae", values=values)
+        wadv, wret = PO.gae_tb(pre["rewards"], pre["dones"], values=pre["values"], gamma=0.99, gae_lambda=0.95, normalize_advantages=False)
+        atol = (4e-6 + 2e-7 * seq ** 0.5) * (float(wret.abs().max()) + 1.0)
+        close(ret, wret.transpose(0, 1), atol, 1e-5, "returns")
+        close(adv, wadv.transpose(0, 1), atol, 1e-5, "advantages")
+
+
 def test_empty_and_degenerate_inputs():
     """Zero tokens / sequences, a one-entry vocabulary, a one-bin categorical head, an empty tensor inside a synced state
     dict: defined results, no launches with zero-sized grids."""
