@@ -17,6 +17,7 @@
 // Response masks start with True, for which this is seq-1: the scalar reward sits on the last position of the row.
 
 #include <algorithm>
+#include <stdlib.h>
 
 #include "rlx_common.h"
 
@@ -194,6 +195,187 @@ __global__ __launch_bounds__(RTV) void reinpp_returns_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Rows of 16-byte aligned length: the returns in REGISTERS, one wavefront per U x 256 tokens (the shape of gae_seq_reg_kernel).
+// The kernel above walks a row tile by tile with two workgroup barriers per tile (wave totals through LDS): its waves alternate
+// between loading and waiting (0.63-0.70 of the HBM peak).  Here a wave requests ALL operands of its segment first -- U float4s of
+// each log-prob array and U mask words per lane --, turns them into per-token rewards, forms each 256-token group's suffix sums
+// in f64 on DPP row shifts + lane reads (no LDS), hands its total to the row's other waves through ONE barrier, and writes
+// return-to-go and the masked moments from registers.  S waves share a row (S = 1: four rows per workgroup, no barrier).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_or_d(double old, double src) {  // a lane whose source lies outside its row keeps `old`
+    const long long o = __double_as_longlong(old), x = __double_as_longlong(src);
+    const int lo = __builtin_amdgcn_update_dpp((int)o, (int)x, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(x >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double lane_value_d(double x, int l) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// sums over the lanes to the RIGHT of this one (exclusive) and over the whole wave
+__device__ __forceinline__ void suffix_sums(double v, int lane, double& excl, double& total) {
+    double i = v;
+    i += dpp_or_d<0x101>(0.0, i);  // row_shl:1, 2, 4, 8 -- inside the rows of 16 lanes
+    i += dpp_or_d<0x102>(0.0, i);
+    i += dpp_or_d<0x104>(0.0, i);
+    i += dpp_or_d<0x108>(0.0, i);
+    const double a0 = lane_value_d(i, 0), a1 = lane_value_d(i, 16), a2 = lane_value_d(i, 32), a3 = lane_value_d(i, 48);
+    const double t1 = a2 + a3, t0 = a1 + t1;  // everything right of row 1 / row 0
+    const int rowi = lane >> 4;
+    const double t = rowi == 3 ? 0.0 : rowi == 2 ? a3 : rowi == 1 ? t1 : t0;
+    excl = dpp_or_d<0x101>(0.0, i) + t;
+    total = a0 + t0;
+}
+
+template <int S, int U>  // waves per row (a power of two <= 16), 256-token groups per wave
+__global__ __launch_bounds__(64 * (S < 4 ? 4 : S)) void reinpp_returns_reg_kernel(
+    const float* __restrict__ rewards, const uint8_t* __restrict__ mask, const float* __restrict__ logprob,
+    const float* __restrict__ ref, int kl_kind, float kl_beta, float* __restrict__ ret, double* __restrict__ partials, long long B,
+    int seq) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int WAVES = S < 4 ? 4 : S, ROWS = WAVES / S;
+    __shared__ double sTot[WAVES];
+    __shared__ double sRed[WAVES][3];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int w = wid % S;  // this wave's segment, counted from the row's end
+    const long long row_raw = (long long)blockIdx.x * ROWS + wid / S;
+    const bool row_live = row_raw < B;
+    const long long row = row_live ? row_raw : B - 1;  // (a dead wave of the last workgroup repeats a row, stores nothing)
+    const bool has_kl = kl_beta > 0.f;
+    const f32x4* lp4 = reinterpret_cast<const f32x4*>(logprob + row * (long long)seq);
+    const f32x4* rf4 = reinterpret_cast<const f32x4*>(ref + row * (long long)seq);
+    const uint32_t* m32 = reinterpret_cast<const uint32_t*>(mask + row * (long long)seq);
+    f32x4* out4 = reinterpret_cast<f32x4*>(ret + row * (long long)seq);
+    const int nq = seq / 4, ngroups = (nq + 63) / 64;  // group k (from the END) holds float4s [nq - 64 (k + 1), nq - 64 k)
+    const int per = (ngroups + S - 1) / S;             // <= U
+    const int k0 = w * per, k1 = min(ngroups, k0 + per);
+    f32x4 a[U], c[U];
+    uint32_t mw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // (clamped, unconditional: all in flight together)
+        const int q = min(max(nq - 64 * (k0 + u + 1) + lane, 0), nq - 1);
+        if (has_kl) {
+#if RLX_REINPP_NT
+            a[u] = __builtin_nontemporal_load(lp4 + q);
+            c[u] = __builtin_nontemporal_load(rf4 + q);
+#else
+            a[u] = lp4[q];
+            c[u] = rf4[q];
+#endif
+        } else {
+            a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            c[u] = a[u];
+        }
+        mw[u] = m32[q];
+    }
+    const float reward = rewards[row];
+    // ---- reward position (see the header): first True of the mirrored sequence's mask; none -> argmax's 0
+    long long first = 0;
+    if (!mask[(B - 1 - row) * (long long)seq]) {  // (wave-uniform; response masks start with True: then eos = seq - 1, no search)
+        const uint32_t* mm = reinterpret_cast<const uint32_t*>(mask + (B - 1 - row) * (long long)seq);
+        first = seq;
+        for (int i = lane; i < nq && first == seq; i += 64) {
+            const uint32_t x = mm[i];
+            if (x) first = (long long)i * 4 + (__ffs((int)x) - 1) / 8;  // bool bytes are 0 / 1: the lowest set bit names the byte
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long o = __shfl_xor(first, off, 64);
+            first = o < first ? o : first;
+        }
+        if (first == seq) first = 0;
+    }
+    const long long eos = seq - 1 - first;
+    float r[U][4];
+    double excl[U], tot[U];
+    double wsum = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        excl[u] = 0.0, tot[u] = 0.0;
+        r[u][0] = r[u][1] = r[u][2] = r[u][3] = 0.f;
+        if (k < k1) {  // (wave-uniform)
+            const int q = nq - 64 * (k + 1) + lane;
+            if (q >= 0) {
+                if (has_kl) {
+                    r[u][0] = -fmul(kl_beta, kl_value(kl_kind, a[u].x, c[u].x)), r[u][1] = -fmul(kl_beta, kl_value(kl_kind, a[u].y, c[u].y));
+                    r[u][2] = -fmul(kl_beta, kl_value(kl_kind, a[u].z, c[u].z)), r[u][3] = -fmul(kl_beta, kl_value(kl_kind, a[u].w, c[u].w));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((long long)q * 4 + j == eos) r[u][j] = has_kl ? fadd(reward, r[u][j]) : reward;  // r_matrix[eos] = reward, then -= beta * kl
+            } else {
+                mw[u] = 0u;
+            }
+            const double l0 = (((double)r[u][3] + (double)r[u][2]) + (double)r[u][1]) + (double)r[u][0];
+            suffix_sums(l0, lane, excl[u], tot[u]);
+            wsum += tot[u];
+        } else {
+            mw[u] = 0u;
+        }
+    }
+    double carry = 0.0;  // sum of r over everything right of this wave's segment
+    if constexpr (S > 1) {
+        if (lane == 0) sTot[wid] = wsum;
+        __syncthreads();
+        const int base = wid - w;
+        for (int j = 0; j < w; ++j) carry += sTot[base + j];
+    }
+    double cnt = 0.0, sum = 0.0, sq = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        if (k < k1) {
+            const int q = nq - 64 * (k + 1) + lane;
+            const double right = carry + excl[u];
+            const double l3 = (double)r[u][3], l2 = l3 + (double)r[u][2], l1 = l2 + (double)r[u][1], l0 = l1 + (double)r[u][0];
+            const f32x4 v = {(float)(right + l0), (float)(right + l1), (float)(right + l2), (float)(right + l3)};
+            if (q >= 0 && row_live) out4[q] = v;
+            const uint32_t m = mw[u];
+            if (m & 0xffu) cnt += 1.0, sum += (double)v.x, sq += (double)v.x * (double)v.x;
+            if (m & 0xff00u) cnt += 1.0, sum += (double)v.y, sq += (double)v.y * (double)v.y;
+            if (m & 0xff0000u) cnt += 1.0, sum += (double)v.z, sq += (double)v.z * (double)v.z;
+            if (m & 0xff000000u) cnt += 1.0, sum += (double)v.w, sq += (double)v.w * (double)v.w;
+            carry += tot[u];
+        }
+    }
+    cnt = wave_sum(cnt), sum = wave_sum(sum), sq = wave_sum(sq);
+    if constexpr (S > 1) {
+        if (lane == 0) sRed[wid][0] = cnt, sRed[wid][1] = sum, sRed[wid][2] = sq;
+        __syncthreads();
+        if (w == 0 && lane < 3 && row_live) {
+            double t = 0.0;
+            for (int j = 0; j < S; ++j) t += sRed[wid + j][lane];
+            partials[row * 3 + lane] = t;
+        }
+    } else if (lane == 0 && row_live) {
+        partials[row * 3] = cnt, partials[row * 3 + 1] = sum, partials[row * 3 + 2] = sq;
+    }
+}
+
+template <int S, int U>
+void launch_returns_reg(const float* rewards, const uint8_t* mask, const float* lp, const float* ref, int kl_kind, float kl_beta,
+                        float* ret, double* partials, long long B, int seq, hipStream_t st) {
+    constexpr int WAVES = S < 4 ? 4 : S, ROWS = WAVES / S;
+    hipLaunchKernelGGL((reinpp_returns_reg_kernel<S, U>), dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(64 * WAVES), 0, st, rewards, mask,
+                       lp, ref, kl_kind, kl_beta, ret, partials, B, seq);
+}
+
+template <int U>
+bool returns_reg(const float* rewards, const uint8_t* mask, const float* lp, const float* ref, int kl_kind, float kl_beta, float* ret,
+                 double* partials, long long B, long long seq, hipStream_t st) {
+    const long long ngroups = (seq / 4 + 63) / 64, need = (ngroups + U - 1) / U;
+    if (need > 16) return false;
+    if (need <= 1) launch_returns_reg<1, U>(rewards, mask, lp, ref, kl_kind, kl_beta, ret, partials, B, (int)seq, st);
+    else if (need <= 2) launch_returns_reg<2, U>(rewards, mask, lp, ref, kl_kind, kl_beta, ret, partials, B, (int)seq, st);
+    else if (need <= 4) launch_returns_reg<4, U>(rewards, mask, lp, ref, kl_kind, kl_beta, ret, partials, B, (int)seq, st);
+    else if (need <= 8) launch_returns_reg<8, U>(rewards, mask, lp, ref, kl_kind, kl_beta, ret, partials, B, (int)seq, st);
+    else launch_returns_reg<16, U>(rewards, mask, lp, ref, kl_kind, kl_beta, ret, partials, B, (int)seq, st);
+    return true;
+}
+
 // partials [B][3] -> groups [G][3]: block g sums sequences g, g + G, ... (one single workgroup walking 3 B doubles was
 // 50 us at 32768 sequences)
 constexpr int MAX_GROUPS = 64;
@@ -285,7 +467,16 @@ extern "C" int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask
                            (kl_beta > 0.f ? (reinterpret_cast<uintptr_t>(logprob) | reinterpret_cast<uintptr_t>(ref_logprob)) : 0);
     // (A one-wave-per-row variant for rows of <= 2048 tokens -- no LDS, no barrier, 16 / 32 tokens per lane in registers -- was
     //  measured and dropped: 0.41 / 0.23 of the HBM peak at 32768 x 1024 / 16384 x 2048 against 0.51 / 0.57 for this kernel.)
-    {
+    // 16-byte aligned rows: the register kernel (RLX_REINPP_REG=0: the tile walk for every shape; 4 / 8: groups per wave)
+    const int reg_mode = [] { const char* e = getenv("RLX_REINPP_REG"); return e ? atoi(e) : -1; }();
+    bool done = false;
+    if ((bits & 15) == 0 && seq % 4 == 0 && seq < (1ll << 31) && reg_mode != 0) {
+        if (reg_mode == 8 || (reg_mode != 4 && seq > 16384))
+            done = returns_reg<8>(rewards, loss_mask, logprob, ref_logprob, kl_type, kl_beta, advantages, partials, bsz, seq, st);
+        else
+            done = returns_reg<4>(rewards, loss_mask, logprob, ref_logprob, kl_type, kl_beta, advantages, partials, bsz, seq, st);
+    }
+    if (!done) {
         // lanes per sequence (a tile is 4 x lanes tokens), measured on three shapes (profiles/r02_reinpp_lanes_sweep.txt):
         // rows of <= 2048 tokens want 64 lanes (0.65-0.66 of the HBM peak against 0.58-0.62 with 256: a row is 4-8 short tiles
         // of one wave each, no cross-wave hand-off, and many rows share a CU), rows of >= 4096 tokens 256 lanes (0.69 against 0.63)

@@ -675,6 +675,30 @@ def test_reinpp_vs_oracle(seq, kl, beta, masks):
     _reinpp_close(adv.t(), want, seq)
 
 
+@pytest.mark.parametrize("bsz,seq", [(7, 3000), (5, 4100), (3, 20000), (9, 260), (600, 2048), (2, 32772)])
+@pytest.mark.parametrize("masks", ["prefix", "ragged"])
+def test_reinpp_register_kernel_against_the_tile_walk_and_the_oracle(bsz, seq, masks, monkeypatch):
+    """Rows of 16-byte aligned length take reinpp_returns_reg_kernel (one wave per 1024 / 2048 tokens, f64 suffix sums on DPP row
+    shifts, one barrier): one to sixteen waves per row, dead waves of the last workgroup, a group only the row's first lanes fill,
+    the mirrored-mask search, a row longer than sixteen waves cover (tile walk).  Both group counts per wave against the tile walk
+    (RLX_REINPP_REG=0) -- the f64 sums round to the same f32 returns, so the normalised output is compared tightly -- and the oracle."""
+    from oracle.make_golden import reinpp_batch
+    rewards, mask, lp, rlp = reinpp_batch(77 + seq, bsz, seq, masks)
+    args = (rewards.to(DEV), mask.to(DEV), lp.to(DEV), rlp.to(DEV), 0.02, "low_var_kl")
+    monkeypatch.setenv("RLX_REINPP_REG", "0")
+    walk = token_ops.reinpp_seq_adv(*args)
+    for forced in ("4", "8", None):
+        if forced is None:
+            monkeypatch.delenv("RLX_REINPP_REG", raising=False)
+        else:
+            monkeypatch.setenv("RLX_REINPP_REG", forced)
+        got = token_ops.reinpp_seq_adv(*args)
+        close(got, walk, 2e-6, 2e-6, f"register kernel ({forced}) vs the tile walk")
+    if bsz * seq <= 100000:
+        want = TO.reinpp_reasoning_advantages(rewards.clone(), mask, 3, False, 0.02, lp, rlp, "low_var_kl")
+        _reinpp_close(got, want, seq)
+
+
 def test_reinpp_reward_position_follows_the_mirrored_mask():
     """The reference reads the 'last valid token' off the batch-flipped mask: sequence b's reward goes to seq-1 minus the
     first-True index of sequence bsz-1-b.  With kl_beta = 0 the return-to-go is the reward up to that position and 0 after."""
