@@ -7,6 +7,7 @@
 //   returns   one workgroup per sequence: locate the reward position, suffix-sum r[t] = [t == eos] reward - beta * kl[t]
 //             from the right in 1024-element tiles (coalesced 16-byte loads, wave-shuffle scans, f64 carries), write the
 //             return-to-go, accumulate (count, sum, sum of squares) of the masked returns -> per-sequence partials
+//             (rows of 16-byte aligned length: reinpp_returns_reg_kernel further down -- the same sums from registers)
 //   reduce    <= 64 workgroups: per-sequence partials -> group sums
 //   normalize every workgroup folds the group sums into mean, rsqrt(max(var, 1e-8)) itself; adv = (ret - mean) * rstd, float4
 //
