@@ -672,14 +672,14 @@ __global__ __launch_bounds__(256) void standardize_kernel(float* x, size_t n, co
                 if (threadIdx.x < 3) w = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((__ballot((w >> 32) != 0ull) & 7ull) == 7ull) break;
                 if (spins > 16) {
-                    if (wall_clock64() - t0 > 200000000ll) {  // 2 s: block 0 never ran -- leave the array as it is rather than hang
-                        late = true;
+                    if (wall_clock64() - t0 > 200000000ll) {  // 2 s: block 0 never ran -- never hang the GPU over it; the array
+                        late = true;                           // comes back NaN (loud in every metric), not silently unscaled
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (threadIdx.x < 3) s_pub[which * 3 + threadIdx.x] = late ? 1u : (unsigned)w;
+            if (threadIdx.x < 3) s_pub[which * 3 + threadIdx.x] = late ? (threadIdx.x < 2 ? 0x7FC00000u : 0u) : (unsigned)w;
         }
     }
     __syncthreads();

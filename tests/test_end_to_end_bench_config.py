@@ -218,6 +218,23 @@ def test_first_optimizer_step_gradient_at_bench_configuration(precision):
                                              loss=[float(host[PPO_OUT_NAMES["loss"]]), loss32, loss16]))
     assert rel <= 2.0 * rel_auto + 1e-3 and cos > 0.995, (rel, rel_auto, cos)
     assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(loss32, rel=2e-2, abs=2e-3)
+    # ... and the PIN: the same minibatch (the product's own rows, so the upstream rollout's rounding is not in the comparison)
+    # through oracle/bf16_operand_model.py -- the oracle's arithmetic with the launches' operand roundings written out, float64.
+    # First step of an iteration: ratio = 1 and value gap = 0 up to the roundings, no sample near a clip edge.
+    from oracle import bf16_operand_model as BM
+    polm = O.OracleMLPPolicy(D, A, 1)
+    polm.load_state_dict(sd)
+    c = {k: v.detach().cpu() for k, v in mb.items() if isinstance(v, torch.Tensor)}
+    outm = BM.evaluate(polm, c["states"], c["action"])
+    shaped = O.shape_loss_inputs(outm["logprobs"], c["prev_logprobs"], c["advantages"], "action_level", A, values=outm["values"],
+                                 prev_values=c["prev_values"], returns=c["returns"])
+    lossm, _ = O.ppo_actor_critic_loss(clip_ratio_low=0.2, clip_ratio_high=0.2, value_clip=1.0, huber_delta=10.0, **shaped)
+    lossm.backward()
+    gm = _flat_grad(polm)
+    rel_pin = float((got - gm).norm() / gm.norm())
+    _report("first_step_gradient_bf16_pinned", dict(rel_l2_vs_operand_rounded_model=rel_pin, loss=[float(host[PPO_OUT_NAMES["loss"]]), float(lossm)]))
+    assert rel_pin <= 1e-3, rel_pin
+    assert float(host[PPO_OUT_NAMES["loss"]]) == pytest.approx(float(lossm), rel=1e-4, abs=1e-6)
 
 
 def _flat_grad(pol):
