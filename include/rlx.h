@@ -706,8 +706,9 @@ int rlx_reinpp_seq_adv(const float* rewards, const uint8_t* loss_mask, const flo
  *   values [bsz, seq] f32, rewards [bsz] f32 (the scalar reward sits on the LAST position of the row, as the reference
  *   places it) -> advantages, returns [bsz, seq] f32, un-normalised; gamma_lambda = (float)((double)gamma * gae_lambda).
  *   Normalisation is rlx_masked_standardize over the [bsz, seq] buffer with the loss mask (layout-agnostic).
- *   Rows longer than 2048 tokens are cut into 2048-token segments, one workgroup each, whose carries travel through
- *   `workspace` (rlx_gae_seq_workspace_bytes; decoupled look-back, see csrc/gae_seq.hip); shorter rows need none (NULL is fine).
+ *   Rows of 16-byte aligned length (seq % 4 == 0, 16-byte aligned base pointers, seq <= 32768) run in registers, one wave per
+ *   2048 tokens (csrc/gae_seq.hip); other shapes are staged through LDS.  `workspace` (rlx_gae_seq_workspace_bytes) is only read
+ *   by a development variant of the long-row kernel; NULL is accepted otherwise.
  * ------------------------------------------------------------------------------------------ */
 size_t rlx_gae_seq_workspace_bytes(int64_t bsz, int64_t seq);
 int rlx_gae_seq(const float* values, const float* rewards, float* advantages, float* returns, int64_t bsz, int64_t seq,
