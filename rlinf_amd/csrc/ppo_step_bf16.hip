@@ -100,6 +100,17 @@ struct RowGemmB {
             if (d < nit) gload(d, bq[d]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // stages [D0, D1) of a layer whose PD covers all of its k-steps: a launch may spread its requests over several points
+    template <int D0, int D1>
+    __device__ __forceinline__ void prefetch_part(const __bf16* __restrict__ P, int nit_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        nit = nit_;
+        wbase = P + (size_t)(wave * CT) * 512 + lane * 8;
+#pragma unroll
+        for (int d = D0; d < D1; ++d)
+            if (d < nit) gload(d, bq[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __device__ __forceinline__ void run(const __bf16* Xb, f32x4 (&acc)[RT][CT]) {
         const int lane = threadIdx.x & 63, r16 = lane & 15, kb = lane >> 4;
         zero_acc(acc);
@@ -260,7 +271,7 @@ __device__ __forceinline__ void head_forward_mfma(const __bf16* Xb, const float*
 // ---------------------------------------------------------------------------------------------------------------
 // rollout step (RT = 1, NW = 8)
 // ---------------------------------------------------------------------------------------------------------------
-template <int RT>  // 16 RT rows per workgroup
+template <int RT, int ORDER = 1345>  // 16 RT rows per workgroup; ORDER: where the weight fragments of layers 2 and 3 are requested
 __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
     constexpr int NW = 8;
     touch_kernargs<(int)sizeof(RolloutArgs)>();
@@ -294,6 +305,17 @@ __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
     // lane's output element, and ALL three layers' weight fragments (16 rows per workgroup leave the registers for it:
     // 16 + 64 + 64 VGPRs).  The launch then costs one memory round trip plus the compute chain, instead of one round trip per
     // layer (each layer's first fragment loads used to be waited for by the previous epilogue's bias load).
+#ifdef RLX_DEV_VARIANTS
+    Stamps ts{a.stamps, 0};  // development: phase stamps of block 0 (tools/phase_times.py)
+#define RLX_MARK() ts.mark()
+#else
+#define RLX_MARK()
+#endif
+    RLX_MARK();
+#ifdef RLX_DEV_VARIANTS
+    if (a.stamps != nullptr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // kernel arguments arrived
+#endif
+    RLX_MARK();
     StatesB<RT, NW> st;
     st.issue(states, D, m0, M);
     SmallInputsB<G::NT> si;
@@ -306,25 +328,57 @@ __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     RowGemmB<RT, NW, Tiles::K1P / 32> gemm1;
     RowGemmB<RT, NW, HID / 32> gemm2, gemm3;
+    // WHEN the weight fragments are requested decides this launch.  A workgroup's 288 KB of fragments pass the CU's address
+    // unit at 64 B / clk: 4.6 k cycles, and a wave that issues loads faster than that STALLS in issue -- with everything requested
+    // up front (rounds 3-5: "one memory round trip per launch") the waves spent 3.9 k cycles issuing and the first barrier fell at
+    // 7.8 k of the launch's 13.7 k (phase stamps, development build), the products and epilogues (5.9 k) queueing behind it.
+    // Requested one phase ahead of their use, half a layer at a time, the same bytes stream while the earlier layers compute.
+    // ORDER = four decimal digits (W2 first half, W2 second half, W3 first half, W3 second half): the point at which that half
+    // layer is requested -- 0 up front, 1 behind the commits, 2 behind the first barrier, 3 behind the first layer's products,
+    // 4 behind its epilogue, 5 behind the second layer's products.  Same loads, same arithmetic: bit-identical outputs.
+    constexpr int P2A = ORDER / 1000 % 10, P2B = ORDER / 100 % 10, P3A = ORDER / 10 % 10, P3B = ORDER % 10, H = HID / 64;
+#define RLX_POINT(N)                                                                               \
+    {                                                                                              \
+        if constexpr (P2A == N) gemm2.template prefetch_part<0, H>(tiles + Tiles::mat(y, 1), HID / 32);      \
+        if constexpr (P2B == N) gemm2.template prefetch_part<H, 2 * H>(tiles + Tiles::mat(y, 1), HID / 32);  \
+        if constexpr (P3A == N) gemm3.template prefetch_part<0, H>(tiles + Tiles::mat(y, 2), HID / 32);      \
+        if constexpr (P3B == N) gemm3.template prefetch_part<H, 2 * H>(tiles + Tiles::mat(y, 2), HID / 32);  \
+    }
     gemm1.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
-    gemm2.prefetch(tiles + Tiles::mat(y, 1), HID / 32);
-    gemm3.prefetch(tiles + Tiles::mat(y, 2), HID / 32);
+    RLX_POINT(0)
+    RLX_MARK();  // every load issued
     st.commit(states_copy, D, m0, M, Xb);
+    RLX_MARK();  // states arrived
     si.commit(n_out, sBias, W4s, b4s, sStd);
     for (int i = n_out * W4S + tid; i < MAX_OUT * W4S; i += G::NT) W4s[i] = 0.f;
+    RLX_POINT(1)
     lds_barrier();
+    RLX_MARK();  // inputs staged
+    RLX_POINT(2)
     f32x4 acc[RT][G::CT];
     gemm1.run(Xb, acc);
+    RLX_POINT(3)
+    RLX_MARK();
     epilogue_tanh_b<RT, NW, false>(acc, sBias, Xb, nullptr, nullptr, nullptr, 0, m0);
+    RLX_POINT(4)
+    RLX_MARK();
     gemm2.run(Xb, acc);
+    RLX_POINT(5)
+#undef RLX_POINT
+    RLX_MARK();
     epilogue_tanh_b<RT, NW, false>(acc, sBias + HID, Xb, nullptr, nullptr, nullptr, 0, m0);
+    RLX_MARK();
     gemm3.run(Xb, acc);
+    RLX_MARK();
     epilogue_tanh_b<RT, NW, false>(acc, sBias + 2 * HID, Xb, nullptr, nullptr, nullptr, 0, m0);
+    RLX_MARK();
 
     static_assert(G::BM * MAX_OUT <= G::NT, "one head output per lane");
     float* sP0 = b4s + MAX_OUT, *sP1 = sP0 + G::BM * MAX_OUT;
     head_forward_mfma<RT>(Xb, W4s, sP0, sP1);
     lds_barrier();
+    RLX_MARK();  // head
+#undef RLX_MARK
     if (tid < G::BM * n_out) {
         float s = fadd(sP0[orow * MAX_OUT + oo], sP1[orow * MAX_OUT + oo]);
         if (lay.off_b[y][3] >= 0) s = fadd(s, b4s[oo]);
@@ -1119,8 +1173,23 @@ int launch_rollout_bf16(const RolloutArgs& a, int blocks, hipStream_t st) {
 #endif
     {
         const size_t lds = GeoB<1, 8>::LDS_BYTES;
-        if (int rc = set_lds_b(rollout_step_bf16_kernel<1>, lds)) return rc;
-        hipLaunchKernelGGL(rollout_step_bf16_kernel<1>, dim3(blocks), dim3(512), lds, st, a);
+        // Half layers requested one phase ahead of their use (ORDER 1345, see the kernel): measured in a replayed graph of 64 steps,
+        // 7.84 -> 6.84 us against everything up front (ORDER 0); profiles/r06_rollout_request_order.txt.
+#define RLX_RO(O) { if (int rc = set_lds_b(rollout_step_bf16_kernel<1, O>, lds)) return rc; hipLaunchKernelGGL((rollout_step_bf16_kernel<1, O>), dim3(blocks), dim3(512), lds, st, a); }
+#ifdef RLX_DEV_VARIANTS
+        switch (dev_variant("RLX_ROLLOUT_ORDER", 1345)) {
+            case 0: RLX_RO(0) break;
+            case 1135: RLX_RO(1135) break;
+            case 1134: RLX_RO(1134) break;
+            case 33: RLX_RO(33) break;
+            case 1355: RLX_RO(1355) break;
+            case 2345: RLX_RO(2345) break;
+            default: RLX_RO(1345) break;
+        }
+#else
+        RLX_RO(1345)
+#endif
+#undef RLX_RO
     }
     RLX_LAUNCH_CHECK();
     return RLX_OK;

@@ -59,11 +59,11 @@ for rep in range(3):
     t = t[32:48]
     print(f"dw bf16 (item 0): prologue->first barrier {t[1]-t[0]}  per k-block {[t[i+1]-t[i] for i in range(1, 11)]}  loop end {t[14]-t[0]}  stores drained {t[15]-t[14]}")
 states, eps = torch.randn(1024, 42, device="cuda"), torch.randn(1024, 8, device="cuda")
-rn = ["start", "states+head staged", "gemm L1", "epi1", "gemm L2", "epi2", "gemm L3", "epi3", "head+outputs"]
+rn = ["start", "kernargs arrived", "loads issued", "states arrived", "inputs staged", "gemm L1", "epi1", "gemm L2", "epi2", "gemm L3", "epi3", "head"]
 for B in (1024, 128):
     for rep in range(2):
         buf.zero_()
-        ops.mlp_rollout_step(pol.flat.data, pol.tiles(), lay, states[:B], eps[:B])
+        ops.mlp_rollout_step(pol16.flat.data, pol16.tiles(), lay, states[:B], eps[:B])
         torch.cuda.synchronize()
         t = buf.cpu().tolist()
         print(f"rollout_step B={B} block 0: total {t[len(rn)-1]-t[0]} ticks")
