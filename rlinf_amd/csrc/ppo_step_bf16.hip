@@ -166,28 +166,59 @@ template <int RT, int NW>
 struct StatesB {
     typedef GeoB<RT, NW> G;
     static_assert(Tiles::K1P == 64, "one pass per lane assumes a 64-wide padded first layer");
-    static constexpr int UB = G::BM * Tiles::K1P / G::NT;  // loads per lane: the whole tile travels in ONE round trip
-    float x[UB];
+    // The tile's rows are CONTIGUOUS in memory (BM x D floats, starting on a multiple of 16 floats), so it travels as float4s
+    // (dword alignment is all a global 16-byte load needs): one instruction for each of the first few waves, where round 5's
+    // form issued BM * 64 / NT dword instructions in EVERY wave -- a vector-memory instruction costs the CU's address unit ~16
+    // cycles whatever its width, and the launch's first wait sits behind all of them (32 wave-instructions per workgroup -> 6
+    // at 32 x 42).  Floats past the end of the array are never read: the (at most three) valid floats behind the last whole
+    // float4 of the array's last tile are fetched by three lanes in commit().
+    static constexpr int UV = (G::BM * (Tiles::K1P / 4) + G::NT - 1) / G::NT;
+    f32x4 xv[UV];
+    __device__ __forceinline__ static int valid_floats(int D, long long m0, long long M) {  // of this tile
+        return (int)(min((long long)G::BM, M - m0) * D);
+    }
     __device__ __forceinline__ void issue(const float* __restrict__ states, int D, long long m0, long long M) {
-        const int kp = round_up(D, KPAD);
+        const int nfloat = valid_floats(D, m0, M);
+        const int nfull4 = nfloat >> 2, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63;  // (scalar: see SmallInputsB)
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(states + (size_t)m0 * D);
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int i = min((int)threadIdx.x + u * G::NT, G::BM * kp - 1);
-            const int r = i / kp, c = i % kp;
-            x[u] = states[(size_t)min(m0 + r, M - 1) * D + min(c, D - 1)];  // clamped, unconditional load
+        for (int u = 0; u < UV; ++u) {
+            xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wave0 + u * G::NT < nfull4) xv[u] = t4[min((int)threadIdx.x + u * G::NT, nfull4 - 1)];  // (wave-uniform skip)
         }
     }
-    __device__ __forceinline__ void commit(float* __restrict__ states_copy, int D, long long m0, long long M, __bf16* Xb) const {
-        const int kp = round_up(D, KPAD);
+    __device__ __forceinline__ void commit(const float* __restrict__ states, float* __restrict__ states_copy, int D, long long m0,
+                                           long long M, __bf16* Xb) const {
+        const int kp = round_up(D, KPAD), nfloat = valid_floats(D, m0, M), nfull4 = nfloat >> 2, rem = nfloat & 3;
+        const float inv_d = 1.f / (float)D;
+        auto row_of = [&](int e) {  // e / D for an element index e < 4096: the float quotient is off by far less than one
+            int r = (int)(((float)e + 0.5f) * inv_d);
+            r -= (r * D > e);
+            r += ((r + 1) * D <= e);
+            return r;
+        };
+        float* copy = states_copy ? states_copy + (size_t)m0 * D : nullptr;
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int i = (int)threadIdx.x + u * G::NT;
-            if (i >= G::BM * kp) continue;
-            const int r = i / kp, c = i % kp;
-            const bool ok = c < D && m0 + r < M;
-            if (ok && states_copy) states_copy[(size_t)(m0 + r) * D + c] = x[u];
-            Xb[r * XSB + c] = (__bf16)(ok ? x[u] : 0.f);
+        for (int u = 0; u < UV; ++u) {
+            const int q = (int)threadIdx.x + u * G::NT;
+            if (q >= G::BM * D / 4) continue;
+            const bool ok = q < nfull4;
+            if (ok && copy) *reinterpret_cast<f32x4*>(copy + 4 * q) = xv[u];
+            int r = row_of(4 * q), c = 4 * q - r * D;  // element 4 q + j sits at (r, c): one division, then a carry per element
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ok || 4 * q + j >= nfloat) Xb[r * XSB + c] = (__bf16)(ok ? xv[u][j] : 0.f);  // (rows past M: zeros)
+                if (++c == D) c = 0, ++r;
+            }
         }
+        if ((int)threadIdx.x < rem) {  // the floats behind the array's last whole float4: fetched here (a second round trip, paid by
+            const int e = 4 * nfull4 + threadIdx.x, r = row_of(e);  // the last tile of an array whose size is no multiple of four floats)
+            const float tail = states[(size_t)m0 * D + e];
+            Xb[r * XSB + (e - r * D)] = (__bf16)tail;
+            if (copy) copy[e] = tail;
+        }
+        const int padc = kp - D;  // the zero columns behind every row (the k tail of the first layer)
+        for (int i = threadIdx.x; i < G::BM * padc; i += G::NT) Xb[(i / padc) * XSB + D + i % padc] = (__bf16)0.f;
     }
     // after an LDS barrier behind commit()
     __device__ __forceinline__ static void tiles(__bf16* __restrict__ st_tiles, int nrb, int D, long long m0, const __bf16* Xb) {
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(512) void rollout_step_bf16_kernel(RolloutArgs a) {
     gemm1.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
     RLX_POINT(0)
     RLX_MARK();  // every load issued
-    st.commit(states_copy, D, m0, M, Xb);
+    st.commit(states, states_copy, D, m0, M, Xb);
     RLX_MARK();  // states arrived
     si.commit(n_out, sBias, W4s, b4s, sStd);
     for (int i = n_out * W4S + tid; i < MAX_OUT * W4S; i += G::NT) W4s[i] = 0.f;
@@ -489,7 +520,8 @@ __global__ __launch_bounds__(64 * NW, RT == 2 ? 4 : 2) void ppo_step_fused_bf16_
     __builtin_amdgcn_sched_barrier(0);
     RowGemmB<RT, NW, PD> gemm;
     gemm.prefetch(tiles + Tiles::mat(y, 0), Tiles::K1P / 32);
-    st.commit(nullptr, D, m0, M, Xb);
+    ts.mark();  // (every input requested)
+    st.commit(a.states, nullptr, D, m0, M, Xb);
     ts.mark();
 #pragma unroll
     for (int u = 0; u < PI; ++u) {

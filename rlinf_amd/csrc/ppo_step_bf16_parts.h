@@ -125,27 +125,42 @@ struct SmallInputsB {
     float bv[NB];
     f32x4 hw[NH];
     float b4v, lsv;
+    bool has_b4;
     __device__ __forceinline__ void issue(const float* __restrict__ params, const rlx_mlp_layout& lay, int y, int n_out) {
         const int tid = threadIdx.x;
+        const int wave0 = __builtin_amdgcn_readfirstlane(tid) & ~63;  // (first lane of this wave, in a SCALAR register: the predicates
+        //                                                                 below are scalar branches, no exec-mask divergence)
         // (lay lives in the kernel arguments: indexing it with a per-lane value would turn into a VECTOR load of the argument
         //  block and a dependent round trip -- the three offsets are read as scalars and selected per lane.)
         const long long ob0 = lay.off_b[y][0], ob1 = lay.off_b[y][1], ob2 = lay.off_b[y][2];
+        // A vector-memory instruction occupies the CU's address unit for ~16 cycles whatever its width, and every wave of the
+        // (two) resident workgroups requests its inputs at the same moment: round 6's phase stamps put 3.6-4.6 k cycles of pure
+        // ISSUE in front of the fused launch's first wait.  So a wave none of whose lanes holds a useful index skips the
+        // instruction (a scalar branch: no lane-level divergence, the clamped addresses stay for the partially useful waves).
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int i = min(tid + u * NT, 3 * HID - 1), l = i / HID;
-            bv[u] = params[(l == 0 ? ob0 : l == 1 ? ob1 : ob2) + i % HID];
+            bv[u] = 0.f;
+            if (wave0 + u * NT < 3 * HID) {
+                const int i = min(tid + u * NT, 3 * HID - 1), l = i / HID;
+                bv[u] = params[(l == 0 ? ob0 : l == 1 ? ob1 : ob2) + i % HID];
+            }
         }
         const float* W4 = params + lay.off_w[y][3];
 #pragma unroll
         for (int u = 0; u < NH; ++u) {
-            const int f = min(tid + u * NT, n_out * 64 - 1), o = f >> 6, c4 = (f & 63) * 4;
-            hw[u] = *reinterpret_cast<const f32x4*>(W4 + (size_t)o * HID + c4);
+            hw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wave0 + u * NT < n_out * 64) {
+                const int f = min(tid + u * NT, n_out * 64 - 1), o = f >> 6, c4 = (f & 63) * 4;
+                hw[u] = *reinterpret_cast<const f32x4*>(W4 + (size_t)o * HID + c4);
+            }
         }
-        // unconditional, clamped loads (a load under a branch gets its wait under the branch too)
-        const int oc = min(tid, n_out - 1);
+        // unconditional within the wave, clamped (a load under a LANE-level branch gets its wait under the branch too)
+        // b4 / log-std: every wave loads them (two instructions), unconditionally -- under the wave-0 predicate the compiler moved
+        // commit()'s expf(lsv) up into the predicated block and put a full wait in front of wave 0's weight requests
         const long long ob3 = lay.off_b[y][3];
-        b4v = params[(ob3 >= 0 ? ob3 : 0) + oc];
-        if (ob3 < 0) b4v = 0.f;
+        has_b4 = ob3 >= 0;  // (applied in commit(): a select on the loaded value here would put its wait here)
+        const int oc = min(tid, n_out - 1);
+        b4v = params[(has_b4 ? ob3 : 0) + oc];
         lsv = params[y == 1 ? lay.off_logstd + oc : 0];
     }
     __device__ __forceinline__ void commit(int n_out, float* sBias, float* W4s, float* b4s, float* sStd) const {
@@ -159,7 +174,7 @@ struct SmallInputsB {
             if (f < n_out * 64) *reinterpret_cast<f32x4*>(W4s + (f >> 6) * W4S + (f & 63) * 4) = hw[u];
         }
         if (tid < n_out) {  // (the value network's lanes compute the std terms of a junk word: never read)
-            b4s[tid] = b4v;
+            b4s[tid] = has_b4 ? b4v : 0.f;
             const float stdv = expf(lsv);
             sStd[tid] = stdv;
             sStd[MAX_OUT + tid] = fmul(stdv, stdv);

@@ -45,7 +45,7 @@ for rep in range(3):
 # bf16 fused kernel (block (0,0)) and weight-gradient kernel (LDS-DMA variant): stamps of the workgroup owning GEMM item 0 land at buf[32:]
 pol16 = MLPPolicy(42, 8, 1, True, False, compute_dtype=torch.bfloat16).to("cuda")
 grads16 = torch.empty((ops.ppo_step_slabs(lay, M, bf16=True), lay.n_params), device="cuda")
-names16 = ["start", "states arrived", "inputs staged", "gemm L1", "epi1+tiles", "gemm L2", "epi2+tiles", "gemm L3", "epi3", "head (mfma)",
+names16 = ["start", "loads issued", "states arrived", "inputs staged", "gemm L1", "epi1+tiles", "gemm L2", "epi2+tiles", "gemm L3", "epi3", "head (mfma)",
            "element pass", "loss pass (wave 0)", "dOut pass + metric sums", "head grads", "dz3+tiles", "bwd gemm W3 + epi + tiles",
            "bwd gemm W2 + epi + tiles", "stores drained"]  # ("loss pass" is stamped by the policy network's workgroup only)
 for rep in range(3):
