@@ -528,6 +528,45 @@ def test_rollout_step_bf16_pinned_to_the_operand_rounded_restatement(M):
     torch.testing.assert_close(lp.cpu(), want_lp, rtol=1e-4, atol=1e-4)  # (a - mean) / std is eps itself, whatever the mean's rounding
 
 
+@pytest.mark.parametrize("M,shift", [(37, 3), (1024, 1), (45, 0), (16, 5)])
+def test_states_tile_as_float4_views_and_ragged_ends(M, shift):
+    """The bf16 launches fetch a tile's states as float4s (rows are contiguous; a global 16-byte load needs dword alignment only)
+    and the (at most three) floats behind the array's last whole float4 with a dword load: a view that starts `shift` rows into
+    an allocation (8-byte aligned at best) and row counts whose float total is no multiple of four must give the bits an aligned,
+    padded copy gives -- rollout outputs, the f32 states copy in the trajectory row, and the fused step's gradients."""
+    from rlinf_amd import ops
+    from rlinf_amd._lib import PPO_OUT_FLOATS
+    _, pol = _bf16_policy(seed=3)
+    lay = pol.layout
+    g = torch.Generator().manual_seed(M)
+    base = torch.randn(M + shift + 2, 42, generator=g).cuda()
+    view = base[shift:shift + M]
+    aligned = view.clone()
+    assert view.data_ptr() % 16 == (shift * 42 * 4) % 16
+    eps = torch.randn(M, 8, generator=g).cuda()
+    outs = []
+    for st in (aligned, view):
+        copy = torch.full((M, 42), float("nan"), device="cuda")
+        a, lp, v = ops.mlp_rollout_step(pol.flat.data, pol.tiles(), lay, st, eps, states_copy=copy)
+        outs.append((a, lp, v, copy))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert torch.equal(outs[0][3], aligned)
+    mb = _minibatch(M, g, False)
+    lp_params = ops.make_ppo_params(logprob_type="action_level", action_dim=8, chunks=1, clip_ratio_low=0.2, clip_ratio_high=0.2,
+                                    value_clip=1.0, huber_delta=10.0, max_episode_steps=50, has_critic=True)
+    grads = []
+    for st in (aligned, view):
+        dev_mb = {k: v.cuda().contiguous() for k, v in mb.items()}
+        dev_mb["states"] = st
+        gbuf = torch.full((ops.ppo_step_slabs(lay, M, bf16=True), lay.n_params), float("nan"), device="cuda")
+        ws = torch.empty(ops.ppo_step_workspace_bytes(lay, M), dtype=torch.uint8, device="cuda")
+        row = torch.zeros(PPO_OUT_FLOATS, device="cuda")
+        ops.ppo_step(pol.flat.data, lay, lp_params, dev_mb, gbuf, row, ws, grad_out=1.0, bf16=True)
+        grads.append((gbuf.sum(0), row))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
 @pytest.mark.parametrize("M,prox_mode,with_mask,thr,bf16", [
     (8192, "versions", False, 1.03, False),   # the shipped async configs: interpolated proximal policy + behaviour threshold
     (700, "versions", True, 1.03, False),
