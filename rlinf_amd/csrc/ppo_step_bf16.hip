@@ -81,20 +81,24 @@ struct RowGemmB {
     typedef GeoB<RT, NW> G;
     static constexpr int CT = G::CT, KI = 32, MAXIT = HID / KI;
     bf16x8 bq[PD][CT];
-    const __bf16* wbase;
+    const char* wmat;   // the layer's image (uniform: a scalar register pair)
+    unsigned woff;      // this lane's byte offset into it
     int nit;
 
     // (Rotating the k-tile order per workgroup, to spread identical requests over the L2 channels, was measured: no gain,
     //  and it makes results depend on the block index -- dropped.)
+    // Addresses as uniform base + 32-bit lane offset: the global_load takes its base from scalar registers and a 4-byte offset per
+    // lane instead of a 64-bit address per lane.
     __device__ __forceinline__ void gload(int it, bf16x8 (&b)[CT]) {
-        const int itx = it;
+        const char* stage = wmat + (size_t)it * ((HID / 16) * 512 * sizeof(__bf16));  // (scalar arithmetic: the stage's base)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) b[ct] = *reinterpret_cast<const bf16x8*>(wbase + (size_t)(itx * (HID / 16) + ct) * 512);
+        for (int ct = 0; ct < CT; ++ct) b[ct] = *reinterpret_cast<const bf16x8*>(stage + ct * 512 * sizeof(__bf16) + woff);
     }
     __device__ __forceinline__ void prefetch(const __bf16* __restrict__ P, int nit_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         nit = nit_;
-        wbase = P + (size_t)(wave * CT) * 512 + lane * 8;
+        wmat = reinterpret_cast<const char*>(P);
+        woff = (unsigned)((wave * CT * 512 + lane * 8) * (int)sizeof(__bf16));
 #pragma unroll
         for (int d = 0; d < PD; ++d)
             if (d < nit) gload(d, bq[d]);
@@ -105,7 +109,8 @@ struct RowGemmB {
     __device__ __forceinline__ void prefetch_part(const __bf16* __restrict__ P, int nit_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         nit = nit_;
-        wbase = P + (size_t)(wave * CT) * 512 + lane * 8;
+        wmat = reinterpret_cast<const char*>(P);
+        woff = (unsigned)((wave * CT * 512 + lane * 8) * (int)sizeof(__bf16));
 #pragma unroll
         for (int d = D0; d < D1; ++d)
             if (d < nit) gload(d, bq[d]);
